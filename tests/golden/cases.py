@@ -1,0 +1,191 @@
+"""Golden-vector case table shared by the generator (gen_golden.py, runs only in the
+build container where /root/reference exists) and by the tests (which never touch the
+reference).
+
+Every tensor that goes INTO a case -- parameters, inputs, sampling noise, the cotangent
+`g` -- is drawn from numpy's PCG64 with a seed derived from the case name, so the
+fixtures only have to store what comes OUT of the reference (y, dx, parameter grads) plus
+the parameter key/shape table.  numpy's bit generators are stable across platforms, so
+the GPU box regenerates exactly the same inputs.
+"""
+import zlib
+import numpy as np
+
+# name -> dict(attn=..., args=..., x_shape=..., mask=..., modes=(...))
+# `mask`: None, or ("tail", [n_pad per batch row]) -> key_padding_mask with trailing pads.
+CASES = {
+    # ---------------- EVA (efficient_attention/eva.py:69-243) -------------------------
+    "eva_2d_rpe_tiny": dict(
+        attn="eva", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_rpe=True,
+                  num_landmarks=49, adaptive_proj="default")),
+    "eva_2d_cfg1": dict(  # BASELINE.json configs[0]: [B,H,N,d]=[2,8,196,64], 49 landmarks
+        attn="eva", x_shape=(2, 14, 14, 512), mask=None,
+        args=dict(dim=512, num_heads=8, window_size=7, attn_2d=True, use_rpe=True,
+                  num_landmarks=49, adaptive_proj="default")),
+    "eva_2d_784": dict(  # DeiT-tiny-p8 geometry
+        attn="eva", x_shape=(1, 28, 28, 192), mask=None,
+        args=dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True,
+                  num_landmarks=49, adaptive_proj="default")),
+    "eva_2d_overlap_rpe": dict(
+        attn="eva", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_rpe=True,
+                  overlap_window=True, num_landmarks=49, adaptive_proj="default")),
+    "eva_2d_pvt_w8": dict(  # PvT-style: window 8, 36 landmarks (SURVEY 7 caveat), d=32
+        attn="eva", x_shape=(1, 24, 24, 64), mask=None,
+        args=dict(dim=64, num_heads=2, window_size=8, attn_2d=True, use_rpe=False,
+                  num_landmarks=36, adaptive_proj="default")),
+    "eva_2d_t5": dict(
+        attn="eva", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_t5_rpe=True,
+                  num_landmarks=49, adaptive_proj="no-ln")),
+    "eva_1d_mask_overlap_t5": dict(  # N=50 not a multiple of w=8 -> padded to 56, 7 chunks of 8
+        attn="eva", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_t5_rpe=True,
+                  overlap_window=True, num_landmarks=7, adaptive_proj="default")),
+    "eva_1d_nomask_none": dict(
+        attn="eva", x_shape=(2, 64, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=16, attn_2d=False, use_rpe=True,
+                  num_landmarks=8, adaptive_proj="none")),
+    # ---------------- LARA (efficient_attention/lara.py:14-267) -----------------------
+    "lara_2d_poolmixed_tiny": dict(
+        attn="lara", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=49, proposal_gen="pool-mixed",
+                  mis_type="mis-opt", alpha_coeff=2.0)),
+    "lara_2d_poolmixed_784": dict(  # BASELINE.json configs[2] geometry (headline metric)
+        attn="lara", x_shape=(1, 28, 28, 192), mask=None,
+        args=dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                  mis_type="mis-opt", alpha_coeff=2.0)),
+    "lara_2d_pool_biased": dict(
+        attn="lara", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=49, proposal_gen="pool",
+                  mis_type="mis-biased")),
+    "lara_2d_vmixed_bh": dict(
+        attn="lara", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=16, proposal_gen="pool-vmixed",
+                  mis_type="mis-bh")),
+    "lara_2d_dense_antithetic": dict(
+        attn="lara", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=16, proposal_gen="pool-mixed",
+                  pool_module_type="dense", use_antithetics=True, mis_type="mis-opt")),
+    "lara_2d_noparam_multisample": dict(
+        attn="lara", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=16, proposal_gen="no-param-pool",
+                  use_multisample=True, mis_type="mis-opt")),
+    "lara_1d_uneven_mask": dict(  # 50 tokens / 7 landmarks -> uneven-split branch, pad mask
+        attn="lara", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2, num_landmarks=7, proposal_gen="adaptive-1d",
+                  mis_type="mis-opt")),
+    "lara_1d_even": dict(
+        attn="lara", x_shape=(2, 64, 128), mask=None,
+        args=dict(dim=128, num_heads=2, num_landmarks=16, proposal_gen="adaptive-1d",
+                  mis_type="mis-opt", alpha_coeff=1.0)),
+    # ---------------- softmax baseline (abstract_attention.py:41-140) ------------------
+    "softmax_1d_mask": dict(
+        attn="softmax", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2)),
+    "softmax_2d": dict(
+        attn="softmax", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2)),
+    # ---------------- local baseline (local_attention.py:25-194) -----------------------
+    "local_2d_rpe": dict(
+        attn="local", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_rpe=True)),
+    "local_1d_overlap_mask": dict(
+        attn="local", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True,
+                  overlap_window=True)),
+    # ---------------- Performer baseline (kernelized_attention.py:223-359) -------------
+    "performer_1d_mask": dict(
+        attn="performer", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    "performer_2d": dict(
+        attn="performer", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+}
+
+MODES = ("eval", "train")
+
+
+def _seed(name, salt):
+    return zlib.crc32(("%s/%s" % (name, salt)).encode()) & 0x7FFFFFFF
+
+
+def rng_for(name, salt):
+    return np.random.Generator(np.random.PCG64(_seed(name, salt)))
+
+
+def make_params(name, key_shapes):
+    """Parameters/buffers for a case from the (key -> shape) table stored in its fixture.
+
+    Values are chosen so that every term matters in a parity check: Linear weights are
+    O(1/sqrt(fan_in)), biases are non-zero, LayerNorm affine is not the identity and the
+    relative-position tables are O(0.5).  `relative_position_index` is NOT generated here:
+    it is an integer buffer the module builds itself (and the fixture stores the
+    reference's copy so the two can be compared)."""
+    rng = rng_for(name, "params")
+    out = {}
+    for key in sorted(key_shapes):
+        shape = tuple(key_shapes[key])
+        if key == "relative_position_index":
+            continue
+        base = rng.standard_normal(shape).astype(np.float32)
+        leaf = key.split(".")[-1]
+        if key.endswith("relative_attention_bias.weight") or "bias_table" in key:
+            val = 0.5 * base
+        elif key in ("eval_proj", "random_proj"):
+            val = base
+        elif leaf == "weight" and len(shape) == 2:
+            val = base / np.sqrt(shape[1])
+        elif leaf == "weight" and len(shape) == 1:      # LayerNorm gain
+            val = 1.0 + 0.2 * base
+        elif leaf == "bias":
+            val = 0.1 * base
+        else:
+            val = 0.1 * base
+        out[key] = val.astype(np.float32)
+    return out
+
+
+def make_inputs(name):
+    case = CASES[name]
+    x = rng_for(name, "x").standard_normal(case["x_shape"]).astype(np.float32)
+    g = rng_for(name, "g").standard_normal(case["x_shape"]).astype(np.float32)
+    mask = None
+    if case["mask"] is not None:
+        kind, pads = case["mask"]
+        assert kind == "tail"
+        B, N = case["x_shape"][0], case["x_shape"][1]
+        mask = np.zeros((B, N), dtype=bool)
+        for b, p in enumerate(pads):
+            if p:
+                mask[b, N - p:] = True
+    return x, g, mask
+
+
+def make_noise(name, shape, call_idx=0):
+    """Standard-normal sampling noise for training mode: the i-th randn/randn_like call
+    inside one forward gets stream (name, 'noise<i>')."""
+    return rng_for(name, "noise%d" % call_idx).standard_normal(tuple(shape)).astype(np.float32)
+
+
+GRAD_FULL_MAX = 16384     # parameter grads larger than this are stored as a subsample
+GRAD_SAMPLES = 4096
+
+
+def grad_sample_index(name, key, numel):
+    """Flat indices at which a large parameter gradient is stored in the fixture."""
+    return rng_for(name, "gradidx/" + key).integers(0, numel, size=GRAD_SAMPLES)
+
+
+def pack_grad(name, key, arr):
+    """-> dict of arrays to store for one parameter gradient (full, or subsample+moments)."""
+    arr = np.asarray(arr, np.float32)
+    if arr.size <= GRAD_FULL_MAX:
+        return {"": arr}
+    idx = grad_sample_index(name, key, arr.size)
+    flat = arr.reshape(-1)
+    return {".sample": flat[idx],
+            ".moments": np.array([flat.sum(dtype=np.float64),
+                                  np.abs(flat).sum(dtype=np.float64),
+                                  (flat.astype(np.float64) ** 2).sum()], np.float64)}

@@ -1,0 +1,100 @@
+"""Shared helpers for the parity tests: fixture loading and tolerant comparisons."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import cases  # tests/golden/cases.py
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Fixture:
+    def __init__(self, name):
+        self.name = name
+        self.case = cases.CASES[name]
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.key_shapes = json.loads(str(self.z["key_shapes"]))
+        self.params_np = cases.make_params(name, self.key_shapes)
+        self.x_np, self.g_np, self.mask_np = cases.make_inputs(name)
+
+    def params(self, dtype=torch.float32, device="cpu", requires_grad=False):
+        out = {}
+        for k, v in self.params_np.items():
+            t = torch.from_numpy(v).to(device=device, dtype=dtype)
+            out[k] = t.requires_grad_(requires_grad)
+        return out
+
+    def noise_fn(self, mode, dtype=torch.float32, device="cpu"):
+        """i-th call -> the same stream the generator fed to the reference."""
+        calls = []
+
+        def fn(shape):
+            arr = cases.make_noise(self.name, tuple(shape), len(calls))
+            calls.append(tuple(shape))
+            return torch.from_numpy(arr).to(device=device, dtype=dtype)
+
+        fn.calls = calls
+        return fn
+
+    def expected_noise_shapes(self, mode):
+        return [tuple(s) for s in json.loads(str(self.z["%s.noise_shapes" % mode]))]
+
+    def y(self, mode):
+        return self.z["%s.y" % mode]
+
+    def dx(self, mode):
+        return self.z["%s.dx" % mode]
+
+    def grad_keys(self, mode):
+        pre = "%s.grad." % mode
+        keys = set()
+        for k in self.z.files:
+            if k.startswith(pre):
+                k = k[len(pre):]
+                for suf in (".sample", ".moments"):
+                    if k.endswith(suf):
+                        k = k[:-len(suf)]
+                keys.add(k)
+        return sorted(keys)
+
+    def check_grad(self, mode, key, got, rtol, atol):
+        """Compare a parameter gradient with the stored full array or subsample+moments."""
+        got = np.asarray(got, np.float64)
+        pre = "%s.grad.%s" % (mode, key)
+        if pre in self.z.files:
+            ref = self.z[pre].astype(np.float64)
+            assert got.shape == ref.shape, (key, got.shape, ref.shape)
+            assert_close(got, ref, rtol, atol, "%s/%s grad %s" % (self.name, mode, key))
+            return
+        idx = cases.grad_sample_index(self.name, key, got.size)
+        ref = self.z[pre + ".sample"].astype(np.float64)
+        assert_close(got.reshape(-1)[idx], ref, rtol, atol, "%s/%s grad %s[sample]" % (self.name, mode, key))
+        mom = self.z[pre + ".moments"]
+        flat = got.reshape(-1)
+        # moments are sums over up to ~1e6 entries: compare relative to the abs-sum
+        assert abs(flat.sum() - mom[0]) <= rtol * 50 * mom[1] + atol, (key, flat.sum(), mom)
+        assert abs(np.abs(flat).sum() - mom[1]) <= rtol * 50 * mom[1] + atol, (key,)
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    bad = err > tol
+    if bad.any():
+        i = np.argmax(err - tol)
+        raise AssertionError("%s: %d/%d out of tolerance; worst |err|=%.3e at flat %d (got %.6e ref %.6e), "
+                             "max|ref|=%.3e" % (what, bad.sum(), bad.size, err.reshape(-1)[i], i,
+                                                got.reshape(-1)[i], ref.reshape(-1)[i], np.abs(ref).max()))
+
+
+def scaled_err(got, ref):
+    """max |got-ref| / max|ref| and rms(got-ref)/rms(ref): the two figures the bf16 tolerances
+    are stated in."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    d = got - ref
+    return np.abs(d).max() / max(np.abs(ref).max(), 1e-30), np.sqrt((d * d).mean()) / max(np.sqrt((ref * ref).mean()), 1e-30)
