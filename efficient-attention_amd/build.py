@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Build libea_hip.so (and the hardware probe) for gfx950 with hipcc, in-tree.
+
+    python efficient-attention_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU; the resulting lib/libea_hip.so travels with the repo
+snapshot to the GPU box (it is git-ignored but not gpurun-ignored)."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+
+LIB_SOURCES = ["ea_capi.hip", "ea_window_fwd.hip", "ea_window_bwd.hip", "ea_eva_landmark.hip"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    objs = []
+    for src in LIB_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _newer(o, [s] + headers):
+            if verbose:
+                print("hipcc -c", src, flush=True)
+            _run([HIPCC] + FLAGS + ["-c", s, "-o", o])
+        objs.append(o)
+    lib = os.path.join(LIBDIR, "libea_hip.so")
+    if force or _newer(lib, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    probe_src = os.path.join(CSRC, "probe_primitives.hip")
+    probe = os.path.join(LIBDIR, "probe_primitives")
+    if force or _newer(probe, [probe_src]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", probe_src, "-o", probe])
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,152 @@
+// ea_capi.hip -- extern "C" entry points of libea_hip.so (declared in include/ea_hip.h).
+// Argument validation and launch-parameter construction only; every kernel lives in its own
+// translation unit and is reached through a *_dispatch function.
+#include "ea_window.h"
+
+namespace ea {
+int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st);
+int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStream_t st);
+}  // namespace ea
+#include "ea_landmark_params.h"
+
+using namespace ea;
+
+static bool t4_ok(const ea_t4* t, int D) {
+  // 16-byte vector access: base and every stride must be a multiple of 8 elements
+  return t && t->ptr && ((uintptr_t)t->ptr % 16 == 0) && t->sb % 8 == 0 && t->sh % 8 == 0 &&
+         t->sn % 8 == 0 && t->sn >= D;
+}
+static bool geom_ok(const ea_geom* g) {
+  return g && g->B > 0 && g->H > 0 && g->N > 0 && (g->D == 32 || g->D == 64 || g->D == 128) &&
+         (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0;
+}
+static Geo mk_geo(const ea_geom* g) {
+  Geo G;
+  G.N = g->N; G.attn2d = g->attn_2d; G.gh = g->attn_2d ? g->gh : 1; G.gw = g->attn_2d ? g->gw : g->N;
+  return G;
+}
+
+extern "C" {
+
+const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
+int32_t ea_abi_version(void) { return 1; }
+
+int32_t ea_window_bias_ld(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, false) != EA_OK) return EA_E_BADARG;
+  return t.biasLd;
+}
+int32_t ea_window_bwd_parts(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
+  return t.nblk;
+}
+
+static int fill_win(const ea_geom* g, WinP& p) {
+  if (!geom_ok(g)) return EA_E_BADARG;
+  int rc = win_tiling(*g, p.t, false);
+  if (rc != EA_OK) return rc;
+  if (g->L < 0 || g->L > 64) return EA_E_UNSUPPORTED;      // landmark tiles owned 1:1 by 4 waves
+  p.G = mk_geo(g);
+  p.B = g->B; p.H = g->H; p.L = g->L; p.w = g->window; p.e = g->ext;
+  p.scale = g->scale;
+  p.scale_log2 = g->scale * LOG2E;
+  return EA_OK;
+}
+
+int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                       const float* lk, const float* lv, const float* bias, const uint8_t* mask,
+                       const ea_t4* out, float* lse, void* stream) {
+  WinP p = {};
+  int rc = fill_win(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(out, g->D) || !lse) return EA_E_BADARG;
+  if (g->L > 0 && (!lk || !lv)) return EA_E_BADARG;
+  p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(out);
+  p.lk = lk; p.lv = lv; p.bias = bias; p.mask = mask; p.lse = lse;
+  return window_fwd_dispatch(p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                       const float* lk, const float* lv, const float* bias, const uint8_t* mask,
+                       const ea_t4* out, const ea_t4* dout, const float* lse,
+                       const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
+                       float* dlk_part, float* dlv_part, float* dbias_part,
+                       float* dk_acc, float* dv_acc, void* stream) {
+  WinP p = {};
+  int rc = fill_win(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dout, g->D) ||
+      !t4_ok(out, g->D) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !lse) return EA_E_BADARG;
+  if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
+  if (bias && !dbias_part) return EA_E_BADARG;
+  p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(dout);
+  p.dq = mk(dq); p.dk = mk(dk); p.dv = mk(dv);
+  p.lk = lk; p.lv = lv; p.bias = bias; p.mask = mask; p.lse = const_cast<float*>(lse);
+  p.dlk_part = dlk_part; p.dlv_part = dlv_part; p.dbias_part = dbias_part;
+  p.dk32 = dk_acc; p.dv32 = dv_acc;
+  return window_bwd_dispatch(p, mk(out), g->dtype, g->D, (hipStream_t)stream);
+}
+
+// ---- EVA landmark statistics ----
+static int fill_lm(const ea_geom* g, LmP& p) {
+  if (!geom_ok(g) || g->chunk <= 0 || g->L <= 0) return EA_E_BADARG;
+  p.G = mk_geo(g);
+  if (g->attn_2d && (g->gh * g->gw != g->N)) return EA_E_BADARG;
+  const int side = g->chunk + 2 * g->ext;
+  const int nchunks = g->attn_2d ? (g->gh / g->chunk) * (g->gw / g->chunk) : g->N / g->chunk;
+  if (nchunks != g->L) return EA_E_BADARG;
+  p.B = g->B; p.H = g->H; p.L = g->L; p.r = g->chunk; p.e = g->ext;
+  p.J = g->attn_2d ? side * side : side;
+  p.scale = g->scale;
+  return EA_OK;
+}
+#define SET3(dst, src) do { p.dst = (char*)(src)->ptr; p.dst##_sb = (src)->sb; p.dst##_sh = (src)->sh; p.dst##_sn = (src)->sn; } while (0)
+
+int ea_eva_chunk_mean_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const uint8_t* mask,
+                          float* qmean, float* kmean, void* stream) {
+  LmP p = {};
+  int rc = fill_lm(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !qmean || !kmean) return EA_E_BADARG;
+  SET3(q, q); SET3(k, k);
+  p.mask = mask; p.qmean = qmean; p.kmean = kmean;
+  return landmark_dispatch(0, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_eva_chunk_mean_bwd(const ea_geom* g, const float* dqmean, const float* dkmean,
+                          const uint8_t* mask, const ea_t4* dq, const ea_t4* dk, void* stream) {
+  LmP p = {};
+  int rc = fill_lm(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !dqmean || !dkmean) return EA_E_BADARG;
+  SET3(dq, dq); SET3(dk, dk);
+  p.mask = mask; p.dqmean = dqmean; p.dkmean = dkmean;
+  return landmark_dispatch(1, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_eva_beta_fwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* omega, float* beta, void* stream) {
+  LmP p = {};
+  int rc = fill_lm(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !omega || !beta) return EA_E_BADARG;
+  SET3(k, k); SET3(v, v);
+  p.mask = mask; p.omega = omega; p.beta_out = beta;
+  return landmark_dispatch(2, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* omega, const float* beta, const float* dbeta,
+                    const ea_t4* dk, const ea_t4* dv, float* domega, void* stream) {
+  LmP p = {};
+  int rc = fill_lm(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !omega ||
+      !beta || !dbeta || !domega) return EA_E_BADARG;
+  SET3(k, k); SET3(v, v); SET3(dk, dk); SET3(dv, dv);
+  p.mask = mask; p.omega = omega; p.beta = beta; p.dbeta = dbeta; p.domega = domega;
+  return landmark_dispatch(3, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// ea_common.h -- device-side building blocks shared by every kernel of libea_hip.so.
+//
+// Everything here is written for gfx950 only: 64-lane wavefronts, v_mfma_f32_16x16x32_{bf16,f16},
+// ds_read_b64_tr_b16.  Lane layouts are verified on hardware by probe_primitives.hip.
+//
+// MFMA conventions used throughout (g = lane >> 4, li = lane & 15):
+//   A operand: lane holds A[row = li][k-slot 8g .. 8g+7]     (8 elements, 16 bytes)
+//   B operand: lane holds B[k-slot 8g .. 8g+7][col = li]
+//   D result : lane holds D[row = 4g + r][col = li], r = 0..3
+// The contraction index is free to be permuted as long as A and B agree, which is what lets
+// score tiles computed as S^T[key][query] (row = key, col = query) be re-used, register for
+// register, as the B operand of the P.V product: a lane's four D values of two adjacent 16-key
+// tiles are exactly its eight k-slots of the next MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ea_hip.h"
+
+namespace ea {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define EA_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define EA_DEV __device__ __forceinline__
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float MASK_FILL = -5e4f;       // finite mask value of local/EVA (eva.py:139)
+
+// ------------------------------------------------------------------------------------------
+// element traits
+// ------------------------------------------------------------------------------------------
+struct BF16 {
+  typedef __bf16 T;
+  typedef __attribute__((ext_vector_type(8))) __bf16 x8;
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 x4v;
+  static EA_DEV f32x4 mma(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static EA_DEV u32x2 tr4(const char* lds) {     // ds_read_b64_tr_b16
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(EA_LDS(x4v, lds)));
+  }
+  static EA_DEV float to_f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+  static EA_DEV uint16_t from_f(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+};
+
+struct F16 {
+  typedef _Float16 T;
+  typedef __attribute__((ext_vector_type(8))) _Float16 x8;
+  typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 x4v;
+  static EA_DEV f32x4 mma(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static EA_DEV u32x2 tr4(const char* lds) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16(EA_LDS(x4v, lds)));
+  }
+  static EA_DEV float to_f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static EA_DEV uint16_t from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+};
+
+template <typename E> EA_DEV uint32_t pack2(float lo, float hi) {
+  return (uint32_t)E::from_f(lo) | ((uint32_t)E::from_f(hi) << 16);
+}
+template <typename E> EA_DEV void unpack2(uint32_t w, float& lo, float& hi) {
+  lo = E::to_f((uint16_t)(w & 0xffffu));
+  hi = E::to_f((uint16_t)(w >> 16));
+}
+// eight consecutive elements (16 B) <-> eight floats
+template <typename E> EA_DEV void unpack8(u32x4 w, float* f) {
+  unpack2<E>(w[0], f[0], f[1]); unpack2<E>(w[1], f[2], f[3]);
+  unpack2<E>(w[2], f[4], f[5]); unpack2<E>(w[3], f[6], f[7]);
+}
+template <typename E> EA_DEV u32x4 pack8(const float* f) {
+  u32x4 w;
+  w[0] = pack2<E>(f[0], f[1]); w[1] = pack2<E>(f[2], f[3]);
+  w[2] = pack2<E>(f[4], f[5]); w[3] = pack2<E>(f[6], f[7]);
+  return w;
+}
+template <typename E> EA_DEV typename E::x8 as_x8(u32x4 w) { return __builtin_bit_cast(typename E::x8, w); }
+template <typename E> EA_DEV typename E::x8 as_x8(u32x2 lo, u32x2 hi) {
+  u32x4 w; w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+  return __builtin_bit_cast(typename E::x8, w);
+}
+
+EA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+EA_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// reduce over the four lanes {li, li+16, li+32, li+48} that share a query/key column
+EA_DEV float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+EA_DEV float quad_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+EA_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+EA_DEV u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+EA_DEV void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+EA_DEV u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+EA_DEV void sts16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------
+// token geometry: (window | chunk, slot) -> token index, -1 outside the sequence / grid
+// (attn_utils.py:155-166 / 190-210 as address arithmetic instead of pad + as_strided copies)
+// ------------------------------------------------------------------------------------------
+struct Geo {
+  int N, attn2d, gh, gw;
+};
+EA_DEV int part_token(const Geo& G, int part, int slot, int side, int ext) {
+  if (G.attn2d) {
+    const int t = side + 2 * ext;
+    const int per_row = G.gw / side;
+    const int p1 = part / per_row, p2 = part - p1 * per_row;
+    const int i = slot / t, j = slot - i * t;
+    const int y = p1 * side - ext + i, x = p2 * side - ext + j;
+    return (y >= 0 && y < G.gh && x >= 0 && x < G.gw) ? y * G.gw + x : -1;
+  }
+  const int tok = part * side - ext + slot;
+  return (tok >= 0 && tok < G.N) ? tok : -1;
+}
+
+// LDS row-major tile [rows][D] with the 16-byte chunk index XOR-swizzled by the row, so that
+// both the b128 operand reads (16 lanes = 16 rows, same chunk) and the b64 transpose reads are
+// spread over the banks (cdna_hip_programming.md T2).
+template <int D> EA_DEV int lds_off(int row, int chunk16) {
+  constexpr int CPR = D / 8;                       // 16-byte chunks per row
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  return row * (D * 2) + ((chunk16 ^ (row & SW)) << 4);
+}
+
+}  // namespace ea

@@ -1,0 +1,336 @@
+// ea_eva_landmark.hip -- EVA landmark statistics (eva.py:155-196) as streaming kernels.
+//
+//   chunk_mean : masked means of q and k over every landmark chunk      (eva.py:160-180)
+//   beta       : beta_c = softmax_j(s w_c.k_j - s|k_j|^2/2) . v_j        (eva.py:192-196)
+// and their backward passes.  These are HBM/L2-bound O(N*D) passes with no matmul shape, so
+// they are plain VALU kernels: one wave per chunk, a row of D channels is spread over D/8
+// lanes (16-byte loads), 64/(D/8) rows are in flight per wave step.
+//
+// The chunk partition (rearrange / pad + as_strided copies in the reference) is address
+// arithmetic (part_token); slots outside the sequence and padded tokens count as zeros in the
+// means and get the finite -5e4 logit, exactly like the reference's masked_fill sequence.
+#include "ea_landmark_params.h"
+
+namespace ea {
+
+
+// reduce across the lanes that hold the same channel chunk (stride CPR in lane id)
+template <int CPR> EA_DEV float rows_sum(float v) {
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// reduce across the CPR lanes of one row
+template <int CPR> EA_DEV float chan_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < CPR; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename E, int D>
+__global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
+  constexpr int CPR = D / 8, RPW = 64 / CPR;
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
+  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk_id >= (long)p.B * p.H * p.L) return;
+  const int cidx = (int)(chunk_id % p.L);
+  const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
+  const char* qb = p.q + (b * p.q_sb + h * p.q_sh) * 2;
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  float aq[8], ak[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) aq[i] = ak[i] = 0.f;
+  for (int j = rg; j < p.J; j += RPW) {
+    const int tok = part_token(p.G, cidx, j, p.r, p.e);
+    if (tok >= 0 && !(mrow && mrow[tok])) {
+      float f[8];
+      unpack8<E>(ldg16(qb + (tok * p.q_sn + c * 8) * 2), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) aq[i] += f[i];
+      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ak[i] += f[i];
+    }
+  }
+  const float inv = 1.f / (float)p.J;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    aq[i] = rows_sum<CPR>(aq[i]) * inv;
+    ak[i] = rows_sum<CPR>(ak[i]) * inv;
+  }
+  if (rg == 0) {
+    float* dq_ = p.qmean + (size_t)chunk_id * D + c * 8;
+    float* dk_ = p.kmean + (size_t)chunk_id * D + c * 8;
+    *reinterpret_cast<float4*>(dq_) = make_float4(aq[0], aq[1], aq[2], aq[3]);
+    *reinterpret_cast<float4*>(dq_ + 4) = make_float4(aq[4], aq[5], aq[6], aq[7]);
+    *reinterpret_cast<float4*>(dk_) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+    *reinterpret_cast<float4*>(dk_ + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
+  }
+}
+
+// dq[tok] += dqmean[c]/J, dk[tok] += dkmean[c]/J for every unmasked in-range slot of chunk c.
+// With e == 0 every token belongs to exactly one chunk, so the read-modify-write is race free;
+// e > 0 (overlapping chunks) is serialised by launching one chunk "colour" at a time (host).
+template <typename E, int D>
+__global__ __launch_bounds__(256) void chunk_mean_bwd_kernel(const LmP p, int colour, int nc) {
+  constexpr int CPR = D / 8, RPW = 64 / CPR;
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
+  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk_id >= (long)p.B * p.H * p.L) return;
+  const int cidx = (int)(chunk_id % p.L);
+  if (nc > 1) {
+    int col;
+    if (p.G.attn2d) { const int per_row = p.G.gw / p.r; col = ((cidx / per_row) % nc) * nc + ((cidx % per_row) % nc); }
+    else col = cidx % nc;
+    if (col != colour) return;
+  }
+  const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
+  char* dqb = p.dq + (b * p.dq_sb + h * p.dq_sh) * 2;
+  char* dkb = p.dk + (b * p.dk_sb + h * p.dk_sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  const float inv = 1.f / (float)p.J;
+  float gq[8], gk[8];
+  {
+    const float* s1 = p.dqmean + (size_t)chunk_id * D + c * 8;
+    const float* s2 = p.dkmean + (size_t)chunk_id * D + c * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gq[i] = s1[i] * inv; gk[i] = s2[i] * inv; }
+  }
+  for (int j = rg; j < p.J; j += RPW) {
+    const int tok = part_token(p.G, cidx, j, p.r, p.e);
+    if (tok >= 0 && !(mrow && mrow[tok])) {
+      float f[8];
+      char* a = dqb + (tok * p.dq_sn + c * 8) * 2;
+      unpack8<E>(ldg16(a), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += gq[i];
+      stg16(a, pack8<E>(f));
+      a = dkb + (tok * p.dk_sn + c * 8) * 2;
+      unpack8<E>(ldg16(a), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += gk[i];
+      stg16(a, pack8<E>(f));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// beta forward: online softmax over the chunk's rows per row-group, merged across row-groups.
+template <typename E, int D>
+__global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
+  constexpr int CPR = D / 8, RPW = 64 / CPR;
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
+  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk_id >= (long)p.B * p.H * p.L) return;
+  const int cidx = (int)(chunk_id % p.L);
+  const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  const char* vb = p.v + (b * p.v_sb + h * p.v_sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  float om[8];
+  {
+    const float* s = p.omega + (size_t)chunk_id * D + c * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) om[i] = s[i];
+  }
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const int jmax = (p.J + RPW - 1) / RPW * RPW;
+  for (int j = rg; j < jmax; j += RPW) {
+    const bool exists = j < p.J;
+    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+    const bool live = tok >= 0 && !(mrow && mrow[tok]);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = vf[i] = 0.f;
+    if (live) {
+      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
+      unpack8<E>(ldg16(vb + (tok * p.v_sn + c * 8) * 2), vf);
+    }
+    float dot = 0.f, nrm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
+    dot = chan_sum<CPR>(dot);
+    nrm = chan_sum<CPR>(nrm);
+    float x = p.scale * (dot - 0.5f * nrm);
+    x = live ? x : (exists ? MASK_FILL : -INFINITY);
+    const float mn = fmaxf(m, x);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    const float a = __expf(m - ms), pj = __expf(x - ms);
+    l = l * a + pj;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pj * vf[i];
+    m = mn;
+  }
+  // merge the RPW row-groups (lanes with equal c)
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
+    const float mn = fmaxf(m, m2);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    const float a1 = __expf(m - ms), a2 = __expf(m2 - ms);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a1 + __shfl_xor(acc[i], o) * a2;
+    m = mn;
+  }
+  if (rg == 0) {
+    const float inv = 1.f / l;
+    float* dst = p.beta_out + (size_t)chunk_id * D + c * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv);
+  }
+}
+
+// beta backward.  With p_j = softmax_j(x_j):  dv_j += p_j dbeta;  dx_j = p_j (v_j.dbeta - beta.dbeta);
+// dk_j += dx_j s (w - k_j);  dw += sum_j dx_j s k_j   (masked / outside slots carry no gradient).
+template <typename E, int D>
+__global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, int nc) {
+  constexpr int CPR = D / 8, RPW = 64 / CPR;
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
+  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk_id >= (long)p.B * p.H * p.L) return;
+  const int cidx = (int)(chunk_id % p.L);
+  if (nc > 1) {
+    int col;
+    if (p.G.attn2d) { const int per_row = p.G.gw / p.r; col = ((cidx / per_row) % nc) * nc + ((cidx % per_row) % nc); }
+    else col = cidx % nc;
+    if (col != colour) return;
+  }
+  const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  const char* vb = p.v + (b * p.v_sb + h * p.v_sh) * 2;
+  char* dkb = p.dk + (b * p.dk_sb + h * p.dk_sh) * 2;
+  char* dvb = p.dv + (b * p.dv_sb + h * p.dv_sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  float om[8], db[8], bt[8];
+  {
+    const size_t off = (size_t)chunk_id * D + c * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { om[i] = p.omega[off + i]; db[i] = p.dbeta[off + i]; bt[i] = p.beta[off + i]; }
+  }
+  float bd = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bd += bt[i] * db[i];
+  bd = chan_sum<CPR>(bd);                                   // beta . dbeta
+  const int jmax = (p.J + RPW - 1) / RPW * RPW;
+  // pass 1: log-sum-exp of the chunk's logits
+  float m = -INFINITY, l = 0.f;
+  for (int j = rg; j < jmax; j += RPW) {
+    const bool exists = j < p.J;
+    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+    const bool live = tok >= 0 && !(mrow && mrow[tok]);
+    float kf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = 0.f;
+    if (live) unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
+    float dot = 0.f, nrm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
+    dot = chan_sum<CPR>(dot);
+    nrm = chan_sum<CPR>(nrm);
+    float x = p.scale * (dot - 0.5f * nrm);
+    x = live ? x : (exists ? MASK_FILL : -INFINITY);
+    const float mn = fmaxf(m, x);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    l = l * __expf(m - ms) + __expf(x - ms);
+    m = mn;
+  }
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
+    const float mn = fmaxf(m, m2);
+    const float ms = mn == -INFINITY ? 0.f : mn;
+    l = l * __expf(m - ms) + l2 * __expf(m2 - ms);
+    m = mn;
+  }
+  const float lse = m + __logf(l);
+  // pass 2: gradients
+  float dom[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dom[i] = 0.f;
+  for (int j = rg; j < jmax; j += RPW) {
+    const bool exists = j < p.J;
+    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+    const bool live = tok >= 0 && !(mrow && mrow[tok]);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = vf[i] = 0.f;
+    if (live) {
+      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
+      unpack8<E>(ldg16(vb + (tok * p.v_sn + c * 8) * 2), vf);
+    }
+    float dot = 0.f, nrm = 0.f, vd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; vd += vf[i] * db[i]; }
+    dot = chan_sum<CPR>(dot);
+    nrm = chan_sum<CPR>(nrm);
+    vd = chan_sum<CPR>(vd);
+    if (live) {
+      const float x = p.scale * (dot - 0.5f * nrm);
+      const float pj = __expf(x - lse);
+      const float dx = pj * (vd - bd) * p.scale;
+      float f[8];
+      char* a = dvb + (tok * p.dv_sn + c * 8) * 2;
+      unpack8<E>(ldg16(a), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += pj * db[i];
+      stg16(a, pack8<E>(f));
+      a = dkb + (tok * p.dk_sn + c * 8) * 2;
+      unpack8<E>(ldg16(a), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { f[i] += dx * (om[i] - kf[i]); dom[i] += dx * kf[i]; }
+      stg16(a, pack8<E>(f));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dom[i] = rows_sum<CPR>(dom[i]);
+  if (rg == 0) {
+    float* dst = p.domega + (size_t)chunk_id * D + c * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(dom[0], dom[1], dom[2], dom[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(dom[4], dom[5], dom[6], dom[7]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename E, int D>
+static int launch_lm(int which, const LmP& p, hipStream_t st) {
+  const long chunks = (long)p.B * p.H * p.L;
+  const dim3 grid((unsigned)((chunks + 3) / 4)), block(256);
+  // overlapping chunks (e > 0): chunks closer than nc = 1 + ceil(2e/r) per dimension share
+  // tokens, so nc (1-D) / nc*nc (2-D) colour classes are launched back to back and the
+  // read-modify-writes of one launch never touch the same token.
+  const int nc = p.e > 0 ? 1 + (2 * p.e + p.r - 1) / p.r : 1;
+  const int ncolour = p.G.attn2d ? nc * nc : nc;
+  switch (which) {
+    case 0: hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D>), grid, block, 0, st, p); break;
+    case 1:
+      for (int col = 0; col < ncolour; ++col)
+        hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D>), grid, block, 0, st, p, col, nc);
+      break;
+    case 2: hipLaunchKernelGGL((beta_fwd_kernel<E, D>), grid, block, 0, st, p); break;
+    case 3:
+      for (int col = 0; col < ncolour; ++col)
+        hipLaunchKernelGGL((beta_bwd_kernel<E, D>), grid, block, 0, st, p, col, nc);
+      break;
+  }
+  return (int)hipGetLastError();
+}
+
+int landmark_dispatch(int which, const LmP& p, int dtype, int D, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (D == 64) return launch_lm<BF16, 64>(which, p, st);
+    if (D == 32) return launch_lm<BF16, 32>(which, p, st);
+    if (D == 128) return launch_lm<BF16, 128>(which, p, st);
+  } else if (dtype == EA_F16) {
+    if (D == 64) return launch_lm<F16, 64>(which, p, st);
+    if (D == 32) return launch_lm<F16, 32>(which, p, st);
+    if (D == 128) return launch_lm<F16, 128>(which, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

@@ -1,0 +1,87 @@
+// ea_window.h -- host-side derived geometry + kernel parameter block of the window-attention
+// kernels (ea_window_fwd.hip / ea_window_bwd.hip).
+#pragma once
+#include "ea_common.h"
+
+namespace ea {
+
+// Tiling derived from ea_geom.  A "key tile" is 16 keys (one MFMA row block); the key list of a
+// window is [nLT local tiles | nCT landmark tiles | dummy tiles up to a multiple of 4]; keys are
+// consumed in chunks of 4 tiles (64 keys = two k-steps of the P.V MFMA) with an online softmax.
+struct WinTiling {
+  int Wq, Wk;          // queries / local keys per window
+  int nQT, nLT, nCT;   // 16-row tiles: queries, local keys, landmarks
+  int nchunks;         // ceil((nLT + nCT) / 4)
+  int nwin;            // windows per (b, h)
+  int wpi;             // windows staged per block iteration
+  int niter;           // ceil(nwin / wpi)
+  int nblk;            // blocks per (b, h)
+  int ipb;             // iterations per block
+  int biasLd;          // nLT * 16
+  int rowsLocal, rowsLm, rowsTotal;
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
+  if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
+  const int w = g.window, e = g.ext;
+  if (g.attn_2d) {
+    if (g.gh <= 0 || g.gw <= 0 || g.gh * g.gw != g.N || g.gh % w || g.gw % w) return EA_E_BADARG;
+    t.Wq = w * w;
+    t.Wk = (w + 2 * e) * (w + 2 * e);
+    t.nwin = (g.gh / w) * (g.gw / w);
+  } else {
+    t.Wq = w;
+    t.Wk = w + 2 * e;
+    t.nwin = ceil_div(g.N, w);
+  }
+  t.nQT = ceil_div(t.Wq, 16);
+  t.nLT = ceil_div(t.Wk, 16);
+  t.nCT = ceil_div(g.L, 16);
+  t.nchunks = ceil_div(t.nLT + t.nCT, 4);
+  t.biasLd = t.nLT * 16;
+  t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
+  if (t.wpi > t.nwin) t.wpi = t.nwin;
+  t.niter = ceil_div(t.nwin, t.wpi);
+  // enough blocks to fill 256 CUs several times over, while each block keeps the landmark rows
+  // (and, in backward, its landmark-gradient accumulators) resident across its iterations
+  const long bh = (long)g.B * g.H;
+  int nblk = (int)((2048 + bh - 1) / bh);
+  if (nblk < 1) nblk = 1;
+  if (nblk > t.niter) nblk = t.niter;
+  t.ipb = ceil_div(t.niter, nblk);
+  t.nblk = ceil_div(t.niter, t.ipb);
+  t.rowsLocal = t.wpi * t.nLT * 16;
+  t.rowsLm = t.nCT * 16;
+  t.rowsTotal = t.rowsLocal + t.rowsLm + 16;
+  (void)backward;
+  return EA_OK;
+}
+
+struct T4 {
+  char* p;
+  int64_t sb, sh, sn;
+};
+inline T4 mk(const ea_t4* t) {
+  T4 r;
+  r.p = t ? (char*)t->ptr : nullptr;
+  r.sb = t ? t->sb : 0; r.sh = t ? t->sh : 0; r.sn = t ? t->sn : 0;
+  return r;
+}
+
+struct WinP {
+  T4 q, k, v, o;            // o = out (fwd) / dout (bwd)
+  T4 dq, dk, dv;            // bwd only
+  const float *lk, *lv, *bias;
+  const uint8_t* mask;
+  float* lse;
+  float *dlk_part, *dlv_part, *dbias_part;   // bwd only
+  float *dk32, *dv32;                        // bwd, overlap (e > 0): fp32 atomics scratch [B,H,N,D]
+  Geo G;
+  int B, H, L, w, e;
+  float scale, scale_log2;
+  WinTiling t;
+};
+
+}  // namespace ea

@@ -1,0 +1,414 @@
+// ea_window_bwd.hip -- backward of window attention with control-variate (landmark) columns.
+//
+// Same workgroup <-> windows mapping and LDS images as the forward (ea_window_fwd.hip), plus the
+// Q and dO rows of the staged windows.  With P = exp(logits - lse) recomputed from the saved
+// log-sum-exp and delta_i = dO_i . O_i:
+//     dS = P o (dO V^T - delta)          dQ = s dS K        dK = s dS^T Q       dV = P^T dO
+//     d(rf_k_bar) = s dS_cv^T Q          d(beta) = P_cv^T dO                    dbias = dS_local
+// Phase A (a wave per 16-query tile): S^T and dP^T tiles [key][query] -> dS^T stays in registers
+//   as the B operand of dQ^T = K^T dS^T, with K^T fragments from ds_read_b64_tr_b16.
+// Phase B (a wave per 16-key tile): S and dP tiles [query][key] -> P, dS stay in registers as the
+//   B operands of dV^T = dO^T P and dK^T = Q^T dS (tr-reads of dO and Q).  Local key tiles are
+//   stored straight to dk/dv; landmark key tiles accumulate in registers across all windows of the
+//   workgroup and are written once as per-workgroup partial sums; the bias gradient accumulates in
+//   LDS and is written once per workgroup.
+// There is no barrier between the phases: delta and lse are staged with the Q/dO rows.
+#include "ea_window.h"
+
+namespace ea {
+
+template <typename E, int D>
+__global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 outp) {
+  constexpr int ROWB = D * 2;
+  constexpr int CPR = D / 8;
+  constexpr int KS = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int DQ = D / 4;
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WinTiling& t = p.t;
+  const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
+  const int rowsQ = t.wpi * nQTe * 16;
+  const int WqPad = t.nQT * 16;
+  char* Ks = smem;
+  char* Vs = Ks + t.rowsTotal * ROWB;
+  char* Qs = Vs + t.rowsTotal * ROWB;
+  char* dOs = Qs + rowsQ * ROWB;
+  float* lse_s = reinterpret_cast<float*>(dOs + rowsQ * ROWB);
+  float* delta_s = lse_s + rowsQ;
+  float* dbias_s = delta_s + rowsQ;
+  const int nbias = p.bias ? WqPad * t.biasLd : 0;
+  uint8_t* flags = reinterpret_cast<uint8_t*>(dbias_s + nbias);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* kb = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const char* vb = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
+  const char* dob = p.o.p + (b * p.o.sb + h * p.o.sh) * 2;
+  const char* ob = outp.p + (b * outp.sb + h * outp.sh) * 2;
+  char* dqb = p.dq.p + (b * p.dq.sb + h * p.dq.sh) * 2;
+  char* dkb = p.dk.p + (b * p.dk.sb + h * p.dk.sh) * 2;
+  char* dvb = p.dv.p + (b * p.dv.sb + h * p.dv.sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  const float* lse_g = p.lse + (size_t)bh * p.G.N;
+
+  // ---- once per workgroup: landmark rows, zero tile, bias-gradient accumulator ----
+  for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+    if (row < p.L) {
+      const size_t off = ((size_t)bh * p.L + row) * D + c * 8;
+      float f[8];
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lk + off);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lk + off + 4);
+      kw = pack8<E>(f);
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lv + off);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
+      vw = pack8<E>(f);
+    }
+    sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
+    sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
+    if (c == 0) flags[t.rowsLocal + row] = row < p.L ? 0 : 2;
+  }
+  for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
+
+  // landmark-gradient accumulators of the landmark tile this wave owns (tile ct = wave)
+  f32x4 dlk[DT], dlv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dlk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dlv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int it_end = min((blk + 1) * t.ipb, t.niter);
+  for (int it = blk * t.ipb; it < it_end; ++it) {
+    __syncthreads();
+    // ---- stage local K/V rows ----
+    for (int idx = tid; idx < t.rowsLocal * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int wi = row / (t.nLT * 16), slot = row - wi * (t.nLT * 16);
+      const int win = it * t.wpi + wi;
+      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+      uint8_t fl = 2;
+      if (win < t.nwin && slot < t.Wk) {
+        const int tok = part_token(p.G, win, slot, p.w, p.e);
+        fl = 1;
+        if (tok >= 0) {
+          kw = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
+          vw = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+          fl = (mrow && mrow[tok]) ? 1 : 0;
+        }
+      }
+      sts16(Ks + lds_off<D>(row, c), kw);
+      sts16(Vs + lds_off<D>(row, c), vw);
+      if (c == 0) flags[row] = fl;
+    }
+    // ---- stage Q / dO rows, lse (log2 domain) and delta = dO . O ----
+    for (int idx = tid; idx < rowsQ * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int wi = row / (nQTe * 16), slot = row - wi * (nQTe * 16);
+      const int win = it * t.wpi + wi;
+      const int tok = (win < t.nwin && slot < t.Wq) ? part_token(p.G, win, slot, p.w, 0) : -1;
+      u32x4 qw = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u};
+      float part = 0.f;
+      if (tok >= 0) {
+        qw = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
+        dw = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
+        const u32x4 ow = ldg16(ob + (tok * outp.sn + c * 8) * 2);
+        float a[8], o8[8];
+        unpack8<E>(dw, a);
+        unpack8<E>(ow, o8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part += a[i] * o8[i];
+      }
+#pragma unroll
+      for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+      sts16(Qs + lds_off<D>(row, c), qw);
+      sts16(dOs + lds_off<D>(row, c), dw);
+      if (c == 0) {
+        delta_s[row] = part;
+        lse_s[row] = tok >= 0 ? lse_g[tok] * LOG2E : INFINITY;
+      }
+    }
+    __syncthreads();
+
+    // =============================== phase A: dQ ===============================
+    for (int qi = wave; qi < t.wpi * t.nQT; qi += 4) {
+      const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
+      const int win = it * t.wpi + wi;
+      if (win >= t.nwin) continue;
+      const int qslot = qt * 16 + li;
+      const int qrow = (wi * nQTe + qt) * 16 + li;
+      const int qtok = qslot < t.Wq ? part_token(p.G, win, qslot, p.w, 0) : -1;
+      typename E::x8 qf[KS], dof[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = as_x8<E>(lds16(Qs + lds_off<D>(qrow, g * KS + ks)));
+        dof[ks] = as_x8<E>(lds16(dOs + lds_off<D>(qrow, g * KS + ks)));
+      }
+      const float lse2 = lse_s[qrow], delta = delta_s[qrow];
+      const float* brow = p.bias
+          ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+      f32x4 dq[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int ch = 0; ch < t.nchunks; ++ch) {
+        int rowbase[4];
+        uint32_t dsw[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int tile = ch * 4 + tt;
+          const bool local = tile < t.nLT;
+          rowbase[tt] = local ? (wi * t.nLT + tile) * 16
+                              : (tile < t.nLT + t.nCT ? t.rowsLocal + (tile - t.nLT) * 16
+                                                      : t.rowsLocal + t.rowsLm);
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          const int row = rowbase[tt] + li;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], s);
+            dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
+          }
+          const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + rowbase[tt] + 4 * g);
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t fl = (f4 >> (8 * r)) & 0xffu;
+            float x = s[r] * p.scale_log2 + bb[r] * LOG2E;
+            x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+            const float pr = fast_exp2(x - lse2);
+            // masked_fill blocks the gradient of the replaced logits (fl != 0)
+            ds[r] = fl == 0 ? pr * (dp[r] - delta) : 0.f;
+          }
+          dsw[tt][0] = pack2<E>(ds[0], ds[1]);
+          dsw[tt][1] = pack2<E>(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          u32x4 f4v;
+          f4v[0] = dsw[2 * kk][0]; f4v[1] = dsw[2 * kk][1];
+          f4v[2] = dsw[2 * kk + 1][0]; f4v[3] = dsw[2 * kk + 1][1];
+          const typename E::x8 dsf = as_x8<E>(f4v);
+          const int r0 = rowbase[2 * kk] + 4 * g + (li >> 2);
+          const int r1 = rowbase[2 * kk + 1] + 4 * g + (li >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+            const int c16 = colb >> 4, within = colb & 15;
+            const u32x2 lo = E::tr4(Ks + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
+            const u32x2 hi = E::tr4(Ks + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+            dq[dt] = E::mma(as_x8<E>(lo, hi), dsf, dq[dt]);
+          }
+        }
+      }
+      if (qtok >= 0) {
+        float f[DQ];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[dt][r] * p.scale;
+        char* dst = dqb + (qtok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+      }
+    }
+
+    // =============================== phase B: dK, dV ===============================
+    // work items: (window wi, local tile lt) for all staged windows, then landmark tile = wave
+    const int nLocalItems = t.wpi * t.nLT;
+    for (int item = wave; item < nLocalItems + 4; item += 4) {
+      const bool is_lm = item >= nLocalItems;
+      int tile, wi_lo, wi_hi;
+      if (is_lm) {
+        tile = wave;                                   // landmark tile owned by this wave
+        if (tile >= t.nCT) continue;
+        wi_lo = 0; wi_hi = t.wpi;
+      } else {
+        wi_lo = item / t.nLT; wi_hi = wi_lo + 1;
+        tile = item - wi_lo * t.nLT;
+        if (it * t.wpi + wi_lo >= t.nwin) continue;
+      }
+      const int krow = (is_lm ? t.rowsLocal + tile * 16 : (wi_lo * t.nLT + tile) * 16) + li;
+      typename E::x8 kf[KS], vf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = as_x8<E>(lds16(Ks + lds_off<D>(krow, g * KS + ks)));
+        vf[ks] = as_x8<E>(lds16(Vs + lds_off<D>(krow, g * KS + ks)));
+      }
+      const uint32_t fl = flags[krow];
+      const int kslot = tile * 16 + li;                // key slot within the window / landmark id
+      f32x4 dk[DT], dv[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+      for (int wi = wi_lo; wi < wi_hi; ++wi) {
+        if (it * t.wpi + wi >= t.nwin) break;
+        for (int qq = 0; qq < nQTe / 2; ++qq) {
+          uint32_t pw[2][2], dsw[2][2];
+          int rq[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int qt = 2 * qq + u;
+            rq[u] = (wi * nQTe + qt) * 16;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              s = E::mma(as_x8<E>(lds16(Qs + lds_off<D>(rq[u] + li, g * KS + ks))), kf[ks], s);
+              dp = E::mma(as_x8<E>(lds16(dOs + lds_off<D>(rq[u] + li, g * KS + ks))), vf[ks], dp);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
+            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            float pr[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qs = qt * 16 + 4 * g + r;       // query slot in the window
+              float bias = 0.f;
+              const bool bias_on = p.bias && !is_lm && qs < t.Wq && kslot < t.Wk;
+              if (bias_on) bias = p.bias[((size_t)h * t.Wq + qs) * t.biasLd + kslot];
+              float x = s[r] * p.scale_log2 + bias * LOG2E;
+              x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+              pr[r] = fast_exp2(x - ll[r]);
+              ds[r] = fl == 0 ? pr[r] * (dp[r] - dd[r]) : 0.f;
+              if (bias_on && ds[r] != 0.f) atomicAdd(dbias_s + qs * t.biasLd + kslot, ds[r]);
+            }
+            pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
+            dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
+          }
+          u32x4 a4, b4;
+          a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
+          b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
+          const typename E::x8 pf = as_x8<E>(a4), dsf = as_x8<E>(b4);
+          const int r0 = rq[0] + 4 * g + (li >> 2), r1 = rq[1] + 4 * g + (li >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+            const int c16 = colb >> 4, within = colb & 15;
+            const int o0 = r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within;
+            const int o1 = r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within;
+            dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
+            dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
+          }
+        }
+      }
+      if (is_lm) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dlk[dt] += dk[dt]; dlv[dt] += dv[dt]; }
+      } else {
+        const int win = it * t.wpi + wi_lo;
+        const int tok = kslot < t.Wk ? part_token(p.G, win, kslot, p.w, p.e) : -1;
+        if (tok >= 0) {
+          float fk[DQ], fv[DQ];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+          if (p.e == 0) {
+            char* d1 = dkb + (tok * p.dk.sn + DQ * g) * 2;
+            char* d2 = dvb + (tok * p.dv.sn + DQ * g) * 2;
+#pragma unroll
+            for (int c = 0; c < DQ / 8; ++c) {
+              stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
+              stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
+            }
+          } else {
+            // overlapping windows: a token is a key of several windows -> fp32 atomics
+            float* a1 = p.dk32 + ((size_t)bh * p.G.N + tok) * D + DQ * g;
+            float* a2 = p.dv32 + ((size_t)bh * p.G.N + tok) * D + DQ * g;
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) { atomicAdd(a1 + i, fk[i]); atomicAdd(a2 + i, fv[i]); }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- per-workgroup partial sums of the landmark and bias gradients ----
+  if (p.L > 0 && wave < t.nCT) {
+    const int lm = wave * 16 + li;
+    if (lm < p.L) {
+      float* d1 = p.dlk_part + (((size_t)blk * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
+      float* d2 = p.dlv_part + (((size_t)blk * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        *reinterpret_cast<float4*>(d1 + 4 * dt) =
+            make_float4(dlk[dt][0] * p.scale, dlk[dt][1] * p.scale, dlk[dt][2] * p.scale, dlk[dt][3] * p.scale);
+        *reinterpret_cast<float4*>(d2 + 4 * dt) = make_float4(dlv[dt][0], dlv[dt][1], dlv[dt][2], dlv[dt][3]);
+      }
+    }
+  }
+  if (p.bias) {
+    __syncthreads();
+    float* dst = p.dbias_part + (((size_t)blk * p.B + b) * p.H + h) * (size_t)t.Wq * t.biasLd;
+    for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[idx];
+  }
+}
+
+// fp32 scratch -> I/O dtype for the overlapping-window path
+template <typename E, int D>
+__global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
+  const long total = (long)p.B * p.H * p.G.N * (D / 8);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % (D / 8));
+    const long row = idx / (D / 8);
+    const int tok = (int)(row % p.G.N);
+    const int bh = (int)(row / p.G.N), b = bh / p.H, h = bh - b * p.H;
+    float f[8];
+    const float* s1 = p.dk32 + row * D + c * 8;
+    const float* s2 = p.dv32 + row * D + c * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = s1[i];
+    stg16(p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + c * 8) * 2, pack8<E>(f));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = s2[i];
+    stg16(p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + c * 8) * 2, pack8<E>(f));
+  }
+}
+
+size_t window_bwd_lds(const WinTiling& t, int D, bool bias) {
+  const int nQTe = (t.nQT + 1) & ~1;
+  const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
+  size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
+  if (bias) b += (size_t)t.nQT * 16 * t.biasLd * 4;
+  b += ((size_t)t.rowsTotal + 15) & ~(size_t)15;
+  return b;
+}
+
+template <typename E, int D>
+static int launch_bwd(const WinP& p, const T4& outp, hipStream_t st) {
+  const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr);
+  if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_bwd_kernel<E, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (p.e > 0) {
+    const size_t bytes = (size_t)p.B * p.H * p.G.N * D * sizeof(float);
+    hipError_t e = hipMemsetAsync(p.dk32, 0, bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p.dv32, 0, bytes, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
+  hipLaunchKernelGGL((win_bwd_kernel<E, D>), grid, dim3(256), lds, st, p, outp);
+  if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+
+int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (D == 64) return launch_bwd<BF16, 64>(p, outp, st);
+    if (D == 32) return launch_bwd<BF16, 32>(p, outp, st);
+    if (D == 128) return launch_bwd<BF16, 128>(p, outp, st);
+  } else if (dtype == EA_F16) {
+    if (D == 64) return launch_bwd<F16, 64>(p, outp, st);
+    if (D == 32) return launch_bwd<F16, 32>(p, outp, st);
+    if (D == 128) return launch_bwd<F16, 128>(p, outp, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

@@ -1,0 +1,228 @@
+// ea_window_fwd.hip -- forward of window attention with control-variate (landmark) columns.
+//
+// Replaces, for EVA (eva.py:151-153,200-227) and LocalAttention (local_attention.py:155-181),
+// the chain: window_partition copies of q/k/v -> einsum QK^T -> +rpe bias -> masked_fill ->
+// cat with the landmark logits -> softmax -> split -> two einsums -> window_merge copy.
+//
+// One 256-thread workgroup (4 waves) owns a run of windows of one (batch, head):
+//   * the landmark keys/values (rf_k_bar, beta: [L, D]) are converted to the MFMA element type
+//     and parked in LDS once per workgroup;
+//   * per iteration the local K/V rows of `wpi` windows are gathered straight from the strided
+//     q/k/v tensors into LDS (the window partition is address arithmetic, nothing is copied in
+//     HBM), out-of-range and padded keys get a per-row flag;
+//   * each wave takes 16-query tiles: Q fragments come directly from global memory as MFMA B
+//     operands, S^T = K.Q^T tiles are produced 64 keys at a time, run through an online softmax
+//     in registers (two 4-lane shuffles per reduction) and fed, register for register, into
+//     O^T = V^T.P^T with V^T fragments from ds_read_b64_tr_b16;
+//   * O is written with each lane owning D/4 contiguous channels of one query (32 B stores).
+// HBM traffic is the algorithmic minimum (q,k,v read once, out written once) plus the landmark
+// rows per workgroup, which come from L2.
+#include "ea_window.h"
+
+namespace ea {
+
+template <typename E, int D>
+__global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
+  constexpr int ROWB = D * 2;      // bytes per LDS row
+  constexpr int CPR = D / 8;       // 16-byte chunks per row
+  constexpr int KS = D / 32;       // k-steps of the score MFMA
+  constexpr int DT = D / 16;       // 16-channel tiles of the output
+  constexpr int DQ = D / 4;        // channels per lane in the output layout
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WinTiling& t = p.t;
+  char* Ks = smem;
+  char* Vs = Ks + t.rowsTotal * ROWB;
+  uint8_t* flags = reinterpret_cast<uint8_t*>(Vs + t.rowsTotal * ROWB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* kb = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const char* vb = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
+  char* ob = p.o.p + (b * p.o.sb + h * p.o.sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+
+  // ---- landmark rows + the all-zero dummy tile: once per workgroup ----
+  for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+    if (row < p.L) {
+      const size_t off = ((size_t)bh * p.L + row) * D + c * 8;
+      float f[8];
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lk + off);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lk + off + 4);
+      kw = pack8<E>(f);
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lv + off);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
+      vw = pack8<E>(f);
+    }
+    sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
+    sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
+    if (c == 0) flags[t.rowsLocal + row] = row < p.L ? 0 : 2;
+  }
+
+  const int it_end = min((blk + 1) * t.ipb, t.niter);
+  for (int it = blk * t.ipb; it < it_end; ++it) {
+    __syncthreads();   // readers of the previous iteration's local rows are done
+    // ---- gather the local K/V rows of this iteration's windows ----
+    for (int idx = tid; idx < t.rowsLocal * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int wi = row / (t.nLT * 16), slot = row - wi * (t.nLT * 16);
+      const int win = it * t.wpi + wi;
+      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+      uint8_t fl = 2;                                  // slot does not exist
+      if (win < t.nwin && slot < t.Wk) {
+        const int tok = part_token(p.G, win, slot, p.w, p.e);
+        fl = 1;                                        // outside the sequence: zero k/v, -5e4
+        if (tok >= 0) {
+          kw = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
+          vw = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+          fl = (mrow && mrow[tok]) ? 1 : 0;
+        }
+      }
+      sts16(Ks + lds_off<D>(row, c), kw);
+      sts16(Vs + lds_off<D>(row, c), vw);
+      if (c == 0) flags[row] = fl;
+    }
+    __syncthreads();
+
+    for (int qi = wave; qi < t.wpi * t.nQT; qi += 4) {
+      const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
+      const int win = it * t.wpi + wi;
+      if (win >= t.nwin) continue;                      // wave-uniform
+      const int qslot = qt * 16 + li;
+      const int qtok = qslot < t.Wq ? part_token(p.G, win, qslot, p.w, 0) : -1;
+      typename E::x8 qf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 w4 = {0u, 0u, 0u, 0u};
+        if (qtok >= 0) w4 = ldg16(qb + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
+        qf[ks] = as_x8<E>(w4);
+      }
+      const float* brow = p.bias
+          ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+
+      float m = -INFINITY, lsum = 0.f;
+      f32x4 o[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      for (int ch = 0; ch < t.nchunks; ++ch) {
+        int rowbase[4];
+        f32x4 s[4];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int tile = ch * 4 + tt;
+          const bool local = tile < t.nLT;
+          rowbase[tt] = local ? (wi * t.nLT + tile) * 16
+                              : (tile < t.nLT + t.nCT ? t.rowsLocal + (tile - t.nLT) * 16
+                                                      : t.rowsLocal + t.rowsLm);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const int row = rowbase[tt] + li;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+          const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + rowbase[tt] + 4 * g);
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t fl = (f4 >> (8 * r)) & 0xffu;
+            float x = acc[r] * p.scale_log2 + bb[r] * LOG2E;
+            x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+            acc[r] = x;
+            mloc = fmaxf(mloc, x);
+          }
+          s[tt] = acc;
+        }
+        mloc = quad_max(mloc);
+        const float mnew = fmaxf(m, mloc);
+        const float msafe = mnew == -INFINITY ? 0.f : mnew;
+        const float alpha = fast_exp2(m - msafe);        // m = -inf -> 0
+        m = mnew;
+        float psum = 0.f;
+        uint32_t pw[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float pv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pv[r] = fast_exp2(s[tt][r] - msafe);
+            psum += pv[r];
+          }
+          pw[tt][0] = pack2<E>(pv[0], pv[1]);
+          pw[tt][1] = pack2<E>(pv[2], pv[3]);
+        }
+        lsum = lsum * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          u32x4 pf4;
+          pf4[0] = pw[2 * kk][0]; pf4[1] = pw[2 * kk][1];
+          pf4[2] = pw[2 * kk + 1][0]; pf4[3] = pw[2 * kk + 1][1];
+          const typename E::x8 pf = as_x8<E>(pf4);
+          const int r0 = rowbase[2 * kk] + 4 * g + (li >> 2);
+          const int r1 = rowbase[2 * kk + 1] + 4 * g + (li >> 2);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int colb = (DQ * (li & 3) + 4 * dt) * 2;          // byte column of 4 channels
+            const int c16 = colb >> 4, within = colb & 15;
+            const u32x2 lo = E::tr4(Vs + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
+            const u32x2 hi = E::tr4(Vs + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+            o[dt] = E::mma(as_x8<E>(lo, hi), pf, o[dt]);
+          }
+        }
+      }
+      // ---- finalize: normalise, store O (lane: query li, channels DQ*g .. DQ*g+DQ-1), lse ----
+      const float ltot = quad_sum(lsum);
+      const float inv = 1.f / ltot;
+      if (qtok >= 0) {
+        float f[DQ];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[4 * dt + r] = o[dt][r] * inv;
+        char* dst = ob + (qtok * p.o.sn + DQ * g) * 2;
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+        if (g == 0) p.lse[((size_t)bh) * p.G.N + qtok] = (m + fast_log2(ltot)) * LN2;
+      }
+    }
+  }
+}
+
+template <typename E, int D>
+static int launch_fwd(const WinP& p, hipStream_t st) {
+  const size_t lds = (size_t)p.t.rowsTotal * D * 2 * 2 + p.t.rowsTotal;
+  if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
+  hipLaunchKernelGGL((win_fwd_kernel<E, D>), grid, dim3(256), lds, st, p);
+  return (int)hipGetLastError();
+}
+
+int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st) {
+#define EA_CASE(EE, DD) return launch_fwd<EE, DD>(p, st)
+  if (dtype == EA_BF16) {
+    if (D == 64) EA_CASE(BF16, 64);
+    if (D == 32) EA_CASE(BF16, 32);
+    if (D == 128) EA_CASE(BF16, 128);
+  } else if (dtype == EA_F16) {
+    if (D == 64) EA_CASE(F16, 64);
+    if (D == 32) EA_CASE(F16, 32);
+    if (D == 128) EA_CASE(F16, 128);
+  }
+#undef EA_CASE
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

@@ -1,0 +1,123 @@
+"""ctypes binding of libea_hip.so (include/ea_hip.h) -- the only way the attention cores run.
+
+There is NO CPU or PyTorch fallback in this package: if the library cannot be loaded, or a
+tensor that is not a contiguous-enough CUDA/HIP tensor reaches a core, a RuntimeError is raised.
+torch is used here for device memory and streams only (`data_ptr()`, current stream handle).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get(
+    "EA_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libea_hip.so"))
+
+EA_BF16, EA_F16 = 0, 1
+_DTYPES = {torch.bfloat16: EA_BF16, torch.float16: EA_F16}
+
+
+class ea_t4(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("sb", ctypes.c_int64), ("sh", ctypes.c_int64),
+                ("sn", ctypes.c_int64)]
+
+
+class ea_geom(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("attn_2d", ctypes.c_int32),
+                ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32),
+                ("ext", ctypes.c_int32), ("chunk", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("scale", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+_G = ctypes.POINTER(ea_geom)
+_T = ctypes.POINTER(ea_t4)
+
+# name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
+SIGNATURES = {
+    "ea_eva_chunk_mean_fwd": [_G, _T, _T, _P, _P, _P, _P],
+    "ea_eva_chunk_mean_bwd": [_G, _P, _P, _P, _T, _T, _P],
+    "ea_eva_beta_fwd": [_G, _T, _T, _P, _P, _P, _P],
+    "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
+    "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
+    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_window_bias_ld": [_G],
+    "ea_window_bwd_parts": [_G],
+}
+
+_lib = None
+
+
+def lib():
+    """Load libea_hip.so once; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                "efficient_attention (MI355X build): %s not found. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` at the repo root; there is "
+                "no CPU fallback for the attention cores." % _LIB_PATH)
+        cdll = ctypes.CDLL(_LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(cdll, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        cdll.ea_version.restype = ctypes.c_char_p
+        cdll.ea_abi_version.restype = ctypes.c_int32
+        _lib = cdll
+    return _lib
+
+
+def version():
+    return lib().ea_version().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported geometry"}.get(rc, "hipError_t %d" % rc)
+        raise RuntimeError("%s failed: %s" % (what, kind))
+
+
+def require_cuda(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(
+            "efficient_attention (MI355X build): %s must be a CUDA/HIP tensor -- the attention "
+            "cores are HIP kernels and have no CPU fallback." % what)
+
+
+def io_dtype(t):
+    if t.dtype not in _DTYPES:
+        raise RuntimeError("attention cores take bf16 or fp16 tensors, got %s" % t.dtype)
+    return _DTYPES[t.dtype]
+
+
+def t4(t):
+    """[B, H, N, D] view (any strides, D contiguous) -> ea_t4."""
+    assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
+    return ea_t4(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0):
+    gh, gw = (seq_shape if attn_2d else (1, N))
+    return ea_geom(B, H, N, D, dtype, 1 if attn_2d else 0, gh, gw, window, ext, chunk, L,
+                   float(D) ** -0.5)
+
+
+def call(name, *args):
+    _check(getattr(lib(), name)(*args), name)
+
+
+def query(name, geom):
+    v = getattr(lib(), name)(ctypes.byref(geom))
+    if v < 0:
+        _check(v, name)
+    return v

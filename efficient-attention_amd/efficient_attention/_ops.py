@@ -1,0 +1,203 @@
+"""Autograd wrappers around the HIP attention cores (libea_hip.so via _native.py).
+
+One torch.autograd.Function per attention variant; each forward/backward is a short sequence
+of HIP kernel launches on the current stream.  q, k and v are never split out of the fused
+projection output: the kernels address the [B, N, 3, h, d] tensor produced by `qkv = Linear(x)`
+in place through strides, and the backward kernels write dq/dk/dv straight into one
+[B, N, 3, h, d] gradient buffer, so none of the reference's permute/contiguous/select-backward
+copies exist here.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as nv
+
+
+def _qkv_views(qkv5):
+    """[B,N,3,h,d] -> three [B,h,N,d] strided views (no copy)."""
+    q, k, v = qkv5.unbind(2)
+    return q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+
+
+def _mask_u8(mask, B, N, device):
+    if mask is None:
+        return None
+    m = mask.to(device=device, dtype=torch.uint8).reshape(B, N).contiguous()
+    return m
+
+
+def _bias_padded(bias, geom):
+    """[h, Wq, Wk] fp32 -> rows padded to the kernel's leading dimension."""
+    if bias is None:
+        return None
+    ld = nv.query("ea_window_bias_ld", geom)
+    b = bias.float()
+    if b.shape[-1] != ld:
+        b = F.pad(b, (0, ld - b.shape[-1]))
+    return b.contiguous()
+
+
+def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8):
+    B, N, _, h, d = qkv5.shape
+    q, k, v = _qkv_views(qkv5)
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
+    lse = torch.empty((B, h, N), dtype=torch.float32, device=qkv5.device)
+    tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
+    nv.call("ea_window_attn_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+            ctypes.byref(tv), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
+            ctypes.byref(to), nv.ptr(lse), nv.stream())
+    return out, lse
+
+
+def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
+    """out, dout: [B,N,h,d] contiguous.  Writes dq,dk,dv into dqkv5; returns dlk, dlv, dbias_padded."""
+    B, N, _, h, d = qkv5.shape
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    parts = nv.query("ea_window_bwd_parts", geom)
+    L = geom.L
+    dev = qkv5.device
+    dlk_p = dlv_p = dbias_p = None
+    if L > 0:
+        dlk_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
+        dlv_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
+    if bias_p is not None:
+        dbias_p = torch.empty((parts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
+    dk_acc = dv_acc = None
+    if geom.ext > 0:
+        dk_acc = torch.empty((B, h, N, d), dtype=torch.float32, device=dev)
+        dv_acc = torch.empty_like(dk_acc)
+    ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
+    nv.call("ea_window_attn_bwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]),
+            ctypes.byref(ts[2]), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
+            ctypes.byref(ts[3]), ctypes.byref(ts[4]), nv.ptr(lse), ctypes.byref(ts[5]),
+            ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(dlk_p), nv.ptr(dlv_p), nv.ptr(dbias_p),
+            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.stream())
+    dlk = dlk_p.sum(0).view(B, h, L, d) if L > 0 else None
+    dlv = dlv_p.sum(0).view(B, h, L, d) if L > 0 else None
+    dbias = dbias_p.sum((0, 1)) if bias_p is not None else None
+    return dlk, dlv, dbias
+
+
+# ------------------------------------------------------------------------------------------
+# local window attention  (reference local_attention.py:134-182)
+# ------------------------------------------------------------------------------------------
+class LocalAttnFn(torch.autograd.Function):
+    """out[B,N,h,d] = per-window softmax(s QK^T + bias, -5e4 mask) V on a fused qkv tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, 0, 0)
+        bias_p = _bias_padded(bias, geom)
+        out, lse = _window_fwd(geom, qkv5, None, None, bias_p, mask_u8)
+        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out)
+        ctx.geom = geom
+        ctx.bias_cols = None if bias is None else bias.shape[-1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
+        dqkv5 = torch.empty_like(qkv5)
+        _, _, dbias = _window_bwd(ctx.geom, qkv5, None, None, bias_p, mask_u8, out,
+                                  dout.contiguous(), lse, dqkv5)
+        if dbias is not None:
+            dbias = dbias[..., :ctx.bias_cols]
+        return dqkv5, dbias, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# EVA  (reference eva.py:145-227)
+# ------------------------------------------------------------------------------------------
+def eva_mu(qmean, kmean, params, adaptive_proj):
+    """rf_k_bar, mu from the chunk means (eva.py:178-185). fp32, [B,h,L,d] -- tiny."""
+    d = kmean.shape[-1]
+    if adaptive_proj in ("default", "no-ln"):
+        if adaptive_proj == "default":
+            wq, bq, gq, cq, wk, bk, gk, ck = params
+            rq = F.layer_norm(F.linear(qmean, wq, bq), (d,), gq, cq, 1e-5)
+            rk = F.layer_norm(F.linear(kmean, wk, bk), (d,), gk, ck, 1e-5)
+        else:
+            wq, bq, wk, bk = params
+            rq, rk = F.linear(qmean, wq, bq), F.linear(kmean, wk, bk)
+        return rk, 0.5 * (rq + rk)
+    wk, bk, gk, ck = params
+    rk = F.layer_norm(F.linear(kmean, wk, bk), (d,), gk, ck, 1e-5)
+    return rk, torch.zeros_like(rk)
+
+
+class EvaAttnFn(torch.autograd.Function):
+    """EVA core on a fused qkv tensor: chunk means -> mu MLP -> omega -> beta -> window attention
+    with control-variate columns.  Returns out [B,N,h,d]."""
+
+    @staticmethod
+    def forward(ctx, qkv5, bias, noise, mask_u8, cfg, *mlp_params):
+        nv.require_cuda(qkv5, "qkv")
+        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg
+        B, N, _, h, d = qkv5.shape
+        dev = qkv5.device
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, chunk, L)
+        q, k, v = _qkv_views(qkv5)
+        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+        qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
+        kmean = torch.empty_like(qmean)
+        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+                nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
+        # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
+        with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+            rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj)
+            omega = (mu if noise is None else mu + noise.float()).contiguous()
+            rf_k_bar = rf_k_bar.contiguous()
+        beta = torch.empty_like(qmean)
+        nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
+        bias_p = _bias_padded(bias, geom)
+        out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8)
+        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out, qmean, kmean, omega, beta, rf_k_bar,
+                              *mlp_params)
+        ctx.geom = geom
+        ctx.adaptive_proj = adaptive_proj
+        ctx.bias_cols = None if bias is None else bias.shape[-1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv5, bias_p, mask_u8, lse, out, qmean, kmean, omega, beta, rf_k_bar,
+         *mlp_params) = ctx.saved_tensors
+        geom = ctx.geom
+        dqkv5 = torch.empty_like(qkv5)
+        d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
+                                           dout.contiguous(), lse, dqkv5)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        tk, tv, tdq, tdk, tdv = nv.t4(k), nv.t4(v), nv.t4(dq), nv.t4(dk), nv.t4(dv)
+        d_omega = torch.empty_like(omega)
+        d_beta = d_beta.contiguous()
+        nv.call("ea_eva_beta_bwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
+                ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
+        # mu MLP backward on the tiny [B,h,L,d] tensors (Linear/LayerNorm parameter grads are
+        # [d,d] GEMMs over B*h*L rows -- left to torch)
+        with torch.enable_grad(), torch.autocast(device_type="cuda", enabled=False):
+            qm = qmean.detach().requires_grad_(True)
+            km = kmean.detach().requires_grad_(True)
+            ps = [p.detach().float().requires_grad_(True) for p in mlp_params]
+            rk, mu = eva_mu(qm, km, ps, ctx.adaptive_proj)
+            outs, gouts = [rk], [d_rfk.contiguous()]
+            if mu.requires_grad:
+                outs.append(mu)
+                gouts.append(d_omega)
+            grads = torch.autograd.grad(outs, [qm, km] + ps, gouts, allow_unused=True)
+        dqm, dkm = grads[0], grads[1]
+        dqm = torch.zeros_like(qmean) if dqm is None else dqm.contiguous()
+        dkm = torch.zeros_like(kmean) if dkm is None else dkm.contiguous()
+        nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
+                nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+        pgrads = [None if g is None else g.to(p.dtype) for g, p in zip(grads[2:], mlp_params)]
+        if dbias is not None:
+            dbias = dbias[..., :ctx.bias_cols]
+        return (dqkv5, dbias, None, None, None) + tuple(pgrads)

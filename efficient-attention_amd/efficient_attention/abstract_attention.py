@@ -1,0 +1,109 @@
+"""Softmax baseline and the base class of every attention module.
+
+Mirrors efficient_attention/abstract_attention.py:41-140 of the reference: same constructor
+kwargs (`fp32` is accepted and, like the reference, never read), same parameters
+(`qkv`, `proj`), same init (trunc-normal std .02 Linear weights, zero biases, unit LayerNorm),
+same `forward(x, key_padding_mask=None)` protocol with `x: [B, *seq_shape, C]`.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import add_nested_argument
+from . import _ops
+
+
+class AbstractAttention(nn.Module):
+    """Unused stub kept for import compatibility (reference :10-39)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.name = "%s.%d" % (self.__class__.__name__, hash(self))
+
+    def _reset_parameters(self):
+        raise NotImplementedError
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _apply_attention(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, dim, num_heads, fp32=False, qkv_bias=True, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.dim = dim
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv_bias = qkv_bias
+        self.fp32 = fp32
+        self.qkv = nn.Linear(dim, 3 * dim, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.zeros_(m.bias)
+            nn.init.ones_(m.weight)
+        elif isinstance(m, nn.Conv2d):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+            m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+            if m.bias is not None:
+                m.bias.data.zero_()
+
+    # ---- projections ---------------------------------------------------------------------
+    def project_qkv(self, x):
+        """x [B, N, C] -> fused qkv [B, N, 3, h, d] in the kernels' I/O dtype (bf16/fp16).
+        Under autocast the Linear already emits it; fp32 activations are rounded to bf16 (the
+        kernels compute bf16 x bf16 -> fp32, the autocast contract of vit/engine.py:47)."""
+        B, N, C = x.shape
+        qkv = self.qkv(x)
+        if qkv.dtype not in (torch.bfloat16, torch.float16):
+            qkv = qkv.to(torch.bfloat16)
+        return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
+
+    def proj_and_split_heads(self, x):
+        """Reference-compatible helper (:72-78): three [B, h, N, d] strided views."""
+        B, *seq_shape, C = x.shape
+        N = int(math.prod(seq_shape))
+        return _ops._qkv_views(self.project_qkv(x.reshape(B, N, C)))
+
+    def merge_and_project(self, out, B, seq_shape, C, dtype):
+        """out [B, N, h, d] (contiguous) -> proj -> proj_drop, shaped [B, *seq_shape, C]."""
+        x = out.reshape((B,) + tuple(seq_shape) + (C,))
+        x = self.proj(x)
+        if not torch.is_autocast_enabled() and x.dtype != dtype:
+            x = x.to(dtype)
+        return self.proj_drop(x)
+
+    # ---- softmax attention ---------------------------------------------------------------
+    def forward(self, x, key_padding_mask=None):
+        B, *seq_shape, C = x.shape
+        N = int(math.prod(seq_shape))
+        qkv5 = self.project_qkv(x.reshape(B, N, C))
+        out = self._attend(qkv5, key_padding_mask, seq_shape)        # [B, N, h, d]
+        return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+    def _attend(self, qkv5, key_padding_mask, seq_shape):
+        if self.training and self.attn_drop.p > 0:
+            raise NotImplementedError("attention dropout inside the fused softmax kernel")
+        B, N = qkv5.shape[:2]
+        mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
+        return _ops.SoftmaxAttnFn.apply(qkv5, mask)
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        group = parent_parser.add_argument_group("Attention")
+        flag_prefix = prefix + "-" if len(prefix) > 1 else ""
+        add_nested_argument(group, "--%sfp32" % flag_prefix, struct_name=struct_name, prefix=prefix,
+                            default=False, action="store_true")
+        return parent_parser

@@ -1,0 +1,175 @@
+"""EVA: attention with control variates (ICLR'23), MI355X build.
+
+Mirrors efficient_attention/eva.py:15-243: `T5RelativePositionBias`, the constructor kwargs
+(`adaptive_proj` in {default, no-ln, none}, `num_landmarks`, `use_t5_rpe` + LocalAttention's),
+the `adaptive_mu_q/k` parameter layout, the 1-D padding rule of `_process_input`, training-time
+sampling `omega = mu + randn_like(mu)` and the argparse flags.  The chunk means, beta, and
+the window attention with control-variate columns run in libea_hip.so (_ops.EvaAttnFn).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import add_nested_argument
+from . import _ops
+from .local_attention import LocalAttention
+
+
+class T5RelativePositionBias(nn.Module):
+    """Bucketed relative-position bias (reference :15-65); forward(x) -> [1,h,1,i,j] * scale."""
+
+    def __init__(self, scale, num_heads, causal=False, num_buckets=32, max_distance=128):
+        super().__init__()
+        self.scale = scale
+        self.causal = causal
+        self.num_buckets = num_buckets
+        self.max_distance = max_distance
+        self.relative_attention_bias = nn.Embedding(num_buckets, num_heads)
+
+    @staticmethod
+    def _relative_position_bucket(relative_position, causal=True, num_buckets=32, max_distance=128):
+        n = -relative_position
+        bucket = torch.zeros_like(n)
+        if causal:
+            n = n.clamp(min=0)
+        else:
+            num_buckets //= 2
+            bucket = bucket + (n < 0).long() * num_buckets
+            n = n.abs()
+        max_exact = num_buckets // 2
+        far = max_exact + (torch.log(n.clamp(min=1).float() / max_exact)
+                           / math.log(max_distance / max_exact) * (num_buckets - max_exact)).long()
+        far = far.clamp(max=num_buckets - 1)
+        return bucket + torch.where(n < max_exact, n, far)
+
+    def bucket_table(self, i, j, device):
+        """[i, j] bucket ids.  The float log + truncation sits on exact bucket boundaries for
+        some distances, so the table is always evaluated on the CPU (as the reference's CPU path
+        does) and cached, never with the device's log implementation."""
+        key = (i, j)
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        if key not in cache:
+            rel = torch.arange(j).view(1, j) - torch.arange(i).view(i, 1)
+            cache[key] = self._relative_position_bucket(
+                rel, causal=self.causal, num_buckets=self.num_buckets, max_distance=self.max_distance)
+        return cache[key].to(device)
+
+    def dense(self, i, j, device):
+        """[h, i, j] bias, already multiplied by scale."""
+        return self.relative_attention_bias(self.bucket_table(i, j, device)).permute(2, 0, 1) * self.scale
+
+    def forward(self, x):
+        i, j = x.shape[-2:]
+        return self.dense(i, j, x.device).unsqueeze(0).unsqueeze(2)
+
+
+class EVA(LocalAttention):
+    def __init__(self, adaptive_proj='default', num_landmarks=49, use_t5_rpe=False, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.adaptive_proj = adaptive_proj
+        d = self.head_dim
+
+        def mu_net(with_ln):
+            layers = [nn.Linear(d, d)] + ([nn.LayerNorm(d)] if with_ln else [])
+            return nn.Sequential(*layers)
+
+        if adaptive_proj == 'default':
+            self.adaptive_mu_q, self.adaptive_mu_k = mu_net(True), mu_net(True)
+        elif adaptive_proj == 'no-ln':
+            self.adaptive_mu_q, self.adaptive_mu_k = mu_net(False), mu_net(False)
+        elif adaptive_proj == 'none':
+            self.adaptive_mu_k = mu_net(True)
+        self.use_t5_rpe = use_t5_rpe
+        self.num_landmarks = num_landmarks
+        if self.use_rpe and self.use_t5_rpe:
+            raise NotImplementedError("Default RPE and T5-style RPE cannot be true simultaneously.")
+        if self.use_rpe:
+            warnings.warn("--use-rpe selects the default window relative positional embedding; "
+                          "the T5-style encoding (--use-t5-rpe alone) usually works slightly better.")
+        if self.use_t5_rpe:
+            span = self.window_size + self.ext_size
+            self.rel_pos_bias = T5RelativePositionBias(
+                self.scale, num_heads=self.num_heads, causal=False,
+                num_buckets=max(min(int(span / 2), 64), 16), max_distance=span)
+        self.apply(self._init_weights)
+
+    def _mu_params(self):
+        if self.adaptive_proj == 'default':
+            q, k = self.adaptive_mu_q, self.adaptive_mu_k
+            return [q[0].weight, q[0].bias, q[1].weight, q[1].bias,
+                    k[0].weight, k[0].bias, k[1].weight, k[1].bias]
+        if self.adaptive_proj == 'no-ln':
+            q, k = self.adaptive_mu_q, self.adaptive_mu_k
+            return [q[0].weight, q[0].bias, k[0].weight, k[0].bias]
+        k = self.adaptive_mu_k
+        return [k[0].weight, k[0].bias, k[1].weight, k[1].bias]
+
+    def _process_input(self, x, key_padding_mask):
+        """2-D: validate the grid; 1-D: pad x to a multiple of the window and build/extend the
+        padding mask (reference :119-136)."""
+        B, *seq_shape, C = x.shape
+        w = self.window_size
+        if self.attn_2d:
+            assert len(seq_shape) == 2
+            if w > 0:
+                assert seq_shape[0] % w == 0 and seq_shape[1] % w == 0
+            return x, key_padding_mask, seq_shape
+        n = seq_shape[0]
+        n_pad = int(math.ceil(n / w) * w) if w > 0 else n
+        mask = torch.zeros(B, n_pad, dtype=torch.bool, device=x.device)
+        if key_padding_mask is not None:
+            mask[:, :n] = key_padding_mask.to(torch.bool)
+        if n_pad != n:
+            x = F.pad(x, (0, 0, 0, n_pad - n))
+            mask[:, n:] = True
+        return x, mask, [n_pad]
+
+    def forward(self, x, key_padding_mask=None):
+        B, *seq_shape, C = x.shape
+        orig_n = int(math.prod(seq_shape))
+        x, key_padding_mask, seq_shape = self._process_input(x, key_padding_mask)
+        N = int(math.prod(seq_shape))
+        w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
+        qkv5 = self.project_qkv(x.reshape(B, N, C))
+
+        if self.attn_2d:
+            r = int(math.sqrt(N // self.num_landmarks))
+            L = (seq_shape[0] // r) * (seq_shape[1] // r)
+            if e == 0:
+                assert seq_shape[0] % r == 0 and seq_shape[1] % r == 0
+            Wq, Wk = w * w, (w + 2 * e) ** 2
+        else:
+            r = int(N // self.num_landmarks)
+            L = N // r
+            if e == 0:
+                assert N % r == 0
+            Wq, Wk = w, w + 2 * e
+
+        if self.use_t5_rpe:
+            bias = self.rel_pos_bias.dense(Wq, Wk, x.device)
+        else:
+            bias = self._table_bias()
+        noise = None
+        if self.training:
+            noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
+        mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+        cfg = (self.attn_2d, tuple(seq_shape), w, e, r, L, self.adaptive_proj)
+        out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask, cfg, *self._mu_params())
+        y = self.merge_and_project(out, B, seq_shape, C, x.dtype)
+        if not self.attn_2d:
+            y = y[..., :orig_n, :]
+        return y
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        parent_parser = LocalAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)
+        group = parent_parser.add_argument_group("attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        kw = dict(struct_name=struct_name, prefix=prefix)
+        add_nested_argument(group, "--%sadaptive-proj" % fp, default='default', type=str, **kw)
+        add_nested_argument(group, "--%snum-landmarks" % fp, default=49, type=int, **kw)
+        add_nested_argument(group, "--%suse-t5-rpe" % fp, action="store_true", default=False, **kw)
+        return parent_parser

@@ -1,0 +1,154 @@
+"""LARA: linear randomized attention (ICML'22), MI355X build.
+
+Mirrors efficient_attention/lara.py:14-267: constructor kwargs, the `q_bar_gen/k_bar_gen`
+Sequential layouts (so state_dict keys are `q_bar_gen.{2,3}.*` for pooled and `{0,1}.*` for
+adaptive-1d proposals), the 2-D / 1-D dispatch on the rank of `x`, the sampling modes and the
+argparse flags.  The O(N L d) estimator -- random-feature projections of q and k, the
+per-landmark softmax statistics over the sequence, the importance weights and the final
+combine -- runs in libea_hip.so (_ops.LaraAttnFn).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import add_nested_argument
+from . import _ops
+from .abstract_attention import MultiheadAttention
+from .attn_utils import FlattenTranspose
+
+
+class LinearRA(MultiheadAttention):
+    def __init__(self, num_landmarks=49, kernel_size=None, proposal_gen='pool',
+                 use_antithetics=False, use_multisample=False, pool_module_type='light',
+                 mis_type='mis-opt', alpha_coeff=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.num_landmarks = num_landmarks
+        self.proposal_gen = proposal_gen
+        self.use_antithetics = use_antithetics
+        self.use_multisample = use_multisample
+        self.pool_module_type = pool_module_type
+        self.mis_type = mis_type
+        self.alpha_coeff = alpha_coeff
+        if pool_module_type == 'dense':
+            ch = self.dim
+        elif pool_module_type == 'light':
+            ch = self.head_dim
+        side = int(math.sqrt(num_landmarks))
+
+        def gen():
+            if proposal_gen.startswith('pool'):
+                return nn.Sequential(nn.AdaptiveAvgPool2d(side), FlattenTranspose(),
+                                     nn.Linear(ch, ch), nn.LayerNorm(ch))
+            if proposal_gen.startswith('no-param-pool'):
+                return nn.Sequential(nn.AdaptiveAvgPool2d(side), FlattenTranspose())
+            if proposal_gen.startswith('adaptive-1d'):
+                return nn.Sequential(nn.Linear(ch, ch), nn.LayerNorm(ch))
+            raise NotImplementedError
+
+        self.q_bar_gen = gen()
+        self.k_bar_gen = gen()
+        self.apply(self._init_weights)
+
+    # ---- landmark proposals (tiny [B,h,L,d] tensors; pooling reads q,k once) -------------
+    def _proposal_gen_2d(self, qkv5, H, W):
+        """Adaptive 2-D average pool of q,k -> [Linear+LN] -> optional softmax mixing of k_bar
+        (reference :129-175).  Returns q_bar, k_bar [B,h,L,d] fp32."""
+        B, N, _, h, d = qkv5.shape
+        side = int(math.sqrt(self.num_landmarks))
+        pooled = _ops.pool2d_qkv(qkv5, H, W, side)                 # [3, B, h, L, d] fp32
+        pq, pk, pv = pooled[0], pooled[1], pooled[2]
+        gen = self.proposal_gen
+        if gen.startswith('pool'):
+            if self.pool_module_type == 'dense':
+                def dense(p, net):
+                    z = p.permute(0, 2, 1, 3).reshape(B, side * side, h * d)
+                    z = net[3](net[2](z))
+                    return z.reshape(B, side * side, h, d).permute(0, 2, 1, 3)
+                q_bar, k_bar = dense(pq, self.q_bar_gen), dense(pk, self.k_bar_gen)
+            else:
+                q_bar = self.q_bar_gen[3](self.q_bar_gen[2](pq))
+                k_bar = self.k_bar_gen[3](self.k_bar_gen[2](pk))
+        else:
+            q_bar, k_bar = pq, pk
+        q_bar, k_bar = q_bar.float(), k_bar.float()
+        if gen.endswith('mixed'):
+            logits = self.scale * torch.einsum('bhpd,bhcd->bhpc', k_bar, k_bar)
+            if gen.endswith('-vmixed'):
+                logits = logits + torch.log(pv.norm(dim=-1) + 1e-4).unsqueeze(-2)
+            k_bar = torch.einsum('bhpc,bhcd->bhpd', torch.softmax(logits, dim=-1), k_bar)
+        return q_bar, k_bar
+
+    def _proposal_gen_1d(self, qkv5, key_padding_mask):
+        """Segment means of (optionally Linear+LN'd) q,k with the even / uneven split rule
+        (reference :84-127).  Returns q_bar, k_bar [B,h,L,d] fp32 and the (mask-zeroed) qkv."""
+        B, N, _, h, d = qkv5.shape
+        L = self.num_landmarks
+        if key_padding_mask is not None:
+            keep = (~key_padding_mask.to(torch.bool)).to(qkv5.dtype).view(B, N, 1, 1, 1)
+            qkv5 = qkv5 * keep
+        q, k, _ = _ops._qkv_views(qkv5)
+        if self.proposal_gen.startswith('adaptive-1d'):
+            q2, k2 = self.q_bar_gen(q), self.k_bar_gen(k)
+        else:
+            q2, k2 = q, k
+        q2, k2 = q2.float(), k2.float()
+        if N <= L:
+            return q2, k2, qkv5
+        segs = N // L
+        if N % L == 0:
+            q_bar = q2.reshape(B, h, L, segs, d).mean(-2)
+            k_bar = k2.reshape(B, h, L, segs, d).mean(-2)
+        else:
+            short = (segs + 1) * L - N
+
+            def seg_mean(t):
+                head = t[:, :, :short * segs].reshape(B, h, short, segs, d).mean(-2)
+                tail = t[:, :, short * segs:].reshape(B, h, L - short, segs + 1, d).mean(-2)
+                return torch.cat([head, tail], dim=-2)
+            q_bar, k_bar = seg_mean(q2), seg_mean(k2)
+        return q_bar, k_bar, qkv5
+
+    def forward(self, x, key_padding_mask=None):
+        B, *seq_shape, C = x.shape
+        N = int(math.prod(seq_shape))
+        h, d = self.num_heads, self.head_dim
+        qkv5 = self.project_qkv(x.reshape(B, N, C))
+        if len(seq_shape) == 2:
+            q_bar, k_bar = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1])
+        elif len(seq_shape) == 1:
+            q_bar, k_bar, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
+        else:
+            raise ValueError("LinearRA expects x of rank 3 or 4")
+        mu = q_bar + k_bar
+        mode, noise = 0, None
+        if self.training:
+            if self.use_multisample:
+                mode = 2
+                noise = torch.randn(B, h, mu.shape[-2] * 2, d, dtype=mu.dtype, device=mu.device)
+            elif self.use_antithetics:
+                mode = 1
+                noise = torch.randn_like(mu)
+            else:
+                noise = torch.randn_like(mu)
+        mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+        out = _ops.lara_attention(qkv5, mask, q_bar, mu, noise, self.mis_type, self.alpha_coeff,
+                                  mode, self.scale)
+        return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        parent_parser = MultiheadAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)
+        group = parent_parser.add_argument_group("attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        kw = dict(struct_name=struct_name, prefix=prefix)
+        add_nested_argument(group, "--%snum-landmarks" % fp, default=49, type=int, **kw)
+        add_nested_argument(group, "--%skernel-size" % fp, default=None, type=int, **kw)
+        add_nested_argument(group, "--%spool-module-type" % fp, default='light', type=str, **kw)
+        add_nested_argument(group, "--%smis-type" % fp, default='mis-opt', type=str, **kw)
+        add_nested_argument(group, "--%sproposal-gen" % fp, default='pool', type=str, **kw)
+        add_nested_argument(group, "--%suse-antithetics" % fp, action='store_true', default=False, **kw)
+        add_nested_argument(group, "--%suse-multisample" % fp, action='store_true', default=False, **kw)
+        add_nested_argument(group, "--%salpha-coeff" % fp, default=1.0, type=float, **kw)
+        return parent_parser

@@ -1,0 +1,97 @@
+"""Local (windowed) attention baseline, and the base class of EVA.
+
+Mirrors efficient_attention/local_attention.py:25-194: constructor kwargs, the learned
+relative-position tables (2-D table + `relative_position_index` buffer, 1-D table), the
+overlap rule `ext_size = max(1, window_size // 2)`, and the argparse flags.  The per-window
+softmax(s QK^T + bias, -5e4 mask) V runs in libea_hip.so (ea_window_attn_fwd/bwd with L = 0);
+windows are never materialised.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import add_nested_argument
+from . import _ops
+from .abstract_attention import MultiheadAttention
+
+
+def relative_position_index_2d(window_size, ext_size):
+    """[w*w, (w+2e)^2] int64 index into the 2-D bias table for query (qi,qj) in [0,w)^2 and key
+    (ki,kj) in [-e, w+e)^2: (qi-ki+e+w-1)*(2e+w) + (qj-kj+e+w-1)  (reference :49-62)."""
+    w, e = window_size, ext_size
+    q = torch.arange(w)
+    k = torch.arange(-e, w + e)
+    off = e + w - 1
+    rows = (q.view(w, 1, 1, 1) - k.view(1, 1, -1, 1) + off) * (2 * e + w)
+    cols = q.view(1, w, 1, 1) - k.view(1, 1, 1, -1) + off
+    return (rows + cols).reshape(w * w, (w + 2 * e) ** 2)
+
+
+class LocalAttention(MultiheadAttention):
+    def __init__(self, use_rpe=False, window_size=2, attn_2d=False, overlap_window=False,
+                 *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.window_size = window_size
+        self.attn_2d = attn_2d
+        self.use_rpe = use_rpe if window_size > 0 else False
+        self.ext_size = max(1, window_size // 2) if overlap_window else 0
+        if self.use_rpe:
+            w, e = window_size, self.ext_size
+            if attn_2d:
+                rows = 2 * (w + e - 1) * (2 * e + w + 1) + 1
+                self.local_relative_position_bias_table = nn.Parameter(torch.zeros(rows, self.num_heads))
+                self.register_buffer("relative_position_index", relative_position_index_2d(w, e))
+            else:
+                self.local_relative_position_bias_table = nn.Parameter(
+                    torch.zeros(self.num_heads, w, w + 2 * e))
+            nn.init.trunc_normal_(self.local_relative_position_bias_table, std=.02)
+        self.apply(self._init_weights)
+
+    # ---- dense per-head bias [h, Wq, Wk] handed to the kernel ---------------------------
+    def _table_bias(self):
+        if not self.use_rpe:
+            return None
+        tab = self.local_relative_position_bias_table
+        if not self.attn_2d:
+            return tab
+        idx = self.relative_position_index
+        return tab[idx.reshape(-1)].reshape(idx.shape[0], idx.shape[1], -1).permute(2, 0, 1)
+
+    def add_rel_pos_bias(self, local_dots):
+        """Reference-compatible helper (:70-79): local_dots [b,h,w,i,j] + bias."""
+        return local_dots + self._table_bias().unsqueeze(0).unsqueeze(2)
+
+    def _geometry(self, N, seq_shape):
+        if self.attn_2d:
+            if len(seq_shape) == 2:
+                H, W = seq_shape
+            else:
+                H = W = int(math.sqrt(N))              # reference :142-146
+            assert H * W == N
+            return True, (H, W)
+        return False, (N,)
+
+    def _attend(self, qkv5, key_padding_mask, seq_shape):
+        B, N = qkv5.shape[:2]
+        attn_2d, shape = self._geometry(N, seq_shape)
+        if attn_2d:
+            H = W = int(math.sqrt(N))
+            assert H * W == N, "LocalAttention with attn_2d expects a square grid"
+            assert H % self.window_size == 0
+            shape = (H, W)
+        mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
+        return _ops.LocalAttnFn.apply(qkv5, self._table_bias(), mask, attn_2d, shape,
+                                      self.window_size, self.ext_size)
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        parent_parser = MultiheadAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)
+        group = parent_parser.add_argument_group("Attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        kw = dict(struct_name=struct_name, prefix=prefix)
+        add_nested_argument(group, "--%suse-rpe" % fp, action="store_true", default=False, **kw)
+        add_nested_argument(group, "--%swindow-size" % fp, default=4, type=int, **kw)
+        add_nested_argument(group, "--%sattn-2d" % fp, action="store_true", default=False, **kw)
+        add_nested_argument(group, "--%soverlap-window" % fp, action="store_true", default=False, **kw)
+        return parent_parser

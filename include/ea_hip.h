@@ -1,0 +1,119 @@
+/*
+ * ea_hip.h -- C ABI of libea_hip.so: the MI355X (gfx950) attention hot path of
+ * HKUNLP/efficient-attention.
+ *
+ * The reference has no FFI: its hot path is chains of torch ops inside
+ *   efficient_attention/{abstract_attention,local_attention,eva,lara,kernelized_attention}.py
+ * (SURVEY.md 8a/8b).  Each entry point below replaces one such chain with hand-written HIP
+ * kernels; the citation on every function names the reference lines it replaces.  The host
+ * mirror of the reference's nn.Module / AttentionFactory surface
+ * (efficient-attention_amd/efficient_attention) binds these symbols with ctypes and passes raw
+ * device pointers -- no torch types cross this boundary (INTEGRATION.md shows the binding a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers.  `stream` is a hipStream_t (NULL = default stream).
+ *   - q/k/v/out-like tensors are logical [B, H, N, D] with the last dim contiguous and
+ *     arbitrary ELEMENT strides for the other three (ea_t4), so the [B, N, 3, H, D] output of
+ *     the fused qkv Linear and the [B, N, H, D] input of the output projection are addressed
+ *     in place (no permute/contiguous copies: abstract_attention.py:72-78,86).
+ *   - I/O element type: EA_BF16 or EA_F16 (ea_geom.dtype).  MFMA operands have that type,
+ *     accumulation / softmax / statistics are fp32 (the autocast contract of vit/engine.py:47).
+ *   - key_padding_mask: uint8 [B, N], 1 = padded key, or NULL.
+ *   - Every function returns 0 on success, a negative EA_E* code on invalid arguments or
+ *     unsupported geometry, or a positive hipError_t from the launch.  Nothing is ever
+ *     computed on the host.
+ */
+#ifndef EA_HIP_H
+#define EA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EA_BF16 0
+#define EA_F16  1
+
+#define EA_OK            0
+#define EA_E_BADARG     -1   /* null pointer / inconsistent sizes */
+#define EA_E_UNSUPPORTED -2  /* geometry outside what the kernels are built for */
+
+/* logical [B,H,N,D] tensor, D contiguous */
+typedef struct {
+  void*   ptr;
+  int64_t sb, sh, sn;        /* element strides of batch, head, token */
+} ea_t4;
+
+/* Window / landmark geometry shared by the local, EVA and LARA entry points. */
+typedef struct {
+  int32_t B, H, N, D;        /* N = tokens per (b,h) AFTER EVA's 1-D padding (eva.py:127-136) */
+  int32_t dtype;             /* EA_BF16 | EA_F16 */
+  int32_t attn_2d;           /* 1: tokens form a gh x gw grid (row-major), 0: 1-D sequence */
+  int32_t gh, gw;            /* grid (2-D); ignored in 1-D */
+  int32_t window;            /* window side w (local_attention.py:36) */
+  int32_t ext;               /* overlap extension e = max(1, w/2) or 0 (local_attention.py:38-41) */
+  int32_t chunk;             /* EVA landmark chunk side r (eva.py:155-158); 0 when unused */
+  int32_t L;                 /* number of landmarks / chunks actually produced */
+  float   scale;             /* D^-0.5 */
+} ea_geom;
+
+/* ---- library info -------------------------------------------------------------------- */
+const char* ea_version(void);                 /* "ea_hip <semver> gfx950" */
+int32_t     ea_abi_version(void);             /* bumped on any signature change */
+
+/* ---- EVA landmark statistics (eva.py:155-196) ------------------------------------------
+ * ea_eva_chunk_mean_fwd: masked means of q and k over every landmark chunk (chunk side r,
+ *   same overlap extension e as the windows; masked/out-of-range slots count as zeros in the
+ *   mean: rf_w_q.masked_fill(...).mean(-2), eva.py:174-180).  qmean,kmean: fp32 [B,H,L,D].
+ * ea_eva_chunk_mean_bwd: dq[b,h,n,:] += sum_{c ni n} dqmean[c]/J (same for k); dq/dk are
+ *   ACCUMULATED INTO (I/O dtype, fp32 math).
+ * ea_eva_beta_fwd: beta_c = sum_j softmax_j(s*omega_c.k_j - s|k_j|^2/2, -5e4 on masked) v_j
+ *   (prm_projection normalize=False, attn_utils.py:324-347; eva.py:192-196). omega, beta: fp32
+ *   [B,H,L,D].
+ * ea_eva_beta_bwd: given dbeta, ACCUMULATES dk, dv and writes domega (fp32 [B,H,L,D]). */
+int ea_eva_chunk_mean_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const uint8_t* mask,
+                          float* qmean, float* kmean, void* stream);
+int ea_eva_chunk_mean_bwd(const ea_geom* g, const float* dqmean, const float* dkmean,
+                          const uint8_t* mask, const ea_t4* dq, const ea_t4* dk, void* stream);
+int ea_eva_beta_fwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* omega, float* beta, void* stream);
+int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* omega, const float* beta, const float* dbeta,
+                    const ea_t4* dk, const ea_t4* dv, float* domega, void* stream);
+
+/* ---- window attention with control-variate columns -----------------------------------------
+ * One joint softmax per query over [ local window keys | L landmark keys ]:
+ *     logits_local = s q.k_j + bias[h,i,j], masked_fill(-5e4)   (eva.py:204-218,
+ *                                                                local_attention.py:159-170)
+ *     logits_cv    = s q.lk_c                                    (eva.py:200)
+ *     out = P_local V_window + P_cv lv                           (eva.py:222-227)
+ * With L == 0 this is LocalAttention._apply_attention (local_attention.py:134-182).
+ *   lk, lv : fp32 [B,H,L,D] (rf_k_bar and beta), may be NULL iff L == 0
+ *   bias   : fp32 [H, Wq, ea_window_bias_ld(g)] dense per-head bias (rows padded), or NULL
+ *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward
+ * Backward consumes the forward's out, lse and dout and produces dq, dk, dv (WRITTEN, not
+ * accumulated).  With overlapping windows (ext > 0) a token is a key of several windows: the
+ * caller then passes two fp32 scratch buffers dk_acc, dv_acc of [B,H,N,D] (zeroed inside) that
+ * take the atomics before the result is converted into dk/dv; they may be NULL when ext == 0.
+ * The landmark and bias gradients come back as per-workgroup partial sums which the caller
+ * reduces over the leading axes:
+ *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
+ *   dbias_part         : fp32 [ea_window_bwd_parts(g), B, H, Wq, ld]   (NULL iff bias NULL) */
+int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
+int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
+int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                       const float* lk, const float* lv, const float* bias, const uint8_t* mask,
+                       const ea_t4* out, float* lse, void* stream);
+int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                       const float* lk, const float* lv, const float* bias, const uint8_t* mask,
+                       const ea_t4* out, const ea_t4* dout, const float* lse,
+                       const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
+                       float* dlk_part, float* dlv_part, float* dbias_part,
+                       float* dk_acc, float* dv_acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EA_HIP_H */

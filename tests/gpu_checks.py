@@ -1,0 +1,92 @@
+"""GPU-side parity helpers shared by the -m gpu tests and __graft_entry__.smoke().
+
+Module-level check: the product nn.Module (HIP cores, bf16 autocast like the reference's AMP
+recipe) vs the golden vectors of the fp32 reference; core-level checks compare a HIP core with
+the oracle evaluated in fp64 on the same bf16-rounded inputs.
+
+Stated tolerances (bf16 operands, fp32 accumulation):
+  module level vs fp32 golden : max|err| <= 4e-2 * max|ref|  and  rms(err) <= 2e-2 * rms(ref)
+  core level vs fp64 oracle   : max|err| <= 2e-2 * max|ref|  and  rms(err) <= 1e-2 * rms(ref)
+"""
+import contextlib
+import warnings
+
+import numpy as np
+import torch
+
+import cases
+from util import Fixture, scaled_err
+
+MODULE_TOL = (4e-2, 2e-2)
+CORE_TOL = (2e-2, 1e-2)
+
+
+@contextlib.contextmanager
+def injected_noise(fx, mode, device):
+    """Route torch.randn / torch.randn_like to the fixture's noise streams during a forward."""
+    calls = []
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def randn(*size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            size = tuple(size[0])
+        arr = cases.make_noise(fx.name, tuple(size), len(calls))
+        calls.append(tuple(size))
+        return torch.from_numpy(arr).to(device=kw.get("device", device), dtype=kw.get("dtype") or torch.float32)
+
+    def randn_like(t, **kw):
+        arr = cases.make_noise(fx.name, tuple(t.shape), len(calls))
+        calls.append(tuple(t.shape))
+        return torch.from_numpy(arr).to(device=t.device, dtype=t.dtype)
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        yield calls
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+def build_module(fx, device="cuda"):
+    import efficient_attention as ea
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod = ea.AttentionFactory.build_attention(fx.case["attn"], dict(fx.case["args"]))
+    sd = mod.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == fx.key_shapes
+    new = {k: (torch.from_numpy(fx.params_np[k]) if k in fx.params_np else v) for k, v in sd.items()}
+    mod.load_state_dict(new, strict=True)
+    return mod.to(device)
+
+
+def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=MODULE_TOL):
+    fx = Fixture(name)
+    mod = build_module(fx)
+    mod.train(mode == "train")
+    x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)
+    mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np).cuda()
+    with injected_noise(fx, mode, "cuda") as calls:
+        with torch.autocast("cuda", dtype=dtype):
+            y = mod(x, mask) if mask is not None else mod(x)
+    assert calls == fx.expected_noise_shapes(mode), (calls, fx.expected_noise_shapes(mode))
+    assert y.shape == x.shape and y.dtype in (dtype, torch.float32)
+    errs = {"y": scaled_err(y.detach().float().cpu().numpy(), fx.y(mode))}
+    if backward:
+        (y.float() * torch.from_numpy(fx.g_np).cuda()).sum().backward()
+        errs["dx"] = scaled_err(x.grad.float().cpu().numpy(), fx.dx(mode))
+        for key, p in mod.named_parameters():
+            pre = "%s.grad.%s" % (mode, key)
+            if pre in fx.z.files:
+                ref = fx.z[pre]
+                got = np.zeros_like(ref) if p.grad is None else p.grad.float().cpu().numpy()
+                if np.abs(ref).max() > 0:
+                    errs["d" + key] = scaled_err(got, ref)
+                else:
+                    assert np.abs(got).max() == 0, key
+            else:
+                idx = cases.grad_sample_index(name, key, p.numel())
+                ref = fx.z[pre + ".sample"]
+                got = p.grad.float().cpu().numpy().reshape(-1)[idx]
+                errs["d" + key] = scaled_err(got, ref)
+    bad = {k: v for k, v in errs.items() if not (v[0] <= tol[0] and v[1] <= tol[1])}
+    assert not bad, "%s/%s out of tolerance %s: %s (all: %s)" % (name, mode, tol, bad, errs)
+    return errs

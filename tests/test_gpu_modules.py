@@ -1,0 +1,16 @@
+"""-m gpu: product modules (HIP cores through the C ABI, bf16 autocast) vs the golden vectors
+of the fp32 reference, forward and backward, eval and training mode (injected noise)."""
+import pytest
+
+import cases
+from gpu_checks import check_module_case
+
+READY = ("eva_", "local_")       # variants whose HIP cores have landed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", cases.MODES)
+@pytest.mark.parametrize("name", [n for n in cases.CASES if n.startswith(READY)])
+def test_module_matches_reference(name, mode):
+    errs = check_module_case(name, mode)
+    print(name, mode, {k: "%.2e/%.2e" % v for k, v in errs.items()})
