@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- attention-layer forward+backward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: x -> attention layer (qkv
+projection, HIP attention core, output projection) -> loss -> backward -> SGD step, under bf16
+autocast, one process per GPU; with N > 1 the layer is wrapped in DistributedDataParallel (RCCL
+all-reduce of the parameter gradients over xGMI, weak scaling: fixed per-GPU batch).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Default workload (config.workload): BASELINE.json configs[2] geometry, the one the metric is
+quoted on -- DeiT-tiny-p8 tokens (N = 28x28 = 784, 3 heads, d = 64), per-GPU batch 128.
+`--attn eva|lara|softmax|local|performer` selects the attention (default: see DEFAULT_ATTN).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "efficient-attention_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+DEFAULT_ATTN = "lara"
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv) at d=64, bf16
+
+
+def attn_args(attn, dim, heads, grid):
+    base = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0)
+    if attn == "eva":
+        base.update(window_size=7, attn_2d=True, use_rpe=True, num_landmarks=49, adaptive_proj="default")
+    elif attn == "local":
+        base.update(window_size=7, attn_2d=True, use_rpe=True)
+    elif attn == "lara":
+        base.update(num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)
+    elif attn == "performer":
+        base.update(approx_attn_dim=64, proj_method="favorp")
+    return base
+
+
+def build_layer(attn, dim, heads, grid, device):
+    import efficient_attention as ea
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, grid)).to(device)
+
+
+def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
+    """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on
+    a bounded sample of the same workload: same layer and token geometry, batch 8, fp32,
+    forward + backward, as many iterations as fit in ~budget_s."""
+    import oracle
+    torch.manual_seed(1234)
+    B = 8
+    layer = build_layer(attn, dim, heads, grid, "cpu")
+    params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
+    args = attn_args(attn, dim, heads, grid)
+    x = torch.randn(B, grid, grid, dim, requires_grad=True)
+    g = torch.randn(B, grid, grid, dim)
+    noise_fn = lambda shape: torch.randn(*shape)  # noqa: E731
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn)
+        (y * g).sum().backward()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    tok_s = n * B * grid * grid / el
+    return {"value": tok_s, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d x fwd+bwd of the oracle layer (%s, fp32) at batch %d, N=%d, dim %d" % (n, attn, B, grid * grid, dim)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--attn", default=DEFAULT_ATTN)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--grid", type=int, default=28, help="token grid side (28 -> N=784)")
+    ap.add_argument("--dim", type=int, default=192)
+    ap.add_argument("--heads", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank)
+
+    B, G, C, H = a.batch, a.grid, a.dim, a.heads
+    N, d = G * G, a.dim // a.heads
+    layer = build_layer(a.attn, C, H, G, dev)
+    layer.train()
+    model = layer
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local])
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-3)
+    x = torch.randn(B, G, G, C, device=dev, requires_grad=True)
+    g = torch.randn(B, G, G, C, device=dev)
+
+    from efficient_attention import _ops
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = model(x)
+        (y.float() * g).sum().backward()
+        opt.step()
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not a.no_graph and world == 1:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as ex:  # capture is an optimisation, never a requirement
+            if rank == 0:
+                print("graph capture unavailable (%s); timing eager" % str(ex).split("\n")[0], file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(a.warmup):
+        run()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # ---- instrumented eager pass: HIP events around every launch of the dominant kernel ----
+    _ops.KERNEL_TIMER.enable()
+    for _ in range(min(a.steps, 10)):
+        step()
+    torch.cuda.synchronize()
+    ktimes = _ops.KERNEL_TIMER.summary()
+    _ops.KERNEL_TIMER.disable()
+
+    if rank == 0:
+        tokens = B * N * world * a.steps
+        value = tokens / el
+        dom = max(ktimes.items(), key=lambda kv: kv[1]["total_ms"]) if ktimes else (None, None)
+        roof = None
+        if dom[0] is not None:
+            name, st = dom
+            units = _ops.KERNEL_ALGO_UNITS.get(name, 0)      # [B,H,N,D] tensors read+written per launch
+            algo_bytes = units * B * H * N * d * 2
+            ach = algo_bytes / (st["avg_ms"] * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.attn)
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get(name)
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
+                    "algo_bytes_per_launch": algo_bytes,
+                    "all_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}}
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(a.attn, C, H, G)
+        line = {
+            "metric": "attn fwd+bwd tokens/s per GPU at N=784, d=64; 1/2/4/8-GPU DDP scaling",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s attention layer fwd+bwd+SGD, x=[%d,%d,%d,%d] per GPU (N=%d, h=%d, d=%d), "
+                                   "bf16 autocast%s" % (a.attn, B, G, G, C, N, H, d, ", DDP" if world > 1 else ""),
+                       "attn": a.attn, "global_batch": B * world, "seq_len": N, "heads": H, "head_dim": d,
+                       "parallelism": "dp%d" % world, "hipgraph": graph is not None},
+            "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

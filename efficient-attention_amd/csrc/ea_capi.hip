@@ -8,6 +8,11 @@ int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st);
 int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStream_t st);
 }  // namespace ea
 #include "ea_landmark_params.h"
+#include "ea_lara.h"
+namespace ea {
+int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
+int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
+}
 
 using namespace ea;
 
@@ -147,6 +152,145 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
   SET3(k, k); SET3(v, v); SET3(dk, dk); SET3(dv, dv);
   p.mask = mask; p.omega = omega; p.beta = beta; p.dbeta = dbeta; p.domega = domega;
   return landmark_dispatch(3, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- LARA ----
+static T4l mkl(const ea_t4* t) {
+  T4l r;
+  r.p = t ? (char*)t->ptr : nullptr;
+  r.sb = t ? t->sb : 0; r.sh = t ? t->sh : 0; r.sn = t ? t->sn : 0;
+  return r;
+}
+static int lara_nsub(int NCT) { return NCT == 1 ? 4 : (NCT == 2 ? 2 : 1); }
+// X passes: blocks per (b,h) and tokens per block; Y passes: sequence splits
+static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->N <= 0 || (g->D != 32 && g->D != 64) || g->C <= 0 ||
+      (g->dtype != EA_BF16 && g->dtype != EA_F16) || g->mis < 0 || g->mis > 2) return EA_E_BADARG;
+  if (g->C > 128) return EA_E_UNSUPPORTED;
+  p.B = g->B; p.H = g->H; p.N = g->N; p.D = g->D; p.C = g->C; p.NCT = (g->C + 15) / 16;
+  p.mis = g->mis; p.kappa = g->kappa; p.scale = g->scale; p.scale_log2 = g->scale * LOG2E;
+  const long bh = (long)g->B * g->H;
+  const int gran = ypass ? 32 * lara_nsub(p.NCT) : 64;
+  const int maxblk = (g->N + gran - 1) / gran;
+  int nblk = (int)((2048 + bh - 1) / bh);
+  if (nblk < 1) nblk = 1;
+  if (nblk > maxblk) nblk = maxblk;
+  int tpb = (g->N + nblk - 1) / nblk;
+  tpb = (tpb + gran - 1) / gran * gran;
+  p.tok_per_block = tpb;
+  p.nsplit = (g->N + tpb - 1) / tpb;
+  return EA_OK;
+}
+
+extern "C" {
+
+int32_t ea_lara_parts(const ea_lara_geom* g) {
+  LaraP p = {};
+  if (fill_lara(g, p, true) != EA_OK) return EA_E_BADARG;
+  return p.nsplit * lara_nsub(p.NCT);
+}
+
+int ea_lara_stats_fwd(const ea_lara_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                      const uint8_t* mask, const float* omega, const float* qbar,
+                      float* p_ml, float* p_kv, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !omega || !p_ml || !p_kv ||
+      (g->mis == EA_MIS_OPT && !qbar)) return EA_E_BADARG;
+  p.q = mkl(q); p.k = mkl(k); p.v = mkl(v); p.mask = mask; p.omega = omega; p.qbar = qbar;
+  p.p_ml = p_ml; p.p_acc0 = p_kv;
+  return lara_y_dispatch(LY_FWD, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_out_fwd(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar,
+                    const float* kv, const float* lse_t, const float* bhv, const float* cst,
+                    const ea_t4* out, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(out, g->D) || !omega || !kv || !cst) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  p.q = mkl(q); p.o = mkl(out); p.omega = omega; p.qbar = qbar; p.kv = kv; p.lse_t = lse_t;
+  p.bhv = bhv; p.cst = cst;
+  return lara_x_dispatch(LX_FWD, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_q(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                  const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                  const float* cst, const ea_t4* dq, float* lseZ, float* tmean, float* rowdot,
+                  float* sda, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(dout, g->D) || !t4_ok(dq, g->D) || !omega || !kv || !cst ||
+      !lseZ || !tmean || !rowdot || !sda) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  p.q = mkl(q); p.dout = mkl(dout); p.dq = mkl(dq); p.omega = omega; p.qbar = qbar; p.kv = kv;
+  p.lse_t = lse_t; p.bhv = bhv; p.cst = cst;
+  p.lseZ = lseZ; p.tmean = tmean; p.rowdot = rowdot; p.sda = sda;
+  return lara_x_dispatch(LX_BWDQ, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_qstats(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                       const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                       const float* cst, const float* lseZ, const float* tmean, const float* rowdot,
+                       const float* sda, float* p_ml, float* p_dkv, float* p_dom, float* p_m1,
+                       float* p_m2, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(dout, g->D) || !omega || !kv || !cst || !lseZ || !tmean ||
+      !rowdot || !sda || !p_ml || !p_dkv || !p_dom) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv || !p_m1 || !p_m2)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  p.q = mkl(q); p.dout = mkl(dout); p.omega = omega; p.qbar = qbar; p.kv = kv; p.lse_t = lse_t;
+  p.bhv = bhv; p.cst = cst;
+  p.lseZ = const_cast<float*>(lseZ); p.tmean = const_cast<float*>(tmean);
+  p.rowdot = const_cast<float*>(rowdot); p.sda = const_cast<float*>(sda);
+  p.p_ml = p_ml; p.p_acc0 = p_dkv; p.p_acc1 = p_dom; p.p_acc2 = p_m1; p.p_acc3 = p_m2;
+  return lara_y_dispatch(LY_BWDQ, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_k(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                  const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                  const float* rsum, const ea_t4* dk, const ea_t4* dv, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !omega ||
+      !dkv || !lse_k || !dkk || !rsum) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.dk = mkl(dk); p.dv = mkl(dv); p.mask = mask; p.omega = omega;
+  p.dkv = dkv; p.lse_k = lse_k; p.dkk = dkk; p.rsum = rsum;
+  return lara_x_dispatch(LX_BWDK, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_kstats(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                       const float* rsum, float* p_dom, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !omega || !dkv || !lse_k || !dkk || !rsum || !p_dom)
+    return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.mask = mask; p.omega = omega; p.dkv = dkv; p.lse_k = lse_k;
+  p.dkk = dkk; p.rsum = rsum; p.p_acc0 = p_dom;
+  return lara_y_dispatch(LY_BWDK, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
+                      const float* lse_t, const ea_t4* dq, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (g->mis != EA_MIS_OPT) return EA_E_BADARG;
+  if (!t4_ok(q, g->D) || !t4_ok(dq, g->D) || !qbar || !uq || !lse_t) return EA_E_BADARG;
+  p.q = mkl(q); p.dq = mkl(dq); p.qbar = qbar; p.uq = uq; p.lse_t = lse_t;
+  return lara_x_dispatch(LX_QCORR, p, g->dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,64 @@
+// ea_lara.h -- parameter block and shared device code of the LARA kernels.
+//
+// LARA (lara.py:177-251) couples every token n with C <= 128 landmark samples c through
+// [C x N] score matrices.  Two register layouts cover all of its passes:
+//   X ("token-column", ea_lara_x.hip): MFMA tiles D[c = 4g+r][n = li].  Reductions and
+//      contractions over c are in-lane / 4-lane, so this layout produces per-token results:
+//      the forward combine out_n = sum_c W[c,n] kv_c, dq, dk, dv.
+//   Y ("token-row", ea_lara_y.hip): MFMA tiles D[n = 4g+r][c = li].  Reductions and
+//      contractions over n are in-lane / 4-lane and accumulate across the whole sequence, so
+//      this layout produces per-landmark results: kv_stats / LSE_k / LSE_t in the forward and
+//      d(kv_stats), d(omega), d(q_bar) and the scalar sums in the backward.
+// Natural-log quantities are carried in the log2 domain inside the kernels (suffix 2).
+#pragma once
+#include "ea_common.h"
+
+namespace ea {
+
+struct T4l {
+  char* p;
+  int64_t sb, sh, sn;
+};
+
+enum { MIS_OPT = 0, MIS_BIASED = 1, MIS_BH = 2 };
+enum { LX_FWD = 0, LX_BWDQ = 1, LX_BWDK = 2, LX_QCORR = 3 };
+enum { LY_FWD = 0, LY_BWDQ = 1, LY_BWDK = 2 };
+
+struct LaraP {
+  T4l q, k, v, o, dout, dq, dk, dv;
+  const uint8_t* mask;          // [B,N] key padding mask or null
+  // landmark-side matrices, fp32 [BH, C, D]
+  const float *omega, *qbar, *kv, *dkv, *uq;
+  // per-landmark scalars, fp32 [BH, C] (natural log units)
+  const float *lse_k, *lse_t, *bhv, *cst, *dkk, *rsum;
+  // per-token scalars, fp32 [BH, N]
+  float *lseZ, *tmean, *rowdot, *sda;
+  // Y-pass partial outputs: [BH, nsplit, C, *]
+  float *p_ml;                  // FWD: [.., C, 4] = (m_k, l_k, m_t, l_t) ; BWDQ: (r, dbh, u, 0)
+  float *p_acc0, *p_acc1, *p_acc2, *p_acc3;   // [.., C, D]: FWD kv ; BWDQ dkv, domega, M1, M2 ; BWDK domega
+  int B, H, N, D, C, NCT;       // NCT = 16-landmark tiles (C padded to NCT*16)
+  int mis;                      // MIS_*
+  int nsplit;                   // Y: sequence splits per (b,h); X: blocks per (b,h)
+  int tok_per_block;            // tokens handled by one block (multiple of 64)
+  float kappa, scale, scale_log2;
+};
+
+// ---- the elementwise core of the estimator (lara.py:221-243), one (c, n) entry -------------
+// inputs in the log2 domain: A2 = s*log2e*omega_c.q_n, T2 = s*log2e*qbar_c.q_n
+struct LaraElem {
+  float t, alpha, la2;
+};
+EA_DEV LaraElem lara_alpha(int mis, float T2, float lse_t2, float bh, float kappa, float tmean) {
+  LaraElem e;
+  e.t = 0.f; e.alpha = 1.f; e.la2 = 0.f;
+  if (mis == MIS_OPT) {
+    e.t = fast_exp2(T2 - lse_t2);
+    e.alpha = bh + kappa * (e.t - tmean);
+    e.la2 = fast_log2(fmaxf(e.alpha, 1e-8f));
+  } else if (mis == MIS_BIASED) {
+    e.la2 = T2;
+  }
+  return e;
+}
+
+}  // namespace ea

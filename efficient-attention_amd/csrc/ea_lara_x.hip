@@ -1,0 +1,391 @@
+// ea_lara_x.hip -- LARA passes in the token-column layout (see ea_lara.h).
+//
+//   LX_FWD   out_n = sum_c W[c,n] kv_c,  W = softmax_c(log alpha + s w_c.q_n + lse_k - log_prop)
+//            (lara.py:201,221-246; the -s|q_n|^2/2 term of log_proj_q is constant in c and cancels)
+//   LX_BWDQ  recomputes W, forms dZ / d(alpha) / dt and writes the part of dq that needs no
+//            sequence-wide sum, plus the per-token scalars (lse_Z, mean_c t, dout.out, sum_c dalpha)
+//            the token-row pass needs
+//   LX_BWDK  dk, dv from Pk = softmax_m(log_proj_k) recomputed with the saved lse_k
+//   LX_QCORR dq -= s sum_c t[c,n] (u_c qbar_c): the softmax-over-sequence correction of t
+// One 16-token tile per wave step: token rows come straight from global memory as MFMA B
+// operands; the landmark matrices live in LDS (row-major for the score MFMAs, transposed for
+// the contraction over c); each lane ends up owning D/4 contiguous channels of one token.
+#include "ea_lara.h"
+
+namespace ea {
+
+template <int D> struct LxCfg {
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+};
+
+// stage fp32 [C][D] -> LDS [Cp][D] element-type rows (swizzled), zero rows beyond C
+template <typename E, int D>
+EA_DEV void stage_rows(char* dst, const float* src, int C, int Cp, int tid) {
+  constexpr int CPR = D / 8;
+  for (int idx = tid; idx < Cp * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (row < C) {
+      float f[8];
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
+      w = pack8<E>(f);
+    }
+    sts16(dst + lds_off<D>(row, c), w);
+  }
+}
+// stage fp32 [C][D] -> LDS transposed [D][Cp + 4] element type, zero columns beyond C
+template <typename E, int D>
+EA_DEV void stage_cols(char* dst, const float* src, int C, int Cp, int tid) {
+  constexpr int CPR = D / 8;
+  const int ld = Cp + 4;
+  for (int idx = tid; idx < Cp * CPR; idx += 256) {
+    const int row = idx / CPR, c = idx - row * CPR;
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    if (row < C) {
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
+    }
+    uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d16[(c * 8 + i) * ld + row] = E::from_f(f[i]);
+  }
+}
+
+template <typename E, int D, int NCT, int MODE>
+__global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
+  using Cfg = LxCfg<D>;
+  constexpr int ROWB = Cfg::ROWB, KS = Cfg::KS, DT = Cfg::DT, DQ = Cfg::DQ;
+  constexpr int Cp = NCT * 16;
+  constexpr int MT_LDB = (Cp + 4) * 2;             // bytes per row of a transposed matrix
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R1 = smem;                                  // omega rows
+  char* R2 = R1 + Cp * ROWB;                        // qbar rows
+  char* R3 = R2 + Cp * ROWB;                        // kv / dkv rows
+  char* M1 = R3 + Cp * ROWB;
+  char* M2 = M1 + D * MT_LDB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.x / p.nsplit, blk = blockIdx.x - bh * p.nsplit;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const size_t lm = (size_t)bh * p.C;               // landmark row offset
+  const bool use_t = p.mis != MIS_BH;
+
+  if (MODE != LX_QCORR) stage_rows<E, D>(R1, p.omega + lm * D, p.C, Cp, tid);
+  if (MODE != LX_BWDK && use_t) stage_rows<E, D>(R2, p.qbar + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDQ) stage_rows<E, D>(R3, p.kv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDK) stage_rows<E, D>(R3, p.dkv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_FWD) stage_cols<E, D>(M1, p.kv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDQ) {
+    stage_cols<E, D>(M1, p.omega + lm * D, p.C, Cp, tid);
+    if (use_t) stage_cols<E, D>(M2, p.qbar + lm * D, p.C, Cp, tid);
+  }
+  if (MODE == LX_BWDK) {
+    stage_cols<E, D>(M1, p.dkv + lm * D, p.C, Cp, tid);
+    stage_cols<E, D>(M2, p.omega + lm * D, p.C, Cp, tid);
+  }
+  if (MODE == LX_QCORR) stage_cols<E, D>(M1, p.uq + lm * D, p.C, Cp, tid);
+
+  // per-landmark scalars of this lane's rows c = 16 ct + 4 g + r
+  float cst2[NCT][4], lset2[NCT][4], bhv[NCT][4], lsek2[NCT][4], dkk[NCT][4], rs[NCT][4];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = ct * 16 + 4 * g + r;
+      const bool ok = c < p.C;
+      cst2[ct][r] = -INFINITY; lset2[ct][r] = INFINITY; bhv[ct][r] = 1.f;
+      lsek2[ct][r] = INFINITY; dkk[ct][r] = 0.f; rs[ct][r] = 0.f;
+      if (ok) {
+        if (MODE == LX_FWD || MODE == LX_BWDQ) {
+          cst2[ct][r] = p.cst[lm + c] * LOG2E;
+          if (p.mis == MIS_OPT) bhv[ct][r] = p.bhv[lm + c];
+        }
+        if (MODE != LX_BWDK && p.mis == MIS_OPT) lset2[ct][r] = p.lse_t[lm + c] * LOG2E;
+        if (MODE == LX_BWDK) {
+          lsek2[ct][r] = p.lse_k[lm + c] * LOG2E;
+          dkk[ct][r] = p.dkk[lm + c];
+          rs[ct][r] = p.rsum[lm + c];
+        }
+      }
+    }
+  __syncthreads();
+
+  const T4l& tk1 = (MODE == LX_BWDK) ? p.k : p.q;
+  const char* t1b = tk1.p + (b * tk1.sb + h * tk1.sh) * 2;
+  const T4l& tk2 = (MODE == LX_BWDK) ? p.v : p.dout;
+  const char* t2b = tk2.p ? tk2.p + (b * tk2.sb + h * tk2.sh) * 2 : nullptr;
+  const float invC = 1.f / (float)p.C;
+  const int n0 = blk * p.tok_per_block;
+  const int n1 = min(p.N, n0 + p.tok_per_block);
+
+  for (int tile = wave; n0 + tile * 16 < n1; tile += 4) {
+    const int tok = n0 + tile * 16 + li;
+    const bool valid = tok < n1;
+    typename E::x8 f1[KS], f2[KS];
+    u32x4 raw1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 w1 = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
+      if (valid) {
+        w1 = ldg16(t1b + (tok * tk1.sn + (g * KS + ks) * 8) * 2);
+        if (MODE == LX_BWDQ || MODE == LX_BWDK) w2 = ldg16(t2b + (tok * tk2.sn + (g * KS + ks) * 8) * 2);
+      }
+      raw1[ks] = w1;
+      f1[ks] = as_x8<E>(w1);
+      f2[ks] = as_x8<E>(w2);
+    }
+    // ---- score tiles ----
+    f32x4 a[NCT], tt[NCT], dw[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      a[ct] = tt[ct] = dw[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = ct * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (MODE != LX_QCORR) a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
+        if (MODE != LX_BWDK && use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt[ct]);
+        if (MODE == LX_BWDQ || MODE == LX_BWDK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+      }
+    }
+    // ---- elementwise stage -> weight tiles w1 (x M1) and w2 (x M2) ----
+    float w1[NCT][4], w2[NCT][4];
+    float sdb = 0.f;
+    if (MODE == LX_FWD || MODE == LX_BWDQ) {
+      float tl = 0.f;
+      if (p.mis == MIS_OPT) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tl += fast_exp2(tt[ct][r] * p.scale_log2 - lset2[ct][r]);
+      }
+      const float tmean = quad_sum(tl) * invC;
+      float z2[NCT][4], tv[NCT][4], al[NCT][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const LaraElem e = lara_alpha(p.mis, tt[ct][r] * p.scale_log2, lset2[ct][r], bhv[ct][r], p.kappa, tmean);
+          tv[ct][r] = e.t; al[ct][r] = e.alpha;
+          z2[ct][r] = a[ct][r] * p.scale_log2 + e.la2 + cst2[ct][r];
+          mx = fmaxf(mx, z2[ct][r]);
+        }
+      mx = quad_max(mx);
+      float ssum = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z2[ct][r] = fast_exp2(z2[ct][r] - mx); ssum += z2[ct][r]; }
+      ssum = quad_sum(ssum);
+      const float inv = 1.f / ssum;
+      if (MODE == LX_FWD) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w1[ct][r] = z2[ct][r] * inv;
+      } else {
+        float rd = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { z2[ct][r] *= inv; rd += z2[ct][r] * dw[ct][r]; }
+        rd = quad_sum(rd);                                   // = dout_n . out_n
+        float sda = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = z2[ct][r] * (dw[ct][r] - rd);
+            w1[ct][r] = dz;
+            float da = 0.f;
+            if (p.mis == MIS_OPT) da = al[ct][r] > 1e-8f ? dz / al[ct][r] : 0.f;
+            w2[ct][r] = da;
+            sda += da;
+          }
+        sda = quad_sum(sda);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (p.mis == MIS_OPT) w2[ct][r] = tv[ct][r] * p.kappa * (w2[ct][r] - sda * invC);   // t * dt
+            else if (p.mis == MIS_BIASED) w2[ct][r] = w1[ct][r];                                  // dT = dZ
+          }
+        if (valid && g == 0) {
+          const size_t o = (size_t)bh * p.N + tok;
+          p.lseZ[o] = mx + fast_log2(ssum);
+          p.tmean[o] = tmean;
+          p.rowdot[o] = rd;
+          p.sda[o] = sda;
+        }
+      }
+    } else if (MODE == LX_QCORR) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w1[ct][r] = fast_exp2(tt[ct][r] * p.scale_log2 - lset2[ct][r]);
+    } else {   // LX_BWDK
+      float nrm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float kf[8];
+        unpack8<E>(raw1[ks], kf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nrm += kf[i] * kf[i];
+      }
+      nrm = quad_sum(nrm);
+      const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + (valid ? tok : 0)]);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bk2 = a[ct][r] * p.scale_log2 - 0.5f * p.scale_log2 * nrm;
+          const float pk = dead ? 0.f : fast_exp2(bk2 - lsek2[ct][r]);
+          const float db = pk * (dw[ct][r] - dkk[ct][r] + rs[ct][r]);
+          w1[ct][r] = pk;
+          w2[ct][r] = db;
+          sdb += db;
+        }
+      sdb = quad_sum(sdb);
+    }
+    // ---- contraction over c: out^T[d][n] = M1^T . w1 (+ M2^T . w2) ----
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc2[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool two = (MODE == LX_BWDK) || (MODE == LX_BWDQ && use_t);
+#pragma unroll
+    for (int kk = 0; kk < NCT / 2; ++kk) {
+      u32x4 p1, p2;
+      p1[0] = pack2<E>(w1[2 * kk][0], w1[2 * kk][1]); p1[1] = pack2<E>(w1[2 * kk][2], w1[2 * kk][3]);
+      p1[2] = pack2<E>(w1[2 * kk + 1][0], w1[2 * kk + 1][1]); p1[3] = pack2<E>(w1[2 * kk + 1][2], w1[2 * kk + 1][3]);
+      if (two) {
+        p2[0] = pack2<E>(w2[2 * kk][0], w2[2 * kk][1]); p2[1] = pack2<E>(w2[2 * kk][2], w2[2 * kk][3]);
+        p2[2] = pack2<E>(w2[2 * kk + 1][0], w2[2 * kk + 1][1]); p2[3] = pack2<E>(w2[2 * kk + 1][2], w2[2 * kk + 1][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int drow = DQ * (li >> 2) + 4 * dt + (li & 3);
+        const int c0 = (32 * kk + 4 * g) * 2;
+        const char* r1 = M1 + drow * MT_LDB;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(r1 + c0);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(r1 + c0 + 32);
+        acc[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(p1), acc[dt]);
+        if (two) {
+          const char* r2 = M2 + drow * MT_LDB;
+          const u32x2 lo2 = *reinterpret_cast<const u32x2*>(r2 + c0);
+          const u32x2 hi2 = *reinterpret_cast<const u32x2*>(r2 + c0 + 32);
+          if (MODE == LX_BWDK) acc2[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc2[dt]);
+          else acc[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc[dt]);
+        }
+      }
+    }
+    if (!valid) continue;
+    // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` ----
+    float f[DQ];
+    if (MODE == LX_FWD) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
+      char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    } else if (MODE == LX_BWDQ) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
+      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    } else if (MODE == LX_QCORR) {
+      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) {
+        float old[8];
+        unpack8<E>(ldg16(dst + c * 16), old);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = 8 * c + i;
+          old[i] -= acc[j >> 2][j & 3] * p.scale;
+        }
+        stg16(dst + c * 16, pack8<E>(old));
+      }
+    } else {   // LX_BWDK: dv = acc, dk = s (acc2 - k * sdb)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
+      char* dstv = p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
+      char* dstk = p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + DQ * g) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float kf[8], o8[8];
+        unpack8<E>(raw1[ks], kf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = 8 * ks + i;
+          o8[i] = p.scale * (acc2[j >> 2][j & 3] - kf[i] * sdb);
+        }
+        stg16(dstk + ks * 16, pack8<E>(o8));
+      }
+    }
+  }
+}
+
+size_t lara_x_lds(int D, int NCT) {
+  const int Cp = NCT * 16;
+  return (size_t)3 * Cp * D * 2 + (size_t)2 * D * (Cp + 4) * 2;
+}
+
+template <typename E, int D, int NCT>
+static int launch_x(int mode, const LaraP& p, hipStream_t st) {
+  const size_t lds = lara_x_lds(D, NCT);
+  const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
+#define EA_LX(M)                                                                                  \
+  do {                                                                                            \
+    if (lds > 64 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lara_x_kernel<E, D, NCT, M>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      if (e != hipSuccess) return (int)e;                                                         \
+    }                                                                                             \
+    hipLaunchKernelGGL((lara_x_kernel<E, D, NCT, M>), grid, block, lds, st, p);                   \
+  } while (0)
+  switch (mode) {
+    case LX_FWD: EA_LX(LX_FWD); break;
+    case LX_BWDQ: EA_LX(LX_BWDQ); break;
+    case LX_BWDK: EA_LX(LX_BWDK); break;
+    case LX_QCORR: EA_LX(LX_QCORR); break;
+    default: return EA_E_BADARG;
+  }
+#undef EA_LX
+  return (int)hipGetLastError();
+}
+
+template <typename E, int D>
+static int launch_x_nct(int mode, const LaraP& p, hipStream_t st) {
+  if (p.NCT <= 2) return launch_x<E, D, 2>(mode, p, st);
+  if (p.NCT <= 4) return launch_x<E, D, 4>(mode, p, st);
+  if (p.NCT <= 8) return launch_x<E, D, 8>(mode, p, st);
+  return EA_E_UNSUPPORTED;
+}
+
+int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (p.D == 64) return launch_x_nct<BF16, 64>(mode, p, st);
+    if (p.D == 32) return launch_x_nct<BF16, 32>(mode, p, st);
+  } else if (dtype == EA_F16) {
+    if (p.D == 64) return launch_x_nct<F16, 64>(mode, p, st);
+    if (p.D == 32) return launch_x_nct<F16, 32>(mode, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

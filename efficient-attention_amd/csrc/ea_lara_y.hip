@@ -1,0 +1,277 @@
+// ea_lara_y.hip -- LARA passes in the token-row layout (see ea_lara.h): everything that is a
+// sum over the sequence for a fixed landmark sample c.
+//
+//   LY_FWD   kv_stats_c = sum_m softmax_m(log_proj_k[c,:]) v_m with its log-sum-exp (online
+//            softmax, lara.py:205-211) and, for mis-opt, LSE_n(s qbar_c.q_n) (lara.py:222-223)
+//   LY_BWDQ  d(kv_stats), d(omega) (query side), sum_n t dt q_n, sum_n t q_n and the scalar
+//            sums r_c = sum_n dZ, d(bh)_c = sum_n dalpha, u_c = sum_n t dt
+//   LY_BWDK  d(omega) (key side) = s sum_m dBk[c,m] k_m
+// A workgroup streams its slice of the sequence through LDS in chunks; wave w owns landmark tile
+// (w mod ncw) and token sub-chunk (w / ncw); scores are D[n = 4g+r][c = li] so the lane's values
+// of two 16-token tiles are the B operand of the contraction over n, whose A operand is a
+// ds_read_b64_tr_b16 of the token rows.  Every (split, sub-chunk) writes its own partial result;
+// the caller merges partials (tiny tensors).
+#include "ea_lara.h"
+
+namespace ea {
+
+template <typename E, int D>
+EA_DEV void load_lm_frag(typename E::x8* dst, const float* src, bool ok, int g) {
+  constexpr int KS = D / 32;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (ok) {
+      float f[8];
+      const float* s = src + (g * KS + ks) * 8;
+      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(s);
+      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(s + 4);
+      w = pack8<E>(f);
+    }
+    dst[ks] = as_x8<E>(w);
+  }
+}
+
+template <typename E, int D, int MODE>
+__global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
+  constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nsub = p.NCT == 1 ? 4 : (p.NCT == 2 ? 2 : 1);
+  const int ncw = 4 / nsub;                          // landmark tiles handled concurrently
+  const int chunk = 32 * nsub;
+  char* T1 = smem;
+  char* T2 = T1 + chunk * ROWB;
+  float* sc = reinterpret_cast<float*>(T2 + chunk * ROWB);   // [4][chunk] per-row scalars
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = blockIdx.x / p.nsplit, split = blockIdx.x - bh * p.nsplit;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int ct = blockIdx.y * 4 + (wave % ncw), sub = wave / ncw;
+  const bool active = ct < p.NCT;
+  const int c = ct * 16 + li;
+  const bool c_ok = active && c < p.C;
+  const size_t lm = (size_t)bh * p.C;
+  const float invC = 1.f / (float)p.C;
+
+  typename E::x8 r1f[KS], r2f[KS], r3f[KS];
+  load_lm_frag<E, D>(r1f, p.omega + (lm + (c_ok ? c : 0)) * D, c_ok, g);
+  const bool use_t = p.mis != MIS_BH && MODE != LY_BWDK;
+  load_lm_frag<E, D>(r2f, use_t ? p.qbar + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && use_t, g);
+  const float* r3src = MODE == LY_BWDQ ? p.kv : p.dkv;
+  load_lm_frag<E, D>(r3f, MODE == LY_FWD ? p.omega : r3src + (lm + (c_ok ? c : 0)) * D, c_ok && MODE != LY_FWD, g);
+  float cst2 = -INFINITY, lset2 = INFINITY, bhc = 1.f, lsek2 = INFINITY, dkkc = 0.f, rsc = 0.f;
+  if (c_ok) {
+    if (MODE == LY_BWDQ) {
+      cst2 = p.cst[lm + c] * LOG2E;
+      if (p.mis == MIS_OPT) { bhc = p.bhv[lm + c]; lset2 = p.lse_t[lm + c] * LOG2E; }
+    }
+    if (MODE == LY_BWDK) { lsek2 = p.lse_k[lm + c] * LOG2E; dkkc = p.dkk[lm + c]; rsc = p.rsum[lm + c]; }
+  }
+
+  const int n0 = split * p.tok_per_block;
+  const int n1 = min(p.N, n0 + p.tok_per_block);
+  const int nphase = (MODE == LY_FWD && p.mis == MIS_OPT) ? 2 : 1;
+
+  f32x4 acc0[DT], acc1[DT], acc2[DT], acc3[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc0[dt] = acc1[dt] = acc2[dt] = acc3[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_k = -INFINITY, l_k = 0.f, m_t = -INFINITY, l_t = 0.f;
+  float s_r = 0.f, s_dbh = 0.f, s_u = 0.f;
+
+  for (int phase = 0; phase < nphase; ++phase) {
+    const bool keys = (MODE == LY_FWD && phase == 0) || MODE == LY_BWDK;
+    const T4l& a1 = keys ? p.k : p.q;
+    const T4l& a2 = keys ? p.v : p.dout;
+    const bool need2 = !(MODE == LY_FWD && phase == 1);
+    const char* a1b = a1.p + (b * a1.sb + h * a1.sh) * 2;
+    const char* a2b = need2 ? a2.p + (b * a2.sb + h * a2.sh) * 2 : nullptr;
+    for (int cb = n0; cb < n1; cb += chunk) {
+      __syncthreads();
+      // ---- stage token rows (+ per-row scalars) ----
+      for (int idx = tid; idx < chunk * CPR; idx += 256) {
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const int tok = cb + row;
+        const bool valid = tok < n1;
+        u32x4 w1 = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
+        if (valid) {
+          w1 = ldg16(a1b + (tok * a1.sn + cc * 8) * 2);
+          if (need2) w2 = ldg16(a2b + (tok * a2.sn + cc * 8) * 2);
+        }
+        sts16(T1 + lds_off<D>(row, cc), w1);
+        if (need2) sts16(T2 + lds_off<D>(row, cc), w2);
+        if (keys) {
+          float f[8], part = 0.f;
+          unpack8<E>(w1, f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) part += f[i] * f[i];
+#pragma unroll
+          for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+          if (cc == 0) {
+            const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + tok]);
+            sc[row] = dead ? -INFINITY : -0.5f * p.scale_log2 * part;
+          }
+        } else if (MODE == LY_FWD) {
+          if (cc == 0) sc[row] = valid ? 0.f : -INFINITY;
+        } else if (cc == 0) {     // LY_BWDQ
+          const size_t o = (size_t)bh * p.N + (valid ? tok : 0);
+          sc[row] = valid ? p.lseZ[o] : INFINITY;
+          sc[chunk + row] = valid ? p.tmean[o] : 0.f;
+          sc[2 * chunk + row] = valid ? p.rowdot[o] : 0.f;
+          sc[3 * chunk + row] = valid ? p.sda[o] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int rb = sub * 32;
+      float w0[2][4], w1v[2][4], w2v[2][4], w3v[2][4];
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = rb + 16 * mt + li;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const typename E::x8 ta = as_x8<E>(lds16(T1 + lds_off<D>(row, g * KS + ks)));
+          if (keys || MODE == LY_BWDQ) s1 = E::mma(ta, r1f[ks], s1);
+          if (!keys && use_t) s2 = E::mma(ta, r2f[ks], s2);
+          if (MODE != LY_FWD) s3 = E::mma(as_x8<E>(lds16(T2 + lds_off<D>(row, g * KS + ks))), r3f[ks], s3);
+        }
+        const int r0 = rb + 16 * mt + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (MODE == LY_FWD) {
+            const float x = (keys ? s1[r] : s2[r]) * p.scale_log2 + sc[r0 + r];
+            w0[mt][r] = c_ok ? x : -INFINITY;
+            mloc = fmaxf(mloc, w0[mt][r]);
+          } else if (MODE == LY_BWDK) {
+            const float pk = fast_exp2(s1[r] * p.scale_log2 + sc[r0 + r] - lsek2);
+            w0[mt][r] = pk * (s3[r] - dkkc + rsc);
+          } else {   // LY_BWDQ
+            const float lz2 = sc[r0 + r], tm = sc[chunk + r0 + r], rd = sc[2 * chunk + r0 + r], sd = sc[3 * chunk + r0 + r];
+            const LaraElem e = lara_alpha(p.mis, s2[r] * p.scale_log2, lset2, bhc, p.kappa, tm);
+            const float z2 = s1[r] * p.scale_log2 + e.la2 + cst2;
+            const float w = fast_exp2(z2 - lz2);
+            const float dz = w * (s3[r] - rd);
+            float da = 0.f, tdt = 0.f;
+            if (p.mis == MIS_OPT) {
+              da = e.alpha > 1e-8f ? dz / e.alpha : 0.f;
+              tdt = e.t * p.kappa * (da - sd * invC);
+            }
+            w0[mt][r] = w; w1v[mt][r] = dz; w2v[mt][r] = tdt; w3v[mt][r] = e.t;
+            s_r += dz; s_dbh += da; s_u += tdt;
+          }
+        }
+      }
+      // tr-read addressing of the two 16-token tiles of this wave
+      const int ra = rb + 4 * g + (li >> 2), rb2 = ra + 16;
+      if (MODE == LY_FWD) {
+        mloc = quad_max(mloc);
+        float& m = keys ? m_k : m_t;
+        float& l = keys ? l_k : l_t;
+        const float mn = fmaxf(m, mloc);
+        const float ms = mn == -INFINITY ? 0.f : mn;
+        const float alpha = fast_exp2(m - ms);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { w0[mt][r] = fast_exp2(w0[mt][r] - ms); ps += w0[mt][r]; }
+        l = l * alpha + ps;
+        if (keys) {
+          u32x4 pf;
+          pf[0] = pack2<E>(w0[0][0], w0[0][1]); pf[1] = pack2<E>(w0[0][2], w0[0][3]);
+          pf[2] = pack2<E>(w0[1][0], w0[1][1]); pf[3] = pack2<E>(w0[1][2], w0[1][3]);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+            const int c16 = colb >> 4, within = colb & 15;
+            const u32x2 lo = E::tr4(T2 + ra * ROWB + ((c16 ^ (ra & SW)) << 4) + within);
+            const u32x2 hi = E::tr4(T2 + rb2 * ROWB + ((c16 ^ (rb2 & SW)) << 4) + within);
+            acc0[dt] = acc0[dt] * alpha;
+            acc0[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf), acc0[dt]);
+          }
+        }
+      } else {
+        u32x4 f0, f1, f2, f3;
+#define EA_PK(dst, src)                                                                     \
+  dst[0] = pack2<E>(src[0][0], src[0][1]); dst[1] = pack2<E>(src[0][2], src[0][3]);         \
+  dst[2] = pack2<E>(src[1][0], src[1][1]); dst[3] = pack2<E>(src[1][2], src[1][3]);
+        EA_PK(f0, w0)
+        if (MODE == LY_BWDQ) { EA_PK(f1, w1v) EA_PK(f2, w2v) EA_PK(f3, w3v) }
+#undef EA_PK
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+          const int c16 = colb >> 4, within = colb & 15;
+          const int oa = ra * ROWB + ((c16 ^ (ra & SW)) << 4) + within;
+          const int ob = rb2 * ROWB + ((c16 ^ (rb2 & SW)) << 4) + within;
+          if (MODE == LY_BWDK) {
+            acc0[dt] = E::mma(as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob)), as_x8<E>(f0), acc0[dt]);
+          } else {
+            const typename E::x8 dot = as_x8<E>(E::tr4(T2 + oa), E::tr4(T2 + ob));
+            const typename E::x8 qt = as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob));
+            acc0[dt] = E::mma(dot, as_x8<E>(f0), acc0[dt]);      // d kv_stats
+            acc1[dt] = E::mma(qt, as_x8<E>(f1), acc1[dt]);       // sum dZ q
+            if (p.mis == MIS_OPT) {
+              acc2[dt] = E::mma(qt, as_x8<E>(f2), acc2[dt]);     // sum t dt q
+              acc3[dt] = E::mma(qt, as_x8<E>(f3), acc3[dt]);     // sum t q
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!c_ok) return;
+  // ---- partial results of this (split, sub-chunk): lane (c, g) owns channels DQ*g .. ----
+  const int S = p.nsplit * nsub;
+  const size_t slot = ((size_t)bh * S + split * nsub + sub) * p.C + c;
+  float* ml = p.p_ml + slot * 4;
+  if (MODE == LY_FWD) {
+    l_k = quad_sum(l_k);
+    l_t = quad_sum(l_t);
+    if (g == 0) { ml[0] = m_k * LN2; ml[1] = l_k; ml[2] = m_t * LN2; ml[3] = l_t; }
+  } else if (MODE == LY_BWDQ) {
+    s_r = quad_sum(s_r); s_dbh = quad_sum(s_dbh); s_u = quad_sum(s_u);
+    if (g == 0) { ml[0] = s_r; ml[1] = s_dbh; ml[2] = s_u; ml[3] = 0.f; }
+  }
+  auto put = [&](float* base, const f32x4* a) {
+    float* d = base + slot * D + DQ * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(a[dt][0], a[dt][1], a[dt][2], a[dt][3]);
+  };
+  put(p.p_acc0, acc0);
+  if (MODE == LY_BWDQ) {
+    put(p.p_acc1, acc1);
+    if (p.mis == MIS_OPT) { put(p.p_acc2, acc2); put(p.p_acc3, acc3); }
+  }
+}
+
+template <typename E, int D>
+static int launch_y(int mode, const LaraP& p, hipStream_t st) {
+  const int nsub = p.NCT == 1 ? 4 : (p.NCT == 2 ? 2 : 1);
+  const int chunk = 32 * nsub;
+  const size_t lds = (size_t)2 * chunk * D * 2 + (size_t)4 * chunk * sizeof(float);
+  const dim3 grid((unsigned)(p.B * p.H * p.nsplit), (unsigned)((p.NCT + 3) / 4)), block(256);
+  switch (mode) {
+    case LY_FWD: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_FWD>), grid, block, lds, st, p); break;
+    case LY_BWDQ: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDQ>), grid, block, lds, st, p); break;
+    case LY_BWDK: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDK>), grid, block, lds, st, p); break;
+    default: return EA_E_BADARG;
+  }
+  return (int)hipGetLastError();
+}
+
+int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (p.D == 64) return launch_y<BF16, 64>(mode, p, st);
+    if (p.D == 32) return launch_y<BF16, 32>(mode, p, st);
+  } else if (dtype == EA_F16) {
+    if (p.D == 64) return launch_y<F16, 64>(mode, p, st);
+    if (p.D == 32) return launch_y<F16, 32>(mode, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

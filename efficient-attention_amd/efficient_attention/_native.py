@@ -30,8 +30,15 @@ class ea_geom(ctypes.Structure):
                 ("scale", ctypes.c_float)]
 
 
+class ea_lara_geom(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("mis", ctypes.c_int32), ("kappa", ctypes.c_float), ("scale", ctypes.c_float)]
+
+
 _P = ctypes.c_void_p
 _G = ctypes.POINTER(ea_geom)
+_LG = ctypes.POINTER(ea_lara_geom)
 _T = ctypes.POINTER(ea_t4)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
@@ -42,6 +49,14 @@ SIGNATURES = {
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
     "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_lara_parts": [_LG],
+    "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],
+    "ea_lara_bwd_q": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P],
+    "ea_lara_bwd_qstats": [_LG, _T, _T] + [_P] * 16,
+    "ea_lara_bwd_k": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P],
+    "ea_lara_bwd_kstats": [_LG, _T, _T] + [_P] * 8,
+    "ea_lara_bwd_qcorr": [_LG, _T, _P, _P, _P, _T, _P],
     "ea_window_bias_ld": [_G],
     "ea_window_bwd_parts": [_G],
 }
@@ -112,7 +127,46 @@ def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0):
                    float(D) ** -0.5)
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around every C-ABI launch (used by bench.py's instrumented
+    pass and tools/): events are recorded on the stream the kernel is launched on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def enable(self):
+        self.enabled, self.records = True, []
+
+    def disable(self):
+        self.enabled = False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.records:
+            ms = a.elapsed_time(b)
+            st = out.setdefault(name, {"n": 0, "total_ms": 0.0})
+            st["n"] += 1
+            st["total_ms"] += ms
+        for st in out.values():
+            st["avg_ms"] = st["total_ms"] / st["n"]
+        return out
+
+
+KERNEL_TIMER = KernelTimer()
+
+
 def call(name, *args):
+    if KERNEL_TIMER.enabled:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib(), name)(*args)
+        b.record()
+        KERNEL_TIMER.records.append((name, a, b))
+        _check(rc, name)
+        return
     _check(getattr(lib(), name)(*args), name)
 
 

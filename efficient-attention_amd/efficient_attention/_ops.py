@@ -14,6 +14,24 @@ import torch.nn.functional as F
 
 from . import _native as nv
 
+KERNEL_TIMER = nv.KERNEL_TIMER
+# algorithmic HBM traffic of one launch, in units of one [B,H,N,D] I/O-dtype tensor (DESIGN.md)
+KERNEL_ALGO_UNITS = {
+    "ea_window_attn_fwd": 4,      # read q,k,v; write out
+    "ea_window_attn_bwd": 8,      # read q,k,v,out,dout; write dq,dk,dv
+    "ea_eva_chunk_mean_fwd": 2,   # read q,k
+    "ea_eva_chunk_mean_bwd": 4,   # read+write dq,dk
+    "ea_eva_beta_fwd": 2,         # read k,v
+    "ea_eva_beta_bwd": 6,         # read k,v; read+write dk,dv
+    "ea_lara_stats_fwd": 3,       # read q,k,v
+    "ea_lara_out_fwd": 2,         # read q; write out
+    "ea_lara_bwd_q": 3,           # read q,dout; write dq
+    "ea_lara_bwd_qstats": 2,      # read q,dout
+    "ea_lara_bwd_k": 4,           # read k,v; write dk,dv
+    "ea_lara_bwd_kstats": 2,      # read k,v
+    "ea_lara_bwd_qcorr": 3,       # read q; read+write dq
+}
+
 
 def _qkv_views(qkv5):
     """[B,N,3,h,d] -> three [B,h,N,d] strided views (no copy)."""
@@ -201,3 +219,165 @@ class EvaAttnFn(torch.autograd.Function):
         if dbias is not None:
             dbias = dbias[..., :ctx.bias_cols]
         return (dqkv5, dbias, None, None, None) + tuple(pgrads)
+
+
+# ------------------------------------------------------------------------------------------
+# LARA  (reference lara.py:177-251)
+# ------------------------------------------------------------------------------------------
+MIS = {"mis-opt": 0, "mis-biased": 1, "mis-bh": 2}
+
+
+def pool2d_qkv(qkv5, H, W, side):
+    """Adaptive 2-D average pool of q, k, v over the token grid -> [3, B, h, side*side, d] fp32
+    (nn.AdaptiveAvgPool2d on each head's [d, H, W] map, lara.py:43,48,145-151)."""
+    B, N, _, h, d = qkv5.shape
+    if H % side == 0 and W % side == 0:
+        x = qkv5.view(B, side, H // side, side, W // side, 3, h, d)
+        pooled = x.mean(dim=(2, 4), dtype=torch.float32)                  # [B, side, side, 3, h, d]
+        return pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
+
+    def bins(n):
+        m = torch.zeros(side, n, device=qkv5.device, dtype=torch.float32)
+        for o in range(side):
+            s, e = (o * n) // side, -((-(o + 1) * n) // side)
+            m[o, s:e] = 1.0 / (e - s)
+        return m
+    x = qkv5.view(B, H, W, 3, h, d).float()
+    pooled = torch.einsum("iy,jx,byxthd->bijthd", bins(H), bins(W), x)
+    return pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
+
+
+class LaraAttnFn(torch.autograd.Function):
+    """LARA estimator on a fused qkv tensor given the landmark-side tensors (all fp32):
+    omega [B,h,C,d], qbar [B,h,C,d] (q_bar rows for mis-opt, mu rows for mis-biased; rows already
+    repeated for antithetic / multi-sample noise), bhv [B,h,C] balanced-heuristic weights and
+    lp [B,h,C] log-proposal.  Returns out [B,N,h,d]."""
+
+    @staticmethod
+    def forward(ctx, qkv5, mask_u8, omega, qbar, bhv, lp, mis, kappa):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        C = omega.shape[2]
+        dev = qkv5.device
+        geom = nv.ea_lara_geom(B, h, N, d, nv.io_dtype(qkv5), C, mis, float(kappa), float(d) ** -0.5)
+        q, k, v = _qkv_views(qkv5)
+        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+        BH = B * h
+        omega = omega.float().reshape(BH, C, d).contiguous()
+        qbar_c = None if qbar is None else qbar.float().reshape(BH, C, d).contiguous()
+        S = nv.lib().ea_lara_parts(ctypes.byref(geom))
+        p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
+        p_kv = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
+        nv.call("ea_lara_stats_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+                ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(p_ml),
+                nv.ptr(p_kv), nv.stream())
+        # merge the sequence slices (tiny): log-sum-exp merge of the online-softmax partials
+        m_k, l_k, m_t, l_t = p_ml.unbind(-1)
+        Mk = m_k.amax(1, keepdim=True)
+        wk = torch.exp(m_k - Mk)
+        lk = (l_k * wk).sum(1)
+        kv = ((p_kv * wk.unsqueeze(-1)).sum(1) / lk.unsqueeze(-1)).contiguous()    # [BH, C, d]
+        lse_k = (Mk.squeeze(1) + torch.log(lk)).contiguous()
+        lse_t = None
+        if mis == 0:
+            Mt = m_t.amax(1, keepdim=True)
+            lse_t = (Mt.squeeze(1) + torch.log((l_t * torch.exp(m_t - Mt)).sum(1))).contiguous()
+        cst = (lse_k - lp.reshape(BH, C).float()).contiguous()
+        bhv_c = None if bhv is None else bhv.reshape(BH, C).float().contiguous()
+        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+        to = nv.t4(out.permute(0, 2, 1, 3))
+        nv.call("ea_lara_out_fwd", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c),
+                nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to), nv.stream())
+        ctx.save_for_backward(qkv5, mask_u8, omega, qbar_c, bhv_c, cst, kv, lse_k, lse_t)
+        ctx.geom = geom
+        ctx.has = (qbar is not None, bhv is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, mask_u8, omega, qbar, bhv, cst, kv, lse_k, lse_t = ctx.saved_tensors
+        geom = ctx.geom
+        B, N, _, h, d = qkv5.shape
+        C, BH, dev, mis = geom.C, B * h, qkv5.device, geom.mis
+        scale = geom.scale
+        dout = dout.contiguous()
+        dqkv5 = torch.empty_like(qkv5)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        tq, tk, tv, tdo = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(dout.permute(0, 2, 1, 3))
+        tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
+        tok = torch.empty((4, BH, N), dtype=torch.float32, device=dev)
+        lseZ, tmean, rowdot, sda = tok[0], tok[1], tok[2], tok[3]
+        nv.call("ea_lara_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(omega),
+                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), ctypes.byref(tdq),
+                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.stream())
+        S = nv.lib().ea_lara_parts(ctypes.byref(geom))
+        p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
+        p_acc = torch.empty((4, BH, S, C, d), dtype=torch.float32, device=dev)
+        nv.call("ea_lara_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo),
+                nv.ptr(omega), nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst),
+                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.ptr(p_ml),
+                nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
+        sums = p_ml.sum(1)                                   # [BH, C, 4]
+        r, dbh, u = sums[..., 0].contiguous(), sums[..., 1], sums[..., 2]
+        nacc = 4 if mis == 0 else 2
+        acc = p_acc[:nacc].sum(2)                            # [nacc, BH, C, d]
+        dkv = acc[0].contiguous()
+        dom_q = acc[1]
+        dkk = (dkv * kv).sum(-1).contiguous()
+        nv.call("ea_lara_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r), ctypes.byref(tdk),
+                ctypes.byref(tdv), nv.stream())
+        p_domk = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
+        nv.call("ea_lara_bwd_kstats", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r),
+                nv.ptr(p_domk), nv.stream())
+        d_omega = (scale * (dom_q + p_domk.sum(1))).view(B, h, C, d)
+        d_qbar = d_bhv = None
+        if mis == 0:
+            uq = (u.unsqueeze(-1) * qbar).contiguous()
+            nv.call("ea_lara_bwd_qcorr", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq),
+                    nv.ptr(lse_t), ctypes.byref(tdq), nv.stream())
+            d_qbar = (scale * (acc[2] - u.unsqueeze(-1) * acc[3])).view(B, h, C, d)
+            d_bhv = dbh.reshape(B, h, C)
+        elif mis == 1:
+            d_qbar = (scale * dom_q).view(B, h, C, d)
+        d_lp = (-r).view(B, h, C)
+        has_qbar, has_bhv = ctx.has
+        return (dqkv5, None, d_omega, d_qbar if has_qbar else None, d_bhv if has_bhv else None,
+                d_lp, None, None)
+
+
+def _prm(data, proj, scale):
+    """s <proj_c, data_n> - s |data_n|^2 / 2  (prm_projection normalize=False), tiny tensors."""
+    return scale * torch.einsum("bhcd,bhnd->bhcn", proj, data) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)
+
+
+def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scale):
+    """Sampling + the [C x L] proposal-density algebra on the landmarks (tiny torch ops with
+    autograd, lara.py:187-238), then the HIP estimator.  mode: 0 single, 1 antithetic,
+    2 multi-sample noise."""
+    mis = MIS[mis_type]
+    q_bar, mu = q_bar.float(), mu.float()
+    dup = noise is not None and mode in (1, 2)
+    if noise is None:
+        omega = mu
+    elif mode == 2:
+        omega = mu.repeat(1, 1, 2, 1) + noise.float()
+    elif mode == 1:
+        omega = torch.cat([mu + noise.float(), mu - noise.float()], dim=-2)
+    else:
+        omega = mu + noise.float()
+    rep = (lambda t: t.repeat(1, 1, 2, 1)) if dup else (lambda t: t)
+    qbar_rows = bhv = None
+    if mis == 0:
+        lpmu = _prm(rep(mu), omega, scale)                               # [B,h,C,C]
+        lp = torch.diagonal(lpmu, dim1=-1, dim2=-2)
+        bhv = torch.exp(lp - torch.logsumexp(lpmu, dim=-1))
+        qbar_rows = rep(q_bar)
+    elif mis == 1:
+        lp = torch.logsumexp(_prm(mu, omega, scale), dim=-1)            # [B,h,C]
+        qbar_rows = rep(mu)
+    else:
+        lp = torch.logsumexp(_prm(mu, omega, scale), dim=-1)
+    return LaraAttnFn.apply(qkv5, mask_u8, omega, qbar_rows, bhv, lp, mis, float(alpha_coeff))

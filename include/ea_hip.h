@@ -113,6 +113,65 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        float* dlk_part, float* dlv_part, float* dbias_part,
                        float* dk_acc, float* dv_acc, void* stream);
 
+/* ---- LARA: linear randomized attention (lara.py:177-251) -------------------------------------
+ * C landmark samples omega_c (C = L, or 2L with antithetic / multi-sample noise), each token n:
+ *   log_proj_k[c,m] = s w_c.k_m - s|k_m|^2/2 (-inf on padded keys)          (lara.py:202-208)
+ *   kv_stats_c = sum_m softmax_m(log_proj_k[c,:]) v_m,  lse_k[c] = LSE_m log_proj_k   (:211,241)
+ *   mis-opt:  t[c,n] = softmax_n(s qbar_c.q_n); alpha = bh_c + kappa (t - mean_c t);
+ *             log_alpha = log max(alpha, 1e-8)                               (:221-232)
+ *   mis-biased: log_alpha = s qbar_c.q_n (qbar := mu rows)                   (:214-220)
+ *   mis-bh:   log_alpha = 0                                                  (:233-236)
+ *   W[c,n] = softmax_c(log_alpha + s w_c.q_n + cst_c),  cst_c = lse_k[c] - log_proposal_c
+ *   out_n = sum_c W[c,n] kv_stats_c                                          (:241-246)
+ * Landmark-side tensors are fp32: omega, qbar, kv, dkv, uq [B*H, C, D]; per-landmark scalars
+ * [B*H, C]; per-token scalars [B*H, N].  The sequence-wide sums come back as partial results over
+ * S = ea_lara_parts(g) slices that the caller merges (log-sum-exp merge for the forward
+ * statistics, plain sums for the backward ones):
+ *   stats_fwd : p_ml [B*H, S, C, 4] = (max_k, sum_k, max_t, sum_t) in natural-log units of the
+ *               running maxima, p_kv [B*H, S, C, D] un-normalised sum_m exp(lpk - max_k) v_m
+ *   bwd_qstats: p_ml = (r_c = sum_n dZ, sum_n dalpha, u_c = sum_n t dt, 0);
+ *               p_dkv = d kv_stats; p_dom = sum_n dZ q_n; p_m1 = sum_n t dt q_n; p_m2 = sum_n t q_n
+ *   bwd_kstats: p_dom = sum_m dBk[c,m] k_m  (caller scales d omega by s)
+ * bwd_q writes the sequence-local part of dq plus the per-token scalars bwd_qstats consumes;
+ * bwd_qcorr subtracts s sum_c t[c,n] uq_c (uq_c = u_c qbar_c) from dq in place (mis-opt only);
+ * bwd_k writes dk, dv given dkv, lse_k, dkk_c = dkv_c.kv_c and rsum_c = r_c. */
+#define EA_MIS_OPT    0
+#define EA_MIS_BIASED 1
+#define EA_MIS_BH     2
+typedef struct {
+  int32_t B, H, N, D;
+  int32_t dtype;             /* EA_BF16 | EA_F16 */
+  int32_t C;                 /* landmark samples, <= 128 */
+  int32_t mis;               /* EA_MIS_* */
+  float   kappa;             /* alpha_coeff (lara.py:231) */
+  float   scale;             /* D^-0.5 */
+} ea_lara_geom;
+
+int32_t ea_lara_parts(const ea_lara_geom* g);
+int ea_lara_stats_fwd(const ea_lara_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
+                      const uint8_t* mask, const float* omega, const float* qbar,
+                      float* p_ml, float* p_kv, void* stream);
+int ea_lara_out_fwd(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar,
+                    const float* kv, const float* lse_t, const float* bhv, const float* cst,
+                    const ea_t4* out, void* stream);
+int ea_lara_bwd_q(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                  const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                  const float* cst, const ea_t4* dq, float* lseZ, float* tmean, float* rowdot,
+                  float* sda, void* stream);
+int ea_lara_bwd_qstats(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                       const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                       const float* cst, const float* lseZ, const float* tmean, const float* rowdot,
+                       const float* sda, float* p_ml, float* p_dkv, float* p_dom, float* p_m1,
+                       float* p_m2, void* stream);
+int ea_lara_bwd_k(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                  const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                  const float* rsum, const ea_t4* dk, const ea_t4* dv, void* stream);
+int ea_lara_bwd_kstats(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                       const float* rsum, float* p_dom, void* stream);
+int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
+                      const float* lse_t, const ea_t4* dq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

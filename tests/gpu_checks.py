@@ -4,8 +4,16 @@ Module-level check: the product nn.Module (HIP cores, bf16 autocast like the ref
 recipe) vs the golden vectors of the fp32 reference; core-level checks compare a HIP core with
 the oracle evaluated in fp64 on the same bf16-rounded inputs.
 
-Stated tolerances (bf16 operands, fp32 accumulation):
+Stated tolerances (bf16 operands: 8 significant bits, unit round-off 2^-9 = 2e-3; fp32
+accumulation; every figure is relative to the reference tensor's own scale):
   module level vs fp32 golden : max|err| <= 4e-2 * max|ref|  and  rms(err) <= 2e-2 * rms(ref)
+  LARA module level           : max|err| <= 8e-2 * max|ref|  and  rms(err) <= 4e-2 * rms(ref)
+      (its gradients pass through three more bf16-rounded stages than a softmax kernel: the
+       importance weights, d(log alpha)/alpha and the softmax-over-sequence term t(dt - u), whose
+       two halves cancel, and the landmark matrices are rounded to bf16 exactly as autocast
+       rounds einsum operands; observed 1-3e-2 rms, 8x smaller in fp16)
+  fp16 autocast (the reference's own AMP dtype, 11 significant bits), every variant:
+                                max|err| <= 1e-2 * max|ref|  and  rms(err) <= 5e-3 * rms(ref)
   core level vs fp64 oracle   : max|err| <= 2e-2 * max|ref|  and  rms(err) <= 1e-2 * rms(ref)
 """
 import contextlib
@@ -18,6 +26,8 @@ import cases
 from util import Fixture, scaled_err
 
 MODULE_TOL = (4e-2, 2e-2)
+LARA_TOL = (8e-2, 4e-2)
+FP16_TOL = (1e-2, 5e-3)
 CORE_TOL = (2e-2, 1e-2)
 
 
@@ -58,8 +68,13 @@ def build_module(fx, device="cuda"):
     return mod.to(device)
 
 
-def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=MODULE_TOL):
+def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None):
     fx = Fixture(name)
+    if tol is None:
+        if dtype == torch.float16:
+            tol = FP16_TOL
+        else:
+            tol = LARA_TOL if fx.case["attn"] == "lara" else MODULE_TOL
     mod = build_module(fx)
     mod.train(mode == "train")
     x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)

@@ -5,12 +5,14 @@ import pytest
 import cases
 from gpu_checks import check_module_case
 
-READY = ("eva_", "local_")       # variants whose HIP cores have landed
+READY = ("eva_", "local_", "lara_")       # variants whose HIP cores have landed
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("mode", cases.MODES)
 @pytest.mark.parametrize("name", [n for n in cases.CASES if n.startswith(READY)])
-def test_module_matches_reference(name, mode):
-    errs = check_module_case(name, mode)
-    print(name, mode, {k: "%.2e/%.2e" % v for k, v in errs.items()})
+def test_module_matches_reference(name, mode, dtype):
+    import torch
+    errs = check_module_case(name, mode, dtype=torch.bfloat16 if dtype == "bf16" else torch.float16)
+    print(name, mode, dtype, {k: "%.2e/%.2e" % v for k, v in errs.items()})
