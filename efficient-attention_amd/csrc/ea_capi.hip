@@ -9,6 +9,7 @@ int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStre
 }  // namespace ea
 #include "ea_landmark_params.h"
 #include "ea_lara.h"
+#include "ea_softmax.h"
 namespace ea {
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
@@ -291,6 +292,46 @@ int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, 
   if (!t4_ok(q, g->D) || !t4_ok(dq, g->D) || !qbar || !uq || !lse_t) return EA_E_BADARG;
   p.q = mkl(q); p.dq = mkl(dq); p.qbar = qbar; p.uq = uq; p.lse_t = lse_t;
   return lara_x_dispatch(LX_QCORR, p, g->dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- softmax baseline ----
+#define SM_SET(dst, src) do { if (src) { p.dst.p = (char*)(src)->ptr; p.dst.sb = (src)->sb; p.dst.sh = (src)->sh; p.dst.sn = (src)->sn; } } while (0)
+static int fill_sm(int B, int H, int N, int D, int dtype, float scale, SmP& p) {
+  if (B <= 0 || H <= 0 || N <= 0 || (D != 32 && D != 64 && D != 128) || (dtype != EA_BF16 && dtype != EA_F16))
+    return EA_E_BADARG;
+  p.B = B; p.H = H; p.N = N; p.scale = scale; p.scale_log2 = scale * LOG2E;
+  return EA_OK;
+}
+
+extern "C" {
+
+int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                        const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const ea_t4* out, float* lse, void* stream) {
+  SmP p = {};
+  int rc = fill_sm(B, H, N, D, dtype, scale, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !lse) return EA_E_BADARG;
+  SM_SET(q, q); SM_SET(k, k); SM_SET(v, v); SM_SET(o, out);
+  p.mask = mask; p.lse = lse;
+  return softmax_dispatch(0, p, dtype, D, (hipStream_t)stream);
+}
+
+int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                        const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
+                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv, void* stream) {
+  SmP p = {};
+  int rc = fill_sm(B, H, N, D, dtype, scale, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !t4_ok(dout, D) ||
+      !t4_ok(dq, D) || !t4_ok(dk, D) || !t4_ok(dv, D) || !lse || !delta) return EA_E_BADARG;
+  SM_SET(q, q); SM_SET(k, k); SM_SET(v, v); SM_SET(o, out); SM_SET(dout, dout);
+  SM_SET(dq, dq); SM_SET(dk, dk); SM_SET(dv, dv);
+  p.mask = mask; p.lse = const_cast<float*>(lse); p.delta = delta;
+  return softmax_dispatch(1, p, dtype, D, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,364 @@
+// ea_softmax.hip -- the softmax baseline (abstract_attention.py:120-133) as streaming
+// (flash-style) kernels: softmax(s QK^T, -inf on padded keys) V without materialising the
+// [N, N] score matrix.  This is the one MFMA-bound member of the family (AI ~ 0.6 N FLOP/B).
+//
+//   fwd     : workgroup = 64 queries (a wave per 16-query tile), K/V streamed through LDS in
+//             64-key chunks, S^T = K Q^T tiles -> online softmax in registers -> O^T = V^T P^T
+//             (same register-level chaining as ea_window_fwd.hip); writes out and lse
+//   bwd_dq  : same streaming; P from the saved lse, dS^T = P o (V dO^T - delta) -> dQ^T = K^T dS^T;
+//             also writes delta_n = dO_n . O_n for the second pass
+//   bwd_dkv : workgroup = 64 keys (a wave per 16-key tile), Q/dO streamed through LDS in 64-query
+//             chunks, S = Q K^T, dP = dO V^T tiles [query][key] -> dV^T = dO^T P, dK^T = Q^T dS
+// Two recomputing passes instead of fp32 atomics on dQ: deterministic, and no read-modify-write
+// traffic on the gradient.
+#include "ea_softmax.h"
+
+namespace ea {
+
+
+template <typename E, int D>
+__global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
+  constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) uint8_t dead[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqb = (p.N + 63) / 64;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* qbase = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* kbase = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const char* vbase = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.N : nullptr;
+  const int qtok = qb * 64 + wave * 16 + li;
+  const bool qvalid = qtok < p.N;
+  typename E::x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (qvalid) w = ldg16(qbase + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
+    qf[ks] = as_x8<E>(w);
+  }
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < p.N; kc += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = kc + row;
+      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+      if (tok < p.N) {
+        kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
+        vw = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
+      }
+      sts16(Ks + lds_off<D>(row, c), kw);
+      sts16(Vs + lds_off<D>(row, c), vw);
+      if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
+    }
+    __syncthreads();
+    f32x4 s[4];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int row = tt * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+      const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = ((f4 >> (8 * r)) & 0xffu) ? -INFINITY : acc[r] * p.scale_log2;
+        acc[r] = x;
+        mloc = fmaxf(mloc, x);
+      }
+      s[tt] = acc;
+    }
+    mloc = quad_max(mloc);
+    const float mnew = fmaxf(m, mloc);
+    const float msafe = mnew == -INFINITY ? 0.f : mnew;
+    const float alpha = fast_exp2(m - msafe);
+    m = mnew;
+    float psum = 0.f;
+    uint32_t pw[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(s[tt][r] - msafe); psum += pv[r]; }
+      pw[tt][0] = pack2<E>(pv[0], pv[1]);
+      pw[tt][1] = pack2<E>(pv[2], pv[3]);
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 pf4;
+      pf4[0] = pw[2 * kk][0]; pf4[1] = pw[2 * kk][1]; pf4[2] = pw[2 * kk + 1][0]; pf4[3] = pw[2 * kk + 1][1];
+      const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+        const int c16 = colb >> 4, within = colb & 15;
+        const u32x2 lo = E::tr4(Vs + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
+        const u32x2 hi = E::tr4(Vs + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+        o[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf4), o[dt]);
+      }
+    }
+  }
+  const float ltot = quad_sum(lsum);
+  if (qvalid) {
+    const float inv = 1.f / ltot;
+    float f[DQ];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f[4 * dt + r] = o[dt][r] * inv;
+    char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + qtok * p.o.sn + DQ * g) * 2;
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    if (g == 0) p.lse[(size_t)bh * p.N + qtok] = (m + fast_log2(ltot)) * LN2;
+  }
+}
+
+template <typename E, int D>
+__global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
+  constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) uint8_t dead[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqb = (p.N + 63) / 64;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* kbase = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const char* vbase = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.N : nullptr;
+  const int qtok = qb * 64 + wave * 16 + li;
+  const bool qvalid = qtok < p.N;
+  typename E::x8 qf[KS], dof[KS];
+  float delta = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 w = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u}, ow = {0u, 0u, 0u, 0u};
+    if (qvalid) {
+      const int eo = (g * KS + ks) * 8;
+      w = ldg16(p.q.p + (b * p.q.sb + h * p.q.sh + qtok * p.q.sn + eo) * 2);
+      dw = ldg16(p.dout.p + (b * p.dout.sb + h * p.dout.sh + qtok * p.dout.sn + eo) * 2);
+      ow = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + qtok * p.o.sn + eo) * 2);
+    }
+    qf[ks] = as_x8<E>(w);
+    dof[ks] = as_x8<E>(dw);
+    float a[8], c8[8];
+    unpack8<E>(dw, a);
+    unpack8<E>(ow, c8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) delta += a[i] * c8[i];
+  }
+  delta = quad_sum(delta);
+  const float lse2 = qvalid ? p.lse[(size_t)bh * p.N + qtok] * LOG2E : INFINITY;
+  if (qvalid && g == 0) p.delta[(size_t)bh * p.N + qtok] = delta;
+  f32x4 dq[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < p.N; kc += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = kc + row;
+      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+      if (tok < p.N) {
+        kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
+        vw = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
+      }
+      sts16(Ks + lds_off<D>(row, c), kw);
+      sts16(Vs + lds_off<D>(row, c), vw);
+      if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
+    }
+    __syncthreads();
+    uint32_t dsw[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      const int row = tt * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], s);
+        dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
+      }
+      const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dd = (f4 >> (8 * r)) & 0xffu;
+        const float pr = dd ? 0.f : fast_exp2(s[r] * p.scale_log2 - lse2);
+        ds[r] = pr * (dp[r] - delta);
+      }
+      dsw[tt][0] = pack2<E>(ds[0], ds[1]);
+      dsw[tt][1] = pack2<E>(ds[2], ds[3]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 f4v;
+      f4v[0] = dsw[2 * kk][0]; f4v[1] = dsw[2 * kk][1]; f4v[2] = dsw[2 * kk + 1][0]; f4v[3] = dsw[2 * kk + 1][1];
+      const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+        const int c16 = colb >> 4, within = colb & 15;
+        const u32x2 lo = E::tr4(Ks + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
+        const u32x2 hi = E::tr4(Ks + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+        dq[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(f4v), dq[dt]);
+      }
+    }
+  }
+  if (qvalid) {
+    float f[DQ];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[dt][r] * p.scale;
+    char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + qtok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+  }
+}
+
+template <typename E, int D>
+__global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
+  constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  __shared__ __attribute__((aligned(16))) char Qs[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) char dOs[64 * ROWB];
+  __shared__ __attribute__((aligned(16))) float lse_s[64];
+  __shared__ __attribute__((aligned(16))) float delta_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nkb = (p.N + 63) / 64;
+  const int bh = blockIdx.x / nkb, kb = blockIdx.x - bh * nkb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* qbase = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* dobase = p.dout.p + (b * p.dout.sb + h * p.dout.sh) * 2;
+  const int ktok = kb * 64 + wave * 16 + li;
+  const bool kvalid = ktok < p.N;
+  const bool kdead = !kvalid || (p.mask && p.mask[(size_t)b * p.N + ktok]);
+  typename E::x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+    if (kvalid) {
+      const int eo = (g * KS + ks) * 8;
+      kw = ldg16(p.k.p + (b * p.k.sb + h * p.k.sh + ktok * p.k.sn + eo) * 2);
+      vw = ldg16(p.v.p + (b * p.v.sb + h * p.v.sh + ktok * p.v.sn + eo) * 2);
+    }
+    kf[ks] = as_x8<E>(kw);
+    vf[ks] = as_x8<E>(vw);
+  }
+  f32x4 dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int qc = 0; qc < p.N; qc += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = qc + row;
+      u32x4 qw = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u};
+      if (tok < p.N) {
+        qw = ldg16(qbase + (tok * p.q.sn + c * 8) * 2);
+        dw = ldg16(dobase + (tok * p.dout.sn + c * 8) * 2);
+      }
+      sts16(Qs + lds_off<D>(row, c), qw);
+      sts16(dOs + lds_off<D>(row, c), dw);
+      if (c == 0) {
+        lse_s[row] = tok < p.N ? p.lse[(size_t)bh * p.N + tok] * LOG2E : INFINITY;
+        delta_s[row] = tok < p.N ? p.delta[(size_t)bh * p.N + tok] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      uint32_t pw[2][2], dsw[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rq = (2 * qq + u) * 16;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = E::mma(as_x8<E>(lds16(Qs + lds_off<D>(rq + li, g * KS + ks))), kf[ks], s);
+          dp = E::mma(as_x8<E>(lds16(dOs + lds_off<D>(rq + li, g * KS + ks))), vf[ks], dp);
+        }
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq + 4 * g);
+        const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq + 4 * g);
+        const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        float pr[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = kdead ? 0.f : fast_exp2(s[r] * p.scale_log2 - ll[r]);
+          ds[r] = pr[r] * (dp[r] - dd[r]);
+        }
+        pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
+        dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
+      }
+      u32x4 a4, b4;
+      a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
+      b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
+      const int r0 = 32 * qq + 4 * g + (li >> 2), r1 = r0 + 16;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+        const int c16 = colb >> 4, within = colb & 15;
+        const int o0 = r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within;
+        const int o1 = r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within;
+        dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), as_x8<E>(a4), dv[dt]);
+        dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), as_x8<E>(b4), dk[dt]);
+      }
+    }
+  }
+  if (kvalid) {
+    float fk[DQ], fv[DQ];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+    char* d1 = p.dk.p + (b * p.dk.sb + h * p.dk.sh + ktok * p.dk.sn + DQ * g) * 2;
+    char* d2 = p.dv.p + (b * p.dv.sb + h * p.dv.sh + ktok * p.dv.sn + DQ * g) * 2;
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) {
+      stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
+      stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
+    }
+  }
+}
+
+template <typename E, int D>
+static int launch_sm(int which, const SmP& p, hipStream_t st) {
+  const dim3 grid((unsigned)((long)p.B * p.H * ((p.N + 63) / 64))), block(256);
+  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D>), grid, block, 0, st, p);
+  else {
+    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D>), grid, block, 0, st, p);
+  }
+  return (int)hipGetLastError();
+}
+
+int softmax_dispatch(int which, const SmP& p, int dtype, int D, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (D == 64) return launch_sm<BF16, 64>(which, p, st);
+    if (D == 32) return launch_sm<BF16, 32>(which, p, st);
+    if (D == 128) return launch_sm<BF16, 128>(which, p, st);
+  } else if (dtype == EA_F16) {
+    if (D == 64) return launch_sm<F16, 64>(which, p, st);
+    if (D == 32) return launch_sm<F16, 32>(which, p, st);
+    if (D == 128) return launch_sm<F16, 128>(which, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

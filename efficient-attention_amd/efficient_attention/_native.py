@@ -37,6 +37,8 @@ class ea_lara_geom(ctypes.Structure):
 
 
 _P = ctypes.c_void_p
+_I = ctypes.c_int32
+_F = ctypes.c_float
 _G = ctypes.POINTER(ea_geom)
 _LG = ctypes.POINTER(ea_lara_geom)
 _T = ctypes.POINTER(ea_t4)
@@ -57,6 +59,8 @@ SIGNATURES = {
     "ea_lara_bwd_k": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_lara_bwd_kstats": [_LG, _T, _T] + [_P] * 8,
     "ea_lara_bwd_qcorr": [_LG, _T, _P, _P, _P, _T, _P],
+    "ea_softmax_attn_fwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _P, _P],
+    "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P],
     "ea_window_bias_ld": [_G],
     "ea_window_bwd_parts": [_G],
 }

@@ -23,6 +23,8 @@ KERNEL_ALGO_UNITS = {
     "ea_eva_chunk_mean_bwd": 4,   # read+write dq,dk
     "ea_eva_beta_fwd": 2,         # read k,v
     "ea_eva_beta_bwd": 6,         # read k,v; read+write dk,dv
+    "ea_softmax_attn_fwd": 4,     # read q,k,v; write out
+    "ea_softmax_attn_bwd": 8,     # read q,k,v,out,dout; write dq,dk,dv (two passes)
     "ea_lara_stats_fwd": 3,       # read q,k,v
     "ea_lara_out_fwd": 2,         # read q; write out
     "ea_lara_bwd_q": 3,           # read q,dout; write dq
@@ -381,3 +383,39 @@ def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode,
     else:
         lp = torch.logsumexp(_prm(mu, omega, scale), dim=-1)
     return LaraAttnFn.apply(qkv5, mask_u8, omega, qbar_rows, bhv, lp, mis, float(alpha_coeff))
+
+
+# ------------------------------------------------------------------------------------------
+# softmax baseline  (reference abstract_attention.py:120-133)
+# ------------------------------------------------------------------------------------------
+class SoftmaxAttnFn(torch.autograd.Function):
+    """out[B,N,h,d] = softmax(s QK^T, -inf on padded keys) V on a fused qkv tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv5, mask_u8):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        q, k, v = _qkv_views(qkv5)
+        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
+        lse = torch.empty((B * h, N), dtype=torch.float32, device=qkv5.device)
+        tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
+        nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(tq),
+                ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse), nv.stream())
+        ctx.save_for_backward(qkv5, mask_u8, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, mask_u8, out, lse = ctx.saved_tensors
+        B, N, _, h, d = qkv5.shape
+        dout = dout.contiguous()
+        dqkv5 = torch.empty_like(qkv5)
+        delta = torch.empty_like(lse)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
+        nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(ts[0]),
+                ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8), ctypes.byref(ts[3]),
+                ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
+                ctypes.byref(ts[7]), nv.stream())
+        return dqkv5, None

@@ -172,6 +172,18 @@ int ea_lara_bwd_kstats(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, co
 int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
                       const float* lse_t, const ea_t4* dq, void* stream);
 
+/* ---- softmax baseline (abstract_attention.py:120-133) ----------------------------------------
+ * out = softmax(s Q K^T, -inf on padded keys) V, streamed (no [N,N] matrix); attn_drop = 0.
+ * lse: fp32 [B*H, N] saved for backward; delta: fp32 [B*H, N] scratch (dO.O) written by the dQ
+ * pass and read by the dK/dV pass of ea_softmax_attn_bwd. */
+int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                        const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const ea_t4* out, float* lse, void* stream);
+int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                        const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
+                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
