@@ -172,6 +172,8 @@ static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
   if (g->C > 128) return EA_E_UNSUPPORTED;
   p.B = g->B; p.H = g->H; p.N = g->N; p.D = g->D; p.C = g->C; p.NCT = (g->C + 15) / 16;
   p.mis = g->mis; p.kappa = g->kappa; p.scale = g->scale; p.scale_log2 = g->scale * LOG2E;
+  p.norm_coef2 = 0.5f * g->scale * LOG2E;      // s |k|^2 / 2 in the log2 domain
+  p.knorm_coef = g->scale;
   const long bh = (long)g->B * g->H;
   const int gran = ypass ? 32 * lara_nsub(p.NCT) : 64;
   const int maxblk = (g->N + gran - 1) / gran;
@@ -332,6 +334,102 @@ int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtyp
   SM_SET(dq, dq); SM_SET(dk, dk); SM_SET(dv, dv);
   p.mask = mask; p.lse = const_cast<float*>(lse); p.delta = delta;
   return softmax_dispatch(1, p, dtype, D, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- Performer (FAVOR+) on the LARA skeletons ----
+static int fill_perf(const ea_perf_geom* g, LaraP& p, bool ypass) {
+  if (!g) return EA_E_BADARG;
+  ea_lara_geom lg;
+  lg.B = g->B; lg.H = g->H; lg.N = g->N; lg.D = g->D; lg.dtype = g->dtype; lg.C = g->M;
+  lg.mis = EA_MIS_BH; lg.kappa = 0.f;
+  lg.scale = 1.f / sqrtf(sqrtf((float)g->D));            // data_normalizer d^-1/4
+  int rc = fill_lara(&lg, p, ypass);
+  if (rc != EA_OK) return rc;
+  p.w_per_head = 1;
+  p.norm_coef2 = 0.5f * lg.scale * lg.scale * LOG2E;      // d^-1/2 |x|^2 / 2
+  p.knorm_coef = lg.scale * lg.scale;
+  p.ratio = 1.f / sqrtf((float)g->M);
+  p.feps = 1e-4f;
+  return EA_OK;
+}
+
+extern "C" {
+
+int32_t ea_performer_parts(const ea_perf_geom* g) {
+  LaraP p = {};
+  if (fill_perf(g, p, true) != EA_OK) return EA_E_BADARG;
+  return p.nsplit * lara_nsub(p.NCT);
+}
+
+int ea_performer_kmax(const ea_perf_geom* g, const ea_t4* k, const float* W, float* p_ml, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !W || !p_ml) return EA_E_BADARG;
+  p.k = mkl(k); p.omega = W; p.p_ml = p_ml;
+  return lara_y_dispatch(LY_PMAX, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_performer_kv(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* W, const float* stab, float* p_ml, float* p_kv, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !W || !stab || !p_ml || !p_kv) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.mask = mask; p.omega = W; p.stab = stab; p.p_ml = p_ml; p.p_acc0 = p_kv;
+  return lara_y_dispatch(LY_PKV, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_performer_out(const ea_perf_geom* g, const ea_t4* q, const float* W, const float* kv,
+                     const float* ksum, const ea_t4* out, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(out, g->D) || !W || !kv || !ksum) return EA_E_BADARG;
+  p.q = mkl(q); p.o = mkl(out); p.omega = W; p.kv = kv; p.cst = ksum;
+  return lara_x_dispatch(LX_POUT, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_performer_bwd_q(const ea_perf_geom* g, const ea_t4* q, const ea_t4* out, const ea_t4* dout,
+                       const float* W, const float* kv, const float* ksum, const ea_t4* dq,
+                       float* stabq, float* invden, float* dden, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(out, g->D) || !t4_ok(dout, g->D) || !t4_ok(dq, g->D) || !W || !kv ||
+      !ksum || !stabq || !invden || !dden) return EA_E_BADARG;
+  p.q = mkl(q); p.o = mkl(out); p.dout = mkl(dout); p.dq = mkl(dq); p.omega = W; p.kv = kv; p.cst = ksum;
+  p.lseZ = stabq; p.tmean = invden; p.rowdot = dden;
+  return lara_x_dispatch(LX_PBWDQ, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_performer_bwd_qstats(const ea_perf_geom* g, const ea_t4* q, const ea_t4* dout, const float* W,
+                            const float* stabq, const float* invden, const float* dden,
+                            float* p_ml, float* p_dkv, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, true);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, g->D) || !t4_ok(dout, g->D) || !W || !stabq || !invden || !dden || !p_ml || !p_dkv)
+    return EA_E_BADARG;
+  p.q = mkl(q); p.dout = mkl(dout); p.omega = W;
+  p.lseZ = const_cast<float*>(stabq); p.tmean = const_cast<float*>(invden); p.rowdot = const_cast<float*>(dden);
+  p.p_ml = p_ml; p.p_acc0 = p_dkv;
+  return lara_y_dispatch(LY_PBWDQ, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* W, const float* stab, const float* dkv, const float* dksum,
+                       const ea_t4* dk, const ea_t4* dv, void* stream) {
+  LaraP p = {};
+  int rc = fill_perf(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !W || !stab ||
+      !dkv || !dksum) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.dk = mkl(dk); p.dv = mkl(dv); p.mask = mask; p.omega = W; p.stab = stab;
+  p.dkv = dkv; p.rsum = dksum;
+  return lara_x_dispatch(LX_PBWDK, p, g->dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -21,8 +21,11 @@ struct T4l {
 };
 
 enum { MIS_OPT = 0, MIS_BIASED = 1, MIS_BH = 2 };
-enum { LX_FWD = 0, LX_BWDQ = 1, LX_BWDK = 2, LX_QCORR = 3 };
-enum { LY_FWD = 0, LY_BWDQ = 1, LY_BWDK = 2 };
+enum { LX_FWD = 0, LX_BWDQ = 1, LX_BWDK = 2, LX_QCORR = 3, LX_POUT = 4, LX_PBWDQ = 5, LX_PBWDK = 6 };
+enum { LY_FWD = 0, LY_BWDQ = 1, LY_BWDK = 2, LY_PMAX = 3, LY_PKV = 4, LY_PBWDQ = 5 };
+// The Performer baseline (kernelized_attention.py:20-56,116-121) runs on the same two skeletons
+// with the m random features W_j in the role of the landmark rows (modes LX_P*, LY_P*):
+//   phi(x)[j] = m^-1/2 exp(d^-1/4 W_j.x - d^-1/2 |x|^2/2 - stab) + 1e-4
 
 struct LaraP {
   T4l q, k, v, o, dout, dq, dk, dv;
@@ -41,6 +44,12 @@ struct LaraP {
   int nsplit;                   // Y: sequence splits per (b,h); X: blocks per (b,h)
   int tok_per_block;            // tokens handled by one block (multiple of 64)
   float kappa, scale, scale_log2;
+  // Performer: omega = W indexed per head, stab [BH] key stabiliser (natural units)
+  int w_per_head;
+  const float* stab;
+  float norm_coef2;             // log2-domain coefficient of |x|^2 in the logits
+  float knorm_coef;             // coefficient of x * (sum of logit grads) in dk / dq
+  float ratio, feps;
 };
 
 // ---- the elementwise core of the estimator (lara.py:221-243), one (c, n) entry -------------

@@ -71,20 +71,22 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
   const int bh = blockIdx.x / p.nsplit, blk = blockIdx.x - bh * p.nsplit;
   const int b = bh / p.H, h = bh - b * p.H;
   const size_t lm = (size_t)bh * p.C;               // landmark row offset
-  const bool use_t = p.mis != MIS_BH;
+  const size_t lmw = (size_t)(p.w_per_head ? h : bh) * p.C;   // ... of omega / W
+  constexpr bool PERF = MODE >= LX_POUT;
+  const bool use_t = p.mis != MIS_BH && !PERF;
 
-  if (MODE != LX_QCORR) stage_rows<E, D>(R1, p.omega + lm * D, p.C, Cp, tid);
+  if (MODE != LX_QCORR) stage_rows<E, D>(R1, p.omega + lmw * D, p.C, Cp, tid);
   if (MODE != LX_BWDK && use_t) stage_rows<E, D>(R2, p.qbar + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDQ) stage_rows<E, D>(R3, p.kv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDK) stage_rows<E, D>(R3, p.dkv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_FWD) stage_cols<E, D>(M1, p.kv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDQ) {
-    stage_cols<E, D>(M1, p.omega + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDQ || MODE == LX_PBWDQ) stage_rows<E, D>(R3, p.kv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDK || MODE == LX_PBWDK) stage_rows<E, D>(R3, p.dkv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_FWD || MODE == LX_POUT) stage_cols<E, D>(M1, p.kv + lm * D, p.C, Cp, tid);
+  if (MODE == LX_BWDQ || MODE == LX_PBWDQ) {
+    stage_cols<E, D>(M1, p.omega + lmw * D, p.C, Cp, tid);
     if (use_t) stage_cols<E, D>(M2, p.qbar + lm * D, p.C, Cp, tid);
   }
-  if (MODE == LX_BWDK) {
+  if (MODE == LX_BWDK || MODE == LX_PBWDK) {
     stage_cols<E, D>(M1, p.dkv + lm * D, p.C, Cp, tid);
-    stage_cols<E, D>(M2, p.omega + lm * D, p.C, Cp, tid);
+    stage_cols<E, D>(M2, p.omega + lmw * D, p.C, Cp, tid);
   }
   if (MODE == LX_QCORR) stage_cols<E, D>(M1, p.uq + lm * D, p.C, Cp, tid);
 
@@ -109,13 +111,18 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
           dkk[ct][r] = p.dkk[lm + c];
           rs[ct][r] = p.rsum[lm + c];
         }
+        if (MODE == LX_POUT || MODE == LX_PBWDQ) cst2[ct][r] = p.cst[lm + c];      // sum_n phi(k_n)[j]
+        if (MODE == LX_PBWDK) rs[ct][r] = p.rsum[lm + c];                          // d ksum[j]
       }
     }
+  const float stabk2 = (MODE == LX_PBWDK) ? p.stab[bh] * LOG2E : 0.f;
   __syncthreads();
 
-  const T4l& tk1 = (MODE == LX_BWDK) ? p.k : p.q;
+  constexpr bool KEYS = MODE == LX_BWDK || MODE == LX_PBWDK;
+  constexpr bool TWO_TOK = MODE == LX_BWDQ || MODE == LX_BWDK || MODE == LX_PBWDQ || MODE == LX_PBWDK;
+  const T4l& tk1 = KEYS ? p.k : p.q;
   const char* t1b = tk1.p + (b * tk1.sb + h * tk1.sh) * 2;
-  const T4l& tk2 = (MODE == LX_BWDK) ? p.v : p.dout;
+  const T4l& tk2 = KEYS ? p.v : p.dout;
   const char* t2b = tk2.p ? tk2.p + (b * tk2.sb + h * tk2.sh) * 2 : nullptr;
   const float invC = 1.f / (float)p.C;
   const int n0 = blk * p.tok_per_block;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
       u32x4 w1 = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
       if (valid) {
         w1 = ldg16(t1b + (tok * tk1.sn + (g * KS + ks) * 8) * 2);
-        if (MODE == LX_BWDQ || MODE == LX_BWDK) w2 = ldg16(t2b + (tok * tk2.sn + (g * KS + ks) * 8) * 2);
+        if (TWO_TOK) w2 = ldg16(t2b + (tok * tk2.sn + (g * KS + ks) * 8) * 2);
       }
       raw1[ks] = w1;
       f1[ks] = as_x8<E>(w1);
@@ -147,12 +154,12 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
       for (int ks = 0; ks < KS; ++ks) {
         if (MODE != LX_QCORR) a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
         if (MODE != LX_BWDK && use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt[ct]);
-        if (MODE == LX_BWDQ || MODE == LX_BWDK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+        if (TWO_TOK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
     // ---- elementwise stage -> weight tiles w1 (x M1) and w2 (x M2) ----
     float w1[NCT][4], w2[NCT][4];
-    float sdb = 0.f;
+    float sdb = 0.f, pden = 1.f;
     if (MODE == LX_FWD || MODE == LX_BWDQ) {
       float tl = 0.f;
       if (p.mis == MIS_OPT) {
@@ -221,6 +228,90 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
           p.sda[o] = sda;
         }
       }
+    } else if (PERF) {
+      // squared norm of this token (lane holds D/4 channels) -> log2-domain diagonal term
+      float nrm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float xf[8];
+        unpack8<E>(raw1[ks], xf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nrm += xf[i] * xf[i];
+      }
+      const float diag2 = p.norm_coef2 * quad_sum(nrm);
+      float stab2 = stabk2;
+      if (MODE != LX_PBWDK) {                       // queries: stabiliser = max over features
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ct * 16 + 4 * g + r < p.C) mx = fmaxf(mx, a[ct][r] * p.scale_log2);
+        stab2 = quad_max(mx);
+      }
+      const bool dead = (MODE == LX_PBWDK) && (!valid || (p.mask && p.mask[(size_t)b * p.N + (valid ? tok : 0)]));
+      float phi[NCT][4];
+      float den = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = ct * 16 + 4 * g + r < p.C;
+          phi[ct][r] = (ok && !dead) ? p.ratio * fast_exp2(a[ct][r] * p.scale_log2 - diag2 - stab2) + p.feps : 0.f;
+          if (MODE != LX_PBWDK && ok) den += phi[ct][r] * cst2[ct][r];
+        }
+      if (MODE == LX_POUT) {
+        den = quad_sum(den);
+        pden = 1.f / fmaxf(den, 1e-2f);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w1[ct][r] = phi[ct][r];
+      } else if (MODE == LX_PBWDQ) {
+        den = quad_sum(den);
+        const float invden = 1.f / fmaxf(den, 1e-2f);
+        // dout . out in the B-fragment layout
+        float dd = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          u32x4 ow = {0u, 0u, 0u, 0u};
+          if (valid) ow = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + (g * KS + ks) * 8) * 2);
+          float x8[8], y8[8];
+          unpack8<E>(ow, x8);
+          unpack8<E>(__builtin_bit_cast(u32x4, f2[ks]), y8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dd += x8[i] * y8[i];
+        }
+        dd = quad_sum(dd);
+        const float dden = den > 1e-2f ? -dd * invden : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = ct * 16 + 4 * g + r < p.C;
+            const float dphi = dw[ct][r] * invden + cst2[ct][r] * dden;
+            const float dz = ok ? dphi * (phi[ct][r] - p.feps) : 0.f;
+            w1[ct][r] = dz;
+            sdb += dz;
+          }
+        sdb = quad_sum(sdb);
+        if (valid && g == 0) {
+          const size_t o = (size_t)bh * p.N + tok;
+          p.lseZ[o] = stab2; p.tmean[o] = invden; p.rowdot[o] = dden;
+        }
+      } else {   // LX_PBWDK
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = ct * 16 + 4 * g + r < p.C;
+            const float dz = (ok && !dead) ? (dw[ct][r] + rs[ct][r]) * (phi[ct][r] - p.feps) : 0.f;
+            w1[ct][r] = phi[ct][r];
+            w2[ct][r] = dz;
+            sdb += dz;
+          }
+        sdb = quad_sum(sdb);
+      }
     } else if (MODE == LX_QCORR) {
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
@@ -257,7 +348,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
     f32x4 acc2[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc2[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool two = (MODE == LX_BWDK) || (MODE == LX_BWDQ && use_t);
+    const bool two = (MODE == LX_BWDK) || (MODE == LX_PBWDK) || (MODE == LX_BWDQ && use_t);
 #pragma unroll
     for (int kk = 0; kk < NCT / 2; ++kk) {
       u32x4 p1, p2;
@@ -279,7 +370,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
           const char* r2 = M2 + drow * MT_LDB;
           const u32x2 lo2 = *reinterpret_cast<const u32x2*>(r2 + c0);
           const u32x2 hi2 = *reinterpret_cast<const u32x2*>(r2 + c0 + 32);
-          if (MODE == LX_BWDK) acc2[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc2[dt]);
+          if (KEYS) acc2[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc2[dt]);
           else acc[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc[dt]);
         }
       }
@@ -287,11 +378,11 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
     if (!valid) continue;
     // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` ----
     float f[DQ];
-    if (MODE == LX_FWD) {
+    if (MODE == LX_FWD || MODE == LX_POUT) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * pden;
       char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2;
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
@@ -303,6 +394,19 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
       char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    } else if (MODE == LX_PBWDQ) {
+      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float qf8[8], o8[8];
+        unpack8<E>(raw1[ks], qf8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = 8 * ks + i;
+          o8[i] = p.scale * acc[j >> 2][j & 3] - p.knorm_coef * qf8[i] * sdb;
+        }
+        stg16(dst + ks * 16, pack8<E>(o8));
+      }
     } else if (MODE == LX_QCORR) {
       char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
 #pragma unroll
@@ -332,7 +436,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int j = 8 * ks + i;
-          o8[i] = p.scale * (acc2[j >> 2][j & 3] - kf[i] * sdb);
+          o8[i] = p.scale * acc2[j >> 2][j & 3] - p.knorm_coef * kf[i] * sdb;
         }
         stg16(dstk + ks * 16, pack8<E>(o8));
       }
@@ -363,6 +467,9 @@ static int launch_x(int mode, const LaraP& p, hipStream_t st) {
     case LX_BWDQ: EA_LX(LX_BWDQ); break;
     case LX_BWDK: EA_LX(LX_BWDK); break;
     case LX_QCORR: EA_LX(LX_QCORR); break;
+    case LX_POUT: EA_LX(LX_POUT); break;
+    case LX_PBWDQ: EA_LX(LX_PBWDQ); break;
+    case LX_PBWDK: EA_LX(LX_PBWDK); break;
     default: return EA_E_BADARG;
   }
 #undef EA_LX

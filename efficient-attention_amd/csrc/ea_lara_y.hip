@@ -52,14 +52,18 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
   const int c = ct * 16 + li;
   const bool c_ok = active && c < p.C;
   const size_t lm = (size_t)bh * p.C;
+  const size_t lmw = (size_t)(p.w_per_head ? h : bh) * p.C;
   const float invC = 1.f / (float)p.C;
+  constexpr bool PERF = MODE >= LY_PMAX;
 
   typename E::x8 r1f[KS], r2f[KS], r3f[KS];
-  load_lm_frag<E, D>(r1f, p.omega + (lm + (c_ok ? c : 0)) * D, c_ok, g);
-  const bool use_t = p.mis != MIS_BH && MODE != LY_BWDK;
+  load_lm_frag<E, D>(r1f, p.omega + (lmw + (c_ok ? c : 0)) * D, c_ok, g);
+  const bool use_t = p.mis != MIS_BH && MODE != LY_BWDK && !PERF;
   load_lm_frag<E, D>(r2f, use_t ? p.qbar + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && use_t, g);
   const float* r3src = MODE == LY_BWDQ ? p.kv : p.dkv;
-  load_lm_frag<E, D>(r3f, MODE == LY_FWD ? p.omega : r3src + (lm + (c_ok ? c : 0)) * D, c_ok && MODE != LY_FWD, g);
+  constexpr bool HAS_R3 = MODE == LY_BWDQ || MODE == LY_BWDK;
+  load_lm_frag<E, D>(r3f, HAS_R3 ? r3src + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && HAS_R3, g);
+  const float stabk2 = (MODE == LY_PKV) ? p.stab[bh] * LOG2E : 0.f;
   float cst2 = -INFINITY, lset2 = INFINITY, bhc = 1.f, lsek2 = INFINITY, dkkc = 0.f, rsc = 0.f;
   if (c_ok) {
     if (MODE == LY_BWDQ) {
@@ -80,10 +84,10 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
   float s_r = 0.f, s_dbh = 0.f, s_u = 0.f;
 
   for (int phase = 0; phase < nphase; ++phase) {
-    const bool keys = (MODE == LY_FWD && phase == 0) || MODE == LY_BWDK;
+    const bool keys = (MODE == LY_FWD && phase == 0) || MODE == LY_BWDK || MODE == LY_PMAX || MODE == LY_PKV;
     const T4l& a1 = keys ? p.k : p.q;
     const T4l& a2 = keys ? p.v : p.dout;
-    const bool need2 = !(MODE == LY_FWD && phase == 1);
+    const bool need2 = !(MODE == LY_FWD && phase == 1) && MODE != LY_PMAX;
     const char* a1b = a1.p + (b * a1.sb + h * a1.sh) * 2;
     const char* a2b = need2 ? a2.p + (b * a2.sb + h * a2.sh) * 2 : nullptr;
     for (int cb = n0; cb < n1; cb += chunk) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
         }
         sts16(T1 + lds_off<D>(row, cc), w1);
         if (need2) sts16(T2 + lds_off<D>(row, cc), w2);
-        if (keys) {
+        if (keys || MODE == LY_PBWDQ) {
           float f[8], part = 0.f;
           unpack8<E>(w1, f);
 #pragma unroll
@@ -108,8 +112,17 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
 #pragma unroll
           for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
           if (cc == 0) {
-            const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + tok]);
-            sc[row] = dead ? -INFINITY : -0.5f * p.scale_log2 * part;
+            if (MODE == LY_PMAX) {
+              sc[row] = valid ? 0.f : -INFINITY;          // stabiliser: max over ALL keys, no diagonal term
+            } else if (MODE == LY_PBWDQ) {
+              const size_t o = (size_t)bh * p.N + (valid ? tok : 0);
+              sc[row] = valid ? -p.norm_coef2 * part - p.lseZ[o] : -INFINITY;
+              sc[chunk + row] = valid ? p.tmean[o] : 0.f;        // 1 / clamp(den)
+              sc[2 * chunk + row] = valid ? p.rowdot[o] : 0.f;   // d den
+            } else {
+              const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + tok]);
+              sc[row] = dead ? -INFINITY : -p.norm_coef2 * part;
+            }
           }
         } else if (MODE == LY_FWD) {
           if (cc == 0) sc[row] = valid ? 0.f : -INFINITY;
@@ -133,9 +146,9 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const typename E::x8 ta = as_x8<E>(lds16(T1 + lds_off<D>(row, g * KS + ks)));
-          if (keys || MODE == LY_BWDQ) s1 = E::mma(ta, r1f[ks], s1);
+          if (keys || MODE == LY_BWDQ || MODE == LY_PBWDQ) s1 = E::mma(ta, r1f[ks], s1);
           if (!keys && use_t) s2 = E::mma(ta, r2f[ks], s2);
-          if (MODE != LY_FWD) s3 = E::mma(as_x8<E>(lds16(T2 + lds_off<D>(row, g * KS + ks))), r3f[ks], s3);
+          if (HAS_R3) s3 = E::mma(as_x8<E>(lds16(T2 + lds_off<D>(row, g * KS + ks))), r3f[ks], s3);
         }
         const int r0 = rb + 16 * mt + 4 * g;
 #pragma unroll
@@ -147,6 +160,18 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
           } else if (MODE == LY_BWDK) {
             const float pk = fast_exp2(s1[r] * p.scale_log2 + sc[r0 + r] - lsek2);
             w0[mt][r] = pk * (s3[r] - dkkc + rsc);
+          } else if (MODE == LY_PMAX) {
+            if (c_ok) mloc = fmaxf(mloc, s1[r] * p.scale_log2 + sc[r0 + r]);
+          } else if (MODE == LY_PKV) {
+            const float sr = sc[r0 + r];
+            const float phi = (c_ok && sr != -INFINITY) ? p.ratio * fast_exp2(s1[r] * p.scale_log2 + sr - stabk2) + p.feps : 0.f;
+            w0[mt][r] = phi;
+            s_r += phi;
+          } else if (MODE == LY_PBWDQ) {
+            const float sr = sc[r0 + r];
+            const float phi = (c_ok && sr != -INFINITY) ? p.ratio * fast_exp2(s1[r] * p.scale_log2 + sr) + p.feps : 0.f;
+            w0[mt][r] = phi * sc[chunk + r0 + r];
+            s_r += phi * sc[2 * chunk + r0 + r];
           } else {   // LY_BWDQ
             const float lz2 = sc[r0 + r], tm = sc[chunk + r0 + r], rd = sc[2 * chunk + r0 + r], sd = sc[3 * chunk + r0 + r];
             const LaraElem e = lara_alpha(p.mis, s2[r] * p.scale_log2, lset2, bhc, p.kappa, tm);
@@ -193,6 +218,8 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
             acc0[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf), acc0[dt]);
           }
         }
+      } else if (MODE == LY_PMAX) {
+        m_k = fmaxf(m_k, quad_max(mloc));
       } else {
         u32x4 f0, f1, f2, f3;
 #define EA_PK(dst, src)                                                                     \
@@ -209,6 +236,8 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
           const int ob = rb2 * ROWB + ((c16 ^ (rb2 & SW)) << 4) + within;
           if (MODE == LY_BWDK) {
             acc0[dt] = E::mma(as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob)), as_x8<E>(f0), acc0[dt]);
+          } else if (MODE == LY_PKV || MODE == LY_PBWDQ) {
+            acc0[dt] = E::mma(as_x8<E>(E::tr4(T2 + oa), E::tr4(T2 + ob)), as_x8<E>(f0), acc0[dt]);
           } else {
             const typename E::x8 dot = as_x8<E>(E::tr4(T2 + oa), E::tr4(T2 + ob));
             const typename E::x8 qt = as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob));
@@ -235,6 +264,12 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
   } else if (MODE == LY_BWDQ) {
     s_r = quad_sum(s_r); s_dbh = quad_sum(s_dbh); s_u = quad_sum(s_u);
     if (g == 0) { ml[0] = s_r; ml[1] = s_dbh; ml[2] = s_u; ml[3] = 0.f; }
+  } else if (MODE == LY_PMAX) {
+    if (g == 0) { ml[0] = m_k * LN2; ml[1] = 0.f; ml[2] = 0.f; ml[3] = 0.f; }
+    return;
+  } else if (PERF) {
+    s_r = quad_sum(s_r);
+    if (g == 0) { ml[0] = s_r; ml[1] = 0.f; ml[2] = 0.f; ml[3] = 0.f; }
   }
   auto put = [&](float* base, const f32x4* a) {
     float* d = base + slot * D + DQ * g;
@@ -258,6 +293,9 @@ static int launch_y(int mode, const LaraP& p, hipStream_t st) {
     case LY_FWD: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_FWD>), grid, block, lds, st, p); break;
     case LY_BWDQ: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDQ>), grid, block, lds, st, p); break;
     case LY_BWDK: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDK>), grid, block, lds, st, p); break;
+    case LY_PMAX: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PMAX>), grid, block, lds, st, p); break;
+    case LY_PKV: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PKV>), grid, block, lds, st, p); break;
+    case LY_PBWDQ: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PBWDQ>), grid, block, lds, st, p); break;
     default: return EA_E_BADARG;
   }
   return (int)hipGetLastError();

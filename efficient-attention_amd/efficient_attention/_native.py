@@ -30,6 +30,11 @@ class ea_geom(ctypes.Structure):
                 ("scale", ctypes.c_float)]
 
 
+class ea_perf_geom(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("M", ctypes.c_int32)]
+
+
 class ea_lara_geom(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("C", ctypes.c_int32),
@@ -41,6 +46,7 @@ _I = ctypes.c_int32
 _F = ctypes.c_float
 _G = ctypes.POINTER(ea_geom)
 _LG = ctypes.POINTER(ea_lara_geom)
+_PG = ctypes.POINTER(ea_perf_geom)
 _T = ctypes.POINTER(ea_t4)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
@@ -59,6 +65,13 @@ SIGNATURES = {
     "ea_lara_bwd_k": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_lara_bwd_kstats": [_LG, _T, _T] + [_P] * 8,
     "ea_lara_bwd_qcorr": [_LG, _T, _P, _P, _P, _T, _P],
+    "ea_performer_parts": [_PG],
+    "ea_performer_kmax": [_PG, _T, _P, _P, _P],
+    "ea_performer_kv": [_PG, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_performer_out": [_PG, _T, _P, _P, _P, _T, _P],
+    "ea_performer_bwd_q": [_PG, _T, _T, _T, _P, _P, _P, _T, _P, _P, _P, _P],
+    "ea_performer_bwd_qstats": [_PG, _T, _T, _P, _P, _P, _P, _P, _P, _P],
+    "ea_performer_bwd_k": [_PG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_softmax_attn_fwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _P, _P],
     "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P],
     "ea_window_bias_ld": [_G],

@@ -25,6 +25,12 @@ KERNEL_ALGO_UNITS = {
     "ea_eva_beta_bwd": 6,         # read k,v; read+write dk,dv
     "ea_softmax_attn_fwd": 4,     # read q,k,v; write out
     "ea_softmax_attn_bwd": 8,     # read q,k,v,out,dout; write dq,dk,dv (two passes)
+    "ea_performer_kmax": 1,       # read k
+    "ea_performer_kv": 2,         # read k,v
+    "ea_performer_out": 2,        # read q; write out
+    "ea_performer_bwd_q": 4,      # read q,out,dout; write dq
+    "ea_performer_bwd_qstats": 2, # read q,dout
+    "ea_performer_bwd_k": 4,      # read k,v; write dk,dv
     "ea_lara_stats_fwd": 3,       # read q,k,v
     "ea_lara_out_fwd": 2,         # read q; write out
     "ea_lara_bwd_q": 3,           # read q,dout; write dq
@@ -419,3 +425,71 @@ class SoftmaxAttnFn(torch.autograd.Function):
                 ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
                 ctypes.byref(ts[7]), nv.stream())
         return dqkv5, None
+
+
+# ------------------------------------------------------------------------------------------
+# Performer / FAVOR+  (reference kernelized_attention.py:20-56,116-121,326-346)
+# ------------------------------------------------------------------------------------------
+class PerformerAttnFn(torch.autograd.Function):
+    """out[B,N,h,d] = phi(q) (phi(k)^T v) / clamp(phi(q) . sum phi(k), 1e-2) with positive random
+    features W [h, m, d] (no gradient to W: the default sample scheme redraws / fixes it)."""
+
+    @staticmethod
+    def forward(ctx, qkv5, mask_u8, W):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        m = W.shape[1]
+        BH, dev = B * h, qkv5.device
+        W = W.float().contiguous()
+        geom = nv.ea_perf_geom(B, h, N, d, nv.io_dtype(qkv5), m)
+        q, k, v = _qkv_views(qkv5)
+        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+        S = nv.lib().ea_performer_parts(ctypes.byref(geom))
+        p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
+        nv.call("ea_performer_kmax", ctypes.byref(geom), ctypes.byref(tk), nv.ptr(W), nv.ptr(p_ml), nv.stream())
+        stab = p_ml[..., 0].amax((1, 2)).contiguous()                     # [BH]
+        p_kv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+        nv.call("ea_performer_kv", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(W), nv.ptr(stab), nv.ptr(p_ml), nv.ptr(p_kv), nv.stream())
+        kv = p_kv.sum(1).contiguous()                                     # [BH, m, d]
+        ksum = p_ml[..., 0].sum(1).contiguous()                           # [BH, m]
+        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+        to = nv.t4(out.permute(0, 2, 1, 3))
+        nv.call("ea_performer_out", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(W), nv.ptr(kv), nv.ptr(ksum),
+                ctypes.byref(to), nv.stream())
+        ctx.save_for_backward(qkv5, mask_u8, W, stab, kv, ksum, out)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, mask_u8, W, stab, kv, ksum, out = ctx.saved_tensors
+        geom = ctx.geom
+        B, N, _, h, d = qkv5.shape
+        m, BH, dev = geom.M, B * h, qkv5.device
+        dout = dout.contiguous()
+        dqkv5 = torch.empty_like(qkv5)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+        to, tdo = nv.t4(out.permute(0, 2, 1, 3)), nv.t4(dout.permute(0, 2, 1, 3))
+        tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
+        tok = torch.empty((3, BH, N), dtype=torch.float32, device=dev)
+        nv.call("ea_performer_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(to), ctypes.byref(tdo),
+                nv.ptr(W), nv.ptr(kv), nv.ptr(ksum), ctypes.byref(tdq), nv.ptr(tok[0]), nv.ptr(tok[1]),
+                nv.ptr(tok[2]), nv.stream())
+        S = nv.lib().ea_performer_parts(ctypes.byref(geom))
+        p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
+        p_dkv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+        nv.call("ea_performer_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(W),
+                nv.ptr(tok[0]), nv.ptr(tok[1]), nv.ptr(tok[2]), nv.ptr(p_ml), nv.ptr(p_dkv), nv.stream())
+        dkv = p_dkv.sum(1).contiguous()
+        dksum = p_ml[..., 0].sum(1).contiguous()
+        nv.call("ea_performer_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(W), nv.ptr(stab), nv.ptr(dkv), nv.ptr(dksum), ctypes.byref(tdk), ctypes.byref(tdv),
+                nv.stream())
+        return dqkv5, None, None
+
+
+def performer_attention(qkv5, mask_u8, proj):
+    return PerformerAttnFn.apply(qkv5, mask_u8, proj)

@@ -184,6 +184,35 @@ int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtyp
                         const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
                         const ea_t4* dq, const ea_t4* dk, const ea_t4* dv, void* stream);
 
+/* ---- Performer / FAVOR+ baseline (kernelized_attention.py:20-56,116-121,326-346) ---------------
+ * phi(x)[j] = M^-1/2 exp(d^-1/4 W_j.x - d^-1/2 |x|^2/2 - stab) + 1e-4 with W fp32 [H, M, D] (fresh
+ * Gaussian features per training call, `eval_proj` otherwise); stab = max_j for queries, the max
+ * over all keys and features of one (b,h) for keys (detached); phi(k) is zeroed at padded keys.
+ *   kv[j] = sum_n phi(k_n)[j] v_n,  ksum[j] = sum_n phi(k_n)[j]
+ *   out_n = phi(q_n).kv / max(phi(q_n).ksum, 1e-2)
+ * Sequence-wide sums come back as partials over S = ea_performer_parts(g) slices (p_ml[...,0] holds
+ * the scalar per feature: max of d^-1/4 W_j.k_n for kmax, ksum for kv, d(ksum) for bwd_qstats). */
+typedef struct {
+  int32_t B, H, N, D;
+  int32_t dtype;
+  int32_t M;                 /* number of random features (approx_attn_dim), <= 128 */
+} ea_perf_geom;
+int32_t ea_performer_parts(const ea_perf_geom* g);
+int ea_performer_kmax(const ea_perf_geom* g, const ea_t4* k, const float* W, float* p_ml, void* stream);
+int ea_performer_kv(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* W, const float* stab, float* p_ml, float* p_kv, void* stream);
+int ea_performer_out(const ea_perf_geom* g, const ea_t4* q, const float* W, const float* kv,
+                     const float* ksum, const ea_t4* out, void* stream);
+int ea_performer_bwd_q(const ea_perf_geom* g, const ea_t4* q, const ea_t4* out, const ea_t4* dout,
+                       const float* W, const float* kv, const float* ksum, const ea_t4* dq,
+                       float* stabq, float* invden, float* dden, void* stream);
+int ea_performer_bwd_qstats(const ea_perf_geom* g, const ea_t4* q, const ea_t4* dout, const float* W,
+                            const float* stabq, const float* invden, const float* dden,
+                            float* p_ml, float* p_dkv, void* stream);
+int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* W, const float* stab, const float* dkv, const float* dksum,
+                       const ea_t4* dk, const ea_t4* dv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
