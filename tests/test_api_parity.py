@@ -1,0 +1,114 @@
+"""-m "not gpu": the drop-in surface -- factory names, constructor kwargs,
+state_dict keys/shapes, buffers, argparse flags/defaults/prefix nesting -- and loud failure of the
+attention cores without a GPU tensor (no CPU fallback)."""
+import argparse
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import efficient_attention as ea
+from util import Fixture
+
+
+def build(case):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ea.AttentionFactory.build_attention(case["attn"], dict(case["args"]))
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_state_dict_matches_reference(name):
+    fx = Fixture(name)
+    mod = build(fx.case)
+    sd = mod.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == fx.key_shapes
+    if "relative_position_index" in fx.z.files:
+        assert np.array_equal(sd["relative_position_index"].numpy(), fx.z["relative_position_index"])
+    # a reference checkpoint loads strictly
+    new = {k: (torch.from_numpy(fx.params_np[k]) if k in fx.params_np else v) for k, v in sd.items()}
+    mod.load_state_dict(new, strict=True)
+
+
+def test_factory_names_and_errors():
+    assert set(ea.AttentionFactory.attn_dict) == {"performer", "softmax", "local", "lara", "ra",
+                                                  "scatterbrain", "eva", "causal_eva"}
+    with pytest.raises(KeyError):
+        ea.AttentionFactory.build_attention("nope", {})
+    with pytest.raises(TypeError):
+        ea.AttentionFactory.build_attention("softmax", dict(dim=64, num_heads=2, bogus=1))
+    with pytest.raises(NotImplementedError):
+        ea.AttentionFactory.build_attention("eva", dict(dim=64, num_heads=2, use_rpe=True, use_t5_rpe=True,
+                                                        window_size=4))
+    for name in ("ra", "scatterbrain", "causal_eva"):
+        with pytest.raises(NotImplementedError):
+            ea.AttentionFactory.build_attention(name, dict(dim=64, num_heads=2))
+
+
+DEFAULTS = {
+    "softmax": dict(fp32=False),
+    "local": dict(fp32=False, use_rpe=False, window_size=4, attn_2d=False, overlap_window=False),
+    "eva": dict(fp32=False, use_rpe=False, window_size=4, attn_2d=False, overlap_window=False,
+                adaptive_proj="default", num_landmarks=49, use_t5_rpe=False),
+    "lara": dict(fp32=False, num_landmarks=49, kernel_size=None, pool_module_type="light", mis_type="mis-opt",
+                 proposal_gen="pool", use_antithetics=False, use_multisample=False, alpha_coeff=1.0),
+    "performer": dict(fp32=False, approx_attn_dim=64, proj_method="favorp", cos_weighting=False,
+                      sample_scheme="default"),
+}
+
+
+@pytest.mark.parametrize("attn", list(DEFAULTS))
+def test_argparse_defaults_and_nesting(attn):
+    parser = argparse.ArgumentParser()
+    parser = ea.AttentionFactory.add_attn_specific_args(parser, attn)
+    args = parser.parse_args([], namespace=ea.NestedNamespace())
+    assert vars(args.attn_args) == DEFAULTS[attn]
+    # the kwargs the call sites build (efficient_vit.py:175-184) construct the module
+    kw = dict(vars(args.attn_args), dim=64, num_heads=2, qkv_bias=True, attn_drop=0.0, proj_drop=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ea.AttentionFactory.build_attention(attn, kw)
+
+
+def test_argparse_prefix_like_fairseq():
+    parser = argparse.ArgumentParser()
+    ea.AttentionFactory.add_attn_specific_args(parser, "eva", struct_name="attn_args_encoder", prefix="encoder-attn")
+    ea.AttentionFactory.add_attn_specific_args(parser, "lara", struct_name="attn_args_decoder", prefix="decoder-attn")
+    args = parser.parse_args(["--encoder-attn-window-size", "8", "--encoder-attn-use-t5-rpe",
+                              "--decoder-attn-alpha-coeff", "2.0"], namespace=ea.NestedNamespace())
+    assert args.attn_args_encoder.window_size == 8 and args.attn_args_encoder.use_t5_rpe is True
+    assert args.attn_args_encoder.num_landmarks == 49
+    assert args.attn_args_decoder.alpha_coeff == 2.0 and args.attn_args_decoder.mis_type == "mis-opt"
+
+
+def test_remove_argument_and_helpers():
+    parser = argparse.ArgumentParser()
+    ea.add_nested_argument(parser, "--window-size", default=3, type=int)
+    ea.remove_argument(parser, "--window-size")
+    assert parser.parse_args([], namespace=ea.NestedNamespace()).__dict__ == {}
+    assert ea.remove_prefix("--enc-x", "--enc-") == "x" and ea.remove_prefix("abc", "zz") == "abc"
+
+
+@pytest.mark.parametrize("attn", ["softmax", "local", "eva", "lara", "performer"])
+def test_no_cpu_fallback(attn):
+    """A CPU tensor must never be silently computed by something else."""
+    args = dict(dim=64, num_heads=2)
+    if attn in ("local", "eva"):
+        args.update(window_size=4, num_landmarks=4) if attn == "eva" else args.update(window_size=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mod = ea.AttentionFactory.build_attention(attn, args).eval()
+    x = torch.randn(2, 16, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mod(x)
+
+
+def test_product_package_does_not_import_oracle():
+    import os
+    pkg = os.path.dirname(ea.__file__)
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,86 @@
+"""-m "not gpu": the N > 1 path on CPU -- two gloo ranks, one process per rank, rendezvous on
+127.0.0.1.  The attention path shards over the batch with no data-path collective;
+the only exchange is the parameter-gradient all-reduce of DistributedDataParallel.  The product
+module supplies the parameters (every one must receive a gradient on every rank, as DDP
+requires); its forward is stood in for by the oracle on CPU, since the HIP cores need a GPU.
+Checked: DDP-averaged gradients of the two half-batches == gradients of the full batch."""
+import os
+import socket
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+
+CASES = {
+    "eva": dict(dim=64, num_heads=2, window_size=7, attn_2d=True, use_rpe=True, num_landmarks=4),
+    "lara": dict(dim=64, num_heads=2, num_landmarks=4, proposal_gen="pool-mixed", mis_type="mis-opt",
+                 alpha_coeff=2.0),
+}
+
+
+class OracleBacked(torch.nn.Module):
+    """Product module's parameters + the oracle's CPU forward (test stand-in for the HIP cores)."""
+
+    def __init__(self, attn, args, inner):
+        super().__init__()
+        self.attn, self.args, self.inner = attn, args, inner
+
+    def forward(self, x):
+        params = dict(self.inner.named_parameters())
+        params.update(dict(self.inner.named_buffers()))
+        return oracle.module_forward(self.attn, self.args, params, x, None, training=False)
+
+
+def _build(attn):
+    import efficient_attention as ea
+    torch.manual_seed(7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        inner = ea.AttentionFactory.build_attention(attn, dict(CASES[attn]))
+    with torch.no_grad():                       # make zero-initialised biases/tables matter
+        for p in inner.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    return OracleBacked(attn, CASES[attn], inner)
+
+
+def _worker(rank, world, port, attn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        model = _build(attn)
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        torch.manual_seed(123)
+        x = torch.randn(4, 14, 14, 64)
+        g = torch.randn(4, 14, 14, 64)
+        shard = slice(rank * 2, rank * 2 + 2)                     # weak-scaling style batch shard
+        (ddp(x[shard]) * g[shard]).sum().backward()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if rank == 0:
+            ref = _build(attn)
+            (ref(x) * g).sum().backward()
+            worst = 0.0
+            for k, p in ref.named_parameters():
+                assert p.grad is not None, k
+                full = p.grad / world                             # DDP averages over ranks
+                err = (grads[k] - full).abs().max().item() / max(full.abs().max().item(), 1e-12)
+                worst = max(worst, err)
+            ret["worst"] = worst
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("attn", list(CASES))
+def test_two_rank_gloo_ddp_matches_full_batch(attn):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, attn, ret), nprocs=2, join=True)
+        assert ret["worst"] < 1e-4, dict(ret)

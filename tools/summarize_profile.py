@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory (gpurun_out/prof_<tag>_<attn>) into the small,
+committed files under profiles/:  <tag>_<attn>_kernel_stats.csv (rocprofv3 --kernel-trace --stats
+summary, ea:: kernels + the top library kernels), <tag>_<attn>_hbm.md and pmc_<attn>.json (per
+C-ABI entry point: HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+MI355X_MICROARCH.md 'HBM': FETCH_SIZE reports half of a 16 B/lane streaming read)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+KERNEL_TO_ENTRY = {
+    "lara_x_kernel<ea::BF16, 64, 4, 0>": "ea_lara_out_fwd", "lara_x_kernel<ea::BF16, 64, 4, 1>": "ea_lara_bwd_q",
+    "lara_x_kernel<ea::BF16, 64, 4, 2>": "ea_lara_bwd_k", "lara_x_kernel<ea::BF16, 64, 4, 3>": "ea_lara_bwd_qcorr",
+    "lara_y_kernel<ea::BF16, 64, 0>": "ea_lara_stats_fwd", "lara_y_kernel<ea::BF16, 64, 1>": "ea_lara_bwd_qstats",
+    "lara_y_kernel<ea::BF16, 64, 2>": "ea_lara_bwd_kstats",
+    "win_fwd_kernel<ea::BF16, 64>": "ea_window_attn_fwd", "win_bwd_kernel<ea::BF16, 64>": "ea_window_attn_bwd",
+    "chunk_mean_fwd_kernel<ea::BF16, 64>": "ea_eva_chunk_mean_fwd", "chunk_mean_bwd_kernel<ea::BF16, 64>": "ea_eva_chunk_mean_bwd",
+    "beta_fwd_kernel<ea::BF16, 64>": "ea_eva_beta_fwd", "beta_bwd_kernel<ea::BF16, 64>": "ea_eva_beta_bwd",
+    "sm_fwd_kernel<ea::BF16, 64>": "ea_softmax_attn_fwd", "sm_bwd_dq_kernel<ea::BF16, 64>": "ea_softmax_attn_bwd(dq)",
+    "sm_bwd_dkv_kernel<ea::BF16, 64>": "ea_softmax_attn_bwd(dkv)",
+}
+
+
+def entry_of(kname):
+    for k, v in KERNEL_TO_ENTRY.items():
+        if k in kname:
+            return v
+    return None
+
+
+def main(src, tag, attn, outdir):
+    os.makedirs(outdir, exist_ok=True)
+    stats = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
+    keep = [r for r in stats if "ea::" in r["Name"]] + [r for r in stats if "ea::" not in r["Name"]][:12]
+    with open(os.path.join(outdir, "%s_%s_kernel_stats.csv" % (tag, attn)), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for cname, sub, fn in (("FETCH_SIZE", "pmc_fetch", "f"), ("WRITE_SIZE", "pmc_write", "w")):
+        path = os.path.join(src, sub, fn + "_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        for r in csv.DictReader(open(path)):
+            e = entry_of(r["Kernel_Name"])
+            if e and r["Counter_Name"] == cname:
+                pmc[e][cname].append(float(r["Counter_Value"]))
+    avg_ns = {entry_of(r["Name"]): float(r["AverageNs"]) for r in stats if entry_of(r["Name"])}
+    out, lines = {}, ["| C-ABI entry | avg us | FETCH_SIZE raw KB | WRITE_SIZE KB | HBM bytes/launch (2xF+W) MB |", "|---|---|---|---|---|"]
+    for e, d in sorted(pmc.items()):
+        f = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
+        wv = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
+        total = (2 * f + wv) * 1024
+        out[e] = total
+        lines.append("| %s | %.1f | %.0f | %.0f | %.1f |" % (e, avg_ns.get(e, 0) / 1e3, f, wv, total / 1e6))
+    json.dump(out, open(os.path.join(outdir, "pmc_%s.json" % attn), "w"), indent=1)
+    open(os.path.join(outdir, "%s_%s_hbm.md" % (tag, attn)), "w").write(
+        "HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --attn %s "
+        "default workload.\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B; "
+        "calibrated here on ea_lara_out_fwd whose WRITE_SIZE equals its 38.5 MB output exactly).\n\n" % attn
+        + "\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles")
