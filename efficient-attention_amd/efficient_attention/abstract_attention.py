@@ -66,7 +66,7 @@ class MultiheadAttention(nn.Module):
         Under autocast the Linear already emits it; fp32 activations are rounded to bf16 (the
         kernels compute bf16 x bf16 -> fp32, the autocast contract of vit/engine.py:47)."""
         B, N, C = x.shape
-        qkv = self.qkv(x)
+        qkv = _ops.linear(x, self.qkv)
         if qkv.dtype not in (torch.bfloat16, torch.float16):
             qkv = qkv.to(torch.bfloat16)
         return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
@@ -80,7 +80,7 @@ class MultiheadAttention(nn.Module):
     def merge_and_project(self, out, B, seq_shape, C, dtype):
         """out [B, N, h, d] (contiguous) -> proj -> proj_drop, shaped [B, *seq_shape, C]."""
         x = out.reshape((B,) + tuple(seq_shape) + (C,))
-        x = self.proj(x)
+        x = _ops.linear(x, self.proj)
         if not torch.is_autocast_enabled() and x.dtype != dtype:
             x = x.to(dtype)
         return self.proj_drop(x)
