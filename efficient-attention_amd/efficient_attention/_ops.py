@@ -235,14 +235,63 @@ class EvaAttnFn(torch.autograd.Function):
 MIS = {"mis-opt": 0, "mis-biased": 1, "mis-bh": 2}
 
 
-def pool2d_qkv(qkv5, H, W, side):
-    """Adaptive 2-D average pool of q, k, v over the token grid -> [3, B, h, side*side, d] fp32
-    (nn.AdaptiveAvgPool2d on each head's [d, H, W] map, lara.py:43,48,145-151)."""
+class _GradSlot:
+    """Side channel between two autograd Functions that share one gradient buffer: the core's
+    backward publishes the [B,N,3,h,d] buffer it returns for qkv; the pooling backward, which the
+    graph orders after it (its outputs feed the core), accumulates into that buffer in place and
+    reports no gradient of its own, so autograd never materialises a second full-size tensor."""
+
+    def __init__(self):
+        self.buf = None
+
+
+class PoolMeanFn(torch.autograd.Function):
+    """Uniform 2-D average pool of q and k over r x r token blocks -> fp32 [B,h,L,d] x2 through the
+    chunk-mean kernel (the adaptive pool of lara.py:43,48 when the grid divides evenly)."""
+
+    @staticmethod
+    def forward(ctx, qkv5, H, W, r, slot):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        L = (H // r) * (W // r)
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), True, (H, W), r, 0, r, L)
+        q, k, _ = _qkv_views(qkv5)
+        tq, tk = nv.t4(q), nv.t4(k)
+        qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=qkv5.device)
+        kmean = torch.empty_like(qmean)
+        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk), None,
+                nv.ptr(qmean), nv.ptr(kmean), nv.stream())
+        ctx.geom, ctx.slot = geom, slot
+        ctx.shape, ctx.dtype = qkv5.shape, qkv5.dtype
+        return qmean, kmean
+
+    @staticmethod
+    def backward(ctx, dqm, dkm):
+        slot = ctx.slot
+        dqm = dqm.float().contiguous()
+        dkm = dkm.float().contiguous()
+        own = slot.buf is None
+        buf = torch.zeros(ctx.shape, dtype=ctx.dtype, device=dqm.device) if own else slot.buf
+        dq, dk, _ = _qkv_views(buf)
+        tdq, tdk = nv.t4(dq), nv.t4(dk)
+        nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(ctx.geom), nv.ptr(dqm), nv.ptr(dkm), None,
+                ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+        slot.buf = None
+        return (buf if own else None), None, None, None, None
+
+
+def pool2d_qkv(qkv5, H, W, side, slot=None, need_v=False):
+    """Adaptive 2-D average pool of q, k (and v when asked) over the token grid -> fp32
+    [B, h, side*side, d] each (nn.AdaptiveAvgPool2d on each head's [d, H, W] map,
+    lara.py:43,48,145-151,166-169).  Evenly dividing grids go through the HIP chunk-mean kernel."""
     B, N, _, h, d = qkv5.shape
-    if H % side == 0 and W % side == 0:
-        x = qkv5.view(B, side, H // side, side, W // side, 3, h, d)
-        pooled = x.mean(dim=(2, 4), dtype=torch.float32)                  # [B, side, side, 3, h, d]
-        return pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
+    pv = None
+    if H % side == 0 and W % side == 0 and H // side == W // side:
+        pq, pk = PoolMeanFn.apply(qkv5, H, W, H // side, slot if slot is not None else _GradSlot())
+        if need_v:
+            x = qkv5.view(B, side, H // side, side, W // side, 3, h, d)[:, :, :, :, :, 2]
+            pv = x.mean(dim=(2, 4), dtype=torch.float32).reshape(B, side * side, h, d).permute(0, 2, 1, 3)
+        return pq, pk, pv
 
     def bins(n):
         m = torch.zeros(side, n, device=qkv5.device, dtype=torch.float32)
@@ -252,7 +301,8 @@ def pool2d_qkv(qkv5, H, W, side):
         return m
     x = qkv5.view(B, H, W, 3, h, d).float()
     pooled = torch.einsum("iy,jx,byxthd->bijthd", bins(H), bins(W), x)
-    return pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
+    pooled = pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
+    return pooled[0], pooled[1], (pooled[2] if need_v else None)
 
 
 class LaraAttnFn(torch.autograd.Function):
@@ -262,10 +312,11 @@ class LaraAttnFn(torch.autograd.Function):
     lp [B,h,C] log-proposal.  Returns out [B,N,h,d]."""
 
     @staticmethod
-    def forward(ctx, qkv5, mask_u8, omega, qbar, bhv, lp, mis, kappa):
+    def forward(ctx, qkv5, mask_u8, omega, qbar, bhv, lp, mis, kappa, slot=None):
         nv.require_cuda(qkv5, "qkv")
         B, N, _, h, d = qkv5.shape
         C = omega.shape[2]
+        ctx.slot = slot
         dev = qkv5.device
         geom = nv.ea_lara_geom(B, h, N, d, nv.io_dtype(qkv5), C, mis, float(kappa), float(d) ** -0.5)
         q, k, v = _qkv_views(qkv5)
@@ -352,8 +403,10 @@ class LaraAttnFn(torch.autograd.Function):
             d_qbar = (scale * dom_q).view(B, h, C, d)
         d_lp = (-r).view(B, h, C)
         has_qbar, has_bhv = ctx.has
+        if ctx.slot is not None:
+            ctx.slot.buf = dqkv5          # the pooling backward accumulates into this buffer in place
         return (dqkv5, None, d_omega, d_qbar if has_qbar else None, d_bhv if has_bhv else None,
-                d_lp, None, None)
+                d_lp, None, None, None)
 
 
 def _prm(data, proj, scale):
@@ -361,7 +414,7 @@ def _prm(data, proj, scale):
     return scale * torch.einsum("bhcd,bhnd->bhcn", proj, data) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)
 
 
-def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scale):
+def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scale, slot=None):
     """Sampling + the [C x L] proposal-density algebra on the landmarks (tiny torch ops with
     autograd, lara.py:187-238), then the HIP estimator.  mode: 0 single, 1 antithetic,
     2 multi-sample noise."""
@@ -388,7 +441,7 @@ def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode,
         qbar_rows = rep(mu)
     else:
         lp = torch.logsumexp(_prm(mu, omega, scale), dim=-1)
-    return LaraAttnFn.apply(qkv5, mask_u8, omega, qbar_rows, bhv, lp, mis, float(alpha_coeff))
+    return LaraAttnFn.apply(qkv5, mask_u8, omega, qbar_rows, bhv, lp, mis, float(alpha_coeff), slot)
 
 
 # ------------------------------------------------------------------------------------------
@@ -551,7 +604,7 @@ class LinearFn(torch.autograd.Function):
 def linear(x, layer):
     """nn.Linear forward through LinearFn, in the autocast dtype when autocast is on."""
     if torch.is_autocast_enabled():
-        dtype = torch.get_autocast_gpu_dtype()
+        dtype = torch.get_autocast_dtype("cuda")
     else:
         dtype = x.dtype
     if not x.is_cuda:

@@ -52,14 +52,13 @@ class LinearRA(MultiheadAttention):
         self.apply(self._init_weights)
 
     # ---- landmark proposals (tiny [B,h,L,d] tensors; pooling reads q,k once) -------------
-    def _proposal_gen_2d(self, qkv5, H, W):
+    def _proposal_gen_2d(self, qkv5, H, W, slot=None):
         """Adaptive 2-D average pool of q,k -> [Linear+LN] -> optional softmax mixing of k_bar
         (reference :129-175).  Returns q_bar, k_bar [B,h,L,d] fp32."""
         B, N, _, h, d = qkv5.shape
         side = int(math.sqrt(self.num_landmarks))
-        pooled = _ops.pool2d_qkv(qkv5, H, W, side)                 # [3, B, h, L, d] fp32
-        pq, pk, pv = pooled[0], pooled[1], pooled[2]
         gen = self.proposal_gen
+        pq, pk, pv = _ops.pool2d_qkv(qkv5, H, W, side, slot, need_v=gen.endswith('-vmixed'))
         if gen.startswith('pool'):
             if self.pool_module_type == 'dense':
                 def dense(p, net):
@@ -115,8 +114,9 @@ class LinearRA(MultiheadAttention):
         N = int(math.prod(seq_shape))
         h, d = self.num_heads, self.head_dim
         qkv5 = self.project_qkv(x.reshape(B, N, C))
+        slot = _ops._GradSlot()
         if len(seq_shape) == 2:
-            q_bar, k_bar = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1])
+            q_bar, k_bar = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
         elif len(seq_shape) == 1:
             q_bar, k_bar, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
         else:
@@ -134,7 +134,7 @@ class LinearRA(MultiheadAttention):
                 noise = torch.randn_like(mu)
         mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
         out = _ops.lara_attention(qkv5, mask, q_bar, mu, noise, self.mis_type, self.alpha_coeff,
-                                  mode, self.scale)
+                                  mode, self.scale, slot)
         return self.merge_and_project(out, B, seq_shape, C, x.dtype)
 
     @staticmethod
