@@ -177,7 +177,9 @@ static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
   const long bh = (long)g->B * g->H;
   const int gran = ypass ? 32 * lara_nsub(p.NCT) : 64;
   const int maxblk = (g->N + gran - 1) / gran;
-  int nblk = (int)((2048 + bh - 1) / bh);
+  // X passes re-stage the landmark matrices per workgroup: fewer, longer workgroups (~3 per CU);
+  // Y passes only keep landmark fragments in registers: more, shorter slices
+  int nblk = (int)(((ypass ? 2048 : 768) + bh - 1) / bh);
   if (nblk < 1) nblk = 1;
   if (nblk > maxblk) nblk = maxblk;
   int tpb = (g->N + nblk - 1) / nblk;

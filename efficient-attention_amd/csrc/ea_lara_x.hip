@@ -55,7 +55,7 @@ EA_DEV void stage_cols(char* dst, const float* src, int C, int Cp, int tid) {
 }
 
 template <typename E, int D, int NCT, int MODE>
-__global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
+__global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
   using Cfg = LxCfg<D>;
   constexpr int ROWB = Cfg::ROWB, KS = Cfg::KS, DT = Cfg::DT, DQ = Cfg::DQ;
   constexpr int Cp = NCT * 16;
@@ -75,46 +75,88 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
   constexpr bool PERF = MODE >= LX_POUT;
   const bool use_t = p.mis != MIS_BH && !PERF;
 
-  if (MODE != LX_QCORR) stage_rows<E, D>(R1, p.omega + lmw * D, p.C, Cp, tid);
-  if (MODE != LX_BWDK && use_t) stage_rows<E, D>(R2, p.qbar + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDQ || MODE == LX_PBWDQ) stage_rows<E, D>(R3, p.kv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDK || MODE == LX_PBWDK) stage_rows<E, D>(R3, p.dkv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_FWD || MODE == LX_POUT) stage_cols<E, D>(M1, p.kv + lm * D, p.C, Cp, tid);
-  if (MODE == LX_BWDQ || MODE == LX_PBWDQ) {
-    stage_cols<E, D>(M1, p.omega + lmw * D, p.C, Cp, tid);
-    if (use_t) stage_cols<E, D>(M2, p.qbar + lm * D, p.C, Cp, tid);
-  }
-  if (MODE == LX_BWDK || MODE == LX_PBWDK) {
-    stage_cols<E, D>(M1, p.dkv + lm * D, p.C, Cp, tid);
-    stage_cols<E, D>(M2, p.omega + lmw * D, p.C, Cp, tid);
-  }
-  if (MODE == LX_QCORR) stage_cols<E, D>(M1, p.uq + lm * D, p.C, Cp, tid);
-
-  // per-landmark scalars of this lane's rows c = 16 ct + 4 g + r
-  float cst2[NCT][4], lset2[NCT][4], bhv[NCT][4], lsek2[NCT][4], dkk[NCT][4], rs[NCT][4];
+  // ---- stage the landmark matrices: ALL global loads are issued before the first conversion /
+  // LDS store, so the workgroup pays one memory round trip here instead of one per matrix ----
+  {
+    constexpr int CPRs = D / 8;
+    constexpr int SL = (Cp * CPRs + 255) / 256;        // (row, 8-channel chunk) slots per thread
+    const float* rsrc[3] = {nullptr, nullptr, nullptr};
+    const float* csrc[2] = {nullptr, nullptr};
+    if (MODE != LX_QCORR) rsrc[0] = p.omega + lmw * D;
+    if (MODE != LX_BWDK && MODE != LX_PBWDK && use_t) rsrc[1] = p.qbar + lm * D;
+    if (MODE == LX_BWDQ || MODE == LX_PBWDQ) rsrc[2] = p.kv + lm * D;
+    if (MODE == LX_BWDK || MODE == LX_PBWDK) rsrc[2] = p.dkv + lm * D;
+    if (MODE == LX_FWD || MODE == LX_POUT) csrc[0] = p.kv + lm * D;
+    if (MODE == LX_BWDQ || MODE == LX_PBWDQ) { csrc[0] = p.omega + lmw * D; if (use_t) csrc[1] = p.qbar + lm * D; }
+    if (MODE == LX_BWDK || MODE == LX_PBWDK) { csrc[0] = p.dkv + lm * D; csrc[1] = p.omega + lmw * D; }
+    if (MODE == LX_QCORR) csrc[0] = p.uq + lm * D;
+    char* rdst[3] = {R1, R2, R3};
+    char* cdst[2] = {M1, M2};
+    float4 rb[3][SL][2], cb[2][SL][2];
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+    for (int j = 0; j < 5; ++j) {
+      const float* src = j < 3 ? rsrc[j] : csrc[j - 3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = ct * 16 + 4 * g + r;
-      const bool ok = c < p.C;
-      cst2[ct][r] = -INFINITY; lset2[ct][r] = INFINITY; bhv[ct][r] = 1.f;
-      lsek2[ct][r] = INFINITY; dkk[ct][r] = 0.f; rs[ct][r] = 0.f;
-      if (ok) {
-        if (MODE == LX_FWD || MODE == LX_BWDQ) {
-          cst2[ct][r] = p.cst[lm + c] * LOG2E;
-          if (p.mis == MIS_OPT) bhv[ct][r] = p.bhv[lm + c];
+      for (int sl = 0; sl < SL; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / CPRs, c = idx - row * CPRs;
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (src && idx < Cp * CPRs && row < p.C) {
+          lo = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
+          hi = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
         }
-        if (MODE != LX_BWDK && p.mis == MIS_OPT) lset2[ct][r] = p.lse_t[lm + c] * LOG2E;
-        if (MODE == LX_BWDK) {
-          lsek2[ct][r] = p.lse_k[lm + c] * LOG2E;
-          dkk[ct][r] = p.dkk[lm + c];
-          rs[ct][r] = p.rsum[lm + c];
-        }
-        if (MODE == LX_POUT || MODE == LX_PBWDQ) cst2[ct][r] = p.cst[lm + c];      // sum_n phi(k_n)[j]
-        if (MODE == LX_PBWDK) rs[ct][r] = p.rsum[lm + c];                          // d ksum[j]
+        if (j < 3) { rb[j][sl][0] = lo; rb[j][sl][1] = hi; } else { cb[j - 3][sl][0] = lo; cb[j - 3][sl][1] = hi; }
       }
     }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bool on = (j < 3 ? rsrc[j] : csrc[j - 3]) != nullptr;
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / CPRs, c = idx - row * CPRs;
+        if (!on || idx >= Cp * CPRs) continue;
+        const float4 lo = j < 3 ? rb[j][sl][0] : cb[j - 3][sl][0];
+        const float4 hi = j < 3 ? rb[j][sl][1] : cb[j - 3][sl][1];
+        const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (j < 3) {
+          sts16(rdst[j] + lds_off<D>(row, c), pack8<E>(f));
+        } else {
+          uint16_t* d16 = reinterpret_cast<uint16_t*>(cdst[j - 3]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) d16[(c * 8 + i) * (Cp + 4) + row] = E::from_f(f[i]);
+        }
+      }
+    }
+  }
+
+  // per-landmark scalars live in LDS (three [Cp] fp32 vectors); lanes read the entries of their
+  // rows c = 16 ct + 4 g + r at the point of use instead of pinning 6 x NCT x 4 registers
+  float* SC0 = reinterpret_cast<float*>(M2 + D * MT_LDB);
+  float* SC1 = SC0 + Cp;
+  float* SC2 = SC1 + Cp;
+  for (int c = tid; c < Cp; c += 256) {
+    const bool ok = c < p.C;
+    float v0 = -INFINITY, v1 = INFINITY, v2 = 1.f;
+    if (MODE == LX_BWDK) { v0 = INFINITY; v1 = 0.f; v2 = 0.f; }
+    if (MODE == LX_PBWDK) v2 = 0.f;
+    if (ok) {
+      if (MODE == LX_FWD || MODE == LX_BWDQ) {
+        v0 = p.cst[lm + c] * LOG2E;
+        if (p.mis == MIS_OPT) v2 = p.bhv[lm + c];
+      }
+      if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && p.mis == MIS_OPT) v1 = p.lse_t[lm + c] * LOG2E;
+      if (MODE == LX_BWDK) { v0 = p.lse_k[lm + c] * LOG2E; v1 = p.dkk[lm + c]; v2 = p.rsum[lm + c]; }
+      if (MODE == LX_POUT || MODE == LX_PBWDQ) v0 = p.cst[lm + c];       // sum_n phi(k_n)[j]
+      if (MODE == LX_PBWDK) v2 = p.rsum[lm + c];                         // d ksum[j]
+    }
+    SC0[c] = v0; SC1[c] = v1; SC2[c] = v2;
+  }
+  struct LdsVec {
+    const float* base; int g;
+    EA_DEV float operator()(int ct, int r) const { return base[ct * 16 + 4 * g + r]; }
+  };
+  const LdsVec cst2{SC0, g}, lset2{SC1, g}, bhv{SC2, g}, lsek2{SC0, g}, dkk{SC1, g}, rs{SC2, g};
   const float stabk2 = (MODE == LX_PBWDK) ? p.stab[bh] * LOG2E : 0.f;
   __syncthreads();
 
@@ -128,22 +170,38 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
   const int n0 = blk * p.tok_per_block;
   const int n1 = min(p.N, n0 + p.tok_per_block);
 
+  // Software prefetch: the token fragments of this wave's NEXT tile are in flight while the
+  // current tile computes, so a tile costs one exposed memory round trip per wave, not one per tile.
+  constexpr bool NEED_O = MODE == LX_PBWDQ;
+  u32x4 nx1[KS], nx2[KS], nx3[KS];
+  auto issue = [&](int tile_) {
+    const int tok_ = n0 + tile_ * 16 + li;
+    const bool ok_ = tok_ < n1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      nx1[ks] = nx2[ks] = nx3[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (ok_) {
+        const int eo = (g * KS + ks) * 8;
+        nx1[ks] = ldg16(t1b + (tok_ * tk1.sn + eo) * 2);
+        if (TWO_TOK) nx2[ks] = ldg16(t2b + (tok_ * tk2.sn + eo) * 2);
+        if (NEED_O) nx3[ks] = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok_ * p.o.sn + eo) * 2);
+      }
+    }
+  };
+  if (n0 + wave * 16 < n1) issue(wave);
   for (int tile = wave; n0 + tile * 16 < n1; tile += 4) {
     const int tok = n0 + tile * 16 + li;
     const bool valid = tok < n1;
     typename E::x8 f1[KS], f2[KS];
-    u32x4 raw1[KS];
+    u32x4 raw1[KS], raw3[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      u32x4 w1 = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
-      if (valid) {
-        w1 = ldg16(t1b + (tok * tk1.sn + (g * KS + ks) * 8) * 2);
-        if (TWO_TOK) w2 = ldg16(t2b + (tok * tk2.sn + (g * KS + ks) * 8) * 2);
-      }
-      raw1[ks] = w1;
-      f1[ks] = as_x8<E>(w1);
-      f2[ks] = as_x8<E>(w2);
+      raw1[ks] = nx1[ks];
+      raw3[ks] = nx3[ks];
+      f1[ks] = as_x8<E>(nx1[ks]);
+      f2[ks] = as_x8<E>(nx2[ks]);
     }
+    if (n0 + (tile + 4) * 16 < n1) issue(tile + 4);
     // ---- score tiles ----
     f32x4 a[NCT], tt[NCT], dw[NCT];
 #pragma unroll
@@ -166,7 +224,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tl += fast_exp2(tt[ct][r] * p.scale_log2 - lset2[ct][r]);
+          for (int r = 0; r < 4; ++r) tl += fast_exp2(tt[ct][r] * p.scale_log2 - lset2(ct, r));
       }
       const float tmean = quad_sum(tl) * invC;
       float z2[NCT][4], tv[NCT][4], al[NCT][4];
@@ -175,9 +233,9 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
       for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const LaraElem e = lara_alpha(p.mis, tt[ct][r] * p.scale_log2, lset2[ct][r], bhv[ct][r], p.kappa, tmean);
+          const LaraElem e = lara_alpha(p.mis, tt[ct][r] * p.scale_log2, lset2(ct, r), bhv(ct, r), p.kappa, tmean);
           tv[ct][r] = e.t; al[ct][r] = e.alpha;
-          z2[ct][r] = a[ct][r] * p.scale_log2 + e.la2 + cst2[ct][r];
+          z2[ct][r] = a[ct][r] * p.scale_log2 + e.la2 + cst2(ct, r);
           mx = fmaxf(mx, z2[ct][r]);
         }
       mx = quad_max(mx);
@@ -258,7 +316,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
         for (int r = 0; r < 4; ++r) {
           const bool ok = ct * 16 + 4 * g + r < p.C;
           phi[ct][r] = (ok && !dead) ? p.ratio * fast_exp2(a[ct][r] * p.scale_log2 - diag2 - stab2) + p.feps : 0.f;
-          if (MODE != LX_PBWDK && ok) den += phi[ct][r] * cst2[ct][r];
+          if (MODE != LX_PBWDK && ok) den += phi[ct][r] * cst2(ct, r);
         }
       if (MODE == LX_POUT) {
         den = quad_sum(den);
@@ -274,10 +332,8 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
         float dd = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          u32x4 ow = {0u, 0u, 0u, 0u};
-          if (valid) ow = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + (g * KS + ks) * 8) * 2);
           float x8[8], y8[8];
-          unpack8<E>(ow, x8);
+          unpack8<E>(raw3[ks], x8);
           unpack8<E>(__builtin_bit_cast(u32x4, f2[ks]), y8);
 #pragma unroll
           for (int i = 0; i < 8; ++i) dd += x8[i] * y8[i];
@@ -289,7 +345,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = ct * 16 + 4 * g + r < p.C;
-            const float dphi = dw[ct][r] * invden + cst2[ct][r] * dden;
+            const float dphi = dw[ct][r] * invden + cst2(ct, r) * dden;
             const float dz = ok ? dphi * (phi[ct][r] - p.feps) : 0.f;
             w1[ct][r] = dz;
             sdb += dz;
@@ -305,7 +361,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = ct * 16 + 4 * g + r < p.C;
-            const float dz = (ok && !dead) ? (dw[ct][r] + rs[ct][r]) * (phi[ct][r] - p.feps) : 0.f;
+            const float dz = (ok && !dead) ? (dw[ct][r] + rs(ct, r)) * (phi[ct][r] - p.feps) : 0.f;
             w1[ct][r] = phi[ct][r];
             w2[ct][r] = dz;
             sdb += dz;
@@ -316,7 +372,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w1[ct][r] = fast_exp2(tt[ct][r] * p.scale_log2 - lset2[ct][r]);
+        for (int r = 0; r < 4; ++r) w1[ct][r] = fast_exp2(tt[ct][r] * p.scale_log2 - lset2(ct, r));
     } else {   // LX_BWDK
       float nrm = 0.f;
 #pragma unroll
@@ -333,8 +389,8 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float bk2 = a[ct][r] * p.scale_log2 - 0.5f * p.scale_log2 * nrm;
-          const float pk = dead ? 0.f : fast_exp2(bk2 - lsek2[ct][r]);
-          const float db = pk * (dw[ct][r] - dkk[ct][r] + rs[ct][r]);
+          const float pk = dead ? 0.f : fast_exp2(bk2 - lsek2(ct, r));
+          const float db = pk * (dw[ct][r] - dkk(ct, r) + rs(ct, r));
           w1[ct][r] = pk;
           w2[ct][r] = db;
           sdb += db;
@@ -446,7 +502,7 @@ __global__ __launch_bounds__(256) void lara_x_kernel(const LaraP p) {
 
 size_t lara_x_lds(int D, int NCT) {
   const int Cp = NCT * 16;
-  return (size_t)3 * Cp * D * 2 + (size_t)2 * D * (Cp + 4) * 2;
+  return (size_t)3 * Cp * D * 2 + (size_t)2 * D * (Cp + 4) * 2 + (size_t)3 * Cp * sizeof(float);
 }
 
 template <typename E, int D, int NCT>
