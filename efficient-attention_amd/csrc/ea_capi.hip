@@ -10,6 +10,7 @@ int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStre
 #include "ea_landmark_params.h"
 #include "ea_lara.h"
 #include "ea_softmax.h"
+#include "ea_lara_lmk.h"
 namespace ea {
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
@@ -432,6 +433,59 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
   p.k = mkl(k); p.v = mkl(v); p.dk = mkl(dk); p.dv = mkl(dv); p.mask = mask; p.omega = W; p.stab = stab;
   p.dkv = dkv; p.rsum = dksum;
   return lara_x_dispatch(LX_PBWDK, p, g->dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- fused LARA landmark pipeline ----
+static int fill_lmk(const ea_lmk_geom* g, LmkP& p) {
+  if (!g || g->BH <= 0 || g->L <= 0 || g->C <= 0 || (g->D != 32 && g->D != 64)) return EA_E_BADARG;
+  if (g->L > 64 || g->C > 64) return EA_E_UNSUPPORTED;
+  if (g->C % g->L != 0 || (g->dup == 0 && g->C != g->L) || (g->dup != 0 && g->C != 2 * g->L)) return EA_E_BADARG;
+  if (g->mis < 0 || g->mis > 2 || g->dup < 0 || g->dup > 2) return EA_E_BADARG;
+  p.BH = g->BH; p.L = g->L; p.C = g->C; p.D = g->D;
+  p.has_mlp = g->has_mlp; p.mixed = g->mixed; p.mis = g->mis; p.dup = g->dup; p.scale = g->scale;
+  return EA_OK;
+}
+#define LMK_PARAMS(p)                                                                        \
+  p.Wq = Wq; p.bq = bq; p.gq = gq; p.cq = cq; p.Wk = Wk; p.bk = bk; p.gk = gk; p.ck = ck;
+extern "C" {
+
+int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk,
+                          const float* Wq, const float* bq, const float* gq, const float* cq,
+                          const float* Wk, const float* bk, const float* gk, const float* ck,
+                          const float* noise, float* omega, float* qbar_rows, float* bhv, float* lp,
+                          void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pq || !pk || !omega || !lp) return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar_rows || !bhv)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar_rows) return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.omega = omega; p.qbar_rows = qbar_rows; p.bhv = bhv; p.lp = lp;
+  return lara_lmk_dispatch(false, p, (hipStream_t)stream);
+}
+
+int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk,
+                          const float* Wq, const float* bq, const float* gq, const float* cq,
+                          const float* Wk, const float* bk, const float* gk, const float* ck,
+                          const float* noise, const float* d_omega, const float* d_qbar_rows,
+                          const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                          float* dW_part, float* dvec_part, void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pq || !pk || !d_omega || !d_lp || !dpq || !dpk) return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
+    return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
+  p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
+  return lara_lmk_dispatch(true, p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,21 @@
+// ea_lara_lmk.h -- parameter block of the fused LARA landmark kernels (ea_lara_landmark.hip).
+#pragma once
+#include "ea_common.h"
+
+namespace ea {
+
+struct LmkP {
+  const float *pq, *pk;                                   // [BH, L, D] pooled q / k (or q_bar / k_bar)
+  const float *Wq, *bq, *gq, *cq, *Wk, *bk, *gk, *ck;     // Linear + LayerNorm parameters (has_mlp)
+  const float* noise;                                     // standard normal, or null (eval)
+  float *omega, *qbar_rows, *bhv, *lp;                    // forward outputs
+  const float *d_omega, *d_qbar_rows, *d_bhv, *d_lp;      // backward inputs
+  float *dpq, *dpk, *dW_part, *dvec_part;                 // backward outputs
+  int BH, L, C, D;
+  int has_mlp, mixed, mis, dup;
+  float scale;
+};
+
+int lara_lmk_dispatch(bool bwd, const LmkP& p, hipStream_t st);
+
+}  // namespace ea

@@ -35,6 +35,12 @@ class ea_perf_geom(ctypes.Structure):
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("M", ctypes.c_int32)]
 
 
+class ea_lmk_geom(ctypes.Structure):
+    _fields_ = [("BH", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("has_mlp", ctypes.c_int32), ("mixed", ctypes.c_int32), ("mis", ctypes.c_int32),
+                ("dup", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
 class ea_lara_geom(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("C", ctypes.c_int32),
@@ -47,6 +53,7 @@ _F = ctypes.c_float
 _G = ctypes.POINTER(ea_geom)
 _LG = ctypes.POINTER(ea_lara_geom)
 _PG = ctypes.POINTER(ea_perf_geom)
+_MG = ctypes.POINTER(ea_lmk_geom)
 _T = ctypes.POINTER(ea_t4)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
@@ -57,6 +64,8 @@ SIGNATURES = {
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
     "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_lara_landmarks_fwd": [_MG] + [_P] * 16,
+    "ea_lara_landmarks_bwd": [_MG] + [_P] * 20,
     "ea_lara_parts": [_LG],
     "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],

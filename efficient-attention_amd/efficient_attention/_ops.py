@@ -409,6 +409,73 @@ class LaraAttnFn(torch.autograd.Function):
                 d_lp, None, None, None)
 
 
+class LaraLandmarkFn(torch.autograd.Function):
+    """Fused landmark pipeline (ea_lara_landmarks_fwd/bwd): pooled q/k [B,h,L,d] (or ready q_bar/k_bar
+    when has_mlp = mixed = 0) -> omega, qbar_rows [B,h,C,d], bhv, lp [B,h,C].  params = (Wq, bq,
+    gq, cq, Wk, bk, gk, ck) when has_mlp."""
+
+    @staticmethod
+    def forward(ctx, pq, pk, noise, cfg, *params):
+        has_mlp, mixed, mis, dup, scale = cfg
+        B, h, L, d = pq.shape
+        C = L * (2 if dup else 1)
+        BH, dev = B * h, pq.device
+        pq = pq.float().contiguous()
+        pk = pk.float().contiguous()
+        noise_c = None if noise is None else noise.float().contiguous()
+        ps = [t.float().contiguous() for t in params]
+        geom = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale))
+        omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
+        qrows = torch.empty_like(omega) if mis != 2 else None
+        bhv = torch.empty((B, h, C), dtype=torch.float32, device=dev) if mis == 0 else None
+        lp = torch.empty((B, h, C), dtype=torch.float32, device=dev)
+        pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+        nv.call("ea_lara_landmarks_fwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.stream())
+        ctx.save_for_backward(pq, pk, noise_c, *ps)
+        ctx.geom = geom
+        ctx.pdtypes = [t.dtype for t in params]
+        return omega, qrows, bhv, lp
+
+    @staticmethod
+    def backward(ctx, d_omega, d_qrows, d_bhv, d_lp):
+        pq, pk, noise_c, *ps = ctx.saved_tensors
+        geom = ctx.geom
+        BH, L, C, d = geom.BH, geom.L, geom.C, geom.D
+        dev = pq.device
+
+        def fz(t, shape):
+            return (torch.zeros(shape, dtype=torch.float32, device=dev) if t is None
+                    else t.float().contiguous())
+        d_omega = fz(d_omega, (BH, C, d))
+        d_lp = fz(d_lp, (BH, C))
+        d_qrows = None if d_qrows is None else d_qrows.float().contiguous()
+        d_bhv = None if d_bhv is None else d_bhv.float().contiguous()
+        dpq = torch.empty_like(pq)
+        dpk = torch.empty_like(pk)
+        dW = dvec = None
+        if geom.has_mlp:
+            dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
+            dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
+        pp = [nv.ptr(t) for t in ps] if geom.has_mlp else [None] * 8
+        nv.call("ea_lara_landmarks_bwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+                nv.ptr(dW), nv.ptr(dvec), nv.stream())
+        pgrads = []
+        if geom.has_mlp:
+            dWs, dvs = dW.sum(0), dvec.sum(0)              # [2,d,d], [2,3,d]
+            raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+            pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
+        return (dpq, dpk, None, None) + tuple(pgrads)
+
+
+def lara_landmarks(pq, pk, noise, mis_type, mode, scale, params=None, mixed=False):
+    """-> omega, qbar_rows, bhv, lp through the fused HIP landmark kernels (L, C <= 64)."""
+    has_mlp = params is not None
+    cfg = (has_mlp, bool(mixed), MIS[mis_type], int(mode) if noise is not None else 0, float(scale))
+    return LaraLandmarkFn.apply(pq, pk, noise, cfg, *(params or ()))
+
+
 def _prm(data, proj, scale):
     """s <proj_c, data_n> - s |data_n|^2 / 2  (prm_projection normalize=False), tiny tensors."""
     return scale * torch.einsum("bhcd,bhnd->bhcn", proj, data) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)

@@ -109,32 +109,60 @@ class LinearRA(MultiheadAttention):
             q_bar, k_bar = seg_mean(q2), seg_mean(k2)
         return q_bar, k_bar, qkv5
 
+    def _mlp_params(self):
+        q, k = self.q_bar_gen, self.k_bar_gen
+        return [q[2].weight, q[2].bias, q[3].weight, q[3].bias, k[2].weight, k[2].bias, k[3].weight, k[3].bias]
+
     def forward(self, x, key_padding_mask=None):
         B, *seq_shape, C = x.shape
         N = int(math.prod(seq_shape))
         h, d = self.num_heads, self.head_dim
         qkv5 = self.project_qkv(x.reshape(B, N, C))
-        slot = _ops._GradSlot()
-        if len(seq_shape) == 2:
-            q_bar, k_bar = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
-        elif len(seq_shape) == 1:
-            q_bar, k_bar, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
-        else:
-            raise ValueError("LinearRA expects x of rank 3 or 4")
-        mu = q_bar + k_bar
-        mode, noise = 0, None
+        L = self.num_landmarks
+        gen = self.proposal_gen
+        dup = self.training and (self.use_multisample or self.use_antithetics)
+        mode = 0
         if self.training:
-            if self.use_multisample:
-                mode = 2
-                noise = torch.randn(B, h, mu.shape[-2] * 2, d, dtype=mu.dtype, device=mu.device)
-            elif self.use_antithetics:
-                mode = 1
-                noise = torch.randn_like(mu)
-            else:
-                noise = torch.randn_like(mu)
+            mode = 2 if self.use_multisample else (1 if self.use_antithetics else 0)
+        slot = _ops._GradSlot()
         mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
-        out = _ops.lara_attention(qkv5, mask, q_bar, mu, noise, self.mis_type, self.alpha_coeff,
-                                  mode, self.scale, slot)
+
+        # ---- landmark proposals.  Fused HIP pipeline whenever the sample count fits (C <= 64) ----
+        side = int(math.sqrt(L))
+        n_lm = side * side if len(seq_shape) == 2 else min(L, N)
+        fused_b = n_lm * (2 if dup else 1) <= 64 and d in (32, 64)
+        fused_a = (fused_b and len(seq_shape) == 2 and self.pool_module_type == 'light'
+                   and not gen.endswith('-vmixed') and (gen.startswith('pool') or gen.startswith('no-param-pool'))
+                   and seq_shape[0] % side == 0 and seq_shape[1] % side == 0
+                   and seq_shape[0] // side == seq_shape[1] // side)
+        if fused_a:
+            pq, pk, _ = _ops.pool2d_qkv(qkv5, seq_shape[0], seq_shape[1], side, slot)
+            params = self._mlp_params() if gen.startswith('pool') else None
+            mixed = gen.endswith('mixed')
+        else:
+            if len(seq_shape) == 2:
+                pq, pk = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
+            elif len(seq_shape) == 1:
+                pq, pk, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
+            else:
+                raise ValueError("LinearRA expects x of rank 3 or 4")
+            params, mixed = None, False
+
+        noise = None
+        if self.training:
+            nl = pq.shape[-2]
+            if self.use_multisample:
+                noise = torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=x.device)
+            else:
+                noise = torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=x.device))
+        if fused_b:
+            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, self.mis_type, mode, self.scale,
+                                                        params, mixed)
+            out = _ops.LaraAttnFn.apply(qkv5, mask, omega, qrows, bhv, lp, _ops.MIS[self.mis_type],
+                                        float(self.alpha_coeff), slot)
+        else:
+            out = _ops.lara_attention(qkv5, mask, pq, pq + pk, noise, self.mis_type, self.alpha_coeff,
+                                      mode, self.scale, slot)
         return self.merge_and_project(out, B, seq_shape, C, x.dtype)
 
     @staticmethod

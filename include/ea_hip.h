@@ -213,6 +213,38 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
                        const float* W, const float* stab, const float* dkv, const float* dksum,
                        const ea_t4* dk, const ea_t4* dv, void* stream);
 
+/* ---- LARA landmark pipeline, fused (lara.py:145-198,214-238) -----------------------------------
+ * One workgroup per (b,h), all matrices in LDS, exact fp32:
+ *   q_bar = LN(pq Wq^T + bq), k0 = LN(pk Wk^T + bk)         (has_mlp; else q_bar = pq, k0 = pk)
+ *   k_bar = softmax(s k0 k0^T) k0                            (mixed; else k_bar = k0)
+ *   mu = q_bar + k_bar;  omega_c = mu[c mod L] + eps_c       (dup 0: C = L; 1 antithetic: C = 2L,
+ *                                                             eps [BH,L,D], second half negated;
+ *                                                             2 multi-sample: C = 2L, eps [BH,2L,D])
+ *   M[c,l] = s omega_c.mu_l - s|mu_l|^2/2
+ *   mis-opt   : lp_c = M[c, c mod L]; bh_c = exp(lp_c - LSE over the C (repeated) columns);
+ *               qbar_rows_c = q_bar[c mod L]
+ *   mis-biased: lp_c = LSE_l M[c,l]; qbar_rows_c = mu[c mod L];   mis-bh: lp_c = LSE_l M[c,l]
+ * Outputs omega, qbar_rows [BH,C,D], bhv, lp [BH,C] feed ea_lara_*.  The backward takes their
+ * gradients and returns d pq, d pk [BH,L,D] plus per-(b,h) partial parameter gradients
+ * dW_part [BH,2,D,D] (q then k; [out][in]) and dvec_part [BH,2,3,D] (Linear bias, LN weight, LN
+ * bias) which the caller sums over BH.  L, C <= 64. */
+typedef struct {
+  int32_t BH, L, C, D;
+  int32_t has_mlp, mixed, mis, dup;
+  float   scale;
+} ea_lmk_geom;
+int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk,
+                          const float* Wq, const float* bq, const float* gq, const float* cq,
+                          const float* Wk, const float* bk, const float* gk, const float* ck,
+                          const float* noise, float* omega, float* qbar_rows, float* bhv, float* lp,
+                          void* stream);
+int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk,
+                          const float* Wq, const float* bq, const float* gq, const float* cq,
+                          const float* Wk, const float* bk, const float* gk, const float* ck,
+                          const float* noise, const float* d_omega, const float* d_qbar_rows,
+                          const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                          float* dW_part, float* dvec_part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

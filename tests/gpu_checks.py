@@ -7,11 +7,11 @@ the oracle evaluated in fp64 on the same bf16-rounded inputs.
 Stated tolerances (bf16 operands: 8 significant bits, unit round-off 2^-9 = 2e-3; fp32
 accumulation; every figure is relative to the reference tensor's own scale):
   module level vs fp32 golden : max|err| <= 4e-2 * max|ref|  and  rms(err) <= 2e-2 * rms(ref)
-  LARA module level           : max|err| <= 8e-2 * max|ref|  and  rms(err) <= 4e-2 * rms(ref)
+  LARA module level           : max|err| <= 5e-2 * max|ref|  and  rms(err) <= 2.5e-2 * rms(ref)
       (its gradients pass through three more bf16-rounded stages than a softmax kernel: the
        importance weights, d(log alpha)/alpha and the softmax-over-sequence term t(dt - u), whose
        two halves cancel, and the landmark matrices are rounded to bf16 exactly as autocast
-       rounds einsum operands; observed 1-3e-2 rms, 8x smaller in fp16)
+       rounds einsum operands; observed <= 2.3e-2, 8x smaller in fp16)
   fp16 autocast (the reference's own AMP dtype, 11 significant bits), every variant:
                                 max|err| <= 1e-2 * max|ref|  and  rms(err) <= 5e-3 * rms(ref)
   core level vs fp64 oracle   : max|err| <= 2e-2 * max|ref|  and  rms(err) <= 1e-2 * rms(ref)
@@ -26,7 +26,7 @@ import cases
 from util import Fixture, scaled_err
 
 MODULE_TOL = (4e-2, 2e-2)
-LARA_TOL = (8e-2, 4e-2)
+LARA_TOL = (5e-2, 2.5e-2)
 FP16_TOL = (1e-2, 5e-3)
 CORE_TOL = (2e-2, 1e-2)
 
