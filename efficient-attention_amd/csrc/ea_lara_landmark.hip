@@ -14,7 +14,7 @@
 
 namespace ea {
 
-constexpr int LMK_T = 256;
+constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
 
 // C[m][n] (+)= alpha * sum_k A(m,k) B(k,n), all operands in LDS (fp32); TA/TB read A/B transposed.
 // 16x16 output tiles on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32 (bit-identical to
@@ -30,15 +30,19 @@ EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int l
     const int m0 = (tile / tn) << 4, n0 = (tile - (tile / tn) * tn) << 4;
     const int am = m0 + li, bn = n0 + li;
     const bool a_ok = am < M, b_ok = bn < N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 4) {
-      const int k = k0 + g;
+    // all LDS operand reads of the tile are issued before the dependent MFMA chain (K <= 64)
+    float av[16], bv[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = ks * 4 + g;
       const bool k_ok = k < K;
-      const float a = (a_ok && k_ok) ? (TA ? A[k * lda + am] : A[am * lda + k]) : 0.f;
-      const float b = (b_ok && k_ok) ? (TB ? B[bn * ldb + k] : B[k * ldb + bn]) : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      av[ks] = (a_ok && k_ok) ? (TA ? A[k * lda + am] : A[am * lda + k]) : 0.f;
+      bv[ks] = (b_ok && k_ok) ? (TB ? B[bn * ldb + k] : B[k * ldb + bn]) : 0.f;
     }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks * 4 < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
     if (b_ok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -83,9 +87,40 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   const float s = p.scale;
   const size_t oL = (size_t)bh * L * D, oC = (size_t)bh * C * D;
 
-  auto load_rows = [&](float* dst, const float* src, int rows) {
-    for (int idx = tid; idx < rows * D; idx += LMK_T) dst[(idx / D) * LD + (idx % D)] = src[idx];
+  // Global -> LDS in two steps: `issue` puts up to 4 float4 per thread in flight (a whole [64][D]
+  // matrix per workgroup), `commit` writes them to the padded LDS rows.  Everything a phase needs is
+  // issued at its start, so the workgroup pays ~one memory round trip per phase, not one per row.
+  constexpr int NSLOT = (64 * D / 4 + LMK_T - 1) / LMK_T;
+  struct Pre { float4 v[NSLOT]; };
+  auto issue = [&](Pre& b, const float* src, int rows) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = (tid + i * LMK_T) * 4;
+      b.v[i] = (src && e < rows * D) ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
+  auto commit = [&](float* dst, const Pre& b, int rows) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = (tid + i * LMK_T) * 4;
+      if (e < rows * D) {
+        float* d = dst + (e / D) * LD + (e % D);
+        d[0] = b.v[i].x; d[1] = b.v[i].y; d[2] = b.v[i].z; d[3] = b.v[i].w;
+      }
+    }
+  };
+  Pre r_pq, r_pk, r_wq, r_wk, r_noise, r_dom, r_dqr;
+  issue(r_pq, p.pq + oL, L);
+  issue(r_pk, p.pk + oL, L);
+  if (p.has_mlp) { issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
+  {
+    const float* nsrc = p.noise ? (p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC) : nullptr;
+    issue(r_noise, nsrc, p.dup == 1 ? L : C);
+  }
+  if (BWD) {
+    issue(r_dom, p.d_omega + oC, C);
+    issue(r_dqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, C);
+  }
   if (p.has_mlp) {
     for (int i = tid; i < D; i += LMK_T) {
       pv[i] = p.gq[i]; pv[D + i] = p.cq[i]; pv[2 * D + i] = p.gk[i]; pv[3 * D + i] = p.ck[i];
@@ -101,13 +136,14 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   for (int side = 0; side < 2; ++side) {
     float* X = side == 0 ? S1 : S2;
     const float* src = (side == 0 ? p.pq : p.pk) + oL;
+    (void)src;
     if (!p.has_mlp) {
-      load_rows(X, src, L);
+      commit(X, side == 0 ? r_pq : r_pk, L);
       __syncthreads();
       continue;
     }
-    load_rows(S3, src, L);
-    load_rows(S7, side == 0 ? p.Wq : p.Wk, D);                 // W [out][in]
+    commit(S3, side == 0 ? r_pq : r_pk, L);
+    commit(S7, side == 0 ? r_wq : r_wk, D);                    // W [out][in]
     __syncthreads();
     mm<false, true, false>(X, LD, S3, LD, S7, LD, L, D, D, 1.f, tid);     // H = P W^T
     __syncthreads();
@@ -159,13 +195,12 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   }
   __syncthreads();
   const int nrep = C / L;                                       // 1, or 2 with duplicated samples
+  commit(S3, r_noise, p.dup == 1 ? L : C);                      // S3 (k0 copy) is free again
+  __syncthreads();
   for (int idx = tid; idx < C * D; idx += LMK_T) {
     const int c = idx / D, j = idx % D, l = c % L;
     float eps = 0.f;
-    if (p.noise) {
-      if (p.dup == 1) eps = (c >= L ? -1.f : 1.f) * p.noise[(size_t)bh * L * D + l * D + j];
-      else eps = p.noise[oC + idx];
-    }
+    if (p.noise) eps = p.dup == 1 ? (c >= L ? -1.f : 1.f) * S3[l * LD + j] : S3[c * LD + j];
     S7[c * LD + j] = S0[l * LD + j] + eps;
   }
   for (int r = tid; r < L; r += LMK_T) {                          // colsum[l] = |mu_l|^2
@@ -218,8 +253,10 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
 
   // =================================== backward ===================================
   // live: S0 MU, S1 Xq, S2 Xk, S5 A, S6 M, S7 OM.   S4 <- dOM (incoming), S3 <- dMU
-  for (int idx = tid; idx < C * D; idx += LMK_T) S4[(idx / D) * LD + (idx % D)] = p.d_omega[oC + idx];
+  commit(S4, r_dom, C);
   for (int idx = tid; idx < L * D; idx += LMK_T) S3[(idx / D) * LD + (idx % D)] = 0.f;
+  // re-issue the Linear operands of the parameter-gradient stage now; they land during stage B
+  if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
   // dM[c][l] in place of M
   for (int c = tid; c < C; c += LMK_T) {
     const size_t oc = (size_t)bh * C + c;
@@ -258,6 +295,8 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   __syncthreads();
   // fold the C sample rows onto the L landmarks: omega_c = mu[c mod L] +- eps
   // S6 (dM no longer needed) <- d q_bar extra (mis-opt: from qbar_rows), dMU gets dOM (+ mis-biased rows)
+  commit(S0, r_dqr, C);                                          // MU is dead: S0 <- d qbar_rows
+  __syncthreads();
   for (int idx = tid; idx < L * D; idx += LMK_T) {
     const int r = idx / D, j = idx % D;
     float dm = S3[r * LD + j], dqx = 0.f;
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       const int c = r + k * L;
       dm += S4[c * LD + j];
       if (p.d_qbar_rows) {
-        const float g = p.d_qbar_rows[oC + (size_t)c * D + j];
+        const float g = S0[c * LD + j];
         if (p.mis == 0) dqx += g; else if (p.mis == 1) dm += g;
       }
     }
@@ -338,8 +377,8 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       dvec[j] = db;
     }
     // dP = dH W ; dW = dH^T P     (S7 <- W, S0 <- P, S5 <- results)
-    load_rows(S7, side == 0 ? p.Wq : p.Wk, D);
-    load_rows(S0, (side == 0 ? p.pq : p.pk) + oL, L);
+    commit(S7, side == 0 ? r_wq : r_wk, D);
+    commit(S0, side == 0 ? r_pq : r_pk, L);
     __syncthreads();
     mm<false, false, false>(S5, LD, dY, LD, S7, LD, L, D, D, 1.f, tid);
     __syncthreads();
