@@ -180,7 +180,9 @@ static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
   const int maxblk = (g->N + gran - 1) / gran;
   // X passes re-stage the landmark matrices per workgroup: fewer, longer workgroups (~3 per CU);
   // Y passes only keep landmark fragments in registers: more, shorter slices
-  int nblk = (int)(((ypass ? 2048 : 768) + bh - 1) / bh);
+  // (Y-pass partial results are [BH, nsplit, C, D] fp32 per accumulator -- as large as the token
+  // tensors themselves at 6 slices -- so both passes aim at ~3 workgroups per CU, not more)
+  int nblk = (int)((768 + bh - 1) / bh);
   if (nblk < 1) nblk = 1;
   if (nblk > maxblk) nblk = maxblk;
   int tpb = (g->N + nblk - 1) / nblk;
