@@ -447,6 +447,8 @@ static int fill_lmk(const ea_lmk_geom* g, LmkP& p) {
   if (g->mis < 0 || g->mis > 2 || g->dup < 0 || g->dup > 2) return EA_E_BADARG;
   p.BH = g->BH; p.L = g->L; p.C = g->C; p.D = g->D;
   p.has_mlp = g->has_mlp; p.mixed = g->mixed; p.mis = g->mis; p.dup = g->dup; p.scale = g->scale;
+  p.eva = g->eva;
+  if (g->eva && (g->dup != 0 || !g->has_mlp)) return EA_E_BADARG;
   return EA_OK;
 }
 #define LMK_PARAMS(p)                                                                        \
@@ -461,10 +463,10 @@ int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk
   LmkP p = {};
   int rc = fill_lmk(g, p);
   if (rc != EA_OK) return rc;
-  if (!pq || !pk || !omega || !lp) return EA_E_BADARG;
+  if (!pq || !pk || !omega || (!lp && !g->eva)) return EA_E_BADARG;
   if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck)) return EA_E_BADARG;
-  if (g->mis == EA_MIS_OPT && (!qbar_rows || !bhv)) return EA_E_BADARG;
-  if (g->mis == EA_MIS_BIASED && !qbar_rows) return EA_E_BADARG;
+  if (!g->eva && g->mis == EA_MIS_OPT && (!qbar_rows || !bhv)) return EA_E_BADARG;
+  if ((g->eva || g->mis == EA_MIS_BIASED) && !qbar_rows) return EA_E_BADARG;
   if (g->dup != 0 && !noise) return EA_E_BADARG;
   p.pq = pq; p.pk = pk; LMK_PARAMS(p)
   p.noise = noise; p.omega = omega; p.qbar_rows = qbar_rows; p.bhv = bhv; p.lp = lp;
@@ -480,7 +482,8 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
   LmkP p = {};
   int rc = fill_lmk(g, p);
   if (rc != EA_OK) return rc;
-  if (!pq || !pk || !d_omega || !d_lp || !dpq || !dpk) return EA_E_BADARG;
+  if (!pq || !pk || !d_omega || (!d_lp && !g->eva) || !dpq || !dpk) return EA_E_BADARG;
+  if (g->eva && !d_qbar_rows) return EA_E_BADARG;
   if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
     return EA_E_BADARG;
   if (g->dup != 0 && !noise) return EA_E_BADARG;

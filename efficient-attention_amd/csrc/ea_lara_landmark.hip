@@ -165,6 +165,30 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     }
     __syncthreads();
   }
+  if (p.eva) {
+    // EVA (eva.py:178-190): rf_q_bar = q_bar, rf_k_bar = k0, mu = (rf_q_bar + rf_k_bar) / 2, omega = mu + eps
+    if (!BWD) {
+      commit(S3, r_noise, L);
+      __syncthreads();
+      for (int idx = tid; idx < L * D; idx += LMK_T) {
+        const int r = idx / D, j = idx % D;
+        const float k0v = K0(r, j);
+        p.qbar_rows[oC + idx] = k0v;                                        // rf_k_bar
+        p.omega[oC + idx] = 0.5f * (QB(r, j) + k0v) + (p.noise ? S3[r * LD + j] : 0.f);
+      }
+      return;
+    }
+    commit(S3, r_dom, L);                                                   // d omega
+    commit(S0, r_dqr, L);                                                   // d rf_k_bar
+    if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
+    __syncthreads();
+    for (int idx = tid; idx < L * D; idx += LMK_T) {
+      const int o = (idx / D) * LD + (idx % D);
+      S6[o] = 0.5f * S3[o];                                                 // d rf_q_bar
+      S4[o] = 0.5f * S3[o] + S0[o];                                         // d rf_k_bar (total)
+    }
+    __syncthreads();
+  } else {
   // ---- stage A2: mixing  A = softmax(s k0 k0^T), k_bar = A k0  (S6 = k_bar) ----
   for (int idx = tid; idx < L * D; idx += LMK_T) S3[(idx / D) * LD + (idx % D)] = K0(idx / D, idx % D);
   __syncthreads();
@@ -335,6 +359,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     for (int idx = tid; idx < L * D; idx += LMK_T) S4[(idx / D) * LD + (idx % D)] = S3[(idx / D) * LD + (idx % D)];
   }
   __syncthreads();
+  }   // !p.eva
   // ---- LayerNorm + Linear backward for both sides: dY in (S4 for k, S6 for q) ----
   for (int side = 0; side < 2; ++side) {
     float* dY = side == 0 ? S6 : S4;

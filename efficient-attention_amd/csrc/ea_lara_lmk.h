@@ -13,6 +13,7 @@ struct LmkP {
   float *dpq, *dpk, *dW_part, *dvec_part;                 // backward outputs
   int BH, L, C, D;
   int has_mlp, mixed, mis, dup;
+  int eva;                                                // EVA's mu pipeline (eva.py:178-190) instead of LARA's
   float scale;
 };
 

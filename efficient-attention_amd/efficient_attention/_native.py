@@ -38,7 +38,7 @@ class ea_perf_geom(ctypes.Structure):
 class ea_lmk_geom(ctypes.Structure):
     _fields_ = [("BH", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("D", ctypes.c_int32),
                 ("has_mlp", ctypes.c_int32), ("mixed", ctypes.c_int32), ("mis", ctypes.c_int32),
-                ("dup", ctypes.c_int32), ("scale", ctypes.c_float)]
+                ("dup", ctypes.c_int32), ("scale", ctypes.c_float), ("eva", ctypes.c_int32)]
 
 
 class ea_lara_geom(ctypes.Structure):

@@ -173,11 +173,25 @@ class EvaAttnFn(torch.autograd.Function):
         kmean = torch.empty_like(qmean)
         nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
                 nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
-        # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
-        with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
-            rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj)
-            omega = (mu if noise is None else mu + noise.float()).contiguous()
-            rf_k_bar = rf_k_bar.contiguous()
+        fused_mu = adaptive_proj == "default" and L <= 64 and d in (32, 64)
+        if fused_mu:
+            # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
+            lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
+            ps = [p.float().contiguous() for p in mlp_params]
+            noise_c = None if noise is None else noise.float().contiguous()
+            omega = torch.empty_like(qmean)
+            rf_k_bar = torch.empty_like(qmean)
+            nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
+                    *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(omega), nv.ptr(rf_k_bar), None, None,
+                    nv.stream())
+            ctx.lmk = (lg, noise_c)
+        else:
+            # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
+            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
+                rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj)
+                omega = (mu if noise is None else mu + noise.float()).contiguous()
+                rf_k_bar = rf_k_bar.contiguous()
+            ctx.lmk = None
         beta = torch.empty_like(qmean)
         nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
                 nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
@@ -206,6 +220,25 @@ class EvaAttnFn(torch.autograd.Function):
         nv.call("ea_eva_beta_bwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
                 nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
                 ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
+        if ctx.lmk is not None:
+            lg, noise_c = ctx.lmk
+            L_, d_ = lg.L, lg.D
+            ps = [p.float().contiguous() for p in mlp_params]
+            dqm = torch.empty_like(qmean)
+            dkm = torch.empty_like(kmean)
+            dW = torch.empty((lg.BH, 2, d_, d_), dtype=torch.float32, device=qmean.device)
+            dvec = torch.empty((lg.BH, 2, 3, d_), dtype=torch.float32, device=qmean.device)
+            nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
+                    *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(d_omega), nv.ptr(d_rfk.contiguous()),
+                    None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.stream())
+            nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
+                    nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+            dWs, dvs = dW.sum(0), dvec.sum(0)
+            raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+            pgrads = [g.to(p.dtype) for g, p in zip(raw, mlp_params)]
+            if dbias is not None:
+                dbias = dbias[..., :ctx.bias_cols]
+            return (dqkv5, dbias, None, None, None) + tuple(pgrads)
         # mu MLP backward on the tiny [B,h,L,d] tensors (Linear/LayerNorm parameter grads are
         # [d,d] GEMMs over B*h*L rows -- left to torch)
         with torch.enable_grad(), torch.autocast(device_type="cuda", enabled=False):
@@ -424,7 +457,7 @@ class LaraLandmarkFn(torch.autograd.Function):
         pk = pk.float().contiguous()
         noise_c = None if noise is None else noise.float().contiguous()
         ps = [t.float().contiguous() for t in params]
-        geom = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale))
+        geom = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale), 0)
         omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
         qrows = torch.empty_like(omega) if mis != 2 else None
         bhv = torch.empty((B, h, C), dtype=torch.float32, device=dev) if mis == 0 else None

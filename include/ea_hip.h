@@ -232,6 +232,9 @@ typedef struct {
   int32_t BH, L, C, D;
   int32_t has_mlp, mixed, mis, dup;
   float   scale;
+  int32_t eva;               /* 1: EVA's mu pipeline instead (eva.py:178-190, adaptive_proj='default'):
+                                qbar_rows = rf_k_bar = LN(pk Wk^T + bk), omega = (rf_q_bar + rf_k_bar)/2 + eps;
+                                bhv / lp unused; the backward takes d_omega and d_qbar_rows = d rf_k_bar */
 } ea_lmk_geom;
 int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk,
                           const float* Wq, const float* bq, const float* gq, const float* cq,
