@@ -5,7 +5,7 @@
 
 namespace ea {
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st);
-int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStream_t st);
+int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st);
 }  // namespace ea
 #include "ea_landmark_params.h"
 #include "ea_lara.h"
@@ -79,20 +79,20 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const ea_t4* out, const ea_t4* dout, const float* lse,
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
-                       float* dk_acc, float* dv_acc, void* stream) {
+                       float* dk_acc, float* dv_acc, const float* bias_t, void* stream) {
   WinP p = {};
   int rc = fill_win(g, p);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dout, g->D) ||
       !t4_ok(out, g->D) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
-  if (bias && !dbias_part) return EA_E_BADARG;
+  if (bias && (!dbias_part || !bias_t)) return EA_E_BADARG;
   p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(dout);
   p.dq = mk(dq); p.dk = mk(dk); p.dv = mk(dv);
   p.lk = lk; p.lv = lv; p.bias = bias; p.mask = mask; p.lse = const_cast<float*>(lse);
   p.dlk_part = dlk_part; p.dlv_part = dlv_part; p.dbias_part = dbias_part;
   p.dk32 = dk_acc; p.dv32 = dv_acc;
-  return window_bwd_dispatch(p, mk(out), g->dtype, g->D, (hipStream_t)stream);
+  return window_bwd_dispatch(p, mk(out), bias ? bias_t : nullptr, g->dtype, g->D, (hipStream_t)stream);
 }
 
 // ---- EVA landmark statistics ----

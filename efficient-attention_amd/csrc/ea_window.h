@@ -84,4 +84,39 @@ struct WinP {
   WinTiling t;
 };
 
+// ---- slot tables: the (window-independent) offset of every key / query slot, built once per
+// workgroup in LDS so that staging needs no integer division per row.
+//   2-D: packed (dy & 0xffff) | (dx << 16) relative to the window origin; 1-D: offset from it.
+EA_DEV void build_slot_tables(int* kd, int* qd, const WinTiling& t, const Geo& G, int w, int e, int nq, int tid) {
+  const int tt = w + 2 * e;
+  for (int s = tid; s < t.nLT * 16; s += 256) {
+    const int i = s / tt, j = s - i * tt;
+    kd[s] = G.attn2d ? (((i - e) & 0xffff) | ((j - e) << 16)) : (s - e);
+  }
+  for (int s = tid; s < nq; s += 256) {
+    const int i = s / w, j = s - i * w;
+    qd[s] = G.attn2d ? ((i & 0xffff) | (j << 16)) : s;
+  }
+}
+// window origin (oy, ox) in 2-D, (first token, 0) in 1-D
+EA_DEV void win_origin(const Geo& G, int win, int w, int& oy, int& ox) {
+  if (G.attn2d) {
+    const int per_row = G.gw / w;
+    const int wy = win / per_row;
+    oy = wy * w;
+    ox = (win - wy * per_row) * w;
+  } else {
+    oy = win * w;
+    ox = 0;
+  }
+}
+EA_DEV int slot_token(const Geo& G, int packed, int oy, int ox) {
+  if (G.attn2d) {
+    const int y = oy + (int)(short)(packed & 0xffff), x = ox + (packed >> 16);
+    return (y >= 0 && y < G.gh && x >= 0 && x < G.gw) ? y * G.gw + x : -1;
+  }
+  const int tok = oy + packed;
+  return (tok >= 0 && tok < G.N) ? tok : -1;
+}
+
 }  // namespace ea

@@ -18,7 +18,7 @@
 namespace ea {
 
 template <typename E, int D>
-__global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 outp) {
+__global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
   constexpr int KS = D / 32;
@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
   float* delta_s = lse_s + rowsQ;
   float* dbias_s = delta_s + rowsQ;
   const int nbias = p.bias ? WqPad * t.biasLd : 0;
-  uint8_t* flags = reinterpret_cast<uint8_t*>(dbias_s + nbias);
+  float* kmul = dbias_s + nbias;
+  float* kadd = kmul + t.rowsTotal;
+  int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
+  int* qd = kd + t.nLT * 16;
+  const int rowsPerWin = t.nLT * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
@@ -70,9 +74,14 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
     }
     sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
     sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
-    if (c == 0) flags[t.rowsLocal + row] = row < p.L ? 0 : 2;
+    if (c == 0) {
+      kmul[t.rowsLocal + row] = row < p.L ? 1.f : 0.f;
+      kadd[t.rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
+    }
   }
   for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
+  build_slot_tables(kd, qd, t, p.G, p.w, p.e, nQTe * 16, tid);
+  __syncthreads();
 
   // landmark-gradient accumulators of the landmark tile this wave owns (tile ct = wave)
   f32x4 dlk[DT], dlv[DT];
@@ -82,51 +91,93 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
   const int it_end = min((blk + 1) * t.ipb, t.niter);
   for (int it = blk * t.ipb; it < it_end; ++it) {
     __syncthreads();
-    // ---- stage local K/V rows ----
-    for (int idx = tid; idx < t.rowsLocal * CPR; idx += 256) {
-      const int row = idx / CPR, c = idx - row * CPR;
-      const int wi = row / (t.nLT * 16), slot = row - wi * (t.nLT * 16);
-      const int win = it * t.wpi + wi;
-      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
-      uint8_t fl = 2;
-      if (win < t.nwin && slot < t.Wk) {
-        const int tok = part_token(p.G, win, slot, p.w, p.e);
-        fl = 1;
-        if (tok >= 0) {
-          kw = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
-          vw = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
-          fl = (mrow && mrow[tok]) ? 1 : 0;
+    // ---- stage local K/V rows and Q/dO rows (+ lse, delta = dO.O).  Batches of NB slots per thread:
+    // every global load of a batch is in flight before the first conversion / LDS store, so the
+    // staging costs ~one memory round trip per iteration instead of one per 256-slot sweep. ----
+    constexpr int NB = 2;
+    for (int base = 0; base < t.rowsLocal * CPR; base += 256 * NB) {
+      u32x4 kr[NB], vr[NB];
+      int rowv[NB];
+      float mulv[NB], addv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = base + tid + i * 256;
+        kr[i] = vr[i] = u32x4{0u, 0u, 0u, 0u};
+        rowv[i] = -1; mulv[i] = 0.f; addv[i] = -INFINITY;
+        if (idx < t.rowsLocal * CPR) {
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+          const int slot = row - wi * rowsPerWin;
+          const int win = it * t.wpi + wi;
+          rowv[i] = row;
+          if (win < t.nwin && slot < t.Wk) {
+            int oy, ox;
+            win_origin(p.G, win, p.w, oy, ox);
+            const int tok = slot_token(p.G, kd[slot], oy, ox);
+            addv[i] = MASK_FILL * LOG2E;
+            if (tok >= 0) {
+              kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
+              vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+              if (!(mrow && mrow[tok])) { mulv[i] = 1.f; addv[i] = 0.f; }
+            }
+          }
         }
       }
-      sts16(Ks + lds_off<D>(row, c), kw);
-      sts16(Vs + lds_off<D>(row, c), vw);
-      if (c == 0) flags[row] = fl;
-    }
-    // ---- stage Q / dO rows, lse (log2 domain) and delta = dO . O ----
-    for (int idx = tid; idx < rowsQ * CPR; idx += 256) {
-      const int row = idx / CPR, c = idx - row * CPR;
-      const int wi = row / (nQTe * 16), slot = row - wi * (nQTe * 16);
-      const int win = it * t.wpi + wi;
-      const int tok = (win < t.nwin && slot < t.Wq) ? part_token(p.G, win, slot, p.w, 0) : -1;
-      u32x4 qw = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u};
-      float part = 0.f;
-      if (tok >= 0) {
-        qw = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
-        dw = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
-        const u32x4 ow = ldg16(ob + (tok * outp.sn + c * 8) * 2);
-        float a[8], o8[8];
-        unpack8<E>(dw, a);
-        unpack8<E>(ow, o8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) part += a[i] * o8[i];
+      for (int i = 0; i < NB; ++i) {
+        if (rowv[i] >= 0) {
+          const int c = (base + tid + i * 256) - rowv[i] * CPR;
+          sts16(Ks + lds_off<D>(rowv[i], c), kr[i]);
+          sts16(Vs + lds_off<D>(rowv[i], c), vr[i]);
+          if (c == 0) { kmul[rowv[i]] = mulv[i]; kadd[rowv[i]] = addv[i]; }
+        }
+      }
+    }
+    for (int base = 0; base < rowsQ * CPR; base += 256 * NB) {
+      u32x4 qr[NB], dr[NB], orr[NB];
+      float lsv[NB];
+      int rowv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = base + tid + i * 256;
+        qr[i] = dr[i] = orr[i] = u32x4{0u, 0u, 0u, 0u};
+        rowv[i] = -1; lsv[i] = INFINITY;
+        if (idx < rowsQ * CPR) {
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
+          const int slot = row - wi * (nQTe * 16);
+          const int win = it * t.wpi + wi;
+          int tok = -1;
+          if (win < t.nwin && slot < t.Wq) {
+            int oy, ox;
+            win_origin(p.G, win, p.w, oy, ox);
+            tok = slot_token(p.G, qd[slot], oy, ox);
+          }
+          rowv[i] = row;
+          if (tok >= 0) {
+            qr[i] = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
+            dr[i] = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
+            orr[i] = ldg16(ob + (tok * outp.sn + c * 8) * 2);
+            if (c == 0) lsv[i] = lse_g[tok] * LOG2E;
+          }
+        }
       }
 #pragma unroll
-      for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
-      sts16(Qs + lds_off<D>(row, c), qw);
-      sts16(dOs + lds_off<D>(row, c), dw);
-      if (c == 0) {
-        delta_s[row] = part;
-        lse_s[row] = tok >= 0 ? lse_g[tok] * LOG2E : INFINITY;
+      for (int i = 0; i < NB; ++i) {
+        float part = 0.f;
+        float a8[8], o8[8];
+        unpack8<E>(dr[i], a8);
+        unpack8<E>(orr[i], o8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += a8[j] * o8[j];
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+        if (rowv[i] >= 0) {
+          const int c = (base + tid + i * 256) - rowv[i] * CPR;
+          sts16(Qs + lds_off<D>(rowv[i], c), qr[i]);
+          sts16(dOs + lds_off<D>(rowv[i], c), dr[i]);
+          if (c == 0) { delta_s[rowv[i]] = part; lse_s[rowv[i]] = lsv[i]; }
+        }
       }
     }
     __syncthreads();
@@ -138,7 +189,12 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
       if (win >= t.nwin) continue;
       const int qslot = qt * 16 + li;
       const int qrow = (wi * nQTe + qt) * 16 + li;
-      const int qtok = qslot < t.Wq ? part_token(p.G, win, qslot, p.w, 0) : -1;
+      int qtok = -1;
+      if (qslot < t.Wq) {
+        int oy, ox;
+        win_origin(p.G, win, p.w, oy, ox);
+        qtok = slot_token(p.G, qd[qslot], oy, ox);
+      }
       typename E::x8 qf[KS], dof[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -169,19 +225,19 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
             s = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], s);
             dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
           }
-          const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + rowbase[tt] + 4 * g);
+          const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
+          const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
+          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);   // log2-domain bias
           const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
           float ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t fl = (f4 >> (8 * r)) & 0xffu;
-            float x = s[r] * p.scale_log2 + bb[r] * LOG2E;
-            x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+            const float x = fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
             const float pr = fast_exp2(x - lse2);
-            // masked_fill blocks the gradient of the replaced logits (fl != 0)
-            ds[r] = fl == 0 ? pr * (dp[r] - delta) : 0.f;
+            // masked_fill blocks the gradient of the replaced logits (mul == 0)
+            ds[r] = mm[r] * pr * (dp[r] - delta);
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
@@ -238,7 +294,7 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
         kf[ks] = as_x8<E>(lds16(Ks + lds_off<D>(krow, g * KS + ks)));
         vf[ks] = as_x8<E>(lds16(Vs + lds_off<D>(krow, g * KS + ks)));
       }
-      const uint32_t fl = flags[krow];
+      const float kmu = kmul[krow], kad = kadd[krow];
       const int kslot = tile * 16 + li;                // key slot within the window / landmark id
       f32x4 dk[DT], dv[DT];
 #pragma unroll
@@ -262,17 +318,20 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
             const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
             const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            // bias of (queries 16 qt + 4g .. +3, this key) from the transposed copy: one 16-B load
+            float4 bt4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (biasT && !is_lm && kslot < t.Wk) bt4 = *reinterpret_cast<const float4*>(
+                biasT + ((size_t)h * t.biasLd + kslot) * (t.nQT * 16) + qt * 16 + 4 * g);
+            const float bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
             float pr[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qs = qt * 16 + 4 * g + r;       // query slot in the window
-              float bias = 0.f;
-              const bool bias_on = p.bias && !is_lm && qs < t.Wq && kslot < t.Wk;
-              if (bias_on) bias = p.bias[((size_t)h * t.Wq + qs) * t.biasLd + kslot];
-              float x = s[r] * p.scale_log2 + bias * LOG2E;
-              x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+              const bool bias_on = biasT && !is_lm && qs < t.Wq && kslot < t.Wk;
+              const float bias = bias_on ? bt[r] : 0.f;
+              const float x = fmaf(kmu, fmaf(s[r], p.scale_log2, bias), kad);
               pr[r] = fast_exp2(x - ll[r]);
-              ds[r] = fl == 0 ? pr[r] * (dp[r] - dd[r]) : 0.f;
+              ds[r] = kmu * pr[r] * (dp[r] - dd[r]);
               if (bias_on && ds[r] != 0.f) atomicAdd(dbias_s + qs * t.biasLd + kslot, ds[r]);
             }
             pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
@@ -299,7 +358,12 @@ __global__ __launch_bounds__(256) void win_bwd_kernel(const WinP p, const T4 out
         for (int dt = 0; dt < DT; ++dt) { dlk[dt] += dk[dt]; dlv[dt] += dv[dt]; }
       } else {
         const int win = it * t.wpi + wi_lo;
-        const int tok = kslot < t.Wk ? part_token(p.G, win, kslot, p.w, p.e) : -1;
+        int tok = -1;
+        if (kslot < t.Wk) {
+          int oy, ox;
+          win_origin(p.G, win, p.w, oy, ox);
+          tok = slot_token(p.G, kd[kslot], oy, ox);
+        }
         if (tok >= 0) {
           float fk[DQ], fv[DQ];
 #pragma unroll
@@ -373,12 +437,12 @@ size_t window_bwd_lds(const WinTiling& t, int D, bool bias) {
   const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
   size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
   if (bias) b += (size_t)t.nQT * 16 * t.biasLd * 4;
-  b += ((size_t)t.rowsTotal + 15) & ~(size_t)15;
+  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4;
   return b;
 }
 
 template <typename E, int D>
-static int launch_bwd(const WinP& p, const T4& outp, hipStream_t st) {
+static int launch_bwd(const WinP& p, const T4& outp, const float* biasT, hipStream_t st) {
   const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
@@ -393,20 +457,20 @@ static int launch_bwd(const WinP& p, const T4& outp, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  hipLaunchKernelGGL((win_bwd_kernel<E, D>), grid, dim3(256), lds, st, p, outp);
+  hipLaunchKernelGGL((win_bwd_kernel<E, D>), grid, dim3(256), lds, st, p, outp, biasT);
   if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);
   return (int)hipGetLastError();
 }
 
-int window_bwd_dispatch(const WinP& p, const T4& outp, int dtype, int D, hipStream_t st) {
+int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st) {
   if (dtype == EA_BF16) {
-    if (D == 64) return launch_bwd<BF16, 64>(p, outp, st);
-    if (D == 32) return launch_bwd<BF16, 32>(p, outp, st);
-    if (D == 128) return launch_bwd<BF16, 128>(p, outp, st);
+    if (D == 64) return launch_bwd<BF16, 64>(p, outp, biasT, st);
+    if (D == 32) return launch_bwd<BF16, 32>(p, outp, biasT, st);
+    if (D == 128) return launch_bwd<BF16, 128>(p, outp, biasT, st);
   } else if (dtype == EA_F16) {
-    if (D == 64) return launch_bwd<F16, 64>(p, outp, st);
-    if (D == 32) return launch_bwd<F16, 32>(p, outp, st);
-    if (D == 128) return launch_bwd<F16, 128>(p, outp, st);
+    if (D == 64) return launch_bwd<F16, 64>(p, outp, biasT, st);
+    if (D == 32) return launch_bwd<F16, 32>(p, outp, biasT, st);
+    if (D == 128) return launch_bwd<F16, 128>(p, outp, biasT, st);
   }
   return EA_E_UNSUPPORTED;
 }

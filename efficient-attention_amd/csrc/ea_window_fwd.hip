@@ -6,14 +6,15 @@
 //
 // One 256-thread workgroup (4 waves) owns a run of windows of one (batch, head):
 //   * the landmark keys/values (rf_k_bar, beta: [L, D]) are converted to the MFMA element type
-//     and parked in LDS once per workgroup;
+//     and parked in LDS once per workgroup, together with the slot-offset tables;
 //   * per iteration the local K/V rows of `wpi` windows are gathered straight from the strided
 //     q/k/v tensors into LDS (the window partition is address arithmetic, nothing is copied in
-//     HBM), out-of-range and padded keys get a per-row flag;
-//   * each wave takes 16-query tiles: Q fragments come directly from global memory as MFMA B
-//     operands, S^T = K.Q^T tiles are produced 64 keys at a time, run through an online softmax
-//     in registers (two 4-lane shuffles per reduction) and fed, register for register, into
-//     O^T = V^T.P^T with V^T fragments from ds_read_b64_tr_b16;
+//     HBM); all loads of the iteration -- the K/V rows and the waves' Q fragments -- are in
+//     flight before the first LDS store; every key row carries (mul, add) so that
+//     logit = mul * (s q.k + bias) + add reproduces masked_fill(-5e4) / absent slots with FMAs;
+//   * each wave takes 16-query tiles: S^T = K.Q^T tiles are produced 64 keys at a time, run
+//     through an online softmax in registers (two 4-lane shuffles per reduction) and fed,
+//     register for register, into O^T = V^T.P^T with V^T fragments from ds_read_b64_tr_b16;
 //   * O is written with each lane owning D/4 contiguous channels of one query (32 B stores).
 // HBM traffic is the algorithmic minimum (q,k,v read once, out written once) plus the landmark
 // rows per workgroup, which come from L2.
@@ -22,18 +23,22 @@
 namespace ea {
 
 template <typename E, int D>
-__global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
+__global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
   constexpr int ROWB = D * 2;      // bytes per LDS row
   constexpr int CPR = D / 8;       // 16-byte chunks per row
   constexpr int KS = D / 32;       // k-steps of the score MFMA
   constexpr int DT = D / 16;       // 16-channel tiles of the output
   constexpr int DQ = D / 4;        // channels per lane in the output layout
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  constexpr int NB = 2;            // staging slots per thread per batch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WinTiling& t = p.t;
   char* Ks = smem;
   char* Vs = Ks + t.rowsTotal * ROWB;
-  uint8_t* flags = reinterpret_cast<uint8_t*>(Vs + t.rowsTotal * ROWB);
+  float* kmul = reinterpret_cast<float*>(Vs + t.rowsTotal * ROWB);
+  float* kadd = kmul + t.rowsTotal;
+  int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
+  int* qd = kd + t.nLT * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
@@ -43,48 +48,94 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
   const char* vb = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
   char* ob = p.o.p + (b * p.o.sb + h * p.o.sh) * 2;
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
+  const int rowsPerWin = t.nLT * 16;
 
-  // ---- landmark rows + the all-zero dummy tile: once per workgroup ----
+  // ---- once per workgroup: slot tables, landmark rows, the all-zero dummy tile ----
+  build_slot_tables(kd, qd, t, p.G, p.w, p.e, t.nQT * 16, tid);
   for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
     const int row = idx / CPR, c = idx - row * CPR;
     u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
     if (row < p.L) {
       const size_t off = ((size_t)bh * p.L + row) * D + c * 8;
-      float f[8];
+      float f[8], f2[8];
       *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lk + off);
       *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lk + off + 4);
+      *reinterpret_cast<float4*>(f2) = *reinterpret_cast<const float4*>(p.lv + off);
+      *reinterpret_cast<float4*>(f2 + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
       kw = pack8<E>(f);
-      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.lv + off);
-      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
-      vw = pack8<E>(f);
+      vw = pack8<E>(f2);
     }
     sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
     sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
-    if (c == 0) flags[t.rowsLocal + row] = row < p.L ? 0 : 2;
+    if (c == 0) {
+      kmul[t.rowsLocal + row] = row < p.L ? 1.f : 0.f;
+      kadd[t.rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
+    }
   }
 
   const int it_end = min((blk + 1) * t.ipb, t.niter);
   for (int it = blk * t.ipb; it < it_end; ++it) {
-    __syncthreads();   // readers of the previous iteration's local rows are done
-    // ---- gather the local K/V rows of this iteration's windows ----
-    for (int idx = tid; idx < t.rowsLocal * CPR; idx += 256) {
-      const int row = idx / CPR, c = idx - row * CPR;
-      const int wi = row / (t.nLT * 16), slot = row - wi * (t.nLT * 16);
-      const int win = it * t.wpi + wi;
-      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
-      uint8_t fl = 2;                                  // slot does not exist
-      if (win < t.nwin && slot < t.Wk) {
-        const int tok = part_token(p.G, win, slot, p.w, p.e);
-        fl = 1;                                        // outside the sequence: zero k/v, -5e4
-        if (tok >= 0) {
-          kw = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
-          vw = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
-          fl = (mrow && mrow[tok]) ? 1 : 0;
+    __syncthreads();   // readers of the previous iteration's local rows are done (and tables ready)
+    // ---- this wave's first query tile: Q fragments issued before anything is waited for ----
+    typename E::x8 qf[KS];
+    int qtok0 = -1;
+    {
+      const int qi = wave;
+      if (qi < t.wpi * t.nQT) {
+        const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
+        const int win = it * t.wpi + wi;
+        const int qslot = qt * 16 + li;
+        if (win < t.nwin && qslot < t.Wq) {
+          int oy, ox;
+          win_origin(p.G, win, p.w, oy, ox);
+          qtok0 = slot_token(p.G, qd[qslot], oy, ox);
         }
       }
-      sts16(Ks + lds_off<D>(row, c), kw);
-      sts16(Vs + lds_off<D>(row, c), vw);
-      if (c == 0) flags[row] = fl;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 w4 = {0u, 0u, 0u, 0u};
+        if (qtok0 >= 0) w4 = ldg16(qb + (qtok0 * p.q.sn + (g * KS + ks) * 8) * 2);
+        qf[ks] = as_x8<E>(w4);
+      }
+    }
+    // ---- gather the local K/V rows of this iteration's windows (batched loads) ----
+    for (int base = 0; base < t.rowsLocal * CPR; base += 256 * NB) {
+      u32x4 kr[NB], vr[NB];
+      int rowv[NB];
+      float mulv[NB], addv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = base + tid + i * 256;
+        kr[i] = vr[i] = u32x4{0u, 0u, 0u, 0u};
+        rowv[i] = -1; mulv[i] = 0.f; addv[i] = -INFINITY;      // slot does not exist
+        if (idx < t.rowsLocal * CPR) {
+          const int row = idx / CPR, c = idx - row * CPR;
+          const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+          const int slot = row - wi * rowsPerWin;
+          const int win = it * t.wpi + wi;
+          rowv[i] = row;
+          if (win < t.nwin && slot < t.Wk) {
+            int oy, ox;
+            win_origin(p.G, win, p.w, oy, ox);
+            const int tok = slot_token(p.G, kd[slot], oy, ox);
+            addv[i] = MASK_FILL * LOG2E;                         // outside / padded: zero k,v, -5e4
+            if (tok >= 0) {
+              kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
+              vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+              if (!(mrow && mrow[tok])) { mulv[i] = 1.f; addv[i] = 0.f; }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (rowv[i] >= 0) {
+          const int c = (base + tid + i * 256) - rowv[i] * CPR;
+          sts16(Ks + lds_off<D>(rowv[i], c), kr[i]);
+          sts16(Vs + lds_off<D>(rowv[i], c), vr[i]);
+          if (c == 0) { kmul[rowv[i]] = mulv[i]; kadd[rowv[i]] = addv[i]; }
+        }
+      }
     }
     __syncthreads();
 
@@ -93,14 +144,22 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
       const int win = it * t.wpi + wi;
       if (win >= t.nwin) continue;                      // wave-uniform
       const int qslot = qt * 16 + li;
-      const int qtok = qslot < t.Wq ? part_token(p.G, win, qslot, p.w, 0) : -1;
-      typename E::x8 qf[KS];
+      int qtok = qtok0;
+      if (qi != wave) {                                 // further tiles of this wave (rare: nQT*wpi > 4)
+        qtok = -1;
+        if (qslot < t.Wq) {
+          int oy, ox;
+          win_origin(p.G, win, p.w, oy, ox);
+          qtok = slot_token(p.G, qd[qslot], oy, ox);
+        }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        u32x4 w4 = {0u, 0u, 0u, 0u};
-        if (qtok >= 0) w4 = ldg16(qb + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
-        qf[ks] = as_x8<E>(w4);
+        for (int ks = 0; ks < KS; ++ks) {
+          u32x4 w4 = {0u, 0u, 0u, 0u};
+          if (qtok >= 0) w4 = ldg16(qb + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
+          qf[ks] = as_x8<E>(w4);
+        }
       }
+      // bias is pre-multiplied by log2(e) by the caller
       const float* brow = p.bias
           ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
 
@@ -113,6 +172,13 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
         int rowbase[4];
         f32x4 s[4];
         float mloc = -INFINITY;
+        float4 b4[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {                 // bias loads first: they overlap the MFMAs
+          const int tile = ch * 4 + tt;
+          b4[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (brow && tile < t.nLT) b4[tt] = *reinterpret_cast<const float4*>(brow + tile * 16);
+        }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const int tile = ch * 4 + tt;
@@ -125,15 +191,13 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
             acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
-          const uint32_t f4 = *reinterpret_cast<const uint32_t*>(flags + rowbase[tt] + 4 * g);
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
-          const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
+          const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
+          const float bb[4] = {b4[tt].x, b4[tt].y, b4[tt].z, b4[tt].w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t fl = (f4 >> (8 * r)) & 0xffu;
-            float x = acc[r] * p.scale_log2 + bb[r] * LOG2E;
-            x = fl == 0 ? x : (fl == 1 ? MASK_FILL * LOG2E : -INFINITY);
+            const float x = fmaf(mm[r], fmaf(acc[r], p.scale_log2, bb[r]), aa[r]);
             acc[r] = x;
             mloc = fmaxf(mloc, x);
           }
@@ -196,9 +260,13 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(const WinP p) {
   }
 }
 
+size_t window_fwd_lds(const WinTiling& t, int D) {
+  return (size_t)t.rowsTotal * D * 2 * 2 + (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + t.nQT * 16) * 4;
+}
+
 template <typename E, int D>
 static int launch_fwd(const WinP& p, hipStream_t st) {
-  const size_t lds = (size_t)p.t.rowsTotal * D * 2 * 2 + p.t.rowsTotal;
+  const size_t lds = window_fwd_lds(p.t, D);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D>),

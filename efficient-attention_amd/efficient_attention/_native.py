@@ -63,7 +63,7 @@ SIGNATURES = {
     "ea_eva_beta_fwd": [_G, _T, _T, _P, _P, _P, _P],
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
-    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 16,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 20,
     "ea_lara_parts": [_LG],

@@ -54,12 +54,17 @@ def _mask_u8(mask, B, N, device):
     return m
 
 
+_LOG2E = 1.4426950408889634
+
+
 def _bias_padded(bias, geom):
-    """[h, Wq, Wk] fp32 -> rows padded to the kernel's leading dimension."""
+    """[h, Wq, Wk] fp32 -> rows padded to the kernel's leading dimension, pre-multiplied by
+    log2(e): the kernels evaluate the softmax in the log2 domain (the bias GRADIENT they return is
+    with respect to the natural-unit bias)."""
     if bias is None:
         return None
     ld = nv.query("ea_window_bias_ld", geom)
-    b = bias.float()
+    b = bias.float() * _LOG2E
     if b.shape[-1] != ld:
         b = F.pad(b, (0, ld - b.shape[-1]))
     return b.contiguous()
@@ -95,12 +100,16 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
     if geom.ext > 0:
         dk_acc = torch.empty((B, h, N, d), dtype=torch.float32, device=dev)
         dv_acc = torch.empty_like(dk_acc)
+    bias_t = None
+    if bias_p is not None:
+        wq_pad = -(-bias_p.shape[1] // 16) * 16
+        bias_t = F.pad(bias_p.transpose(1, 2), (0, wq_pad - bias_p.shape[1])).contiguous()   # [h, ld, WqPad]
     ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
     nv.call("ea_window_attn_bwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]),
             ctypes.byref(ts[2]), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
             ctypes.byref(ts[3]), ctypes.byref(ts[4]), nv.ptr(lse), ctypes.byref(ts[5]),
             ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(dlk_p), nv.ptr(dlv_p), nv.ptr(dbias_p),
-            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.stream())
+            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.stream())
     dlk = dlk_p.sum(0).view(B, h, L, d) if L > 0 else None
     dlv = dlv_p.sum(0).view(B, h, L, d) if L > 0 else None
     dbias = dbias_p.sum((0, 1)) if bias_p is not None else None

@@ -91,7 +91,8 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  *     out = P_local V_window + P_cv lv                           (eva.py:222-227)
  * With L == 0 this is LocalAttention._apply_attention (local_attention.py:134-182).
  *   lk, lv : fp32 [B,H,L,D] (rf_k_bar and beta), may be NULL iff L == 0
- *   bias   : fp32 [H, Wq, ea_window_bias_ld(g)] dense per-head bias (rows padded), or NULL
+ *   bias   : fp32 [H, Wq, ea_window_bias_ld(g)] dense per-head bias MULTIPLIED BY log2(e) (the
+ *            softmax runs in the log2 domain), rows padded, or NULL; dbias_part is d/d(natural bias)
  *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward
  * Backward consumes the forward's out, lse and dout and produces dq, dk, dv (WRITTEN, not
  * accumulated).  With overlapping windows (ext > 0) a token is a key of several windows: the
@@ -100,7 +101,9 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  * The landmark and bias gradients come back as per-workgroup partial sums which the caller
  * reduces over the leading axes:
  *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
- *   dbias_part         : fp32 [ea_window_bwd_parts(g), B, H, Wq, ld]   (NULL iff bias NULL) */
+ *   dbias_part         : fp32 [ea_window_bwd_parts(g), B, H, Wq, ld]   (NULL iff bias NULL)
+ *   bias_t             : fp32 [H, ld, 16*ceil(Wq/16)] transposed copy of `bias` (rows padded with
+ *                        zeros), read by the key-tile phase with 16-B loads (NULL iff bias NULL) */
 int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
 int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
@@ -111,7 +114,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const ea_t4* out, const ea_t4* dout, const float* lse,
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
-                       float* dk_acc, float* dv_acc, void* stream);
+                       float* dk_acc, float* dv_acc, const float* bias_t, void* stream);
 
 /* ---- LARA: linear randomized attention (lara.py:177-251) -------------------------------------
  * C landmark samples omega_c (C = L, or 2L with antithetic / multi-sample noise), each token n:
