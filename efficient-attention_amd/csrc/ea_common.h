@@ -136,4 +136,26 @@ template <int D> EA_DEV int lds_off(int row, int chunk16) {
   return row * (D * 2) + ((chunk16 ^ (row & SW)) << 4);
 }
 
+// Per-lane byte offsets into a swizzled LDS tile, computed ONCE per kernel: every tile base used by
+// the kernels is a multiple of 16 rows, and the swizzle only looks at (row & 7), so the offset of a
+// lane's operand inside "its" 16-row tile is a lane constant -- the hot loops then address LDS with
+// one scalar-plus-vector add instead of re-deriving the shift/xor chain per read.
+template <int D> struct LaneOff {
+  static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
+  static constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
+  int plain[KS];   // A/B operand chunk (row = lane & 15, k-step ks) of a 16-row tile
+  int tr[DT];      // ds_read_b64_tr_b16 source (row = 4g + (li >> 2), channel tile dt)
+  EA_DEV void init(int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) plain[ks] = li * ROWB + (((g * KS + ks) ^ (li & SW)) << 4);
+    const int r = 4 * g + (li >> 2);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int colb = (DQ * (li & 3) + 4 * dt) * 2;
+      tr[dt] = r * ROWB + ((((colb >> 4)) ^ (r & SW)) << 4) + (colb & 15);
+    }
+  }
+};
+
 }  // namespace ea

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   constexpr int KS = D / 32;
   constexpr int DT = D / 16;
   constexpr int DQ = D / 4;
-  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WinTiling& t = p.t;
   const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
@@ -45,6 +44,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   const int rowsPerWin = t.nLT * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  LaneOff<D> lo;
+  lo.init(lane);
   const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       typename E::x8 qf[KS], dof[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = as_x8<E>(lds16(Qs + lds_off<D>(qrow, g * KS + ks)));
-        dof[ks] = as_x8<E>(lds16(dOs + lds_off<D>(qrow, g * KS + ks)));
+        qf[ks] = as_x8<E>(lds16(Qs + (qrow - li) * ROWB + lo.plain[ks]));
+        dof[ks] = as_x8<E>(lds16(dOs + (qrow - li) * ROWB + lo.plain[ks]));
       }
       const float lse2 = lse_s[qrow], delta = delta_s[qrow];
       const float* brow = p.bias
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           const int row = rowbase[tt] + li;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            s = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], s);
-            dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
+            s = E::mma(as_x8<E>(lds16(Ks + rowbase[tt] * ROWB + lo.plain[ks])), qf[ks], s);
+            dp = E::mma(as_x8<E>(lds16(Vs + rowbase[tt] * ROWB + lo.plain[ks])), dof[ks], dp);
           }
           const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
@@ -248,15 +249,11 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           f4v[0] = dsw[2 * kk][0]; f4v[1] = dsw[2 * kk][1];
           f4v[2] = dsw[2 * kk + 1][0]; f4v[3] = dsw[2 * kk + 1][1];
           const typename E::x8 dsf = as_x8<E>(f4v);
-          const int r0 = rowbase[2 * kk] + 4 * g + (li >> 2);
-          const int r1 = rowbase[2 * kk + 1] + 4 * g + (li >> 2);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-            const int c16 = colb >> 4, within = colb & 15;
-            const u32x2 lo = E::tr4(Ks + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
-            const u32x2 hi = E::tr4(Ks + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
-            dq[dt] = E::mma(as_x8<E>(lo, hi), dsf, dq[dt]);
+            const u32x2 lo_ = E::tr4(Ks + rowbase[2 * kk] * ROWB + lo.tr[dt]);
+            const u32x2 hi_ = E::tr4(Ks + rowbase[2 * kk + 1] * ROWB + lo.tr[dt]);
+            dq[dt] = E::mma(as_x8<E>(lo_, hi_), dsf, dq[dt]);
           }
         }
       }
@@ -291,8 +288,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       typename E::x8 kf[KS], vf[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = as_x8<E>(lds16(Ks + lds_off<D>(krow, g * KS + ks)));
-        vf[ks] = as_x8<E>(lds16(Vs + lds_off<D>(krow, g * KS + ks)));
+        kf[ks] = as_x8<E>(lds16(Ks + (krow - li) * ROWB + lo.plain[ks]));
+        vf[ks] = as_x8<E>(lds16(Vs + (krow - li) * ROWB + lo.plain[ks]));
       }
       const float kmu = kmul[krow], kad = kadd[krow];
       const int kslot = tile * 16 + li;                // key slot within the window / landmark id
@@ -312,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-              s = E::mma(as_x8<E>(lds16(Qs + lds_off<D>(rq[u] + li, g * KS + ks))), kf[ks], s);
-              dp = E::mma(as_x8<E>(lds16(dOs + lds_off<D>(rq[u] + li, g * KS + ks))), vf[ks], dp);
+              s = E::mma(as_x8<E>(lds16(Qs + rq[u] * ROWB + lo.plain[ks])), kf[ks], s);
+              dp = E::mma(as_x8<E>(lds16(dOs + rq[u] * ROWB + lo.plain[ks])), vf[ks], dp);
             }
             const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
@@ -341,13 +338,10 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
           b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
           const typename E::x8 pf = as_x8<E>(a4), dsf = as_x8<E>(b4);
-          const int r0 = rq[0] + 4 * g + (li >> 2), r1 = rq[1] + 4 * g + (li >> 2);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-            const int c16 = colb >> 4, within = colb & 15;
-            const int o0 = r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within;
-            const int o1 = r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within;
+            const int o0 = rq[0] * ROWB + lo.tr[dt];
+            const int o1 = rq[1] * ROWB + lo.tr[dt];
             dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
             dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
           }

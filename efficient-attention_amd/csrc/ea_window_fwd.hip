@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
   constexpr int KS = D / 32;       // k-steps of the score MFMA
   constexpr int DT = D / 16;       // 16-channel tiles of the output
   constexpr int DQ = D / 4;        // channels per lane in the output layout
-  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   constexpr int NB = 2;            // staging slots per thread per batch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WinTiling& t = p.t;
@@ -41,6 +40,8 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
   int* qd = kd + t.nLT * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  LaneOff<D> lo;
+  lo.init(lane);
   const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
           const int row = rowbase[tt] + li;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
-            acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+            acc = E::mma(as_x8<E>(lds16(Ks + rowbase[tt] * ROWB + lo.plain[ks])), qf[ks], acc);
           const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -230,15 +231,11 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
           pf4[0] = pw[2 * kk][0]; pf4[1] = pw[2 * kk][1];
           pf4[2] = pw[2 * kk + 1][0]; pf4[3] = pw[2 * kk + 1][1];
           const typename E::x8 pf = as_x8<E>(pf4);
-          const int r0 = rowbase[2 * kk] + 4 * g + (li >> 2);
-          const int r1 = rowbase[2 * kk + 1] + 4 * g + (li >> 2);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const int colb = (DQ * (li & 3) + 4 * dt) * 2;          // byte column of 4 channels
-            const int c16 = colb >> 4, within = colb & 15;
-            const u32x2 lo = E::tr4(Vs + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
-            const u32x2 hi = E::tr4(Vs + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
-            o[dt] = E::mma(as_x8<E>(lo, hi), pf, o[dt]);
+            const u32x2 lo_ = E::tr4(Vs + rowbase[2 * kk] * ROWB + lo.tr[dt]);
+            const u32x2 hi_ = E::tr4(Vs + rowbase[2 * kk + 1] * ROWB + lo.tr[dt]);
+            o[dt] = E::mma(as_x8<E>(lo_, hi_), pf, o[dt]);
           }
         }
       }
