@@ -11,6 +11,7 @@ int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int d
 #include "ea_lara.h"
 #include "ea_softmax.h"
 #include "ea_lara_lmk.h"
+#include "ea_lara_merge.h"
 namespace ea {
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
@@ -491,6 +492,38 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
   p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
   p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
   return lara_lmk_dispatch(true, p, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- LARA partial merges ----
+extern "C" {
+
+int ea_lara_merge_fwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t,
+                      const float* p_ml, const float* p_kv, const float* lp,
+                      float* kv, float* lse_k, float* lse_t, float* cst, void* stream) {
+  if (BH <= 0 || S <= 0 || C <= 0 || D <= 0 || !p_ml || !p_kv || !lp || !kv || !lse_k || !cst ||
+      (has_t && !lse_t)) return EA_E_BADARG;
+  MergeP p = {};
+  p.BH = BH; p.S = S; p.C = C; p.D = D; p.has_t = has_t;
+  p.p_ml = p_ml; p.p_kv = p_kv; p.lp = lp; p.kv = kv; p.lse_k = lse_k; p.lse_t = lse_t; p.cst = cst;
+  return lara_merge_dispatch(false, p, (hipStream_t)stream);
+}
+
+int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t, float scale,
+                      const float* p_ml, const float* p_dkv, const float* p_dom, const float* p_m1,
+                      const float* p_m2, const float* kv, const float* qbar,
+                      float* r, float* dbh, float* dlp, float* dkk, float* dkv, float* domq,
+                      float* dqbar, float* uq, void* stream) {
+  if (BH <= 0 || S <= 0 || C <= 0 || D <= 0 || !p_ml || !p_dkv || !p_dom || !kv || !r || !dkk ||
+      !dkv || !domq) return EA_E_BADARG;
+  if (has_t && (!p_m1 || !p_m2 || !qbar || !dqbar || !uq)) return EA_E_BADARG;
+  MergeP p = {};
+  p.BH = BH; p.S = S; p.C = C; p.D = D; p.has_t = has_t; p.scale = scale;
+  p.p_ml = p_ml; p.acc0 = p_dkv; p.acc1 = p_dom; p.acc2 = p_m1; p.acc3 = p_m2;
+  p.kv = const_cast<float*>(kv); p.qbar = qbar;
+  p.r = r; p.dbh = dbh; p.dlp = dlp; p.dkk = dkk; p.dkv = dkv; p.domq = domq; p.dqbar = dqbar; p.uq = uq;
+  return lara_merge_dispatch(true, p, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 16,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 20,
+    "ea_lara_merge_fwd": [_I] * 5 + [_P] * 8,
+    "ea_lara_merge_bwd": [_I] * 5 + [_F] + [_P] * 16,
     "ea_lara_parts": [_LG],
     "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],

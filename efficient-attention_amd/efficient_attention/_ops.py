@@ -372,18 +372,14 @@ class LaraAttnFn(torch.autograd.Function):
         nv.call("ea_lara_stats_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
                 ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(p_ml),
                 nv.ptr(p_kv), nv.stream())
-        # merge the sequence slices (tiny): log-sum-exp merge of the online-softmax partials
-        m_k, l_k, m_t, l_t = p_ml.unbind(-1)
-        Mk = m_k.amax(1, keepdim=True)
-        wk = torch.exp(m_k - Mk)
-        lk = (l_k * wk).sum(1)
-        kv = ((p_kv * wk.unsqueeze(-1)).sum(1) / lk.unsqueeze(-1)).contiguous()    # [BH, C, d]
-        lse_k = (Mk.squeeze(1) + torch.log(lk)).contiguous()
-        lse_t = None
-        if mis == 0:
-            Mt = m_t.amax(1, keepdim=True)
-            lse_t = (Mt.squeeze(1) + torch.log((l_t * torch.exp(m_t - Mt)).sum(1))).contiguous()
-        cst = (lse_k - lp.reshape(BH, C).float()).contiguous()
+        # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
+        kv = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+        sc = torch.empty((3, BH, C), dtype=torch.float32, device=dev)
+        lse_k, cst = sc[0], sc[1]
+        lse_t = sc[2] if mis == 0 else None
+        lp_c = lp.reshape(BH, C).float().contiguous()
+        nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
+                nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
         bhv_c = None if bhv is None else bhv.reshape(BH, C).float().contiguous()
         out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
         to = nv.t4(out.permute(0, 2, 1, 3))
@@ -419,13 +415,16 @@ class LaraAttnFn(torch.autograd.Function):
                 nv.ptr(omega), nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst),
                 nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.ptr(p_ml),
                 nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
-        sums = p_ml.sum(1)                                   # [BH, C, 4]
-        r, dbh, u = sums[..., 0].contiguous(), sums[..., 1], sums[..., 2]
-        nacc = 4 if mis == 0 else 2
-        acc = p_acc[:nacc].sum(2)                            # [nacc, BH, C, d]
-        dkv = acc[0].contiguous()
-        dom_q = acc[1]
-        dkk = (dkv * kv).sum(-1).contiguous()
+        # sums over the slices + derived per-landmark quantities (one tiny kernel)
+        big = torch.empty((4, BH, C, d), dtype=torch.float32, device=dev)
+        dkv, dom_q, dqbar_m, uq = big[0], big[1], big[2], big[3]
+        small = torch.empty((4, BH, C), dtype=torch.float32, device=dev)
+        r, dbh, dlp_m, dkk = small[0], small[1], small[2], small[3]
+        want_dqbar = mis in (0, 1)
+        nv.call("ea_lara_merge_bwd", BH, S, C, d, 1 if mis == 0 else 0, float(scale), nv.ptr(p_ml),
+                nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.ptr(kv), nv.ptr(qbar),
+                nv.ptr(r), nv.ptr(dbh), nv.ptr(dlp_m), nv.ptr(dkk), nv.ptr(dkv), nv.ptr(dom_q),
+                nv.ptr(dqbar_m) if want_dqbar else None, nv.ptr(uq) if mis == 0 else None, nv.stream())
         nv.call("ea_lara_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
                 nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r), ctypes.byref(tdk),
                 ctypes.byref(tdv), nv.stream())
@@ -436,14 +435,13 @@ class LaraAttnFn(torch.autograd.Function):
         d_omega = (scale * (dom_q + p_domk.sum(1))).view(B, h, C, d)
         d_qbar = d_bhv = None
         if mis == 0:
-            uq = (u.unsqueeze(-1) * qbar).contiguous()
             nv.call("ea_lara_bwd_qcorr", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq),
                     nv.ptr(lse_t), ctypes.byref(tdq), nv.stream())
-            d_qbar = (scale * (acc[2] - u.unsqueeze(-1) * acc[3])).view(B, h, C, d)
+            d_qbar = dqbar_m.view(B, h, C, d)
             d_bhv = dbh.reshape(B, h, C)
         elif mis == 1:
-            d_qbar = (scale * dom_q).view(B, h, C, d)
-        d_lp = (-r).view(B, h, C)
+            d_qbar = dqbar_m.view(B, h, C, d)
+        d_lp = dlp_m.view(B, h, C)
         has_qbar, has_bhv = ctx.has
         if ctx.slot is not None:
             ctx.slot.buf = dqkv5          # the pooling backward accumulates into this buffer in place
@@ -702,7 +700,9 @@ class LinearFn(torch.autograd.Function):
             S = _split_k(rows)
             if S > 1:
                 part = torch.bmm(dy2.view(S, rows // S, -1).transpose(1, 2), xl.view(S, rows // S, -1))
-                dw = part.sum(0, dtype=torch.float32).to(wdtype)
+                # sum over the slices as a [1,S] x [S, out*in] GEMM (fp32 accumulation inside the GEMM)
+                ones = torch.ones((1, S), dtype=part.dtype, device=part.device)
+                dw = (ones @ part.view(S, -1)).view(part.shape[1:]).to(wdtype)
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:

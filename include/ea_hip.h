@@ -251,6 +251,21 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
                           const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
                           float* dW_part, float* dvec_part, void* stream);
 
+/* ---- LARA: merging the sequence slices of the token-row passes (tiny, one workgroup per (b,h)) ----
+ * merge_fwd: (p_ml, p_kv of ea_lara_stats_fwd over S slices, lp) -> kv_stats [BH,C,D], lse_k,
+ *   lse_t (has_t: mis-opt) and cst = lse_k - lp [BH,C].
+ * merge_bwd: (p_ml, p_dkv, p_dom, p_m1, p_m2 of ea_lara_bwd_qstats) -> r, d(bh), d(lp) = -r,
+ *   dkk = dkv.kv [BH,C]; dkv, domq = sum_n dZ q_n [BH,C,D]; with has_t also
+ *   dqbar = s (M1 - u M2) and uq = u qbar; without, dqbar (if non-NULL) = s domq (mis-biased). */
+int ea_lara_merge_fwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t,
+                      const float* p_ml, const float* p_kv, const float* lp,
+                      float* kv, float* lse_k, float* lse_t, float* cst, void* stream);
+int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t, float scale,
+                      const float* p_ml, const float* p_dkv, const float* p_dom, const float* p_m1,
+                      const float* p_m2, const float* kv, const float* qbar,
+                      float* r, float* dbh, float* dlp, float* dkk, float* dkv, float* domq,
+                      float* dqbar, float* uq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
