@@ -87,15 +87,29 @@ template <typename E> EA_DEV typename E::x8 as_x8(u32x2 lo, u32x2 hi) {
 EA_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 EA_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-// reduce over the four lanes {li, li+16, li+32, li+48} that share a query/key column
+// reduce over the four lanes {li, li+16, li+32, li+48} that share a query/key column.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two VGPRs in
+// the VALU (no LDS crossbar round trip like ds_bpermute): swap(v, v) leaves one register holding
+// the even rows' values and the other the odd rows', so each level is one swap + one add/max.
+// (Inline asm: with identical inputs the builtin's two results get folded together by hipcc; the
+// s_nop covers the VALU-write -> permlane-read hazard.)
+EA_DEV void lane_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+EA_DEV void lane_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 EA_DEV float quad_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
+  float a = v, b = v;
+  lane_swap16(a, b);
+  a = fmaxf(a, b); b = a;
+  lane_swap32(a, b);
+  return fmaxf(a, b);
 }
 EA_DEV float quad_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+  float a = v, b = v;
+  lane_swap16(a, b);
+  a = a + b; b = a;
+  lane_swap32(a, b);
+  return a + b;
 }
+EA_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 EA_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -23,7 +23,7 @@ constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product
 // 2 LDS reads per 1024 MACs instead of 2 per MAC.  A wave per tile, tiles round-robin over waves.
 template <bool TA, bool TB, bool ACC>
 EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
-               float alpha, int tid) {
+               float alpha, int tid, const float* colbias = nullptr) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
   for (int tile = wave; tile < tm * tn; tile += LMK_T / 64) {
@@ -44,10 +44,11 @@ EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int l
     for (int ks = 0; ks < 16; ++ks)
       if (ks * 4 < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
     if (b_ok) {
+      const float cb = colbias ? colbias[bn] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + 4 * g + r;
-        if (m < M) C[m * ldc + bn] = ACC ? C[m * ldc + bn] + alpha * acc[r] : alpha * acc[r];
+        if (m < M) C[m * ldc + bn] = (ACC ? C[m * ldc + bn] + alpha * acc[r] : alpha * acc[r]) + cb;
       }
     }
   }
@@ -145,15 +146,15 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     commit(S3, side == 0 ? r_pq : r_pk, L);
     commit(S7, side == 0 ? r_wq : r_wk, D);                    // W [out][in]
     __syncthreads();
-    mm<false, true, false>(X, LD, S3, LD, S7, LD, L, D, D, 1.f, tid);     // H = P W^T
+    const float* bias = pv + (side == 0 ? 4 * D : 5 * D);
+    mm<false, true, false>(X, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, bias);     // H = P W^T + b
     __syncthreads();
     float* rstd = side == 0 ? rstd_q : rstd_k;
-    const float* bias = pv + (side == 0 ? 4 * D : 5 * D);
     // a thread per row (row stride D+1 floats: conflict-free across rows); serial over D, no shuffles
     for (int r = tid; r < L; r += LMK_T) {
       float sum = 0.f;
       _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) { const float v = X[r * LD + j] + bias[j]; X[r * LD + j] = v; sum += v; }
+      for (int j = 0; j < D; ++j) sum += X[r * LD + j];
       const float mean = sum / D;
       float var = 0.f;
       _Pragma("unroll 16")

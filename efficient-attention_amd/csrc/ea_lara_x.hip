@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { z2[ct][r] = fast_exp2(z2[ct][r] - mx); ssum += z2[ct][r]; }
       ssum = quad_sum(ssum);
-      const float inv = 1.f / ssum;
+      const float inv = fast_rcp(ssum);
       if (MODE == LX_FWD) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
             const float dz = z2[ct][r] * (dw[ct][r] - rd);
             w1[ct][r] = dz;
             float da = 0.f;
-            if (p.mis == MIS_OPT) da = al[ct][r] > 1e-8f ? dz / al[ct][r] : 0.f;
+            if (p.mis == MIS_OPT) da = al[ct][r] > 1e-8f ? dz * fast_rcp(al[ct][r]) : 0.f;
             w2[ct][r] = da;
             sda += da;
           }
@@ -320,14 +320,14 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
         }
       if (MODE == LX_POUT) {
         den = quad_sum(den);
-        pden = 1.f / fmaxf(den, 1e-2f);
+        pden = fast_rcp(fmaxf(den, 1e-2f));
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) w1[ct][r] = phi[ct][r];
       } else if (MODE == LX_PBWDQ) {
         den = quad_sum(den);
-        const float invden = 1.f / fmaxf(den, 1e-2f);
+        const float invden = fast_rcp(fmaxf(den, 1e-2f));
         // dout . out in the B-fragment layout
         float dd = 0.f;
 #pragma unroll

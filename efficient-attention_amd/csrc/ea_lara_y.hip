@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
             const float dz = w * (s3[r] - rd);
             float da = 0.f, tdt = 0.f;
             if (p.mis == MIS_OPT) {
-              da = e.alpha > 1e-8f ? dz / e.alpha : 0.f;
+              da = e.alpha > 1e-8f ? dz * fast_rcp(e.alpha) : 0.f;
               tdt = e.t * p.kappa * (da - sd * invC);
             }
             w0[mt][r] = w; w1v[mt][r] = dz; w2v[mt][r] = tdt; w3v[mt][r] = e.t;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   }
   const float ltot = quad_sum(lsum);
   if (qvalid) {
-    const float inv = 1.f / ltot;
+    const float inv = fast_rcp(ltot);
     float f[DQ];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
       }
       // ---- finalize: normalise, store O (lane: query li, channels DQ*g .. DQ*g+DQ-1), lse ----
       const float ltot = quad_sum(lsum);
-      const float inv = 1.f / ltot;
+      const float inv = fast_rcp(ltot);
       if (qtok >= 0) {
         float f[DQ];
 #pragma unroll
