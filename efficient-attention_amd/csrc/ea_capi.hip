@@ -177,7 +177,7 @@ static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
   p.norm_coef2 = 0.5f * g->scale * LOG2E;      // s |k|^2 / 2 in the log2 domain
   p.knorm_coef = g->scale;
   const long bh = (long)g->B * g->H;
-  const int gran = ypass ? 32 * lara_nsub(p.NCT) : 64;
+  const int gran = ypass ? 128 : 64;
   const int maxblk = (g->N + gran - 1) / gran;
   // X passes re-stage the landmark matrices per workgroup: fewer, longer workgroups (~3 per CU);
   // Y passes only keep landmark fragments in registers: more, shorter slices

@@ -33,13 +33,14 @@ EA_DEV void load_lm_frag(typename E::x8* dst, const float* src, bool ok, int g) 
 }
 
 template <typename E, int D, int MODE>
-__global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
+__global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nsub = p.NCT == 1 ? 4 : (p.NCT == 2 ? 2 : 1);
   const int ncw = 4 / nsub;                          // landmark tiles handled concurrently
-  const int chunk = 32 * nsub;
+  constexpr int chunk = 128;                         // tokens staged per barrier pair (4 x 32-row blocks)
+  constexpr int NSL = chunk * CPR / 256;             // staging slots per thread
   char* T1 = smem;
   char* T2 = T1 + chunk * ROWB;
   float* sc = reinterpret_cast<float*>(T2 + chunk * ROWB);   // [4][chunk] per-row scalars
@@ -90,53 +91,78 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
     const bool need2 = !(MODE == LY_FWD && phase == 1) && MODE != LY_PMAX;
     const char* a1b = a1.p + (b * a1.sb + h * a1.sh) * 2;
     const char* a2b = need2 ? a2.p + (b * a2.sb + h * a2.sh) * 2 : nullptr;
-    for (int cb = n0; cb < n1; cb += chunk) {
-      __syncthreads();
-      // ---- stage token rows (+ per-row scalars) ----
-      for (int idx = tid; idx < chunk * CPR; idx += 256) {
+    // Software pipeline: the rows of chunk i+1 (and their per-token scalars) are loaded into
+    // registers while chunk i is being computed; the LDS image is refreshed between two barriers.
+    u32x4 pw1[NSL], pw2[NSL];
+    float ps0[NSL], ps1[NSL], ps2[NSL], ps3[NSL];
+    auto issue = [&](int cb_) {
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) {
+        const int idx = tid + i * 256;
         const int row = idx / CPR, cc = idx - row * CPR;
-        const int tok = cb + row;
+        const int tok = cb_ + row;
         const bool valid = tok < n1;
-        u32x4 w1 = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
+        pw1[i] = pw2[i] = u32x4{0u, 0u, 0u, 0u};
+        ps0[i] = ps1[i] = ps2[i] = ps3[i] = 0.f;
         if (valid) {
-          w1 = ldg16(a1b + (tok * a1.sn + cc * 8) * 2);
-          if (need2) w2 = ldg16(a2b + (tok * a2.sn + cc * 8) * 2);
+          pw1[i] = ldg16(a1b + (tok * a1.sn + cc * 8) * 2);
+          if (need2) pw2[i] = ldg16(a2b + (tok * a2.sn + cc * 8) * 2);
+          if (cc == 0 && (MODE == LY_BWDQ || MODE == LY_PBWDQ)) {
+            const size_t o = (size_t)bh * p.N + tok;
+            ps0[i] = p.lseZ[o]; ps1[i] = p.tmean[o]; ps2[i] = p.rowdot[o];
+            if (MODE == LY_BWDQ) ps3[i] = p.sda[o];
+          }
+          if (cc == 0 && keys && MODE != LY_PMAX) ps0[i] = (p.mask && p.mask[(size_t)b * p.N + tok]) ? 1.f : 0.f;
         }
-        sts16(T1 + lds_off<D>(row, cc), w1);
-        if (need2) sts16(T2 + lds_off<D>(row, cc), w2);
+      }
+    };
+    auto commit = [&](int cb_) {
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / CPR, cc = idx - row * CPR;
+        const bool valid = cb_ + row < n1;
+        sts16(T1 + lds_off<D>(row, cc), pw1[i]);
+        if (need2) sts16(T2 + lds_off<D>(row, cc), pw2[i]);
         if (keys || MODE == LY_PBWDQ) {
           float f[8], part = 0.f;
-          unpack8<E>(w1, f);
+          unpack8<E>(pw1[i], f);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) part += f[i] * f[i];
+          for (int k = 0; k < 8; ++k) part += f[k] * f[k];
 #pragma unroll
           for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
           if (cc == 0) {
             if (MODE == LY_PMAX) {
               sc[row] = valid ? 0.f : -INFINITY;          // stabiliser: max over ALL keys, no diagonal term
             } else if (MODE == LY_PBWDQ) {
-              const size_t o = (size_t)bh * p.N + (valid ? tok : 0);
-              sc[row] = valid ? -p.norm_coef2 * part - p.lseZ[o] : -INFINITY;
-              sc[chunk + row] = valid ? p.tmean[o] : 0.f;        // 1 / clamp(den)
-              sc[2 * chunk + row] = valid ? p.rowdot[o] : 0.f;   // d den
+              sc[row] = valid ? -p.norm_coef2 * part - ps0[i] : -INFINITY;
+              sc[chunk + row] = ps1[i];                   // 1 / clamp(den)
+              sc[2 * chunk + row] = ps2[i];               // d den
             } else {
-              const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + tok]);
+              const bool dead = !valid || ps0[i] != 0.f;
               sc[row] = dead ? -INFINITY : -p.norm_coef2 * part;
             }
           }
         } else if (MODE == LY_FWD) {
           if (cc == 0) sc[row] = valid ? 0.f : -INFINITY;
         } else if (cc == 0) {     // LY_BWDQ
-          const size_t o = (size_t)bh * p.N + (valid ? tok : 0);
-          sc[row] = valid ? p.lseZ[o] : INFINITY;
-          sc[chunk + row] = valid ? p.tmean[o] : 0.f;
-          sc[2 * chunk + row] = valid ? p.rowdot[o] : 0.f;
-          sc[3 * chunk + row] = valid ? p.sda[o] : 0.f;
+          sc[row] = valid ? ps0[i] : INFINITY;
+          sc[chunk + row] = ps1[i];
+          sc[2 * chunk + row] = ps2[i];
+          sc[3 * chunk + row] = ps3[i];
         }
       }
+    };
+    if (n0 < n1) issue(n0);
+    for (int cb = n0; cb < n1; cb += chunk) {
+      __syncthreads();                    // previous chunk's readers are done
+      commit(cb);
       __syncthreads();
+      if (cb + chunk < n1) issue(cb + chunk);
       if (!active) continue;
-      const int rb = sub * 32;
+      for (int sb = sub; sb < chunk / 32; sb += nsub) {
+      const int rb = sb * 32;
+      if (cb + rb >= n1) break;
       float w0[2][4], w1v[2][4], w2v[2][4], w3v[2][4];
       float mloc = -INFINITY;
 #pragma unroll
@@ -250,6 +276,7 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
           }
         }
       }
+      }   // sub-blocks
     }
   }
   if (!c_ok) return;
@@ -285,9 +312,7 @@ __global__ __launch_bounds__(256) void lara_y_kernel(const LaraP p) {
 
 template <typename E, int D>
 static int launch_y(int mode, const LaraP& p, hipStream_t st) {
-  const int nsub = p.NCT == 1 ? 4 : (p.NCT == 2 ? 2 : 1);
-  const int chunk = 32 * nsub;
-  const size_t lds = (size_t)2 * chunk * D * 2 + (size_t)4 * chunk * sizeof(float);
+  const size_t lds = (size_t)2 * 128 * D * 2 + (size_t)4 * 128 * sizeof(float);
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit), (unsigned)((p.NCT + 3) / 4)), block(256);
   switch (mode) {
     case LY_FWD: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_FWD>), grid, block, lds, st, p); break;
