@@ -105,8 +105,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # EA_BENCH_BACKEND=gloo + EA_BENCH_ONE_DEVICE=1: dev-only way to exercise the N > 1 code path
+    # (DDP hooks, barriers, max-over-ranks) on a single-GPU box; never used by the driver.
+    backend = os.environ.get("EA_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
+    if os.environ.get("EA_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
@@ -117,7 +122,7 @@ def main():
     layer.train()
     model = layer
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local])
+        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local] if backend == "nccl" else None)
     opt = torch.optim.SGD(layer.parameters(), lr=1e-3)
     x = torch.randn(B, G, G, C, device=dev, requires_grad=True)
     g = torch.randn(B, G, G, C, device=dev).to(torch.bfloat16)     # cotangent of y, in y's dtype
