@@ -130,7 +130,7 @@ def main():
     from efficient_attention import _ops
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=True)
         x.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = model(x)

@@ -527,3 +527,20 @@ int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t
 }
 
 }  // extern "C"
+
+// ---- projection bias gradient ----
+namespace ea {
+int colsum_parts(int rows, int cols);
+int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows, int cols, hipStream_t st);
+}  // namespace ea
+
+extern "C" {
+
+int ea_bias_grad_parts(int32_t rows, int32_t cols) { return ea::colsum_parts(rows, cols); }
+
+int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, float* part, float* db, void* stream) {
+  if (!dy || !part || !db) return EA_E_BADARG;
+  return ea::colsum_dispatch(dtype, dy, part, db, rows, cols, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -4,29 +4,48 @@
 //     k_bar = softmax(s k0 k0^T) k0                               ('-mixed', :157-174)
 //     mu = q_bar + k_bar,  omega_c = mu[c mod L] (+/-) eps        (:182-198)
 //     M[c,l] = s omega_c.mu_l - s|mu_l|^2/2;  log-proposal / balanced-heuristic weights (:214-238)
-// and its backward.  In the reference this is ~45 tiny torch kernels forward and ~90 backward on
-// [B,h,L,d] tensors; here one workgroup owns one (b,h) and keeps every matrix (<= 64 x 64 fp32) in
-// LDS.  The matrices are far too small for MFMA tiles to matter -- plain fp32 FMA loops, exact
-// fp32 like the reference's autocast-exempt LayerNorm/softmax.
-// Parameter gradients leave as per-(b,h) partials that the caller sums.
+// and its backward (with `eva`: the mu = (q_bar + k0)/2 pipeline of eva.py:178-190).  In the
+// reference this is ~45 tiny torch kernels forward and ~90 backward on [B,h,L,d] tensors; here one
+// 16-wave workgroup owns one (b,h) and keeps every matrix (<= 64 x 64 fp32) in LDS:
+//   * matrix products: 16x16 tiles on the exact-fp32 v_mfma_f32_16x16x4_f32, a wave per tile;
+//   * row-wise steps (LayerNorm, softmax, their backward): four lanes per row, 16 columns per
+//     lane in registers, reduced with the permlane swaps of ea_common.h;
+//   * column sums (parameter gradients): four columns per wave, 16 row-lanes per column.
+// All of it exact fp32 like the reference's autocast-exempt LayerNorm/softmax.  The step is
+// latency-bound (a few MB of traffic in total), so the design goal is few, short barrier phases:
+// 9 forward, 16 backward.  Parameter gradients leave as per-(b,h) partials that the caller sums.
 #include "ea_common.h"
 #include "ea_lara_lmk.h"
+#ifdef EA_LMK_PROFILE
+#include <stdio.h>
+#endif
 
 namespace ea {
 
-constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
+#ifdef EA_LMK_PROFILE
+#define STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && p.prof) p.prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
-// C[m][n] (+)= alpha * sum_k A(m,k) B(k,n), all operands in LDS (fp32); TA/TB read A/B transposed.
-// 16x16 output tiles on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32 (bit-identical to
-// an fmaf chain, same peak rate as the fp32 VALU): one operand float per lane per 4-deep k-step,
-// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15] --
-// 2 LDS reads per 1024 MACs instead of 2 per MAC.  A wave per tile, tiles round-robin over waves.
+constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
+constexpr int LD = 65;          // row stride (floats) of every LDS matrix
+constexpr int BUF = 64 * LD;
+
+// C[m][n] (+)= alpha * sum_k A(m,k) B(k,n) (+ colbias[n]); A, B in LDS (fp32), C in LDS or global;
+// TA/TB read A/B transposed.  Operand layout of v_mfma_f32_16x16x4_f32: one float per lane per
+// k-step, A[i = lane&15][k' = lane>>4], B[k' = lane>>4][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15].
+// The k order inside a dot product is free, so lane group g = lane>>4 takes the contiguous k range
+// [g*steps, (g+1)*steps): with the odd row stride 65 the 64 lanes of every operand read then hit
+// (nearly) distinct banks in all four transpose combinations.  Tiles go round-robin over the waves
+// starting at wave `wofs`, so two products issued back to back in one phase spread over all 16.
 template <bool TA, bool TB, bool ACC>
 EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
-               float alpha, int tid, const float* colbias = nullptr) {
+               float alpha, int tid, int wofs = 0, const float* colbias = nullptr) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
-  for (int tile = wave; tile < tm * tn; tile += LMK_T / 64) {
+  const int steps = (K + 3) >> 2, kb = steps * g;
+  for (int tile = (wave - wofs) & 15; tile < tm * tn; tile += LMK_T / 64) {
     const int m0 = (tile / tn) << 4, n0 = (tile - (tile / tn) * tn) << 4;
     const int am = m0 + li, bn = n0 + li;
     const bool a_ok = am < M, b_ok = bn < N;
@@ -34,15 +53,15 @@ EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int l
     float av[16], bv[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int k = ks * 4 + g;
-      const bool k_ok = k < K;
+      const int k = kb + ks;
+      const bool k_ok = ks < steps && k < K;
       av[ks] = (a_ok && k_ok) ? (TA ? A[k * lda + am] : A[am * lda + k]) : 0.f;
       bv[ks] = (b_ok && k_ok) ? (TB ? B[bn * ldb + k] : B[k * ldb + bn]) : 0.f;
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-      if (ks * 4 < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
+      if (ks < steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
     if (b_ok) {
       const float cb = colbias ? colbias[bn] : 0.f;
 #pragma unroll
@@ -54,43 +73,47 @@ EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int l
   }
 }
 
-EA_DEV float wave_max(float v) {
+// sum over the 16 lanes that share lane>>4 (xor shuffles below 16 stay inside the group)
+EA_DEV float group16_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
 template <int D, bool BWD>
 __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
-  constexpr int LD = D + 1;                  // padded row stride (floats)
-  constexpr int BUF = 64 * LD;               // one [64][D+1] matrix
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* S0 = sm;              // MU
+  float* S0 = sm;              // MU                       | bwd: dA / dG, then Pq
   float* S1 = S0 + BUF;        // Xq: normalised (pre-affine) q rows, or q_bar itself without MLP
   float* S2 = S1 + BUF;        // Xk: same for k0
-  float* S3 = S2 + BUF;        // scratch / dMU
-  float* S4 = S3 + BUF;        // scratch / dOM
-  float* S5 = S4 + BUF;        // A (mixing softmax) [L][65]
-  float* S6 = S5 + BUF;        // k_bar, then M / P [C][65]
-  float* S7 = S6 + BUF;        // W, then OM [C][D+1]
-  float* vec = S7 + BUF;       // small vectors
+  float* S3 = S2 + BUF;        // Pq, then k0             | bwd: dMU, then Pk
+  float* S4 = S3 + BUF;        // Pk, then noise          | bwd: dOM, then d k0
+  float* S5 = S4 + BUF;        // Wk, then A (mixing softmax) [L][L]   | bwd tail: Wk
+  float* S6 = S5 + BUF;        // k_bar, then M           | bwd: dM, then d q_bar
+  float* S7 = S6 + BUF;        // Wq, then OM [C][D]      | bwd: k0, then Wq
+  float* S8 = S7 + BUF;        // bwd: d qbar_rows (incoming)
+  float* vec = S8 + BUF;       // small vectors
   float* rstd_q = vec;         // [64]
   float* rstd_k = vec + 64;
-  float* lse_c = vec + 128;    // [64]
-  float* lp_c = vec + 192;
-  float* bh_c = vec + 256;
-  float* colsum = vec + 320;   // [64]
-  float* pv = vec + 384;       // affine params: gq, cq, gk, ck, bq, bk (6 x D)
+  float* musq = vec + 128;     // |mu_l|^2
+  float* dmcol = vec + 192;    // column sums of dM
+  float* pv = vec + 256;       // affine params: gq, cq, gk, ck, bq, bk (6 x D)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.x;
   const int L = p.L, C = p.C;
   const float s = p.scale;
   const size_t oL = (size_t)bh * L * D, oC = (size_t)bh * C * D;
+  const int nrep = C / L;                                       // 1, or 2 with duplicated samples
+  // row phases: four lanes (g = 0..3) per row, lane (li, g) owns columns 16g .. 16g+15 of row
+  // rrow; waves 0-3 cover 64 rows of one matrix, waves 4-7 those of a second one.
+  const int rrow = ((wave & 3) << 4) + li, cbase = g << 4;
+  // column phases: wave w owns columns 4w .. 4w+3, the 16 lanes li stride over the rows
+  const int ccol = (wave << 2) + g;
 
-  // Global -> LDS in two steps: `issue` puts up to 4 float4 per thread in flight (a whole [64][D]
-  // matrix per workgroup), `commit` writes them to the padded LDS rows.  Everything a phase needs is
-  // issued at its start, so the workgroup pays ~one memory round trip per phase, not one per row.
+  // Global -> LDS in two steps: `issue` puts a whole [64][D] matrix per workgroup in flight (one
+  // float4 per thread), `commit` writes it to the padded LDS rows.  Everything a phase needs is
+  // issued long before, so the workgroup pays one exposed memory round trip (the first).
   constexpr int NSLOT = (64 * D / 4 + LMK_T - 1) / LMK_T;
   struct Pre { float4 v[NSLOT]; };
   auto issue = [&](Pre& b, const float* src, int rows) {
@@ -100,13 +123,25 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       b.v[i] = (src && e < rows * D) ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto commit = [&](float* dst, const Pre& b, int rows) {
+  // dst = sa * a + sb * b
+  auto commit2 = [&](float* dst, const Pre& a, float sa, const Pre& b, float sb, int rows) {
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const int e = (tid + i * LMK_T) * 4;
       if (e < rows * D) {
         float* d = dst + (e / D) * LD + (e % D);
-        d[0] = b.v[i].x; d[1] = b.v[i].y; d[2] = b.v[i].z; d[3] = b.v[i].w;
+        d[0] = sa * a.v[i].x + sb * b.v[i].x; d[1] = sa * a.v[i].y + sb * b.v[i].y;
+        d[2] = sa * a.v[i].z + sb * b.v[i].z; d[3] = sa * a.v[i].w + sb * b.v[i].w;
+      }
+    }
+  };
+  auto commit = [&](float* dst, const Pre& a, int rows) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = (tid + i * LMK_T) * 4;
+      if (e < rows * D) {
+        float* d = dst + (e / D) * LD + (e % D);
+        d[0] = a.v[i].x; d[1] = a.v[i].y; d[2] = a.v[i].z; d[3] = a.v[i].w;
       }
     }
   };
@@ -118,9 +153,14 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     const float* nsrc = p.noise ? (p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC) : nullptr;
     issue(r_noise, nsrc, p.dup == 1 ? L : C);
   }
+  float pre_dlp = 0.f, pre_dbh = 0.f;
   if (BWD) {
     issue(r_dom, p.d_omega + oC, C);
     issue(r_dqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, C);
+    if (!p.eva && wave < 4 && rrow < C) {
+      pre_dlp = p.d_lp[(size_t)bh * C + rrow];
+      pre_dbh = p.d_bhv ? p.d_bhv[(size_t)bh * C + rrow] : 0.f;
+    }
   }
   if (p.has_mlp) {
     for (int i = tid; i < D; i += LMK_T) {
@@ -133,135 +173,142 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   auto K0 = [&](int r, int j) { return p.has_mlp ? pv[2 * D + j] * S2[r * LD + j] + pv[3 * D + j] : S2[r * LD + j]; };
 
   // =========================== forward (recomputed in backward) ===========================
-  // ---- stage A1: Linear + LayerNorm of the pooled rows ----
-  for (int side = 0; side < 2; ++side) {
-    float* X = side == 0 ? S1 : S2;
-    const float* src = (side == 0 ? p.pq : p.pk) + oL;
-    (void)src;
-    if (!p.has_mlp) {
-      commit(X, side == 0 ? r_pq : r_pk, L);
-      __syncthreads();
-      continue;
-    }
-    commit(S3, side == 0 ? r_pq : r_pk, L);
-    commit(S7, side == 0 ? r_wq : r_wk, D);                    // W [out][in]
+  STAMP(0);
+  // ---- F1/F2/F3: Linear + LayerNorm of the pooled rows, both sides at once ----
+  if (p.has_mlp) {
+    commit(S3, r_pq, L); commit(S7, r_wq, D);                    // W [out][in]
+    commit(S4, r_pk, L); commit(S5, r_wk, D);
+  } else {
+    commit(S1, r_pq, L); commit(S2, r_pk, L);
+  }
+  if (BWD && !p.eva) commit(S8, r_dqr, C);
+  __syncthreads();
+  STAMP(1);
+  if (p.has_mlp) {
+    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
+    mm<false, true, false>(S1, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, 0, pv + 4 * D);     // H = P W^T + b
+    mm<false, true, false>(S2, LD, S4, LD, S5, LD, L, D, D, 1.f, tid, t1, pv + 5 * D);
     __syncthreads();
-    const float* bias = pv + (side == 0 ? 4 * D : 5 * D);
-    mm<false, true, false>(X, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, bias);     // H = P W^T + b
-    __syncthreads();
-    float* rstd = side == 0 ? rstd_q : rstd_k;
-    // a thread per row (row stride D+1 floats: conflict-free across rows); serial over D, no shuffles
-    for (int r = tid; r < L; r += LMK_T) {
-      float sum = 0.f;
-      _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) sum += X[r * LD + j];
-      const float mean = sum / D;
+    STAMP(2);
+    if (wave < 8) {
+      float* X = wave < 4 ? S1 : S2;
+      float* rstd = wave < 4 ? rstd_q : rstd_k;
+      const bool r_ok = rrow < L;
+      float x[16], sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = (r_ok && cbase + i < D) ? X[rrow * LD + cbase + i] : 0.f;
+        sum += x[i];
+      }
+      const float mean = quad_sum(sum) / D;
       float var = 0.f;
-      _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) { const float c0 = X[r * LD + j] - mean; var += c0 * c0; }
-      const float rs = rsqrtf(var / D + 1e-5f);
-      _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) X[r * LD + j] = (X[r * LD + j] - mean) * rs;
-      rstd[r] = rs;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float c0 = (cbase + i < D) ? x[i] - mean : 0.f;
+        var += c0 * c0;
+      }
+      const float rs = rsqrtf(quad_sum(var) / D + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (r_ok && cbase + i < D) X[rrow * LD + cbase + i] = (x[i] - mean) * rs;
+      if (g == 0 && r_ok) rstd[rrow] = rs;
     }
     __syncthreads();
+    STAMP(3);
   }
   if (p.eva) {
     // EVA (eva.py:178-190): rf_q_bar = q_bar, rf_k_bar = k0, mu = (rf_q_bar + rf_k_bar) / 2, omega = mu + eps
     if (!BWD) {
-      commit(S3, r_noise, L);
-      __syncthreads();
-      for (int idx = tid; idx < L * D; idx += LMK_T) {
-        const int r = idx / D, j = idx % D;
-        const float k0v = K0(r, j);
-        p.qbar_rows[oC + idx] = k0v;                                        // rf_k_bar
-        p.omega[oC + idx] = 0.5f * (QB(r, j) + k0v) + (p.noise ? S3[r * LD + j] : 0.f);
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        const int e = (tid + i * LMK_T) * 4;
+        if (e < L * D) {
+          const int r = e / D, j = e % D;
+          const float nz[4] = {r_noise.v[i].x, r_noise.v[i].y, r_noise.v[i].z, r_noise.v[i].w};
+          float4 kk, om;
+          float* kp = &kk.x; float* op = &om.x;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float k0v = K0(r, j + t);
+            kp[t] = k0v;                                                     // rf_k_bar
+            op[t] = 0.5f * (QB(r, j + t) + k0v) + nz[t];
+          }
+          *reinterpret_cast<float4*>(p.qbar_rows + oC + e) = kk;
+          *reinterpret_cast<float4*>(p.omega + oC + e) = om;
+        }
       }
       return;
     }
-    commit(S3, r_dom, L);                                                   // d omega
-    commit(S0, r_dqr, L);                                                   // d rf_k_bar
+    commit2(S6, r_dom, 0.5f, r_dom, 0.f, L);                                // d rf_q_bar = d omega / 2
+    commit2(S4, r_dom, 0.5f, r_dqr, 1.f, L);                                // d rf_k_bar (total)
     if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
     __syncthreads();
-    for (int idx = tid; idx < L * D; idx += LMK_T) {
-      const int o = (idx / D) * LD + (idx % D);
-      S6[o] = 0.5f * S3[o];                                                 // d rf_q_bar
-      S4[o] = 0.5f * S3[o] + S0[o];                                         // d rf_k_bar (total)
-    }
-    __syncthreads();
   } else {
-  // ---- stage A2: mixing  A = softmax(s k0 k0^T), k_bar = A k0  (S6 = k_bar) ----
-  for (int idx = tid; idx < L * D; idx += LMK_T) S3[(idx / D) * LD + (idx % D)] = K0(idx / D, idx % D);
+  // ---- F4..F7: mixing  A = softmax(s k0 k0^T), k_bar = A k0  (S6 = k_bar) ----
+  for (int idx = tid; idx < L * D; idx += LMK_T) {
+    const int o = (idx / D) * LD + (idx % D);
+    const float k0v = K0(idx / D, idx % D);
+    S3[o] = k0v;
+    if (!p.mixed) S6[o] = k0v;
+  }
+  commit(S4, r_noise, p.dup == 1 ? L : C);                       // S4 (pk staging) is free again
+  // re-issue the Linear operands of the parameter-gradient stage now; they land long before use
+  if (BWD && p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
   __syncthreads();
+  STAMP(4);
   if (p.mixed) {
     mm<false, true, false>(S5, LD, S3, LD, S3, LD, L, L, D, s, tid);
     __syncthreads();
-    for (int r = tid; r < L; r += LMK_T) {
-      float mx = -INFINITY;
-      _Pragma("unroll 8")
-      for (int j = 0; j < L; ++j) mx = fmaxf(mx, S5[r * LD + j]);
+    STAMP(5);
+    if (wave < 4) {
+      const bool r_ok = rrow < L;
+      float x[16], mx = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = (r_ok && cbase + i < L) ? S5[rrow * LD + cbase + i] : -INFINITY;
+        mx = fmaxf(mx, x[i]);
+      }
+      mx = quad_max(mx);
       float den = 0.f;
-      _Pragma("unroll 8")
-      for (int j = 0; j < L; ++j) { const float e = __expf(S5[r * LD + j] - mx); S5[r * LD + j] = e; den += e; }
-      const float inv = 1.f / den;
-      _Pragma("unroll 8")
-      for (int j = 0; j < L; ++j) S5[r * LD + j] *= inv;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { x[i] = __expf(x[i] - mx); den += x[i]; }
+      const float inv = 1.f / quad_sum(den);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (r_ok && cbase + i < L) S5[rrow * LD + cbase + i] = x[i] * inv;
     }
     __syncthreads();
+    STAMP(6);
     mm<false, false, false>(S6, LD, S5, LD, S3, LD, L, D, L, 1.f, tid);
-  } else {
-    for (int idx = tid; idx < L * D; idx += LMK_T) S6[(idx / D) * LD + (idx % D)] = S3[(idx / D) * LD + (idx % D)];
+    __syncthreads();
+    STAMP(7);
   }
-  __syncthreads();
-  // ---- stage B: mu, omega, proposal densities ----
+  // ---- F8: mu and the sample rows omega ----
   for (int idx = tid; idx < L * D; idx += LMK_T) {
     const int r = idx / D, j = idx % D;
-    S0[r * LD + j] = QB(r, j) + S6[r * LD + j];
+    const float mu = QB(r, j) + S6[r * LD + j];
+    S0[r * LD + j] = mu;
+    for (int k = 0; k < nrep; ++k) {
+      const int c = r + k * L;
+      float eps = 0.f;
+      if (p.noise) eps = p.dup == 1 ? (k ? -1.f : 1.f) * S4[r * LD + j] : S4[c * LD + j];
+      S7[c * LD + j] = mu + eps;
+    }
   }
   __syncthreads();
-  const int nrep = C / L;                                       // 1, or 2 with duplicated samples
-  commit(S3, r_noise, p.dup == 1 ? L : C);                      // S3 (k0 copy) is free again
-  __syncthreads();
-  for (int idx = tid; idx < C * D; idx += LMK_T) {
-    const int c = idx / D, j = idx % D, l = c % L;
-    float eps = 0.f;
-    if (p.noise) eps = p.dup == 1 ? (c >= L ? -1.f : 1.f) * S3[l * LD + j] : S3[c * LD + j];
-    S7[c * LD + j] = S0[l * LD + j] + eps;
-  }
-  for (int r = tid; r < L; r += LMK_T) {                          // colsum[l] = |mu_l|^2
-    float a2 = 0.f;
-    _Pragma("unroll 16")
-    for (int j = 0; j < D; ++j) a2 += S0[r * LD + j] * S0[r * LD + j];
-    colsum[r] = a2;
-  }
-  __syncthreads();
+  STAMP(8);
+  // ---- F9: M = s omega mu^T (all waves), |mu_l|^2 (waves 4-7), forward outputs ----
   mm<false, true, false>(S6, LD, S7, LD, S0, LD, C, L, D, s, tid);      // s omega_c . mu_l
-  __syncthreads();
-  for (int c = tid; c < C; c += LMK_T) {
-    float mx = -INFINITY;
-    _Pragma("unroll 8")
-    for (int l = 0; l < L; ++l) {
-      const float x = S6[c * LD + l] - 0.5f * s * colsum[l];
-      S6[c * LD + l] = x;                                        // M[c][l]
-      mx = fmaxf(mx, x);
+  if (wave >= 4 && wave < 8) {
+    float a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float m = (rrow < L && cbase + i < D) ? S0[rrow * LD + cbase + i] : 0.f;
+      a2 += m * m;
     }
-    float den = 0.f;
-    _Pragma("unroll 8")
-    for (int l = 0; l < L; ++l) den += __expf(S6[c * LD + l] - mx);
-    if (p.mis == 0) den *= (float)nrep;                          // mis-opt: columns repeat nrep times
-    const float lse = mx + __logf(den);
-    lse_c[c] = lse;
-    if (p.mis == 0) {
-      const float d0 = S6[c * LD + (c % L)];
-      lp_c[c] = d0;
-      bh_c[c] = __expf(d0 - lse);
-    } else {
-      lp_c[c] = lse;
-      bh_c[c] = 1.f;
-    }
+    a2 = quad_sum(a2);
+    if (g == 0 && rrow < L) musq[rrow] = a2;
   }
-  __syncthreads();
-
   if (!BWD) {
     for (int idx = tid; idx < C * D; idx += LMK_T) {
       const int c = idx / D, j = idx % D, l = c % L;
@@ -269,156 +316,205 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       if (p.mis == 0) p.qbar_rows[oC + idx] = QB(l, j);
       else if (p.mis == 1) p.qbar_rows[oC + idx] = S0[l * LD + j];
     }
-    for (int c = tid; c < C; c += LMK_T) {
-      p.lp[(size_t)bh * C + c] = lp_c[c];
-      if (p.mis == 0) p.bhv[(size_t)bh * C + c] = bh_c[c];
-    }
-    return;
   }
+  __syncthreads();
+  STAMP(9);
+  // ---- F10: proposal densities per sample row (and, in backward, dM in place of M) ----
+  if (wave < 4) {
+    const int c = rrow;
+    const bool r_ok = c < C;
+    const int cl = r_ok ? c % L : -1;
+    float x[16], mx = -1e30f, d0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int l = cbase + i;
+      x[i] = (r_ok && l < L) ? S6[c * LD + l] - 0.5f * s * musq[l] : -INFINITY;       // M[c][l]
+      mx = fmaxf(mx, x[i]);
+      if (l == cl) d0 = x[i];
+    }
+    mx = quad_max(mx);
+    d0 = quad_sum(d0);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) den += __expf(x[i] - mx);
+    den = quad_sum(den);
+    if (p.mis == 0) den *= (float)nrep;                          // mis-opt: columns repeat nrep times
+    const float lse = mx + __logf(den);
+    const float lpv = p.mis == 0 ? d0 : lse;
+    const float bhv = p.mis == 0 ? __expf(d0 - lse) : 1.f;
+    if (!BWD) {
+      if (g == 0 && r_ok) {
+        p.lp[(size_t)bh * C + c] = lpv;
+        if (p.mis == 0) p.bhv[(size_t)bh * C + c] = bhv;
+      }
+    } else {
+      float dlp, dlse;
+      if (p.mis == 0) {
+        const float dbh = pre_dbh * bhv;
+        dlp = pre_dlp + dbh;
+        dlse = -dbh;
+      } else {
+        dlp = 0.f;
+        dlse = pre_dlp;
+      }
+      const float mult = p.mis == 0 ? (float)nrep : 1.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = cbase + i;
+        if (r_ok && l < L)
+          S6[c * LD + l] = dlse * __expf(x[i] - lse) * mult + ((p.mis == 0 && l == cl) ? dlp : 0.f);
+      }
+    }
+  }
+  if (!BWD) return;
 
   // =================================== backward ===================================
-  // live: S0 MU, S1 Xq, S2 Xk, S5 A, S6 M, S7 OM.   S4 <- dOM (incoming), S3 <- dMU
-  commit(S4, r_dom, C);
-  for (int idx = tid; idx < L * D; idx += LMK_T) S3[(idx / D) * LD + (idx % D)] = 0.f;
-  // re-issue the Linear operands of the parameter-gradient stage now; they land during stage B
-  if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
-  // dM[c][l] in place of M
-  for (int c = tid; c < C; c += LMK_T) {
-    const size_t oc = (size_t)bh * C + c;
-    const float dlp_in = p.d_lp[oc];
-    float dlp, dlse;
-    if (p.mis == 0) {
-      const float dbh = p.d_bhv ? p.d_bhv[oc] * bh_c[c] : 0.f;
-      dlp = dlp_in + dbh;
-      dlse = -dbh;
-    } else {
-      dlp = 0.f;
-      dlse = dlp_in;
-    }
-    const float mult = p.mis == 0 ? (float)nrep : 1.f;
-    _Pragma("unroll 8")
-    for (int l = 0; l < L; ++l) {
-      const float pr = __expf(S6[c * LD + l] - lse_c[c]) * mult;
-      S6[c * LD + l] = dlse * pr + ((p.mis == 0 && l == c % L) ? dlp : 0.f);
-    }
-  }
+  // live: S0 MU, S1 Xq, S2 Xk, S5 A, S6 dM, S7 OM, S8 d qbar_rows.   S4 <- dOM (incoming; with
+  // mis-biased the cotangent of the mu rows joins it: both fold onto mu[c mod L])
+  commit2(S4, r_dom, 1.f, r_dqr, (p.mis == 1 && p.d_qbar_rows) ? 1.f : 0.f, C);
   __syncthreads();
-  // column sums of dM (for the -s|mu_l|^2/2 and the (omega - mu) terms)
-  for (int l = tid; l < L; l += LMK_T) {
+  STAMP(10);
+  // ---- B2: column sums of dM; dMU = s dM^T OM; dOM += s dM MU ----
+  {
     float a = 0.f;
-    _Pragma("unroll 8")
-    for (int c = 0; c < C; ++c) a += S6[c * LD + l];
-    colsum[l] = a;
+    if (ccol < L)
+      for (int r = li; r < C; r += 16) a += S6[r * LD + ccol];
+    a = group16_sum(a);
+    if (li == 0 && ccol < L) dmcol[ccol] = a;
   }
-  mm<true, false, true>(S3, LD, S6, LD, S7, LD, L, D, C, s, tid);        // dMU += s dM^T OM
-  __syncthreads();
-  mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid);       // dOM += s dM MU
-  for (int idx = tid; idx < L * D; idx += LMK_T) {                        // dMU -= s colsum mu
-    const int r = idx / D, j = idx % D;
-    S3[r * LD + j] -= s * colsum[r] * S0[r * LD + j];
+  {
+    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
+    mm<true, false, false>(S3, LD, S6, LD, S7, LD, L, D, C, s, tid);             // dMU = s dM^T OM
+    mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid, t1);         // dOM += s dM MU
   }
   __syncthreads();
-  // fold the C sample rows onto the L landmarks: omega_c = mu[c mod L] +- eps
-  // S6 (dM no longer needed) <- d q_bar extra (mis-opt: from qbar_rows), dMU gets dOM (+ mis-biased rows)
-  commit(S0, r_dqr, C);                                          // MU is dead: S0 <- d qbar_rows
-  __syncthreads();
+  STAMP(11);
+  // ---- B3: fold the C sample rows onto the L landmarks (omega_c = mu[c mod L] +- eps) ----
+  //   S3 <- d mu = d k_bar (common part), S6 <- d q_bar, S7 <- k0 (mixed) / S4 <- d k0 (not mixed)
   for (int idx = tid; idx < L * D; idx += LMK_T) {
-    const int r = idx / D, j = idx % D;
-    float dm = S3[r * LD + j], dqx = 0.f;
+    const int r = idx / D, j = idx % D, o = r * LD + j;
+    float dm = S3[o] - s * dmcol[r] * S0[o], dqx = 0.f;
     for (int k = 0; k < nrep; ++k) {
       const int c = r + k * L;
       dm += S4[c * LD + j];
-      if (p.d_qbar_rows) {
-        const float g = S0[c * LD + j];
-        if (p.mis == 0) dqx += g; else if (p.mis == 1) dm += g;
-      }
+      if (p.mis == 0 && p.d_qbar_rows) dqx += S8[c * LD + j];
     }
-    S3[r * LD + j] = dm;                 // dMU = d q_bar (common part) = d k_bar
-    S6[r * LD + j] = dm + dqx;           // d q_bar
+    S3[o] = dm;
+    S6[o] = dm + dqx;
+    if (p.mixed) S7[o] = K0(r, j); else S4[o] = dm;
   }
   __syncthreads();
-  // ---- stage A backward, k side.  S4 <- d k0 ----
+  STAMP(12);
+  // ---- B4..B6: mixing backward.  S4 <- d k0 ----
   if (p.mixed) {
-    // K0 materialised in S7 (OM no longer needed)
-    for (int idx = tid; idx < L * D; idx += LMK_T) S7[(idx / D) * LD + (idx % D)] = K0(idx / D, idx % D);
+    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
+    mm<true, false, false>(S4, LD, S5, LD, S3, LD, L, D, L, 1.f, tid);          // dK0 = A^T dKb
+    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid, t1);      // dA = dKb K0^T  (MU is dead)
     __syncthreads();
-    mm<true, false, false>(S4, LD, S5, LD, S3, LD, L, D, L, 1.f, tid);   // dK0 = A^T dKb
-    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid);   // dA = dKb K0^T  (MU no longer needed)
-    __syncthreads();
-    for (int r = tid; r < L; r += LMK_T) {                                // dG = A o (dA - rowsum(A o dA)), in S0
-      float rs = 0.f;
-      _Pragma("unroll 8")
-      for (int j = 0; j < L; ++j) rs += S5[r * LD + j] * S0[r * LD + j];
-      _Pragma("unroll 8")
-      for (int j = 0; j < L; ++j) S0[r * LD + j] = S5[r * LD + j] * (S0[r * LD + j] - rs);
+    STAMP(13);
+    if (wave < 4) {                                                             // dG = A o (dA - rowsum(A o dA)), in S0
+      const bool r_ok = rrow < L;
+      float a[16], d[16], rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = r_ok && cbase + i < L;
+        a[i] = ok ? S5[rrow * LD + cbase + i] : 0.f;
+        d[i] = ok ? S0[rrow * LD + cbase + i] : 0.f;
+        rs += a[i] * d[i];
+      }
+      rs = quad_sum(rs);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (r_ok && cbase + i < L) S0[rrow * LD + cbase + i] = a[i] * (d[i] - rs);
     }
     __syncthreads();
-    mm<false, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);     // dK0 += s dG K0
+    STAMP(14);
+    // same tile -> same wave in both calls, so the second accumulation sees the first
+    mm<false, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);            // dK0 += s dG K0
+    mm<true, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);             // dK0 += s dG^T K0
     __syncthreads();
-    mm<true, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);      // dK0 += s dG^T K0
-  } else {
-    for (int idx = tid; idx < L * D; idx += LMK_T) S4[(idx / D) * LD + (idx % D)] = S3[(idx / D) * LD + (idx % D)];
+    STAMP(15);
+  }
+  }   // !p.eva
+  // ---- tail: LayerNorm + Linear backward, both sides at once.  dY: S6 (q side), S4 (k side) ----
+  if (!p.has_mlp) {
+    for (int idx = tid; idx < L * D; idx += LMK_T) {
+      const int o = (idx / D) * LD + (idx % D);
+      p.dpq[oL + idx] = S6[o];
+      p.dpk[oL + idx] = S4[o];
+    }
+    return;
+  }
+  // T1: d gamma = sum_r dY xhat, d beta = sum_r dY (column phases); stage W, P of both sides
+  for (int side = 0; side < 2; ++side) {
+    const float* dY = side == 0 ? S6 : S4;
+    const float* X = side == 0 ? S1 : S2;
+    float dg = 0.f, db = 0.f;
+    if (ccol < D)
+      for (int r = li; r < L; r += 16) {
+        const float y = dY[r * LD + ccol];
+        dg += y * X[r * LD + ccol];
+        db += y;
+      }
+    dg = group16_sum(dg);
+    db = group16_sum(db);
+    if (li == 0 && ccol < D) {
+      float* dvec = p.dvec_part + ((size_t)bh * 2 + side) * 3 * D;
+      dvec[D + ccol] = dg;
+      dvec[2 * D + ccol] = db;
+    }
+  }
+  commit(S7, r_wq, D); commit(S0, r_pq, L);
+  commit(S5, r_wk, D); commit(S3, r_pk, L);
+  __syncthreads();
+  STAMP(16);
+  // T2: dH = rstd (dxh - mean(dxh) - xhat mean(dxh xhat)),  dxh = dY gamma     (in place in dY)
+  if (wave < 8) {
+    float* dY = wave < 4 ? S6 : S4;
+    const float* X = wave < 4 ? S1 : S2;
+    const float* gam = pv + (wave < 4 ? 0 : 2 * D);
+    const bool r_ok = rrow < L;
+    float dxh[16], xh[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool ok = r_ok && cbase + i < D;
+      xh[i] = ok ? X[rrow * LD + cbase + i] : 0.f;
+      dxh[i] = ok ? dY[rrow * LD + cbase + i] * gam[cbase + i] : 0.f;
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+    }
+    s1 = quad_sum(s1) / D;
+    s2 = quad_sum(s2) / D;
+    const float rs = r_ok ? (wave < 4 ? rstd_q : rstd_k)[rrow] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (r_ok && cbase + i < D) dY[rrow * LD + cbase + i] = rs * (dxh[i] - s1 - xh[i] * s2);
   }
   __syncthreads();
-  }   // !p.eva
-  // ---- LayerNorm + Linear backward for both sides: dY in (S4 for k, S6 for q) ----
+  STAMP(17);
+  // T3: d bias of the Linear (column sums of dH); dP = dH W and dW = dH^T P straight to global
   for (int side = 0; side < 2; ++side) {
-    float* dY = side == 0 ? S6 : S4;
-    const float* X = side == 0 ? S1 : S2;
-    float* dP = (side == 0 ? p.dpq : p.dpk) + oL;
-    if (!p.has_mlp) {
-      for (int idx = tid; idx < L * D; idx += LMK_T) dP[idx] = dY[(idx / D) * LD + (idx % D)];
-      continue;
-    }
-    const float* gam = pv + (side == 0 ? 0 : 2 * D);
-    const float* rstd = side == 0 ? rstd_q : rstd_k;
-    // parameter-gradient partials: d gamma = sum_r dY xhat, d beta = sum_r dY
-    float* dvec = p.dvec_part + ((size_t)bh * 2 + side) * 3 * D;
-    for (int j = tid; j < D; j += LMK_T) {
-      float dg = 0.f, db = 0.f;
-      _Pragma("unroll 8")
-      for (int r = 0; r < L; ++r) { dg += dY[r * LD + j] * X[r * LD + j]; db += dY[r * LD + j]; }
-      dvec[D + j] = dg;
-      dvec[2 * D + j] = db;
-    }
-    __syncthreads();
-    // dH = rstd (dxh - mean(dxh) - xhat mean(dxh xhat)),  dxh = dY gamma     (in place in dY)
-    for (int r = tid; r < L; r += LMK_T) {
-      float s1 = 0.f, s2 = 0.f;
-      _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) {
-        const float dxh = dY[r * LD + j] * gam[j];
-        s1 += dxh; s2 += dxh * X[r * LD + j];
-      }
-      s1 /= D; s2 /= D;
-      const float rs = rstd[r];
-      _Pragma("unroll 16")
-      for (int j = 0; j < D; ++j) dY[r * LD + j] = rs * (dY[r * LD + j] * gam[j] - s1 - X[r * LD + j] * s2);
-    }
-    __syncthreads();
-    for (int j = tid; j < D; j += LMK_T) {                                  // d bias of the Linear
-      float db = 0.f;
-      _Pragma("unroll 8")
-      for (int r = 0; r < L; ++r) db += dY[r * LD + j];
-      dvec[j] = db;
-    }
-    // dP = dH W ; dW = dH^T P     (S7 <- W, S0 <- P, S5 <- results)
-    commit(S7, side == 0 ? r_wq : r_wk, D);
-    commit(S0, side == 0 ? r_pq : r_pk, L);
-    __syncthreads();
-    mm<false, false, false>(S5, LD, dY, LD, S7, LD, L, D, D, 1.f, tid);
-    __syncthreads();
-    for (int idx = tid; idx < L * D; idx += LMK_T) dP[idx] = S5[(idx / D) * LD + (idx % D)];
-    __syncthreads();
-    mm<true, false, false>(S5, LD, dY, LD, S0, LD, D, D, L, 1.f, tid);      // dW[out][in]
-    __syncthreads();
-    float* dW = p.dW_part + ((size_t)bh * 2 + side) * D * D;
-    for (int idx = tid; idx < D * D; idx += LMK_T) dW[idx] = S5[(idx / D) * LD + (idx % D)];
-    __syncthreads();
+    const float* dY = side == 0 ? S6 : S4;
+    float db = 0.f;
+    if (ccol < D)
+      for (int r = li; r < L; r += 16) db += dY[r * LD + ccol];
+    db = group16_sum(db);
+    if (li == 0 && ccol < D) p.dvec_part[((size_t)bh * 2 + side) * 3 * D + ccol] = db;
   }
+  {
+    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
+    const int t2 = (((D + 15) >> 4) * ((D + 15) >> 4)) & 15;
+    float* dWq = p.dW_part + ((size_t)bh * 2 + 0) * D * D;
+    float* dWk = p.dW_part + ((size_t)bh * 2 + 1) * D * D;
+    mm<false, false, false>(p.dpq + oL, D, S6, LD, S7, LD, L, D, D, 1.f, tid);
+    mm<false, false, false>(p.dpk + oL, D, S4, LD, S5, LD, L, D, D, 1.f, tid, t1);
+    mm<true, false, false>(dWq, D, S6, LD, S0, LD, D, D, L, 1.f, tid, (2 * t1) & 15);      // dW[out][in]
+    mm<true, false, false>(dWk, D, S4, LD, S3, LD, D, D, L, 1.f, tid, (2 * t1 + t2) & 15);
+  }
+  STAMP(18);
 }
 
-size_t lara_lmk_lds(int D) { return ((size_t)8 * 64 * (D + 1) + 384 + 6 * D) * sizeof(float); }
+size_t lara_lmk_lds(int D) { return ((size_t)9 * BUF + 256 + 6 * D) * sizeof(float); }
 
 template <int D>
 static int launch_lmk(bool bwd, const LmkP& p, hipStream_t st) {
@@ -432,7 +528,20 @@ static int launch_lmk(bool bwd, const LmkP& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int lara_lmk_dispatch(bool bwd, const LmkP& p, hipStream_t st) {
+int lara_lmk_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
+  LmkP p = p0;
+  p.prof = nullptr;
+#ifdef EA_LMK_PROFILE
+  static long long* dprof = nullptr;
+  if (!dprof) hipMalloc(&dprof, 64 * sizeof(long long));
+  hipMemsetAsync(dprof, 0, 64 * sizeof(long long), st);
+  p.prof = dprof;
+  struct Rep { long long* d; hipStream_t st; bool bwd; ~Rep() {
+    long long h[64]; hipStreamSynchronize(st); hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "lmk %s:", bwd ? "bwd" : "fwd"); long long prev = h[0];
+    for (int i = 1; i < 40; ++i) if (h[i]) { fprintf(stderr, " [%d]%lld", i, h[i] - prev); prev = h[i]; }
+    fprintf(stderr, " total %lld\n", prev - h[0]); } } rep{dprof, st, bwd};
+#endif
   if (p.D == 64) return launch_lmk<64>(bwd, p, st);
   if (p.D == 32) return launch_lmk<32>(bwd, p, st);
   return EA_E_UNSUPPORTED;

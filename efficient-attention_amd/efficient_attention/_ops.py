@@ -668,6 +668,19 @@ def _split_k(rows):
     return best
 
 
+def bias_grad(dy2):
+    """db = dY.sum(0) in fp32 through ea_bias_grad (dY: contiguous [rows, cols] bf16/fp16)."""
+    rows, cols = dy2.shape
+    if dy2.dtype not in (torch.bfloat16, torch.float16) or cols % 8 or cols > 2048 or not dy2.is_contiguous():
+        return dy2.sum(0, dtype=torch.float32)
+    nb = nv.lib().ea_bias_grad_parts(rows, cols)
+    part = torch.empty(nb * cols, dtype=torch.float32, device=dy2.device)
+    db = torch.empty(cols, dtype=torch.float32, device=dy2.device)
+    nv.call("ea_bias_grad", 0 if dy2.dtype == torch.bfloat16 else 1, rows, cols, nv.ptr(dy2),
+                 nv.ptr(part), nv.ptr(db), nv.stream())
+    return db
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b in the autocast dtype.  dW = dY^T X contracts over all B*N tokens with a
     [out, in] result of a few tiles: left to a single library GEMM it occupies ~9 of 256 CUs
@@ -706,7 +719,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
-            db = dy2.sum(0, dtype=torch.float32).to(bdtype)
+            db = bias_grad(dy2).to(bdtype)
         return dx, dw, db, None
 
 
