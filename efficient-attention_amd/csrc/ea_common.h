@@ -16,9 +16,59 @@
 #include <stdint.h>
 #include "../../include/ea_hip.h"
 
+// ---- dev-only phase profiling (-DEA_PROFILE, tools/build_prof_lib.sh): thread 0 of workgroup 0
+// stamps s_memtime into p.prof[i]; the dispatcher prints the deltas.  Compiled out of the product.
+#ifdef EA_PROFILE
+#include <stdio.h>
+#include <algorithm>
+#include <vector>
+#define EA_STAMP(p, i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (p).prof) (p).prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
+// per-workgroup begin / end on the chip-wide 100 MHz clock
+#define EA_BLK(p, e) do { if (threadIdx.x == 0 && (p).prof && blockIdx.x < 8192) (p).prof[128 + 2 * blockIdx.x + (e)] = (long long)wall_clock64(); } while (0)
+namespace ea {
+struct ProfReport {
+  static constexpr int NW = 128 + 2 * 8192;
+  long long* d = nullptr; hipStream_t st; const char* name; int mode;
+  long long* arm(hipStream_t s, const char* nm, int md) {
+    static long long* buf = nullptr;
+    if (!buf) hipMalloc(&buf, NW * sizeof(long long));
+    hipMemsetAsync(buf, 0, NW * sizeof(long long), s);
+    d = buf; st = s; name = nm; mode = md;
+    return buf;
+  }
+  ~ProfReport() {
+    if (!d) return;
+    std::vector<long long> h(NW);
+    hipStreamSynchronize(st);
+    hipMemcpy(h.data(), d, NW * sizeof(long long), hipMemcpyDeviceToHost);
+    fprintf(stderr, "%s mode %d:", name, mode);
+    long long prev = h[0];
+    for (int i = 1; i < 128; ++i) if (h[i]) { fprintf(stderr, " [%d]%lld", i, h[i] - prev); prev = h[i]; }
+    fprintf(stderr, " total %lld\n", prev - h[0]);
+    std::vector<long long> b, e, dur;
+    for (int i = 0; i < 8192; ++i) if (h[128 + 2 * i] && h[129 + 2 * i]) { b.push_back(h[128 + 2 * i]); e.push_back(h[129 + 2 * i]); dur.push_back(h[129 + 2 * i] - h[128 + 2 * i]); }
+    if (!b.empty()) {
+      const long long t0 = *std::min_element(b.begin(), b.end());
+      std::vector<long long> bs(b), es(e), ds(dur);
+      for (auto& x : bs) x -= t0; for (auto& x : es) x -= t0;
+      std::sort(bs.begin(), bs.end()); std::sort(es.begin(), es.end()); std::sort(ds.begin(), ds.end());
+      const size_t n = bs.size();
+      fprintf(stderr, "  %zu blocks (10 ns ticks): start p50 %lld p90 %lld max %lld | dur min %lld p50 %lld p90 %lld max %lld | end p50 %lld max %lld\n",
+              n, bs[n / 2], bs[n * 9 / 10], bs[n - 1], ds[0], ds[n / 2], ds[n * 9 / 10], ds[n - 1], es[n / 2], es[n - 1]);
+    }
+  }
+};
+}  // namespace ea
+#else
+#define EA_STAMP(p, i) do { } while (0)
+#define EA_BLK(p, e) do { } while (0)
+#endif
+
+
 namespace ea {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;   // arithmetic on it maps to v_pk_*_f32
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 

@@ -50,6 +50,7 @@ struct LaraP {
   float norm_coef2;             // log2-domain coefficient of |x|^2 in the logits
   float knorm_coef;             // coefficient of x * (sum of logit grads) in dk / dq
   float ratio, feps;
+  long long* prof;              // dev builds (-DEA_PROFILE): phase time stamps
 };
 
 // ---- the elementwise core of the estimator (lara.py:221-243), one (c, n) entry -------------

@@ -16,17 +16,10 @@
 // 9 forward, 16 backward.  Parameter gradients leave as per-(b,h) partials that the caller sums.
 #include "ea_common.h"
 #include "ea_lara_lmk.h"
-#ifdef EA_LMK_PROFILE
-#include <stdio.h>
-#endif
 
 namespace ea {
 
-#ifdef EA_LMK_PROFILE
-#define STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && p.prof) p.prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
+#define STAMP(i) EA_STAMP(p, i)
 
 constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
 constexpr int LD = 65;          // row stride (floats) of every LDS matrix
@@ -531,16 +524,9 @@ static int launch_lmk(bool bwd, const LmkP& p, hipStream_t st) {
 int lara_lmk_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
   LmkP p = p0;
   p.prof = nullptr;
-#ifdef EA_LMK_PROFILE
-  static long long* dprof = nullptr;
-  if (!dprof) hipMalloc(&dprof, 64 * sizeof(long long));
-  hipMemsetAsync(dprof, 0, 64 * sizeof(long long), st);
-  p.prof = dprof;
-  struct Rep { long long* d; hipStream_t st; bool bwd; ~Rep() {
-    long long h[64]; hipStreamSynchronize(st); hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "lmk %s:", bwd ? "bwd" : "fwd"); long long prev = h[0];
-    for (int i = 1; i < 40; ++i) if (h[i]) { fprintf(stderr, " [%d]%lld", i, h[i] - prev); prev = h[i]; }
-    fprintf(stderr, " total %lld\n", prev - h[0]); } } rep{dprof, st, bwd};
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "lara_lmk", bwd ? 1 : 0);
 #endif
   if (p.D == 64) return launch_lmk<64>(bwd, p, st);
   if (p.D == 32) return launch_lmk<32>(bwd, p, st);

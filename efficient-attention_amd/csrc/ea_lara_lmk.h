@@ -15,7 +15,7 @@ struct LmkP {
   int has_mlp, mixed, mis, dup;
   int eva;                                                // EVA's mu pipeline (eva.py:178-190) instead of LARA's
   float scale;
-  long long* prof;                                        // dev builds (-DEA_LMK_PROFILE): phase time stamps
+  long long* prof;                                        // dev builds (-DEA_PROFILE): phase time stamps
 };
 
 int lara_lmk_dispatch(bool bwd, const LmkP& p, hipStream_t st);

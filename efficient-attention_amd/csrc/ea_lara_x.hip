@@ -55,7 +55,7 @@ EA_DEV void stage_cols(char* dst, const float* src, int C, int Cp, int tid) {
 }
 
 template <typename E, int D, int NCT, int MODE>
-__global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
+__global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const LaraP p) {
   using Cfg = LxCfg<D>;
   constexpr int ROWB = Cfg::ROWB, KS = Cfg::KS, DT = Cfg::DT, DQ = Cfg::DQ;
   constexpr int Cp = NCT * 16;
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
   constexpr bool PERF = MODE >= LX_POUT;
   const bool use_t = p.mis != MIS_BH && !PERF;
 
+  EA_STAMP(p, 0);
+  EA_BLK(p, 0);
   // ---- stage the landmark matrices: ALL global loads are issued before the first conversion /
   // LDS store, so the workgroup pays one memory round trip here instead of one per matrix ----
   {
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
     }
   }
 
+  EA_STAMP(p, 1);
   // per-landmark scalars live in LDS (three [Cp] fp32 vectors); lanes read the entries of their
   // rows c = 16 ct + 4 g + r at the point of use instead of pinning 6 x NCT x 4 registers
   float* SC0 = reinterpret_cast<float*>(M2 + D * MT_LDB);
@@ -155,10 +158,14 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
   struct LdsVec {
     const float* base; int g;
     EA_DEV float operator()(int ct, int r) const { return base[ct * 16 + 4 * g + r]; }
+    EA_DEV float4 v4(int ct) const { return *reinterpret_cast<const float4*>(base + ct * 16 + 4 * g); }
   };
   const LdsVec cst2{SC0, g}, lset2{SC1, g}, bhv{SC2, g}, lsek2{SC0, g}, dkk{SC1, g}, rs{SC2, g};
   const float stabk2 = (MODE == LX_PBWDK) ? p.stab[bh] * LOG2E : 0.f;
   __syncthreads();
+  EA_STAMP(p, 2);
+  int prof_it = 0;
+  (void)prof_it;
 
   constexpr bool KEYS = MODE == LX_BWDK || MODE == LX_PBWDK;
   constexpr bool TWO_TOK = MODE == LX_BWDQ || MODE == LX_BWDK || MODE == LX_PBWDQ || MODE == LX_PBWDK;
@@ -173,22 +180,22 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
   // Software prefetch: the token fragments of this wave's NEXT tile are in flight while the
   // current tile computes, so a tile costs one exposed memory round trip per wave, not one per tile.
   constexpr bool NEED_O = MODE == LX_PBWDQ;
+  // (Straight-line on purpose: the tile index and the token are clamped instead of branched on --
+  // rows fetched for tokens >= n1 are never stored -- because with a conditional refill hipcc
+  // parks the fragment arrays in scratch memory and the prefetch turns synchronous.)
   u32x4 nx1[KS], nx2[KS], nx3[KS];
+  const int last_tok = n1 - 1;
   auto issue = [&](int tile_) {
-    const int tok_ = n0 + tile_ * 16 + li;
-    const bool ok_ = tok_ < n1;
+    const int tok_ = min(n0 + tile_ * 16 + li, last_tok);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      nx1[ks] = nx2[ks] = nx3[ks] = u32x4{0u, 0u, 0u, 0u};
-      if (ok_) {
-        const int eo = (g * KS + ks) * 8;
-        nx1[ks] = ldg16(t1b + (tok_ * tk1.sn + eo) * 2);
-        if (TWO_TOK) nx2[ks] = ldg16(t2b + (tok_ * tk2.sn + eo) * 2);
-        if (NEED_O) nx3[ks] = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok_ * p.o.sn + eo) * 2);
-      }
+      const int eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(t1b + (tok_ * tk1.sn + eo) * 2);
+      if (TWO_TOK) nx2[ks] = ldg16(t2b + (tok_ * tk2.sn + eo) * 2);
+      if (NEED_O) nx3[ks] = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok_ * p.o.sn + eo) * 2);
     }
   };
-  if (n0 + wave * 16 < n1) issue(wave);
+  if (n0 + wave * 16 < n1) issue(wave);   // (uniform per wave)
   for (int tile = wave; n0 + tile * 16 < n1; tile += 4) {
     const int tok = n0 + tile * 16 + li;
     const bool valid = tok < n1;
@@ -201,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
       f1[ks] = as_x8<E>(nx1[ks]);
       f2[ks] = as_x8<E>(nx2[ks]);
     }
-    if (n0 + (tile + 4) * 16 < n1) issue(tile + 4);
+    issue(tile + 4);
+    if (prof_it < 8) EA_STAMP(p, 3 + prof_it * 5);
     // ---- score tiles ----
     f32x4 a[NCT], tt[NCT], dw[NCT];
 #pragma unroll
@@ -215,68 +223,120 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
         if (TWO_TOK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 4 + prof_it * 5);
     // ---- elementwise stage -> weight tiles w1 (x M1) and w2 (x M2) ----
     float w1[NCT][4], w2[NCT][4];
     float sdb = 0.f, pden = 1.f;
     if (MODE == LX_FWD || MODE == LX_BWDQ) {
-      float tl = 0.f;
+      // The stage is VALU-bound (16 (c, n) entries per lane and tile), so it is written on float2
+      // values (v_pk_fma/mul/add_f32) and avoids per-entry log2 / rcp: with
+      //   Z = log alpha + s w.q + cst,  softmax_c Z = alpha 2^z / sum_c alpha 2^z,  z = Z - log alpha
+      // alpha enters as a factor, and d(alpha) = dZ / alpha = 2^z (dW - rd) / sum needs no division.
+      const float s2 = p.scale_log2;
+      const f32x2 s22 = {s2, s2};
+      f32x2 tv[NCT][2], ez[NCT][2];     // ez: 2^(z - mx), zeroed in backward where alpha is clamped
+      f32x2 tl2 = {0.f, 0.f};
       if (p.mis == MIS_OPT) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tl += fast_exp2(tt[ct][r] * p.scale_log2 - lset2(ct, r));
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float4 ls = lset2.v4(ct);
+          const f32x2 x0 = f32x2{tt[ct][0], tt[ct][1]} * s22 - f32x2{ls.x, ls.y};
+          const f32x2 x1 = f32x2{tt[ct][2], tt[ct][3]} * s22 - f32x2{ls.z, ls.w};
+          tv[ct][0] = f32x2{fast_exp2(x0[0]), fast_exp2(x0[1])};
+          tv[ct][1] = f32x2{fast_exp2(x1[0]), fast_exp2(x1[1])};
+          tl2 += tv[ct][0] + tv[ct][1];
+        }
       }
-      const float tmean = quad_sum(tl) * invC;
-      float z2[NCT][4], tv[NCT][4], al[NCT][4];
+      const float tmean = quad_sum(tl2[0] + tl2[1]) * invC;
       float mx = -INFINITY;
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const LaraElem e = lara_alpha(p.mis, tt[ct][r] * p.scale_log2, lset2(ct, r), bhv(ct, r), p.kappa, tmean);
-          tv[ct][r] = e.t; al[ct][r] = e.alpha;
-          z2[ct][r] = a[ct][r] * p.scale_log2 + e.la2 + cst2(ct, r);
-          mx = fmaxf(mx, z2[ct][r]);
+      for (int ct = 0; ct < NCT; ++ct) {
+        const float4 cs = cst2.v4(ct);
+        f32x2 z0 = f32x2{a[ct][0], a[ct][1]} * s22 + f32x2{cs.x, cs.y};
+        f32x2 z1 = f32x2{a[ct][2], a[ct][3]} * s22 + f32x2{cs.z, cs.w};
+        if (p.mis == MIS_BIASED) {
+          z0 += f32x2{tt[ct][0], tt[ct][1]} * s22;
+          z1 += f32x2{tt[ct][2], tt[ct][3]} * s22;
         }
+        ez[ct][0] = z0; ez[ct][1] = z1;
+        mx = fmaxf(fmaxf(mx, fmaxf(z0[0], z0[1])), fmaxf(z1[0], z1[1]));
+      }
       mx = quad_max(mx);
-      float ssum = 0.f;
+      const f32x2 mx2 = {mx, mx};
+      f32x2 ss2 = {0.f, 0.f};
+      f32x2 wv[NCT][2];                                  // alpha 2^(z - mx): un-normalised weights
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
+      for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { z2[ct][r] = fast_exp2(z2[ct][r] - mx); ssum += z2[ct][r]; }
-      ssum = quad_sum(ssum);
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x2 x = ez[ct][hh] - mx2;
+          ez[ct][hh] = f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
+        }
+        if (p.mis == MIS_OPT) {
+          const float4 bv = bhv.v4(ct);
+          const float kt = -p.kappa * tmean;
+          const f32x2 kap = {p.kappa, p.kappa};
+          const f32x2 a0 = kap * tv[ct][0] + f32x2{bv.x + kt, bv.y + kt};
+          const f32x2 a1 = kap * tv[ct][1] + f32x2{bv.z + kt, bv.w + kt};
+          wv[ct][0] = ez[ct][0] * f32x2{fmaxf(a0[0], 1e-8f), fmaxf(a0[1], 1e-8f)};
+          wv[ct][1] = ez[ct][1] * f32x2{fmaxf(a1[0], 1e-8f), fmaxf(a1[1], 1e-8f)};
+          if (MODE == LX_BWDQ) {                         // d(alpha) = 0 where the clamp is active
+            ez[ct][0] = f32x2{a0[0] > 1e-8f ? ez[ct][0][0] : 0.f, a0[1] > 1e-8f ? ez[ct][0][1] : 0.f};
+            ez[ct][1] = f32x2{a1[0] > 1e-8f ? ez[ct][1][0] : 0.f, a1[1] > 1e-8f ? ez[ct][1][1] : 0.f};
+          }
+        } else {
+          wv[ct][0] = ez[ct][0];
+          wv[ct][1] = ez[ct][1];
+        }
+        ss2 += wv[ct][0] + wv[ct][1];
+      }
+      const float ssum = quad_sum(ss2[0] + ss2[1]);
       const float inv = fast_rcp(ssum);
       if (MODE == LX_FWD) {
+        pden = inv;                                       // normalisation folded into the output scale
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) w1[ct][r] = z2[ct][r] * inv;
+        for (int ct = 0; ct < NCT; ++ct) {
+          w1[ct][0] = wv[ct][0][0]; w1[ct][1] = wv[ct][0][1];
+          w1[ct][2] = wv[ct][1][0]; w1[ct][3] = wv[ct][1][1];
+        }
       } else {
-        float rd = 0.f;
+        const f32x2 inv2 = {inv, inv};
+        f32x2 rd2 = {0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < NCT; ++ct) {
+          wv[ct][0] *= inv2; wv[ct][1] *= inv2;                               // W
+          rd2 += wv[ct][0] * f32x2{dw[ct][0], dw[ct][1]} + wv[ct][1] * f32x2{dw[ct][2], dw[ct][3]};
+        }
+        const float rd = quad_sum(rd2[0] + rd2[1]);                            // = dout_n . out_n
+        const f32x2 rdv = {rd, rd};
+        f32x2 sda2 = {0.f, 0.f};
+        f32x2 da[NCT][2];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { z2[ct][r] *= inv; rd += z2[ct][r] * dw[ct][r]; }
-        rd = quad_sum(rd);                                   // = dout_n . out_n
-        float sda = 0.f;
+        for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float dz = z2[ct][r] * (dw[ct][r] - rd);
-            w1[ct][r] = dz;
-            float da = 0.f;
-            if (p.mis == MIS_OPT) da = al[ct][r] > 1e-8f ? dz * fast_rcp(al[ct][r]) : 0.f;
-            w2[ct][r] = da;
-            sda += da;
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 dd = f32x2{dw[ct][2 * hh], dw[ct][2 * hh + 1]} - rdv;  // dW - rd
+            const f32x2 dz = wv[ct][hh] * dd;
+            w1[ct][2 * hh] = dz[0]; w1[ct][2 * hh + 1] = dz[1];
+            if (p.mis == MIS_OPT) {
+              da[ct][hh] = ez[ct][hh] * inv2 * dd;                             // dZ / alpha
+              sda2 += da[ct][hh];
+            }
           }
-        sda = quad_sum(sda);
+        }
+        const float sda = quad_sum(sda2[0] + sda2[1]);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (p.mis == MIS_OPT) w2[ct][r] = tv[ct][r] * p.kappa * (w2[ct][r] - sda * invC);   // t * dt
-            else if (p.mis == MIS_BIASED) w2[ct][r] = w1[ct][r];                                  // dT = dZ
+          for (int hh = 0; hh < 2; ++hh) {
+            if (p.mis == MIS_OPT) {
+              const float m = sda * invC;
+              const f32x2 kap = {p.kappa, p.kappa};
+              const f32x2 t2 = tv[ct][hh] * kap * (da[ct][hh] - f32x2{m, m});  // t * dt
+              w2[ct][2 * hh] = t2[0]; w2[ct][2 * hh + 1] = t2[1];
+            } else if (p.mis == MIS_BIASED) {
+              w2[ct][2 * hh] = w1[ct][2 * hh]; w2[ct][2 * hh + 1] = w1[ct][2 * hh + 1];   // dT = dZ
+            }
           }
         if (valid && g == 0) {
           const size_t o = (size_t)bh * p.N + tok;
@@ -397,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
         }
       sdb = quad_sum(sdb);
     }
+    if (prof_it < 8) EA_STAMP(p, 5 + prof_it * 5);
     // ---- contraction over c: out^T[d][n] = M1^T . w1 (+ M2^T . w2) ----
     f32x4 acc[DT];
 #pragma unroll
@@ -431,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
         }
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 6 + prof_it * 5);
     if (!valid) continue;
     // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` ----
     float f[DQ];
@@ -497,7 +559,11 @@ __global__ __launch_bounds__(256, 2) void lara_x_kernel(const LaraP p) {
         stg16(dstk + ks * 16, pack8<E>(o8));
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 7 + prof_it * 5);
+    ++prof_it;
   }
+  EA_STAMP(p, 60);
+  EA_BLK(p, 1);
 }
 
 size_t lara_x_lds(int D, int NCT) {
@@ -540,7 +606,13 @@ static int launch_x_nct(int mode, const LaraP& p, hipStream_t st) {
   return EA_E_UNSUPPORTED;
 }
 
-int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st) {
+int lara_x_dispatch(int mode, const LaraP& p0, int dtype, hipStream_t st) {
+  LaraP p = p0;
+  p.prof = nullptr;
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "lara_x", mode);
+#endif
   if (dtype == EA_BF16) {
     if (p.D == 64) return launch_x_nct<BF16, 64>(mode, p, st);
     if (p.D == 32) return launch_x_nct<BF16, 32>(mode, p, st);
