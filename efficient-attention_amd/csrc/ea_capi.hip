@@ -186,6 +186,13 @@ static int fill_lara(const ea_lara_geom* g, LaraP& p, bool ypass) {
   int nblk = (int)((768 + bh - 1) / bh);
   if (nblk < 1) nblk = 1;
   if (nblk > maxblk) nblk = maxblk;
+  if (ypass) {
+    // the slice boundaries are laid out at launch (lara_y_plan: they depend on how many
+    // workgroups of the particular pass fit on the chip); only the count is fixed here
+    p.nsplit = nblk > 16 ? 16 : nblk;
+    p.tok_per_block = 0;
+    return EA_OK;
+  }
   int tpb = (g->N + nblk - 1) / nblk;
   tpb = (tpb + gran - 1) / gran * gran;
   p.tok_per_block = tpb;

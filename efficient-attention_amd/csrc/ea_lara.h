@@ -42,7 +42,8 @@ struct LaraP {
   int B, H, N, D, C, NCT;       // NCT = 16-landmark tiles (C padded to NCT*16)
   int mis;                      // MIS_*
   int nsplit;                   // Y: sequence splits per (b,h); X: blocks per (b,h)
-  int tok_per_block;            // tokens handled by one block (multiple of 64)
+  int tok_per_block;            // X: tokens handled by one block (multiple of 64)
+  int tok_begin[17];            // Y: token range of slice i is [tok_begin[i], tok_begin[i+1])
   float kappa, scale, scale_log2;
   // Performer: omega = W indexed per head, stab [BH] key stabiliser (natural units)
   int w_per_head;

@@ -15,20 +15,27 @@
 
 namespace ea {
 
-template <typename E, int D>
-EA_DEV void load_lm_frag(typename E::x8* dst, const float* src, bool ok, int g) {
+// landmark row -> MFMA B-operand fragment, in two steps so that the global loads of all three
+// matrices (and of the first token chunk) are in flight together before the first conversion
+template <int D> struct LmRaw { float4 v[D / 32][2]; };
+template <int D>
+EA_DEV void load_lm_raw(LmRaw<D>& dst, const float* src, bool ok, int g) {
   constexpr int KS = D / 32;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    u32x4 w = {0u, 0u, 0u, 0u};
-    if (ok) {
-      float f[8];
-      const float* s = src + (g * KS + ks) * 8;
-      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(s);
-      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(s + 4);
-      w = pack8<E>(f);
-    }
-    dst[ks] = as_x8<E>(w);
+    const float* s = src + (g * KS + ks) * 8;
+    dst.v[ks][0] = ok ? *reinterpret_cast<const float4*>(s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dst.v[ks][1] = ok ? *reinterpret_cast<const float4*>(s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <typename E, int D>
+EA_DEV void conv_lm_frag(typename E::x8* dst, const LmRaw<D>& raw) {
+  constexpr int KS = D / 32;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float f[8] = {raw.v[ks][0].x, raw.v[ks][0].y, raw.v[ks][0].z, raw.v[ks][0].w,
+                        raw.v[ks][1].x, raw.v[ks][1].y, raw.v[ks][1].z, raw.v[ks][1].w};
+    dst[ks] = as_x8<E>(pack8<E>(f));
   }
 }
 
@@ -46,7 +53,10 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   float* sc = reinterpret_cast<float*>(T2 + chunk * ROWB);   // [4][chunk] per-row scalars
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int bh = blockIdx.x / p.nsplit, split = blockIdx.x - bh * p.nsplit;
+  // split-major block order: all first slices are dispatched before any second slice (see
+  // lara_y_plan: with uneven slices the long ones must start first)
+  const int nbh = p.B * p.H;
+  const int split = blockIdx.x / nbh, bh = blockIdx.x - split * nbh;
   const int b = bh / p.H, h = bh - b * p.H;
   const int ct = blockIdx.y * 4 + (wave % ncw), sub = wave / ncw;
   const bool active = ct < p.NCT;
@@ -57,13 +67,16 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   const float invC = 1.f / (float)p.C;
   constexpr bool PERF = MODE >= LY_PMAX;
 
+  EA_STAMP(p, 0);
+  EA_BLK(p, 0);
   typename E::x8 r1f[KS], r2f[KS], r3f[KS];
-  load_lm_frag<E, D>(r1f, p.omega + (lmw + (c_ok ? c : 0)) * D, c_ok, g);
+  LmRaw<D> raw1, raw2, raw3;
+  load_lm_raw<D>(raw1, p.omega + (lmw + (c_ok ? c : 0)) * D, c_ok, g);
   const bool use_t = p.mis != MIS_BH && MODE != LY_BWDK && !PERF;
-  load_lm_frag<E, D>(r2f, use_t ? p.qbar + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && use_t, g);
+  load_lm_raw<D>(raw2, use_t ? p.qbar + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && use_t, g);
   const float* r3src = MODE == LY_BWDQ ? p.kv : p.dkv;
   constexpr bool HAS_R3 = MODE == LY_BWDQ || MODE == LY_BWDK;
-  load_lm_frag<E, D>(r3f, HAS_R3 ? r3src + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && HAS_R3, g);
+  load_lm_raw<D>(raw3, HAS_R3 ? r3src + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && HAS_R3, g);
   const float stabk2 = (MODE == LY_PKV) ? p.stab[bh] * LOG2E : 0.f;
   float cst2 = -INFINITY, lset2 = INFINITY, bhc = 1.f, lsek2 = INFINITY, dkkc = 0.f, rsc = 0.f;
   if (c_ok) {
@@ -74,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
     if (MODE == LY_BWDK) { lsek2 = p.lse_k[lm + c] * LOG2E; dkkc = p.dkk[lm + c]; rsc = p.rsum[lm + c]; }
   }
 
-  const int n0 = split * p.tok_per_block;
-  const int n1 = min(p.N, n0 + p.tok_per_block);
+  const int n0 = p.tok_begin[split];
+  const int n1 = p.tok_begin[split + 1];
   const int nphase = (MODE == LY_FWD && p.mis == MIS_OPT) ? 2 : 1;
 
   f32x4 acc0[DT], acc1[DT], acc2[DT], acc3[DT];
@@ -149,16 +162,27 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
           sc[row] = valid ? ps0[i] : INFINITY;
           sc[chunk + row] = ps1[i];
           sc[2 * chunk + row] = ps2[i];
-          sc[3 * chunk + row] = ps3[i];
+          sc[3 * chunk + row] = ps3[i] * invC;
         }
       }
     };
     if (n0 < n1) issue(n0);
+    if (phase == 0) {
+      conv_lm_frag<E, D>(r1f, raw1);
+      conv_lm_frag<E, D>(r2f, raw2);
+      conv_lm_frag<E, D>(r3f, raw3);
+    }
+    EA_STAMP(p, 1);
+    int prof_ci = 0;
+    (void)prof_ci;
     for (int cb = n0; cb < n1; cb += chunk) {
       __syncthreads();                    // previous chunk's readers are done
+      if (prof_ci < 5) EA_STAMP(p, 2 + prof_ci * 8);
       commit(cb);
       __syncthreads();
+      if (prof_ci < 5) EA_STAMP(p, 3 + prof_ci * 8);
       if (cb + chunk < n1) issue(cb + chunk);
+      if (prof_ci < 5) EA_STAMP(p, 4 + prof_ci * 8);
       if (!active) continue;
       for (int sb = sub; sb < chunk / 32; sb += nsub) {
       const int rb = sb * 32;
@@ -177,6 +201,50 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
           if (HAS_R3) s3 = E::mma(as_x8<E>(lds16(T2 + lds_off<D>(row, g * KS + ks))), r3f[ks], s3);
         }
         const int r0 = rb + 16 * mt + 4 * g;
+        if (MODE == LY_BWDQ) {
+          // VALU-bound stage: float2 arithmetic (v_pk_*_f32), per-row scalars as one float4 each,
+          // alpha as a factor instead of log2(alpha) in the exponent, d(alpha) = 2^z (dW - rd)
+          // without a division (same algebra as LX_BWDQ in ea_lara_x.hip).
+          const float4 lz4 = *reinterpret_cast<const float4*>(sc + r0);
+          const float4 tm4 = *reinterpret_cast<const float4*>(sc + chunk + r0);
+          const float4 rd4 = *reinterpret_cast<const float4*>(sc + 2 * chunk + r0);
+          const float4 sd4 = *reinterpret_cast<const float4*>(sc + 3 * chunk + r0);     // sda / C
+          const f32x2 s22 = {p.scale_log2, p.scale_log2}, kap = {p.kappa, p.kappa};
+          const f32x2 lzv[2] = {{lz4.x, lz4.y}, {lz4.z, lz4.w}}, tmv[2] = {{tm4.x, tm4.y}, {tm4.z, tm4.w}};
+          const f32x2 rdv[2] = {{rd4.x, rd4.y}, {rd4.z, rd4.w}}, sdv[2] = {{sd4.x, sd4.y}, {sd4.z, sd4.w}};
+          f32x2 sr2 = {0.f, 0.f}, sdbh2 = {0.f, 0.f}, su2 = {0.f, 0.f};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x2 S1 = {s1[2 * hh], s1[2 * hh + 1]};
+            const f32x2 T2 = f32x2{s2[2 * hh], s2[2 * hh + 1]} * s22;
+            f32x2 x = S1 * s22 + (f32x2{cst2, cst2} - lzv[hh]);
+            f32x2 t = {0.f, 0.f}, al = {1.f, 1.f};
+            if (p.mis == MIS_OPT) {
+              const f32x2 tx = T2 - f32x2{lset2, lset2};
+              t = f32x2{fast_exp2(tx[0]), fast_exp2(tx[1])};
+              al = kap * t + (f32x2{bhc, bhc} - kap * tmv[hh]);
+            } else if (p.mis == MIS_BIASED) {
+              x += T2;
+            }
+            const f32x2 wz = {fast_exp2(x[0]), fast_exp2(x[1])};
+            f32x2 w = wz;
+            if (p.mis == MIS_OPT) w = wz * f32x2{fmaxf(al[0], 1e-8f), fmaxf(al[1], 1e-8f)};
+            const f32x2 dd = f32x2{s3[2 * hh], s3[2 * hh + 1]} - rdv[hh];
+            const f32x2 dz = w * dd;
+            f32x2 da = {0.f, 0.f}, tdt = {0.f, 0.f};
+            if (p.mis == MIS_OPT) {
+              const f32x2 d0 = wz * dd;
+              da = f32x2{al[0] > 1e-8f ? d0[0] : 0.f, al[1] > 1e-8f ? d0[1] : 0.f};
+              tdt = t * kap * (da - sdv[hh]);
+            }
+            w0[mt][2 * hh] = w[0]; w0[mt][2 * hh + 1] = w[1];
+            w1v[mt][2 * hh] = dz[0]; w1v[mt][2 * hh + 1] = dz[1];
+            w2v[mt][2 * hh] = tdt[0]; w2v[mt][2 * hh + 1] = tdt[1];
+            w3v[mt][2 * hh] = t[0]; w3v[mt][2 * hh + 1] = t[1];
+            sr2 += dz; sdbh2 += da; su2 += tdt;
+          }
+          s_r += sr2[0] + sr2[1]; s_dbh += sdbh2[0] + sdbh2[1]; s_u += su2[0] + su2[1];
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (MODE == LY_FWD) {
@@ -207,13 +275,15 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
             float da = 0.f, tdt = 0.f;
             if (p.mis == MIS_OPT) {
               da = e.alpha > 1e-8f ? dz * fast_rcp(e.alpha) : 0.f;
-              tdt = e.t * p.kappa * (da - sd * invC);
+              tdt = e.t * p.kappa * (da - sd);
             }
             w0[mt][r] = w; w1v[mt][r] = dz; w2v[mt][r] = tdt; w3v[mt][r] = e.t;
             s_r += dz; s_dbh += da; s_u += tdt;
           }
         }
+        }
       }
+      if (prof_ci < 5 && sb == sub) EA_STAMP(p, 5 + prof_ci * 8);
       // tr-read addressing of the two 16-token tiles of this wave
       const int ra = rb + 4 * g + (li >> 2), rb2 = ra + 16;
       if (MODE == LY_FWD) {
@@ -276,10 +346,14 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
           }
         }
       }
+      if (prof_ci < 5 && sb == sub) EA_STAMP(p, 6 + prof_ci * 8);
       }   // sub-blocks
+      if (prof_ci < 5) EA_STAMP(p, 7 + prof_ci * 8);
+      ++prof_ci;
     }
   }
-  if (!c_ok) return;
+  EA_STAMP(p, 60);
+  if (!c_ok) { EA_BLK(p, 1); return; }
   // ---- partial results of this (split, sub-chunk): lane (c, g) owns channels DQ*g .. ----
   const int S = p.nsplit * nsub;
   const size_t slot = ((size_t)bh * S + split * nsub + sub) * p.C + c;
@@ -293,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
     if (g == 0) { ml[0] = s_r; ml[1] = s_dbh; ml[2] = s_u; ml[3] = 0.f; }
   } else if (MODE == LY_PMAX) {
     if (g == 0) { ml[0] = m_k * LN2; ml[1] = 0.f; ml[2] = 0.f; ml[3] = 0.f; }
+    EA_BLK(p, 1);
     return;
   } else if (PERF) {
     s_r = quad_sum(s_r);
@@ -308,25 +383,74 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
     put(p.p_acc1, acc1);
     if (p.mis == MIS_OPT) { put(p.p_acc2, acc2); put(p.p_acc3, acc3); }
   }
+  EA_STAMP(p, 61);
+  EA_BLK(p, 1);
 }
 
-template <typename E, int D>
-static int launch_y(int mode, const LaraP& p, hipStream_t st) {
-  const size_t lds = (size_t)2 * 128 * D * 2 + (size_t)4 * 128 * sizeof(float);
-  const dim3 grid((unsigned)(p.B * p.H * p.nsplit), (unsigned)((p.NCT + 3) / 4)), block(256);
-  switch (mode) {
-    case LY_FWD: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_FWD>), grid, block, lds, st, p); break;
-    case LY_BWDQ: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDQ>), grid, block, lds, st, p); break;
-    case LY_BWDK: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_BWDK>), grid, block, lds, st, p); break;
-    case LY_PMAX: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PMAX>), grid, block, lds, st, p); break;
-    case LY_PKV: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PKV>), grid, block, lds, st, p); break;
-    case LY_PBWDQ: hipLaunchKernelGGL((lara_y_kernel<E, D, LY_PBWDQ>), grid, block, lds, st, p); break;
-    default: return EA_E_BADARG;
+// Slice boundaries of the sequence for one token-row pass.  Slices are equal unless the 2 BH
+// workgroups of a two-slice launch do not fit on the chip at once (BH < slots < 2 BH): then the
+// second "round" would run on a mostly idle chip.  With split-major dispatch order the BH first
+// slices start immediately next to slots - BH second slices; the remaining second slices follow
+// in rb = ceil(BH / (slots - BH)) rounds, so first : second = rb : 1 makes everything end together
+// (e.g. B*h = 384 on 256 CUs x 2 resident workgroups: 588 + 196 tokens instead of 392 + 392).
+static void lara_y_plan(LaraP& p, int slots) {
+  const int BH = p.B * p.H, k = p.nsplit, gran = 16;
+  const int tpb = ((p.N + k - 1) / k + gran - 1) / gran * gran;
+  for (int i = 0; i <= k; ++i) p.tok_begin[i] = i * tpb < p.N ? i * tpb : p.N;
+  p.tok_begin[k] = p.N;
+  if (k == 2 && BH < slots && slots < 2 * BH) {
+    const int rb = (BH + (slots - BH) - 1) / (slots - BH);
+    int b = p.N / (1 + rb) / gran * gran;
+    if (b >= gran) p.tok_begin[1] = p.N - b;
   }
+}
+
+static int device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename E, int D, int MODE>
+static int launch_y_mode(LaraP& p, hipStream_t st) {
+  const size_t lds = (size_t)2 * 128 * D * 2 + (size_t)4 * 128 * sizeof(float);
+  static int occ = 0;                       // resident workgroups per CU of this instantiation
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&lara_y_kernel<E, D, MODE>), 256, lds) != hipSuccess || n <= 0) n = 2;
+    occ = n;
+  }
+  lara_y_plan(p, occ * device_cus());
+  const dim3 grid((unsigned)(p.B * p.H * p.nsplit), (unsigned)((p.NCT + 3) / 4)), block(256);
+  hipLaunchKernelGGL((lara_y_kernel<E, D, MODE>), grid, block, lds, st, p);
   return (int)hipGetLastError();
 }
 
-int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st) {
+template <typename E, int D>
+static int launch_y(int mode, LaraP& p, hipStream_t st) {
+  switch (mode) {
+    case LY_FWD: return launch_y_mode<E, D, LY_FWD>(p, st);
+    case LY_BWDQ: return launch_y_mode<E, D, LY_BWDQ>(p, st);
+    case LY_BWDK: return launch_y_mode<E, D, LY_BWDK>(p, st);
+    case LY_PMAX: return launch_y_mode<E, D, LY_PMAX>(p, st);
+    case LY_PKV: return launch_y_mode<E, D, LY_PKV>(p, st);
+    case LY_PBWDQ: return launch_y_mode<E, D, LY_PBWDQ>(p, st);
+    default: return EA_E_BADARG;
+  }
+}
+
+int lara_y_dispatch(int mode, const LaraP& p0, int dtype, hipStream_t st) {
+  LaraP p = p0;
+  p.prof = nullptr;
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "lara_y", mode);
+#endif
   if (dtype == EA_BF16) {
     if (p.D == 64) return launch_y<BF16, 64>(mode, p, st);
     if (p.D == 32) return launch_y<BF16, 32>(mode, p, st);
