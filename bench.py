@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tune", action="store_true",
                     help="skip PyTorch TunableOp selection of the hipBLASLt/rocBLAS projection GEMMs")
+    ap.add_argument("--gemm-tune-file", default=None,
+                    help="TunableOp results file: read (no tuning) if it exists, else tuned and written at exit")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,8 +142,12 @@ def main():
     if tune:
         import torch.cuda.tunable as tunable
         tunable.enable(True)
-        tunable.tuning_enable(True)
-        tunable.set_filename(os.path.join(tempfile.gettempdir(), "ea_bench_tunableop_%d.csv" % os.getpid()))
+        if a.gemm_tune_file:
+            tunable.set_filename(a.gemm_tune_file)
+            tunable.tuning_enable(not os.path.exists(a.gemm_tune_file))
+        else:
+            tunable.set_filename(os.path.join(tempfile.gettempdir(), "ea_bench_tunableop_%d.csv" % os.getpid()))
+            tunable.tuning_enable(True)
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -539,6 +539,8 @@ int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t
 namespace ea {
 int colsum_parts(int rows, int cols);
 int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows, int cols, hipStream_t st);
+int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, hipStream_t st);
+int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
 }  // namespace ea
 
 extern "C" {
@@ -548,6 +550,17 @@ int ea_bias_grad_parts(int32_t rows, int32_t cols) { return ea::colsum_parts(row
 int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, float* part, float* db, void* stream) {
   if (!dy || !part || !db) return EA_E_BADARG;
   return ea::colsum_dispatch(dtype, dy, part, db, rows, cols, (hipStream_t)stream);
+}
+
+int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* stream) {
+  if (!x || !out) return EA_E_BADARG;
+  return ea::colsum_f32_dispatch(x, out, rows, cols, (hipStream_t)stream);
+}
+
+int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
+                 float* out, void* stream) {
+  if (!parts || !out) return EA_E_BADARG;
+  return ea::slice_sum_dispatch(a, parts, out, BH, S, n, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,6 +1,9 @@
-// ea_proj.hip -- bias gradient of the qkv / output projections: db[c] = sum_t dY[t][c] over all
-// B*N tokens (torch does this with a generic strided reduce at ~1.7 TB/s; this is a plain
-// 16-B/lane streaming column sum with a fixed-order two-stage reduction, so it is deterministic).
+// ea_proj.hip -- the small reductions around the attention cores:
+//   * bias gradient of the qkv / output projections, db[c] = sum_t dY[t][c] over all B*N tokens
+//     (torch does this with a generic strided reduce at ~1.7 TB/s; this is a plain 16-B/lane
+//     streaming column sum with a fixed-order two-stage reduction, so it is deterministic);
+//   * fp32 column sums of per-(b,h) parameter-gradient partials;
+//   * scale * (a + sum over sequence slices) of a per-landmark tensor.
 #include "ea_common.h"
 
 namespace ea {
@@ -59,23 +62,49 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const uint16_t* __rest
   }
 }
 
-// stage 2: out[c] = sum_b part[b][c]; a block owns 16 columns, 16 threads per column.
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            int nblk, int cols) {
-  __shared__ float red[16][17];
+// stage 2 / generic fp32 column sum: out[c] = sum_r x[r][c] (fixed order).  A block owns 16 columns
+// (64-B row segments), 64 row-lanes per column; the partials are L2-resident, so what matters is
+// having every load of a thread in flight at once.
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           int rows, int cols) {
+  __shared__ float red[64][17];
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
   const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  if (c < cols)
-    for (int b = rl; b < nblk; b += 16) s += part[(size_t)b * cols + c];
+  if (c < cols) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rl;
+    for (; r + 192 < rows; r += 256) {
+      s0 += x[(size_t)r * cols + c];
+      s1 += x[(size_t)(r + 64) * cols + c];
+      s2 += x[(size_t)(r + 128) * cols + c];
+      s3 += x[(size_t)(r + 192) * cols + c];
+    }
+    for (; r < rows; r += 64) s0 += x[(size_t)r * cols + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[rl][cl] = s;
   __syncthreads();
   if (tid < 16 && blockIdx.x * 16 + tid < cols) {
     float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) t += red[j][tid];
+    for (int j = 0; j < 64; ++j) t += red[j][tid];
     out[blockIdx.x * 16 + tid] = t;
   }
+}
+
+// out[bh][j] = scale * (a[bh][j] + sum_s p[bh][s][j]),  j < n  (float4 granularity)
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                        float* __restrict__ out, int S, int n4, float scale, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const size_t bh = i / n4, j = i - bh * n4;
+  float4 acc = a ? reinterpret_cast<const float4*>(a)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const float4 v = reinterpret_cast<const float4*>(p)[(bh * S + s) * n4 + j];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
 }
 
 int colsum_parts(int rows, int cols) {
@@ -101,7 +130,20 @@ int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows,
     hipLaunchKernelGGL(colsum_part_kernel<F16>, dim3(nblk), dim3(256), lds, st, (const uint16_t*)x, part, rows, cols, rpb);
   else
     return EA_E_BADARG;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, part, out, nblk, cols);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, part, out, nblk, cols);
+  return (int)hipGetLastError();
+}
+
+int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return EA_E_BADARG;
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, x, out, rows, cols);
+  return (int)hipGetLastError();
+}
+
+int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st) {
+  if (BH <= 0 || S <= 0 || n <= 0 || (n & 3)) return EA_E_BADARG;
+  const size_t total4 = (size_t)BH * (n / 4);
+  hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, a, p, out, S, n / 4, scale, total4);
   return (int)hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ SIGNATURES = {
     "ea_lara_merge_bwd": [_I] * 5 + [_F] + [_P] * 16,
     "ea_bias_grad_parts": [_I, _I],
     "ea_bias_grad": [_I, _I, _I, _P, _P, _P, _P],
+    "ea_colsum_f32": [_I, _I, _P, _P, _P],
+    "ea_slice_sum": [_I, _I, _I, _F, _P, _P, _P, _P],
     "ea_lara_parts": [_LG],
     "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],

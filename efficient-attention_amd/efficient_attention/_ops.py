@@ -242,7 +242,8 @@ class EvaAttnFn(torch.autograd.Function):
                     None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.stream())
             nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
                     nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
-            dWs, dvs = dW.sum(0), dvec.sum(0)
+            dWs = colsum_f32(dW.view(lg.BH, -1)).view(2, d_, d_)
+            dvs = colsum_f32(dvec.view(lg.BH, -1)).view(2, 3, d_)
             raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
             pgrads = [g.to(p.dtype) for g, p in zip(raw, mlp_params)]
             if dbias is not None:
@@ -432,7 +433,8 @@ class LaraAttnFn(torch.autograd.Function):
         nv.call("ea_lara_bwd_kstats", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
                 nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r),
                 nv.ptr(p_domk), nv.stream())
-        d_omega = (scale * (dom_q + p_domk.sum(1))).view(B, h, C, d)
+        d_omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
+        nv.call("ea_slice_sum", BH, S, C * d, float(scale), nv.ptr(dom_q), nv.ptr(p_domk), nv.ptr(d_omega), nv.stream())
         d_qbar = d_bhv = None
         if mis == 0:
             nv.call("ea_lara_bwd_qcorr", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq),
@@ -503,7 +505,7 @@ class LaraLandmarkFn(torch.autograd.Function):
                 nv.ptr(dW), nv.ptr(dvec), nv.stream())
         pgrads = []
         if geom.has_mlp:
-            dWs, dvs = dW.sum(0), dvec.sum(0)              # [2,d,d], [2,3,d]
+            dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
             raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
             pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
         return (dpq, dpk, None, None) + tuple(pgrads)
@@ -666,6 +668,14 @@ def _split_k(rows):
         if rows % s == 0 and rows // s >= 512:
             best = s
     return best
+
+
+def colsum_f32(x2):
+    """x2.sum(0) of a contiguous fp32 [rows, cols] tensor through ea_colsum_f32 (fixed order)."""
+    rows, cols = x2.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    nv.call("ea_colsum_f32", rows, cols, nv.ptr(x2), nv.ptr(out), nv.stream())
+    return out
 
 
 def bias_grad(dy2):

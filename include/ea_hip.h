@@ -276,6 +276,17 @@ int ea_bias_grad_parts(int32_t rows, int32_t cols);
 int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, float* part, float* db,
                  void* stream);
 
+/* ---- small fp32 reductions around the cores (replace chains of tiny torch kernels) ----
+ * ea_colsum_f32: out[c] = sum_r x[r][c], x fp32 [rows, cols] contiguous, fixed summation order.
+ *   Used for the per-(b,h) partials of the landmark-MLP parameter gradients
+ *   (ea_lara_landmarks_bwd dW_part / dvec_part: autograd's accumulation over the batch for
+ *   q_bar_gen / k_bar_gen, lara.py:45-54, eva.py:93-103).
+ * ea_slice_sum: out[bh][j] = scale * (a[bh][j] + sum_s parts[bh][s][j]), j < n (n % 4 == 0), a may
+ *   be NULL.  Used for d(omega) = s (d_omega_q + sum over sequence slices of ea_lara_bwd_kstats). */
+int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* stream);
+int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
+                 float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

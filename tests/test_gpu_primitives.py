@@ -32,3 +32,32 @@ def test_bias_grad_matches_fp64_column_sum(rows, cols, dtype):
     assert bool(((got.double() - ref).abs() <= tol + 1e-6).all())
     again = _ops.bias_grad(dy)
     assert torch.equal(got, again)          # fixed-order two-stage sum: deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(384, 8192), (384, 384), (7, 5), (1000, 33)])
+def test_colsum_f32_matches_fp64(rows, cols):
+    import torch
+    from efficient_attention import _ops
+    g = torch.Generator(device="cuda").manual_seed(rows * 31 + cols)
+    x = torch.randn(rows, cols, device="cuda", generator=g)
+    got = _ops.colsum_f32(x)
+    ref = x.double().sum(0)
+    assert torch.allclose(got.double(), ref, rtol=0, atol=2e-6 * float(x.abs().sum(0).max()) + 1e-6)
+    assert torch.equal(got, _ops.colsum_f32(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_a", [True, False])
+def test_slice_sum(with_a):
+    import ctypes
+    import torch
+    from efficient_attention import _native as nv
+    BH, S, n = 12, 3, 49 * 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(BH, n, device="cuda", generator=g)
+    p = torch.randn(BH, S, n, device="cuda", generator=g)
+    out = torch.empty(BH, n, device="cuda")
+    nv.call("ea_slice_sum", BH, S, n, 0.125, nv.ptr(a) if with_a else None, nv.ptr(p), nv.ptr(out), nv.stream())
+    ref = 0.125 * ((a if with_a else 0) + p.sum(1))
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
