@@ -82,6 +82,8 @@ struct WinP {
   int B, H, L, w, e;
   float scale, scale_log2;
   WinTiling t;
+  int bias_lds;                              // bwd: the bias table of the head is staged in LDS
+  long long* prof;                           // dev builds (-DEA_PROFILE): phase time stamps
 };
 
 // ---- slot tables: the (window-independent) offset of every key / query slot, built once per

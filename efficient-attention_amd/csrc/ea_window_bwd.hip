@@ -14,10 +14,14 @@
 //   LDS and is written once per workgroup.
 // There is no barrier between the phases: delta and lse are staged with the Q/dO rows.
 #include "ea_window.h"
+#include <type_traits>
 
 namespace ea {
 
-template <typename E, int D>
+// GB: the bias table is too large for LDS and is read from global memory (bias / biasT); otherwise
+// every bias read goes to LDS -- the staged table, or a block of zeros when there is no bias -- so
+// that the inner loops carry no branches and hipcc can interleave the independent tiles.
+template <typename E, int D, bool GB>
 __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
@@ -28,16 +32,24 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   const WinTiling& t = p.t;
   const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
   const int rowsQ = t.wpi * nQTe * 16;
-  const int WqPad = t.nQT * 16;
   char* Ks = smem;
   char* Vs = Ks + t.rowsTotal * ROWB;
   char* Qs = Vs + t.rowsTotal * ROWB;
   char* dOs = Qs + rowsQ * ROWB;
   float* lse_s = reinterpret_cast<float*>(dOs + rowsQ * ROWB);
   float* delta_s = lse_s + rowsQ;
+  // bias-gradient accumulator [Wq][BLD] and (bias_lds) the head's log2-domain bias [Wq][BLD]; the
+  // odd row stride keeps both the row-wise (phase A) and the column-wise (phase B) accesses of
+  // the 64 lanes on distinct banks
+  const int BLD = t.biasLd + 1;
   float* dbias_s = delta_s + rowsQ;
-  const int nbias = p.bias ? WqPad * t.biasLd : 0;
-  float* kmul = dbias_s + nbias;
+  const int nbias = p.bias ? t.Wq * BLD : 0;
+  float* bias_s = dbias_s + nbias;
+  float* zero64 = bias_s + (p.bias_lds ? nbias : 0);   // bias reads without a bias table land here
+  float* trash64 = zero64 + 64;                        // bias-gradient writes of padded entries
+  float* kmul = trash64 + 64;
+  const float* bread = p.bias_lds ? bias_s : zero64;
+  const int brs = p.bias_lds ? BLD : 0, btm = p.bias_lds ? 16 : 0;
   float* kadd = kmul + t.rowsTotal;
   int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
   int* qd = kd + t.nLT * 16;
@@ -59,6 +71,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
   const float* lse_g = p.lse + (size_t)bh * p.G.N;
 
+  EA_STAMP(p, 0);
+  EA_BLK(p, 0);
   // ---- once per workgroup: landmark rows, zero tile, bias-gradient accumulator ----
   for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
     const int row = idx / CPR, c = idx - row * CPR;
@@ -81,6 +95,15 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
     }
   }
   for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
+  if (tid < 128) zero64[tid] = 0.f;
+  if (p.bias_lds) {
+    const float* bsrc = p.bias + (size_t)h * t.Wq * t.biasLd;
+    for (int idx = tid * 4; idx < t.Wq * t.biasLd; idx += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(bsrc + idx);
+      float* d = bias_s + (idx / t.biasLd) * BLD + (idx % t.biasLd);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
   build_slot_tables(kd, qd, t, p.G, p.w, p.e, nQTe * 16, tid);
   __syncthreads();
 
@@ -90,59 +113,61 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   for (int dt = 0; dt < DT; ++dt) { dlk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dlv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int it_end = min((blk + 1) * t.ipb, t.niter);
+  EA_STAMP(p, 1);
+  int prof_it = 0;
+  (void)prof_it;
   for (int it = blk * t.ipb; it < it_end; ++it) {
     __syncthreads();
+    if (prof_it < 4) EA_STAMP(p, 2 + prof_it * 6);
     // ---- stage local K/V rows and Q/dO rows (+ lse, delta = dO.O).  Batches of NB slots per thread:
     // every global load of a batch is in flight before the first conversion / LDS store, so the
     // staging costs ~one memory round trip per iteration instead of one per 256-slot sweep. ----
     constexpr int NB = 2;
-    for (int base = 0; base < t.rowsLocal * CPR; base += 256 * NB) {
-      u32x4 kr[NB], vr[NB];
-      int rowv[NB];
-      float mulv[NB], addv[NB];
+    struct KVb { u32x4 kr[NB], vr[NB]; int rowv[NB]; float mulv[NB], addv[NB]; };
+    struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB]; int rowv[NB]; };
+    auto issueKV = [&](KVb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        kr[i] = vr[i] = u32x4{0u, 0u, 0u, 0u};
-        rowv[i] = -1; mulv[i] = 0.f; addv[i] = -INFINITY;
+        x.kr[i] = x.vr[i] = u32x4{0u, 0u, 0u, 0u};
+        x.rowv[i] = -1; x.mulv[i] = 0.f; x.addv[i] = -INFINITY;
         if (idx < t.rowsLocal * CPR) {
           const int row = idx / CPR, c = idx - row * CPR;
           const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
           const int slot = row - wi * rowsPerWin;
           const int win = it * t.wpi + wi;
-          rowv[i] = row;
+          x.rowv[i] = row;
           if (win < t.nwin && slot < t.Wk) {
             int oy, ox;
             win_origin(p.G, win, p.w, oy, ox);
             const int tok = slot_token(p.G, kd[slot], oy, ox);
-            addv[i] = MASK_FILL * LOG2E;
+            x.addv[i] = MASK_FILL * LOG2E;
             if (tok >= 0) {
-              kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
-              vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
-              if (!(mrow && mrow[tok])) { mulv[i] = 1.f; addv[i] = 0.f; }
+              x.kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
+              x.vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+              if (!(mrow && mrow[tok])) { x.mulv[i] = 1.f; x.addv[i] = 0.f; }
             }
           }
         }
       }
+    };
+    auto commitKV = [&](const KVb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        if (rowv[i] >= 0) {
-          const int c = (base + tid + i * 256) - rowv[i] * CPR;
-          sts16(Ks + lds_off<D>(rowv[i], c), kr[i]);
-          sts16(Vs + lds_off<D>(rowv[i], c), vr[i]);
-          if (c == 0) { kmul[rowv[i]] = mulv[i]; kadd[rowv[i]] = addv[i]; }
+        if (x.rowv[i] >= 0) {
+          const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
+          sts16(Ks + lds_off<D>(x.rowv[i], c), x.kr[i]);
+          sts16(Vs + lds_off<D>(x.rowv[i], c), x.vr[i]);
+          if (c == 0) { kmul[x.rowv[i]] = x.mulv[i]; kadd[x.rowv[i]] = x.addv[i]; }
         }
       }
-    }
-    for (int base = 0; base < rowsQ * CPR; base += 256 * NB) {
-      u32x4 qr[NB], dr[NB], orr[NB];
-      float lsv[NB];
-      int rowv[NB];
+    };
+    auto issueQ = [&](Qb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        qr[i] = dr[i] = orr[i] = u32x4{0u, 0u, 0u, 0u};
-        rowv[i] = -1; lsv[i] = INFINITY;
+        x.qr[i] = x.dr[i] = x.orr[i] = u32x4{0u, 0u, 0u, 0u};
+        x.rowv[i] = -1; x.lsv[i] = INFINITY;
         if (idx < rowsQ * CPR) {
           const int row = idx / CPR, c = idx - row * CPR;
           const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
@@ -154,34 +179,58 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             win_origin(p.G, win, p.w, oy, ox);
             tok = slot_token(p.G, qd[slot], oy, ox);
           }
-          rowv[i] = row;
+          x.rowv[i] = row;
           if (tok >= 0) {
-            qr[i] = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
-            dr[i] = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
-            orr[i] = ldg16(ob + (tok * outp.sn + c * 8) * 2);
-            if (c == 0) lsv[i] = lse_g[tok] * LOG2E;
+            x.qr[i] = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
+            x.dr[i] = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
+            x.orr[i] = ldg16(ob + (tok * outp.sn + c * 8) * 2);
+            if (c == 0) x.lsv[i] = lse_g[tok] * LOG2E;
           }
         }
       }
+    };
+    auto commitQ = [&](const Qb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         float part = 0.f;
         float a8[8], o8[8];
-        unpack8<E>(dr[i], a8);
-        unpack8<E>(orr[i], o8);
+        unpack8<E>(x.dr[i], a8);
+        unpack8<E>(x.orr[i], o8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part += a8[j] * o8[j];
 #pragma unroll
         for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
-        if (rowv[i] >= 0) {
-          const int c = (base + tid + i * 256) - rowv[i] * CPR;
-          sts16(Qs + lds_off<D>(rowv[i], c), qr[i]);
-          sts16(dOs + lds_off<D>(rowv[i], c), dr[i]);
-          if (c == 0) { delta_s[rowv[i]] = part; lse_s[rowv[i]] = lsv[i]; }
+        if (x.rowv[i] >= 0) {
+          const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
+          sts16(Qs + lds_off<D>(x.rowv[i], c), x.qr[i]);
+          sts16(dOs + lds_off<D>(x.rowv[i], c), x.dr[i]);
+          if (c == 0) { delta_s[x.rowv[i]] = part; lse_s[x.rowv[i]] = x.lsv[i]; }
         }
       }
+    };
+    {
+      // first batch of both row sets in flight together (the whole iteration when wpi == 1)
+      KVb kv0;
+      Qb q0;
+      issueKV(kv0, 0);
+      issueQ(q0, 0);
+      commitKV(kv0, 0);
+      commitQ(q0, 0);
     }
+    for (int base = 256 * NB; base < t.rowsLocal * CPR; base += 256 * NB) {
+      KVb x;
+      issueKV(x, base);
+      commitKV(x, base);
+    }
+    if (prof_it < 4) EA_STAMP(p, 3 + prof_it * 6);
+    for (int base = 256 * NB; base < rowsQ * CPR; base += 256 * NB) {
+      Qb x;
+      issueQ(x, base);
+      commitQ(x, base);
+    }
+    if (prof_it < 4) EA_STAMP(p, 4 + prof_it * 6);
     __syncthreads();
+    if (prof_it < 4) EA_STAMP(p, 5 + prof_it * 6);
 
     // =============================== phase A: dQ ===============================
     for (int qi = wave; qi < t.wpi * t.nQT; qi += 4) {
@@ -203,12 +252,14 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
         dof[ks] = as_x8<E>(lds16(dOs + (qrow - li) * ROWB + lo.plain[ks]));
       }
       const float lse2 = lse_s[qrow], delta = delta_s[qrow];
-      const float* brow = p.bias
+      const float* brow = (GB && p.bias)
           ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+      const float* brow_s = bread + (qslot < t.Wq ? qslot : 0) * brs + 4 * g;
       f32x4 dq[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+      if (prof_it == 0) EA_STAMP(p, 20);
       for (int ch = 0; ch < t.nchunks; ++ch) {
         int rowbase[4];
         uint32_t dsw[4][2];
@@ -229,8 +280,14 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);   // log2-domain bias
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);                                  // log2-domain bias
+          if (GB) {
+            if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
+          } else {
+            const float* bs = brow_s + (local ? tile : 0) * btm;
+            const float lf = local ? 1.f : 0.f;
+            b4 = make_float4(bs[0] * lf, bs[1] * lf, bs[2] * lf, bs[3] * lf);
+          }
           const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
           float ds[4];
 #pragma unroll
@@ -243,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
         }
+        if (prof_it == 0 && ch < 3) EA_STAMP(p, 21 + 2 * ch);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           u32x4 f4v;
@@ -256,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             dq[dt] = E::mma(as_x8<E>(lo_, hi_), dsf, dq[dt]);
           }
         }
+        if (prof_it == 0 && ch < 3) EA_STAMP(p, 22 + 2 * ch);
       }
       if (qtok >= 0) {
         float f[DQ];
@@ -269,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       }
     }
 
+    if (prof_it < 4) EA_STAMP(p, 6 + prof_it * 6);
     // =============================== phase B: dK, dV ===============================
     // work items: (window wi, local tile lt) for all staged windows, then landmark tile = wave
     const int nLocalItems = t.wpi * t.nLT;
@@ -293,60 +353,89 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       }
       const float kmu = kmul[krow], kad = kadd[krow];
       const int kslot = tile * 16 + li;                // key slot within the window / landmark id
+      const int pb = 30 + (is_lm ? 12 : 0);
+      if (prof_it == 0) EA_STAMP(p, pb);
       f32x4 dk[DT], dv[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-      for (int wi = wi_lo; wi < wi_hi; ++wi) {
-        if (it * t.wpi + wi >= t.nwin) break;
-        for (int qq = 0; qq < nQTe / 2; ++qq) {
-          uint32_t pw[2][2], dsw[2][2];
-          int rq[2];
+      // BM: 0 = no bias terms (landmark keys, or no bias at all); 1 = bias, one window per
+      // iteration: the (query, key) entry of the bias gradient belongs to this lane alone, so a plain
+      // LDS read-modify-write does (float atomics stall the LDS queue behind them); 2 = bias, several
+      // windows in flight: LDS atomics.  Padded entries write to a trash line instead of branching.
+      auto sweep = [&](auto bm_tag) {
+        constexpr int BM = decltype(bm_tag)::value;
+        for (int wi = wi_lo; wi < wi_hi; ++wi) {
+          if (it * t.wpi + wi >= t.nwin) break;
+          for (int qq = 0; qq < nQTe / 2; ++qq) {
+            uint32_t pw[2][2], dsw[2][2];
+            int rq[2];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int qt = 2 * qq + u;
-            rq[u] = (wi * nQTe + qt) * 16;
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 2; ++u) {
+              const int qt = 2 * qq + u;
+              rq[u] = (wi * nQTe + qt) * 16;
+              f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              s = E::mma(as_x8<E>(lds16(Qs + rq[u] * ROWB + lo.plain[ks])), kf[ks], s);
-              dp = E::mma(as_x8<E>(lds16(dOs + rq[u] * ROWB + lo.plain[ks])), vf[ks], dp);
+              for (int ks = 0; ks < KS; ++ks) {
+                s = E::mma(as_x8<E>(lds16(Qs + rq[u] * ROWB + lo.plain[ks])), kf[ks], s);
+                dp = E::mma(as_x8<E>(lds16(dOs + rq[u] * ROWB + lo.plain[ks])), vf[ks], dp);
+              }
+              const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
+              const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
+              const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+              const int q0 = qt * 16 + 4 * g;            // first of this lane's four query slots
+              float bt[4] = {0.f, 0.f, 0.f, 0.f};
+              if (BM != 0) {
+                if (GB) {
+                  // from the transposed copy in global memory: one 16-B load
+                  if (kslot < t.Wk) {
+                    const float4 bt4 = *reinterpret_cast<const float4*>(
+                        biasT + ((size_t)h * t.biasLd + kslot) * (t.nQT * 16) + q0);
+                    bt[0] = bt4.x; bt[1] = bt4.y; bt[2] = bt4.z; bt[3] = bt4.w;
+                  }
+                } else {
+                  const float* bs = bread + kslot;       // rows beyond Wq are masked by bias_on below
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) bt[r] = bs[min(q0 + r, t.Wq - 1) * brs];
+                }
+              }
+              float pr[4], ds[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int qs = q0 + r;                    // query slot in the window
+                const bool bias_on = BM != 0 && qs < t.Wq && kslot < t.Wk;
+                const float bias = bias_on ? bt[r] : 0.f;
+                const float x = fmaf(kmu, fmaf(s[r], p.scale_log2, bias), kad);
+                pr[r] = fast_exp2(x - ll[r]);
+                ds[r] = kmu * pr[r] * (dp[r] - dd[r]);
+                if (BM == 1) {
+                  float* dst = bias_on ? dbias_s + qs * BLD + kslot : trash64 + lane;
+                  *dst += ds[r];
+                } else if (BM == 2) {
+                  if (bias_on && ds[r] != 0.f) atomicAdd(dbias_s + qs * BLD + kslot, ds[r]);
+                }
+              }
+              pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
+              dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
             }
-            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
-            const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
-            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-            // bias of (queries 16 qt + 4g .. +3, this key) from the transposed copy: one 16-B load
-            float4 bt4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (biasT && !is_lm && kslot < t.Wk) bt4 = *reinterpret_cast<const float4*>(
-                biasT + ((size_t)h * t.biasLd + kslot) * (t.nQT * 16) + qt * 16 + 4 * g);
-            const float bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
-            float pr[4], ds[4];
+            u32x4 a4, b4;
+            a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
+            b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
+            const typename E::x8 pf = as_x8<E>(a4), dsf = as_x8<E>(b4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int qs = qt * 16 + 4 * g + r;       // query slot in the window
-              const bool bias_on = biasT && !is_lm && qs < t.Wq && kslot < t.Wk;
-              const float bias = bias_on ? bt[r] : 0.f;
-              const float x = fmaf(kmu, fmaf(s[r], p.scale_log2, bias), kad);
-              pr[r] = fast_exp2(x - ll[r]);
-              ds[r] = kmu * pr[r] * (dp[r] - dd[r]);
-              if (bias_on && ds[r] != 0.f) atomicAdd(dbias_s + qs * t.biasLd + kslot, ds[r]);
+            for (int dt = 0; dt < DT; ++dt) {
+              const int o0 = rq[0] * ROWB + lo.tr[dt];
+              const int o1 = rq[1] * ROWB + lo.tr[dt];
+              dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
+              dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
             }
-            pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
-            dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
-          }
-          u32x4 a4, b4;
-          a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
-          b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
-          const typename E::x8 pf = as_x8<E>(a4), dsf = as_x8<E>(b4);
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int o0 = rq[0] * ROWB + lo.tr[dt];
-            const int o1 = rq[1] * ROWB + lo.tr[dt];
-            dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
-            dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
           }
         }
-      }
+      };
+      if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
+      else if (t.wpi == 1) sweep(std::integral_constant<int, 1>{});
+      else sweep(std::integral_constant<int, 2>{});
+      if (prof_it == 0) EA_STAMP(p, pb + 9);
       if (is_lm) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dlk[dt] += dk[dt]; dlv[dt] += dv[dt]; }
@@ -382,7 +471,11 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
         }
       }
     }
+    if (prof_it == 0) EA_STAMP(p, 55);
+    if (prof_it < 4) EA_STAMP(p, 7 + prof_it * 6);
+    ++prof_it;
   }
+  EA_STAMP(p, 60);
 
   // ---- per-workgroup partial sums of the landmark and bias gradients ----
   if (p.L > 0 && wave < t.nCT) {
@@ -401,8 +494,10 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   if (p.bias) {
     __syncthreads();
     float* dst = p.dbias_part + (((size_t)blk * p.B + b) * p.H + h) * (size_t)t.Wq * t.biasLd;
-    for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[idx];
+    for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[(idx / t.biasLd) * BLD + (idx % t.biasLd)];
   }
+  EA_STAMP(p, 61);
+  EA_BLK(p, 1);
 }
 
 // fp32 scratch -> I/O dtype for the overlapping-window path
@@ -426,21 +521,26 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
   }
 }
 
-size_t window_bwd_lds(const WinTiling& t, int D, bool bias) {
+size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
   const int nQTe = (t.nQT + 1) & ~1;
   const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
   size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
-  if (bias) b += (size_t)t.nQT * 16 * t.biasLd * 4;
-  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4;
+  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
+  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
   return b;
 }
 
 template <typename E, int D>
-static int launch_bwd(const WinP& p, const T4& outp, const float* biasT, hipStream_t st) {
-  const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr);
+static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t st) {
+  // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
+  // every window; from global memory those loads sit exposed in the inner loops)
+  p.bias_lds = (p.bias && window_bwd_lds(p.t, D, true, true) <= 160 * 1024) ? 1 : 0;
+  const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
+  const bool gb = p.bias && !p.bias_lds;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_bwd_kernel<E, D>),
+    hipError_t e = hipFuncSetAttribute(gb ? reinterpret_cast<const void*>(&win_bwd_kernel<E, D, true>)
+                                          : reinterpret_cast<const void*>(&win_bwd_kernel<E, D, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
@@ -451,12 +551,19 @@ static int launch_bwd(const WinP& p, const T4& outp, const float* biasT, hipStre
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  hipLaunchKernelGGL((win_bwd_kernel<E, D>), grid, dim3(256), lds, st, p, outp, biasT);
+  if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, p, outp, biasT);
+  else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, p, outp, biasT);
   if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);
   return (int)hipGetLastError();
 }
 
-int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st) {
+int window_bwd_dispatch(const WinP& p0, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st) {
+  WinP p = p0;
+  p.prof = nullptr;
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "win_bwd", 0);
+#endif
   if (dtype == EA_BF16) {
     if (D == 64) return launch_bwd<BF16, 64>(p, outp, biasT, st);
     if (D == 32) return launch_bwd<BF16, 32>(p, outp, biasT, st);
