@@ -6,6 +6,7 @@
 namespace ea {
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st);
 int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st);
+size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds);
 }  // namespace ea
 #include "ea_landmark_params.h"
 #include "ea_lara.h"
@@ -49,6 +50,11 @@ int32_t ea_window_bwd_parts(const ea_geom* g) {
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
   return t.nblk;
 }
+int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
+  return window_bwd_lds(t, g->D, true, true) <= 160 * 1024 ? 0 : 1;
+}
 
 static int fill_win(const ea_geom* g, WinP& p) {
   if (!geom_ok(g)) return EA_E_BADARG;
@@ -87,7 +93,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
   if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dout, g->D) ||
       !t4_ok(out, g->D) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
-  if (bias && (!dbias_part || !bias_t)) return EA_E_BADARG;
+  if (bias && (!dbias_part || (!bias_t && ea_window_bwd_needs_bias_t(g) != 0))) return EA_E_BADARG;
   p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(dout);
   p.dq = mk(dq); p.dk = mk(dk); p.dv = mk(dv);
   p.lk = lk; p.lv = lv; p.bias = bias; p.mask = mask; p.lse = const_cast<float*>(lse);

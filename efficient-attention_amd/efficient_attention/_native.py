@@ -91,6 +91,7 @@ SIGNATURES = {
     "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P],
     "ea_window_bias_ld": [_G],
     "ea_window_bwd_parts": [_G],
+    "ea_window_bwd_needs_bias_t": [_G],
 }
 
 _lib = None

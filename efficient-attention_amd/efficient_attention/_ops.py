@@ -101,7 +101,7 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
         dk_acc = torch.empty((B, h, N, d), dtype=torch.float32, device=dev)
         dv_acc = torch.empty_like(dk_acc)
     bias_t = None
-    if bias_p is not None:
+    if bias_p is not None and nv.query("ea_window_bwd_needs_bias_t", geom):
         wq_pad = -(-bias_p.shape[1] // 16) * 16
         bias_t = F.pad(bias_p.transpose(1, 2), (0, wq_pad - bias_p.shape[1])).contiguous()   # [h, ld, WqPad]
     ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
@@ -110,9 +110,16 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
             ctypes.byref(ts[3]), ctypes.byref(ts[4]), nv.ptr(lse), ctypes.byref(ts[5]),
             ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(dlk_p), nv.ptr(dlv_p), nv.ptr(dbias_p),
             nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.stream())
-    dlk = dlk_p.sum(0).view(B, h, L, d) if L > 0 else None
-    dlv = dlv_p.sum(0).view(B, h, L, d) if L > 0 else None
-    dbias = dbias_p.sum((0, 1)) if bias_p is not None else None
+    dlk = dlv = dbias = None
+    if L > 0:
+        # per-workgroup partials [parts, B*h*L*d] -> one pass each (fixed summation order)
+        dlk = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
+        dlv = torch.empty_like(dlk)
+        n = B * h * L * d
+        nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlk_p), nv.ptr(dlk), nv.stream())
+        nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlv_p), nv.ptr(dlv), nv.stream())
+    if bias_p is not None:
+        dbias = colsum_f32(dbias_p.view(parts * B, -1)).view(bias_p.shape)
     return dlk, dlv, dbias
 
 
@@ -459,6 +466,7 @@ class LaraLandmarkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pq, pk, noise, cfg, *params):
         has_mlp, mixed, mis, dup, scale = cfg
+        nv.require_cuda(pq, "pooled q/k")
         B, h, L, d = pq.shape
         C = L * (2 if dup else 1)
         BH, dev = B * h, pq.device

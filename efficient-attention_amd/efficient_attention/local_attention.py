@@ -16,6 +16,22 @@ from . import _ops
 from .abstract_attention import MultiheadAttention
 
 
+class _TableGather(torch.autograd.Function):
+    """table[idx] (reference local_attention.py:70-79 `relative_position_bias_table[index]`) whose
+    backward is one dense [rows, len(idx)] x [len(idx), h] product with a one-hot matrix instead of
+    autograd's sort-based index_put (six kernels for a 169 x 3 table): deterministic, one tiny GEMM."""
+
+    @staticmethod
+    def forward(ctx, table, idx, onehot):
+        ctx.save_for_backward(onehot)
+        return table.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (onehot,) = ctx.saved_tensors
+        return (onehot @ g.float()).to(g.dtype), None, None
+
+
 def relative_position_index_2d(window_size, ext_size):
     """[w*w, (w+2e)^2] int64 index into the 2-D bias table for query (qi,qj) in [0,w)^2 and key
     (ki,kj) in [-e, w+e)^2: (qi-ki+e+w-1)*(2e+w) + (qj-kj+e+w-1)  (reference :49-62)."""
@@ -42,6 +58,10 @@ class LocalAttention(MultiheadAttention):
                 rows = 2 * (w + e - 1) * (2 * e + w + 1) + 1
                 self.local_relative_position_bias_table = nn.Parameter(torch.zeros(rows, self.num_heads))
                 self.register_buffer("relative_position_index", relative_position_index_2d(w, e))
+                flat = self.relative_position_index.reshape(-1)
+                onehot = torch.zeros(rows, flat.numel())
+                onehot[flat, torch.arange(flat.numel())] = 1.0
+                self.register_buffer("_rpe_onehot", onehot, persistent=False)   # not part of state_dict
             else:
                 self.local_relative_position_bias_table = nn.Parameter(
                     torch.zeros(self.num_heads, w, w + 2 * e))
@@ -56,7 +76,8 @@ class LocalAttention(MultiheadAttention):
         if not self.attn_2d:
             return tab
         idx = self.relative_position_index
-        return tab[idx.reshape(-1)].reshape(idx.shape[0], idx.shape[1], -1).permute(2, 0, 1)
+        return _TableGather.apply(tab, idx.reshape(-1), self._rpe_onehot).reshape(
+            idx.shape[0], idx.shape[1], -1).permute(2, 0, 1)
 
     def add_rel_pos_bias(self, local_dots):
         """Reference-compatible helper (:70-79): local_dots [b,h,w,i,j] + bias."""

@@ -103,9 +103,11 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
  *   dbias_part         : fp32 [ea_window_bwd_parts(g), B, H, Wq, ld]   (NULL iff bias NULL)
  *   bias_t             : fp32 [H, ld, 16*ceil(Wq/16)] transposed copy of `bias` (rows padded with
- *                        zeros), read by the key-tile phase with 16-B loads (NULL iff bias NULL) */
+ *                        zeros).  Only read when the head's bias table does not fit next to the
+ *                        window in LDS (ea_window_bwd_needs_bias_t(g) == 1); may be NULL otherwise. */
 int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
 int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
+int32_t ea_window_bwd_needs_bias_t(const ea_geom* g);
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
                        const ea_t4* out, float* lse, void* stream);
