@@ -16,6 +16,28 @@ from . import _native as nv
 
 KERNEL_TIMER = nv.KERNEL_TIMER
 # algorithmic HBM traffic of one launch, in units of one [B,H,N,D] I/O-dtype tensor
+def landmark_flops(BH, L, C, D, has_mlp, mixed, eva, bwd):
+    """Algorithmic FLOPs of one ea_lara_landmarks_fwd/bwd launch (real sizes, 2 per multiply-add):
+    the matrix products of ea_lara_landmark.hip; the backward recomputes the forward."""
+    f = 0
+    if has_mlp:
+        f += 2 * (2 * L * D * D)                      # H = P W^T, both sides
+    if not eva:
+        if mixed:
+            f += 2 * (2 * L * L * D)                  # A = k0 k0^T ; k_bar = A k0
+        f += 2 * C * L * D                            # M = omega mu^T
+    if bwd:
+        if not eva:
+            f += 2 * (2 * L * D * C)                  # dMU, dOM
+            if mixed:
+                f += 4 * (2 * L * L * D)              # dK0 = A^T dKb, dA, dK0 += dG K0, += dG^T K0
+        if has_mlp:
+            f += 2 * (2 * L * D * D) + 2 * (2 * D * D * L)   # dP = dH W, dW = dH^T P, both sides
+    return BH * f
+
+
+LAST_LMK_GEOM = None      # (BH, L, C, D, has_mlp, mixed, eva) of the most recent landmark launch (bench.py)
+
 KERNEL_ALGO_UNITS = {
     "ea_window_attn_fwd": 4,      # read q,k,v; write out
     "ea_window_attn_bwd": 8,      # read q,k,v,out,dout; write dq,dk,dv
@@ -193,6 +215,8 @@ class EvaAttnFn(torch.autograd.Function):
         if fused_mu:
             # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
             lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
+            global LAST_LMK_GEOM
+            LAST_LMK_GEOM = (B * h, L, L, d, 1, 0, 1)
             ps = [p.float().contiguous() for p in mlp_params]
             noise_c = None if noise is None else noise.float().contiguous()
             omega = torch.empty_like(qmean)
@@ -475,6 +499,8 @@ class LaraLandmarkFn(torch.autograd.Function):
         noise_c = None if noise is None else noise.float().contiguous()
         ps = [t.float().contiguous() for t in params]
         geom = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale), 0)
+        global LAST_LMK_GEOM
+        LAST_LMK_GEOM = (BH, L, C, d, int(has_mlp), int(mixed), 0)
         omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
         qrows = torch.empty_like(omega) if mis != 2 else None
         bhv = torch.empty((B, h, C), dtype=torch.float32, device=dev) if mis == 0 else None
@@ -670,9 +696,9 @@ def performer_attention(qkv5, mask_u8, proj):
 # ------------------------------------------------------------------------------------------
 def _split_k(rows):
     """Slices for the weight-gradient reduction over `rows` tokens: the largest divisor of rows
-    that is <= 128 and leaves >= 512 rows per slice (1 = no split)."""
+    that is <= 64 and leaves >= 512 rows per slice (1 = no split)."""
     best = 1
-    for s in range(2, 129):
+    for s in range(2, 65):
         if rows % s == 0 and rows // s >= 512:
             best = s
     return best

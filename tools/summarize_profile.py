@@ -10,21 +10,26 @@ import json
 import os
 import sys
 
-KERNEL_TO_ENTRY = {
-    "lara_x_kernel<ea::BF16, 64, 4, 0>": "ea_lara_out_fwd", "lara_x_kernel<ea::BF16, 64, 4, 1>": "ea_lara_bwd_q",
-    "lara_x_kernel<ea::BF16, 64, 4, 2>": "ea_lara_bwd_k", "lara_x_kernel<ea::BF16, 64, 4, 3>": "ea_lara_bwd_qcorr",
-    "lara_y_kernel<ea::BF16, 64, 0>": "ea_lara_stats_fwd", "lara_y_kernel<ea::BF16, 64, 1>": "ea_lara_bwd_qstats",
-    "lara_y_kernel<ea::BF16, 64, 2>": "ea_lara_bwd_kstats",
-    "win_fwd_kernel<ea::BF16, 64>": "ea_window_attn_fwd", "win_bwd_kernel<ea::BF16, 64>": "ea_window_attn_bwd",
-    "chunk_mean_fwd_kernel<ea::BF16, 64>": "ea_eva_chunk_mean_fwd", "chunk_mean_bwd_kernel<ea::BF16, 64>": "ea_eva_chunk_mean_bwd",
-    "beta_fwd_kernel<ea::BF16, 64>": "ea_eva_beta_fwd", "beta_bwd_kernel<ea::BF16, 64>": "ea_eva_beta_bwd",
-    "sm_fwd_kernel<ea::BF16, 64>": "ea_softmax_attn_fwd", "sm_bwd_dq_kernel<ea::BF16, 64>": "ea_softmax_attn_bwd(dq)",
-    "sm_bwd_dkv_kernel<ea::BF16, 64>": "ea_softmax_attn_bwd(dkv)",
-}
+# kernel-name substring -> C-ABI entry point (first match wins)
+KERNEL_TO_ENTRY = [
+    ("lara_x_kernel<ea::BF16, 64, 4, 0>", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1>", "ea_lara_bwd_q"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 2>", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3>", "ea_lara_bwd_qcorr"),
+    ("lara_y_kernel<ea::BF16, 64, 0>", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1>", "ea_lara_bwd_qstats"),
+    ("lara_y_kernel<ea::BF16, 64, 2>", "ea_lara_bwd_kstats"),
+    ("lara_lmk_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lara_lmk_kernel<64, true>", "ea_lara_landmarks_bwd"),
+    ("lara_merge_fwd_kernel", "ea_lara_merge_fwd"), ("lara_merge_bwd_kernel", "ea_lara_merge_bwd"),
+    ("win_fwd_kernel<ea::BF16, 64>", "ea_window_attn_fwd"), ("win_bwd_kernel<ea::BF16, 64", "ea_window_attn_bwd"),
+    ("chunk_mean_fwd_kernel<ea::BF16, 64>", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<ea::BF16, 64>", "ea_eva_chunk_mean_bwd"),
+    ("beta_fwd_kernel<ea::BF16, 64>", "ea_eva_beta_fwd"), ("beta_bwd_kernel<ea::BF16, 64>", "ea_eva_beta_bwd"),
+    ("sm_fwd_kernel<ea::BF16, 64>", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dq)"),
+    ("sm_bwd_dkv_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dkv)"),
+    ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
+    ("slice_sum_kernel", "ea_slice_sum"),
+]
 
 
 def entry_of(kname):
-    for k, v in KERNEL_TO_ENTRY.items():
+    for k, v in KERNEL_TO_ENTRY:
         if k in kname:
             return v
     return None
