@@ -22,6 +22,7 @@ namespace ea {
 #define STAMP(i) EA_STAMP(p, i)
 
 constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
+constexpr int LMK_W = LMK_T / 64;
 constexpr int LD = 65;          // row stride (floats) of every LDS matrix
 constexpr int BUF = 64 * LD;
 
@@ -30,39 +31,127 @@ constexpr int BUF = 64 * LD;
 // k-step, A[i = lane&15][k' = lane>>4], B[k' = lane>>4][j = lane&15], D[i = 4*(lane>>4)+r][j = lane&15].
 // The k order inside a dot product is free, so lane group g = lane>>4 takes the contiguous k range
 // [g*steps, (g+1)*steps): with the odd row stride 65 the 64 lanes of every operand read then hit
-// (nearly) distinct banks in all four transpose combinations.  Tiles go round-robin over the waves
-// starting at wave `wofs`, so two products issued back to back in one phase spread over all 16.
+// (nearly) distinct banks in all four transpose combinations.  Tiles go round-robin over the waves.
+struct MMJob {
+  float* C; int ldc;
+  const float* A; int lda;
+  const float* B; int ldb;
+  int M, N, K;
+  float alpha;
+  const float* colbias;
+};
+struct MMOp { float av[16], bv[16]; };
+
+EA_DEV int mm_tiles(const MMJob& j) { return ((j.M + 15) >> 4) * ((j.N + 15) >> 4); }
+
+// operand fetch of one 16x16 tile: every LDS read is issued here, before any MFMA
+template <bool TA, bool TB>
+EA_DEV void mm_load(MMOp& o, const MMJob& j, int tile, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  const int tn = (j.N + 15) >> 4;
+  const int m0 = (tile / tn) << 4, n0 = (tile - (tile / tn) * tn) << 4;
+  const int am = m0 + li, bn = n0 + li;
+  const int steps = (j.K + 3) >> 2, kb = steps * g;
+  // Unconditional loads (am, bn, k < 64 always lie inside the 64 x 65 buffers) and a select on the
+  // k range only: rows am >= M / columns bn >= N may hold anything, they only reach outputs that
+  // mm_store drops.  (Per-load predication costs an exec-mask branch per element.)
+  const int nk = min(steps, j.K - kb);                  // valid k-steps of this lane group
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int k = kb + ks;
+    const float a = TA ? j.A[k * j.lda + am] : j.A[am * j.lda + k];
+    const float b = TB ? j.B[bn * j.ldb + k] : j.B[k * j.ldb + bn];
+    o.av[ks] = ks < nk ? a : 0.f;
+    o.bv[ks] = ks < nk ? b : 0.f;
+  }
+}
+EA_DEV f32x4 mm_chain(const MMOp& o, int K, f32x4 acc) {
+  const int steps = (K + 3) >> 2;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    if (ks < steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[ks], o.bv[ks], acc, 0, 0, 0);
+  return acc;
+}
+template <bool ACC>
+EA_DEV void mm_store(const MMJob& j, int tile, int lane, f32x4 acc) {
+  const int g = lane >> 4, li = lane & 15;
+  const int tn = (j.N + 15) >> 4;
+  const int m0 = (tile / tn) << 4, n0 = (tile - (tile / tn) * tn) << 4;
+  const int bn = n0 + li;
+  if (bn < j.N) {
+    const float cb = j.colbias ? j.colbias[bn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * g + r;
+      if (m < j.M) j.C[m * j.ldc + bn] = (ACC ? j.C[m * j.ldc + bn] + j.alpha * acc[r] : j.alpha * acc[r]) + cb;
+    }
+  }
+}
+
+// C (+)= alpha * A B (+ colbias).  A wave takes its tiles two at a time and fetches the operands of
+// BOTH before the first MFMA, so the second fetch and the two 16-deep MFMA chains overlap instead of
+// running fetch -> chain -> fetch -> chain (the fp32 matrix pipe is the bound of this kernel: a
+// 64x64x64 product is 2048 cycles of it per SIMD).  An odd tile out is paired with a recomputation
+// of the last tile whose store is skipped (keeps the instruction stream branch-free).
 template <bool TA, bool TB, bool ACC>
 EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
-               float alpha, int tid, int wofs = 0, const float* colbias = nullptr) {
-  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
-  const int steps = (K + 3) >> 2, kb = steps * g;
-  for (int tile = (wave - wofs) & 15; tile < tm * tn; tile += LMK_T / 64) {
-    const int m0 = (tile / tn) << 4, n0 = (tile - (tile / tn) * tn) << 4;
-    const int am = m0 + li, bn = n0 + li;
-    const bool a_ok = am < M, b_ok = bn < N;
-    // all LDS operand reads of the tile are issued before the dependent MFMA chain (K <= 64)
-    float av[16], bv[16];
+               float alpha, int tid, const float* colbias = nullptr) {
+  const MMJob j = {C, ldc, A, lda, B, ldb, M, N, K, alpha, colbias};
+  const int lane = tid & 63, wave = tid >> 6;
+  const int nt = mm_tiles(j);
+  if (LMK_W >= 16) {                 // a tile per wave: two accumulation chains (even / odd k-steps)
+    for (int t1 = wave; t1 < nt; t1 += LMK_W) {
+      MMOp o1;
+      mm_load<TA, TB>(o1, j, t1, lane);
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, b1 = a1;
+      const int steps = (K + 3) >> 2;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = kb + ks;
-      const bool k_ok = ks < steps && k < K;
-      av[ks] = (a_ok && k_ok) ? (TA ? A[k * lda + am] : A[am * lda + k]) : 0.f;
-      bv[ks] = (b_ok && k_ok) ? (TB ? B[bn * ldb + k] : B[k * ldb + bn]) : 0.f;
+      for (int ks = 0; ks < 16; ks += 2) {
+        if (ks < steps) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks], o1.bv[ks], a1, 0, 0, 0);
+        if (ks + 1 < steps) b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks + 1], o1.bv[ks + 1], b1, 0, 0, 0);
+      }
+      a1 += b1;
+      mm_store<ACC>(j, t1, lane, a1);
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  for (int t1 = wave; t1 < nt; t1 += 2 * LMK_W) {
+    const int t2 = min(t1 + LMK_W, nt - 1);
+    MMOp o1, o2;
+    mm_load<TA, TB>(o1, j, t1, lane);
+    mm_load<TA, TB>(o2, j, t2, lane);
+    // four independent accumulation chains (two per tile) keep the matrix pipe busy
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
+    const int steps = (K + 3) >> 2;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      if (ks < steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
-    if (b_ok) {
-      const float cb = colbias ? colbias[bn] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * g + r;
-        if (m < M) C[m * ldc + bn] = (ACC ? C[m * ldc + bn] + alpha * acc[r] : alpha * acc[r]) + cb;
+    for (int ks = 0; ks < 16; ks += 2) {
+      if (ks < steps) {
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks], o1.bv[ks], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(o2.av[ks], o2.bv[ks], a2, 0, 0, 0);
+      }
+      if (ks + 1 < steps) {
+        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks + 1], o1.bv[ks + 1], b1, 0, 0, 0);
+        b2 = __builtin_amdgcn_mfma_f32_16x16x4f32(o2.av[ks + 1], o2.bv[ks + 1], b2, 0, 0, 0);
       }
     }
+    a1 += b1;
+    a2 += b2;
+    mm_store<ACC>(j, t1, lane, a1);
+    if (t1 + LMK_W < nt) mm_store<ACC>(j, t2, lane, a2);
+  }
+}
+
+// C += alpha * (A1 B1 + A2 B2): two products with the same shape into one accumulator
+template <bool TA1, bool TB1, bool TA2, bool TB2>
+EA_DEV void mm_sum2(const MMJob& j1, const MMJob& j2, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int tile = wave; tile < mm_tiles(j1); tile += LMK_W) {
+    MMOp o1, o2;
+    mm_load<TA1, TB1>(o1, j1, tile, lane);
+    mm_load<TA2, TB2>(o2, j2, tile, lane);
+    f32x4 acc = mm_chain(o1, j1.K, f32x4{0.f, 0.f, 0.f, 0.f});
+    acc = mm_chain(o2, j2.K, acc);
+    mm_store<true>(j1, tile, lane, acc);
   }
 }
 
@@ -101,8 +190,8 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   // row phases: four lanes (g = 0..3) per row, lane (li, g) owns columns 16g .. 16g+15 of row
   // rrow; waves 0-3 cover 64 rows of one matrix, waves 4-7 those of a second one.
   const int rrow = ((wave & 3) << 4) + li, cbase = g << 4;
-  // column phases: wave w owns columns 4w .. 4w+3, the 16 lanes li stride over the rows
-  const int ccol = (wave << 2) + g;
+  // column phases: wave w owns columns 4w .. 4w+3 (+ 4 LMK_W, ...), the 16 lanes li stride over the rows
+  const int ccol0 = (wave << 2) + g;
 
   // Global -> LDS in two steps: `issue` puts a whole [64][D] matrix per workgroup in flight (one
   // float4 per thread), `commit` writes it to the padded LDS rows.  Everything a phase needs is
@@ -178,9 +267,8 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   __syncthreads();
   STAMP(1);
   if (p.has_mlp) {
-    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
-    mm<false, true, false>(S1, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, 0, pv + 4 * D);     // H = P W^T + b
-    mm<false, true, false>(S2, LD, S4, LD, S5, LD, L, D, D, 1.f, tid, t1, pv + 5 * D);
+    mm<false, true, false>(S1, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, pv + 4 * D);          // H = P W^T + b
+    mm<false, true, false>(S2, LD, S4, LD, S5, LD, L, D, D, 1.f, tid, pv + 5 * D);
     __syncthreads();
     STAMP(2);
     if (wave < 8) {
@@ -245,8 +333,6 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     if (!p.mixed) S6[o] = k0v;
   }
   commit(S4, r_noise, p.dup == 1 ? L : C);                       // S4 (pk staging) is free again
-  // re-issue the Linear operands of the parameter-gradient stage now; they land long before use
-  if (BWD && p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
   __syncthreads();
   STAMP(4);
   if (p.mixed) {
@@ -368,7 +454,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   __syncthreads();
   STAMP(10);
   // ---- B2: column sums of dM; dMU = s dM^T OM; dOM += s dM MU ----
-  {
+  for (int ccol = ccol0; ccol < 64; ccol += 4 * LMK_W) {
     float a = 0.f;
     if (ccol < L)
       for (int r = li; r < C; r += 16) a += S6[r * LD + ccol];
@@ -376,9 +462,8 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     if (li == 0 && ccol < L) dmcol[ccol] = a;
   }
   {
-    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
     mm<true, false, false>(S3, LD, S6, LD, S7, LD, L, D, C, s, tid);             // dMU = s dM^T OM
-    mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid, t1);         // dOM += s dM MU
+    mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid);             // dOM += s dM MU
   }
   __syncthreads();
   STAMP(11);
@@ -396,13 +481,14 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     S6[o] = dm + dqx;
     if (p.mixed) S7[o] = K0(r, j); else S4[o] = dm;
   }
+  // re-issue the Linear operands of the parameter-gradient stage; they land during the mixing backward
+  if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
   __syncthreads();
   STAMP(12);
   // ---- B4..B6: mixing backward.  S4 <- d k0 ----
   if (p.mixed) {
-    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
     mm<true, false, false>(S4, LD, S5, LD, S3, LD, L, D, L, 1.f, tid);          // dK0 = A^T dKb
-    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid, t1);      // dA = dKb K0^T  (MU is dead)
+    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid);          // dA = dKb K0^T  (MU is dead)
     __syncthreads();
     STAMP(13);
     if (wave < 4) {                                                             // dG = A o (dA - rowsum(A o dA)), in S0
@@ -422,9 +508,9 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     }
     __syncthreads();
     STAMP(14);
-    // same tile -> same wave in both calls, so the second accumulation sees the first
-    mm<false, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);            // dK0 += s dG K0
-    mm<true, false, true>(S4, LD, S0, LD, S7, LD, L, D, L, s, tid);             // dK0 += s dG^T K0
+    mm_sum2<false, false, true, false>(                                         // dK0 += s (dG + dG^T) K0
+        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr},
+        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr}, tid);
     __syncthreads();
     STAMP(15);
   }
@@ -442,19 +528,21 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   for (int side = 0; side < 2; ++side) {
     const float* dY = side == 0 ? S6 : S4;
     const float* X = side == 0 ? S1 : S2;
-    float dg = 0.f, db = 0.f;
-    if (ccol < D)
-      for (int r = li; r < L; r += 16) {
-        const float y = dY[r * LD + ccol];
-        dg += y * X[r * LD + ccol];
-        db += y;
+    for (int ccol = ccol0; ccol < 64; ccol += 4 * LMK_W) {
+      float dg = 0.f, db = 0.f;
+      if (ccol < D)
+        for (int r = li; r < L; r += 16) {
+          const float y = dY[r * LD + ccol];
+          dg += y * X[r * LD + ccol];
+          db += y;
+        }
+      dg = group16_sum(dg);
+      db = group16_sum(db);
+      if (li == 0 && ccol < D) {
+        float* dvec = p.dvec_part + ((size_t)bh * 2 + side) * 3 * D;
+        dvec[D + ccol] = dg;
+        dvec[2 * D + ccol] = db;
       }
-    dg = group16_sum(dg);
-    db = group16_sum(db);
-    if (li == 0 && ccol < D) {
-      float* dvec = p.dvec_part + ((size_t)bh * 2 + side) * 3 * D;
-      dvec[D + ccol] = dg;
-      dvec[2 * D + ccol] = db;
     }
   }
   commit(S7, r_wq, D); commit(S0, r_pq, L);
@@ -488,21 +576,21 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   // T3: d bias of the Linear (column sums of dH); dP = dH W and dW = dH^T P straight to global
   for (int side = 0; side < 2; ++side) {
     const float* dY = side == 0 ? S6 : S4;
-    float db = 0.f;
-    if (ccol < D)
-      for (int r = li; r < L; r += 16) db += dY[r * LD + ccol];
-    db = group16_sum(db);
-    if (li == 0 && ccol < D) p.dvec_part[((size_t)bh * 2 + side) * 3 * D + ccol] = db;
+    for (int ccol = ccol0; ccol < 64; ccol += 4 * LMK_W) {
+      float db = 0.f;
+      if (ccol < D)
+        for (int r = li; r < L; r += 16) db += dY[r * LD + ccol];
+      db = group16_sum(db);
+      if (li == 0 && ccol < D) p.dvec_part[((size_t)bh * 2 + side) * 3 * D + ccol] = db;
+    }
   }
   {
-    const int t1 = (((L + 15) >> 4) * ((D + 15) >> 4)) & 15;
-    const int t2 = (((D + 15) >> 4) * ((D + 15) >> 4)) & 15;
     float* dWq = p.dW_part + ((size_t)bh * 2 + 0) * D * D;
     float* dWk = p.dW_part + ((size_t)bh * 2 + 1) * D * D;
     mm<false, false, false>(p.dpq + oL, D, S6, LD, S7, LD, L, D, D, 1.f, tid);
-    mm<false, false, false>(p.dpk + oL, D, S4, LD, S5, LD, L, D, D, 1.f, tid, t1);
-    mm<true, false, false>(dWq, D, S6, LD, S0, LD, D, D, L, 1.f, tid, (2 * t1) & 15);      // dW[out][in]
-    mm<true, false, false>(dWk, D, S4, LD, S3, LD, D, D, L, 1.f, tid, (2 * t1 + t2) & 15);
+    mm<false, false, false>(p.dpk + oL, D, S4, LD, S5, LD, L, D, D, 1.f, tid);
+    mm<true, false, false>(dWq, D, S6, LD, S0, LD, D, D, L, 1.f, tid);                    // dW[out][in]
+    mm<true, false, false>(dWk, D, S4, LD, S3, LD, D, D, L, 1.f, tid);
   }
   STAMP(18);
 }
