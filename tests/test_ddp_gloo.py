@@ -47,19 +47,37 @@ def _build(attn):
     return OracleBacked(attn, CASES[attn], inner)
 
 
-def _worker(rank, world, port, attn, ret):
+def _worker(rank, world, port, attn, ret, flat=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
         model = _build(attn)
-        ddp = torch.nn.parallel.DistributedDataParallel(model)
         torch.manual_seed(123)
         x = torch.randn(4, 14, 14, 64)
         g = torch.randn(4, 14, 14, 64)
         shard = slice(rank * 2, rank * 2 + 2)                     # weak-scaling style batch shard
-        (ddp(x[shard]) * g[shard]).sum().backward()
-        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if flat:
+            # the bench's N > 1 path: one flat gradient bucket, one all-reduce, SGD from the bucket
+            from efficient_attention.data_parallel import FlatGradBucket
+            if rank != 0:                                         # broadcast must repair a diverged replica
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.add_(1.0)
+            bucket = FlatGradBucket(model.parameters())
+            bucket.broadcast_parameters(0)
+            before = [p.detach().clone() for p in model.parameters()]
+            (model(x[shard]) * g[shard]).sum().backward()
+            bucket.pack()
+            bucket.all_reduce()
+            grads = {k: v.clone() for (k, _), v in zip(model.named_parameters(), bucket.averaged_grads())}
+            bucket.sgd_step(0.5)
+            for p, b0, (k, _) in zip(model.parameters(), before, model.named_parameters()):
+                assert torch.allclose(p, b0 - 0.5 * grads[k], rtol=1e-6, atol=1e-7), k
+        else:
+            ddp = torch.nn.parallel.DistributedDataParallel(model)
+            (ddp(x[shard]) * g[shard]).sum().backward()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters()}
         if rank == 0:
             ref = _build(attn)
             (ref(x) * g).sum().backward()
@@ -74,13 +92,24 @@ def _worker(rank, world, port, attn, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("attn", list(CASES))
-def test_two_rank_gloo_ddp_matches_full_batch(attn):
+def _run(attn, flat):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, attn, ret), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, attn, ret, flat), nprocs=2, join=True)
         assert ret["worst"] < 1e-4, dict(ret)
+
+
+@pytest.mark.parametrize("attn", list(CASES))
+def test_two_rank_gloo_ddp_matches_full_batch(attn):
+    _run(attn, False)
+
+
+@pytest.mark.parametrize("attn", list(CASES))
+def test_two_rank_gloo_flat_bucket_matches_full_batch(attn):
+    """bench.py's N > 1 path (FlatGradBucket): parameter broadcast, one all-reduce of all gradients,
+    averaged gradients == full-batch gradients, SGD step applied from the bucket."""
+    _run(attn, True)
