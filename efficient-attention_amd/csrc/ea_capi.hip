@@ -473,7 +473,7 @@ int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk
                           const float* Wq, const float* bq, const float* gq, const float* cq,
                           const float* Wk, const float* bk, const float* gk, const float* ck,
                           const float* noise, float* omega, float* qbar_rows, float* bhv, float* lp,
-                          void* stream) {
+                          float* saved, void* stream) {
   LmkP p = {};
   int rc = fill_lmk(g, p);
   if (rc != EA_OK) return rc;
@@ -484,7 +484,14 @@ int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk
   if (g->dup != 0 && !noise) return EA_E_BADARG;
   p.pq = pq; p.pk = pk; LMK_PARAMS(p)
   p.noise = noise; p.omega = omega; p.qbar_rows = qbar_rows; p.bhv = bhv; p.lp = lp;
+  p.saved = saved;
   return lara_lmk_dispatch(false, p, (hipStream_t)stream);
+}
+
+int64_t ea_lara_landmarks_saved_floats(const ea_lmk_geom* g) {
+  LmkP p = {};
+  if (fill_lmk(g, p) != EA_OK) return EA_E_BADARG;
+  return (int64_t)g->BH * (int64_t)lara_lmk_saved_per_bh(g->L, g->D);
 }
 
 int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk,
@@ -492,7 +499,7 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
                           const float* Wk, const float* bk, const float* gk, const float* ck,
                           const float* noise, const float* d_omega, const float* d_qbar_rows,
                           const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
-                          float* dW_part, float* dvec_part, void* stream) {
+                          float* dW_part, float* dvec_part, const float* saved, void* stream) {
   LmkP p = {};
   int rc = fill_lmk(g, p);
   if (rc != EA_OK) return rc;
@@ -504,6 +511,7 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
   p.pq = pq; p.pk = pk; LMK_PARAMS(p)
   p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
   p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
+  p.saved = const_cast<float*>(saved);
   return lara_lmk_dispatch(true, p, (hipStream_t)stream);
 }
 

@@ -196,15 +196,26 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   // Global -> LDS in two steps: `issue` puts a whole [64][D] matrix per workgroup in flight (one
   // float4 per thread), `commit` writes it to the padded LDS rows.  Everything a phase needs is
   // issued long before, so the workgroup pays one exposed memory round trip (the first).
-  constexpr int NSLOT = (64 * D / 4 + LMK_T - 1) / LMK_T;
+  constexpr int NSLOT = (64 * 64 / 4 + LMK_T - 1) / LMK_T;      // sized for 64 columns (the mixing matrix)
   struct Pre { float4 v[NSLOT]; };
-  auto issue = [&](Pre& b, const float* src, int rows) {
+  auto issue_n = [&](Pre& b, const float* src, int rows, int cols) {
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const int e = (tid + i * LMK_T) * 4;
-      b.v[i] = (src && e < rows * D) ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b.v[i] = (src && e < rows * cols) ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  auto commit_n = [&](float* dst, const Pre& a, int rows, int cols) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int e = (tid + i * LMK_T) * 4;
+      if (e < rows * cols) {
+        float* d = dst + (e / cols) * LD + (e % cols);
+        d[0] = a.v[i].x; d[1] = a.v[i].y; d[2] = a.v[i].z; d[3] = a.v[i].w;
+      }
+    }
+  };
+  auto issue = [&](Pre& b, const float* src, int rows) { issue_n(b, src, rows, D); };
   // dst = sa * a + sb * b
   auto commit2 = [&](float* dst, const Pre& a, float sa, const Pre& b, float sb, int rows) {
 #pragma unroll
@@ -227,10 +238,25 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       }
     }
   };
+  // forward intermediates kept for the backward (LmkP::saved): Xq, Xk, MU [L][D], A [L][64], 1/std
+  float* sv = p.saved ? p.saved + (size_t)bh * lara_lmk_saved_per_bh(L, D) : nullptr;
+  float* sv_xq = sv, *sv_xk = sv + L * D, *sv_mu = sv + 2 * L * D, *sv_a = sv + 3 * L * D;
+  float* sv_rstd = sv + 3 * L * D + L * 64;
+  const bool reload = BWD && sv != nullptr;             // backward that skips the forward recomputation
   Pre r_pq, r_pk, r_wq, r_wk, r_noise, r_dom, r_dqr;
-  issue(r_pq, p.pq + oL, L);
-  issue(r_pk, p.pk + oL, L);
-  if (p.has_mlp) { issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
+  if (reload) {
+    issue(r_pq, p.has_mlp ? sv_xq : p.pq + oL, L);      // normalised rows (or q_bar / k_bar themselves)
+    issue(r_pk, p.has_mlp ? sv_xk : p.pk + oL, L);
+    if (!p.eva) {
+      issue(r_wq, sv_mu, L);
+      issue_n(r_wk, p.mixed ? sv_a : nullptr, L, 64);
+    }
+    if (tid < 128) rstd_q[tid] = sv_rstd[tid];          // rstd_q, rstd_k are adjacent
+  } else {
+    issue(r_pq, p.pq + oL, L);
+    issue(r_pk, p.pk + oL, L);
+    if (p.has_mlp) { issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
+  }
   {
     const float* nsrc = p.noise ? (p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC) : nullptr;
     issue(r_noise, nsrc, p.dup == 1 ? L : C);
@@ -257,7 +283,14 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   // =========================== forward (recomputed in backward) ===========================
   STAMP(0);
   // ---- F1/F2/F3: Linear + LayerNorm of the pooled rows, both sides at once ----
-  if (p.has_mlp) {
+  if (reload) {
+    commit(S1, r_pq, L); commit(S2, r_pk, L);
+    if (!p.eva) {
+      commit(S0, r_wq, L);                                       // MU
+      if (p.mixed) commit_n(S5, r_wk, L, 64);                    // A
+      commit(S4, r_noise, p.dup == 1 ? L : C);
+    }
+  } else if (p.has_mlp) {
     commit(S3, r_pq, L); commit(S7, r_wq, D);                    // W [out][in]
     commit(S4, r_pk, L); commit(S5, r_wk, D);
   } else {
@@ -266,7 +299,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   if (BWD && !p.eva) commit(S8, r_dqr, C);
   __syncthreads();
   STAMP(1);
-  if (p.has_mlp) {
+  if (p.has_mlp && !reload) {
     mm<false, true, false>(S1, LD, S3, LD, S7, LD, L, D, D, 1.f, tid, pv + 4 * D);          // H = P W^T + b
     mm<false, true, false>(S2, LD, S4, LD, S5, LD, L, D, D, 1.f, tid, pv + 5 * D);
     __syncthreads();
@@ -318,6 +351,13 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
           *reinterpret_cast<float4*>(p.omega + oC + e) = om;
         }
       }
+      if (sv) {
+        for (int idx = tid; idx < L * D; idx += LMK_T) {
+          const int o = (idx / D) * LD + (idx % D);
+          sv_xq[idx] = S1[o]; sv_xk[idx] = S2[o];
+        }
+        if (tid < 128) sv_rstd[tid] = rstd_q[tid];
+      }
       return;
     }
     commit2(S6, r_dom, 0.5f, r_dom, 0.f, L);                                // d rf_q_bar = d omega / 2
@@ -326,6 +366,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     __syncthreads();
   } else {
   // ---- F4..F7: mixing  A = softmax(s k0 k0^T), k_bar = A k0  (S6 = k_bar) ----
+  if (!reload) {
   for (int idx = tid; idx < L * D; idx += LMK_T) {
     const int o = (idx / D) * LD + (idx % D);
     const float k0v = K0(idx / D, idx % D);
@@ -362,10 +403,11 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     __syncthreads();
     STAMP(7);
   }
-  // ---- F8: mu and the sample rows omega ----
+  }   // !reload
+  // ---- F8: mu (unless reloaded) and the sample rows omega ----
   for (int idx = tid; idx < L * D; idx += LMK_T) {
     const int r = idx / D, j = idx % D;
-    const float mu = QB(r, j) + S6[r * LD + j];
+    const float mu = reload ? S0[r * LD + j] : QB(r, j) + S6[r * LD + j];
     S0[r * LD + j] = mu;
     for (int k = 0; k < nrep; ++k) {
       const int c = r + k * L;
@@ -394,6 +436,16 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       p.omega[oC + idx] = S7[c * LD + j];
       if (p.mis == 0) p.qbar_rows[oC + idx] = QB(l, j);
       else if (p.mis == 1) p.qbar_rows[oC + idx] = S0[l * LD + j];
+    }
+    if (sv) {                                                       // keep the intermediates for the backward
+      for (int idx = tid; idx < L * D; idx += LMK_T) {
+        const int o = (idx / D) * LD + (idx % D);
+        if (p.has_mlp) { sv_xq[idx] = S1[o]; sv_xk[idx] = S2[o]; }
+        sv_mu[idx] = S0[o];
+      }
+      if (p.mixed)
+        for (int idx = tid; idx < L * 64; idx += LMK_T) sv_a[idx] = S5[(idx >> 6) * LD + (idx & 63)];
+      if (tid < 128) sv_rstd[tid] = rstd_q[tid];
     }
   }
   __syncthreads();

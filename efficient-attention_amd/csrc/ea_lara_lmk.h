@@ -15,9 +15,12 @@ struct LmkP {
   int has_mlp, mixed, mis, dup;
   int eva;                                                // EVA's mu pipeline (eva.py:178-190) instead of LARA's
   float scale;
+  float* saved;                                           // forward intermediates (fwd writes, bwd reads), or null
   long long* prof;                                        // dev builds (-DEA_PROFILE): phase time stamps
 };
 
 int lara_lmk_dispatch(bool bwd, const LmkP& p, hipStream_t st);
+// per-(b,h) floats of LmkP::saved: Xq, Xk, MU [L][D], A [L][64], rstd_q, rstd_k [64]
+__host__ __device__ inline size_t lara_lmk_saved_per_bh(int L, int D) { return (size_t)3 * L * D + (size_t)L * 64 + 128; }
 
 }  // namespace ea

@@ -64,8 +64,9 @@ SIGNATURES = {
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
     "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P],
-    "ea_lara_landmarks_fwd": [_MG] + [_P] * 16,
-    "ea_lara_landmarks_bwd": [_MG] + [_P] * 20,
+    "ea_lara_landmarks_fwd": [_MG] + [_P] * 17,
+    "ea_lara_landmarks_bwd": [_MG] + [_P] * 21,
+    "ea_lara_landmarks_saved_floats": [_MG],
     "ea_lara_merge_fwd": [_I] * 5 + [_P] * 8,
     "ea_lara_merge_bwd": [_I] * 5 + [_F] + [_P] * 16,
     "ea_bias_grad_parts": [_I, _I],
@@ -111,6 +112,7 @@ def lib():
             fn = getattr(cdll, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        cdll.ea_lara_landmarks_saved_floats.restype = ctypes.c_int64
         cdll.ea_version.restype = ctypes.c_char_p
         cdll.ea_abi_version.restype = ctypes.c_int32
         _lib = cdll

@@ -221,10 +221,11 @@ class EvaAttnFn(torch.autograd.Function):
             noise_c = None if noise is None else noise.float().contiguous()
             omega = torch.empty_like(qmean)
             rf_k_bar = torch.empty_like(qmean)
+            saved = _lmk_saved(lg, qmean.device) if any(ctx.needs_input_grad) else None
             nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
                     *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(omega), nv.ptr(rf_k_bar), None, None,
-                    nv.stream())
-            ctx.lmk = (lg, noise_c)
+                    nv.ptr(saved), nv.stream())
+            ctx.lmk = (lg, noise_c, saved)
         else:
             # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
             with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
@@ -261,7 +262,7 @@ class EvaAttnFn(torch.autograd.Function):
                 nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
                 ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
         if ctx.lmk is not None:
-            lg, noise_c = ctx.lmk
+            lg, noise_c, saved = ctx.lmk
             L_, d_ = lg.L, lg.D
             ps = [p.float().contiguous() for p in mlp_params]
             dqm = torch.empty_like(qmean)
@@ -270,7 +271,7 @@ class EvaAttnFn(torch.autograd.Function):
             dvec = torch.empty((lg.BH, 2, 3, d_), dtype=torch.float32, device=qmean.device)
             nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
                     *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(d_omega), nv.ptr(d_rfk.contiguous()),
-                    None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.stream())
+                    None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
             nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
                     nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
             dWs = colsum_f32(dW.view(lg.BH, -1)).view(2, d_, d_)
@@ -482,6 +483,14 @@ class LaraAttnFn(torch.autograd.Function):
                 d_lp, None, None, None)
 
 
+def _lmk_saved(geom, device):
+    """Workspace in which ea_lara_landmarks_fwd keeps its intermediates for the backward."""
+    n = nv.lib().ea_lara_landmarks_saved_floats(ctypes.byref(geom))
+    if n < 0:
+        raise RuntimeError("ea_lara_landmarks_saved_floats: %d" % n)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 class LaraLandmarkFn(torch.autograd.Function):
     """Fused landmark pipeline (ea_lara_landmarks_fwd/bwd): pooled q/k [B,h,L,d] (or ready q_bar/k_bar
     when has_mlp = mixed = 0) -> omega, qbar_rows [B,h,C,d], bhv, lp [B,h,C].  params = (Wq, bq,
@@ -506,9 +515,11 @@ class LaraLandmarkFn(torch.autograd.Function):
         bhv = torch.empty((B, h, C), dtype=torch.float32, device=dev) if mis == 0 else None
         lp = torch.empty((B, h, C), dtype=torch.float32, device=dev)
         pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+        saved = _lmk_saved(geom, dev) if any(ctx.needs_input_grad) else None
         nv.call("ea_lara_landmarks_fwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.stream())
+                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
         ctx.save_for_backward(pq, pk, noise_c, *ps)
+        ctx.lmk_saved = saved
         ctx.geom = geom
         ctx.pdtypes = [t.dtype for t in params]
         return omega, qrows, bhv, lp
@@ -536,7 +547,7 @@ class LaraLandmarkFn(torch.autograd.Function):
         pp = [nv.ptr(t) for t in ps] if geom.has_mlp else [None] * 8
         nv.call("ea_lara_landmarks_bwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
                 nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
-                nv.ptr(dW), nv.ptr(dvec), nv.stream())
+                nv.ptr(dW), nv.ptr(dvec), nv.ptr(ctx.lmk_saved), nv.stream())
         pgrads = []
         if geom.has_mlp:
             dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)

@@ -232,7 +232,11 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
  * Outputs omega, qbar_rows [BH,C,D], bhv, lp [BH,C] feed ea_lara_*.  The backward takes their
  * gradients and returns d pq, d pk [BH,L,D] plus per-(b,h) partial parameter gradients
  * dW_part [BH,2,D,D] (q then k; [out][in]) and dvec_part [BH,2,3,D] (Linear bias, LN weight, LN
- * bias) which the caller sums over BH.  L, C <= 64. */
+ * bias) which the caller sums over BH.  L, C <= 64.
+ * `saved` (optional, may be NULL in both calls): workspace of ea_lara_landmarks_saved_floats(g)
+ * floats in which the forward keeps its intermediates (normalised rows, LayerNorm 1/std, mixing
+ * matrix, mu); a backward that is handed the same buffer reloads them instead of recomputing the
+ * forward (four of its fourteen matrix products). */
 typedef struct {
   int32_t BH, L, C, D;
   int32_t has_mlp, mixed, mis, dup;
@@ -245,13 +249,14 @@ int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk
                           const float* Wq, const float* bq, const float* gq, const float* cq,
                           const float* Wk, const float* bk, const float* gk, const float* ck,
                           const float* noise, float* omega, float* qbar_rows, float* bhv, float* lp,
-                          void* stream);
+                          float* saved, void* stream);
+int64_t ea_lara_landmarks_saved_floats(const ea_lmk_geom* g);
 int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk,
                           const float* Wq, const float* bq, const float* gq, const float* cq,
                           const float* Wk, const float* bk, const float* gk, const float* ck,
                           const float* noise, const float* d_omega, const float* d_qbar_rows,
                           const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
-                          float* dW_part, float* dvec_part, void* stream);
+                          float* dW_part, float* dvec_part, const float* saved, void* stream);
 
 /* ---- LARA: merging the sequence slices of the token-row passes (tiny, one workgroup per (b,h)) ----
  * merge_fwd: (p_ml, p_kv of ea_lara_stats_fwd over S slices, lp) -> kv_stats [BH,C,D], lse_k,
