@@ -119,3 +119,39 @@ def test_value_bias_gradient_counts_tokens(attn):
     # q / k receive (numerically) no gradient: the output does not depend on the attention weights
     gq = m.qkv.bias.grad[:2 * C].float().abs().max().item()
     assert gq <= 2e-2 * n, gq
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", VARIANTS)
+def test_full_batch_slice_matches_oracle(attn):
+    """Forward and input gradient of two batch elements inside the full B = 128 launch (the launch
+    geometry of the benchmark: two sequence slices per (b,h), uneven backward slices, one resident
+    round of workgroups) against the CPU oracle run on just those two elements."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import oracle
+    from gpu_checks import MODULE_TOL, LARA_TOL
+    from util import scaled_err
+    torch.manual_seed(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = bench.build_layer(attn, C, H, G, "cuda")
+    m.eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    x = _x().requires_grad_(True)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    gy = torch.randn(B, G, G, C, device="cuda", generator=gen)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    (y.float() * gy).sum().backward()
+    sl = slice(40, 42)
+    params = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    xr = x.detach()[sl].cpu().requires_grad_(True)
+    ref = oracle.module_forward(attn, bench.attn_args(attn, C, H, G), params, xr, None, training=False)
+    (ref * gy[sl].cpu()).sum().backward()
+    tol = LARA_TOL if attn == "lara" else MODULE_TOL
+    for name, got, want in (("y", y.detach().float()[sl].cpu(), ref.detach()), ("dx", x.grad[sl].cpu(), xr.grad)):
+        e = scaled_err(got.numpy(), want.numpy())
+        assert e[0] <= tol[0] and e[1] <= tol[1], (attn, name, e)
