@@ -56,9 +56,9 @@ int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
   return window_bwd_lds(t, g->D, true, true) <= 160 * 1024 ? 0 : 1;
 }
 
-static int fill_win(const ea_geom* g, WinP& p) {
+static int fill_win(const ea_geom* g, WinP& p, bool backward) {
   if (!geom_ok(g)) return EA_E_BADARG;
-  int rc = win_tiling(*g, p.t, false);
+  int rc = win_tiling(*g, p.t, backward);
   if (rc != EA_OK) return rc;
   if (g->L < 0 || g->L > 64) return EA_E_UNSUPPORTED;      // landmark tiles owned 1:1 by 4 waves
   p.G = mk_geo(g);
@@ -72,7 +72,7 @@ int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
                        const ea_t4* out, float* lse, void* stream) {
   WinP p = {};
-  int rc = fill_win(g, p);
+  int rc = fill_win(g, p, false);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(out, g->D) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv)) return EA_E_BADARG;
@@ -88,7 +88,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        float* dlk_part, float* dlv_part, float* dbias_part,
                        float* dk_acc, float* dv_acc, const float* bias_t, void* stream) {
   WinP p = {};
-  int rc = fill_win(g, p);
+  int rc = fill_win(g, p, true);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dout, g->D) ||
       !t4_ok(out, g->D) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !lse) return EA_E_BADARG;

@@ -23,6 +23,20 @@ struct WinTiling {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// CUs of the current device (cached; 256 = MI355X when no device is visible, e.g. build checks)
+inline int device_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = 256;
+  }
+  return n;
+}
+
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
   const int w = g.window, e = g.ext;
@@ -44,18 +58,29 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
   if (t.wpi > t.nwin) t.wpi = t.nwin;
   t.niter = ceil_div(t.nwin, t.wpi);
-  // enough blocks to fill 256 CUs several times over, while each block keeps the landmark rows
-  // (and, in backward, its landmark-gradient accumulators) resident across its iterations
+  // Workgroups per (b,h).  A workgroup pays a fixed prologue (landmark rows, bias table, slot tables:
+  // ~0.4 window-iterations, measured) and keeps the landmark rows -- in backward also its landmark-
+  // gradient accumulators -- resident across its windows, so fewer workgroups are cheaper; but the
+  // launch runs in rounds of (CUs x resident workgroups per CU), and a partly filled last round
+  // idles the chip (B*h = 384, 6 workgroups each: 4.5 rounds on 512 slots -> 5).  Pick the count
+  // that minimises rounds x (windows per workgroup + prologue).
   const long bh = (long)g.B * g.H;
-  int nblk = (int)((2048 + bh - 1) / bh);
-  if (nblk < 1) nblk = 1;
-  if (nblk > t.niter) nblk = t.niter;
+  const long slots = (long)device_cu_count() * (backward ? 2 : 4);     // resident workgroups (launch bounds / LDS)
+  int best = 1;
+  double best_cost = 1e30;
+  for (int nb = 1; nb <= t.niter; ++nb) {
+    const int ipb = ceil_div(t.niter, nb);
+    if (ceil_div(t.niter, ipb) != nb) continue;                        // same schedule as a smaller count
+    const long rounds = (bh * nb + slots - 1) / slots;
+    const double cost = (double)rounds * (ipb + 0.4);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
+  }
+  int nblk = best;
   t.ipb = ceil_div(t.niter, nblk);
   t.nblk = ceil_div(t.niter, t.ipb);
   t.rowsLocal = t.wpi * t.nLT * 16;
   t.rowsLm = t.nCT * 16;
   t.rowsTotal = t.rowsLocal + t.rowsLm + 16;
-  (void)backward;
   return EA_OK;
 }
 
