@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   int* qd = kd + t.nLT * 16;
   const int rowsPerWin = t.nLT * 16;
 
+  constexpr bool PHASE_A_GLOBAL_BIAS = GB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   LaneOff<D> lo;
   lo.init(lane);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);                                  // log2-domain bias
-          if (GB) {
+          if (PHASE_A_GLOBAL_BIAS) {
             if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
           } else {
             const float* bs = brow_s + (local ? tile : 0) * btm;
