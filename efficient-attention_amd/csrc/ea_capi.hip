@@ -25,6 +25,10 @@ static bool t4_ok(const ea_t4* t, int D) {
   return t && t->ptr && ((uintptr_t)t->ptr % 16 == 0) && t->sb % 8 == 0 && t->sh % 8 == 0 &&
          t->sn % 8 == 0 && t->sn >= D;
 }
+// kernels that form token * stride in 32-bit arithmetic additionally need N * sn < 2^31 elements
+static bool t4_ok32(const ea_t4* t, int D, int N) {
+  return t4_ok(t, D) && (int64_t)N * t->sn < ((int64_t)1 << 31);
+}
 static bool geom_ok(const ea_geom* g) {
   return g && g->B > 0 && g->H > 0 && g->N > 0 && (g->D == 32 || g->D == 64 || g->D == 128) &&
          (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0;
@@ -90,8 +94,10 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
   WinP p = {};
   int rc = fill_win(g, p, true);
   if (rc != EA_OK) return rc;
-  if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dout, g->D) ||
-      !t4_ok(out, g->D) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok(dq, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !lse) return EA_E_BADARG;
+  const int N = g->N;
+  if (!t4_ok32(q, g->D, N) || !t4_ok32(k, g->D, N) || !t4_ok32(v, g->D, N) || !t4_ok32(dout, g->D, N) ||
+      !t4_ok32(out, g->D, N) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||
+      !t4_ok32(dk, g->D, N) || !t4_ok32(dv, g->D, N) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
   if (bias && (!dbias_part || (!bias_t && ea_window_bwd_needs_bias_t(g) != 0))) return EA_E_BADARG;
   p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(dout);

@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   char* dvb = p.dv.p + (b * p.dv.sb + h * p.dv.sh) * 2;
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
   const float* lse_g = p.lse + (size_t)bh * p.G.N;
+  // token strides as 32-bit element counts (N * stride < 2^31 is checked on the host): the per-row
+  // address arithmetic stays in 32-bit VALU ops and the 64-bit strides free their SGPR pairs
+  const int ksn = (int)p.k.sn, vsn = (int)p.v.sn, qsn = (int)p.q.sn, dosn = (int)p.o.sn, osn = (int)outp.sn;
+  const int dqsn = (int)p.dq.sn, dksn = (int)p.dk.sn, dvsn = (int)p.dv.sn;
 
   EA_STAMP(p, 0);
   EA_BLK(p, 0);
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             const int tok = slot_token(p.G, kd[slot], oy, ox);
             x.addv[i] = MASK_FILL * LOG2E;
             if (tok >= 0) {
-              x.kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
-              x.vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
+              x.kr[i] = ldg16(kb + (tok * ksn + c * 8) * 2);
+              x.vr[i] = ldg16(vb + (tok * vsn + c * 8) * 2);
               if (!(mrow && mrow[tok])) { x.mulv[i] = 1.f; x.addv[i] = 0.f; }
             }
           }
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           }
           x.rowv[i] = row;
           if (tok >= 0) {
-            x.qr[i] = ldg16(qb + (tok * p.q.sn + c * 8) * 2);
-            x.dr[i] = ldg16(dob + (tok * p.o.sn + c * 8) * 2);
-            x.orr[i] = ldg16(ob + (tok * outp.sn + c * 8) * 2);
+            x.qr[i] = ldg16(qb + (tok * qsn + c * 8) * 2);
+            x.dr[i] = ldg16(dob + (tok * dosn + c * 8) * 2);
+            x.orr[i] = ldg16(ob + (tok * osn + c * 8) * 2);
             if (c == 0) x.lsv[i] = lse_g[tok] * LOG2E;
           }
         }
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[dt][r] * p.scale;
-        char* dst = dqb + (qtok * p.dq.sn + DQ * g) * 2;
+        char* dst = dqb + (qtok * dqsn + DQ * g) * 2;
 #pragma unroll
         for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
       }
@@ -455,8 +459,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
           if (p.e == 0) {
-            char* d1 = dkb + (tok * p.dk.sn + DQ * g) * 2;
-            char* d2 = dvb + (tok * p.dv.sn + DQ * g) * 2;
+            char* d1 = dkb + (tok * dksn + DQ * g) * 2;
+            char* d2 = dvb + (tok * dvsn + DQ * g) * 2;
 #pragma unroll
             for (int c = 0; c < DQ / 8; ++c) {
               stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
