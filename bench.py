@@ -37,24 +37,37 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv) at d=64, bf16
 
 
-def attn_args(attn, dim, heads, grid):
+def attn_args(attn, dim, heads, seq):
+    """seq: (side, side) for the vit recipes (cfg2 / cfg3), (N,) for the fairseq-style 1-D ones (cfg5)."""
     base = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0)
+    two_d = len(seq) == 2
     if attn == "eva":
-        base.update(window_size=7, attn_2d=True, use_rpe=True, num_landmarks=49, adaptive_proj="default")
+        if two_d:
+            base.update(window_size=7, attn_2d=True, use_rpe=True, num_landmarks=49, adaptive_proj="default")
+        else:
+            base.update(window_size=16, attn_2d=False, use_t5_rpe=True, overlap_window=True, num_landmarks=8,
+                        adaptive_proj="default")
     elif attn == "local":
-        base.update(window_size=7, attn_2d=True, use_rpe=True)
+        base.update(window_size=7 if two_d else 16, attn_2d=two_d, use_rpe=True)
     elif attn == "lara":
-        base.update(num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)
+        if two_d:
+            base.update(num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)
+        else:
+            base.update(num_landmarks=49, proposal_gen="adaptive-1d", mis_type="mis-opt")
     elif attn == "performer":
         base.update(approx_attn_dim=64, proj_method="favorp")
     return base
+
+
+def _seq(grid):
+    return tuple(grid) if isinstance(grid, (tuple, list)) else (grid, grid)
 
 
 def build_layer(attn, dim, heads, grid, device):
     import efficient_attention as ea
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, grid)).to(device)
+        return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, _seq(grid))).to(device)
 
 
 def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
@@ -66,9 +79,10 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
     B = 8
     layer = build_layer(attn, dim, heads, grid, "cpu")
     params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
-    args = attn_args(attn, dim, heads, grid)
-    x = torch.randn(B, grid, grid, dim, requires_grad=True)
-    g = torch.randn(B, grid, grid, dim)
+    seq = _seq(grid)
+    args = attn_args(attn, dim, heads, seq)
+    x = torch.randn(B, *seq, dim, requires_grad=True)
+    g = torch.randn(B, *seq, dim)
     noise_fn = lambda shape: torch.randn(*shape)  # noqa: E731
 
     def step():
@@ -100,6 +114,9 @@ def main():
     ap.add_argument("--grid", type=int, default=28, help="token grid side (28 -> N=784)")
     ap.add_argument("--dim", type=int, default=192)
     ap.add_argument("--heads", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"],
+                    help="cfg3 (default, the metric's config): [128,28,28,192] h=3; cfg2: [128,14,14,192] h=3; "
+                         "cfg5: 1-D [16,4096,512] h=8 (BASELINE.json configs / SURVEY.md 8d)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tune", action="store_true",
@@ -130,15 +147,24 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
 
-    B, G, C, H = a.batch, a.grid, a.dim, a.heads
-    N, d = G * G, a.dim // a.heads
+    B, C, H = a.batch, a.dim, a.heads
+    seq = (a.grid, a.grid)
+    if a.workload == "cfg2":
+        seq = (14, 14)
+    elif a.workload == "cfg5":
+        B, C, H, seq = (16 if a.batch == 128 else a.batch), 512, 8, (4096,)
+    G = seq
+    N = 1
+    for s_ in seq:
+        N *= s_
+    d = C // H
     layer = build_layer(a.attn, C, H, G, dev)
     layer.train()
     model = layer
     LR = 1e-3
     opt = torch.optim.SGD(layer.parameters(), lr=LR)
-    x = torch.randn(B, G, G, C, device=dev, requires_grad=True)
-    g = torch.randn(B, G, G, C, device=dev).to(torch.bfloat16)     # cotangent of y, in y's dtype
+    x = torch.randn(B, *seq, C, device=dev, requires_grad=True)
+    g = torch.randn(B, *seq, C, device=dev).to(torch.bfloat16)     # cotangent of y, in y's dtype
 
     from efficient_attention import _ops
 
@@ -300,8 +326,9 @@ def main():
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s attention layer fwd+bwd+SGD, x=[%d,%d,%d,%d] per GPU (N=%d, h=%d, d=%d), "
-                                   "bf16 autocast%s" % (a.attn, B, G, G, C, N, H, d, ", data-parallel flat-bucket all-reduce" if ddp else ""),
+            "config": {"workload": "%s attention layer fwd+bwd+SGD, x=[%s] per GPU (N=%d, h=%d, d=%d), "
+                                   "bf16 autocast%s" % (a.attn, ",".join(str(v) for v in (B,) + tuple(seq) + (C,)), N, H, d,
+                                                        ", data-parallel flat-bucket all-reduce" if ddp else ""),
                        "attn": a.attn, "global_batch": B * world, "seq_len": N, "heads": H, "head_dim": d,
                        "parallelism": "dp%d" % world, "hipgraph": graphed,
                        "gemm_tunableop": tune},

@@ -55,7 +55,10 @@ class T5RelativePositionBias(nn.Module):
             rel = torch.arange(j).view(1, j) - torch.arange(i).view(i, 1)
             cache[key] = self._relative_position_bucket(
                 rel, causal=self.causal, num_buckets=self.num_buckets, max_distance=self.max_distance)
-        return cache[key].to(device)
+        dkey = (i, j, str(device))                      # device copy cached too: an H2D copy from pageable
+        if dkey not in cache:                           # memory per forward would also break hipGraph capture
+            cache[dkey] = cache[key].to(device)
+        return cache[dkey]
 
     def dense(self, i, j, device):
         """[h, i, j] bias, already multiplied by scale."""
