@@ -40,6 +40,7 @@ BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv)
 def attn_args(attn, dim, heads, seq):
     """seq: (side, side) for the vit recipes (cfg2 / cfg3), (N,) for the fairseq-style 1-D ones (cfg5)."""
     base = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0)
+    seq = _seq(seq)
     two_d = len(seq) == 2
     if attn == "eva":
         if two_d:

@@ -52,7 +52,7 @@ int32_t ea_window_bias_ld(const ea_geom* g) {
 int32_t ea_window_bwd_parts(const ea_geom* g) {
   WinTiling t;
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
-  return t.nblk;
+  return t.parts_total;
 }
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
   WinTiling t;

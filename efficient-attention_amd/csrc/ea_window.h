@@ -19,6 +19,14 @@ struct WinTiling {
   int ipb;             // iterations per block
   int biasLd;          // nLT * 16
   int rowsLocal, rowsLm, rowsTotal;
+  // Backward with overlapping windows (ext > 0): a token is a key of several windows, so dk/dv
+  // accumulate.  The windows are split into colour classes (every ncx-th window per axis) such that
+  // no two windows of one class share a key; one launch per class, plain read-modify-write inside.
+  int ncx, ncy;        // colour classes per axis (1 without overlap); classes = ncx * ncy
+  int col_x, col_y;    // class of this launch
+  int sub_x;           // windows per row of this class (2-D)
+  int blk0;            // offset of this launch's workgroups in the *_part buffers
+  int parts_total;     // workgroups per (b,h) summed over the classes (leading dim of *_part)
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -35,6 +43,46 @@ inline int device_cu_count() {
       n = 256;
   }
   return n;
+}
+
+// Workgroups per (b,h) for t.niter iterations.  A workgroup pays a fixed prologue (landmark rows,
+// bias table, slot tables: ~0.4 window-iterations, measured) and keeps the landmark rows -- in
+// backward also its landmark-gradient accumulators -- resident across its windows, so fewer
+// workgroups are cheaper; but the launch runs in rounds of (CUs x resident workgroups per CU), and a
+// partly filled last round idles the chip (B*h = 384, 6 workgroups each: 4.5 rounds on 512 slots
+// -> 5).  Pick the count that minimises rounds x (windows per workgroup + prologue).
+inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
+  const long bh = (long)g.B * g.H;
+  const long slots = (long)device_cu_count() * (backward ? 2 : 4);     // resident workgroups (launch bounds / LDS)
+  int best = 1;
+  double best_cost = 1e30;
+  for (int nb = 1; nb <= t.niter; ++nb) {
+    const int ipb = ceil_div(t.niter, nb);
+    if (ceil_div(t.niter, ipb) != nb) continue;                        // same schedule as a smaller count
+    const long rounds = (bh * nb + slots - 1) / slots;
+    const double cost = (double)rounds * (ipb + 0.4);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
+  }
+  t.ipb = ceil_div(t.niter, best);
+  t.nblk = ceil_div(t.niter, t.ipb);
+}
+
+// Restrict a backward tiling to colour class (cy, cx): nwin / niter / nblk of that class.
+// Returns false when the class is empty.
+inline bool win_colour(const ea_geom& g, WinTiling& t, int cy, int cx) {
+  const int w = g.window;
+  const int WX = g.attn_2d ? g.gw / w : ceil_div(g.N, w), WY = g.attn_2d ? g.gh / w : 1;
+  if (cx >= WX || cy >= WY) return false;
+  const int sx = ceil_div(WX - cx, t.ncx), sy = ceil_div(WY - cy, t.ncy);
+  t.col_x = cx; t.col_y = cy; t.sub_x = sx;
+  t.nwin = sx * sy;
+  int wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
+  if (wpi > t.nwin) wpi = t.nwin;
+  // (wpi fixes the LDS image: keep the value of the full tiling unless the class is smaller)
+  if (wpi < t.wpi) { t.wpi = wpi; t.rowsLocal = t.wpi * t.nLT * 16; t.rowsTotal = t.rowsLocal + t.rowsLm + 16; }
+  t.niter = ceil_div(t.nwin, t.wpi);
+  win_blocks(g, t, true);
+  return true;
 }
 
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
@@ -58,26 +106,21 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
   if (t.wpi > t.nwin) t.wpi = t.nwin;
   t.niter = ceil_div(t.nwin, t.wpi);
-  // Workgroups per (b,h).  A workgroup pays a fixed prologue (landmark rows, bias table, slot tables:
-  // ~0.4 window-iterations, measured) and keeps the landmark rows -- in backward also its landmark-
-  // gradient accumulators -- resident across its windows, so fewer workgroups are cheaper; but the
-  // launch runs in rounds of (CUs x resident workgroups per CU), and a partly filled last round
-  // idles the chip (B*h = 384, 6 workgroups each: 4.5 rounds on 512 slots -> 5).  Pick the count
-  // that minimises rounds x (windows per workgroup + prologue).
-  const long bh = (long)g.B * g.H;
-  const long slots = (long)device_cu_count() * (backward ? 2 : 4);     // resident workgroups (launch bounds / LDS)
-  int best = 1;
-  double best_cost = 1e30;
-  for (int nb = 1; nb <= t.niter; ++nb) {
-    const int ipb = ceil_div(t.niter, nb);
-    if (ceil_div(t.niter, ipb) != nb) continue;                        // same schedule as a smaller count
-    const long rounds = (bh * nb + slots - 1) / slots;
-    const double cost = (double)rounds * (ipb + 0.4);
-    if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
+  t.ncx = t.ncy = 1;
+  t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
+  win_blocks(g, t, backward);
+  t.parts_total = t.nblk;
+  if (backward && e > 0) {
+    t.ncx = 1 + ceil_div(2 * e, w);
+    t.ncy = g.attn_2d ? t.ncx : 1;
+    int total = 0;
+    for (int cy = 0; cy < t.ncy; ++cy)
+      for (int cx = 0; cx < t.ncx; ++cx) {
+        WinTiling c = t;
+        if (win_colour(g, c, cy, cx)) total += c.nblk;
+      }
+    t.parts_total = total;
   }
-  int nblk = best;
-  t.ipb = ceil_div(t.niter, nblk);
-  t.nblk = ceil_div(t.niter, t.ipb);
   t.rowsLocal = t.wpi * t.nLT * 16;
   t.rowsLm = t.nCT * 16;
   t.rowsTotal = t.rowsLocal + t.rowsLm + 16;
@@ -136,6 +179,13 @@ EA_DEV void win_origin(const Geo& G, int win, int w, int& oy, int& ox) {
     oy = win * w;
     ox = 0;
   }
+}
+// window id of logical window `lw` of this launch's colour class
+EA_DEV int colour_win(const WinTiling& t, const Geo& G, int w, int lw) {
+  if (t.ncx == 1 && t.ncy == 1) return lw;
+  if (!G.attn2d) return lw * t.ncx + t.col_x;
+  const int sy = lw / t.sub_x, sx = lw - sy * t.sub_x;
+  return (sy * t.ncy + t.col_y) * (G.gw / w) + sx * t.ncx + t.col_x;
 }
 EA_DEV int slot_token(const Geo& G, int packed, int oy, int ox) {
   if (G.attn2d) {

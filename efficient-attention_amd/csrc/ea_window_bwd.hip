@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           x.rowv[i] = row;
           if (win < t.nwin && slot < t.Wk) {
             int oy, ox;
-            win_origin(p.G, win, p.w, oy, ox);
+            win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
             const int tok = slot_token(p.G, kd[slot], oy, ox);
             x.addv[i] = MASK_FILL * LOG2E;
             if (tok >= 0) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           int tok = -1;
           if (win < t.nwin && slot < t.Wq) {
             int oy, ox;
-            win_origin(p.G, win, p.w, oy, ox);
+            win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
             tok = slot_token(p.G, qd[slot], oy, ox);
           }
           x.rowv[i] = row;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       int qtok = -1;
       if (qslot < t.Wq) {
         int oy, ox;
-        win_origin(p.G, win, p.w, oy, ox);
+        win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
         qtok = slot_token(p.G, qd[qslot], oy, ox);
       }
       typename E::x8 qf[KS], dof[KS];
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
         int tok = -1;
         if (kslot < t.Wk) {
           int oy, ox;
-          win_origin(p.G, win, p.w, oy, ox);
+          win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
           tok = slot_token(p.G, kd[kslot], oy, ox);
         }
         if (tok >= 0) {
@@ -467,11 +467,17 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
               stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
             }
           } else {
-            // overlapping windows: a token is a key of several windows -> fp32 atomics
-            float* a1 = p.dk32 + ((size_t)bh * p.G.N + tok) * D + DQ * g;
-            float* a2 = p.dv32 + ((size_t)bh * p.G.N + tok) * D + DQ * g;
+            // overlapping windows: a token is a key of several windows, but of only one window of
+            // this launch's colour class -> plain 16-B read-modify-write into the fp32 scratch
+            float4* a1 = reinterpret_cast<float4*>(p.dk32 + ((size_t)bh * p.G.N + tok) * D + DQ * g);
+            float4* a2 = reinterpret_cast<float4*>(p.dv32 + ((size_t)bh * p.G.N + tok) * D + DQ * g);
 #pragma unroll
-            for (int i = 0; i < DQ; ++i) { atomicAdd(a1 + i, fk[i]); atomicAdd(a2 + i, fv[i]); }
+            for (int i = 0; i < DQ / 4; ++i) {
+              float4 x = a1[i], y = a2[i];
+              x.x += fk[4 * i]; x.y += fk[4 * i + 1]; x.z += fk[4 * i + 2]; x.w += fk[4 * i + 3];
+              y.x += fv[4 * i]; y.y += fv[4 * i + 1]; y.z += fv[4 * i + 2]; y.w += fv[4 * i + 3];
+              a1[i] = x; a2[i] = y;
+            }
           }
         }
       }
@@ -486,8 +492,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   if (p.L > 0 && wave < t.nCT) {
     const int lm = wave * 16 + li;
     if (lm < p.L) {
-      float* d1 = p.dlk_part + (((size_t)blk * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
-      float* d2 = p.dlv_part + (((size_t)blk * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
+      float* d1 = p.dlk_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
+      float* d2 = p.dlv_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         *reinterpret_cast<float4*>(d1 + 4 * dt) =
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   }
   if (p.bias) {
     __syncthreads();
-    float* dst = p.dbias_part + (((size_t)blk * p.B + b) * p.H + h) * (size_t)t.Wq * t.biasLd;
+    float* dst = p.dbias_part + (((size_t)(t.blk0 + blk) * p.B + b) * p.H + h) * (size_t)t.Wq * t.biasLd;
     for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[(idx / t.biasLd) * BLD + (idx % t.biasLd)];
   }
   EA_STAMP(p, 61);
@@ -555,9 +561,26 @@ static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t s
     if (e == hipSuccess) e = hipMemsetAsync(p.dv32, 0, bytes, st);
     if (e != hipSuccess) return (int)e;
   }
-  const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, p, outp, biasT);
-  else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, p, outp, biasT);
+  if (p.e == 0) {
+    const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
+    if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, p, outp, biasT);
+    else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, p, outp, biasT);
+  } else {
+    // one launch per colour class (stream order separates the classes)
+    ea_geom gg = {};
+    gg.B = p.B; gg.H = p.H; gg.N = p.G.N; gg.attn_2d = p.G.attn2d; gg.gh = p.G.gh; gg.gw = p.G.gw; gg.window = p.w;
+    int blk0 = 0;
+    for (int cy = 0; cy < p.t.ncy; ++cy)
+      for (int cx = 0; cx < p.t.ncx; ++cx) {
+        WinP pc = p;
+        if (!win_colour(gg, pc.t, cy, cx)) continue;
+        pc.t.blk0 = blk0;
+        blk0 += pc.t.nblk;
+        const dim3 grid((unsigned)(p.B * p.H * pc.t.nblk));
+        if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, pc, outp, biasT);
+        else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, pc, outp, biasT);
+      }
+  }
   if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);
   return (int)hipGetLastError();
 }
