@@ -135,6 +135,10 @@ def main():
     # EA_BENCH_FORCE_DDP=1: dev-only, run the N > 1 code path (process group, DDP wrapper, eager
     # stepping) with a single rank to measure its host-side overhead on one GPU
     ddp = world > 1 or bool(os.environ.get("EA_BENCH_FORCE_DDP"))
+    if os.environ.get("EA_BENCH_ONE_DEVICE"):
+        local = 0
+    torch.cuda.set_device(local)                # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local)
     if ddp:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -142,10 +146,6 @@ def main():
             dist.init_process_group(backend, rank=0, world_size=1)
         else:
             dist.init_process_group(backend)
-    if os.environ.get("EA_BENCH_ONE_DEVICE"):
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
 
     B, C, H = a.batch, a.dim, a.heads
