@@ -736,6 +736,21 @@ def bias_grad(dy2):
     return db
 
 
+_MM_OUT_DTYPE = [True]      # torch.mm(..., out_dtype=) available (library GEMM with fp32 output)
+
+
+def _mm_out(a, b, out_dtype):
+    """a @ b with the result in `out_dtype`.  For a low-precision product consumed in fp32 (the input
+    gradient of a projection whose input is fp32) the library GEMM writes fp32 directly instead of
+    bf16 + a separate cast pass over the activation-sized tensor."""
+    if out_dtype == torch.float32 and a.dtype in (torch.bfloat16, torch.float16) and _MM_OUT_DTYPE[0]:
+        try:
+            return torch.mm(a, b, out_dtype=torch.float32)
+        except (TypeError, RuntimeError, NotImplementedError):
+            _MM_OUT_DTYPE[0] = False
+    return (a @ b).to(out_dtype)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b in the autocast dtype.  dW = dY^T X contracts over all B*N tokens with a
     [out, in] result of a few tiles: left to a single library GEMM it occupies ~9 of 256 CUs
@@ -762,7 +777,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.to(xl.dtype)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ wl).view(xshape).to(xdtype)
+            dx = _mm_out(dy2, wl, xdtype).view(xshape)
         if ctx.needs_input_grad[1]:
             rows = xl.shape[0]
             S = _split_k(rows)
