@@ -13,6 +13,7 @@ size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds);
 #include "ea_softmax.h"
 #include "ea_lara_lmk.h"
 #include "ea_lara_merge.h"
+#include "ea_lara_segment.h"
 namespace ea {
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
@@ -581,6 +582,49 @@ int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, 
                  float* out, void* stream) {
   if (!parts || !out) return EA_E_BADARG;
   return ea::slice_sum_dispatch(a, parts, out, BH, S, n, scale, (hipStream_t)stream);
+}
+
+// ---- LARA 1-D landmark proposals: segment means of (LayerNorm'd) rows ----
+static int fill_seg(const ea_geom* g, SegP& p) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->N <= 0 || g->L <= 0 || (g->D != 32 && g->D != 64) ||
+      (g->dtype != EA_BF16 && g->dtype != EA_F16)) return EA_E_BADARG;
+  if (g->N <= g->L) return EA_E_UNSUPPORTED;            // the reference uses the rows themselves then
+  p.B = g->B; p.H = g->H; p.N = g->N; p.L = g->L;
+  p.segs = g->N / g->L;
+  p.nshort = g->N % g->L == 0 ? g->L : (p.segs + 1) * g->L - g->N;   // lara.py:111-124
+  return EA_OK;
+}
+
+int ea_lara_segment_fwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, const uint8_t* mask,
+                        const float* bias_q, const float* bias_k, const float* mbias_q, const float* mbias_k,
+                        const float* gq, const float* cq, const float* gk, const float* ck,
+                        float* qbar, float* kbar, void* stream) {
+  SegP p = {};
+  int rc = fill_seg(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok32(q2, g->D, g->N) || !t4_ok32(k2, g->D, g->N) || !qbar || !kbar) return EA_E_BADARG;
+  if ((gq == nullptr) != (gk == nullptr) || (gq && (!cq || !ck))) return EA_E_BADARG;
+  SET3(q, q2); SET3(k, k2);
+  p.mask = mask; p.bias_q = bias_q; p.bias_k = bias_k; p.mbias_q = mbias_q; p.mbias_k = mbias_k;
+  p.gq = gq; p.cq = cq; p.gk = gk; p.ck = ck; p.qbar = qbar; p.kbar = kbar;
+  return lara_segment_dispatch(false, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_lara_segment_bwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, const uint8_t* mask,
+                        const float* bias_q, const float* bias_k, const float* mbias_q, const float* mbias_k,
+                        const float* gq, const float* cq, const float* gk, const float* ck,
+                        const float* d_qbar, const float* d_kbar, const ea_t4* dq2, const ea_t4* dk2,
+                        float* part, void* stream) {
+  SegP p = {};
+  int rc = fill_seg(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok32(q2, g->D, g->N) || !t4_ok32(k2, g->D, g->N) || !t4_ok32(dq2, g->D, g->N) ||
+      !t4_ok32(dk2, g->D, g->N) || !d_qbar || !d_kbar) return EA_E_BADARG;
+  if ((gq == nullptr) != (gk == nullptr) || (gq && (!cq || !ck || !part))) return EA_E_BADARG;
+  SET3(q, q2); SET3(k, k2); SET3(dq, dq2); SET3(dk, dk2);
+  p.mask = mask; p.bias_q = bias_q; p.bias_k = bias_k; p.mbias_q = mbias_q; p.mbias_k = mbias_k;
+  p.gq = gq; p.cq = cq; p.gk = gk; p.ck = ck; p.d_qbar = d_qbar; p.d_kbar = d_kbar; p.part = part;
+  return lara_segment_dispatch(true, p, g->dtype, g->D, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,165 @@
+// ea_lara_segment.hip -- LARA's 1-D landmark proposals (lara.py:84-127): the segment means of
+//     LayerNorm(Linear(q)), LayerNorm(Linear(k))      ('adaptive-1d')   or of q, k themselves,
+// with the reference's even / uneven split of N tokens into L segments.  The Linear itself is folded
+// into the qkv projection by the host module (two more groups of output columns of the same GEMM,
+// W' = Wgen Wq), so this kernel reads those pre-LayerNorm rows once, normalises each row in
+// registers and averages; nothing token-sized is written in the forward.  The backward recomputes
+// the row statistics, writes the gradient of the pre-LayerNorm rows and leaves the LayerNorm / bias
+// parameter gradients as per-segment partial sums.
+// One wave per (b, h, segment, q|k); a row (D elements) is spread over D/8 lanes (16-B loads).
+#include "ea_lara_segment.h"
+
+namespace ea {
+
+template <int CPR> EA_DEV float row_sum(float v) {          // over the CPR lanes that share a row
+#pragma unroll
+  for (int o = 1; o < CPR; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int CPR> EA_DEV float col_sum(float v) {          // over the 64/CPR row groups (same channels)
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename E, int D, bool BWD>
+__global__ __launch_bounds__(256) void lara_segment_kernel(const SegP p) {
+  constexpr int CPR = D / 8, RPI = 64 / CPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= p.B * p.H * p.L * 2) return;
+  const int side = unit & 1, rest = unit >> 1;
+  const int l = rest % p.L, bh = rest / p.L, b = bh / p.H, h = bh - b * p.H;
+  const int s0 = l < p.nshort ? l * p.segs : p.nshort * p.segs + (l - p.nshort) * (p.segs + 1);
+  const int len = l < p.nshort ? p.segs : p.segs + 1;
+  const int rl = lane / CPR, cl = lane - rl * CPR;
+  const char* src = side ? p.k + (b * p.k_sb + h * p.k_sh) * 2 : p.q + (b * p.q_sb + h * p.q_sh) * 2;
+  const int sn = (int)(side ? p.k_sn : p.q_sn);
+  const float* gam = side ? p.gk : p.gq;
+  const float* bet = side ? p.ck : p.cq;
+  const float* bias = side ? p.bias_k : p.bias_q;
+  const float* mbias = side ? p.mbias_k : p.mbias_q;
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.N : nullptr;
+  const bool ln = gam != nullptr;
+  float g8[8], c8[8], b8[8], m8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    g8[i] = ln ? gam[cl * 8 + i] : 1.f;
+    c8[i] = ln ? bet[cl * 8 + i] : 0.f;
+    b8[i] = bias ? bias[h * D + cl * 8 + i] : 0.f;
+    m8[i] = mbias ? mbias[cl * 8 + i] : 0.f;
+  }
+  const float inv_len = 1.f / (float)len;
+  float dy8[8];
+  char* dst = nullptr;
+  int dsn = 0;
+  if (BWD) {
+    const float* dbar = (side ? p.d_kbar : p.d_qbar) + ((size_t)bh * p.L + l) * D + cl * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dy8[i] = dbar[i] * inv_len;
+    dst = side ? p.dk + (b * p.dk_sb + h * p.dk_sh) * 2 : p.dq + (b * p.dq_sb + h * p.dq_sh) * 2;
+    dsn = (int)(side ? p.dk_sn : p.dq_sn);
+  }
+  float acc[8], a_dg[8], a_db[8], a_bu[8], a_bm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = a_dg[i] = a_db[i] = a_bu[i] = a_bm[i] = 0.f;
+
+  const int iters = (len + RPI - 1) / RPI;
+  for (int it = 0; it < iters; ++it) {
+    const int off = it * RPI + rl;
+    const bool valid = off < len;
+    const int tok = s0 + (valid ? off : 0);                 // clamped: the load is unconditional
+    const bool masked = mrow && mrow[tok];
+    float f[8];
+    unpack8<E>(ldg16(src + (tok * sn + cl * 8) * 2), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] += masked ? m8[i] : b8[i];
+    float xh[8], rs = 1.f;
+    if (ln) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += f[i];
+      const float mean = row_sum<CPR>(s) * (1.f / D);
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { xh[i] = f[i] - mean; v += xh[i] * xh[i]; }
+      rs = rsqrtf(row_sum<CPR>(v) * (1.f / D) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xh[i] *= rs;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xh[i] = f[i];
+    }
+    if (!BWD) {
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += g8[i] * xh[i] + c8[i];
+      }
+    } else {
+      float dh[8];
+      if (ln) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dh[i] = dy8[i] * g8[i]; s1 += dh[i]; s2 += dh[i] * xh[i]; }
+        s1 = row_sum<CPR>(s1) * (1.f / D);
+        s2 = row_sum<CPR>(s2) * (1.f / D);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dh[i] = rs * (dh[i] - s1 - xh[i] * s2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dh[i] = dy8[i];
+      }
+      if (valid) {
+        stg16(dst + (tok * dsn + cl * 8) * 2, pack8<E>(dh));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a_dg[i] += dy8[i] * xh[i];
+          a_db[i] += dy8[i];
+          if (masked) a_bm[i] += dh[i]; else a_bu[i] += dh[i];
+        }
+      }
+    }
+  }
+  if (!BWD) {
+    float* out = (side ? p.kbar : p.qbar) + ((size_t)bh * p.L + l) * D + cl * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = col_sum<CPR>(acc[i]) * inv_len;
+    if (rl == 0) {
+      *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(out + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  } else if (p.part) {
+    float* pr = p.part + (((size_t)bh * p.L + l) * 2 + side) * 4 * D + cl * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a_dg[i] = col_sum<CPR>(a_dg[i]); a_db[i] = col_sum<CPR>(a_db[i]);
+      a_bu[i] = col_sum<CPR>(a_bu[i]); a_bm[i] = col_sum<CPR>(a_bm[i]);
+    }
+    if (rl == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { pr[i] = a_dg[i]; pr[D + i] = a_db[i]; pr[2 * D + i] = a_bu[i]; pr[3 * D + i] = a_bm[i]; }
+    }
+  }
+}
+
+template <typename E, int D>
+static int launch_seg(bool bwd, const SegP& p, hipStream_t st) {
+  const long units = (long)p.B * p.H * p.L * 2;
+  const dim3 grid((unsigned)((units + 3) / 4));
+  if (bwd) hipLaunchKernelGGL((lara_segment_kernel<E, D, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((lara_segment_kernel<E, D, false>), grid, dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+
+int lara_segment_dispatch(bool bwd, const SegP& p, int dtype, int D, hipStream_t st) {
+  if (dtype == EA_BF16) {
+    if (D == 64) return launch_seg<BF16, 64>(bwd, p, st);
+    if (D == 32) return launch_seg<BF16, 32>(bwd, p, st);
+  } else if (dtype == EA_F16) {
+    if (D == 64) return launch_seg<F16, 64>(bwd, p, st);
+    if (D == 32) return launch_seg<F16, 32>(bwd, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

@@ -73,6 +73,8 @@ SIGNATURES = {
     "ea_bias_grad": [_I, _I, _I, _P, _P, _P, _P],
     "ea_colsum_f32": [_I, _I, _P, _P, _P],
     "ea_slice_sum": [_I, _I, _I, _F, _P, _P, _P, _P],
+    "ea_lara_segment_fwd": [_G, _T, _T] + [_P] * 12,
+    "ea_lara_segment_bwd": [_G, _T, _T] + [_P] * 11 + [_T, _T, _P, _P],
     "ea_lara_parts": [_LG],
     "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],

@@ -64,9 +64,9 @@ KERNEL_ALGO_UNITS = {
 
 
 def _qkv_views(qkv5):
-    """[B,N,3,h,d] -> three [B,h,N,d] strided views (no copy)."""
-    q, k, v = qkv5.unbind(2)
-    return q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    """[B,N,S>=3,h,d] -> the q, k, v [B,h,N,d] strided views (no copy); further slots (the pre-LayerNorm
+    rows of LARA's 1-D proposals) are left alone."""
+    return tuple(qkv5[:, :, i].permute(0, 2, 1, 3) for i in range(3))
 
 
 def _mask_u8(mask, B, N, device):
@@ -353,6 +353,54 @@ class PoolMeanFn(torch.autograd.Function):
                 ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
         slot.buf = None
         return (buf if own else None), None, None, None, None
+
+
+class SegmentLnMeanFn(torch.autograd.Function):
+    """LARA 'adaptive-1d' proposals (lara.py:84-127): segment means of LayerNorm(Linear(q)) and
+    LayerNorm(Linear(k)).  The Linear is folded into the qkv projection by the module, whose output
+    qkvE [B,N,5,h,d] carries its (bias-free) rows in slots 3 and 4; this Function normalises and
+    averages them (ea_lara_segment_fwd/bwd) and, like the 2-D pooling, writes its input gradient
+    straight into the gradient buffer the attention core publishes for qkvE.
+    bias_* [h,d]: bias of an ordinary token's row; mbias_* [d]: the whole row of a masked token."""
+
+    @staticmethod
+    def forward(ctx, qkvE, mask_u8, L, slot, bias_q, bias_k, mbias_q, mbias_k, gq, cq, gk, ck):
+        nv.require_cuda(qkvE, "qkv")
+        B, N, S, h, d = qkvE.shape
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkvE), False, (N,), 0, 0, 0, L)
+        ps = [t.detach().float().contiguous() for t in (bias_q, bias_k, mbias_q, mbias_k, gq, cq, gk, ck)]
+        q2, k2 = qkvE[:, :, 3].permute(0, 2, 1, 3), qkvE[:, :, 4].permute(0, 2, 1, 3)
+        tq, tk = nv.t4(q2), nv.t4(k2)
+        qbar = torch.empty((B, h, L, d), dtype=torch.float32, device=qkvE.device)
+        kbar = torch.empty_like(qbar)
+        nv.call("ea_lara_segment_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk), nv.ptr(mask_u8),
+                *[nv.ptr(t) for t in ps], nv.ptr(qbar), nv.ptr(kbar), nv.stream())
+        ctx.save_for_backward(qkvE, mask_u8, *ps)
+        ctx.geom, ctx.slot = geom, slot
+        return qbar, kbar
+
+    @staticmethod
+    def backward(ctx, dqb, dkb):
+        qkvE, mask_u8, *ps = ctx.saved_tensors
+        geom, slot = ctx.geom, ctx.slot
+        B, N, S, h, d = qkvE.shape
+        L = geom.L
+        own = slot is None or slot.buf is None
+        buf = torch.zeros_like(qkvE) if own else slot.buf
+        q2, k2 = qkvE[:, :, 3].permute(0, 2, 1, 3), qkvE[:, :, 4].permute(0, 2, 1, 3)
+        dq2, dk2 = buf[:, :, 3].permute(0, 2, 1, 3), buf[:, :, 4].permute(0, 2, 1, 3)
+        ts = [nv.t4(t) for t in (q2, k2, dq2, dk2)]
+        part = torch.empty((B, h, L, 2, 4, d), dtype=torch.float32, device=qkvE.device)
+        nv.call("ea_lara_segment_bwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), nv.ptr(mask_u8),
+                *[nv.ptr(t) for t in ps], nv.ptr(dqb.float().contiguous()), nv.ptr(dkb.float().contiguous()),
+                ctypes.byref(ts[2]), ctypes.byref(ts[3]), nv.ptr(part), nv.stream())
+        if slot is not None:
+            slot.buf = None
+        sums = part.sum((0, 2))                                   # [h, 2, 4, d]
+        tot = sums.sum(0)                                         # [2, 4, d]
+        # bias_q, bias_k, mbias_q, mbias_k, gq, cq, gk, ck
+        grads = (sums[:, 0, 2], sums[:, 1, 2], tot[0, 3], tot[1, 3], tot[0, 0], tot[0, 1], tot[1, 0], tot[1, 1])
+        return ((buf if own else None), None, None, None) + grads
 
 
 def pool2d_qkv(qkv5, H, W, side, slot=None, need_v=False):
@@ -795,10 +843,15 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, layer):
     """nn.Linear forward through LinearFn, in the autocast dtype when autocast is on."""
+    if not x.is_cuda:
+        return layer(x)
+    return linear_wb(x, layer.weight, layer.bias)
+
+
+def linear_wb(x, weight, bias):
+    """F.linear(x, weight, bias) through LinearFn, in the autocast dtype when autocast is on."""
     if torch.is_autocast_enabled():
         dtype = torch.get_autocast_dtype("cuda")
     else:
         dtype = x.dtype
-    if not x.is_cuda:
-        return layer(x)
-    return LinearFn.apply(x, layer.weight, layer.bias, dtype)
+    return LinearFn.apply(x, weight, bias, dtype)

@@ -109,6 +109,48 @@ class LinearRA(MultiheadAttention):
             q_bar, k_bar = seg_mean(q2), seg_mean(k2)
         return q_bar, k_bar, qkv5
 
+    # ---- 'adaptive-1d' with the generators' Linear folded into the qkv projection --------------
+    def _project_qkv_folded(self, x):
+        """x [B,N,C] -> [B,N,5,h,d]: q, k, v and, in slots 3 / 4, Linear_q(q), Linear_k(k) without
+        their biases (W' = W_gen W_q per head: the composition of the two projections is one more
+        group of output columns of the same GEMM instead of a K = d GEMM over B*h*N strided rows)."""
+        B, N, C = x.shape
+        h, d = self.num_heads, self.head_dim
+        with torch.autocast(device_type="cuda", enabled=False):
+            W = self.qkv.weight.float()
+            Wq, Wk = W[:C].view(h, d, C), W[C:2 * C].view(h, d, C)
+            W2q = torch.matmul(self.q_bar_gen[0].weight.float(), Wq).reshape(C, C)
+            W2k = torch.matmul(self.k_bar_gen[0].weight.float(), Wk).reshape(C, C)
+            w_ext = torch.cat([W, W2q, W2k], 0)
+            b_ext = None
+            if self.qkv.bias is not None:
+                b_ext = torch.cat([self.qkv.bias.float(), self.qkv.bias.new_zeros(2 * C, dtype=torch.float32)])
+        qkv = _ops.linear_wb(x, w_ext, b_ext)
+        if qkv.dtype not in (torch.bfloat16, torch.float16):
+            qkv = qkv.to(torch.bfloat16)
+        return qkv.reshape(B, N, 5, h, d)
+
+    def _proposal_gen_1d_folded(self, qkvE, key_padding_mask, mask_u8, slot):
+        """Segment means of LayerNorm(Linear(q)), LayerNorm(Linear(k)) (reference :84-127) from the
+        folded projection.  Returns q_bar, k_bar [B,h,L,d] fp32 and the (mask-zeroed) qkvE."""
+        B, N, _, h, d = qkvE.shape
+        if key_padding_mask is not None:
+            keep = (~key_padding_mask.to(torch.bool)).to(qkvE.dtype).view(B, N, 1, 1, 1)
+            qkvE = qkvE * keep
+        lq, nq, lk, nk = self.q_bar_gen[0], self.q_bar_gen[1], self.k_bar_gen[0], self.k_bar_gen[1]
+        with torch.autocast(device_type="cuda", enabled=False):
+            C = h * d
+            if self.qkv.bias is not None:
+                bq, bk = self.qkv.bias[:C].float().view(h, d), self.qkv.bias[C:2 * C].float().view(h, d)
+                bias_q = bq @ lq.weight.float().t() + lq.bias.float()
+                bias_k = bk @ lk.weight.float().t() + lk.bias.float()
+            else:
+                bias_q = lq.bias.float().expand(h, d)
+                bias_k = lk.bias.float().expand(h, d)
+        pq, pk = _ops.SegmentLnMeanFn.apply(qkvE, mask_u8, self.num_landmarks, slot, bias_q, bias_k,
+                                            lq.bias, lk.bias, nq.weight, nq.bias, nk.weight, nk.bias)
+        return pq, pk, qkvE
+
     def _mlp_params(self):
         q, k = self.q_bar_gen, self.k_bar_gen
         return [q[2].weight, q[2].bias, q[3].weight, q[3].bias, k[2].weight, k[2].bias, k[3].weight, k[3].bias]
@@ -117,9 +159,11 @@ class LinearRA(MultiheadAttention):
         B, *seq_shape, C = x.shape
         N = int(math.prod(seq_shape))
         h, d = self.num_heads, self.head_dim
-        qkv5 = self.project_qkv(x.reshape(B, N, C))
         L = self.num_landmarks
         gen = self.proposal_gen
+        # 'adaptive-1d' on the GPU: the per-token Linear of q_bar_gen / k_bar_gen rides along in the qkv GEMM
+        fold_1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and d in (32, 64) and x.is_cuda)
+        qkv5 = self._project_qkv_folded(x.reshape(B, N, C)) if fold_1d else self.project_qkv(x.reshape(B, N, C))
         dup = self.training and (self.use_multisample or self.use_antithetics)
         mode = 0
         if self.training:
@@ -142,6 +186,8 @@ class LinearRA(MultiheadAttention):
         else:
             if len(seq_shape) == 2:
                 pq, pk = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
+            elif fold_1d:
+                pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
             elif len(seq_shape) == 1:
                 pq, pk, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
             else:

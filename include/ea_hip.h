@@ -294,6 +294,30 @@ int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* 
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream);
 
+/* ---- LARA 1-D landmark proposals (LinearRA._proposal_gen_1d, lara.py:84-127) ----
+ * Segment means over the sequence, q_bar_l = mean_{n in segment l} row_n, with the reference's
+ * split of N tokens into L = g->L segments (N % L == 0: equal; otherwise (segs+1)L - N segments of
+ * segs = N / L tokens followed by segments of segs + 1).  Geometry: ea_geom with B, H, N, D, dtype,
+ * L (other fields ignored); N > L.
+ *   'adaptive-1d' (gq != NULL): row_n = LayerNorm(x_n + bias), x = the rows q2 / k2 [B,H,N,D]
+ *   (element type) holding Linear(q) WITHOUT its bias -- the host folds that Linear into the qkv
+ *   projection --, bias = bias_q/k [H,D] for ordinary tokens and mbias_q/k [D] for tokens under
+ *   `mask` (the reference zeroes q, k of padded tokens BEFORE the Linear, so their row is
+ *   LayerNorm(Linear bias)); gq, cq / gk, ck = LayerNorm weight, bias [D].
+ *   Plain means (gq == NULL): row_n = x_n (+ bias when given).
+ * Forward: qbar, kbar fp32 [B*H, L, D].  Backward: d_qbar, d_kbar -> dq2, dk2 (gradient of the
+ * rows x, WRITTEN) and per-segment partials part [B*H*L, 2 (q,k), 4, D] = (d LN weight, d LN bias,
+ * d bias (sum over unmasked rows), d mbias (sum over masked rows)) which the caller sums. */
+int ea_lara_segment_fwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, const uint8_t* mask,
+                        const float* bias_q, const float* bias_k, const float* mbias_q, const float* mbias_k,
+                        const float* gq, const float* cq, const float* gk, const float* ck,
+                        float* qbar, float* kbar, void* stream);
+int ea_lara_segment_bwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, const uint8_t* mask,
+                        const float* bias_q, const float* bias_k, const float* mbias_q, const float* mbias_k,
+                        const float* gq, const float* cq, const float* gk, const float* ck,
+                        const float* d_qbar, const float* d_kbar, const ea_t4* dq2, const ea_t4* dk2,
+                        float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
