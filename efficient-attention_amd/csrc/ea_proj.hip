@@ -14,7 +14,8 @@ constexpr int CS_UNROLL = 8;
 // group (16 B) and every R-th row of the slab.
 template <class T>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const uint16_t* __restrict__ x, float* __restrict__ part,
-                                                           int rows, int cols, int rpb) {
+                                                           int rows, int cols, int rpb, int pitch, int pcols) {
+  // x: this launch's column window of a [rows, pitch] matrix; part[b][pcols] (window offset applied by the host)
   extern __shared__ float red[];              // [R][cols]
   const int tpr = cols >> 3, R = 256 / tpr, tid = threadIdx.x;
   const int r = tid / tpr, cg = tid - r * tpr;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const uint16_t* __rest
   if (r < R) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u4;
     const u4* base = (const u4*)(x + (size_t)cg * 8);
-    const size_t ld = (size_t)cols >> 3;      // row pitch in uint4
+    const size_t ld = (size_t)pitch >> 3;     // row pitch in uint4
     int row = row0 + r;
     for (; row + (CS_UNROLL - 1) * R < row1; row += CS_UNROLL * R) {
       u4 v[CS_UNROLL];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const uint16_t* __rest
   for (int c = tid; c < cols; c += 256) {
     float s = 0.f;
     for (int j = 0; j < R; ++j) s += red[(size_t)j * cols + c];
-    part[(size_t)blockIdx.x * cols + c] = s;
+    part[(size_t)blockIdx.x * pcols + c] = s;
   }
 }
 
@@ -107,9 +108,11 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict_
   reinterpret_cast<float4*>(out)[i] = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
 }
 
+constexpr int CS_MAXW = 2048;     // columns per launch (256 threads x 8); wider matrices go in windows
+
 int colsum_parts(int rows, int cols) {
-  if (rows <= 0 || cols <= 0 || (cols & 7) || cols > 2048) return EA_E_BADARG;
-  const int R = 256 / (cols >> 3);
+  if (rows <= 0 || cols <= 0 || (cols & 7) || cols > 16384) return EA_E_BADARG;
+  const int R = 256 / ((cols < CS_MAXW ? cols : CS_MAXW) >> 3);
   // ~512 slabs (two per CU; measured best on MI355X: 3.3 TB/s cold at 100352 x 576), each at least
   // two unrolled sweeps deep
   int rpb = (rows + 511) / 512;
@@ -122,14 +125,18 @@ int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows,
   const int nblk = colsum_parts(rows, cols);
   if (nblk < 0) return nblk;
   const int rpb = (rows + nblk - 1) / nblk;
-  const int R = 256 / (cols >> 3);
-  const size_t lds = (size_t)R * cols * sizeof(float);
-  if (dtype == EA_BF16)
-    hipLaunchKernelGGL(colsum_part_kernel<BF16>, dim3(nblk), dim3(256), lds, st, (const uint16_t*)x, part, rows, cols, rpb);
-  else if (dtype == EA_F16)
-    hipLaunchKernelGGL(colsum_part_kernel<F16>, dim3(nblk), dim3(256), lds, st, (const uint16_t*)x, part, rows, cols, rpb);
-  else
-    return EA_E_BADARG;
+  for (int c0 = 0; c0 < cols; c0 += CS_MAXW) {
+    const int w = cols - c0 < CS_MAXW ? cols - c0 : CS_MAXW;
+    const int Rw = 256 / (w >> 3);
+    const size_t lds = (size_t)Rw * w * sizeof(float);
+    const uint16_t* xw = (const uint16_t*)x + c0;
+    if (dtype == EA_BF16)
+      hipLaunchKernelGGL(colsum_part_kernel<BF16>, dim3(nblk), dim3(256), lds, st, xw, part + c0, rows, w, rpb, cols, cols);
+    else if (dtype == EA_F16)
+      hipLaunchKernelGGL(colsum_part_kernel<F16>, dim3(nblk), dim3(256), lds, st, xw, part + c0, rows, w, rpb, cols, cols);
+    else
+      return EA_E_BADARG;
+  }
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, part, out, nblk, cols);
   return (int)hipGetLastError();
 }

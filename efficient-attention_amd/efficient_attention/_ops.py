@@ -774,7 +774,7 @@ def colsum_f32(x2):
 def bias_grad(dy2):
     """db = dY.sum(0) in fp32 through ea_bias_grad (dY: contiguous [rows, cols] bf16/fp16)."""
     rows, cols = dy2.shape
-    if dy2.dtype not in (torch.bfloat16, torch.float16) or cols % 8 or cols > 2048 or not dy2.is_contiguous():
+    if dy2.dtype not in (torch.bfloat16, torch.float16) or cols % 8 or cols > 16384 or not dy2.is_contiguous():
         return dy2.sum(0, dtype=torch.float32)
     nb = nv.lib().ea_bias_grad_parts(rows, cols)
     part = torch.empty(nb * cols, dtype=torch.float32, device=dy2.device)

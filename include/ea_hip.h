@@ -278,7 +278,7 @@ int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t
  * attention module (abstract_attention.py:34-36 `self.qkv`, `self.proj`; eva.py:76-77, lara.py:88-90):
  * dY is the contiguous [rows = B*N, cols] cotangent of the projection output in the I/O dtype,
  * db is fp32 [cols].  Deterministic two-stage sum; `part` is caller workspace of
- * ea_bias_grad_parts(rows, cols) * cols floats.  cols % 8 == 0, cols <= 2048. */
+ * ea_bias_grad_parts(rows, cols) * cols floats.  cols % 8 == 0, cols <= 16384. */
 int ea_bias_grad_parts(int32_t rows, int32_t cols);
 int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, float* part, float* db,
                  void* stream);

@@ -15,7 +15,7 @@ def test_probe_primitives():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols", [(100352, 576), (100352, 192), (1000, 64), (37, 8), (5000, 2048)])
+@pytest.mark.parametrize("rows,cols", [(100352, 576), (100352, 192), (1000, 64), (37, 8), (5000, 2048), (4096, 2560), (300, 4104)])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_bias_grad_matches_fp64_column_sum(rows, cols, dtype):
     """ea_bias_grad (projection bias gradient) against an fp64 column sum of the same bf16/fp16 data."""
