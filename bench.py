@@ -37,7 +37,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 
 BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv) at d=64, bf16
 
 
+OVERRIDES = {}      # --window / --landmarks
+
+
 def attn_args(attn, dim, heads, seq):
+    args = _attn_args(attn, dim, heads, seq)
+    for k, v in OVERRIDES.items():
+        if k in args and v is not None:
+            args[k] = v
+    return args
+
+
+def _attn_args(attn, dim, heads, seq):
     """seq: (side, side) for the vit recipes (cfg2 / cfg3), (N,) for the fairseq-style 1-D ones (cfg5)."""
     base = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0)
     seq = _seq(seq)
@@ -115,6 +126,8 @@ def main():
     ap.add_argument("--grid", type=int, default=28, help="token grid side (28 -> N=784)")
     ap.add_argument("--dim", type=int, default=192)
     ap.add_argument("--heads", type=int, default=3)
+    ap.add_argument("--window", type=int, default=None, help="override window_size (eva / local), e.g. 8 for the PvT stages")
+    ap.add_argument("--landmarks", type=int, default=None, help="override num_landmarks (eva / lara), e.g. 36 for the PvT stages")
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"],
                     help="cfg3 (default, the metric's config): [128,28,28,192] h=3; cfg2: [128,14,14,192] h=3; "
                          "cfg5: 1-D [16,4096,512] h=8 (BASELINE.json configs / SURVEY.md 8d)")
@@ -148,6 +161,7 @@ def main():
             dist.init_process_group(backend)
     torch.manual_seed(1234 + rank)
 
+    OVERRIDES.update(window_size=a.window, num_landmarks=a.landmarks)
     B, C, H = a.batch, a.dim, a.heads
     seq = (a.grid, a.grid)
     if a.workload == "cfg2":

@@ -3,8 +3,11 @@
 //   chunk_mean : masked means of q and k over every landmark chunk      (eva.py:160-180)
 //   beta       : beta_c = softmax_j(s w_c.k_j - s|k_j|^2/2) . v_j        (eva.py:192-196)
 // and their backward passes.  These are HBM/L2-bound O(N*D) passes with no matmul shape, so
-// they are plain VALU kernels: one wave per chunk, a row of D channels is spread over D/8
-// lanes (16-byte loads), 64/(D/8) rows are in flight per wave step.
+// they are plain VALU kernels: a row of D channels is spread over D/8 lanes (16-byte loads),
+// 64/(D/8) rows are in flight per wave step.  Short chunks (2-D pooling: 16-64 tokens) get one
+// wave each (WPC = 1); long chunks (1-D sequences: hundreds of tokens per landmark, where
+// B*h*L waves would not fill the chip) are shared by the four waves of a workgroup (WPC = 4) whose
+// partial results are merged through LDS in a fixed order.
 //
 // The chunk partition (rearrange / pad + as_strided copies in the reference) is address
 // arithmetic (part_token); slots outside the sequence and padded tokens count as zeros in the
@@ -28,11 +31,12 @@ template <int CPR> EA_DEV float chan_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <typename E, int D>
+template <typename E, int D, int WPC>
 __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
   constexpr int CPR = D / 8, RPW = 64 / CPR;
-  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
-  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR, wave = threadIdx.x >> 6;
+  const int sub = WPC == 1 ? 0 : wave;
+  const long chunk_id = WPC == 1 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
   if (chunk_id >= (long)p.B * p.H * p.L) return;
   const int cidx = (int)(chunk_id % p.L);
   const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
   float aq[8], ak[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) aq[i] = ak[i] = 0.f;
-  for (int j = rg; j < p.J; j += RPW) {
+  for (int j = sub * RPW + rg; j < p.J; j += WPC * RPW) {
     const int tok = part_token(p.G, cidx, j, p.r, p.e);
     if (tok >= 0 && !(mrow && mrow[tok])) {
       float f[8];
@@ -60,6 +64,21 @@ __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
     aq[i] = rows_sum<CPR>(aq[i]) * inv;
     ak[i] = rows_sum<CPR>(ak[i]) * inv;
   }
+  if (WPC > 1) {
+    __shared__ float red[WPC][2][D];
+    if (rg == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { red[wave][0][c * 8 + i] = aq[i]; red[wave][1][c * 8 + i] = ak[i]; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      aq[i] = ak[i] = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPC; ++w) { aq[i] += red[w][0][c * 8 + i]; ak[i] += red[w][1][c * 8 + i]; }
+    }
+  }
   if (rg == 0) {
     float* dq_ = p.qmean + (size_t)chunk_id * D + c * 8;
     float* dk_ = p.kmean + (size_t)chunk_id * D + c * 8;
@@ -73,11 +92,12 @@ __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
 // dq[tok] += dqmean[c]/J, dk[tok] += dkmean[c]/J for every unmasked in-range slot of chunk c.
 // With e == 0 every token belongs to exactly one chunk, so the read-modify-write is race free;
 // e > 0 (overlapping chunks) is serialised by launching one chunk "colour" at a time (host).
-template <typename E, int D>
+template <typename E, int D, int WPC>
 __global__ __launch_bounds__(256) void chunk_mean_bwd_kernel(const LmP p, int colour, int nc) {
   constexpr int CPR = D / 8, RPW = 64 / CPR;
-  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
-  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR, wave = threadIdx.x >> 6;
+  const int sub = WPC == 1 ? 0 : wave;
+  const long chunk_id = WPC == 1 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
   if (chunk_id >= (long)p.B * p.H * p.L) return;
   const int cidx = (int)(chunk_id % p.L);
   if (nc > 1) {
@@ -98,7 +118,7 @@ __global__ __launch_bounds__(256) void chunk_mean_bwd_kernel(const LmP p, int co
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gq[i] = s1[i] * inv; gk[i] = s2[i] * inv; }
   }
-  for (int j = rg; j < p.J; j += RPW) {
+  for (int j = sub * RPW + rg; j < p.J; j += WPC * RPW) {
     const int tok = part_token(p.G, cidx, j, p.r, p.e);
     if (tok >= 0 && !(mrow && mrow[tok])) {
       float f[8];
@@ -118,11 +138,12 @@ __global__ __launch_bounds__(256) void chunk_mean_bwd_kernel(const LmP p, int co
 
 // ------------------------------------------------------------------------------------------
 // beta forward: online softmax over the chunk's rows per row-group, merged across row-groups.
-template <typename E, int D>
+template <typename E, int D, int WPC>
 __global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
   constexpr int CPR = D / 8, RPW = 64 / CPR;
-  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
-  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR, wave = threadIdx.x >> 6;
+  const int sub = WPC == 1 ? 0 : wave;
+  const long chunk_id = WPC == 1 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
   if (chunk_id >= (long)p.B * p.H * p.L) return;
   const int cidx = (int)(chunk_id % p.L);
   const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;
@@ -138,8 +159,8 @@ __global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  const int jmax = (p.J + RPW - 1) / RPW * RPW;
-  for (int j = rg; j < jmax; j += RPW) {
+  const int jmax = (p.J + WPC * RPW - 1) / (WPC * RPW) * (WPC * RPW);
+  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
     const bool exists = j < p.J;
     const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
     const bool live = tok >= 0 && !(mrow && mrow[tok]);
@@ -177,6 +198,31 @@ __global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
     for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a1 + __shfl_xor(acc[i], o) * a2;
     m = mn;
   }
+  if (WPC > 1) {                                           // merge the waves' (m, l, acc) in wave order
+    __shared__ float red_ml[WPC][2];
+    __shared__ float red_acc[WPC][D];
+    if (rg == 0) {
+      if (c == 0) { red_ml[wave][0] = m; red_ml[wave][1] = l; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red_acc[wave][c * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < WPC; ++w) m = fmaxf(m, red_ml[w][0]);
+    const float ms = m == -INFINITY ? 0.f : m;
+    l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPC; ++w) {
+      const float aw = __expf(red_ml[w][0] - ms);
+      l += red_ml[w][1] * aw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += red_acc[w][c * 8 + i] * aw;
+    }
+  }
   if (rg == 0) {
     const float inv = 1.f / l;
     float* dst = p.beta_out + (size_t)chunk_id * D + c * 8;
@@ -187,11 +233,12 @@ __global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
 
 // beta backward.  With p_j = softmax_j(x_j):  dv_j += p_j dbeta;  dx_j = p_j (v_j.dbeta - beta.dbeta);
 // dk_j += dx_j s (w - k_j);  dw += sum_j dx_j s k_j   (masked / outside slots carry no gradient).
-template <typename E, int D>
+template <typename E, int D, int WPC>
 __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, int nc) {
   constexpr int CPR = D / 8, RPW = 64 / CPR;
-  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR;
-  const long chunk_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR, wave = threadIdx.x >> 6;
+  const int sub = WPC == 1 ? 0 : wave;
+  const long chunk_id = WPC == 1 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
   if (chunk_id >= (long)p.B * p.H * p.L) return;
   const int cidx = (int)(chunk_id % p.L);
   if (nc > 1) {
@@ -216,10 +263,10 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
 #pragma unroll
   for (int i = 0; i < 8; ++i) bd += bt[i] * db[i];
   bd = chan_sum<CPR>(bd);                                   // beta . dbeta
-  const int jmax = (p.J + RPW - 1) / RPW * RPW;
+  const int jmax = (p.J + WPC * RPW - 1) / (WPC * RPW) * (WPC * RPW);
   // pass 1: log-sum-exp of the chunk's logits
   float m = -INFINITY, l = 0.f;
-  for (int j = rg; j < jmax; j += RPW) {
+  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
     const bool exists = j < p.J;
     const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
     const bool live = tok >= 0 && !(mrow && mrow[tok]);
@@ -247,12 +294,25 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
     l = l * __expf(m - ms) + l2 * __expf(m2 - ms);
     m = mn;
   }
+  __shared__ float red_ml[WPC][2];
+  __shared__ float red_dom[WPC][D];
+  if (WPC > 1) {
+    if (lane == 0) { red_ml[wave][0] = m; red_ml[wave][1] = l; }
+    __syncthreads();
+    m = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < WPC; ++w) m = fmaxf(m, red_ml[w][0]);
+    const float ms = m == -INFINITY ? 0.f : m;
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPC; ++w) l += red_ml[w][1] * __expf(red_ml[w][0] - ms);
+  }
   const float lse = m + __logf(l);
   // pass 2: gradients
   float dom[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) dom[i] = 0.f;
-  for (int j = rg; j < jmax; j += RPW) {
+  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
     const bool exists = j < p.J;
     const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
     const bool live = tok >= 0 && !(mrow && mrow[tok]);
@@ -288,6 +348,20 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) dom[i] = rows_sum<CPR>(dom[i]);
+  if (WPC > 1) {
+    if (rg == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red_dom[wave][c * 8 + i] = dom[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dom[i] = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPC; ++w) dom[i] += red_dom[w][c * 8 + i];
+    }
+  }
   if (rg == 0) {
     float* dst = p.domega + (size_t)chunk_id * D + c * 8;
     *reinterpret_cast<float4*>(dst) = make_float4(dom[0], dom[1], dom[2], dom[3]);
@@ -299,22 +373,34 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
 template <typename E, int D>
 static int launch_lm(int which, const LmP& p, hipStream_t st) {
   const long chunks = (long)p.B * p.H * p.L;
-  const dim3 grid((unsigned)((chunks + 3) / 4)), block(256);
+  // long chunks, or too few chunks to give every CU a few waves: four waves per chunk
+  const bool coop = p.J >= 128 || (p.J >= 64 && chunks < 4096);
+  const dim3 grid((unsigned)(coop ? chunks : (chunks + 3) / 4)), block(256);
   // overlapping chunks (e > 0): chunks closer than nc = 1 + ceil(2e/r) per dimension share
   // tokens, so nc (1-D) / nc*nc (2-D) colour classes are launched back to back and the
   // read-modify-writes of one launch never touch the same token.
   const int nc = p.e > 0 ? 1 + (2 * p.e + p.r - 1) / p.r : 1;
   const int ncolour = p.G.attn2d ? nc * nc : nc;
   switch (which) {
-    case 0: hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D>), grid, block, 0, st, p); break;
-    case 1:
-      for (int col = 0; col < ncolour; ++col)
-        hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D>), grid, block, 0, st, p, col, nc);
+    case 0:
+      if (coop) hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D, 4>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D, 1>), grid, block, 0, st, p);
       break;
-    case 2: hipLaunchKernelGGL((beta_fwd_kernel<E, D>), grid, block, 0, st, p); break;
+    case 1:
+      for (int col = 0; col < ncolour; ++col) {
+        if (coop) hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 4>), grid, block, 0, st, p, col, nc);
+        else hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 1>), grid, block, 0, st, p, col, nc);
+      }
+      break;
+    case 2:
+      if (coop) hipLaunchKernelGGL((beta_fwd_kernel<E, D, 4>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((beta_fwd_kernel<E, D, 1>), grid, block, 0, st, p);
+      break;
     case 3:
-      for (int col = 0; col < ncolour; ++col)
-        hipLaunchKernelGGL((beta_bwd_kernel<E, D>), grid, block, 0, st, p, col, nc);
+      for (int col = 0; col < ncolour; ++col) {
+        if (coop) hipLaunchKernelGGL((beta_bwd_kernel<E, D, 4>), grid, block, 0, st, p, col, nc);
+        else hipLaunchKernelGGL((beta_bwd_kernel<E, D, 1>), grid, block, 0, st, p, col, nc);
+      }
       break;
   }
   return (int)hipGetLastError();
