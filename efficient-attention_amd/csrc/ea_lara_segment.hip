@@ -64,14 +64,11 @@ __global__ __launch_bounds__(256) void lara_segment_kernel(const SegP p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = a_dg[i] = a_db[i] = a_bu[i] = a_bm[i] = 0.f;
 
-  const int iters = (len + RPI - 1) / RPI;
-  for (int it = 0; it < iters; ++it) {
-    const int off = it * RPI + rl;
-    const bool valid = off < len;
-    const int tok = s0 + (valid ? off : 0);                 // clamped: the load is unconditional
-    const bool masked = mrow && mrow[tok];
+  // one row per lane group and step; two steps are fetched together so that their global loads and
+  // the shuffle reductions of the LayerNorm statistics overlap
+  auto row = [&](const u32x4 raw, int tok, bool valid, bool masked) {
     float f[8];
-    unpack8<E>(ldg16(src + (tok * sn + cl * 8) * 2), f);
+    unpack8<E>(raw, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] += masked ? m8[i] : b8[i];
     float xh[8], rs = 1.f;
@@ -91,10 +88,9 @@ __global__ __launch_bounds__(256) void lara_segment_kernel(const SegP p) {
       for (int i = 0; i < 8; ++i) xh[i] = f[i];
     }
     if (!BWD) {
-      if (valid) {
+      const float w = valid ? 1.f : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += g8[i] * xh[i] + c8[i];
-      }
+      for (int i = 0; i < 8; ++i) acc[i] += w * (g8[i] * xh[i] + c8[i]);
     } else {
       float dh[8];
       if (ln) {
@@ -119,6 +115,17 @@ __global__ __launch_bounds__(256) void lara_segment_kernel(const SegP p) {
         }
       }
     }
+  };
+  const int iters = (len + RPI - 1) / RPI;
+  for (int it = 0; it < iters; it += 2) {
+    const int off0 = it * RPI + rl, off1 = off0 + RPI;
+    const bool v0 = off0 < len, v1 = off1 < len;
+    const int tok0 = s0 + (v0 ? off0 : 0), tok1 = s0 + (v1 ? off1 : 0);     // clamped: unconditional loads
+    const u32x4 r0 = ldg16(src + (tok0 * sn + cl * 8) * 2);
+    const u32x4 r1 = ldg16(src + (tok1 * sn + cl * 8) * 2);
+    const bool k0 = mrow && mrow[tok0], k1 = mrow && mrow[tok1];
+    row(r0, tok0, v0, k0);
+    row(r1, tok1, v1, k1);
   }
   if (!BWD) {
     float* out = (side ? p.kbar : p.qbar) + ((size_t)bh * p.L + l) * D + cl * 8;
