@@ -17,14 +17,16 @@ from . import _native as nv
 KERNEL_TIMER = nv.KERNEL_TIMER
 # algorithmic HBM traffic of one launch, in units of one [B,H,N,D] I/O-dtype tensor
 def landmark_flops(BH, L, C, D, has_mlp, mixed, eva, bwd):
-    """Algorithmic FLOPs of one ea_lara_landmarks_fwd/bwd launch (real sizes, 2 per multiply-add):
-    the matrix products of ea_lara_landmark.hip; the backward recomputes the forward."""
+    """FLOPs executed by one ea_lara_landmarks_fwd/bwd launch (real sizes, 2 per multiply-add): the
+    matrix products of ea_lara_landmark.hip.  The backward reloads the forward's saved intermediates
+    and only recomputes M = omega mu^T."""
     f = 0
-    if has_mlp:
-        f += 2 * (2 * L * D * D)                      # H = P W^T, both sides
-    if not eva:
-        if mixed:
+    if not bwd:
+        if has_mlp:
+            f += 2 * (2 * L * D * D)                  # H = P W^T, both sides
+        if not eva and mixed:
             f += 2 * (2 * L * L * D)                  # A = k0 k0^T ; k_bar = A k0
+    if not eva:
         f += 2 * C * L * D                            # M = omega mu^T
     if bwd:
         if not eva:
