@@ -77,6 +77,56 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
 
   EA_STAMP(p, 0);
   EA_BLK(p, 0);
+  constexpr bool KEYS = MODE == LX_BWDK || MODE == LX_PBWDK;
+  constexpr bool TWO_TOK = MODE == LX_BWDQ || MODE == LX_BWDK || MODE == LX_PBWDQ || MODE == LX_PBWDK;
+  const T4l& tk1 = KEYS ? p.k : p.q;
+  const char* t1b = tk1.p + (b * tk1.sb + h * tk1.sh) * 2;
+  const T4l& tk2 = KEYS ? p.v : p.dout;
+  const char* t2b = tk2.p ? tk2.p + (b * tk2.sb + h * tk2.sh) * 2 : nullptr;
+  const float invC = 1.f / (float)p.C;
+  const int n0 = blk * p.tok_per_block;
+  const int n1 = min(p.N, n0 + p.tok_per_block);
+
+  // Software prefetch: the token fragments of this wave's NEXT tile are in flight while the
+  // current tile computes, so a tile costs one exposed memory round trip per wave, not one per tile.
+  constexpr bool NEED_O = MODE == LX_PBWDQ;
+  // (Straight-line on purpose: the tile index and the token are clamped instead of branched on --
+  // rows fetched for tokens >= n1 are never stored -- because with a conditional refill hipcc
+  // parks the fragment arrays in scratch memory and the prefetch turns synchronous.)
+  u32x4 nx1[KS], nx2[KS], nx3[KS];
+  const int last_tok = n1 - 1;
+  auto issue = [&](int tile_) {
+    const int tok_ = min(n0 + tile_ * 16 + li, last_tok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(t1b + (tok_ * tk1.sn + eo) * 2);
+      if (TWO_TOK) nx2[ks] = ldg16(t2b + (tok_ * tk2.sn + eo) * 2);
+      if (NEED_O) nx3[ks] = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok_ * p.o.sn + eo) * 2);
+    }
+  };
+  // the first tile's token rows are requested before anything else: their round trip hides
+  // behind the staging of the landmark matrices
+  if (n0 + wave * 16 < n1) issue(wave);   // (uniform per wave)
+  // per-landmark scalars: one landmark per thread (Cp <= 128), loaded before the matrices so that
+  // every global load of the prologue is in flight together (one exposed round trip, not two)
+  float sc_v0 = -INFINITY, sc_v1 = INFINITY, sc_v2 = 1.f;
+  {
+    const int c = tid;
+    const bool ok = c < p.C;
+    if (MODE == LX_BWDK) { sc_v0 = INFINITY; sc_v1 = 0.f; sc_v2 = 0.f; }
+    if (MODE == LX_PBWDK) sc_v2 = 0.f;
+    if (ok) {
+      if (MODE == LX_FWD || MODE == LX_BWDQ) {
+        sc_v0 = p.cst[lm + c] * LOG2E;
+        if (p.mis == MIS_OPT) sc_v2 = p.bhv[lm + c];
+      }
+      if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && p.mis == MIS_OPT) sc_v1 = p.lse_t[lm + c] * LOG2E;
+      if (MODE == LX_BWDK) { sc_v0 = p.lse_k[lm + c] * LOG2E; sc_v1 = p.dkk[lm + c]; sc_v2 = p.rsum[lm + c]; }
+      if (MODE == LX_POUT || MODE == LX_PBWDQ) sc_v0 = p.cst[lm + c];       // sum_n phi(k_n)[j]
+      if (MODE == LX_PBWDK) sc_v2 = p.rsum[lm + c];                         // d ksum[j]
+    }
+  }
   // ---- stage the landmark matrices: ALL global loads are issued before the first conversion /
   // LDS store, so the workgroup pays one memory round trip here instead of one per matrix ----
   {
@@ -138,23 +188,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   float* SC0 = reinterpret_cast<float*>(M2 + D * MT_LDB);
   float* SC1 = SC0 + Cp;
   float* SC2 = SC1 + Cp;
-  for (int c = tid; c < Cp; c += 256) {
-    const bool ok = c < p.C;
-    float v0 = -INFINITY, v1 = INFINITY, v2 = 1.f;
-    if (MODE == LX_BWDK) { v0 = INFINITY; v1 = 0.f; v2 = 0.f; }
-    if (MODE == LX_PBWDK) v2 = 0.f;
-    if (ok) {
-      if (MODE == LX_FWD || MODE == LX_BWDQ) {
-        v0 = p.cst[lm + c] * LOG2E;
-        if (p.mis == MIS_OPT) v2 = p.bhv[lm + c];
-      }
-      if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && p.mis == MIS_OPT) v1 = p.lse_t[lm + c] * LOG2E;
-      if (MODE == LX_BWDK) { v0 = p.lse_k[lm + c] * LOG2E; v1 = p.dkk[lm + c]; v2 = p.rsum[lm + c]; }
-      if (MODE == LX_POUT || MODE == LX_PBWDQ) v0 = p.cst[lm + c];       // sum_n phi(k_n)[j]
-      if (MODE == LX_PBWDK) v2 = p.rsum[lm + c];                         // d ksum[j]
-    }
-    SC0[c] = v0; SC1[c] = v1; SC2[c] = v2;
-  }
+  if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
   struct LdsVec {
     const float* base; int g;
     EA_DEV float operator()(int ct, int r) const { return base[ct * 16 + 4 * g + r]; }
@@ -167,35 +201,6 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   int prof_it = 0;
   (void)prof_it;
 
-  constexpr bool KEYS = MODE == LX_BWDK || MODE == LX_PBWDK;
-  constexpr bool TWO_TOK = MODE == LX_BWDQ || MODE == LX_BWDK || MODE == LX_PBWDQ || MODE == LX_PBWDK;
-  const T4l& tk1 = KEYS ? p.k : p.q;
-  const char* t1b = tk1.p + (b * tk1.sb + h * tk1.sh) * 2;
-  const T4l& tk2 = KEYS ? p.v : p.dout;
-  const char* t2b = tk2.p ? tk2.p + (b * tk2.sb + h * tk2.sh) * 2 : nullptr;
-  const float invC = 1.f / (float)p.C;
-  const int n0 = blk * p.tok_per_block;
-  const int n1 = min(p.N, n0 + p.tok_per_block);
-
-  // Software prefetch: the token fragments of this wave's NEXT tile are in flight while the
-  // current tile computes, so a tile costs one exposed memory round trip per wave, not one per tile.
-  constexpr bool NEED_O = MODE == LX_PBWDQ;
-  // (Straight-line on purpose: the tile index and the token are clamped instead of branched on --
-  // rows fetched for tokens >= n1 are never stored -- because with a conditional refill hipcc
-  // parks the fragment arrays in scratch memory and the prefetch turns synchronous.)
-  u32x4 nx1[KS], nx2[KS], nx3[KS];
-  const int last_tok = n1 - 1;
-  auto issue = [&](int tile_) {
-    const int tok_ = min(n0 + tile_ * 16 + li, last_tok);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int eo = (g * KS + ks) * 8;
-      nx1[ks] = ldg16(t1b + (tok_ * tk1.sn + eo) * 2);
-      if (TWO_TOK) nx2[ks] = ldg16(t2b + (tok_ * tk2.sn + eo) * 2);
-      if (NEED_O) nx3[ks] = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tok_ * p.o.sn + eo) * 2);
-    }
-  };
-  if (n0 + wave * 16 < n1) issue(wave);   // (uniform per wave)
   for (int tile = wave; n0 + tile * 16 < n1; tile += 4) {
     const int tok = n0 + tile * 16 + li;
     const bool valid = tok < n1;
