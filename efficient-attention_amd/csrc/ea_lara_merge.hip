@@ -36,14 +36,18 @@ __global__ __launch_bounds__(256) void lara_merge_fwd_kernel(const MergeP p) {
     p.cst[o] = lsek - p.lp[o];
   }
   __syncthreads();
-  for (int idx = tid; idx < C * D; idx += 256) {
-    const int c = idx / D;
-    float acc = 0.f;
+  // four channels per thread (16-B loads; D % 4 == 0)
+  for (int e = tid * 4; e < C * D; e += 1024) {
+    const int c = e / D, j = e - c * D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
       const size_t slot = ((size_t)bh * S + s) * C + c;
-      acc += p.p_kv[slot * D + (idx - c * D)] * __expf(p.p_ml[slot * 4] - Mk[c]);
+      const float w = __expf(p.p_ml[slot * 4] - Mk[c]);
+      const float4 v = *reinterpret_cast<const float4*>(p.p_kv + slot * D + j);
+      acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
     }
-    p.kv[(size_t)bh * C * D + idx] = acc * inv[c];
+    const float iv = inv[c];
+    *reinterpret_cast<float4*>(p.kv + (size_t)bh * C * D + e) = make_float4(acc.x * iv, acc.y * iv, acc.z * iv, acc.w * iv);
   }
 }
 
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void lara_merge_fwd_kernel(const MergeP p) {
 __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
   const int bh = blockIdx.x, tid = threadIdx.x;
   const int C = p.C, D = p.D, S = p.S;
-  __shared__ float us[128], dk[128];
+  __shared__ float us[128];
   for (int c = tid; c < C; c += 256) {
     float r = 0.f, dbh = 0.f, u = 0.f;
     for (int s = 0; s < S; ++s) {
@@ -65,31 +69,50 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
     if (p.dbh) p.dbh[o] = dbh;
     if (p.dlp) p.dlp[o] = -r;
     us[c] = u;
-    dk[c] = 0.f;
   }
   __syncthreads();
-  for (int idx = tid; idx < C * D; idx += 256) {
-    const int c = idx / D, j = idx - c * D;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  // four channels per thread (16-B loads); the D/4 lanes of a row sit in one wave, so
+  // dkk[c] = dkv[c] . kv[c] is a fixed-order shuffle reduction (no LDS atomics)
+  const int lpr = D >> 2;                                  // lanes per landmark row: 16 (D = 64) or 8
+  const int n4 = (C * D) >> 2;
+  for (int base = 0; base < n4; base += 256) {
+    const int i4 = base + tid;
+    const bool ok = i4 < n4;
+    const int e = (ok ? i4 : 0) * 4;
+    const int c = e / D, j = e - c * D;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
     for (int s = 0; s < S; ++s) {
-      const size_t e = (((size_t)bh * S + s) * C + c) * D + j;
-      a0 += p.acc0[e];
-      a1 += p.acc1[e];
-      if (p.has_t) { a2 += p.acc2[e]; a3 += p.acc3[e]; }
+      const size_t o4 = (((size_t)bh * S + s) * C + c) * D + j;
+      const float4 v0 = *reinterpret_cast<const float4*>(p.acc0 + o4);
+      const float4 v1 = *reinterpret_cast<const float4*>(p.acc1 + o4);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      if (p.has_t) {
+        const float4 v2 = *reinterpret_cast<const float4*>(p.acc2 + o4);
+        const float4 v3 = *reinterpret_cast<const float4*>(p.acc3 + o4);
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
     }
-    const size_t o = (size_t)bh * C * D + idx;
-    p.dkv[o] = a0;
-    p.domq[o] = a1;
-    if (p.has_t) {
-      p.dqbar[o] = p.scale * (a2 - us[c] * a3);
-      p.uq[o] = us[c] * p.qbar[o];
-    } else if (p.dqbar) {
-      p.dqbar[o] = p.scale * a1;                       // mis-biased: d(mu rows) = s sum dZ q
+    const size_t o = (size_t)bh * C * D + e;
+    const float4 kv4 = *reinterpret_cast<const float4*>(p.kv + o);
+    float dot = a0.x * kv4.x + a0.y * kv4.y + a0.z * kv4.z + a0.w * kv4.w;
+    for (int sh = 1; sh < lpr; sh <<= 1) dot += __shfl_xor(dot, sh);
+    if (ok) {
+      *reinterpret_cast<float4*>(p.dkv + o) = a0;
+      *reinterpret_cast<float4*>(p.domq + o) = a1;
+      if (p.has_t) {
+        const float u = us[c], sc = p.scale;
+        const float4 qb = *reinterpret_cast<const float4*>(p.qbar + o);
+        *reinterpret_cast<float4*>(p.dqbar + o) =
+            make_float4(sc * (a2.x - u * a3.x), sc * (a2.y - u * a3.y), sc * (a2.z - u * a3.z), sc * (a2.w - u * a3.w));
+        *reinterpret_cast<float4*>(p.uq + o) = make_float4(u * qb.x, u * qb.y, u * qb.z, u * qb.w);
+      } else if (p.dqbar) {                              // mis-biased: d(mu rows) = s sum dZ q
+        *reinterpret_cast<float4*>(p.dqbar + o) = make_float4(p.scale * a1.x, p.scale * a1.y, p.scale * a1.z, p.scale * a1.w);
+      }
+      if (j == 0) p.dkk[(size_t)bh * C + c] = dot;
     }
-    atomicAdd(&dk[c], a0 * p.kv[o]);
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) p.dkk[(size_t)bh * C + c] = dk[c];
 }
 
 int lara_merge_dispatch(bool bwd, const MergeP& p, hipStream_t st) {
