@@ -19,8 +19,8 @@ KERNEL_TO_ENTRY = [
     ("lara_lmk_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lara_lmk_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("lara_merge_fwd_kernel", "ea_lara_merge_fwd"), ("lara_merge_bwd_kernel", "ea_lara_merge_bwd"),
     ("win_fwd_kernel<ea::BF16, 64>", "ea_window_attn_fwd"), ("win_bwd_kernel<ea::BF16, 64", "ea_window_attn_bwd"),
-    ("chunk_mean_fwd_kernel<ea::BF16, 64>", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<ea::BF16, 64>", "ea_eva_chunk_mean_bwd"),
-    ("beta_fwd_kernel<ea::BF16, 64>", "ea_eva_beta_fwd"), ("beta_bwd_kernel<ea::BF16, 64>", "ea_eva_beta_bwd"),
+    ("chunk_mean_fwd_kernel<ea::BF16, 64", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<ea::BF16, 64", "ea_eva_chunk_mean_bwd"),
+    ("beta_fwd_kernel<ea::BF16, 64", "ea_eva_beta_fwd"), ("beta_bwd_kernel<ea::BF16, 64", "ea_eva_beta_bwd"),
     ("sm_fwd_kernel<ea::BF16, 64>", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dq)"),
     ("sm_bwd_dkv_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dkv)"),
     ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
