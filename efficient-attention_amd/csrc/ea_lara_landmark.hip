@@ -24,6 +24,14 @@ namespace ea {
 constexpr int LMK_T = 1024;     // 16 waves: every 16x16 tile of a 64x64 product gets its own wave
 constexpr int LMK_W = LMK_T / 64;
 constexpr int LD = 65;          // row stride (floats) of every LDS matrix
+// Matrix products: fp32 matrices in LDS, operands rounded to fp16 (11 significant bits, 8x finer than
+// the bf16 operands autocast gives the reference's own Linear / einsum here) when a tile is fetched,
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation -- 1/16 of the matrix-pipe time of the exact-fp32
+// v_mfma_f32_16x16x4_f32 (which made this kernel matrix-pipe bound: 2048 cycles per 64^3 product
+// and SIMD).  Gradient-side operands (dM, d k_bar, dG, dH) are pre-scaled by a per-matrix power of
+// two taken from their block-wide maximum, so loss scaling cannot push them out of fp16 range.
+// LMK_HALF = false keeps the exact-fp32 products (debugging).
+constexpr bool LMK_HALF = true;
 constexpr int BUF = 64 * LD;
 
 // C[m][n] (+)= alpha * sum_k A(m,k) B(k,n) (+ colbias[n]); A, B in LDS (fp32), C in LDS or global;
@@ -39,6 +47,7 @@ struct MMJob {
   int M, N, K;
   float alpha;
   const float* colbias;
+  float sa, sb;                 // power-of-two pre-scales of the A / B operand (fp16 range), undone in alpha
 };
 struct MMOp { float av[16], bv[16]; };
 
@@ -65,12 +74,28 @@ EA_DEV void mm_load(MMOp& o, const MMJob& j, int tile, int lane) {
     o.bv[ks] = ks < nk ? b : 0.f;
   }
 }
-EA_DEV f32x4 mm_chain(const MMOp& o, int K, f32x4 acc) {
-  const int steps = (K + 3) >> 2;
+EA_DEV f32x4 mm_chain(const MMOp& o, const MMJob& j, f32x4 acc) {
+  const int steps = (j.K + 3) >> 2;
+  if (LMK_HALF) {
+    // k-slot (s, j') of the 32-deep MFMA step s <-> this lane's ks = 8 s + j' (same map for A and B)
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 xa0, xa1, xb0, xb1;
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks)
-    if (ks < steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[ks], o.bv[ks], acc, 0, 0, 0);
-  return acc;
+    for (int i = 0; i < 8; ++i) {
+      xa0[i] = (_Float16)(o.av[i] * j.sa); xa1[i] = (_Float16)(o.av[8 + i] * j.sa);
+      xb0[i] = (_Float16)(o.bv[i] * j.sb); xb1[i] = (_Float16)(o.bv[8 + i] * j.sb);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa0, xb0, acc, 0, 0, 0);
+    if (steps > 8) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa1, xb1, acc, 0, 0, 0);
+    return acc;
+  }
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 16; ks += 2) {             // two accumulation chains (even / odd k-steps)
+    if (ks < steps) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[ks] * j.sa, o.bv[ks] * j.sb, acc, 0, 0, 0);
+    if (ks + 1 < steps) b = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[ks + 1] * j.sa, o.bv[ks + 1] * j.sb, b, 0, 0, 0);
+  }
+  return acc + b;
 }
 template <bool ACC>
 EA_DEV void mm_store(const MMJob& j, int tile, int lane, f32x4 acc) {
@@ -80,64 +105,26 @@ EA_DEV void mm_store(const MMJob& j, int tile, int lane, f32x4 acc) {
   const int bn = n0 + li;
   if (bn < j.N) {
     const float cb = j.colbias ? j.colbias[bn] : 0.f;
+    const float al = j.alpha / (j.sa * j.sb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + 4 * g + r;
-      if (m < j.M) j.C[m * j.ldc + bn] = (ACC ? j.C[m * j.ldc + bn] + j.alpha * acc[r] : j.alpha * acc[r]) + cb;
+      if (m < j.M) j.C[m * j.ldc + bn] = (ACC ? j.C[m * j.ldc + bn] + al * acc[r] : al * acc[r]) + cb;
     }
   }
 }
 
-// C (+)= alpha * A B (+ colbias).  A wave takes its tiles two at a time and fetches the operands of
-// BOTH before the first MFMA, so the second fetch and the two 16-deep MFMA chains overlap instead of
-// running fetch -> chain -> fetch -> chain (the fp32 matrix pipe is the bound of this kernel: a
-// 64x64x64 product is 2048 cycles of it per SIMD).  An odd tile out is paired with a recomputation
-// of the last tile whose store is skipped (keeps the instruction stream branch-free).
+// C (+)= alpha * A B (+ colbias); sa / sb: power-of-two pre-scales of the operands (gradient matrices).
+// A tile per wave, tiles round-robin over the waves; all LDS reads of a tile precede its MFMAs.
 template <bool TA, bool TB, bool ACC>
 EA_DEV void mm(float* C, int ldc, const float* A, int lda, const float* B, int ldb, int M, int N, int K,
-               float alpha, int tid, const float* colbias = nullptr) {
-  const MMJob j = {C, ldc, A, lda, B, ldb, M, N, K, alpha, colbias};
+               float alpha, int tid, const float* colbias = nullptr, float sa = 1.f, float sb = 1.f) {
+  const MMJob j = {C, ldc, A, lda, B, ldb, M, N, K, alpha, colbias, sa, sb};
   const int lane = tid & 63, wave = tid >> 6;
-  const int nt = mm_tiles(j);
-  if (LMK_W >= 16) {                 // a tile per wave: two accumulation chains (even / odd k-steps)
-    for (int t1 = wave; t1 < nt; t1 += LMK_W) {
-      MMOp o1;
-      mm_load<TA, TB>(o1, j, t1, lane);
-      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, b1 = a1;
-      const int steps = (K + 3) >> 2;
-#pragma unroll
-      for (int ks = 0; ks < 16; ks += 2) {
-        if (ks < steps) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks], o1.bv[ks], a1, 0, 0, 0);
-        if (ks + 1 < steps) b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks + 1], o1.bv[ks + 1], b1, 0, 0, 0);
-      }
-      a1 += b1;
-      mm_store<ACC>(j, t1, lane, a1);
-    }
-    return;
-  }
-  for (int t1 = wave; t1 < nt; t1 += 2 * LMK_W) {
-    const int t2 = min(t1 + LMK_W, nt - 1);
-    MMOp o1, o2;
-    mm_load<TA, TB>(o1, j, t1, lane);
-    mm_load<TA, TB>(o2, j, t2, lane);
-    // four independent accumulation chains (two per tile) keep the matrix pipe busy
-    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
-    const int steps = (K + 3) >> 2;
-#pragma unroll
-    for (int ks = 0; ks < 16; ks += 2) {
-      if (ks < steps) {
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks], o1.bv[ks], a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(o2.av[ks], o2.bv[ks], a2, 0, 0, 0);
-      }
-      if (ks + 1 < steps) {
-        b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(o1.av[ks + 1], o1.bv[ks + 1], b1, 0, 0, 0);
-        b2 = __builtin_amdgcn_mfma_f32_16x16x4f32(o2.av[ks + 1], o2.bv[ks + 1], b2, 0, 0, 0);
-      }
-    }
-    a1 += b1;
-    a2 += b2;
-    mm_store<ACC>(j, t1, lane, a1);
-    if (t1 + LMK_W < nt) mm_store<ACC>(j, t2, lane, a2);
+  for (int t = wave; t < mm_tiles(j); t += LMK_W) {
+    MMOp o;
+    mm_load<TA, TB>(o, j, t, lane);
+    mm_store<ACC>(j, t, lane, mm_chain(o, j, f32x4{0.f, 0.f, 0.f, 0.f}));
   }
 }
 
@@ -149,10 +136,26 @@ EA_DEV void mm_sum2(const MMJob& j1, const MMJob& j2, int tid) {
     MMOp o1, o2;
     mm_load<TA1, TB1>(o1, j1, tile, lane);
     mm_load<TA2, TB2>(o2, j2, tile, lane);
-    f32x4 acc = mm_chain(o1, j1.K, f32x4{0.f, 0.f, 0.f, 0.f});
-    acc = mm_chain(o2, j2.K, acc);
+    f32x4 acc = mm_chain(o1, j1, f32x4{0.f, 0.f, 0.f, 0.f});
+    acc = mm_chain(o2, j2, acc);                         // (same operand scales in both)
     mm_store<true>(j1, tile, lane, acc);
   }
+}
+
+EA_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// power-of-two 1/scale for a matrix whose per-wave maxima of |x| sit in gm[0..n): m * scale in [0.5, 1)
+EA_DEV float pow2_inv_scale(const float* gm, int n) {
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) m = fmaxf(m, gm[i]);
+  if (!(m > 0.f) || m > 3e38f) return 1.f;
+  int e;
+  (void)frexpf(m, &e);
+  return ldexpf(1.f, -e);
 }
 
 // sum over the 16 lanes that share lane>>4 (xor shuffles below 16 stay inside the group)
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   float* musq = vec + 128;     // |mu_l|^2
   float* dmcol = vec + 192;    // column sums of dM
   float* pv = vec + 256;       // affine params: gq, cq, gk, ck, bq, bk (6 x D)
+  float* gmx = pv + 6 * D;     // [4][16] per-wave max |x| of the gradient matrices dM, d k_bar, dG, dH
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.x;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       pre_dbh = p.d_bhv ? p.d_bhv[(size_t)bh * C + rrow] : 0.f;
     }
   }
+  if (BWD && tid < 64) gmx[tid] = 0.f;
   if (p.has_mlp) {
     for (int i = tid; i < D; i += LMK_T) {
       pv[i] = p.gq[i]; pv[D + i] = p.cq[i]; pv[2 * D + i] = p.gk[i]; pv[3 * D + i] = p.ck[i];
@@ -489,12 +494,18 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
         dlse = pre_dlp;
       }
       const float mult = p.mis == 0 ? (float)nrep : 1.f;
+      float gm = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int l = cbase + i;
-        if (r_ok && l < L)
-          S6[c * LD + l] = dlse * __expf(x[i] - lse) * mult + ((p.mis == 0 && l == cl) ? dlp : 0.f);
+        if (r_ok && l < L) {
+          const float dm = dlse * __expf(x[i] - lse) * mult + ((p.mis == 0 && l == cl) ? dlp : 0.f);
+          S6[c * LD + l] = dm;
+          gm = fmaxf(gm, fabsf(dm));
+        }
       }
+      gm = wave_max(gm);
+      if (lane == 0) gmx[wave] = gm;
     }
   }
   if (!BWD) return;
@@ -514,13 +525,15 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     if (li == 0 && ccol < L) dmcol[ccol] = a;
   }
   {
-    mm<true, false, false>(S3, LD, S6, LD, S7, LD, L, D, C, s, tid);             // dMU = s dM^T OM
-    mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid);             // dOM += s dM MU
+    const float sdm = pow2_inv_scale(gmx, 4);
+    mm<true, false, false>(S3, LD, S6, LD, S7, LD, L, D, C, s, tid, nullptr, sdm);       // dMU = s dM^T OM
+    mm<false, false, true>(S4, LD, S6, LD, S0, LD, C, D, L, s, tid, nullptr, sdm);       // dOM += s dM MU
   }
   __syncthreads();
   STAMP(11);
   // ---- B3: fold the C sample rows onto the L landmarks (omega_c = mu[c mod L] +- eps) ----
   //   S3 <- d mu = d k_bar (common part), S6 <- d q_bar, S7 <- k0 (mixed) / S4 <- d k0 (not mixed)
+  float gkb = 0.f;
   for (int idx = tid; idx < L * D; idx += LMK_T) {
     const int r = idx / D, j = idx % D, o = r * LD + j;
     float dm = S3[o] - s * dmcol[r] * S0[o], dqx = 0.f;
@@ -530,17 +543,21 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
       if (p.mis == 0 && p.d_qbar_rows) dqx += S8[c * LD + j];
     }
     S3[o] = dm;
+    gkb = fmaxf(gkb, fabsf(dm));
     S6[o] = dm + dqx;
     if (p.mixed) S7[o] = K0(r, j); else S4[o] = dm;
   }
+  gkb = wave_max(gkb);
+  if (lane == 0) gmx[16 + wave] = gkb;
   // re-issue the Linear operands of the parameter-gradient stage; they land during the mixing backward
   if (p.has_mlp) { issue(r_pq, p.pq + oL, L); issue(r_pk, p.pk + oL, L); issue(r_wq, p.Wq, D); issue(r_wk, p.Wk, D); }
   __syncthreads();
   STAMP(12);
   // ---- B4..B6: mixing backward.  S4 <- d k0 ----
   if (p.mixed) {
-    mm<true, false, false>(S4, LD, S5, LD, S3, LD, L, D, L, 1.f, tid);          // dK0 = A^T dKb
-    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid);          // dA = dKb K0^T  (MU is dead)
+    const float skb = pow2_inv_scale(gmx + 16, 16);
+    mm<true, false, false>(S4, LD, S5, LD, S3, LD, L, D, L, 1.f, tid, nullptr, 1.f, skb);   // dK0 = A^T dKb
+    mm<false, true, false>(S0, LD, S3, LD, S7, LD, L, L, D, 1.f, tid, nullptr, skb, 1.f);   // dA = dKb K0^T  (MU is dead)
     __syncthreads();
     STAMP(13);
     if (wave < 4) {                                                             // dG = A o (dA - rowsum(A o dA)), in S0
@@ -554,15 +571,23 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
         rs += a[i] * d[i];
       }
       rs = quad_sum(rs);
+      float gm = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        if (r_ok && cbase + i < L) S0[rrow * LD + cbase + i] = a[i] * (d[i] - rs);
+        if (r_ok && cbase + i < L) {
+          const float dg = a[i] * (d[i] - rs);
+          S0[rrow * LD + cbase + i] = dg;
+          gm = fmaxf(gm, fabsf(dg));
+        }
+      gm = wave_max(gm);
+      if (lane == 0) gmx[32 + wave] = gm;
     }
     __syncthreads();
     STAMP(14);
+    const float sdg = pow2_inv_scale(gmx + 32, 4);
     mm_sum2<false, false, true, false>(                                         // dK0 += s (dG + dG^T) K0
-        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr},
-        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr}, tid);
+        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr, sdg, 1.f},
+        MMJob{S4, LD, S0, LD, S7, LD, L, D, L, s, nullptr, sdg, 1.f}, tid);
     __syncthreads();
     STAMP(15);
   }
@@ -619,9 +644,16 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
     s1 = quad_sum(s1) / D;
     s2 = quad_sum(s2) / D;
     const float rs = r_ok ? (wave < 4 ? rstd_q : rstd_k)[rrow] : 0.f;
+    float gm = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (r_ok && cbase + i < D) dY[rrow * LD + cbase + i] = rs * (dxh[i] - s1 - xh[i] * s2);
+      if (r_ok && cbase + i < D) {
+        const float dh = rs * (dxh[i] - s1 - xh[i] * s2);
+        dY[rrow * LD + cbase + i] = dh;
+        gm = fmaxf(gm, fabsf(dh));
+      }
+    gm = wave_max(gm);
+    if (lane == 0) gmx[48 + wave] = gm;
   }
   __syncthreads();
   STAMP(17);
@@ -639,15 +671,16 @@ __global__ __launch_bounds__(LMK_T) void lara_lmk_kernel(const LmkP p) {
   {
     float* dWq = p.dW_part + ((size_t)bh * 2 + 0) * D * D;
     float* dWk = p.dW_part + ((size_t)bh * 2 + 1) * D * D;
-    mm<false, false, false>(p.dpq + oL, D, S6, LD, S7, LD, L, D, D, 1.f, tid);
-    mm<false, false, false>(p.dpk + oL, D, S4, LD, S5, LD, L, D, D, 1.f, tid);
-    mm<true, false, false>(dWq, D, S6, LD, S0, LD, D, D, L, 1.f, tid);                    // dW[out][in]
-    mm<true, false, false>(dWk, D, S4, LD, S3, LD, D, D, L, 1.f, tid);
+    const float shq = pow2_inv_scale(gmx + 48, 4), shk = pow2_inv_scale(gmx + 52, 4);
+    mm<false, false, false>(p.dpq + oL, D, S6, LD, S7, LD, L, D, D, 1.f, tid, nullptr, shq);
+    mm<false, false, false>(p.dpk + oL, D, S4, LD, S5, LD, L, D, D, 1.f, tid, nullptr, shk);
+    mm<true, false, false>(dWq, D, S6, LD, S0, LD, D, D, L, 1.f, tid, nullptr, shq);        // dW[out][in]
+    mm<true, false, false>(dWk, D, S4, LD, S3, LD, D, D, L, 1.f, tid, nullptr, shk);
   }
   STAMP(18);
 }
 
-size_t lara_lmk_lds(int D) { return ((size_t)9 * BUF + 256 + 6 * D) * sizeof(float); }
+size_t lara_lmk_lds(int D) { return ((size_t)9 * BUF + 256 + 6 * D + 64) * sizeof(float); }
 
 template <int D>
 static int launch_lmk(bool bwd, const LmkP& p, hipStream_t st) {

@@ -155,3 +155,42 @@ def test_full_batch_slice_matches_oracle(attn):
     for name, got, want in (("y", y.detach().float()[sl].cpu(), ref.detach()), ("dx", x.grad[sl].cpu(), xr.grad)):
         e = scaled_err(got.numpy(), want.numpy())
         assert e[0] <= tol[0] and e[1] <= tol[1], (attn, name, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["lara", "eva"])
+def test_backward_is_loss_scale_invariant(attn):
+    """The landmark pipeline multiplies fp16-rounded operands; its gradient-side matrices carry a
+    per-matrix power-of-two scale so that a loss scale cannot push them out of fp16 range:
+    backward(2^20 * g) == 2^20 * backward(g) (to rounding), and nothing overflows."""
+    import bench
+    torch.manual_seed(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = bench.build_layer(attn, C, H, G, "cuda")
+    m.train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    bsz = 16
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.randn(bsz, G, G, C, device="cuda", generator=gen)
+    gy = torch.randn(bsz, G, G, C, device="cuda", generator=gen)
+    grads = []
+    for scale in (1.0, 2.0 ** 20):
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(77)                       # same sampling noise in both runs
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        (y.float() * gy * scale).sum().backward()
+        g = {"x": x.grad.float() / scale}
+        g.update({k: p.grad.float() / scale for k, p in m.named_parameters() if p.grad is not None})
+        grads.append(g)
+    for k, a in grads[0].items():
+        b = grads[1][k]
+        assert torch.isfinite(b).all(), k
+        err = (a - b).abs().max().item()
+        ref = a.abs().max().item()
+        assert err <= 2e-2 * ref + 1e-12, (k, err, ref)
