@@ -32,7 +32,6 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 DEFAULT_ATTN = "lara"
-FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv) at d=64, bf16
 
@@ -329,11 +328,16 @@ def main():
             common = {"kernel": name, "traffic": traffic, "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
                       "all_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}}
             if name in ("ea_lara_landmarks_fwd", "ea_lara_landmarks_bwd") and _ops.LAST_LMK_GEOM:
-                # tiny-matrix pipeline in LDS: bounded by the exact-fp32 matrix pipe, not by HBM
-                flops = _ops.landmark_flops(*_ops.LAST_LMK_GEOM, bwd=name.endswith("bwd"))
-                ach = flops / (st["avg_ms"] * 1e-3) / 1e12
-                roof = dict(common, bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), algo_flops_per_launch=flops)
+                # tiny-matrix pipeline in LDS (fp16-operand MFMA, ~1 % of the matrix peak): latency-bound;
+                # priced on the tensors it has to move, with its executed FLOPs alongside
+                bwd = name.endswith("bwd")
+                algo_bytes = _ops.landmark_bytes(*_ops.LAST_LMK_GEOM, bwd=bwd)
+                flops = _ops.landmark_flops(*_ops.LAST_LMK_GEOM, bwd=bwd)
+                ach = algo_bytes / (st["avg_ms"] * 1e-3) / 1e9
+                roof = dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 4), algo_bytes_per_launch=algo_bytes,
+                            algo_flops_per_launch=flops,
+                            mfma_tflops=round(flops / (st["avg_ms"] * 1e-3) / 1e12, 2))
             else:
                 units = _ops.KERNEL_ALGO_UNITS.get(name, 0)      # [B,H,N,D] tensors read+written per launch
                 algo_bytes = units * B * H * N * d * 2
@@ -342,7 +346,7 @@ def main():
                             frac=round(ach / HBM_PEAK_GBS, 4), algo_bytes_per_launch=algo_bytes)
             # the streaming kernel with the largest total time, for reference next to an mfma-bound dominant
             hb = [(k, v) for k, v in ktimes.items() if k in _ops.KERNEL_ALGO_UNITS]
-            if hb and roof["bound"] != "hbm":
+            if hb and name not in _ops.KERNEL_ALGO_UNITS:
                 k2, v2 = max(hb, key=lambda kv: kv[1]["total_ms"])
                 b2 = _ops.KERNEL_ALGO_UNITS[k2] * B * H * N * d * 2
                 a2 = b2 / (v2["avg_ms"] * 1e-3) / 1e9

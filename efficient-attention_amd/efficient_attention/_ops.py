@@ -38,6 +38,22 @@ def landmark_flops(BH, L, C, D, has_mlp, mixed, eva, bwd):
     return BH * f
 
 
+def landmark_bytes(BH, L, C, D, has_mlp, mixed, eva, bwd):
+    """Algorithmic HBM bytes of one ea_lara_landmarks_fwd/bwd launch: the [B*h, L|C, D] fp32 tensors it
+    must read and write (the pipeline itself lives in LDS; parameters and per-landmark scalars are
+    negligible).  The kernel is latency-bound -- these are the bytes its roofline is priced on."""
+    row = D * 4
+    saved = (3 * L * D + 64 * L + 128) * 4
+    if not bwd:
+        per = 2 * L * row + C * row + 2 * C * row + saved           # pq, pk, noise -> omega, qbar_rows, saved
+    else:
+        per = saved + C * row + 2 * C * row + 2 * L * row            # saved, noise, d_omega, d_qbar_rows, pq/pk
+        per += 2 * L * row                                           # -> dpq, dpk
+        if has_mlp:
+            per += 2 * D * D * 4 + 6 * D * 4                         # -> dW_part, dvec_part
+    return BH * per
+
+
 LAST_LMK_GEOM = None      # (BH, L, C, D, has_mlp, mixed, eva) of the most recent landmark launch (bench.py)
 
 KERNEL_ALGO_UNITS = {
