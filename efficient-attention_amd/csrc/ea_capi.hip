@@ -32,7 +32,7 @@ static bool t4_ok32(const ea_t4* t, int D, int N) {
 }
 static bool geom_ok(const ea_geom* g) {
   return g && g->B > 0 && g->H > 0 && g->N > 0 && (g->D == 32 || g->D == 64 || g->D == 128) &&
-         (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0;
+         (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0 && g->causal >= 0 && g->causal <= 2;
 }
 static Geo mk_geo(const ea_geom* g) {
   Geo G;
@@ -43,7 +43,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 1; }
+int32_t ea_abi_version(void) { return 2; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -68,6 +68,7 @@ static int fill_win(const ea_geom* g, WinP& p, bool backward) {
   if (g->L < 0 || g->L > 64) return EA_E_UNSUPPORTED;      // landmark tiles owned 1:1 by 4 waves
   p.G = mk_geo(g);
   p.B = g->B; p.H = g->H; p.L = g->L; p.w = g->window; p.e = g->ext;
+  p.causal = g->causal; p.chunk = g->chunk;
   p.scale = g->scale;
   p.scale_log2 = g->scale * LOG2E;
   return EA_OK;
@@ -114,10 +115,12 @@ static int fill_lm(const ea_geom* g, LmP& p) {
   if (!geom_ok(g) || g->chunk <= 0 || g->L <= 0) return EA_E_BADARG;
   p.G = mk_geo(g);
   if (g->attn_2d && (g->gh * g->gw != g->N)) return EA_E_BADARG;
-  const int side = g->chunk + 2 * g->ext;
+  if (g->causal && (g->attn_2d || g->N % g->chunk)) return EA_E_BADARG;
+  const int ext = g->causal ? 0 : g->ext;                  // causal_eva.py:688-694: chunks are not extended
+  const int side = g->chunk + 2 * ext;
   const int nchunks = g->attn_2d ? (g->gh / g->chunk) * (g->gw / g->chunk) : g->N / g->chunk;
   if (nchunks != g->L) return EA_E_BADARG;
-  p.B = g->B; p.H = g->H; p.L = g->L; p.r = g->chunk; p.e = g->ext;
+  p.B = g->B; p.H = g->H; p.L = g->L; p.r = g->chunk; p.e = ext;
   p.J = g->attn_2d ? side * side : side;
   p.scale = g->scale;
   return EA_OK;

@@ -27,6 +27,7 @@ struct WinTiling {
   int sub_x;           // windows per row of this class (2-D)
   int blk0;            // offset of this launch's workgroups in the *_part buffers
   int parts_total;     // workgroups per (b,h) summed over the classes (leading dim of *_part)
+  int causal;          // ea_geom.causal: left-only extension, query-padding and causal masks
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -87,7 +88,11 @@ inline bool win_colour(const ea_geom& g, WinTiling& t, int cy, int cx) {
 
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
+  if (g.causal < 0 || g.causal > 2 || (g.causal && (g.attn_2d || g.N % g.window))) return EA_E_BADARG;
+  if (g.causal == 2 && g.L > 0 && g.chunk <= 0) return EA_E_BADARG;
   const int w = g.window, e = g.ext;
+  const int kext = g.causal ? e : 2 * e;             // keys beyond the window's own tokens
+  t.causal = g.causal;
   if (g.attn_2d) {
     if (g.gh <= 0 || g.gw <= 0 || g.gh * g.gw != g.N || g.gh % w || g.gw % w) return EA_E_BADARG;
     t.Wq = w * w;
@@ -95,7 +100,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
     t.nwin = (g.gh / w) * (g.gw / w);
   } else {
     t.Wq = w;
-    t.Wk = w + 2 * e;
+    t.Wk = w + kext;
     t.nwin = ceil_div(g.N, w);
   }
   t.nQT = ceil_div(t.Wq, 16);
@@ -111,7 +116,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   win_blocks(g, t, backward);
   t.parts_total = t.nblk;
   if (backward && e > 0) {
-    t.ncx = 1 + ceil_div(2 * e, w);
+    t.ncx = 1 + ceil_div(kext, w);
     t.ncy = g.attn_2d ? t.ncx : 1;
     int total = 0;
     for (int cy = 0; cy < t.ncy; ++cy)
@@ -148,6 +153,7 @@ struct WinP {
   float *dk32, *dv32;                        // bwd, overlap (e > 0): fp32 atomics scratch [B,H,N,D]
   Geo G;
   int B, H, L, w, e;
+  int causal, chunk;                         // ea_geom.causal and the landmark chunk length (causal masks)
   float scale, scale_log2;
   WinTiling t;
   int bias_lds;                              // bwd: the bias table of the head is staged in LDS
@@ -186,6 +192,20 @@ EA_DEV int colour_win(const WinTiling& t, const Geo& G, int w, int lw) {
   if (!G.attn2d) return lw * t.ncx + t.col_x;
   const int sy = lw / t.sub_x, sx = lw - sy * t.sub_x;
   return (sy * t.ncy + t.col_y) * (G.gw / w) + sx * t.ncx + t.col_x;
+}
+// causal_eva.py visibility limits of one query: the last visible local key slot and the last visible
+// landmark.  A padded query sees no local key (:742-755); with the causal masks, query slot i sees
+// local slots j <= i + e (:767-773) and the landmarks of the chunks before its own (:716-738).
+struct QLim { int local, lm; };
+EA_DEV QLim query_limits(int causal, int qslot, int qtok, int e, int chunk, const uint8_t* mrow) {
+  QLim r;
+  r.local = 0x7fffffff; r.lm = 0x7fffffff;
+  if (causal >= 2) {
+    r.local = qslot + e;
+    r.lm = (qtok >= 0 && chunk > 0) ? qtok / chunk - 1 : -1;
+  }
+  if (qtok < 0 || (mrow && mrow[qtok])) r.local = -1;
+  return r;
 }
 EA_DEV int slot_token(const Geo& G, int packed, int oy, int ox) {
   if (G.attn2d) {

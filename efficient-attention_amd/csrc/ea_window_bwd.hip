@@ -21,7 +21,9 @@ namespace ea {
 // GB: the bias table is too large for LDS and is read from global memory (bias / biasT); otherwise
 // every bias read goes to LDS -- the staged table, or a block of zeros when there is no bias -- so
 // that the inner loops carry no branches and hipcc can interleave the independent tiles.
-template <typename E, int D, bool GB>
+// CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits, staged per
+// query row in LDS for phase B.
+template <typename E, int D, bool GB, bool CA>
 __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   float* kadd = kmul + t.rowsTotal;
   int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
   int* qd = kd + t.nLT * 16;
+  int* qlim_s = qd + nQTe * 16;                      // CA only: last visible local slot / landmark per query row
+  int* clim_s = qlim_s + rowsQ;
   const int rowsPerWin = t.nLT * 16;
 
   constexpr bool PHASE_A_GLOBAL_BIAS = GB;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
     // staging costs ~one memory round trip per iteration instead of one per 256-slot sweep. ----
     constexpr int NB = 2;
     struct KVb { u32x4 kr[NB], vr[NB]; int rowv[NB]; float mulv[NB], addv[NB]; };
-    struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB]; int rowv[NB]; };
+    struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB]; int rowv[NB]; QLim lim[NB]; };
     auto issueKV = [&](KVb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             tok = slot_token(p.G, qd[slot], oy, ox);
           }
           x.rowv[i] = row;
+          if (CA && c == 0) x.lim[i] = query_limits(p.causal, slot, tok, p.e, p.chunk, mrow);
           if (tok >= 0) {
             x.qr[i] = ldg16(qb + (tok * qsn + c * 8) * 2);
             x.dr[i] = ldg16(dob + (tok * dosn + c * 8) * 2);
@@ -209,7 +214,10 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
           sts16(Qs + lds_off<D>(x.rowv[i], c), x.qr[i]);
           sts16(dOs + lds_off<D>(x.rowv[i], c), x.dr[i]);
-          if (c == 0) { delta_s[x.rowv[i]] = part; lse_s[x.rowv[i]] = x.lsv[i]; }
+          if (c == 0) {
+            delta_s[x.rowv[i]] = part; lse_s[x.rowv[i]] = x.lsv[i];
+            if (CA) { qlim_s[x.rowv[i]] = x.lim[i].local; clim_s[x.rowv[i]] = x.lim[i].lm; }
+          }
         }
       }
     };
@@ -257,6 +265,9 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
         dof[ks] = as_x8<E>(lds16(dOs + (qrow - li) * ROWB + lo.plain[ks]));
       }
       const float lse2 = lse_s[qrow], delta = delta_s[qrow];
+      QLim ql;
+      ql.local = ql.lm = 0x7fffffff;
+      if (CA) { ql.local = qlim_s[qrow]; ql.lm = clim_s[qrow]; }
       const float* brow = (GB && p.bias)
           ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
       const float* brow_s = bread + (qslot < t.Wq ? qslot : 0) * brs + 4 * g;
@@ -294,13 +305,21 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             b4 = make_float4(bs[0] * lf, bs[1] * lf, bs[2] * lf, bs[3] * lf);
           }
           const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+          const int kidx0 = (local ? tile : tile - t.nLT) * 16 + 4 * g;
+          const int lim = local ? ql.local : ql.lm;
           float ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
+            float x = fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
+            float gm = mm[r];
+            if (CA) {
+              const bool blocked = kidx0 + r > lim;
+              x = blocked ? fminf(x, MASK_FILL * LOG2E) : x;
+              gm = blocked ? 0.f : gm;
+            }
             const float pr = fast_exp2(x - lse2);
             // masked_fill blocks the gradient of the replaced logits (mul == 0)
-            ds[r] = mm[r] * pr * (dp[r] - delta);
+            ds[r] = gm * pr * (dp[r] - delta);
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
@@ -388,6 +407,11 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
               const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq[u] + 4 * g);
               const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq[u] + 4 * g);
               const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+              int vis[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};   // CA: last visible key of each query
+              if (CA) {
+                const int4 v4 = *reinterpret_cast<const int4*>((is_lm ? clim_s : qlim_s) + rq[u] + 4 * g);
+                vis[0] = v4.x; vis[1] = v4.y; vis[2] = v4.z; vis[3] = v4.w;
+              }
               const int q0 = qt * 16 + 4 * g;            // first of this lane's four query slots
               float bt[4] = {0.f, 0.f, 0.f, 0.f};
               if (BM != 0) {
@@ -410,9 +434,15 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
                 const int qs = q0 + r;                    // query slot in the window
                 const bool bias_on = BM != 0 && qs < t.Wq && kslot < t.Wk;
                 const float bias = bias_on ? bt[r] : 0.f;
-                const float x = fmaf(kmu, fmaf(s[r], p.scale_log2, bias), kad);
+                float x = fmaf(kmu, fmaf(s[r], p.scale_log2, bias), kad);
+                float gm = kmu;
+                if (CA) {
+                  const bool blocked = kslot > vis[r];
+                  x = blocked ? fminf(x, MASK_FILL * LOG2E) : x;
+                  gm = blocked ? 0.f : gm;
+                }
                 pr[r] = fast_exp2(x - ll[r]);
-                ds[r] = kmu * pr[r] * (dp[r] - dd[r]);
+                ds[r] = gm * pr[r] * (dp[r] - dd[r]);
                 if (BM == 1) {
                   float* dst = bias_on ? dbias_s + qs * BLD + kslot : trash64 + lane;
                   *dst += ds[r];
@@ -538,6 +568,7 @@ size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
   size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
   if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
   b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
+  if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
   return b;
 }
 
@@ -549,9 +580,11 @@ static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t s
   const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   const bool gb = p.bias && !p.bias_lds;
+  using KernelT = void (*)(const WinP, const T4, const float*);
+  const KernelT kern = p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
+                                : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(gb ? reinterpret_cast<const void*>(&win_bwd_kernel<E, D, true>)
-                                          : reinterpret_cast<const void*>(&win_bwd_kernel<E, D, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
@@ -563,8 +596,7 @@ static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t s
   }
   if (p.e == 0) {
     const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-    if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, p, outp, biasT);
-    else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, p, outp, biasT);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, outp, biasT);
   } else {
     // one launch per colour class (stream order separates the classes)
     ea_geom gg = {};
@@ -577,8 +609,7 @@ static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t s
         pc.t.blk0 = blk0;
         blk0 += pc.t.nblk;
         const dim3 grid((unsigned)(p.B * p.H * pc.t.nblk));
-        if (gb) hipLaunchKernelGGL((win_bwd_kernel<E, D, true>), grid, dim3(256), lds, st, pc, outp, biasT);
-        else hipLaunchKernelGGL((win_bwd_kernel<E, D, false>), grid, dim3(256), lds, st, pc, outp, biasT);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pc, outp, biasT);
       }
   }
   if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);

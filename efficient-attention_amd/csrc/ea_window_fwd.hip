@@ -22,7 +22,9 @@
 
 namespace ea {
 
-template <typename E, int D>
+// CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits on top of the
+// per-key (mul, add) pairs.
+template <typename E, int D, bool CA>
 __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
   constexpr int ROWB = D * 2;      // bytes per LDS row
   constexpr int CPR = D / 8;       // 16-byte chunks per row
@@ -164,6 +166,10 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
       const float* brow = p.bias
           ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
 
+      QLim ql;
+      ql.local = ql.lm = 0x7fffffff;
+      if (CA) ql = query_limits(p.causal, qslot, qtok, p.e, p.chunk, mrow);
+
       float m = -INFINITY, lsum = 0.f;
       f32x4 o[DT];
 #pragma unroll
@@ -196,9 +202,12 @@ __global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           const float bb[4] = {b4[tt].x, b4[tt].y, b4[tt].z, b4[tt].w};
+          const int kidx0 = (local ? tile : tile - t.nLT) * 16 + 4 * g;   // key slot / landmark id of r = 0
+          const int lim = local ? ql.local : ql.lm;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = fmaf(mm[r], fmaf(acc[r], p.scale_log2, bb[r]), aa[r]);
+            float x = fmaf(mm[r], fmaf(acc[r], p.scale_log2, bb[r]), aa[r]);
+            if (CA) x = kidx0 + r > lim ? fminf(x, MASK_FILL * LOG2E) : x;  // absent slots stay -inf
             acc[r] = x;
             mloc = fmaxf(mloc, x);
           }
@@ -261,18 +270,22 @@ size_t window_fwd_lds(const WinTiling& t, int D) {
   return (size_t)t.rowsTotal * D * 2 * 2 + (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + t.nQT * 16) * 4;
 }
 
-template <typename E, int D>
-static int launch_fwd(const WinP& p, hipStream_t st) {
+template <typename E, int D, bool CA>
+static int launch_fwd_ca(const WinP& p, hipStream_t st) {
   const size_t lds = window_fwd_lds(p.t, D);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D, CA>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  hipLaunchKernelGGL((win_fwd_kernel<E, D>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((win_fwd_kernel<E, D, CA>), grid, dim3(256), lds, st, p);
   return (int)hipGetLastError();
+}
+template <typename E, int D>
+static int launch_fwd(const WinP& p, hipStream_t st) {
+  return p.causal ? launch_fwd_ca<E, D, true>(p, st) : launch_fwd_ca<E, D, false>(p, st);
 }
 
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st) {

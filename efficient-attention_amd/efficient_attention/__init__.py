@@ -59,7 +59,8 @@ from .local_attention import LocalAttention  # noqa: E402
 from .kernelized_attention import KernelizedAttention  # noqa: E402
 from .lara import LinearRA  # noqa: E402
 from .eva import EVA  # noqa: E402
-from ._unported import RandomizedAttention, ScatterBrain, CausalEVAttention  # noqa: E402
+from .causal_eva import CausalEVAttention  # noqa: E402
+from ._unported import RandomizedAttention, ScatterBrain  # noqa: E402
 
 
 class AttentionFactory(object):

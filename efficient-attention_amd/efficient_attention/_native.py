@@ -22,12 +22,15 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
+ABI_VERSION = 2          # ea_abi_version() of include/ea_hip.h this file mirrors
+
+
 class ea_geom(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("attn_2d", ctypes.c_int32),
                 ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32),
                 ("ext", ctypes.c_int32), ("chunk", ctypes.c_int32), ("L", ctypes.c_int32),
-                ("scale", ctypes.c_float)]
+                ("scale", ctypes.c_float), ("causal", ctypes.c_int32)]
 
 
 class ea_perf_geom(ctypes.Structure):
@@ -117,6 +120,9 @@ def lib():
         cdll.ea_lara_landmarks_saved_floats.restype = ctypes.c_int64
         cdll.ea_version.restype = ctypes.c_char_p
         cdll.ea_abi_version.restype = ctypes.c_int32
+        if cdll.ea_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s has ABI version %d, this package binds version %d -- rebuild it "
+                               "(__graft_entry__.build())" % (_LIB_PATH, cdll.ea_abi_version(), ABI_VERSION))
         _lib = cdll
     return _lib
 
@@ -158,10 +164,10 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0):
+def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0, causal=0):
     gh, gw = (seq_shape if attn_2d else (1, N))
     return ea_geom(B, H, N, D, dtype, 1 if attn_2d else 0, gh, gw, window, ext, chunk, L,
-                   float(D) ** -0.5)
+                   float(D) ** -0.5, causal)
 
 
 class KernelTimer:

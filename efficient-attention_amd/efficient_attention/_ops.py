@@ -195,8 +195,9 @@ class LocalAttnFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # EVA  (reference eva.py:145-227)
 # ------------------------------------------------------------------------------------------
-def eva_mu(qmean, kmean, params, adaptive_proj):
-    """rf_k_bar, mu from the chunk means (eva.py:178-185). fp32, [B,h,L,d] -- tiny."""
+def eva_mu(qmean, kmean, params, adaptive_proj, mu_scale=0.5):
+    """rf_k_bar, mu from the chunk means (eva.py:178-185; causal_eva.py:706-709 with
+    mu_scale = 1). fp32, [B,h,L,d] -- tiny."""
     d = kmean.shape[-1]
     if adaptive_proj in ("default", "no-ln"):
         if adaptive_proj == "default":
@@ -206,7 +207,7 @@ def eva_mu(qmean, kmean, params, adaptive_proj):
         else:
             wq, bq, wk, bk = params
             rq, rk = F.linear(qmean, wq, bq), F.linear(kmean, wk, bk)
-        return rk, 0.5 * (rq + rk)
+        return rk, mu_scale * (rq + rk)
     wk, bk, gk, ck = params
     rk = F.layer_norm(F.linear(kmean, wk, bk), (d,), gk, ck, 1e-5)
     return rk, torch.zeros_like(rk)
@@ -214,22 +215,26 @@ def eva_mu(qmean, kmean, params, adaptive_proj):
 
 class EvaAttnFn(torch.autograd.Function):
     """EVA core on a fused qkv tensor: chunk means -> mu MLP -> omega -> beta -> window attention
-    with control-variate columns.  Returns out [B,N,h,d]."""
+    with control-variate columns.  Returns out [B,N,h,d].
+    cfg = (attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj[, causal, mu_scale]); the last
+    two select causal_eva.py's geometry/masks (ea_geom.causal) and its mu = rq + rk."""
 
     @staticmethod
     def forward(ctx, qkv5, bias, noise, mask_u8, cfg, *mlp_params):
         nv.require_cuda(qkv5, "qkv")
-        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg
+        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg[:7]
+        causal, mu_scale = cfg[7:9] if len(cfg) > 7 else (0, 0.5)
         B, N, _, h, d = qkv5.shape
         dev = qkv5.device
-        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, chunk, L)
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, chunk, L,
+                            causal)
         q, k, v = _qkv_views(qkv5)
         tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
         qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
         kmean = torch.empty_like(qmean)
         nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
                 nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
-        fused_mu = adaptive_proj == "default" and L <= 64 and d in (32, 64)
+        fused_mu = adaptive_proj == "default" and L <= 64 and d in (32, 64) and mu_scale == 0.5
         if fused_mu:
             # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
             lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
@@ -247,7 +252,8 @@ class EvaAttnFn(torch.autograd.Function):
         else:
             # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
             with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
-                rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj)
+                rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj,
+                                      mu_scale)
                 omega = (mu if noise is None else mu + noise.float()).contiguous()
                 rf_k_bar = rf_k_bar.contiguous()
             ctx.lmk = None
@@ -260,6 +266,7 @@ class EvaAttnFn(torch.autograd.Function):
                               *mlp_params)
         ctx.geom = geom
         ctx.adaptive_proj = adaptive_proj
+        ctx.mu_scale = mu_scale
         ctx.bias_cols = None if bias is None else bias.shape[-1]
         return out
 
@@ -305,7 +312,7 @@ class EvaAttnFn(torch.autograd.Function):
             qm = qmean.detach().requires_grad_(True)
             km = kmean.detach().requires_grad_(True)
             ps = [p.detach().float().requires_grad_(True) for p in mlp_params]
-            rk, mu = eva_mu(qm, km, ps, ctx.adaptive_proj)
+            rk, mu = eva_mu(qm, km, ps, ctx.adaptive_proj, ctx.mu_scale)
             outs, gouts = [rk], [d_rfk.contiguous()]
             if mu.requires_grad:
                 outs.append(mu)

@@ -1,5 +1,5 @@
 """Factory entries of the reference that are outside this build's hot-path scope (SURVEY.md 8:
-`ra`, `scatterbrain`, `causal_eva` are marked "next").  They keep the names importable and fail
+`ra` and `scatterbrain` are marked "next").  They keep the names importable and fail
 loudly on construction instead of silently running something else."""
 import torch.nn as nn
 
@@ -19,7 +19,3 @@ class RandomizedAttention(_Unported):
 
 class ScatterBrain(_Unported):
     _what = "ScatterBrain ('scatterbrain')"
-
-
-class CausalEVAttention(_Unported):
-    _what = "CausalEVAttention ('causal_eva')"

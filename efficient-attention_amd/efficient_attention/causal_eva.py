@@ -1,0 +1,250 @@
+"""Causal EVA for autoregressive language modelling (fairseq decoder self-attention), MI355X build.
+
+Mirrors efficient_attention/causal_eva.py:301-927 of the reference: the fairseq
+MultiheadAttention-style constructor (`embed_dim, num_heads, kdim, vdim, dropout, bias,
+self_attention, q_noise, qn_block_size, attn_args`), the parameters `q_proj / k_proj / v_proj /
+out_proj`, `adaptive_mu_q/k` and the single-head `rel_pos_bias`, time-first
+`forward(query, key, value, key_padding_mask=None, incremental_state=None, ...) -> (out, None)`,
+the incremental-state helpers fairseq's decoder calls, and the argparse flags.
+
+The training / evaluation path (reference :666-790: chunk means -> mu -> beta, window attention
+whose extension lies on the left only, padded queries masked, causal local mask and per-chunk causal
+control-variate mask under one softmax) runs in libea_hip.so through `_ops.EvaAttnFn` with
+`ea_geom.causal` set; there is no CPU fallback.  Token-by-token decoding with an incremental state
+(reference :542-665) is not built yet and raises.
+"""
+import math
+import uuid
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import add_nested_argument
+from . import _ops
+from .eva import T5RelativePositionBias
+
+
+def _mu_net(d, with_ln):
+    return nn.Sequential(*([nn.Linear(d, d)] + ([nn.LayerNorm(d)] if with_ln else [])))
+
+
+class CausalEVAttention(nn.Module):
+    def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True,
+                 self_attention=False, q_noise=0.0, qn_block_size=8, attn_args=None):
+        super().__init__()
+        self._incremental_state_id = str(uuid.uuid4())
+        self.embed_dim = embed_dim
+        self.kdim = embed_dim if kdim is None else kdim
+        self.vdim = embed_dim if vdim is None else vdim
+        self.qkv_same_dim = self.kdim == embed_dim and self.vdim == embed_dim
+        self.num_heads = num_heads
+        self.dropout_module = nn.Dropout(dropout)       # attribute fairseq reads; p > 0 in training raises
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
+        self.scaling = self.head_dim ** -0.5
+        self.self_attention = self_attention
+        assert not self_attention or self.qkv_same_dim, \
+            "Self-attention requires query, key and value to be of the same size"
+        if q_noise > 0:
+            raise NotImplementedError("quantization noise on the projections (q_noise > 0)")
+        self.k_proj = nn.Linear(self.kdim, embed_dim, bias=bias)
+        self.v_proj = nn.Linear(self.vdim, embed_dim, bias=bias)
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+        self.window_size = attn_args.window_size
+        self.ext_size = max(1, self.window_size) if attn_args.overlap_window else 0
+        self.causal = attn_args.causal
+        self.num_chunks = attn_args.num_chunks
+        self.chunk_size = attn_args.chunk_size
+        if self.chunk_size is not None:
+            assert self.window_size >= self.chunk_size and self.window_size % self.chunk_size == 0
+            self.num_chunks = None                      # chunk_size overrides the number of landmarks
+        self.use_t5_rpe = attn_args.use_t5_rpe if attn_args.window_size > 0 else False
+        if self.use_t5_rpe:
+            span = self.window_size + self.ext_size
+            self.rel_pos_bias = T5RelativePositionBias(
+                self.scaling, num_heads=1, causal=self.causal,
+                num_buckets=max(min(int(span / 2), 64), 16), max_distance=span)
+        else:
+            self.rel_pos_bias = None
+        self.adaptive_proj = attn_args.adaptive_proj
+        if self.adaptive_proj in ("qk", "no-ln"):
+            ln = self.adaptive_proj == "qk"
+            self.adaptive_mu_q = _mu_net(self.head_dim, ln)
+            self.adaptive_mu_k = _mu_net(self.head_dim, ln)
+        self.reset_parameters()
+        self.onnx_trace = False
+
+    # ---- initialisation (reference :397-424) ----------------------------------------------
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight, gain=1 / math.sqrt(2))
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def reset_parameters(self):
+        gain = 1 / math.sqrt(2) if self.qkv_same_dim else 1.0
+        for proj in (self.k_proj, self.v_proj, self.q_proj):
+            nn.init.xavier_uniform_(proj.weight, gain=gain)
+        for name in ("adaptive_mu_q", "adaptive_mu_k"):
+            if hasattr(self, name):
+                getattr(self, name).apply(self._init_weights)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        if self.out_proj.bias is not None:
+            nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def prepare_for_onnx_export_(self):
+        self.onnx_trace = True
+
+    # ---- forward ---------------------------------------------------------------------------
+    def _mu_params(self):
+        q, k = self.adaptive_mu_q, self.adaptive_mu_k
+        if self.adaptive_proj == "qk":
+            return [q[0].weight, q[0].bias, q[1].weight, q[1].bias,
+                    k[0].weight, k[0].bias, k[1].weight, k[1].bias]
+        return [q[0].weight, q[0].bias, k[0].weight, k[0].bias]
+
+    def _project(self, query, key, value):
+        """-> fused [B, N, 3, h, d] in the kernels' I/O dtype."""
+        B, N, C = query.shape
+        if self.self_attention:
+            # one GEMM over the stacked weights instead of three over the same activations
+            weight = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], 0)
+            biases = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
+            bias = None if biases[0] is None else torch.cat(biases, 0)
+            qkv = _ops.linear_wb(query, weight, bias)
+        else:
+            assert key is not None and value is not None
+            assert key.shape[:2] == query.shape[:2] and value.shape[:2] == query.shape[:2], \
+                "the windowed path needs keys/values aligned with the queries"
+            qkv = torch.stack([_ops.linear(query, self.q_proj), _ops.linear(key, self.k_proj),
+                               _ops.linear(value, self.v_proj)], dim=2)
+        if qkv.dtype not in (torch.bfloat16, torch.float16):
+            qkv = qkv.to(torch.bfloat16)
+        return qkv.reshape(B, N, 3, self.num_heads, self.head_dim)
+
+    def forward(self, query, key, value, key_padding_mask=None, incremental_state=None,
+                need_weights=True, attn_mask=None):
+        """query/key/value: Time x Batch x Channel; key_padding_mask: [B, T], 1 = pad.
+        Returns (out [T, B, C], None)."""
+        if incremental_state is not None:
+            raise NotImplementedError(
+                "CausalEVAttention: token-by-token decoding with an incremental state "
+                "(causal_eva.py:542-665) is not part of the MI355X build yet")
+        if self.adaptive_proj not in ("qk", "no-ln"):
+            raise NotImplementedError("Other adaptive projection methods are not implemented yet.")
+        if self.training and self.dropout_module.p > 0:
+            raise NotImplementedError("attention dropout inside the fused window-attention kernel")
+        tgt_len, bsz, embed_dim = query.shape
+        assert embed_dim == self.embed_dim, "query dim %d != %d" % (embed_dim, self.embed_dim)
+        w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
+
+        def batch_first(t):
+            t = t.transpose(0, 1)
+            n_pad = int(math.ceil(tgt_len / w) * w) - tgt_len if w > 0 else 0
+            return F.pad(t, (0, 0, 0, n_pad)) if n_pad else t
+
+        x = batch_first(query)
+        B, N, C = x.shape
+        mask = None
+        if key_padding_mask is not None or N != tgt_len:
+            mask = torch.zeros(B, N, dtype=torch.bool, device=x.device)
+            if key_padding_mask is not None:
+                mask[:, :tgt_len] = key_padding_mask.to(torch.bool)
+            mask[:, tgt_len:] = True
+        if self.self_attention:
+            qkv5 = self._project(x, None, None)
+        else:
+            qkv5 = self._project(x, batch_first(key), batch_first(value))
+
+        r = self.chunk_size if self.chunk_size is not None else int(N // self.num_chunks)
+        if r >= N:
+            raise NotImplementedError("a single chunk spanning the sequence (the reference's own "
+                                      "branch for it, causal_eva.py:680-683, does not run either)")
+        assert N % r == 0, "sequence length %d is not a multiple of the chunk size %d" % (N, r)
+        L = N // r
+        bias = None
+        if self.use_t5_rpe:
+            bias = self.rel_pos_bias.dense(w, w + e, x.device).expand(h, w, w + e)
+        noise = None
+        if self.training:
+            noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
+        cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
+               2 if self.causal else 1, 1.0)
+        out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
+                                   *self._mu_params())
+        y = _ops.linear(out.reshape(B, N, C), self.out_proj)
+        if not torch.is_autocast_enabled() and y.dtype != query.dtype:
+            y = y.to(query.dtype)
+        if N != tgt_len:
+            y = y[:, :tgt_len]
+        return y.transpose(0, 1).contiguous(), None
+
+    # ---- fairseq incremental-state protocol (reference :262-297, 836-871) -------------------
+    def init_incremental_state(self):
+        self._incremental_state_id = str(uuid.uuid4())
+
+    def _get_full_incremental_state_key(self, key):
+        return "%s.%s" % (self._incremental_state_id, key)
+
+    def get_incremental_state(self, incremental_state, key):
+        full = self._get_full_incremental_state_key(key)
+        if incremental_state is None or full not in incremental_state:
+            return None
+        return incremental_state[full]
+
+    def set_incremental_state(self, incremental_state, key, value):
+        if incremental_state is not None:
+            incremental_state[self._get_full_incremental_state_key(key)] = value
+        return incremental_state
+
+    def _get_input_buffer(self, incremental_state):
+        found = self.get_incremental_state(incremental_state, "attn_state")
+        return {} if found is None else found
+
+    def _set_input_buffer(self, incremental_state, buffer):
+        return self.set_incremental_state(incremental_state, "attn_state", buffer)
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        buf = self._get_input_buffer(incremental_state)
+        if buf:
+            for k, t in buf.items():
+                if t is not None:
+                    buf[k] = t.index_select(0, new_order)
+            incremental_state = self._set_input_buffer(incremental_state, buf)
+        return incremental_state
+
+    def apply_sparse_mask(self, attn_weights, tgt_len, src_len, bsz):
+        return attn_weights
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        """Split a legacy fused `in_proj_weight/bias` into q/k/v projections (reference :876-903)."""
+        prefix = name + "." if name != "" else ""
+        for key in [k for k in state_dict if k.endswith(prefix + "in_proj_weight")]:
+            fused = state_dict.pop(key)
+            dim = fused.shape[0] // 3
+            for i, p in enumerate(("q_proj", "k_proj", "v_proj")):
+                state_dict[prefix + p + ".weight"] = fused[i * dim:(i + 1) * dim]
+            bkey = prefix + "in_proj_bias"
+            if bkey in state_dict:
+                fb = state_dict.pop(bkey)
+                for i, p in enumerate(("q_proj", "k_proj", "v_proj")):
+                    state_dict[prefix + p + ".bias"] = fb[i * dim:(i + 1) * dim]
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        group = parent_parser.add_argument_group("attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        kw = dict(struct_name=struct_name, prefix=prefix)
+        add_nested_argument(group, "--%sadaptive-proj" % fp, default="default", type=str, **kw)
+        add_nested_argument(group, "--%snum-chunks" % fp, default=None, type=int, **kw)
+        add_nested_argument(group, "--%schunk-size" % fp, default=None, type=int, **kw)
+        add_nested_argument(group, "--%scausal" % fp, action="store_true", default=False, **kw)
+        add_nested_argument(group, "--%suse-t5-rpe" % fp, action="store_true", default=False, **kw)
+        add_nested_argument(group, "--%swindow-size" % fp, default=4, type=int, **kw)
+        add_nested_argument(group, "--%soverlap-window" % fp, action="store_true", default=False, **kw)
+        return parent_parser

@@ -57,6 +57,13 @@ typedef struct {
   int32_t chunk;             /* EVA landmark chunk side r (eva.py:155-158); 0 when unused */
   int32_t L;                 /* number of landmarks / chunks actually produced */
   float   scale;             /* D^-0.5 */
+  int32_t causal;            /* 0: symmetric windows (eva.py, local_attention.py).  causal_eva.py (1-D only):
+                              * 1: the keys of window g are [g*w - e, g*w + w) (causal_window_1d_partition,
+                              *    causal_eva.py:104-116), the landmark chunks carry no extension (:688-694)
+                              *    and the local logits of padded QUERIES are masked as well (:742-755);
+                              * 2: 1 plus the causal masks -- local key j of query i is masked when
+                              *    j > i + e (:767-773) and landmark c unless c < token / chunk (:716-738).
+                              * Masked logits are REPLACED by -5e4 (masked_fill), their gradient is zero. */
 } ea_geom;
 
 /* ---- library info -------------------------------------------------------------------- */

@@ -17,10 +17,11 @@ tests/golden/*.npz.  tests/test_oracle_golden.py checks y, dL/dx and every param
 gradient for all cases in eval and training mode (injected noise) at fp32 tolerance.
 """
 from .geometry import (window_index_1d, window_index_2d, rpe_index_2d, t5_bucket,
-                       adaptive_pool_matrix)
+                       adaptive_pool_matrix, causal_window_index_1d, t5_bucket_causal)
 from .attention import (softmax_core, local_core, eva_core, lara_core, performer_core,
-                        module_forward, default_args)
+                        causal_eva_core, module_forward, default_args)
 
 __all__ = ["window_index_1d", "window_index_2d", "rpe_index_2d", "t5_bucket",
-           "adaptive_pool_matrix", "softmax_core", "local_core", "eva_core", "lara_core",
-           "performer_core", "module_forward", "default_args"]
+           "adaptive_pool_matrix", "causal_window_index_1d", "t5_bucket_causal", "softmax_core",
+           "local_core", "eva_core", "lara_core", "performer_core", "causal_eva_core",
+           "module_forward", "default_args"]

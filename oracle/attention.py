@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from .geometry import (window_index_1d, window_index_2d, rpe_index_2d, t5_bucket,
-                       adaptive_pool_matrix)
+                       adaptive_pool_matrix, causal_window_index_1d, t5_bucket_causal)
 
 MASK_VAL = -5e4      # finite mask value of local/EVA (local_attention.py:141, eva.py:139)
 
@@ -232,6 +232,66 @@ def eva_core(q, k, v, mask, attn_2d, seq_shape, window_size, ext_size, num_landm
 
 
 # --------------------------------------------------------------------------------------
+# causal EVA (training / evaluation path, no incremental state)
+# --------------------------------------------------------------------------------------
+def causal_eva_core(q, k, v, mask, window_size, ext_size, chunk_size, mu_fn, noise=None,
+                    bias=None, causal=True, scale=None):
+    """CausalEVAttention's q,k,v -> out core (causal_eva.py:666-783).
+
+    q,k,v: [B,h,N,d] with N a multiple of the window (after _process_input); mask [B,N] bool or
+    None; chunk_size r divides N.  Differences from eva_core: the window extension lies on the
+    left only (:104-116), chunks are never extended (:688-694), mu = rf_q_bar + rf_k_bar (:709),
+    padded QUERIES are masked as well (:742-755), and with `causal` a query sees the local keys
+    up to itself (:767-773) and the control variates of the chunks before its own (:716-738).
+    bias: None or [Wq, Wk] shared by the heads (:760-762)."""
+    B, h, n, d = q.shape
+    scale = d ** -0.5 if scale is None else scale
+    w, e, r = window_size, ext_size, chunk_size
+    assert n % w == 0 and n % r == 0 and r < n
+    if mask is None:
+        mask = torch.zeros(B, n, dtype=torch.bool)
+    mask = mask.bool()
+    idx_q = window_index_1d(n, w, 0)
+    idx_k = causal_window_index_1d(n, w, e)
+    idx_c = window_index_1d(n, r, 0)
+
+    cmask = _gather_mask(mask, idx_c)                              # [B,C,r]
+    keep = (~cmask)[:, None, :, :, None].to(q.dtype)
+    cq = _gather_tokens(q, idx_c) * keep
+    ck = _gather_tokens(k, idx_c) * keep
+    cv = _gather_tokens(v, idx_c) * keep
+    rf_k_bar, mu = mu_fn(cq.mean(-2), ck.mean(-2))
+    omega = mu if noise is None else mu + noise
+    logit_c = scale * torch.einsum("bhcd,bhcjd->bhcj", omega, ck) \
+        - 0.5 * scale * (ck * ck).sum(-1)
+    logit_c = logit_c.masked_fill(cmask[:, None], MASK_VAL)
+    beta = torch.einsum("bhcj,bhcjd->bhcd", torch.softmax(logit_c, -1), cv)
+
+    wq = _gather_tokens(q, idx_q)
+    wk = _gather_tokens(k, idx_k)
+    wv = _gather_tokens(v, idx_k)
+    cv_logits = scale * torch.einsum("bhwid,bhcd->bhwic", wq, rf_k_bar)
+    if causal:
+        q_chunk = (idx_q // r).unsqueeze(-1)                       # [G,Wq,1]
+        future = torch.arange(idx_c.shape[0]).view(1, 1, -1) >= q_chunk
+        cv_logits = cv_logits.masked_fill(future[None, None], MASK_VAL)
+    dots = scale * torch.einsum("bhwie,bhwje->bhwij", wq, wk)
+    if bias is not None:
+        dots = dots + bias
+    pad = _gather_mask(mask, idx_q)[:, :, :, None] | _gather_mask(mask, idx_k)[:, :, None, :]
+    dots = dots.masked_fill(pad[:, None], MASK_VAL)
+    if causal:
+        i = torch.arange(w).view(-1, 1)
+        j = torch.arange(w + e).view(1, -1)
+        dots = dots.masked_fill((j - i >= 1 + e)[None, None, None], MASK_VAL)
+    Wk = dots.shape[-1]
+    p = torch.softmax(torch.cat([dots, cv_logits], -1), -1)
+    out_w = torch.einsum("bhwij,bhwjd->bhwid", p[..., :Wk], wv) \
+        + torch.einsum("bhwic,bhcd->bhwid", p[..., Wk:], beta)
+    return _scatter_windows(out_w, idx_q, n)
+
+
+# --------------------------------------------------------------------------------------
 # LARA
 # --------------------------------------------------------------------------------------
 def lara_core(q, k, v, mask, q_bar, mu, noise=None, mis_type="mis-opt", alpha_coeff=1.0,
@@ -394,11 +454,14 @@ def _local_bias(params, args, h, e, scale, Wq=None, Wk=None):
 
 
 def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None):
-    """y = module(x, key_padding_mask) for attn in {softmax, local, eva, lara, performer}.
+    """y = module(x, key_padding_mask) for attn in {softmax, local, eva, lara, performer,
+    causal_eva (batch-first x; training/evaluation path)}.
 
     args: constructor kwargs (missing ones take default_args); params: dict of tensors with
     the reference's state_dict keys; noise_fn(shape) -> standard-normal tensor for the i-th
     sampling call of a training-mode forward."""
+    if attn == "causal_eva":
+        return _causal_eva_forward(args, params, x, mask, training, noise_fn)
     a = default_args(attn)
     a.update(args)
     h = a["num_heads"]
@@ -499,3 +562,49 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
         return _merge_proj(out, params, B, seq_shape, C)
 
     raise KeyError(attn)
+
+
+def _causal_eva_forward(args, params, x, mask, training, noise_fn):
+    """CausalEVAttention.forward without incremental state (causal_eva.py:458-536,666-790) on
+    batch-first x [B,T,C] (the module itself is time-first; callers transpose).  args: the
+    constructor kwargs with `attn_args` as a dict (window_size, overlap_window, causal,
+    num_chunks, chunk_size, use_t5_rpe, adaptive_proj)."""
+    aa = dict(adaptive_proj="default", num_chunks=None, chunk_size=None, causal=False,
+              use_t5_rpe=False, window_size=4, overlap_window=False)
+    aa.update(args["attn_args"])
+    h = args["num_heads"]
+    B, T, C = x.shape
+    d = C // h
+    scale = d ** -0.5
+    w = aa["window_size"]
+    e = max(1, w) if aa["overlap_window"] else 0                 # :354-357 (not w // 2)
+    n = int(math.ceil(T / w) * w)
+    xs = F.pad(x, (0, 0, 0, n - T))
+    pad_mask = torch.zeros(B, n, dtype=torch.bool)
+    pad_mask[:, T:] = True
+    if mask is not None:
+        pad_mask[:, :T] = mask.bool()
+
+    def heads(name):
+        y = F.linear(xs, params[name + ".weight"], params.get(name + ".bias"))
+        return y.reshape(B, n, h, d).transpose(1, 2)
+    q, k, v = heads("q_proj"), heads("k_proj"), heads("v_proj")
+    r = aa["chunk_size"] if aa["chunk_size"] is not None else int(n // aa["num_chunks"])
+    ap = aa["adaptive_proj"]
+    assert ap in ("qk", "no-ln")
+
+    def mu_fn(mq, mk):
+        rq = _mlp(mq, params, ("adaptive_mu_q.0", "adaptive_mu_q.1"), ap == "qk")
+        rk = _mlp(mk, params, ("adaptive_mu_k.0", "adaptive_mu_k.1"), ap == "qk")
+        return rk, rq + rk
+
+    bias = None
+    if aa["use_t5_rpe"] and w > 0:
+        nb = max(min(int((w + e) / 2), 64), 16)                  # :368-374
+        bucket = (t5_bucket_causal if aa["causal"] else t5_bucket)(w, w + e, nb, w + e)
+        bias = params["rel_pos_bias.relative_attention_bias.weight"][bucket][..., 0] * scale
+    noise = noise_fn((B, h, n // r, d)).to(x.dtype) if training else None
+    out = causal_eva_core(q, k, v, pad_mask, w, e, r, mu_fn, noise, bias, aa["causal"], scale)
+    y = F.linear(out.transpose(1, 2).reshape(B, n, C), params["out_proj.weight"],
+                 params.get("out_proj.bias"))
+    return y[:, :T]

@@ -72,6 +72,30 @@ def t5_bucket(i_len, j_len, num_buckets, max_distance):
     return ret + torch.where(is_small, n, large)
 
 
+def causal_window_index_1d(n, w, e=0):
+    """[n//w, e+w] token index of slot j of window g with the extension on the LEFT only, -1 before
+    the sequence start.  Restates causal_window_1d_partition (causal_eva.py:104-116): pad e in
+    front, window g starts at padded position g*w."""
+    g = torch.arange(n // w).unsqueeze(1)
+    j = torch.arange(e + w).unsqueeze(0)
+    tok = g * w - e + j
+    return torch.where(tok >= 0, tok, torch.full_like(tok, -1))
+
+
+def t5_bucket_causal(i_len, j_len, num_buckets, max_distance):
+    """[i_len, j_len] bucket of (k_pos - q_pos) in the causal T5 scheme: distances into the future
+    collapse to 0, no sign split (causal_eva.py:62-99 with causal=True)."""
+    q_pos = torch.arange(i_len).view(-1, 1)
+    k_pos = torch.arange(j_len).view(1, -1)
+    n = (q_pos - k_pos).clamp(min=0)
+    max_exact = num_buckets // 2
+    nf = n.clamp(min=1).float()
+    large = max_exact + (torch.log(nf / max_exact)
+                         / math.log(max_distance / max_exact) * (num_buckets - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, num_buckets - 1))
+    return torch.where(n < max_exact, n, large)
+
+
 def adaptive_pool_matrix(in_size, out_size, dtype=torch.float32):
     """[out_size, in_size] averaging matrix of nn.AdaptiveAvgPool1d: bin o covers
     [floor(o*in/out), ceil((o+1)*in/out)).  The 2-D pool of lara.py:43,48 is the Kronecker

@@ -8,6 +8,7 @@ fixtures only have to store what comes OUT of the reference (y, dx, parameter gr
 the parameter key/shape table.  numpy's bit generators are stable across platforms, so
 the GPU box regenerates exactly the same inputs.
 """
+import argparse
 import zlib
 import numpy as np
 
@@ -102,9 +103,44 @@ CASES = {
     "performer_2d": dict(
         attn="performer", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    # ---------------- causal EVA, training/evaluation path (causal_eva.py:666-790) -----
+    # x is batch-first here; generator and tests transpose to the module's time-first layout
+    "causal_eva_lm_small": dict(  # the wikitext-103 recipe (README.md:184) scaled down
+        attn="causal_eva", x_shape=(2, 64, 128), mask=None,
+        args=dict(embed_dim=128, num_heads=2, self_attention=True,
+                  attn_args=dict(window_size=16, chunk_size=4, causal=True, adaptive_proj="qk",
+                                 use_t5_rpe=True, num_chunks=None, overlap_window=False))),
+    "causal_eva_overlap_mask": dict(  # T=50 -> padded to 56; left extension e = w; pad mask
+        attn="causal_eva", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(embed_dim=128, num_heads=2, self_attention=True,
+                  attn_args=dict(window_size=8, chunk_size=4, causal=True, adaptive_proj="no-ln",
+                                 use_t5_rpe=True, num_chunks=None, overlap_window=True))),
+    "causal_eva_noncausal_chunks": dict(  # causal flag off, chunk length from num_chunks
+        attn="causal_eva", x_shape=(2, 64, 128), mask=("tail", [5, 0]),
+        args=dict(embed_dim=128, num_heads=2, self_attention=True,
+                  attn_args=dict(window_size=8, chunk_size=None, causal=False, adaptive_proj="qk",
+                                 use_t5_rpe=False, num_chunks=8, overlap_window=True))),
 }
 
 MODES = ("eval", "train")
+
+
+def ctor_args(case):
+    """Constructor kwargs of a case as the factory expects them (causal_eva reads its flags from
+    an argparse namespace, causal_eva.py:354-376)."""
+    args = dict(case["args"])
+    if case["attn"] == "causal_eva":
+        args["attn_args"] = argparse.Namespace(**args["attn_args"])
+    return args
+
+
+def call_module(case, mod, x, mask):
+    """y = module(x[, mask]) with batch-first x for every variant (causal_eva is a time-first
+    (query, key, value) module returning (out, None), causal_eva.py:443-470)."""
+    if case["attn"] == "causal_eva":
+        xt = x.transpose(0, 1)
+        return mod(xt, xt, xt, key_padding_mask=mask)[0].transpose(0, 1)
+    return mod(x, mask) if mask is not None else mod(x)
 
 
 def _seed(name, salt):

@@ -82,7 +82,7 @@ def run_case(ref, name):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        mod = ref.AttentionFactory.build_attention(case["attn"], dict(case["args"]))
+        mod = ref.AttentionFactory.build_attention(case["attn"], cases.ctor_args(case))
     sd = mod.state_dict()
     key_shapes = {k: list(v.shape) for k, v in sd.items()}
     params = cases.make_params(name, key_shapes)
@@ -102,7 +102,7 @@ def run_case(ref, name):
         x = torch.from_numpy(x_np).clone().requires_grad_(True)
         mask = None if mask_np is None else torch.from_numpy(mask_np)
         with _NoisePatch(name) as np_patch:
-            y = mod(x, mask) if mask is not None else mod(x)
+            y = cases.call_module(case, mod, x, mask)
         (y * torch.from_numpy(g_np)).sum().backward()
         assert torch.isfinite(y).all(), (name, mode)
         out["%s.y" % mode] = y.detach().numpy()

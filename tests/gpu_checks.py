@@ -60,7 +60,7 @@ def build_module(fx, device="cuda"):
     import efficient_attention as ea
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        mod = ea.AttentionFactory.build_attention(fx.case["attn"], dict(fx.case["args"]))
+        mod = ea.AttentionFactory.build_attention(fx.case["attn"], cases.ctor_args(fx.case))
     sd = mod.state_dict()
     assert {k: list(v.shape) for k, v in sd.items()} == fx.key_shapes
     new = {k: (torch.from_numpy(fx.params_np[k]) if k in fx.params_np else v) for k, v in sd.items()}
@@ -81,7 +81,7 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
     mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np).cuda()
     with injected_noise(fx, mode, "cuda") as calls:
         with torch.autocast("cuda", dtype=dtype):
-            y = mod(x, mask) if mask is not None else mod(x)
+            y = cases.call_module(fx.case, mod, x, mask)
     assert calls == fx.expected_noise_shapes(mode), (calls, fx.expected_noise_shapes(mode))
     assert y.shape == x.shape and y.dtype in (dtype, torch.float32)
     errs = {"y": scaled_err(y.detach().float().cpu().numpy(), fx.y(mode))}

@@ -16,7 +16,7 @@ from util import Fixture
 def build(case):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return ea.AttentionFactory.build_attention(case["attn"], dict(case["args"]))
+        return ea.AttentionFactory.build_attention(case["attn"], cases.ctor_args(case))
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
@@ -42,7 +42,7 @@ def test_factory_names_and_errors():
     with pytest.raises(NotImplementedError):
         ea.AttentionFactory.build_attention("eva", dict(dim=64, num_heads=2, use_rpe=True, use_t5_rpe=True,
                                                         window_size=4))
-    for name in ("ra", "scatterbrain", "causal_eva"):
+    for name in ("ra", "scatterbrain"):
         with pytest.raises(NotImplementedError):
             ea.AttentionFactory.build_attention(name, dict(dim=64, num_heads=2))
 
@@ -103,6 +103,52 @@ def test_no_cpu_fallback(attn):
     x = torch.randn(2, 16, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mod(x)
+
+
+CAUSAL_EVA_DEFAULTS = dict(adaptive_proj="default", num_chunks=None, chunk_size=None, causal=False,
+                           use_t5_rpe=False, window_size=4, overlap_window=False)
+
+
+def _causal_eva(**over):
+    aa = dict(CAUSAL_EVA_DEFAULTS, adaptive_proj="qk", chunk_size=4, causal=True, window_size=8)
+    aa.update(over.pop("attn_args", {}))
+    kw = dict(embed_dim=64, num_heads=2, self_attention=True, attn_args=argparse.Namespace(**aa))
+    kw.update(over)
+    return ea.AttentionFactory.build_attention("causal_eva", kw)
+
+
+def test_causal_eva_flags_and_loud_failures():
+    """causal_eva.py:905-916 flag defaults with fairseq's decoder prefix; the paths this build
+    does not carry (incremental decoding, attention dropout, quantization noise) raise instead of
+    computing something else, and CPU tensors never reach a kernel."""
+    parser = argparse.ArgumentParser()
+    parser = ea.AttentionFactory.add_attn_specific_args(parser, "causal_eva", struct_name="attn_args_decoder",
+                                                        prefix="decoder-attn")
+    args = parser.parse_args([], namespace=ea.NestedNamespace())
+    assert vars(args.attn_args_decoder) == CAUSAL_EVA_DEFAULTS
+    args = parser.parse_args("--decoder-attn-window-size 128 --decoder-attn-causal --decoder-attn-adaptive-proj qk "
+                             "--decoder-attn-chunk-size 8 --decoder-attn-use-t5-rpe".split(),
+                             namespace=ea.NestedNamespace())
+    mod = ea.CausalEVAttention(1024, 8, dropout=0.1, self_attention=True, attn_args=args.attn_args_decoder)
+    assert (mod.num_heads, mod.head_dim, mod.window_size, mod.ext_size, mod.chunk_size) == (8, 128, 128, 0, 8)
+    assert mod.rel_pos_bias.relative_attention_bias.weight.shape == (64, 1) and mod.rel_pos_bias.causal
+    x = torch.randn(16, 2, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _causal_eva().eval()(x, x, x)
+    with pytest.raises(NotImplementedError, match="incremental"):
+        _causal_eva().eval()(x[:1], x[:1], x[:1], incremental_state={})
+    with pytest.raises(NotImplementedError, match="dropout"):
+        _causal_eva(dropout=0.1).train()(x, x, x)
+    with pytest.raises(NotImplementedError, match="quantization"):
+        _causal_eva(q_noise=0.1)
+    with pytest.raises(AssertionError):
+        _causal_eva(attn_args=dict(chunk_size=3))               # window % chunk != 0 (causal_eva.py:362)
+    # legacy fused in_proj checkpoints are split like the reference does (:876-903)
+    sd = {"m.in_proj_weight": torch.arange(12.).view(6, 2), "m.in_proj_bias": torch.arange(6.)}
+    _causal_eva().upgrade_state_dict_named(sd, "m")
+    assert sorted(sd) == ["m.k_proj.bias", "m.k_proj.weight", "m.q_proj.bias", "m.q_proj.weight",
+                          "m.v_proj.bias", "m.v_proj.weight"]
+    assert torch.equal(sd["m.k_proj.weight"], torch.arange(12.).view(6, 2)[2:4])
 
 
 def test_product_package_does_not_import_oracle():
