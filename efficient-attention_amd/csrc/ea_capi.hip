@@ -5,8 +5,8 @@
 
 namespace ea {
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st);
-int window_bwd_dispatch(const WinP& p, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st);
-size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds);
+int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, const float* biasT, int dtype, int D,
+                        hipStream_t st);
 }  // namespace ea
 #include "ea_landmark_params.h"
 #include "ea_lara.h"
@@ -58,7 +58,19 @@ int32_t ea_window_bwd_parts(const ea_geom* g) {
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
   WinTiling t;
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
-  return window_bwd_lds(t, g->D, true, true) <= 160 * 1024 ? 0 : 1;
+  int any = 0;                                             // a launch reads the bias from global memory
+  win_bwd_launches(*g, t, [&](const WinTiling& tl) { any |= window_bwd_lds(tl, g->D, true, true) > WIN_LDS_MAX; });
+  return any;
+}
+int32_t ea_window_bwd_needs_acc(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
+  return win_bwd_single(t) ? 0 : 1;
+}
+int32_t ea_window_bwd_query_blocks(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
+  return t.qsplit;
 }
 
 static int fill_win(const ea_geom* g, WinP& p, bool backward) {
@@ -98,7 +110,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
   if (rc != EA_OK) return rc;
   const int N = g->N;
   if (!t4_ok32(q, g->D, N) || !t4_ok32(k, g->D, N) || !t4_ok32(v, g->D, N) || !t4_ok32(dout, g->D, N) ||
-      !t4_ok32(out, g->D, N) || (g->ext > 0 && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||
+      !t4_ok32(out, g->D, N) || (!win_bwd_single(p.t) && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||
       !t4_ok32(dk, g->D, N) || !t4_ok32(dv, g->D, N) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
   if (bias && (!dbias_part || (!bias_t && ea_window_bwd_needs_bias_t(g) != 0))) return EA_E_BADARG;
@@ -107,7 +119,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
   p.lk = lk; p.lv = lv; p.bias = bias; p.mask = mask; p.lse = const_cast<float*>(lse);
   p.dlk_part = dlk_part; p.dlv_part = dlv_part; p.dbias_part = dbias_part;
   p.dk32 = dk_acc; p.dv32 = dv_acc;
-  return window_bwd_dispatch(p, mk(out), bias ? bias_t : nullptr, g->dtype, g->D, (hipStream_t)stream);
+  return window_bwd_dispatch(p, *g, mk(out), bias ? bias_t : nullptr, g->dtype, g->D, (hipStream_t)stream);
 }
 
 // ---- EVA landmark statistics ----

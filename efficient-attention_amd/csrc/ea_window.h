@@ -28,9 +28,12 @@ struct WinTiling {
   int blk0;            // offset of this launch's workgroups in the *_part buffers
   int parts_total;     // workgroups per (b,h) summed over the classes (leading dim of *_part)
   int causal;          // ea_geom.causal: left-only extension, query-padding and causal masks
+  // Backward of windows too large for one LDS image: the queries of a window are processed in qsplit
+  // blocks of Wq (= WqFull / qsplit) rows, one launch each, like colour classes (they share keys).
+  int qsplit, qoff, WqFull;   // blocks per window; first query slot of this launch's block; w (or w*w)
 };
 
-inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // CUs of the current device (cached; 256 = MI355X when no device is visible, e.g. build checks)
 inline int device_cu_count() {
@@ -68,23 +71,73 @@ inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
   t.nblk = ceil_div(t.niter, t.ipb);
 }
 
-// Restrict a backward tiling to colour class (cy, cx): nwin / niter / nblk of that class.
-// Returns false when the class is empty.
-inline bool win_colour(const ea_geom& g, WinTiling& t, int cy, int cx) {
+// LDS image of the backward kernel (ea_window_bwd.hip) for a tiling
+inline size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
+  const int nQTe = (t.nQT + 1) & ~1;
+  const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
+  size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
+  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
+  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
+  if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
+  return b;
+}
+constexpr size_t WIN_LDS_MAX = 160 * 1024;
+
+// Everything that follows from (Wq, Wk, nwin): tile counts, windows per iteration, LDS rows, blocks.
+// Backward: fewer windows per iteration when the image would not fit (sized with a bias table read
+// from global memory, the larger-geometry mode of the kernel).
+inline void win_derive(const ea_geom& g, WinTiling& t, bool backward) {
+  t.nQT = ceil_div(t.Wq, 16);
+  t.nLT = ceil_div(t.Wk, 16);
+  t.nCT = ceil_div(g.L, 16);
+  t.nchunks = ceil_div(t.nLT + t.nCT, 4);
+  t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
+  if (t.wpi > t.nwin) t.wpi = t.nwin;
+  for (;;) {
+    t.rowsLocal = t.wpi * t.nLT * 16;
+    t.rowsLm = t.nCT * 16;
+    t.rowsTotal = t.rowsLocal + t.rowsLm + 16;
+    if (!backward || t.wpi == 1 || window_bwd_lds(t, g.D, true, false) <= WIN_LDS_MAX) break;
+    t.wpi /= 2;
+  }
+  t.niter = ceil_div(t.nwin, t.wpi);
+  win_blocks(g, t, backward);
+}
+
+// Restrict a backward tiling to one launch: colour class (cy, cx) of the windows and query block qb
+// of every window.  Returns false when the class is empty.  With the causal masks, query block qb
+// sees no key beyond its own last query, so the key list of the launch ends there.
+inline bool win_sub(const ea_geom& g, WinTiling& t, int cy, int cx, int qb) {
   const int w = g.window;
   const int WX = g.attn_2d ? g.gw / w : ceil_div(g.N, w), WY = g.attn_2d ? g.gh / w : 1;
   if (cx >= WX || cy >= WY) return false;
   const int sx = ceil_div(WX - cx, t.ncx), sy = ceil_div(WY - cy, t.ncy);
   t.col_x = cx; t.col_y = cy; t.sub_x = sx;
   t.nwin = sx * sy;
-  int wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
-  if (wpi > t.nwin) wpi = t.nwin;
-  // (wpi fixes the LDS image: keep the value of the full tiling unless the class is smaller)
-  if (wpi < t.wpi) { t.wpi = wpi; t.rowsLocal = t.wpi * t.nLT * 16; t.rowsTotal = t.rowsLocal + t.rowsLm + 16; }
-  t.niter = ceil_div(t.nwin, t.wpi);
-  win_blocks(g, t, true);
+  t.qoff = qb * t.Wq;
+  if (t.qsplit > 1 && g.causal == 2) t.Wk = min(t.Wk, g.ext + (qb + 1) * t.Wq);
+  win_derive(g, t, true);
   return true;
 }
+
+// The backward runs as one launch per (colour class, query block); f(tiling) for each of them, in
+// launch order, with blk0 = the launch's offset in the per-workgroup partial buffers.
+template <typename F>
+inline int win_bwd_launches(const ea_geom& g, const WinTiling& base, F&& f) {
+  int blk0 = 0;
+  for (int cy = 0; cy < base.ncy; ++cy)
+    for (int cx = 0; cx < base.ncx; ++cx)
+      for (int qb = 0; qb < base.qsplit; ++qb) {
+        WinTiling c = base;
+        if (!win_sub(g, c, cy, cx, qb)) continue;
+        c.blk0 = blk0;
+        blk0 += c.nblk;
+        f(c);
+      }
+  return blk0;
+}
+// one launch covers everything: no overlap between windows and the whole window in one query block
+__host__ __device__ inline bool win_bwd_single(const WinTiling& t) { return t.ncx * t.ncy * t.qsplit == 1; }
 
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
@@ -103,32 +156,29 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
     t.Wk = w + kext;
     t.nwin = ceil_div(g.N, w);
   }
-  t.nQT = ceil_div(t.Wq, 16);
-  t.nLT = ceil_div(t.Wk, 16);
-  t.nCT = ceil_div(g.L, 16);
-  t.nchunks = ceil_div(t.nLT + t.nCT, 4);
-  t.biasLd = t.nLT * 16;
-  t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
-  if (t.wpi > t.nwin) t.wpi = t.nwin;
-  t.niter = ceil_div(t.nwin, t.wpi);
+  t.WqFull = t.Wq;
+  t.biasLd = ceil_div(t.Wk, 16) * 16;
+  t.qsplit = 1; t.qoff = 0;
   t.ncx = t.ncy = 1;
   t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
-  win_blocks(g, t, backward);
-  t.parts_total = t.nblk;
-  if (backward && e > 0) {
-    t.ncx = 1 + ceil_div(kext, w);
-    t.ncy = g.attn_2d ? t.ncx : 1;
-    int total = 0;
-    for (int cy = 0; cy < t.ncy; ++cy)
-      for (int cx = 0; cx < t.ncx; ++cx) {
-        WinTiling c = t;
-        if (win_colour(g, c, cy, cx)) total += c.nblk;
-      }
-    t.parts_total = total;
+  win_derive(g, t, backward);
+  if (backward && !g.attn_2d) {
+    // a window whose rows do not fit the LDS image is processed in query blocks (halved until it
+    // fits; a block keeps whole 32-query MFMA steps), one launch per block
+    while (window_bwd_lds(t, g.D, true, false) > WIN_LDS_MAX && t.Wq % 64 == 0) {
+      t.qsplit *= 2;
+      t.Wq /= 2;
+      win_derive(g, t, true);
+    }
   }
-  t.rowsLocal = t.wpi * t.nLT * 16;
-  t.rowsLm = t.nCT * 16;
-  t.rowsTotal = t.rowsLocal + t.rowsLm + 16;
+  t.parts_total = t.nblk;
+  if (backward && (kext > 0 || t.qsplit > 1)) {
+    if (kext > 0) {
+      t.ncx = 1 + ceil_div(kext, w);
+      t.ncy = g.attn_2d ? t.ncx : 1;
+    }
+    t.parts_total = win_bwd_launches(g, t, [](const WinTiling&) {});
+  }
   return EA_OK;
 }
 
@@ -171,7 +221,7 @@ EA_DEV void build_slot_tables(int* kd, int* qd, const WinTiling& t, const Geo& G
   }
   for (int s = tid; s < nq; s += 256) {
     const int i = s / w, j = s - i * w;
-    qd[s] = G.attn2d ? ((i & 0xffff) | (j << 16)) : s;
+    qd[s] = G.attn2d ? ((i & 0xffff) | (j << 16)) : s + t.qoff;
   }
 }
 // window origin (oy, ox) in 2-D, (first token, 0) in 1-D

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   int* qlim_s = qd + nQTe * 16;                      // CA only: last visible local slot / landmark per query row
   int* clim_s = qlim_s + rowsQ;
   const int rowsPerWin = t.nLT * 16;
+  const bool single = win_bwd_single(t);             // the only launch: dk/dv are stored directly
 
   constexpr bool PHASE_A_GLOBAL_BIAS = GB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
   if (tid < 128) zero64[tid] = 0.f;
   if (p.bias_lds) {
-    const float* bsrc = p.bias + (size_t)h * t.Wq * t.biasLd;
+    const float* bsrc = p.bias + ((size_t)h * t.WqFull + t.qoff) * t.biasLd;
     for (int idx = tid * 4; idx < t.Wq * t.biasLd; idx += 1024) {
       const float4 v = *reinterpret_cast<const float4*>(bsrc + idx);
       float* d = bias_s + (idx / t.biasLd) * BLD + (idx % t.biasLd);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
             tok = slot_token(p.G, qd[slot], oy, ox);
           }
           x.rowv[i] = row;
-          if (CA && c == 0) x.lim[i] = query_limits(p.causal, slot, tok, p.e, p.chunk, mrow);
+          if (CA && c == 0) x.lim[i] = query_limits(p.causal, t.qoff + slot, tok, p.e, p.chunk, mrow);
           if (tok >= 0) {
             x.qr[i] = ldg16(qb + (tok * qsn + c * 8) * 2);
             x.dr[i] = ldg16(dob + (tok * dosn + c * 8) * 2);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
       ql.local = ql.lm = 0x7fffffff;
       if (CA) { ql.local = qlim_s[qrow]; ql.lm = clim_s[qrow]; }
       const float* brow = (GB && p.bias)
-          ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+          ? p.bias + ((size_t)h * t.WqFull + t.qoff + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
       const float* brow_s = bread + (qslot < t.Wq ? qslot : 0) * brs + 4 * g;
       f32x4 dq[DT];
 #pragma unroll
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
                   // from the transposed copy in global memory: one 16-B load
                   if (kslot < t.Wk) {
                     const float4 bt4 = *reinterpret_cast<const float4*>(
-                        biasT + ((size_t)h * t.biasLd + kslot) * (t.nQT * 16) + q0);
+                        biasT + ((size_t)h * t.biasLd + kslot) * (ceil_div(t.WqFull, 16) * 16) + t.qoff + q0);
                     bt[0] = bt4.x; bt[1] = bt4.y; bt[2] = bt4.z; bt[3] = bt4.w;
                   }
                 } else {
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
-          if (p.e == 0) {
+          if (single) {
             char* d1 = dkb + (tok * dksn + DQ * g) * 2;
             char* d2 = dvb + (tok * dvsn + DQ * g) * 2;
 #pragma unroll
@@ -497,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
               stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
             }
           } else {
-            // overlapping windows: a token is a key of several windows, but of only one window of
-            // this launch's colour class -> plain 16-B read-modify-write into the fp32 scratch
+            // overlapping windows / query blocks: a token is a key of several (window, query block)
+            // pairs, but of only one of this launch -> plain 16-B read-modify-write into the fp32 scratch
             float4* a1 = reinterpret_cast<float4*>(p.dk32 + ((size_t)bh * p.G.N + tok) * D + DQ * g);
             float4* a2 = reinterpret_cast<float4*>(p.dv32 + ((size_t)bh * p.G.N + tok) * D + DQ * g);
 #pragma unroll
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 
   }
   if (p.bias) {
     __syncthreads();
-    float* dst = p.dbias_part + (((size_t)(t.blk0 + blk) * p.B + b) * p.H + h) * (size_t)t.Wq * t.biasLd;
+    float* dst = p.dbias_part + ((((size_t)(t.blk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)t.biasLd;
     for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[(idx / t.biasLd) * BLD + (idx % t.biasLd)];
   }
   EA_STAMP(p, 61);
@@ -562,61 +563,45 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
   }
 }
 
-size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
-  const int nQTe = (t.nQT + 1) & ~1;
-  const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
-  size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
-  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
-  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
-  if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
-  return b;
-}
-
 template <typename E, int D>
-static int launch_bwd(WinP& p, const T4& outp, const float* biasT, hipStream_t st) {
-  // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
-  // every window; from global memory those loads sit exposed in the inner loops)
-  p.bias_lds = (p.bias && window_bwd_lds(p.t, D, true, true) <= 160 * 1024) ? 1 : 0;
-  const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0);
-  if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
-  const bool gb = p.bias && !p.bias_lds;
+static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
-  const KernelT kern = p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
-                                : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool single = win_bwd_single(p0.t);
+  if (!single) {
+    const size_t bytes = (size_t)p0.B * p0.H * p0.G.N * D * sizeof(float);
+    hipError_t e = hipMemsetAsync(p0.dk32, 0, bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p0.dv32, 0, bytes, st);
     if (e != hipSuccess) return (int)e;
   }
-  if (p.e > 0) {
-    const size_t bytes = (size_t)p.B * p.H * p.G.N * D * sizeof(float);
-    hipError_t e = hipMemsetAsync(p.dk32, 0, bytes, st);
-    if (e == hipSuccess) e = hipMemsetAsync(p.dv32, 0, bytes, st);
-    if (e != hipSuccess) return (int)e;
-  }
-  if (p.e == 0) {
+  int rc = EA_OK;
+  // one launch per (colour class, query block); stream order separates them
+  win_bwd_launches(geom, p0.t, [&](const WinTiling& tl) {
+    if (rc != EA_OK) return;
+    WinP p = p0;
+    p.t = tl;
+    // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
+    // every window; from global memory those loads sit exposed in the inner loops)
+    p.bias_lds = (p.bias && window_bwd_lds(p.t, D, true, true) <= WIN_LDS_MAX) ? 1 : 0;
+    const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0);
+    if (lds > WIN_LDS_MAX) { rc = EA_E_UNSUPPORTED; return; }
+    const bool gb = p.bias && !p.bias_lds;
+    const KernelT kern = p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
+                                  : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { rc = (int)e; return; }
+    }
     const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, outp, biasT);
-  } else {
-    // one launch per colour class (stream order separates the classes)
-    ea_geom gg = {};
-    gg.B = p.B; gg.H = p.H; gg.N = p.G.N; gg.attn_2d = p.G.attn2d; gg.gh = p.G.gh; gg.gw = p.G.gw; gg.window = p.w;
-    int blk0 = 0;
-    for (int cy = 0; cy < p.t.ncy; ++cy)
-      for (int cx = 0; cx < p.t.ncx; ++cx) {
-        WinP pc = p;
-        if (!win_colour(gg, pc.t, cy, cx)) continue;
-        pc.t.blk0 = blk0;
-        blk0 += pc.t.nblk;
-        const dim3 grid((unsigned)(p.B * p.H * pc.t.nblk));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pc, outp, biasT);
-      }
-  }
-  if (p.e > 0) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p);
+  });
+  if (rc != EA_OK) return rc;
+  if (!single) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p0);
   return (int)hipGetLastError();
 }
 
-int window_bwd_dispatch(const WinP& p0, const T4& outp, const float* biasT, int dtype, int D, hipStream_t st) {
+int window_bwd_dispatch(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, int dtype, int D,
+                        hipStream_t st) {
   WinP p = p0;
   p.prof = nullptr;
 #ifdef EA_PROFILE
@@ -624,13 +609,13 @@ int window_bwd_dispatch(const WinP& p0, const T4& outp, const float* biasT, int 
   p.prof = rep.arm(st, "win_bwd", 0);
 #endif
   if (dtype == EA_BF16) {
-    if (D == 64) return launch_bwd<BF16, 64>(p, outp, biasT, st);
-    if (D == 32) return launch_bwd<BF16, 32>(p, outp, biasT, st);
-    if (D == 128) return launch_bwd<BF16, 128>(p, outp, biasT, st);
+    if (D == 64) return launch_bwd<BF16, 64>(p, geom, outp, biasT, st);
+    if (D == 32) return launch_bwd<BF16, 32>(p, geom, outp, biasT, st);
+    if (D == 128) return launch_bwd<BF16, 128>(p, geom, outp, biasT, st);
   } else if (dtype == EA_F16) {
-    if (D == 64) return launch_bwd<F16, 64>(p, outp, biasT, st);
-    if (D == 32) return launch_bwd<F16, 32>(p, outp, biasT, st);
-    if (D == 128) return launch_bwd<F16, 128>(p, outp, biasT, st);
+    if (D == 64) return launch_bwd<F16, 64>(p, geom, outp, biasT, st);
+    if (D == 32) return launch_bwd<F16, 32>(p, geom, outp, biasT, st);
+    if (D == 128) return launch_bwd<F16, 128>(p, geom, outp, biasT, st);
   }
   return EA_E_UNSUPPORTED;
 }

@@ -135,9 +135,11 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
         dlk_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
         dlv_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
     if bias_p is not None:
-        dbias_p = torch.empty((parts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
+        # several query blocks per window: each launch writes only its block's rows
+        alloc = torch.zeros if nv.query("ea_window_bwd_query_blocks", geom) > 1 else torch.empty
+        dbias_p = alloc((parts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
     dk_acc = dv_acc = None
-    if geom.ext > 0:
+    if nv.query("ea_window_bwd_needs_acc", geom):
         dk_acc = torch.empty((B, h, N, d), dtype=torch.float32, device=dev)
         dv_acc = torch.empty_like(dk_acc)
     bias_t = None

@@ -101,10 +101,17 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  *   bias   : fp32 [H, Wq, ea_window_bias_ld(g)] dense per-head bias MULTIPLIED BY log2(e) (the
  *            softmax runs in the log2 domain), rows padded, or NULL; dbias_part is d/d(natural bias)
  *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward
+ * With ea_geom.causal the windows, masks and chunk visibility follow causal_eva.py:666-783 (see the
+ * field's comment); Wk = window + ext there.
  * Backward consumes the forward's out, lse and dout and produces dq, dk, dv (WRITTEN, not
- * accumulated).  With overlapping windows (ext > 0) a token is a key of several windows: the
- * caller then passes two fp32 scratch buffers dk_acc, dv_acc of [B,H,N,D] (zeroed inside) that
- * take the atomics before the result is converted into dk/dv; they may be NULL when ext == 0.
+ * accumulated).  It runs as one launch per group of (window, query block) pairs that share no key:
+ * with overlapping windows (ext > 0) a token is a key of several windows, and a 1-D window whose
+ * rows do not fit one LDS image (e.g. window 128 at D = 128) is processed in
+ * ea_window_bwd_query_blocks(g) blocks of queries.  Whenever there is more than one launch
+ * (ea_window_bwd_needs_acc(g) == 1) the caller passes two fp32 scratch buffers dk_acc, dv_acc of
+ * [B,H,N,D] (zeroed inside) that collect the key/value gradients before they are converted into
+ * dk/dv; they may be NULL otherwise.  With more than one query block dbias_part must be ZEROED by
+ * the caller (a launch writes only its block's rows).
  * The landmark and bias gradients come back as per-workgroup partial sums which the caller
  * reduces over the leading axes:
  *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
@@ -115,6 +122,8 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
 int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
 int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g);
+int32_t ea_window_bwd_needs_acc(const ea_geom* g);  /* 1: dk_acc / dv_acc are required       */
+int32_t ea_window_bwd_query_blocks(const ea_geom* g); /* > 1: dbias_part must be zeroed      */
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
                        const ea_t4* out, float* lse, void* stream);
