@@ -74,10 +74,24 @@ def _seq(grid):
     return tuple(grid) if isinstance(grid, (tuple, list)) else (grid, grid)
 
 
+# causal_eva on the wikitext-103 recipe (reference README.md:184; main.sh:52-81: transformer_lm_wiki103
+# = embed 1024 / 8 heads, --tokens-per-sample 512, --max-tokens 9216 -> 18 samples per GPU).  The
+# recipe's attention dropout (0.1) is not built into the kernel yet: the layer is timed with dropout 0.
+LM_ATTN_ARGS = dict(window_size=128, chunk_size=8, causal=True, adaptive_proj="qk", use_t5_rpe=True,
+                    num_chunks=None, overlap_window=False)
+
+
 def build_layer(attn, dim, heads, grid, device):
     import efficient_attention as ea
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        if attn == "causal_eva":
+            aa = dict(LM_ATTN_ARGS)
+            if OVERRIDES.get("window_size"):
+                aa["window_size"] = OVERRIDES["window_size"]
+            return ea.AttentionFactory.build_attention(attn, dict(
+                embed_dim=dim, num_heads=heads, dropout=0.0, self_attention=True,
+                attn_args=argparse.Namespace(**aa))).to(device)
         return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, _seq(grid))).to(device)
 
 
@@ -91,7 +105,11 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
     layer = build_layer(attn, dim, heads, grid, "cpu")
     params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
     seq = _seq(grid)
-    args = attn_args(attn, dim, heads, seq)
+    if attn == "causal_eva":
+        args = dict(embed_dim=dim, num_heads=heads, attn_args=dict(
+            LM_ATTN_ARGS, window_size=OVERRIDES.get("window_size") or LM_ATTN_ARGS["window_size"]))
+    else:
+        args = attn_args(attn, dim, heads, seq)
     x = torch.randn(B, *seq, dim, requires_grad=True)
     g = torch.randn(B, *seq, dim)
     noise_fn = lambda shape: torch.randn(*shape)  # noqa: E731
@@ -143,9 +161,10 @@ def main():
     ap.add_argument("--heads", type=int, default=3)
     ap.add_argument("--window", type=int, default=None, help="override window_size (eva / local), e.g. 8 for the PvT stages")
     ap.add_argument("--landmarks", type=int, default=None, help="override num_landmarks (eva / lara), e.g. 36 for the PvT stages")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5", "lm"],
                     help="cfg3 (default, the metric's config): [128,28,28,192] h=3; cfg2: [128,14,14,192] h=3; "
-                         "cfg5: 1-D [16,4096,512] h=8 (BASELINE.json configs / SURVEY.md 8d)")
+                         "cfg5: 1-D [16,4096,512] h=8 (BASELINE.json configs / SURVEY.md 8d); lm: the wikitext-103 "
+                         "decoder self-attention, [18,512,1024] h=8 (use with --attn causal_eva)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tune", action="store_true",
@@ -183,6 +202,10 @@ def main():
         seq = (14, 14)
     elif a.workload == "cfg5":
         B, C, H, seq = (16 if a.batch == 128 else a.batch), 512, 8, (4096,)
+    elif a.workload == "lm":
+        B, C, H, seq = (18 if a.batch == 128 else a.batch), 1024, 8, (512,)
+    if (a.attn == "causal_eva") != (a.workload == "lm"):
+        ap.error("--attn causal_eva goes with --workload lm (a time-first 1-D decoder self-attention)")
     G = seq
     N = 1
     for s_ in seq:
@@ -193,8 +216,12 @@ def main():
     model = layer
     LR = 1e-3
     opt = torch.optim.SGD(layer.parameters(), lr=LR)
-    x = torch.randn(B, *seq, C, device=dev, requires_grad=True)
-    g = torch.randn(B, *seq, C, device=dev).to(torch.bfloat16)     # cotangent of y, in y's dtype
+    xshape = (seq[0], B, C) if a.attn == "causal_eva" else (B,) + tuple(seq) + (C,)   # fairseq is time-first
+    x = torch.randn(*xshape, device=dev, requires_grad=True)
+    g = torch.randn(*xshape, device=dev).to(torch.bfloat16)        # cotangent of y, in y's dtype
+    if a.attn == "causal_eva":
+        def model(t):
+            return layer(t, t, t)[0]
 
     from efficient_attention import _ops
 
@@ -367,7 +394,7 @@ def main():
                        "attn": a.attn, "global_batch": B * world, "seq_len": N, "heads": H, "head_dim": d,
                        "parallelism": "dp%d" % world, "hipgraph": graphed,
                        "gemm_tunableop": tune},
-            "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H),
+            "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H * d / 64),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -60,9 +60,23 @@ class T5RelativePositionBias(nn.Module):
             cache[dkey] = cache[key].to(device)
         return cache[dkey]
 
+    def _bucket_onehot(self, i, j, device):
+        """[i*j, num_buckets] fp32 one-hot rows of the bucket table (cached per device)."""
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        key = (i, j, str(device), "onehot")
+        if key not in cache:
+            cache[key] = F.one_hot(self.bucket_table(i, j, device).reshape(-1), self.num_buckets).float()
+        return cache[key]
+
     def dense(self, i, j, device):
-        """[h, i, j] bias, already multiplied by scale."""
-        return self.relative_attention_bias(self.bucket_table(i, j, device)).permute(2, 0, 1) * self.scale
+        """[h, i, j] bias, already multiplied by scale.  The table lookup is a one-hot GEMM (exact in
+        fp32): its backward is the transposed GEMM -- deterministic and safe to capture in a
+        hipGraph, which the sort-based embedding backward torch picks above ~3k indices is not."""
+        if device.type != "cuda":
+            return self.relative_attention_bias(self.bucket_table(i, j, device)).permute(2, 0, 1) * self.scale
+        with torch.autocast(device_type="cuda", enabled=False):
+            vals = self._bucket_onehot(i, j, device) @ self.relative_attention_bias.weight.float()
+        return vals.view(i, j, -1).permute(2, 0, 1) * self.scale
 
     def forward(self, x):
         i, j = x.shape[-2:]
