@@ -49,6 +49,18 @@ inline int device_cu_count() {
   return n;
 }
 
+// LDS image of the backward kernel (ea_window_bwd.hip) for a tiling
+inline size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
+  const int nQTe = (t.nQT + 1) & ~1;
+  const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
+  size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
+  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
+  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
+  if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
+  return b;
+}
+constexpr size_t WIN_LDS_MAX = 160 * 1024;
+
 // Workgroups per (b,h) for t.niter iterations.  A workgroup pays a fixed prologue (landmark rows,
 // bias table, slot tables: ~0.4 window-iterations, measured) and keeps the landmark rows -- in
 // backward also its landmark-gradient accumulators -- resident across its windows, so fewer
@@ -57,7 +69,12 @@ inline int device_cu_count() {
 // -> 5).  Pick the count that minimises rounds x (windows per workgroup + prologue).
 inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
   const long bh = (long)g.B * g.H;
-  const long slots = (long)device_cu_count() * (backward ? 2 : 4);     // resident workgroups (launch bounds / LDS)
+  // resident workgroups per CU: the kernels' launch bounds, or one when the LDS image takes over
+  // half of the CU's 160 KB
+  int per_cu = backward ? (g.D == 128 ? 1 : 2) : (g.D == 128 ? 2 : 4);
+  const size_t lds = backward ? window_bwd_lds(t, g.D, false, false) : (size_t)t.rowsTotal * g.D * 4;
+  if (lds > WIN_LDS_MAX / 2) per_cu = 1;
+  const long slots = (long)device_cu_count() * per_cu;
   int best = 1;
   double best_cost = 1e30;
   for (int nb = 1; nb <= t.niter; ++nb) {
@@ -70,18 +87,6 @@ inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
   t.ipb = ceil_div(t.niter, best);
   t.nblk = ceil_div(t.niter, t.ipb);
 }
-
-// LDS image of the backward kernel (ea_window_bwd.hip) for a tiling
-inline size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds) {
-  const int nQTe = (t.nQT + 1) & ~1;
-  const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
-  size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
-  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
-  b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
-  if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
-  return b;
-}
-constexpr size_t WIN_LDS_MAX = 160 * 1024;
 
 // Everything that follows from (Wq, Wk, nwin): tile counts, windows per iteration, LDS rows, blocks.
 // Backward: fewer windows per iteration when the image would not fit (sized with a bias table read

@@ -24,7 +24,7 @@ namespace ea {
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits, staged per
 // query row in LDS for phase B.
 template <typename E, int D, bool GB, bool CA>
-__global__ __launch_bounds__(256, 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
+__global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
   constexpr int KS = D / 32;

@@ -25,7 +25,7 @@ namespace ea {
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits on top of the
 // per-key (mul, add) pairs.
 template <typename E, int D, bool CA>
-__global__ __launch_bounds__(256, 4) void win_fwd_kernel(const WinP p) {
+__global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const WinP p) {
   constexpr int ROWB = D * 2;      // bytes per LDS row
   constexpr int CPR = D / 8;       // 16-byte chunks per row
   constexpr int KS = D / 32;       // k-steps of the score MFMA
