@@ -113,7 +113,11 @@ def _bias_padded(bias, geom):
 def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8):
     B, N, _, h, d = qkv5.shape
     q, k, v = _qkv_views(qkv5)
-    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
+    if qkv5.stride(1) > qkv5.stride(0):
+        # time-first qkv (a transposed view of [N,B,3,h,d], fairseq's layout): out follows it
+        out = torch.empty((N, B, h, d), dtype=qkv5.dtype, device=qkv5.device).transpose(0, 1)
+    else:
+        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
     lse = torch.empty((B, h, N), dtype=torch.float32, device=qkv5.device)
     tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
     nv.call("ea_window_attn_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
@@ -122,8 +126,16 @@ def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8):
     return out, lse
 
 
+def _rows_contiguous(t):
+    """A [B,N,h,d] tensor the kernels can address through strides (rows of d contiguous, heads packed)
+    as it is -- e.g. a batch-first view of a time-first buffer -- or a contiguous copy."""
+    if t.stride(-1) == 1 and t.stride(-2) == t.shape[-1] and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0:
+        return t
+    return t.contiguous()
+
+
 def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
-    """out, dout: [B,N,h,d] contiguous.  Writes dq,dk,dv into dqkv5; returns dlk, dlv, dbias_padded."""
+    """out, dout: [B,N,h,d] with contiguous rows.  Writes dq,dk,dv into dqkv5; returns dlk, dlv, dbias_padded."""
     B, N, _, h, d = qkv5.shape
     q, k, v = _qkv_views(qkv5)
     dq, dk, dv = _qkv_views(dqkv5)
@@ -279,7 +291,7 @@ class EvaAttnFn(torch.autograd.Function):
         geom = ctx.geom
         dqkv5 = torch.empty_like(qkv5)
         d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
-                                           dout.contiguous(), lse, dqkv5)
+                                           _rows_contiguous(dout), lse, dqkv5)
         q, k, v = _qkv_views(qkv5)
         dq, dk, dv = _qkv_views(dqkv5)
         tk, tv, tdq, tdk, tdv = nv.t4(k), nv.t4(v), nv.t4(dq), nv.t4(dk), nv.t4(dv)

@@ -109,8 +109,8 @@ class CausalEVAttention(nn.Module):
         return [q[0].weight, q[0].bias, k[0].weight, k[0].bias]
 
     def _project(self, query, key, value):
-        """-> fused [B, N, 3, h, d] in the kernels' I/O dtype."""
-        B, N, C = query.shape
+        """Time-first [N, B, C] inputs -> fused [N, B, 3, h, d] in the kernels' I/O dtype."""
+        N, B, C = query.shape
         if self.self_attention:
             # one GEMM over the stacked weights instead of three over the same activations
             weight = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], 0)
@@ -125,7 +125,7 @@ class CausalEVAttention(nn.Module):
                                _ops.linear(value, self.v_proj)], dim=2)
         if qkv.dtype not in (torch.bfloat16, torch.float16):
             qkv = qkv.to(torch.bfloat16)
-        return qkv.reshape(B, N, 3, self.num_heads, self.head_dim)
+        return qkv.reshape(N, B, 3, self.num_heads, self.head_dim)
 
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None,
                 need_weights=True, attn_mask=None):
@@ -143,13 +143,14 @@ class CausalEVAttention(nn.Module):
         assert embed_dim == self.embed_dim, "query dim %d != %d" % (embed_dim, self.embed_dim)
         w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
 
-        def batch_first(t):
-            t = t.transpose(0, 1)
+        # Everything stays in fairseq's time-first layout: the kernels address q/k/v/out through
+        # strides, so the batch-first views below cost no transposes of the activations.
+        def padded(t):
             n_pad = int(math.ceil(tgt_len / w) * w) - tgt_len if w > 0 else 0
-            return F.pad(t, (0, 0, 0, n_pad)) if n_pad else t
+            return F.pad(t, (0, 0, 0, 0, 0, n_pad)) if n_pad else t
 
-        x = batch_first(query)
-        B, N, C = x.shape
+        x = padded(query)
+        N, B, C = x.shape
         mask = None
         if key_padding_mask is not None or N != tgt_len:
             mask = torch.zeros(B, N, dtype=torch.bool, device=x.device)
@@ -159,7 +160,8 @@ class CausalEVAttention(nn.Module):
         if self.self_attention:
             qkv5 = self._project(x, None, None)
         else:
-            qkv5 = self._project(x, batch_first(key), batch_first(value))
+            qkv5 = self._project(x, padded(key), padded(value))
+        qkv5 = qkv5.transpose(0, 1)                       # [B, N, 3, h, d] view of the time-first buffer
 
         r = self.chunk_size if self.chunk_size is not None else int(N // self.num_chunks)
         if r >= N:
@@ -177,12 +179,13 @@ class CausalEVAttention(nn.Module):
                2 if self.causal else 1, 1.0)
         out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
                                    *self._mu_params())
-        y = _ops.linear(out.reshape(B, N, C), self.out_proj)
+        # out [B, N, h, d] comes back as a view of a time-first buffer (it follows qkv's layout)
+        y = _ops.linear(out.transpose(0, 1).reshape(N, B, C), self.out_proj)
         if not torch.is_autocast_enabled() and y.dtype != query.dtype:
             y = y.to(query.dtype)
         if N != tgt_len:
-            y = y[:, :tgt_len]
-        return y.transpose(0, 1).contiguous(), None
+            y = y[:tgt_len]
+        return y.contiguous(), None
 
     # ---- fairseq incremental-state protocol (reference :262-297, 836-871) -------------------
     def init_incremental_state(self):
