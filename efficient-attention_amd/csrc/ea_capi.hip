@@ -62,10 +62,10 @@ int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
   win_bwd_launches(*g, t, [&](const WinTiling& tl) { any |= window_bwd_lds(tl, g->D, true, true) > WIN_LDS_MAX; });
   return any;
 }
-int32_t ea_window_bwd_needs_acc(const ea_geom* g) {
+int32_t ea_window_bwd_acc_slices(const ea_geom* g) {
   WinTiling t;
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
-  return win_bwd_single(t) ? 0 : 1;
+  return win_bwd_acc_slices(t);
 }
 int32_t ea_window_bwd_query_blocks(const ea_geom* g) {
   WinTiling t;
@@ -110,7 +110,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
   if (rc != EA_OK) return rc;
   const int N = g->N;
   if (!t4_ok32(q, g->D, N) || !t4_ok32(k, g->D, N) || !t4_ok32(v, g->D, N) || !t4_ok32(dout, g->D, N) ||
-      !t4_ok32(out, g->D, N) || (!win_bwd_single(p.t) && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||
+      !t4_ok32(out, g->D, N) || (win_bwd_acc_slices(p.t) > 0 && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||
       !t4_ok32(dk, g->D, N) || !t4_ok32(dv, g->D, N) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv || !dlk_part || !dlv_part)) return EA_E_BADARG;
   if (bias && (!dbias_part || (!bias_t && ea_window_bwd_needs_bias_t(g) != 0))) return EA_E_BADARG;

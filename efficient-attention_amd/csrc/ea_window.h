@@ -31,6 +31,7 @@ struct WinTiling {
   // Backward of windows too large for one LDS image: the queries of a window are processed in qsplit
   // blocks of Wq (= WqFull / qsplit) rows, one launch each, like colour classes (they share keys).
   int qsplit, qoff, WqFull;   // blocks per window; first query slot of this launch's block; w (or w*w)
+  int slice;                  // merged query-block launch: this block's slice of the dk/dv scratch
 };
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -143,6 +144,12 @@ inline int win_bwd_launches(const ea_geom& g, const WinTiling& base, F&& f) {
 }
 // one launch covers everything: no overlap between windows and the whole window in one query block
 __host__ __device__ inline bool win_bwd_single(const WinTiling& t) { return t.ncx * t.ncy * t.qsplit == 1; }
+// Query blocks of non-overlapping windows share keys only with each other: given one dk/dv scratch
+// slice per block they need no ordering and run as ONE launch (more workgroups in flight, the long
+// blocks first), and the slices are summed afterwards.
+inline bool win_bwd_merged(const WinTiling& t) { return t.qsplit > 1 && t.qsplit <= 4 && t.ncx * t.ncy == 1; }
+// fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
+inline int win_bwd_acc_slices(const WinTiling& t) { return win_bwd_single(t) ? 0 : (win_bwd_merged(t) ? t.qsplit : 1); }
 
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
@@ -163,7 +170,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   }
   t.WqFull = t.Wq;
   t.biasLd = ceil_div(t.Wk, 16) * 16;
-  t.qsplit = 1; t.qoff = 0;
+  t.qsplit = 1; t.qoff = 0; t.slice = 0;
   t.ncx = t.ncy = 1;
   t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
   win_derive(g, t, backward);
@@ -212,6 +219,13 @@ struct WinP {
   float scale, scale_log2;
   WinTiling t;
   int bias_lds;                              // bwd: the bias table of the head is staged in LDS
+  // bwd, how local dk/dv leave the kernel: 0 = stored to dk/dv; 1 = fp32 read-modify-write into dk32/dv32
+  // (launches ordered by the stream); 2 = plain fp32 stores into slice t.slice of dk32/dv32
+  int acc_mode;
+  // bwd, merged query-block launch: workgroups [qstart[i], qstart[i+1]) run tiling tv[i] (nq > 1)
+  int nq;
+  int qstart[5];
+  WinTiling tv[4];
   long long* prof;                           // dev builds (-DEA_PROFILE): phase time stamps
 };
 

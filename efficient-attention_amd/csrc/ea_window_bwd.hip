@@ -15,6 +15,7 @@
 // There is no barrier between the phases: delta and lse are staged with the Q/dO rows.
 #include "ea_window.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace ea {
 
@@ -31,7 +32,15 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   constexpr int DT = D / 16;
   constexpr int DQ = D / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const WinTiling& t = p.t;
+  // merged query-block launch: this workgroup's tiling and its index within that tiling's range
+  int qi = 0;
+  if (p.nq > 1) {
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < p.nq && (int)blockIdx.x >= p.qstart[i]) qi = i;
+  }
+  const WinTiling& t = p.nq > 1 ? p.tv[qi] : p.t;
+  const int bid = p.nq > 1 ? (int)blockIdx.x - p.qstart[qi] : (int)blockIdx.x;
   const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
   const int rowsQ = t.wpi * nQTe * 16;
   char* Ks = smem;
@@ -58,13 +67,12 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   int* qlim_s = qd + nQTe * 16;                      // CA only: last visible local slot / landmark per query row
   int* clim_s = qlim_s + rowsQ;
   const int rowsPerWin = t.nLT * 16;
-  const bool single = win_bwd_single(t);             // the only launch: dk/dv are stored directly
 
   constexpr bool PHASE_A_GLOBAL_BIAS = GB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   LaneOff<D> lo;
   lo.init(lane);
-  const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
+  const int bh = bid / t.nblk, blk = bid - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
   const char* kb = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
@@ -489,13 +497,23 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
-          if (single) {
+          if (p.acc_mode == 0) {
             char* d1 = dkb + (tok * dksn + DQ * g) * 2;
             char* d2 = dvb + (tok * dvsn + DQ * g) * 2;
 #pragma unroll
             for (int c = 0; c < DQ / 8; ++c) {
               stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
               stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
+            }
+          } else if (p.acc_mode == 2) {
+            // merged query blocks: this block's own slice, every (token, channel) written once
+            const size_t row = ((size_t)t.slice * p.B * p.H + bh) * p.G.N + tok;
+            float4* a1 = reinterpret_cast<float4*>(p.dk32 + row * D + DQ * g);
+            float4* a2 = reinterpret_cast<float4*>(p.dv32 + row * D + DQ * g);
+#pragma unroll
+            for (int i = 0; i < DQ / 4; ++i) {
+              a1[i] = make_float4(fk[4 * i], fk[4 * i + 1], fk[4 * i + 2], fk[4 * i + 3]);
+              a2[i] = make_float4(fv[4 * i], fv[4 * i + 1], fv[4 * i + 2], fv[4 * i + 3]);
             }
           } else {
             // overlapping windows / query blocks: a token is a key of several (window, query block)
@@ -551,52 +569,97 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
     const long row = idx / (D / 8);
     const int tok = (int)(row % p.G.N);
     const int bh = (int)(row / p.G.N), b = bh / p.H, h = bh - b * p.H;
-    float f[8];
-    const float* s1 = p.dk32 + row * D + c * 8;
-    const float* s2 = p.dv32 + row * D + c * 8;
+    float f[8], f2[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = s1[i];
+    for (int i = 0; i < 8; ++i) f[i] = f2[i] = 0.f;
+    // slices that hold this token: all of them, or (causal masks: a query block's key list ends at
+    // its own last query) the blocks from the token's own on
+    int s0 = 0, s1n = 1;
+    if (p.acc_mode == 2) {
+      s1n = p.t.qsplit;
+      if (p.causal == 2) s0 = (tok % p.w) / p.t.Wq;
+    }
+    const size_t slice = (size_t)p.B * p.H * p.G.N * D;
+    for (int sl = s0; sl < s1n; ++sl) {
+      const float* s1 = p.dk32 + sl * slice + row * D + c * 8;
+      const float* s2 = p.dv32 + sl * slice + row * D + c * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { f[i] += s1[i]; f2[i] += s2[i]; }
+    }
     stg16(p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + c * 8) * 2, pack8<E>(f));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = s2[i];
-    stg16(p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + c * 8) * 2, pack8<E>(f));
+    stg16(p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + c * 8) * 2, pack8<E>(f2));
   }
 }
 
 template <typename E, int D>
 static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
-  const bool single = win_bwd_single(p0.t);
-  if (!single) {
-    const size_t bytes = (size_t)p0.B * p0.H * p0.G.N * D * sizeof(float);
-    hipError_t e = hipMemsetAsync(p0.dk32, 0, bytes, st);
-    if (e == hipSuccess) e = hipMemsetAsync(p0.dv32, 0, bytes, st);
-    if (e != hipSuccess) return (int)e;
-  }
-  int rc = EA_OK;
-  // one launch per (colour class, query block); stream order separates them
-  win_bwd_launches(geom, p0.t, [&](const WinTiling& tl) {
-    if (rc != EA_OK) return;
-    WinP p = p0;
-    p.t = tl;
-    // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
-    // every window; from global memory those loads sit exposed in the inner loops)
-    p.bias_lds = (p.bias && window_bwd_lds(p.t, D, true, true) <= WIN_LDS_MAX) ? 1 : 0;
-    const size_t lds = window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0);
-    if (lds > WIN_LDS_MAX) { rc = EA_E_UNSUPPORTED; return; }
+  const bool single = win_bwd_single(p0.t), merged = win_bwd_merged(p0.t);
+  auto pick = [&](const WinP& p, bool gb) -> KernelT {
+    return p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
+                    : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
+  };
+  auto launch = [&](WinP& p, size_t lds, unsigned blocks) -> int {
     const bool gb = p.bias && !p.bias_lds;
-    const KernelT kern = p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
-                                  : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
+    const KernelT kern = pick(p, gb);
+    if (lds > WIN_LDS_MAX) return EA_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { rc = (int)e; return; }
+      if (e != hipSuccess) return (int)e;
     }
-    const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, outp, biasT);
-  });
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, p, outp, biasT);
+    return EA_OK;
+  };
+  int rc = EA_OK;
+  if (merged) {
+    // all query blocks of the (non-overlapping) windows in one launch, the longest key lists first
+    WinTiling tl[4];
+    int n = 0;
+    win_bwd_launches(geom, p0.t, [&](const WinTiling& t) { tl[n] = t; tl[n].slice = t.qoff / t.Wq; ++n; });
+    WinP p = p0;
+    p.acc_mode = 2;
+    p.nq = n;
+    // the bias table is staged in LDS only if every block's image has room for it
+    bool fits = p.bias != nullptr;
+    for (int i = 0; i < n; ++i) fits = fits && window_bwd_lds(tl[i], D, true, true) <= WIN_LDS_MAX;
+    p.bias_lds = fits ? 1 : 0;
+    size_t lds = 0;
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+      p.tv[i] = tl[n - 1 - i];
+      p.qstart[i] = start;
+      start += p.B * p.H * p.tv[i].nblk;
+      lds = std::max(lds, window_bwd_lds(p.tv[i], D, p.bias != nullptr, p.bias_lds != 0));
+    }
+    p.qstart[n] = start;
+    rc = launch(p, lds, (unsigned)start);
+  } else {
+    if (!single) {
+      const size_t bytes = (size_t)p0.B * p0.H * p0.G.N * D * sizeof(float);
+      hipError_t e = hipMemsetAsync(p0.dk32, 0, bytes, st);
+      if (e == hipSuccess) e = hipMemsetAsync(p0.dv32, 0, bytes, st);
+      if (e != hipSuccess) return (int)e;
+    }
+    // one launch per (colour class, query block); stream order separates them
+    win_bwd_launches(geom, p0.t, [&](const WinTiling& t) {
+      if (rc != EA_OK) return;
+      WinP p = p0;
+      p.t = t;
+      p.acc_mode = single ? 0 : 1;
+      p.nq = 0;
+      // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
+      // every window; from global memory those loads sit exposed in the inner loops)
+      p.bias_lds = (p.bias && window_bwd_lds(p.t, D, true, true) <= WIN_LDS_MAX) ? 1 : 0;
+      rc = launch(p, window_bwd_lds(p.t, D, p.bias != nullptr, p.bias_lds != 0), (unsigned)(p.B * p.H * p.t.nblk));
+    });
+  }
   if (rc != EA_OK) return rc;
-  if (!single) hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, p0);
+  if (!single) {
+    WinP pf = p0;
+    pf.acc_mode = merged ? 2 : 1;
+    hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, pf);
+  }
   return (int)hipGetLastError();
 }
 

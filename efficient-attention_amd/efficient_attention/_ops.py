@@ -151,8 +151,9 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
         alloc = torch.zeros if nv.query("ea_window_bwd_query_blocks", geom) > 1 else torch.empty
         dbias_p = alloc((parts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
     dk_acc = dv_acc = None
-    if nv.query("ea_window_bwd_needs_acc", geom):
-        dk_acc = torch.empty((B, h, N, d), dtype=torch.float32, device=dev)
+    slices = nv.query("ea_window_bwd_acc_slices", geom)
+    if slices:
+        dk_acc = torch.empty((slices, B, h, N, d), dtype=torch.float32, device=dev)
         dv_acc = torch.empty_like(dk_acc)
     bias_t = None
     if bias_p is not None and nv.query("ea_window_bwd_needs_bias_t", geom):

@@ -107,11 +107,12 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  * accumulated).  It runs as one launch per group of (window, query block) pairs that share no key:
  * with overlapping windows (ext > 0) a token is a key of several windows, and a 1-D window whose
  * rows do not fit one LDS image (e.g. window 128 at D = 128) is processed in
- * ea_window_bwd_query_blocks(g) blocks of queries.  Whenever there is more than one launch
- * (ea_window_bwd_needs_acc(g) == 1) the caller passes two fp32 scratch buffers dk_acc, dv_acc of
- * [B,H,N,D] (zeroed inside) that collect the key/value gradients before they are converted into
- * dk/dv; they may be NULL otherwise.  With more than one query block dbias_part must be ZEROED by
- * the caller (a launch writes only its block's rows).
+ * ea_window_bwd_query_blocks(g) blocks of queries (launched together when the windows do not
+ * overlap, each block with its own scratch slice).  The caller then passes two fp32 scratch buffers
+ * dk_acc, dv_acc of [ea_window_bwd_acc_slices(g), B,H,N,D] (initialised inside) that collect the
+ * key/value gradients before they are summed and converted into dk/dv; they may be NULL when that
+ * count is 0.  With more than one query block dbias_part must be ZEROED by the caller (a block
+ * writes only its own rows).
  * The landmark and bias gradients come back as per-workgroup partial sums which the caller
  * reduces over the leading axes:
  *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
@@ -122,7 +123,7 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
 int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
 int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g);
-int32_t ea_window_bwd_needs_acc(const ea_geom* g);  /* 1: dk_acc / dv_acc are required       */
+int32_t ea_window_bwd_acc_slices(const ea_geom* g); /* [B,H,N,D] slices of dk_acc / dv_acc  */
 int32_t ea_window_bwd_query_blocks(const ea_geom* g); /* > 1: dbias_part must be zeroed      */
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
