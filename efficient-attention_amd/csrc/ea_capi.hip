@@ -62,6 +62,11 @@ int32_t ea_window_bwd_needs_bias_t(const ea_geom* g) {
   win_bwd_launches(*g, t, [&](const WinTiling& tl) { any |= window_bwd_lds(tl, g->D, true, true) > WIN_LDS_MAX; });
   return any;
 }
+int32_t ea_window_bwd_bias_parts(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
+  return win_bwd_bias_parts(*g, t);
+}
 int32_t ea_window_bwd_acc_slices(const ea_geom* g) {
   WinTiling t;
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;

@@ -32,6 +32,8 @@ struct WinTiling {
   // blocks of Wq (= WqFull / qsplit) rows, one launch each, like colour classes (they share keys).
   int qsplit, qoff, WqFull;   // blocks per window; first query slot of this launch's block; w (or w*w)
   int slice;                  // merged query-block launch: this block's slice of the dk/dv scratch
+  int bblk0;                  // offset of this launch's workgroups in dbias_part (query blocks write
+                              // disjoint rows, so merged blocks share the slabs: bblk0 = 0)
 };
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -126,6 +128,13 @@ inline bool win_sub(const ea_geom& g, WinTiling& t, int cy, int cx, int qb) {
   return true;
 }
 
+// one launch covers everything: no overlap between windows and the whole window in one query block
+__host__ __device__ inline bool win_bwd_single(const WinTiling& t) { return t.ncx * t.ncy * t.qsplit == 1; }
+// Query blocks of non-overlapping windows share keys only with each other: given one dk/dv scratch
+// slice per block they need no ordering and run as ONE launch (more workgroups in flight, the long
+// blocks first), and the slices are summed afterwards.
+inline bool win_bwd_merged(const WinTiling& t) { return t.qsplit > 1 && t.qsplit <= 4 && t.ncx * t.ncy == 1; }
+// fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
 // The backward runs as one launch per (colour class, query block); f(tiling) for each of them, in
 // launch order, with blk0 = the launch's offset in the per-workgroup partial buffers.
 template <typename F>
@@ -137,19 +146,22 @@ inline int win_bwd_launches(const ea_geom& g, const WinTiling& base, F&& f) {
         WinTiling c = base;
         if (!win_sub(g, c, cy, cx, qb)) continue;
         c.blk0 = blk0;
+        c.bblk0 = win_bwd_merged(base) ? 0 : blk0;
         blk0 += c.nblk;
         f(c);
       }
   return blk0;
 }
-// one launch covers everything: no overlap between windows and the whole window in one query block
-__host__ __device__ inline bool win_bwd_single(const WinTiling& t) { return t.ncx * t.ncy * t.qsplit == 1; }
-// Query blocks of non-overlapping windows share keys only with each other: given one dk/dv scratch
-// slice per block they need no ordering and run as ONE launch (more workgroups in flight, the long
-// blocks first), and the slices are summed afterwards.
-inline bool win_bwd_merged(const WinTiling& t) { return t.qsplit > 1 && t.qsplit <= 4 && t.ncx * t.ncy == 1; }
-// fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
+// leading dimension of dbias_part
+inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t);
 inline int win_bwd_acc_slices(const WinTiling& t) { return win_bwd_single(t) ? 0 : (win_bwd_merged(t) ? t.qsplit : 1); }
+
+inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t) {
+  if (!win_bwd_merged(t)) return t.parts_total;
+  int m = 0;
+  win_bwd_launches(g, t, [&](const WinTiling& c) { m = c.nblk > m ? c.nblk : m; });
+  return m;
+}
 
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
@@ -170,7 +182,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   }
   t.WqFull = t.Wq;
   t.biasLd = ceil_div(t.Wk, 16) * 16;
-  t.qsplit = 1; t.qoff = 0; t.slice = 0;
+  t.qsplit = 1; t.qoff = 0; t.slice = 0; t.bblk0 = 0;
   t.ncx = t.ncy = 1;
   t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
   win_derive(g, t, backward);

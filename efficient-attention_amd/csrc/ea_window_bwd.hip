@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   }
   if (p.bias) {
     __syncthreads();
-    float* dst = p.dbias_part + ((((size_t)(t.blk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)t.biasLd;
+    float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)t.biasLd;
     for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[(idx / t.biasLd) * BLD + (idx % t.biasLd)];
   }
   EA_STAMP(p, 61);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "ea_window_bwd_parts": [_G],
     "ea_window_bwd_needs_bias_t": [_G],
     "ea_window_bwd_acc_slices": [_G],
+    "ea_window_bwd_bias_parts": [_G],
     "ea_window_bwd_query_blocks": [_G],
 }
 

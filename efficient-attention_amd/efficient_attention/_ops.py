@@ -149,7 +149,8 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
     if bias_p is not None:
         # several query blocks per window: each launch writes only its block's rows
         alloc = torch.zeros if nv.query("ea_window_bwd_query_blocks", geom) > 1 else torch.empty
-        dbias_p = alloc((parts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
+        bparts = nv.query("ea_window_bwd_bias_parts", geom)
+        dbias_p = alloc((bparts, B) + tuple(bias_p.shape), dtype=torch.float32, device=dev)
     dk_acc = dv_acc = None
     slices = nv.query("ea_window_bwd_acc_slices", geom)
     if slices:
@@ -174,7 +175,7 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
         nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlk_p), nv.ptr(dlk), nv.stream())
         nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlv_p), nv.ptr(dlv), nv.stream())
     if bias_p is not None:
-        dbias = colsum_f32(dbias_p.view(parts * B, -1)).view(bias_p.shape)
+        dbias = colsum_f32(dbias_p.view(dbias_p.shape[0] * B, -1)).view(bias_p.shape)
     return dlk, dlv, dbias
 
 
@@ -210,6 +211,34 @@ class LocalAttnFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # EVA  (reference eva.py:145-227)
 # ------------------------------------------------------------------------------------------
+class _RowsLinearF32(torch.autograd.Function):
+    """fp32 y = x W^T + b over many rows with a small [d,d] weight (the mu MLP on B*h*L chunk
+    means).  The weight gradient contracts over all rows into a 16 K-element result -- as one
+    library GEMM it fills a handful of CUs -- so it runs as a batched GEMM over row slices whose
+    partials are summed; the bias gradient is a fixed-order column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        return torch.addmm(bias, x2, weight.t()).view(x.shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        rows = x2.shape[0]
+        S = 1
+        for s_ in range(2, 65):
+            if rows % s_ == 0 and rows // s_ >= 128:
+                S = s_
+        dx = (dy2 @ weight).view(dy.shape[:-1] + (weight.shape[1],))
+        part = torch.bmm(dy2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1))
+        dw = part.sum(0) if S > 1 else part[0]
+        db = colsum_f32(dy2) if dy2.is_cuda else dy2.sum(0)
+        return dx, dw, db
+
+
 def eva_mu(qmean, kmean, params, adaptive_proj, mu_scale=0.5):
     """rf_k_bar, mu from the chunk means (eva.py:178-185; causal_eva.py:706-709 with
     mu_scale = 1). fp32, [B,h,L,d] -- tiny."""
@@ -217,14 +246,14 @@ def eva_mu(qmean, kmean, params, adaptive_proj, mu_scale=0.5):
     if adaptive_proj in ("default", "no-ln"):
         if adaptive_proj == "default":
             wq, bq, gq, cq, wk, bk, gk, ck = params
-            rq = F.layer_norm(F.linear(qmean, wq, bq), (d,), gq, cq, 1e-5)
-            rk = F.layer_norm(F.linear(kmean, wk, bk), (d,), gk, ck, 1e-5)
+            rq = F.layer_norm(_RowsLinearF32.apply(qmean, wq, bq), (d,), gq, cq, 1e-5)
+            rk = F.layer_norm(_RowsLinearF32.apply(kmean, wk, bk), (d,), gk, ck, 1e-5)
         else:
             wq, bq, wk, bk = params
-            rq, rk = F.linear(qmean, wq, bq), F.linear(kmean, wk, bk)
+            rq, rk = _RowsLinearF32.apply(qmean, wq, bq), _RowsLinearF32.apply(kmean, wk, bk)
         return rk, mu_scale * (rq + rk)
     wk, bk, gk, ck = params
-    rk = F.layer_norm(F.linear(kmean, wk, bk), (d,), gk, ck, 1e-5)
+    rk = F.layer_norm(_RowsLinearF32.apply(kmean, wk, bk), (d,), gk, ck, 1e-5)
     return rk, torch.zeros_like(rk)
 
 
@@ -265,12 +294,20 @@ class EvaAttnFn(torch.autograd.Function):
                     nv.ptr(saved), nv.stream())
             ctx.lmk = (lg, noise_c, saved)
         else:
-            # the tiny mu MLP stays in fp32 (autocast off) so forward and the recompute in backward agree
-            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):
-                rf_k_bar, mu = eva_mu(qmean, kmean, [p.float() for p in mlp_params], adaptive_proj,
-                                      mu_scale)
+            # the tiny mu MLP stays in fp32 (autocast off).  When a backward will follow, its autograd
+            # graph (on detached leaves) is built here and kept, so backward differentiates it without
+            # recomputing the forward.
+            keep = any(ctx.needs_input_grad)
+            with torch.set_grad_enabled(keep), torch.autocast(device_type="cuda", enabled=False):
+                qm = qmean.detach().requires_grad_(keep)
+                km = kmean.detach().requires_grad_(keep)
+                ps = [p.detach().float().requires_grad_(keep) for p in mlp_params]
+                rk_g, mu_g = eva_mu(qm, km, ps, adaptive_proj, mu_scale)
+            ctx.mu_graph = (qm, km, ps, rk_g, mu_g) if keep else None
+            with torch.no_grad():
+                mu = mu_g.detach()
                 omega = (mu if noise is None else mu + noise.float()).contiguous()
-                rf_k_bar = rf_k_bar.contiguous()
+                rf_k_bar = rk_g.detach().contiguous()
             ctx.lmk = None
         beta = torch.empty_like(qmean)
         nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
@@ -324,10 +361,8 @@ class EvaAttnFn(torch.autograd.Function):
         # mu MLP backward on the tiny [B,h,L,d] tensors (Linear/LayerNorm parameter grads are
         # [d,d] GEMMs over B*h*L rows -- left to torch)
         with torch.enable_grad(), torch.autocast(device_type="cuda", enabled=False):
-            qm = qmean.detach().requires_grad_(True)
-            km = kmean.detach().requires_grad_(True)
-            ps = [p.detach().float().requires_grad_(True) for p in mlp_params]
-            rk, mu = eva_mu(qm, km, ps, ctx.adaptive_proj, ctx.mu_scale)
+            qm, km, ps, rk, mu = ctx.mu_graph
+            ctx.mu_graph = None
             outs, gouts = [rk], [d_rfk.contiguous()]
             if mu.requires_grad:
                 outs.append(mu)

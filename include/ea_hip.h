@@ -116,12 +116,13 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  * The landmark and bias gradients come back as per-workgroup partial sums which the caller
  * reduces over the leading axes:
  *   dlk_part, dlv_part : fp32 [ea_window_bwd_parts(g), B*H, L, D]
- *   dbias_part         : fp32 [ea_window_bwd_parts(g), B, H, Wq, ld]   (NULL iff bias NULL)
+ *   dbias_part         : fp32 [ea_window_bwd_bias_parts(g), B, H, Wq, ld]   (NULL iff bias NULL)
  *   bias_t             : fp32 [H, ld, 16*ceil(Wq/16)] transposed copy of `bias` (rows padded with
  *                        zeros).  Only read when the head's bias table does not fit next to the
  *                        window in LDS (ea_window_bwd_needs_bias_t(g) == 1); may be NULL otherwise. */
 int32_t ea_window_bias_ld(const ea_geom* g);        /* padded row length of `bias`           */
-int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of the *_part buffers     */
+int32_t ea_window_bwd_parts(const ea_geom* g);      /* leading dim of dlk_part / dlv_part    */
+int32_t ea_window_bwd_bias_parts(const ea_geom* g); /* leading dim of dbias_part             */
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g);
 int32_t ea_window_bwd_acc_slices(const ea_geom* g); /* [B,H,N,D] slices of dk_acc / dv_acc  */
 int32_t ea_window_bwd_query_blocks(const ea_geom* g); /* > 1: dbias_part must be zeroed      */
