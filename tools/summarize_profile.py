@@ -18,9 +18,10 @@ KERNEL_TO_ENTRY = [
     ("lara_y_kernel<ea::BF16, 64, 2>", "ea_lara_bwd_kstats"),
     ("lara_lmk_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lara_lmk_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("lara_merge_fwd_kernel", "ea_lara_merge_fwd"), ("lara_merge_bwd_kernel", "ea_lara_merge_bwd"),
-    ("win_fwd_kernel<ea::BF16, 64>", "ea_window_attn_fwd"), ("win_bwd_kernel<ea::BF16, 64", "ea_window_attn_bwd"),
-    ("chunk_mean_fwd_kernel<ea::BF16, 64", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<ea::BF16, 64", "ea_eva_chunk_mean_bwd"),
-    ("beta_fwd_kernel<ea::BF16, 64", "ea_eva_beta_fwd"), ("beta_bwd_kernel<ea::BF16, 64", "ea_eva_beta_bwd"),
+    ("win_fwd_kernel<", "ea_window_attn_fwd"), ("win_bwd_finish_kernel<", "ea_window_attn_bwd(finish)"),
+    ("win_bwd_kernel<", "ea_window_attn_bwd"),
+    ("chunk_mean_fwd_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<", "ea_eva_chunk_mean_bwd"),
+    ("beta_fwd_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_kernel<", "ea_eva_beta_bwd"),
     ("sm_fwd_kernel<ea::BF16, 64>", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dq)"),
     ("sm_bwd_dkv_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dkv)"),
     ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
@@ -35,7 +36,7 @@ def entry_of(kname):
     return None
 
 
-def main(src, tag, attn, outdir):
+def main(src, tag, attn, outdir, workload="default workload"):
     os.makedirs(outdir, exist_ok=True)
     stats = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
     keep = [r for r in stats if "ea::" in r["Name"]] + [r for r in stats if "ea::" not in r["Name"]][:12]
@@ -64,11 +65,12 @@ def main(src, tag, attn, outdir):
     json.dump(out, open(os.path.join(outdir, "pmc_%s.json" % attn), "w"), indent=1)
     open(os.path.join(outdir, "%s_%s_hbm.md" % (tag, attn)), "w").write(
         "HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --attn %s "
-        "default workload.\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B; "
-        "calibrated here on ea_lara_out_fwd whose WRITE_SIZE equals its 38.5 MB output exactly).\n\n" % attn
+        "%s.\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B; "
+        "calibrated here on ea_lara_out_fwd whose WRITE_SIZE equals its 38.5 MB output exactly).\n\n" % (attn, workload)
         + "\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles")
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "profiles",
+         sys.argv[5] if len(sys.argv) > 5 else "default workload")
