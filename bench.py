@@ -75,8 +75,9 @@ def _seq(grid):
 
 
 # causal_eva on the wikitext-103 recipe (reference README.md:184; main.sh:52-81: transformer_lm_wiki103
-# = embed 1024 / 8 heads, --tokens-per-sample 512, --max-tokens 9216 -> 18 samples per GPU).  The
-# recipe's attention dropout (0.1) is not built into the kernel yet: the layer is timed with dropout 0.
+# = embed 1024 / 8 heads, attention dropout 0.1, --tokens-per-sample 512, --max-tokens 9216 -> 18
+# samples per GPU).
+LM_ATTENTION_DROPOUT = 0.1
 LM_ATTN_ARGS = dict(window_size=128, chunk_size=8, causal=True, adaptive_proj="qk", use_t5_rpe=True,
                     num_chunks=None, overlap_window=False)
 
@@ -90,7 +91,7 @@ def build_layer(attn, dim, heads, grid, device):
             if OVERRIDES.get("window_size"):
                 aa["window_size"] = OVERRIDES["window_size"]
             return ea.AttentionFactory.build_attention(attn, dict(
-                embed_dim=dim, num_heads=heads, dropout=0.0, self_attention=True,
+                embed_dim=dim, num_heads=heads, dropout=LM_ATTENTION_DROPOUT, self_attention=True,
                 attn_args=argparse.Namespace(**aa))).to(device)
         return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, _seq(grid))).to(device)
 
@@ -106,7 +107,7 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
     params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
     seq = _seq(grid)
     if attn == "causal_eva":
-        args = dict(embed_dim=dim, num_heads=heads, attn_args=dict(
+        args = dict(embed_dim=dim, num_heads=heads, dropout=LM_ATTENTION_DROPOUT, attn_args=dict(
             LM_ATTN_ARGS, window_size=OVERRIDES.get("window_size") or LM_ATTN_ARGS["window_size"]))
     else:
         args = attn_args(attn, dim, heads, seq)
@@ -117,7 +118,8 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
     def step():
         for p in params.values():
             p.grad = None
-        y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn)
+        y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn,
+                                  keep_fn=lambda shape: (torch.rand(*shape) >= LM_ATTENTION_DROPOUT).float())
         (y * g).sum().backward()
 
     ntok = 1

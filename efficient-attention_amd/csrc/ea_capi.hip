@@ -50,6 +50,11 @@ int32_t ea_window_bias_ld(const ea_geom* g) {
   if (!geom_ok(g) || win_tiling(*g, t, false) != EA_OK) return EA_E_BADARG;
   return t.biasLd;
 }
+int32_t ea_window_keep_ld(const ea_geom* g) {
+  WinTiling t;
+  if (!geom_ok(g) || win_tiling(*g, t, false) != EA_OK) return EA_E_BADARG;
+  return t.biasLd + t.nCT * 16;
+}
 int32_t ea_window_bwd_parts(const ea_geom* g) {
   WinTiling t;
   if (!geom_ok(g) || win_tiling(*g, t, true) != EA_OK) return EA_E_BADARG;
@@ -93,10 +98,12 @@ static int fill_win(const ea_geom* g, WinP& p, bool backward) {
 
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
-                       const ea_t4* out, float* lse, void* stream) {
+                       const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale, void* stream) {
   WinP p = {};
   int rc = fill_win(g, p, false);
   if (rc != EA_OK) return rc;
+  if (keep && !g->causal) return EA_E_UNSUPPORTED;
+  p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = p.t.biasLd + p.t.nCT * 16;
   if (!t4_ok(q, g->D) || !t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(out, g->D) || !lse) return EA_E_BADARG;
   if (g->L > 0 && (!lk || !lv)) return EA_E_BADARG;
   p.q = mk(q); p.k = mk(k); p.v = mk(v); p.o = mk(out);
@@ -109,10 +116,13 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const ea_t4* out, const ea_t4* dout, const float* lse,
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
-                       float* dk_acc, float* dv_acc, const float* bias_t, void* stream) {
+                       float* dk_acc, float* dv_acc, const float* bias_t,
+                       const uint8_t* keep, float keep_scale, void* stream) {
   WinP p = {};
   int rc = fill_win(g, p, true);
   if (rc != EA_OK) return rc;
+  if (keep && !g->causal) return EA_E_UNSUPPORTED;
+  p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = p.t.biasLd + p.t.nCT * 16;
   const int N = g->N;
   if (!t4_ok32(q, g->D, N) || !t4_ok32(k, g->D, N) || !t4_ok32(v, g->D, N) || !t4_ok32(dout, g->D, N) ||
       !t4_ok32(out, g->D, N) || (win_bwd_acc_slices(p.t) > 0 && (!dk_acc || !dv_acc)) || !t4_ok32(dq, g->D, N) ||

@@ -133,7 +133,9 @@ __host__ __device__ inline bool win_bwd_single(const WinTiling& t) { return t.nc
 // Query blocks of non-overlapping windows share keys only with each other: given one dk/dv scratch
 // slice per block they need no ordering and run as ONE launch (more workgroups in flight, the long
 // blocks first), and the slices are summed afterwards.
-inline bool win_bwd_merged(const WinTiling& t) { return t.qsplit > 1 && t.qsplit <= 4 && t.ncx * t.ncy == 1; }
+inline bool win_bwd_merged(const WinTiling& t) {
+  return t.causal && t.qsplit > 1 && t.qsplit <= 4 && t.ncx * t.ncy == 1;
+}
 // fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
 // The backward runs as one launch per (colour class, query block); f(tiling) for each of them, in
 // launch order, with blk0 = the launch's offset in the per-workgroup partial buffers.
@@ -230,6 +232,12 @@ struct WinP {
   int causal, chunk;                         // ea_geom.causal and the landmark chunk length (causal masks)
   float scale, scale_log2;
   WinTiling t;
+  // attention dropout (causal_eva.py:778): keep mask [B,H,N,keep_ld] u8 over the softmax columns of a
+  // query -- local slot j at column j, landmark c at column biasLd + c -- or nullptr; kept
+  // probabilities are scaled by keep_scale = 1/(1-p)
+  const uint8_t* keep;
+  int keep_ld;
+  float keep_scale;
   int bias_lds;                              // bwd: the bias table of the head is staged in LDS
   // bwd, how local dk/dv leave the kernel: 0 = stored to dk/dv; 1 = fp32 read-modify-write into dk32/dv32
   // (launches ordered by the stream); 2 = plain fp32 stores into slice t.slice of dk32/dv32

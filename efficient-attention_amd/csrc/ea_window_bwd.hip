@@ -24,7 +24,8 @@ namespace ea {
 // that the inner loops carry no branches and hipcc can interleave the independent tiles.
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits, staged per
 // query row in LDS for phase B.
-template <typename E, int D, bool GB, bool CA>
+// DR (with CA): attention dropout from an explicit keep mask (dP and the P of dV carry the mask).
+template <typename E, int D, bool GB, bool CA, bool DR>
 __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
@@ -33,14 +34,16 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   constexpr int DQ = D / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // merged query-block launch: this workgroup's tiling and its index within that tiling's range
+  // (only in the causal_eva instantiations: a tiling picked at run time keeps its fields out of the
+  // preloaded kernel-argument registers, which costs the other variants ~6 %)
   int qi = 0;
-  if (p.nq > 1) {
+  if (CA && p.nq > 1) {
 #pragma unroll
     for (int i = 1; i < 4; ++i)
       if (i < p.nq && (int)blockIdx.x >= p.qstart[i]) qi = i;
   }
-  const WinTiling& t = p.nq > 1 ? p.tv[qi] : p.t;
-  const int bid = p.nq > 1 ? (int)blockIdx.x - p.qstart[qi] : (int)blockIdx.x;
+  const WinTiling& t = (CA && p.nq > 1) ? p.tv[qi] : p.t;
+  const int bid = (CA && p.nq > 1) ? (int)blockIdx.x - p.qstart[qi] : (int)blockIdx.x;
   const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
   const int rowsQ = t.wpi * nQTe * 16;
   char* Ks = smem;
@@ -316,6 +319,13 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
           const int kidx0 = (local ? tile : tile - t.nLT) * 16 + 4 * g;
           const int lim = local ? ql.local : ql.lm;
+          uint32_t keep4 = 0x01010101u;
+          if (DR) {
+            const bool real = tile < t.nLT + t.nCT;
+            const int col = local ? tile * 16 : t.biasLd + (tile - t.nLT) * 16;
+            keep4 = real ? *reinterpret_cast<const uint32_t*>(
+                               p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + col + 4 * g) : 0u;
+          }
           float ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -327,8 +337,10 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
               gm = blocked ? 0.f : gm;
             }
             const float pr = fast_exp2(x - lse2);
+            float dpr = dp[r];
+            if (DR) dpr = ((keep4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
             // masked_fill blocks the gradient of the replaced logits (mul == 0)
-            ds[r] = gm * pr * (dp[r] - delta);
+            ds[r] = gm * pr * (dpr - delta);
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
@@ -451,7 +463,17 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                   gm = blocked ? 0.f : gm;
                 }
                 pr[r] = fast_exp2(x - ll[r]);
-                ds[r] = gm * pr[r] * (dp[r] - dd[r]);
+                float dpr = dp[r];
+                float km = 1.f;
+                if (DR) {
+                  // 1-D windows: token of query slot qs of window wi; this lane's softmax column
+                  const int qtk = colour_win(t, p.G, p.w, it * t.wpi + wi) * p.w + t.qoff + min(qs, t.Wq - 1);
+                  const int kcol = is_lm ? t.biasLd + kslot : kslot;
+                  km = p.keep[((size_t)bh * p.G.N + qtk) * p.keep_ld + kcol] ? p.keep_scale : 0.f;
+                  dpr *= km;
+                }
+                ds[r] = gm * pr[r] * (dpr - dd[r]);
+                if (DR) pr[r] *= km;                        // dV sees the dropped probabilities
                 if (BM == 1) {
                   float* dst = bias_on ? dbias_s + qs * BLD + kslot : trash64 + lane;
                   *dst += ds[r];
@@ -595,9 +617,11 @@ template <typename E, int D>
 static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
   const bool single = win_bwd_single(p0.t), merged = win_bwd_merged(p0.t);
+  if (p0.keep && !p0.causal) return EA_E_UNSUPPORTED;
   auto pick = [&](const WinP& p, bool gb) -> KernelT {
-    return p.causal ? (gb ? &win_bwd_kernel<E, D, true, true> : &win_bwd_kernel<E, D, false, true>)
-                    : (gb ? &win_bwd_kernel<E, D, true, false> : &win_bwd_kernel<E, D, false, false>);
+    if (p.keep) return gb ? &win_bwd_kernel<E, D, true, true, true> : &win_bwd_kernel<E, D, false, true, true>;
+    return p.causal ? (gb ? &win_bwd_kernel<E, D, true, true, false> : &win_bwd_kernel<E, D, false, true, false>)
+                    : (gb ? &win_bwd_kernel<E, D, true, false, false> : &win_bwd_kernel<E, D, false, false, false>);
   };
   auto launch = [&](WinP& p, size_t lds, unsigned blocks) -> int {
     const bool gb = p.bias && !p.bias_lds;

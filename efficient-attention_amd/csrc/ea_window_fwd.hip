@@ -24,7 +24,8 @@ namespace ea {
 
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits on top of the
 // per-key (mul, add) pairs.
-template <typename E, int D, bool CA>
+// DR (with CA): attention dropout from an explicit keep mask.
+template <typename E, int D, bool CA, bool DR>
 __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const WinP p) {
   constexpr int ROWB = D * 2;      // bytes per LDS row
   constexpr int CPR = D / 8;       // 16-byte chunks per row
@@ -231,6 +232,22 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
           pw[tt][0] = pack2<E>(pv[0], pv[1]);
           pw[tt][1] = pack2<E>(pv[2], pv[3]);
         }
+        if (DR) {
+          // dropped entries leave the numerator only; the normaliser keeps every column
+          const uint8_t* krow = p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + 4 * g;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            const int tile = ch * 4 + tt;
+            const bool real = tile < t.nLT + t.nCT;
+            const int col = tile < t.nLT ? tile * 16 : t.biasLd + (tile - t.nLT) * 16;
+            const uint32_t m4 = real ? *reinterpret_cast<const uint32_t*>(krow + col) : 0u;
+            float pv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = ((m4 >> (8 * r)) & 0xffu) ? fast_exp2(s[tt][r] - msafe) * p.keep_scale : 0.f;
+            pw[tt][0] = pack2<E>(pv[0], pv[1]);
+            pw[tt][1] = pack2<E>(pv[2], pv[3]);
+          }
+        }
         lsum = lsum * alpha + psum;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
@@ -270,22 +287,23 @@ size_t window_fwd_lds(const WinTiling& t, int D) {
   return (size_t)t.rowsTotal * D * 2 * 2 + (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + t.nQT * 16) * 4;
 }
 
-template <typename E, int D, bool CA>
+template <typename E, int D, bool CA, bool DR>
 static int launch_fwd_ca(const WinP& p, hipStream_t st) {
   const size_t lds = window_fwd_lds(p.t, D);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D, CA>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D, CA, DR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  hipLaunchKernelGGL((win_fwd_kernel<E, D, CA>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((win_fwd_kernel<E, D, CA, DR>), grid, dim3(256), lds, st, p);
   return (int)hipGetLastError();
 }
 template <typename E, int D>
 static int launch_fwd(const WinP& p, hipStream_t st) {
-  return p.causal ? launch_fwd_ca<E, D, true>(p, st) : launch_fwd_ca<E, D, false>(p, st);
+  if (p.keep) return p.causal ? launch_fwd_ca<E, D, true, true>(p, st) : EA_E_UNSUPPORTED;
+  return p.causal ? launch_fwd_ca<E, D, true, false>(p, st) : launch_fwd_ca<E, D, false, false>(p, st);
 }
 
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st) {

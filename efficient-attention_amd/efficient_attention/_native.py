@@ -65,8 +65,9 @@ SIGNATURES = {
     "ea_eva_chunk_mean_bwd": [_G, _P, _P, _P, _T, _T, _P],
     "ea_eva_beta_fwd": [_G, _T, _T, _P, _P, _P, _P],
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
-    "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P],
-    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P],
+    "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P, _F, _P],
+    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P, _F, _P],
+    "ea_window_keep_ld": [_G],
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 17,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 21,
     "ea_lara_landmarks_saved_floats": [_MG],

@@ -110,7 +110,7 @@ def _bias_padded(bias, geom):
     return b.contiguous()
 
 
-def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8):
+def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8, keep=None, keep_scale=1.0):
     B, N, _, h, d = qkv5.shape
     q, k, v = _qkv_views(qkv5)
     if qkv5.stride(1) > qkv5.stride(0):
@@ -122,7 +122,7 @@ def _window_fwd(geom, qkv5, lk, lv, bias_p, mask_u8):
     tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
     nv.call("ea_window_attn_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
             ctypes.byref(tv), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
-            ctypes.byref(to), nv.ptr(lse), nv.stream())
+            ctypes.byref(to), nv.ptr(lse), nv.ptr(keep), float(keep_scale), nv.stream())
     return out, lse
 
 
@@ -134,7 +134,7 @@ def _rows_contiguous(t):
     return t.contiguous()
 
 
-def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
+def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep=None, keep_scale=1.0):
     """out, dout: [B,N,h,d] with contiguous rows.  Writes dq,dk,dv into dqkv5; returns dlk, dlv, dbias_padded."""
     B, N, _, h, d = qkv5.shape
     q, k, v = _qkv_views(qkv5)
@@ -165,7 +165,7 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5):
             ctypes.byref(ts[2]), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
             ctypes.byref(ts[3]), ctypes.byref(ts[4]), nv.ptr(lse), ctypes.byref(ts[5]),
             ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(dlk_p), nv.ptr(dlv_p), nv.ptr(dbias_p),
-            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.stream())
+            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.ptr(keep), float(keep_scale), nv.stream())
     dlk = dlv = dbias = None
     if L > 0:
         # per-workgroup partials [parts, B*h*L*d] -> one pass each (fixed summation order)
@@ -268,6 +268,8 @@ class EvaAttnFn(torch.autograd.Function):
         nv.require_cuda(qkv5, "qkv")
         attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg[:7]
         causal, mu_scale = cfg[7:9] if len(cfg) > 7 else (0, 0.5)
+        # attention dropout (causal_eva only): uint8 keep mask in the kernel's column layout + 1/(1-p)
+        keep, keep_scale = cfg[9:11] if len(cfg) > 9 else (None, 1.0)
         B, N, _, h, d = qkv5.shape
         dev = qkv5.device
         geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, chunk, L,
@@ -297,13 +299,13 @@ class EvaAttnFn(torch.autograd.Function):
             # the tiny mu MLP stays in fp32 (autocast off).  When a backward will follow, its autograd
             # graph (on detached leaves) is built here and kept, so backward differentiates it without
             # recomputing the forward.
-            keep = any(ctx.needs_input_grad)
-            with torch.set_grad_enabled(keep), torch.autocast(device_type="cuda", enabled=False):
-                qm = qmean.detach().requires_grad_(keep)
-                km = kmean.detach().requires_grad_(keep)
-                ps = [p.detach().float().requires_grad_(keep) for p in mlp_params]
+            with_graph = any(ctx.needs_input_grad)
+            with torch.set_grad_enabled(with_graph), torch.autocast(device_type="cuda", enabled=False):
+                qm = qmean.detach().requires_grad_(with_graph)
+                km = kmean.detach().requires_grad_(with_graph)
+                ps = [p.detach().float().requires_grad_(with_graph) for p in mlp_params]
                 rk_g, mu_g = eva_mu(qm, km, ps, adaptive_proj, mu_scale)
-            ctx.mu_graph = (qm, km, ps, rk_g, mu_g) if keep else None
+            ctx.mu_graph = (qm, km, ps, rk_g, mu_g) if with_graph else None
             with torch.no_grad():
                 mu = mu_g.detach()
                 omega = (mu if noise is None else mu + noise.float()).contiguous()
@@ -313,9 +315,10 @@ class EvaAttnFn(torch.autograd.Function):
         nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
                 nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
         bias_p = _bias_padded(bias, geom)
-        out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8)
+        out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, keep, keep_scale)
         ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out, qmean, kmean, omega, beta, rf_k_bar,
                               *mlp_params)
+        ctx.keep = (keep, keep_scale)
         ctx.geom = geom
         ctx.adaptive_proj = adaptive_proj
         ctx.mu_scale = mu_scale
@@ -329,7 +332,7 @@ class EvaAttnFn(torch.autograd.Function):
         geom = ctx.geom
         dqkv5 = torch.empty_like(qkv5)
         d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
-                                           _rows_contiguous(dout), lse, dqkv5)
+                                           _rows_contiguous(dout), lse, dqkv5, *ctx.keep)
         q, k, v = _qkv_views(qkv5)
         dq, dk, dv = _qkv_views(dqkv5)
         tk, tv, tdq, tdk, tdv = nv.t4(k), nv.t4(v), nv.t4(dq), nv.t4(dk), nv.t4(dv)

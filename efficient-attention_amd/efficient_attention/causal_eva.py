@@ -10,7 +10,8 @@ the incremental-state helpers fairseq's decoder calls, and the argparse flags.
 The training / evaluation path (reference :666-790: chunk means -> mu -> beta, window attention
 whose extension lies on the left only, padded queries masked, causal local mask and per-chunk causal
 control-variate mask under one softmax) runs in libea_hip.so through `_ops.EvaAttnFn` with
-`ea_geom.causal` set; there is no CPU fallback.  Token-by-token decoding with an incremental state
+`ea_geom.causal` set, attention dropout included (keep mask drawn here, applied in the kernels);
+there is no CPU fallback.  Token-by-token decoding with an incremental state
 (reference :542-665) is not built yet and raises.
 """
 import math
@@ -39,7 +40,7 @@ class CausalEVAttention(nn.Module):
         self.vdim = embed_dim if vdim is None else vdim
         self.qkv_same_dim = self.kdim == embed_dim and self.vdim == embed_dim
         self.num_heads = num_heads
-        self.dropout_module = nn.Dropout(dropout)       # attribute fairseq reads; p > 0 in training raises
+        self.dropout_module = nn.Dropout(dropout)       # holds p (fairseq reads it); applied inside the kernels
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
         self.scaling = self.head_dim ** -0.5
@@ -76,6 +77,7 @@ class CausalEVAttention(nn.Module):
             self.adaptive_mu_k = _mu_net(self.head_dim, ln)
         self.reset_parameters()
         self.onnx_trace = False
+        self._keep_mask_fn = None
 
     # ---- initialisation (reference :397-424) ----------------------------------------------
     @staticmethod
@@ -137,8 +139,6 @@ class CausalEVAttention(nn.Module):
                 "(causal_eva.py:542-665) is not part of the MI355X build yet")
         if self.adaptive_proj not in ("qk", "no-ln"):
             raise NotImplementedError("Other adaptive projection methods are not implemented yet.")
-        if self.training and self.dropout_module.p > 0:
-            raise NotImplementedError("attention dropout inside the fused window-attention kernel")
         tgt_len, bsz, embed_dim = query.shape
         assert embed_dim == self.embed_dim, "query dim %d != %d" % (embed_dim, self.embed_dim)
         w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
@@ -176,7 +176,7 @@ class CausalEVAttention(nn.Module):
         if self.training:
             noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
         cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
-               2 if self.causal else 1, 1.0)
+               2 if self.causal else 1, 1.0) + self._dropout_keep(B, h, N, w + e, L, x.device)
         out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
                                    *self._mu_params())
         # out [B, N, h, d] comes back as a view of a time-first buffer (it follows qkv's layout)
@@ -186,6 +186,28 @@ class CausalEVAttention(nn.Module):
         if N != tgt_len:
             y = y[:tgt_len]
         return y.contiguous(), None
+
+    def _dropout_keep(self, B, h, N, Wk, L, device):
+        """Attention dropout (reference :778, `attn = dropout(attn)` on the [.., Wk + L] softmax rows):
+        the Bernoulli keep decisions are drawn here -- one per (query, column), the reference's
+        layout -- and handed to the kernels as a uint8 mask; -> (keep, 1/(1-p)) or ()."""
+        p = self.dropout_module.p
+        if not (self.training and p > 0):
+            return ()
+        if p >= 1:
+            raise NotImplementedError("attention dropout with p = 1")
+        if self._keep_mask_fn is not None:                         # tests: the fixture's decisions
+            keep = self._keep_mask_fn((B, h, N, Wk + L)).to(device=device, dtype=torch.uint8)
+        else:
+            keep = torch.empty((B, h, N, Wk + L), device=device, dtype=torch.float32).bernoulli_(1 - p).to(torch.uint8)
+        # kernel layout: local columns padded to whole 16-key tiles, then the landmarks
+        ld_local, ld_lm = -(-Wk // 16) * 16, -(-L // 16) * 16
+        if ld_local != Wk or ld_lm != L:
+            padded = torch.zeros((B, h, N, ld_local + ld_lm), device=device, dtype=torch.uint8)
+            padded[..., :Wk] = keep[..., :Wk]
+            padded[..., ld_local:ld_local + L] = keep[..., Wk:]
+            keep = padded
+        return (keep.contiguous(), 1.0 / (1.0 - p))
 
     # ---- fairseq incremental-state protocol (reference :262-297, 836-871) -------------------
     def init_incremental_state(self):

@@ -103,6 +103,11 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward
  * With ea_geom.causal the windows, masks and chunk visibility follow causal_eva.py:666-783 (see the
  * field's comment); Wk = window + ext there.
+ *   keep   : attention dropout of causal_eva.py:778 (`attn = dropout(attn)` on the joint softmax):
+ *            uint8 [B,H,N, ea_window_keep_ld(g)] -- for query n, column j < Wk is local slot j and
+ *            column ea_window_bias_ld(g) + c is landmark c; non-zero = kept.  Kept probabilities are
+ *            multiplied by keep_scale = 1/(1-p); the normaliser (lse) is that of the full row.
+ *            NULL = no dropout.  Only with ea_geom.causal != 0 (the only module that applies it).
  * Backward consumes the forward's out, lse and dout and produces dq, dk, dv (WRITTEN, not
  * accumulated).  It runs as one launch per group of (window, query block) pairs that share no key:
  * with overlapping windows (ext > 0) a token is a key of several windows, and a 1-D window whose
@@ -126,15 +131,18 @@ int32_t ea_window_bwd_bias_parts(const ea_geom* g); /* leading dim of dbias_part
 int32_t ea_window_bwd_needs_bias_t(const ea_geom* g);
 int32_t ea_window_bwd_acc_slices(const ea_geom* g); /* [B,H,N,D] slices of dk_acc / dv_acc  */
 int32_t ea_window_bwd_query_blocks(const ea_geom* g); /* > 1: dbias_part must be zeroed      */
+int32_t ea_window_keep_ld(const ea_geom* g);        /* row length of `keep`                  */
 int ea_window_attn_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
-                       const ea_t4* out, float* lse, void* stream);
+                       const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale,
+                       void* stream);
 int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                        const float* lk, const float* lv, const float* bias, const uint8_t* mask,
                        const ea_t4* out, const ea_t4* dout, const float* lse,
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
-                       float* dk_acc, float* dv_acc, const float* bias_t, void* stream);
+                       float* dk_acc, float* dv_acc, const float* bias_t,
+                       const uint8_t* keep, float keep_scale, void* stream);
 
 /* ---- LARA: linear randomized attention (lara.py:177-251) -------------------------------------
  * C landmark samples omega_c (C = L, or 2L with antithetic / multi-sample noise), each token n:

@@ -235,7 +235,7 @@ def eva_core(q, k, v, mask, attn_2d, seq_shape, window_size, ext_size, num_landm
 # causal EVA (training / evaluation path, no incremental state)
 # --------------------------------------------------------------------------------------
 def causal_eva_core(q, k, v, mask, window_size, ext_size, chunk_size, mu_fn, noise=None,
-                    bias=None, causal=True, scale=None):
+                    bias=None, causal=True, scale=None, drop_keep=None, p_drop=0.0):
     """CausalEVAttention's q,k,v -> out core (causal_eva.py:666-783).
 
     q,k,v: [B,h,N,d] with N a multiple of the window (after _process_input); mask [B,N] bool or
@@ -243,7 +243,8 @@ def causal_eva_core(q, k, v, mask, window_size, ext_size, chunk_size, mu_fn, noi
     left only (:104-116), chunks are never extended (:688-694), mu = rf_q_bar + rf_k_bar (:709),
     padded QUERIES are masked as well (:742-755), and with `causal` a query sees the local keys
     up to itself (:767-773) and the control variates of the chunks before its own (:716-738).
-    bias: None or [Wq, Wk] shared by the heads (:760-762)."""
+    bias: None or [Wq, Wk] shared by the heads (:760-762).  drop_keep: None or the Bernoulli keep
+    decisions [B,h,N,Wk+L] of the attention dropout with probability p_drop (:778)."""
     B, h, n, d = q.shape
     scale = d ** -0.5 if scale is None else scale
     w, e, r = window_size, ext_size, chunk_size
@@ -286,6 +287,8 @@ def causal_eva_core(q, k, v, mask, window_size, ext_size, chunk_size, mu_fn, noi
         dots = dots.masked_fill((j - i >= 1 + e)[None, None, None], MASK_VAL)
     Wk = dots.shape[-1]
     p = torch.softmax(torch.cat([dots, cv_logits], -1), -1)
+    if drop_keep is not None:
+        p = p * drop_keep.reshape(p.shape).to(p.dtype) / (1.0 - p_drop)
     out_w = torch.einsum("bhwij,bhwjd->bhwid", p[..., :Wk], wv) \
         + torch.einsum("bhwic,bhcd->bhwid", p[..., Wk:], beta)
     return _scatter_windows(out_w, idx_q, n)
@@ -453,15 +456,16 @@ def _local_bias(params, args, h, e, scale, Wq=None, Wk=None):
     return None
 
 
-def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None):
+def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None, keep_fn=None):
     """y = module(x, key_padding_mask) for attn in {softmax, local, eva, lara, performer,
     causal_eva (batch-first x; training/evaluation path)}.
 
     args: constructor kwargs (missing ones take default_args); params: dict of tensors with
     the reference's state_dict keys; noise_fn(shape) -> standard-normal tensor for the i-th
-    sampling call of a training-mode forward."""
+    sampling call of a training-mode forward; keep_fn(shape) -> 0/1 keep decisions of causal_eva's
+    attention dropout."""
     if attn == "causal_eva":
-        return _causal_eva_forward(args, params, x, mask, training, noise_fn)
+        return _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn)
     a = default_args(attn)
     a.update(args)
     h = a["num_heads"]
@@ -564,7 +568,7 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
     raise KeyError(attn)
 
 
-def _causal_eva_forward(args, params, x, mask, training, noise_fn):
+def _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn=None):
     """CausalEVAttention.forward without incremental state (causal_eva.py:458-536,666-790) on
     batch-first x [B,T,C] (the module itself is time-first; callers transpose).  args: the
     constructor kwargs with `attn_args` as a dict (window_size, overlap_window, causal,
@@ -604,7 +608,10 @@ def _causal_eva_forward(args, params, x, mask, training, noise_fn):
         bucket = (t5_bucket_causal if aa["causal"] else t5_bucket)(w, w + e, nb, w + e)
         bias = params["rel_pos_bias.relative_attention_bias.weight"][bucket][..., 0] * scale
     noise = noise_fn((B, h, n // r, d)).to(x.dtype) if training else None
-    out = causal_eva_core(q, k, v, pad_mask, w, e, r, mu_fn, noise, bias, aa["causal"], scale)
+    p_drop = float(args.get("dropout", 0.0))
+    keep = keep_fn((B, h, n, w + e + n // r)) if (training and p_drop > 0) else None
+    out = causal_eva_core(q, k, v, pad_mask, w, e, r, mu_fn, noise, bias, aa["causal"], scale,
+                          keep, p_drop)
     y = F.linear(out.transpose(1, 2).reshape(B, n, C), params["out_proj.weight"],
                  params.get("out_proj.bias"))
     return y[:, :T]

@@ -120,6 +120,11 @@ CASES = {
         args=dict(embed_dim=128, num_heads=2, self_attention=True,
                   attn_args=dict(window_size=8, chunk_size=None, causal=False, adaptive_proj="qk",
                                  use_t5_rpe=False, num_chunks=8, overlap_window=True))),
+    "causal_eva_dropout": dict(  # attention dropout 0.1 (transformer_lm_wiki103's default), pad mask
+        attn="causal_eva", x_shape=(2, 48, 128), mask=("tail", [0, 5]),
+        args=dict(embed_dim=128, num_heads=2, dropout=0.1, self_attention=True,
+                  attn_args=dict(window_size=16, chunk_size=4, causal=True, adaptive_proj="qk",
+                                 use_t5_rpe=True, num_chunks=None, overlap_window=True))),
 }
 
 MODES = ("eval", "train")
@@ -203,6 +208,12 @@ def make_noise(name, shape, call_idx=0):
     """Standard-normal sampling noise for training mode: the i-th randn/randn_like call
     inside one forward gets stream (name, 'noise<i>')."""
     return rng_for(name, "noise%d" % call_idx).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def make_keep(name, shape, p_drop, call_idx=0):
+    """0/1 keep decisions of an attention-dropout call (probability p_drop of dropping)."""
+    u = rng_for(name, "keep%d" % call_idx).random(tuple(shape), dtype=np.float32)
+    return (u >= p_drop).astype(np.float32)
 
 
 GRAD_FULL_MAX = 16384     # parameter grads larger than this are stored as a subsample

@@ -48,14 +48,26 @@ def _import_reference():
 
 
 class _NoisePatch:
-    """Replace torch.randn / torch.randn_like during one forward with cases.make_noise."""
+    """Replace torch.randn / torch.randn_like during one forward with cases.make_noise, and
+    F.dropout (causal_eva's attention dropout, causal_eva.py:227) with cases.make_keep decisions."""
 
     def __init__(self, name):
         self.name = name
         self.calls = []
+        self.drops = []
 
     def __enter__(self):
         self._randn, self._randn_like = torch.randn, torch.randn_like
+        self._dropout = torch.nn.functional.dropout
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0:
+                return x
+            keep = torch.from_numpy(cases.make_keep(self.name, tuple(x.shape), p, len(self.drops)))
+            self.drops.append(tuple(x.shape))
+            return x * keep.reshape(x.shape).to(x.dtype) / (1.0 - p)
+
+        torch.nn.functional.dropout = dropout
 
         def randn(*size, **kw):
             if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
@@ -74,6 +86,7 @@ class _NoisePatch:
 
     def __exit__(self, *exc):
         torch.randn, torch.randn_like = self._randn, self._randn_like
+        torch.nn.functional.dropout = self._dropout
 
 
 def run_case(ref, name):
@@ -108,6 +121,7 @@ def run_case(ref, name):
         out["%s.y" % mode] = y.detach().numpy()
         out["%s.dx" % mode] = x.grad.numpy()
         out["%s.noise_shapes" % mode] = np.array(json.dumps(np_patch.calls))
+        out["%s.drop_shapes" % mode] = np.array(json.dumps(np_patch.drops))
         for k, p in mod.named_parameters():
             gnp = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
             for suffix, arr in cases.pack_grad(name, k, gnp).items():

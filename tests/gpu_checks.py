@@ -77,12 +77,16 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
             tol = LARA_TOL if fx.case["attn"] == "lara" else MODULE_TOL
     mod = build_module(fx)
     mod.train(mode == "train")
+    keep_fn = fx.keep_fn(device="cuda")
+    if hasattr(mod, "_keep_mask_fn"):
+        mod._keep_mask_fn = keep_fn                      # attention dropout: the fixture's decisions
     x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)
     mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np).cuda()
     with injected_noise(fx, mode, "cuda") as calls:
         with torch.autocast("cuda", dtype=dtype):
             y = cases.call_module(fx.case, mod, x, mask)
     assert calls == fx.expected_noise_shapes(mode), (calls, fx.expected_noise_shapes(mode))
+    assert [int(np.prod(s)) for s in keep_fn.calls] == fx.expected_drop_elems(mode)
     assert y.shape == x.shape and y.dtype in (dtype, torch.float32)
     errs = {"y": scaled_err(y.detach().float().cpu().numpy(), fx.y(mode))}
     if backward:

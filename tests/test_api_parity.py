@@ -119,7 +119,7 @@ def _causal_eva(**over):
 
 def test_causal_eva_flags_and_loud_failures():
     """causal_eva.py:905-916 flag defaults with fairseq's decoder prefix; the paths this build
-    does not carry (incremental decoding, attention dropout, quantization noise) raise instead of
+    does not carry (incremental decoding, quantization noise) raise instead of
     computing something else, and CPU tensors never reach a kernel."""
     parser = argparse.ArgumentParser()
     parser = ea.AttentionFactory.add_attn_specific_args(parser, "causal_eva", struct_name="attn_args_decoder",
@@ -137,8 +137,6 @@ def test_causal_eva_flags_and_loud_failures():
         _causal_eva().eval()(x, x, x)
     with pytest.raises(NotImplementedError, match="incremental"):
         _causal_eva().eval()(x[:1], x[:1], x[:1], incremental_state={})
-    with pytest.raises(NotImplementedError, match="dropout"):
-        _causal_eva(dropout=0.1).train()(x, x, x)
     with pytest.raises(NotImplementedError, match="quantization"):
         _causal_eva(q_noise=0.1)
     with pytest.raises(AssertionError):

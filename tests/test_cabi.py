@@ -54,7 +54,7 @@ def test_version_and_argument_validation(lib):
     assert _native.lib().ea_window_bwd_parts(ctypes.byref(g)) >= 1
     bad = _native.make_geom(2, 3, 196, 64, 0, True, (14, 13), 7, 0, 2, 49)
     assert _native.lib().ea_window_bias_ld(ctypes.byref(bad)) < 0
-    rc = _native.lib().ea_window_attn_fwd(ctypes.byref(g), None, None, None, None, None, None, None, None, None, None)
+    rc = _native.lib().ea_window_attn_fwd(ctypes.byref(g), None, None, None, None, None, None, None, None, None, None, 1.0, None)
     assert rc == -1
     odd = _native.make_geom(2, 3, 196, 48, 0, True, (14, 14), 7, 0, 2, 49)     # head dim not built
     assert _native.lib().ea_window_bias_ld(ctypes.byref(odd)) < 0

@@ -17,11 +17,11 @@ RECIPE = dict(window_size=128, chunk_size=8, causal=True, adaptive_proj="qk", us
               num_chunks=None, overlap_window=False)          # README.md:184
 
 
-def _build(embed, heads, attn_args, seed=3):
+def _build(embed, heads, attn_args, seed=3, dropout=0.0):
     import efficient_attention as ea
     torch.manual_seed(seed)
     m = ea.AttentionFactory.build_attention(
-        "causal_eva", dict(embed_dim=embed, num_heads=heads, self_attention=True,
+        "causal_eva", dict(embed_dim=embed, num_heads=heads, self_attention=True, dropout=dropout,
                            attn_args=argparse.Namespace(**attn_args))).cuda()
     with torch.no_grad():
         for p in m.parameters():
@@ -31,14 +31,17 @@ def _build(embed, heads, attn_args, seed=3):
     return m.eval()
 
 
-def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None):
-    """oracle.module_forward on batch-first CPU copies; returns y and (if g is given) grads."""
+def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None, keep=None, p_drop=0.0):
+    """oracle.module_forward on batch-first CPU copies; returns y and (if g is given) grads.  With
+    `keep` (attention-dropout decisions) the oracle runs in training mode with zero sampling noise."""
     import oracle
     params = {k: v.detach().float().cpu().requires_grad_(g_bf is not None) for k, v in m.state_dict().items()}
     xr = x_bf.detach().float().cpu().requires_grad_(g_bf is not None)
     mr = None if mask is None else mask.cpu()
-    y = oracle.module_forward("causal_eva", dict(embed_dim=embed, num_heads=heads, attn_args=attn_args),
-                              params, xr, mr, training=False)
+    y = oracle.module_forward("causal_eva", dict(embed_dim=embed, num_heads=heads, attn_args=attn_args, dropout=p_drop),
+                              params, xr, mr, training=keep is not None,
+                              noise_fn=lambda shape: torch.zeros(*shape),
+                              keep_fn=lambda shape: keep.float().cpu().reshape(shape))
     if g_bf is None:
         return y.detach(), None, None
     (y * g_bf.float().cpu()).sum().backward()
@@ -47,14 +50,21 @@ def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_mask"])
+@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_mask", "recipe_d128_dropout",
+                                     "overlap_dropout"])
 def test_recipe_geometry_matches_oracle(variant, dtype):
     from gpu_checks import MODULE_TOL, FP16_TOL
     from util import scaled_err
     base = MODULE_TOL if dtype == "bf16" else FP16_TOL
     dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
+    p_drop = 0.1 if variant.endswith("dropout") else 0.0      # transformer_lm_wiki103's attention dropout
     if variant == "recipe_d64":
         embed, heads, T, B, aa, pads = 512, 8, 512, 4, dict(RECIPE), None
+    elif variant == "recipe_d128_dropout":
+        embed, heads, T, B, aa, pads = 1024, 8, 512, 2, dict(RECIPE), None
+    elif variant == "overlap_dropout":
+        embed, heads, T, B, pads = 128, 2, 100, 2, [0, 11]
+        aa = dict(RECIPE, window_size=24, chunk_size=8, overlap_window=True)   # Wk = 48, L = 15: padded mask columns
     elif variant == "recipe_d128":
         # transformer_lm_wiki103: embed 1024, 8 heads.  128 queries x 128 keys at d = 128 exceed one
         # LDS image in backward: the window runs as 4 query blocks (ea_window_bwd_query_blocks)
@@ -62,21 +72,35 @@ def test_recipe_geometry_matches_oracle(variant, dtype):
     else:
         embed, heads, T, B, pads = 256, 4, 500, 3, [0, 37, 0]
         aa = dict(RECIPE, window_size=32, chunk_size=16, overlap_window=True, adaptive_proj="no-ln")
-    m = _build(embed, heads, aa)
+    m = _build(embed, heads, aa, dropout=p_drop)
     gen = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(B, T, embed, device="cuda", generator=gen).requires_grad_(True)
     g = torch.randn(B, T, embed, device="cuda", generator=gen)
+    keep = None
+    if p_drop:
+        # training mode with the sampling noise silenced and the dropout decisions shared with the oracle
+        w, e = aa["window_size"], (aa["window_size"] if aa["overlap_window"] else 0)
+        n = -(-T // w) * w
+        keep = (torch.rand(B, heads, n, w + e + n // aa["chunk_size"], device="cuda", generator=gen) >= p_drop)
+        m.train()
+        m._keep_mask_fn = lambda shape: keep.reshape(shape)
     mask = None
     if pads is not None:
         mask = torch.zeros(B, T, dtype=torch.bool, device="cuda")
         for b, k in enumerate(pads):
             if k:
                 mask[b, T - k:] = True
-    with torch.autocast("cuda", dtype=dtype):
-        xt = x.transpose(0, 1)
-        y = m(xt, xt, xt, key_padding_mask=mask)[0].transpose(0, 1)
+    real_randn_like = torch.randn_like
+    if p_drop:
+        torch.randn_like = lambda t, **kw: torch.zeros_like(t)
+    try:
+        with torch.autocast("cuda", dtype=dtype):
+            xt = x.transpose(0, 1)
+            y = m(xt, xt, xt, key_padding_mask=mask)[0].transpose(0, 1)
+    finally:
+        torch.randn_like = real_randn_like
     (y.float() * g).sum().backward()
-    yr, dxr, pgr = _oracle(m, embed, heads, aa, x, mask, g)
+    yr, dxr, pgr = _oracle(m, embed, heads, aa, x, mask, g, keep, p_drop)
     errs = {"y": scaled_err(y.detach().float().cpu().numpy(), yr.numpy()),
             "dx": scaled_err(x.grad.cpu().numpy(), dxr.numpy())}
     for k, p in m.named_parameters():

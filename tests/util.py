@@ -38,6 +38,25 @@ class Fixture:
         fn.calls = calls
         return fn
 
+    def keep_fn(self, dtype=torch.float32, device="cpu"):
+        """i-th attention-dropout call -> the keep decisions the generator fed to the reference."""
+        calls = []
+        p_drop = float(self.case["args"].get("dropout", 0.0))
+
+        def fn(shape):
+            arr = cases.make_keep(self.name, tuple(shape), p_drop, len(calls))
+            calls.append(tuple(shape))
+            return torch.from_numpy(arr).to(device=device, dtype=dtype)
+
+        fn.calls = calls
+        return fn
+
+    def expected_drop_elems(self, mode):
+        key = "%s.drop_shapes" % mode
+        if key not in self.z.files:
+            return []
+        return [int(np.prod(s)) for s in json.loads(str(self.z[key]))]
+
     def expected_noise_shapes(self, mode):
         return [tuple(s) for s in json.loads(str(self.z["%s.noise_shapes" % mode]))]
 
