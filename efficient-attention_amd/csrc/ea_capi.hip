@@ -14,7 +14,10 @@ int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, cons
 #include "ea_lara_lmk.h"
 #include "ea_lara_merge.h"
 #include "ea_lara_segment.h"
+#include "ea_rows_mlp.h"
 namespace ea {
+int rows_mlp_dispatch(const RowsP& p, int D, int sides, int layer_norm, bool bwd, hipStream_t st);
+int rows_mlp_blocks(int R, int D);
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 }
@@ -655,6 +658,49 @@ int ea_lara_segment_bwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, cons
   p.mask = mask; p.bias_q = bias_q; p.bias_k = bias_k; p.mbias_q = mbias_q; p.mbias_k = mbias_k;
   p.gq = gq; p.cq = cq; p.gk = gk; p.ck = ck; p.d_qbar = d_qbar; p.d_kbar = d_kbar; p.part = part;
   return lara_segment_dispatch(true, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- mu networks: per-row Linear (+ LayerNorm) on the chunk means ----
+extern "C" {
+
+int32_t ea_rows_mlp_parts(int32_t R, int32_t D) {
+  if (R <= 0 || (D != 32 && D != 64 && D != 128)) return EA_E_BADARG;
+  return ea::rows_mlp_blocks(R, D);
+}
+
+int ea_rows_mlp_fwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
+                    const float* x0, const float* x1, const float* W0, const float* W1,
+                    const float* b0, const float* b1, const float* g0, const float* g1,
+                    const float* c0, const float* c1, float* y0, float* y1,
+                    float* zhat, float* rstd, void* stream) {
+  if (R <= 0 || sides < 1 || sides > 2 || !x0 || !W0 || !b0 || !y0) return EA_E_BADARG;
+  if (sides == 2 && (!x1 || !W1 || !b1 || !y1)) return EA_E_BADARG;
+  if (layer_norm && (!g0 || !c0 || (sides == 2 && (!g1 || !c1)))) return EA_E_BADARG;
+  if ((zhat == nullptr) != (rstd == nullptr)) return EA_E_BADARG;
+  RowsP p = {};
+  p.R = R;
+  p.x[0] = x0; p.x[1] = x1; p.W[0] = W0; p.W[1] = W1; p.b[0] = b0; p.b[1] = b1;
+  p.g[0] = g0; p.g[1] = g1; p.c[0] = c0; p.c[1] = c1; p.y[0] = y0; p.y[1] = y1;
+  p.zhat = zhat; p.rstd = rstd;
+  return ea::rows_mlp_dispatch(p, D, sides, layer_norm, false, (hipStream_t)stream);
+}
+
+int ea_rows_mlp_bwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
+                    const float* dy0, const float* dy1, const float* x0, const float* x1,
+                    const float* W0, const float* W1, const float* g0, const float* g1,
+                    const float* zhat, const float* rstd, float* dx0, float* dx1,
+                    float* feed, float* dW_part, void* stream) {
+  if (R <= 0 || sides < 1 || sides > 2 || !dy0 || !x0 || !W0 || !dx0 || !feed || !dW_part) return EA_E_BADARG;
+  if (sides == 2 && (!dy1 || !x1 || !W1 || !dx1)) return EA_E_BADARG;
+  if (layer_norm && (!g0 || !zhat || !rstd || (sides == 2 && !g1))) return EA_E_BADARG;
+  RowsP p = {};
+  p.R = R;
+  p.dy[0] = dy0; p.dy[1] = dy1; p.x[0] = x0; p.x[1] = x1; p.W[0] = W0; p.W[1] = W1;
+  p.g[0] = g0; p.g[1] = g1; p.zhat = const_cast<float*>(zhat); p.rstd = const_cast<float*>(rstd);
+  p.dx[0] = dx0; p.dx[1] = dx1; p.feed = feed; p.dW_part = dW_part;
+  return ea::rows_mlp_dispatch(p, D, sides, layer_norm, true, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -68,6 +68,9 @@ SIGNATURES = {
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P, _F, _P],
     "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P, _F, _P],
     "ea_window_keep_ld": [_G],
+    "ea_rows_mlp_parts": [_I, _I],
+    "ea_rows_mlp_fwd": [_I] * 4 + [_P] * 15,
+    "ea_rows_mlp_bwd": [_I] * 4 + [_P] * 15,
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 17,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 21,
     "ea_lara_landmarks_saved_floats": [_MG],

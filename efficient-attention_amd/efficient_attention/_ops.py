@@ -211,52 +211,6 @@ class LocalAttnFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # EVA  (reference eva.py:145-227)
 # ------------------------------------------------------------------------------------------
-class _RowsLinearF32(torch.autograd.Function):
-    """fp32 y = x W^T + b over many rows with a small [d,d] weight (the mu MLP on B*h*L chunk
-    means).  The weight gradient contracts over all rows into a 16 K-element result -- as one
-    library GEMM it fills a handful of CUs -- so it runs as a batched GEMM over row slices whose
-    partials are summed; the bias gradient is a fixed-order column sum."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        x2 = x.reshape(-1, x.shape[-1])
-        ctx.save_for_backward(x2, weight)
-        return torch.addmm(bias, x2, weight.t()).view(x.shape[:-1] + (weight.shape[0],))
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
-        rows = x2.shape[0]
-        S = 1
-        for s_ in range(2, 65):
-            if rows % s_ == 0 and rows // s_ >= 128:
-                S = s_
-        dx = (dy2 @ weight).view(dy.shape[:-1] + (weight.shape[1],))
-        part = torch.bmm(dy2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1))
-        dw = part.sum(0) if S > 1 else part[0]
-        db = colsum_f32(dy2) if dy2.is_cuda else dy2.sum(0)
-        return dx, dw, db
-
-
-def eva_mu(qmean, kmean, params, adaptive_proj, mu_scale=0.5):
-    """rf_k_bar, mu from the chunk means (eva.py:178-185; causal_eva.py:706-709 with
-    mu_scale = 1). fp32, [B,h,L,d] -- tiny."""
-    d = kmean.shape[-1]
-    if adaptive_proj in ("default", "no-ln"):
-        if adaptive_proj == "default":
-            wq, bq, gq, cq, wk, bk, gk, ck = params
-            rq = F.layer_norm(_RowsLinearF32.apply(qmean, wq, bq), (d,), gq, cq, 1e-5)
-            rk = F.layer_norm(_RowsLinearF32.apply(kmean, wk, bk), (d,), gk, ck, 1e-5)
-        else:
-            wq, bq, wk, bk = params
-            rq, rk = _RowsLinearF32.apply(qmean, wq, bq), _RowsLinearF32.apply(kmean, wk, bk)
-        return rk, mu_scale * (rq + rk)
-    wk, bk, gk, ck = params
-    rk = F.layer_norm(_RowsLinearF32.apply(kmean, wk, bk), (d,), gk, ck, 1e-5)
-    return rk, torch.zeros_like(rk)
-
-
 class EvaAttnFn(torch.autograd.Function):
     """EVA core on a fused qkv tensor: chunk means -> mu MLP -> omega -> beta -> window attention
     with control-variate columns.  Returns out [B,N,h,d].
@@ -296,20 +250,31 @@ class EvaAttnFn(torch.autograd.Function):
                     nv.ptr(saved), nv.stream())
             ctx.lmk = (lg, noise_c, saved)
         else:
-            # the tiny mu MLP stays in fp32 (autocast off).  When a backward will follow, its autograd
-            # graph (on detached leaves) is built here and kept, so backward differentiates it without
-            # recomputing the forward.
-            with_graph = any(ctx.needs_input_grad)
-            with torch.set_grad_enabled(with_graph), torch.autocast(device_type="cuda", enabled=False):
-                qm = qmean.detach().requires_grad_(with_graph)
-                km = kmean.detach().requires_grad_(with_graph)
-                ps = [p.detach().float().requires_grad_(with_graph) for p in mlp_params]
-                rk_g, mu_g = eva_mu(qm, km, ps, adaptive_proj, mu_scale)
-            ctx.mu_graph = (qm, km, ps, rk_g, mu_g) if with_graph else None
+            # Linear (+ LayerNorm) of both sides in one exact-fp32 HIP pass (ea_rows_mlp_fwd)
+            sides = 1 if adaptive_proj == "none" else 2
+            ln = adaptive_proj != "no-ln"
+            ps = [p.float().contiguous() for p in mlp_params]
+            per = 4 if ln else 2
+            side_p = [ps[i * per:(i + 1) * per] for i in range(sides)]          # (W, b[, gamma, beta]) per side
+            xs = [qmean, kmean] if sides == 2 else [kmean]
+            ys = [torch.empty_like(kmean) for _ in range(sides)]
+            R = B * h * L
+            zhat = rstd = None
+            if ln and any(ctx.needs_input_grad):
+                zhat = torch.empty((sides, R, d), dtype=torch.float32, device=dev)
+                rstd = torch.empty((sides, R), dtype=torch.float32, device=dev)
+
+            def pick(i):                                                      # i-th tensor of each side
+                col = [sp[i] if i < len(sp) else None for sp in side_p] + [None]
+                return [nv.ptr(col[0]), nv.ptr(col[1])]
+            nv.call("ea_rows_mlp_fwd", R, d, sides, 1 if ln else 0,
+                    nv.ptr(xs[0]), nv.ptr(xs[1] if sides == 2 else None), *pick(0), *pick(1), *pick(2), *pick(3),
+                    nv.ptr(ys[0]), nv.ptr(ys[1] if sides == 2 else None), nv.ptr(zhat), nv.ptr(rstd), nv.stream())
+            rf_k_bar = ys[-1]
             with torch.no_grad():
-                mu = mu_g.detach()
+                mu = mu_scale * (ys[0] + ys[1]) if sides == 2 else torch.zeros_like(rf_k_bar)
                 omega = (mu if noise is None else mu + noise.float()).contiguous()
-                rf_k_bar = rk_g.detach().contiguous()
+            ctx.mu_mlp = (sides, ln, zhat, rstd, side_p)
             ctx.lmk = None
         beta = torch.empty_like(qmean)
         nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
@@ -361,22 +326,40 @@ class EvaAttnFn(torch.autograd.Function):
             if dbias is not None:
                 dbias = dbias[..., :ctx.bias_cols]
             return (dqkv5, dbias, None, None, None) + tuple(pgrads)
-        # mu MLP backward on the tiny [B,h,L,d] tensors (Linear/LayerNorm parameter grads are
-        # [d,d] GEMMs over B*h*L rows -- left to torch)
-        with torch.enable_grad(), torch.autocast(device_type="cuda", enabled=False):
-            qm, km, ps, rk, mu = ctx.mu_graph
-            ctx.mu_graph = None
-            outs, gouts = [rk], [d_rfk.contiguous()]
-            if mu.requires_grad:
-                outs.append(mu)
-                gouts.append(d_omega)
-            grads = torch.autograd.grad(outs, [qm, km] + ps, gouts, allow_unused=True)
-        dqm, dkm = grads[0], grads[1]
-        dqm = torch.zeros_like(qmean) if dqm is None else dqm.contiguous()
-        dkm = torch.zeros_like(kmean) if dkm is None else dkm.contiguous()
+        # mu networks backward (ea_rows_mlp_bwd): dz, dx = d(chunk means), per-workgroup dW partials
+        # and the feed buffer whose column sums are the bias / gamma / beta gradients
+        sides, ln, zhat, rstd, side_p = ctx.mu_mlp
+        B_, h_, L_, d_ = kmean.shape
+        R = B_ * h_ * L_
+        d_rfk = d_rfk.contiguous()
+        if sides == 2:
+            d_rq = (ctx.mu_scale * d_omega).contiguous()
+            dys = [d_rq, d_rq + d_rfk]
+            xs = [qmean, kmean]
+        else:
+            dys, xs = [d_rfk], [kmean]
+        dxs = [torch.empty_like(kmean) for _ in range(sides)]
+        planes = 3 if ln else 1
+        parts = nv.lib().ea_rows_mlp_parts(R, d_)
+        feed = torch.empty((R, planes, sides, d_), dtype=torch.float32, device=kmean.device)
+        dW_part = torch.empty((parts, sides, d_, d_), dtype=torch.float32, device=kmean.device)
+
+        def two(ts):
+            ts = list(ts) + [None]
+            return [nv.ptr(ts[0]), nv.ptr(ts[1])]
+        nv.call("ea_rows_mlp_bwd", R, d_, sides, 1 if ln else 0, *two(dys), *two(xs),
+                *two([sp[0] for sp in side_p]), *two([sp[2] if ln else None for sp in side_p]),
+                nv.ptr(zhat), nv.ptr(rstd), *two(dxs), nv.ptr(feed), nv.ptr(dW_part), nv.stream())
+        dkm = dxs[-1]
+        dqm = dxs[0] if sides == 2 else torch.zeros_like(qmean)
         nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
                 nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
-        pgrads = [None if g is None else g.to(p.dtype) for g, p in zip(grads[2:], mlp_params)]
+        dW = colsum_f32(dW_part.view(parts, -1)).view(sides, d_, d_)
+        vec = colsum_f32(feed.view(R, -1)).view(planes, sides, d_)
+        raw = []
+        for i in range(sides):
+            raw += [dW[i], vec[0, i]] + ([vec[1, i], vec[2, i]] if ln else [])
+        pgrads = [g.to(p.dtype) for g, p in zip(raw, mlp_params)]
         if dbias is not None:
             dbias = dbias[..., :ctx.bias_cols]
         return (dqkv5, dbias, None, None, None) + tuple(pgrads)

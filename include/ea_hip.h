@@ -344,6 +344,27 @@ int ea_lara_segment_bwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, cons
                         const float* d_qbar, const float* d_kbar, const ea_t4* dq2, const ea_t4* dk2,
                         float* part, void* stream);
 
+/* ---- mu networks on the chunk means (eva.py:78-98,178-183; causal_eva.py:376-392,706-707) ------
+ * y_s = [LayerNorm_s](x_s W_s^T + b_s) for sides = 1 (key side only: adaptive_proj 'none') or 2
+ * (query side 0, key side 1), rows [R, D] fp32 with D in {32, 64, 128}, exact fp32 arithmetic.
+ * layer_norm: 1 = Linear + LayerNorm (eps 1e-5), 0 = Linear only ('no-ln').
+ *   fwd: zhat [sides,R,D] and rstd [sides,R] receive the normalised rows and 1/std for the backward
+ *        (both NULL when no backward follows or layer_norm == 0).
+ *   bwd: dx_s = d/dx; feed [R, planes, sides, D] with planes = 3 (dz, dy o zhat, dy) or 1 (dz = dy)
+ *        whose column sums over R are (d bias, d gamma, d beta); dW_part
+ *        [ea_rows_mlp_parts(R, D), sides, D, D] per-workgroup partials of d W. */
+int32_t ea_rows_mlp_parts(int32_t R, int32_t D);
+int ea_rows_mlp_fwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
+                    const float* x0, const float* x1, const float* W0, const float* W1,
+                    const float* b0, const float* b1, const float* g0, const float* g1,
+                    const float* c0, const float* c1, float* y0, float* y1,
+                    float* zhat, float* rstd, void* stream);
+int ea_rows_mlp_bwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
+                    const float* dy0, const float* dy1, const float* x0, const float* x1,
+                    const float* W0, const float* W1, const float* g0, const float* g1,
+                    const float* zhat, const float* rstd, float* dx0, float* dx1,
+                    float* feed, float* dW_part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,64 @@ def test_slice_sum(with_a):
     nv.call("ea_slice_sum", BH, S, n, 0.125, nv.ptr(a) if with_a else None, nv.ptr(p), nv.ptr(out), nv.stream())
     ref = 0.125 * ((a if with_a else 0) + p.sum(1))
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ln", [True, False])
+@pytest.mark.parametrize("sides", [1, 2])
+@pytest.mark.parametrize("R,D", [(9216, 128), (1000, 64), (37, 32), (18816, 64)])
+def test_rows_mlp_matches_fp64(R, D, sides, ln):
+    """ea_rows_mlp_fwd/bwd (the mu networks: per-row Linear [+ LayerNorm], exact fp32 MFMA) against
+    torch in fp64: outputs, input gradients and every parameter gradient."""
+    import ctypes
+    import torch
+    import torch.nn.functional as F
+    from efficient_attention import _native as nv
+    from efficient_attention import _ops
+    gen = torch.Generator(device="cuda").manual_seed(R + D + sides)
+
+    def rnd(*shape, scale=1.0, shift=0.0):
+        return (torch.randn(*shape, device="cuda", generator=gen) * scale + shift).contiguous()
+    xs = [rnd(R, D) for _ in range(sides)]
+    Ws = [rnd(D, D, scale=D ** -0.5) for _ in range(sides)]
+    bs = [rnd(D, scale=0.3) for _ in range(sides)]
+    gs = [rnd(D, scale=0.2, shift=1.0) for _ in range(sides)]
+    cs = [rnd(D, scale=0.3) for _ in range(sides)]
+    dys = [rnd(R, D) for _ in range(sides)]
+
+    def two(ts):
+        ts = list(ts) + [None]
+        return [nv.ptr(ts[0]), nv.ptr(ts[1])]
+    ys = [torch.empty(R, D, device="cuda") for _ in range(sides)]
+    zhat = torch.empty(sides, R, D, device="cuda") if ln else None
+    rstd = torch.empty(sides, R, device="cuda") if ln else None
+    nv.call("ea_rows_mlp_fwd", R, D, sides, int(ln), *two(xs), *two(Ws), *two(bs), *two(gs if ln else [None]),
+            *two(cs if ln else [None]), *two(ys), nv.ptr(zhat), nv.ptr(rstd), nv.stream())
+    parts = nv.lib().ea_rows_mlp_parts(R, D)
+    planes = 3 if ln else 1
+    dxs = [torch.empty(R, D, device="cuda") for _ in range(sides)]
+    feed = torch.empty(R, planes, sides, D, device="cuda")
+    dWp = torch.empty(parts, sides, D, D, device="cuda")
+    nv.call("ea_rows_mlp_bwd", R, D, sides, int(ln), *two(dys), *two(xs), *two(Ws), *two(gs if ln else [None]),
+            nv.ptr(zhat), nv.ptr(rstd), *two(dxs), nv.ptr(feed), nv.ptr(dWp), nv.stream())
+    dW = _ops.colsum_f32(dWp.view(parts, -1)).view(sides, D, D)
+    vec = _ops.colsum_f32(feed.view(R, -1)).view(planes, sides, D)
+
+    def close(got, ref, what):
+        err = (got.double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) * (1 + R ** 0.5 * 0.02), (what, err, ref.abs().max().item())
+    for s in range(sides):
+        x = xs[s].double().requires_grad_(True)
+        W, b = Ws[s].double().requires_grad_(True), bs[s].double().requires_grad_(True)
+        g, c = gs[s].double().requires_grad_(True), cs[s].double().requires_grad_(True)
+        y = F.linear(x, W, b)
+        if ln:
+            y = F.layer_norm(y, (D,), g, c, 1e-5)
+        y.backward(dys[s].double())
+        close(ys[s], y.detach(), "y")
+        close(dxs[s], x.grad, "dx")
+        close(dW[s], W.grad, "dW")
+        close(vec[0, s], b.grad, "db")
+        if ln:
+            close(vec[1, s], g.grad, "dgamma")
+            close(vec[2, s], c.grad, "dbeta")
