@@ -370,11 +370,12 @@ extern "C" {
 
 int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
-                        const ea_t4* out, float* lse, void* stream) {
+                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale, void* stream) {
   SmP p = {};
   int rc = fill_sm(B, H, N, D, dtype, scale, p);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !lse) return EA_E_BADARG;
+  p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = (N + 63) / 64 * 64;
   SM_SET(q, q); SM_SET(k, k); SM_SET(v, v); SM_SET(o, out);
   p.mask = mask; p.lse = lse;
   return softmax_dispatch(0, p, dtype, D, (hipStream_t)stream);
@@ -383,10 +384,12 @@ int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtyp
 int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                         const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
-                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv, void* stream) {
+                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
+                        const uint8_t* keep, float keep_scale, void* stream) {
   SmP p = {};
   int rc = fill_sm(B, H, N, D, dtype, scale, p);
   if (rc != EA_OK) return rc;
+  p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = (N + 63) / 64 * 64;
   if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !t4_ok(dout, D) ||
       !t4_ok(dq, D) || !t4_ok(dk, D) || !t4_ok(dv, D) || !lse || !delta) return EA_E_BADARG;
   SM_SET(q, q); SM_SET(k, k); SM_SET(v, v); SM_SET(o, out); SM_SET(dout, dout);

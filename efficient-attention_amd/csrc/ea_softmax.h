@@ -7,6 +7,11 @@ namespace ea {
 struct SmP {
   struct { char* p; int64_t sb, sh, sn; } q, k, v, o, dout, dq, dk, dv;
   const uint8_t* mask;
+  // attention dropout (abstract_attention.py:131): keep mask [B,H,N,keep_ld] u8 over the keys of
+  // every query (non-zero = kept), kept probabilities scaled by keep_scale = 1/(1-p); or nullptr
+  const uint8_t* keep;
+  int keep_ld;
+  float keep_scale;
   float* lse;      // [BH, N] natural log
   float* delta;    // [BH, N]
   int B, H, N;

@@ -16,7 +16,9 @@
 namespace ea {
 
 
-template <typename E, int D>
+// DR: attention dropout from an explicit keep mask -- dropped entries leave the numerator (and dP, and
+// the P of dV in the backward); the normaliser is that of the full row.
+template <typename E, int D, bool DR>
 __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
@@ -85,11 +87,18 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
     m = mnew;
     float psum = 0.f;
     uint32_t pw[4][2];
+    const uint8_t* krow = DR ? p.keep + ((size_t)bh * p.N + (qvalid ? qtok : 0)) * p.keep_ld + kc + 4 * g : nullptr;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       float pv[4];
+      uint32_t k4 = 0;
+      if (DR) k4 = *reinterpret_cast<const uint32_t*>(krow + tt * 16);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pv[r] = fast_exp2(s[tt][r] - msafe); psum += pv[r]; }
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = fast_exp2(s[tt][r] - msafe);
+        psum += pv[r];
+        if (DR) pv[r] = ((k4 >> (8 * r)) & 0xffu) ? pv[r] * p.keep_scale : 0.f;
+      }
       pw[tt][0] = pack2<E>(pv[0], pv[1]);
       pw[tt][1] = pack2<E>(pv[2], pv[3]);
     }
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D>
+template <typename E, int D, bool DR>
 __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
@@ -194,12 +203,17 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
         dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
       }
       const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
+      uint32_t k4 = 0;
+      if (DR) k4 = *reinterpret_cast<const uint32_t*>(
+                  p.keep + ((size_t)bh * p.N + (qvalid ? qtok : 0)) * p.keep_ld + kc + tt * 16 + 4 * g);
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool dd = (f4 >> (8 * r)) & 0xffu;
         const float pr = dd ? 0.f : fast_exp2(s[r] * p.scale_log2 - lse2);
-        ds[r] = pr * (dp[r] - delta);
+        float dpr = dp[r];
+        if (DR) dpr = ((k4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
+        ds[r] = pr * (dpr - delta);
       }
       dsw[tt][0] = pack2<E>(ds[0], ds[1]);
       dsw[tt][1] = pack2<E>(ds[2], ds[3]);
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D>
+template <typename E, int D, bool DR>
 __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
@@ -301,7 +315,15 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pr[r] = kdead ? 0.f : fast_exp2(s[r] * p.scale_log2 - ll[r]);
-          ds[r] = pr[r] * (dp[r] - dd[r]);
+          float dpr = dp[r];
+          float km = 1.f;
+          if (DR) {
+            const int qt = min(qc + rq + 4 * g + r, p.N - 1);
+            km = p.keep[((size_t)bh * p.N + qt) * p.keep_ld + (kvalid ? ktok : 0)] ? p.keep_scale : 0.f;
+            dpr *= km;
+          }
+          ds[r] = pr[r] * (dpr - dd[r]);
+          if (DR) pr[r] *= km;
         }
         pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
         dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
@@ -337,15 +359,19 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D>
-static int launch_sm(int which, const SmP& p, hipStream_t st) {
+template <typename E, int D, bool DR>
+static int launch_sm_dr(int which, const SmP& p, hipStream_t st) {
   const dim3 grid((unsigned)((long)p.B * p.H * ((p.N + 63) / 64))), block(256);
-  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D>), grid, block, 0, st, p);
+  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR>), grid, block, 0, st, p);
   else {
-    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D>), grid, block, 0, st, p);
-    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR>), grid, block, 0, st, p);
   }
   return (int)hipGetLastError();
+}
+template <typename E, int D>
+static int launch_sm(int which, const SmP& p, hipStream_t st) {
+  return p.keep ? launch_sm_dr<E, D, true>(which, p, st) : launch_sm_dr<E, D, false>(which, p, st);
 }
 
 int softmax_dispatch(int which, const SmP& p, int dtype, int D, hipStream_t st) {

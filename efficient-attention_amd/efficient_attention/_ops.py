@@ -711,10 +711,11 @@ def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode,
 # softmax baseline  (reference abstract_attention.py:120-133)
 # ------------------------------------------------------------------------------------------
 class SoftmaxAttnFn(torch.autograd.Function):
-    """out[B,N,h,d] = softmax(s QK^T, -inf on padded keys) V on a fused qkv tensor."""
+    """out[B,N,h,d] = dropout(softmax(s QK^T, -inf on padded keys)) V on a fused qkv tensor; keep: None
+    or the uint8 keep decisions [B,h,N,64*ceil(N/64)] of the attention dropout, scaled by keep_scale."""
 
     @staticmethod
-    def forward(ctx, qkv5, mask_u8):
+    def forward(ctx, qkv5, mask_u8, keep=None, keep_scale=1.0):
         nv.require_cuda(qkv5, "qkv")
         B, N, _, h, d = qkv5.shape
         q, k, v = _qkv_views(qkv5)
@@ -722,13 +723,15 @@ class SoftmaxAttnFn(torch.autograd.Function):
         lse = torch.empty((B * h, N), dtype=torch.float32, device=qkv5.device)
         tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
         nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(tq),
-                ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse), nv.stream())
-        ctx.save_for_backward(qkv5, mask_u8, out, lse)
+                ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse),
+                nv.ptr(keep), float(keep_scale), nv.stream())
+        ctx.save_for_backward(qkv5, mask_u8, out, lse, keep)
+        ctx.keep_scale = keep_scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv5, mask_u8, out, lse = ctx.saved_tensors
+        qkv5, mask_u8, out, lse, keep = ctx.saved_tensors
         B, N, _, h, d = qkv5.shape
         dout = dout.contiguous()
         dqkv5 = torch.empty_like(qkv5)
@@ -739,8 +742,8 @@ class SoftmaxAttnFn(torch.autograd.Function):
         nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(ts[0]),
                 ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8), ctypes.byref(ts[3]),
                 ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
-                ctypes.byref(ts[7]), nv.stream())
-        return dqkv5, None
+                ctypes.byref(ts[7]), nv.ptr(keep), float(ctx.keep_scale), nv.stream())
+        return dqkv5, None, None, None
 
 
 # ------------------------------------------------------------------------------------------

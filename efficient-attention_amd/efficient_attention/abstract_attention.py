@@ -44,6 +44,7 @@ class MultiheadAttention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
+        self._keep_mask_fn = None                      # tests: injected attention-dropout decisions
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -94,11 +95,27 @@ class MultiheadAttention(nn.Module):
         return self.merge_and_project(out, B, seq_shape, C, x.dtype)
 
     def _attend(self, qkv5, key_padding_mask, seq_shape):
-        if self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attention dropout inside the fused softmax kernel")
         B, N = qkv5.shape[:2]
         mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
-        return _ops.SoftmaxAttnFn.apply(qkv5, mask)
+        return _ops.SoftmaxAttnFn.apply(qkv5, mask, *self._attn_keep(B, N, qkv5.device))
+
+    def _attn_keep(self, B, N, device):
+        """Attention dropout (reference :131, `attn = self.attn_drop(attn)` on [B,h,N,N]): the Bernoulli
+        keep decisions are drawn here, one per (query, key), and applied inside the kernels."""
+        p = self.attn_drop.p
+        if not (self.training and p > 0):
+            return ()
+        if p >= 1:
+            raise NotImplementedError("attention dropout with p = 1")
+        h = self.num_heads
+        ld = -(-N // 64) * 64
+        if self._keep_mask_fn is not None:
+            keep = self._keep_mask_fn((B, h, N, N)).to(device=device, dtype=torch.uint8)
+            if ld != N:
+                keep = torch.nn.functional.pad(keep, (0, ld - N))
+        else:
+            keep = torch.empty((B, h, N, ld), device=device, dtype=torch.float32).bernoulli_(1 - p).to(torch.uint8)
+        return (keep.contiguous(), 1.0 / (1.0 - p))
 
     @staticmethod
     def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):

@@ -204,16 +204,20 @@ int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, 
                       const float* lse_t, const ea_t4* dq, void* stream);
 
 /* ---- softmax baseline (abstract_attention.py:120-133) ----------------------------------------
- * out = softmax(s Q K^T, -inf on padded keys) V, streamed (no [N,N] matrix); attn_drop = 0.
+ * out = dropout(softmax(s Q K^T, -inf on padded keys)) V, streamed (no [N,N] score matrix).
  * lse: fp32 [B*H, N] saved for backward; delta: fp32 [B*H, N] scratch (dO.O) written by the dQ
- * pass and read by the dK/dV pass of ea_softmax_attn_bwd. */
+ * pass and read by the dK/dV pass of ea_softmax_attn_bwd.
+ * keep: attention dropout (`attn = self.attn_drop(attn)`, :131): uint8 [B,H,N, 64*ceil(N/64)], entry
+ * (n, j) non-zero = probability of key j for query n is kept and multiplied by keep_scale = 1/(1-p);
+ * NULL = no dropout. */
 int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
-                        const ea_t4* out, float* lse, void* stream);
+                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale, void* stream);
 int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                         const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
-                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv, void* stream);
+                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
+                        const uint8_t* keep, float keep_scale, void* stream);
 
 /* ---- Performer / FAVOR+ baseline (kernelized_attention.py:20-56,116-121,326-346) ---------------
  * phi(x)[j] = M^-1/2 exp(d^-1/4 W_j.x - d^-1/2 |x|^2/2 - stab) + 1e-4 with W fp32 [H, M, D] (fresh

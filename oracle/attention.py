@@ -95,13 +95,17 @@ def prm_log_features(data, proj, scale):
 # --------------------------------------------------------------------------------------
 # softmax baseline
 # --------------------------------------------------------------------------------------
-def softmax_core(q, k, v, mask=None, scale=None):
-    """softmax(s QK^T, -inf on padded keys) V (abstract_attention.py:120-133; attn_drop=0)."""
+def softmax_core(q, k, v, mask=None, scale=None, drop_keep=None, p_drop=0.0):
+    """dropout(softmax(s QK^T, -inf on padded keys)) V (abstract_attention.py:120-133); drop_keep:
+    None or the 0/1 keep decisions [B,h,N,N] of attn_drop with probability p_drop."""
     scale = q.shape[-1] ** -0.5 if scale is None else scale
     s = scale * torch.einsum("bhid,bhjd->bhij", q, k)
     if mask is not None:
         s = s.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
-    return torch.einsum("bhij,bhjd->bhid", torch.softmax(s, -1), v)
+    p = torch.softmax(s, -1)
+    if drop_keep is not None:
+        p = p * drop_keep.reshape(p.shape).to(p.dtype) / (1.0 - p_drop)
+    return torch.einsum("bhij,bhjd->bhid", p, v)
 
 
 # --------------------------------------------------------------------------------------
@@ -476,7 +480,9 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
     if attn == "softmax":
         n = int(math.prod(seq_shape))
         q, k, v = _split_heads(x.reshape(B, n, C), params, h)
-        return _merge_proj(softmax_core(q, k, v, mask, scale), params, B, seq_shape, C)
+        p_drop = float(a["attn_drop"])
+        keep = keep_fn((B, h, n, n)) if (training and p_drop > 0) else None
+        return _merge_proj(softmax_core(q, k, v, mask, scale, keep, p_drop), params, B, seq_shape, C)
 
     if attn == "performer":
         n = int(math.prod(seq_shape))

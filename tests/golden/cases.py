@@ -85,6 +85,9 @@ CASES = {
     "softmax_1d_mask": dict(
         attn="softmax", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
         args=dict(dim=128, num_heads=2)),
+    "softmax_1d_dropout": dict(  # attn_drop on the [N,N] probabilities (abstract_attention.py:131)
+        attn="softmax", x_shape=(2, 70, 128), mask=("tail", [0, 6]),
+        args=dict(dim=128, num_heads=2, attn_drop=0.2)),
     "softmax_2d": dict(
         attn="softmax", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2)),

@@ -41,7 +41,7 @@ class Fixture:
     def keep_fn(self, dtype=torch.float32, device="cpu"):
         """i-th attention-dropout call -> the keep decisions the generator fed to the reference."""
         calls = []
-        p_drop = float(self.case["args"].get("dropout", 0.0))
+        p_drop = float(self.case["args"].get("dropout", self.case["args"].get("attn_drop", 0.0)))
 
         def fn(shape):
             arr = cases.make_keep(self.name, tuple(shape), p_drop, len(calls))
