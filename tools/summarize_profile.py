@@ -26,6 +26,7 @@ KERNEL_TO_ENTRY = [
     ("sm_bwd_dkv_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dkv)"),
     ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("slice_sum_kernel", "ea_slice_sum"),
+    ("rows_mlp_fwd_kernel", "ea_rows_mlp_fwd"), ("rows_mlp_bwd_kernel", "ea_rows_mlp_bwd"),
 ]
 
 
