@@ -13,7 +13,8 @@ resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Default workload (config.workload): BASELINE.json configs[2] geometry, the one the metric is
 quoted on -- DeiT-tiny-p8 tokens (N = 28x28 = 784, 3 heads, d = 64), per-GPU batch 128.
-`--attn eva|lara|softmax|local|performer` selects the attention (default: see DEFAULT_ATTN).
+`--attn eva|lara|softmax|local|performer|ra` selects the attention (default: see DEFAULT_ATTN);
+`--attn causal_eva --workload lm` is the wikitext-103 decoder self-attention.
 """
 import argparse
 import json
@@ -119,7 +120,8 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
         for p in params.values():
             p.grad = None
         y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn,
-                                  keep_fn=lambda shape: (torch.rand(*shape) >= LM_ATTENTION_DROPOUT).float())
+                                  keep_fn=lambda shape: (torch.rand(*shape) >= LM_ATTENTION_DROPOUT).float(),
+                                  index_fn=lambda shape: torch.randint(0, shape[-1], tuple(shape)))
         (y * g).sum().backward()
 
     ntok = 1

@@ -370,11 +370,14 @@ extern "C" {
 
 int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
-                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale, void* stream) {
+                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale,
+                        int32_t key_norm_bias, void* stream) {
   SmP p = {};
   int rc = fill_sm(B, H, N, D, dtype, scale, p);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !lse) return EA_E_BADARG;
+  if (key_norm_bias && keep) return EA_E_UNSUPPORTED;
+  p.key_norm_bias = key_norm_bias;
   p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = (N + 63) / 64 * 64;
   SM_SET(q, q); SM_SET(k, k); SM_SET(v, v); SM_SET(o, out);
   p.mask = mask; p.lse = lse;
@@ -385,10 +388,12 @@ int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtyp
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                         const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
                         const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
-                        const uint8_t* keep, float keep_scale, void* stream) {
+                        const uint8_t* keep, float keep_scale, int32_t key_norm_bias, void* stream) {
   SmP p = {};
   int rc = fill_sm(B, H, N, D, dtype, scale, p);
   if (rc != EA_OK) return rc;
+  if (key_norm_bias && keep) return EA_E_UNSUPPORTED;
+  p.key_norm_bias = key_norm_bias;
   p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = (N + 63) / 64 * 64;
   if (!t4_ok(q, D) || !t4_ok(k, D) || !t4_ok(v, D) || !t4_ok(out, D) || !t4_ok(dout, D) ||
       !t4_ok(dq, D) || !t4_ok(dk, D) || !t4_ok(dv, D) || !lse || !delta) return EA_E_BADARG;
@@ -396,6 +401,18 @@ int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtyp
   SM_SET(dq, dq); SM_SET(dk, dk); SM_SET(dv, dv);
   p.mask = mask; p.lse = const_cast<float*>(lse); p.delta = delta;
   return softmax_dispatch(1, p, dtype, D, (hipStream_t)stream);
+}
+
+int ea_softmax_sample(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                      const ea_t4* q, const ea_t4* k, const uint64_t* seed, int64_t* index, void* stream) {
+  SmP p = {};
+  int rc = fill_sm(B, H, N, D, dtype, scale, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, D) || !t4_ok(k, D) || !seed || !index) return EA_E_BADARG;
+  SM_SET(q, q); SM_SET(k, k);
+  p.seed = reinterpret_cast<const unsigned long long*>(seed);
+  p.sample_out = reinterpret_cast<long long*>(index);
+  return softmax_dispatch(2, p, dtype, D, (hipStream_t)stream);
 }
 
 }  // extern "C"

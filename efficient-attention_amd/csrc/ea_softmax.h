@@ -12,6 +12,13 @@ struct SmP {
   const uint8_t* keep;
   int keep_ld;
   float keep_scale;
+  // key_norm_bias: logits s q.k_j - s |k_j|^2 / 2 (randomized_attention.py:44-50, the second softmax of
+  // RA: prm_projection's norm term as a per-key bias, differentiated with respect to k)
+  int key_norm_bias;
+  // sample: instead of out, draw one key index per query from softmax(s q.k) by Gumbel-max
+  // (randomized_attention.py:35-37); counter-based noise from `seed`
+  long long* sample_out;           // [BH, N]
+  const unsigned long long* seed;  // device scalar
   float* lse;      // [BH, N] natural log
   float* delta;    // [BH, N]
   int B, H, N;

@@ -18,13 +18,26 @@ namespace ea {
 
 // DR: attention dropout from an explicit keep mask -- dropped entries leave the numerator (and dP, and
 // the P of dV in the backward); the normaliser is that of the full row.
-template <typename E, int D, bool DR>
+// -0.5 s log2(e) |k|^2 of the key row a staging thread holds one 16-B chunk of (CPR adjacent lanes)
+template <typename E, int CPR> EA_DEV float key_norm_term(u32x4 kw, float scale_log2) {
+  float f[8], part = 0.f;
+  unpack8<E>(kw, f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part += f[j] * f[j];
+#pragma unroll
+  for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+  return -0.5f * scale_log2 * part;
+}
+
+// KB: per-key bias -s |k|^2 / 2 in the logits (p.key_norm_bias)
+template <typename E, int D, bool DR, bool KB>
 __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
   __shared__ __attribute__((aligned(16))) uint8_t dead[64];
+  __shared__ __attribute__((aligned(16))) float kb_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.N + 63) / 64;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
@@ -59,6 +72,7 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       }
       sts16(Ks + lds_off<D>(row, c), kw);
       sts16(Vs + lds_off<D>(row, c), vw);
+      if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
       if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
     }
     __syncthreads();
@@ -72,9 +86,12 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       for (int ks = 0; ks < KS; ++ks)
         acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
       const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
+      float4 kb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KB) kb4 = *reinterpret_cast<const float4*>(kb_s + tt * 16 + 4 * g);
+      const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float x = ((f4 >> (8 * r)) & 0xffu) ? -INFINITY : acc[r] * p.scale_log2;
+        const float x = ((f4 >> (8 * r)) & 0xffu) ? -INFINITY : fmaf(acc[r], p.scale_log2, kbv[r]);
         acc[r] = x;
         mloc = fmaxf(mloc, x);
       }
@@ -135,13 +152,14 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D, bool DR>
+template <typename E, int D, bool DR, bool KB>
 __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
   __shared__ __attribute__((aligned(16))) uint8_t dead[64];
+  __shared__ __attribute__((aligned(16))) float kb_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.N + 63) / 64;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
       }
       sts16(Ks + lds_off<D>(row, c), kw);
       sts16(Vs + lds_off<D>(row, c), vw);
+      if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
       if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
     }
     __syncthreads();
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool dd = (f4 >> (8 * r)) & 0xffu;
-        const float pr = dd ? 0.f : fast_exp2(s[r] * p.scale_log2 - lse2);
+        const float pr = dd ? 0.f : fast_exp2(fmaf(s[r], p.scale_log2, KB ? kb_s[tt * 16 + 4 * g + r] : 0.f) - lse2);
         float dpr = dp[r];
         if (DR) dpr = ((k4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
         ds[r] = pr * (dpr - delta);
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D, bool DR>
+template <typename E, int D, bool DR, bool KB>
 __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
@@ -277,6 +296,22 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   f32x4 dk[DT], dv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // KB: this lane's key bias (its key row is spread over the four lane groups) and the running
+  // column sum of dS, which is the gradient of that bias
+  float kbias = 0.f, dscol = 0.f;
+  if (KB) {
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float f[8];
+      unpack8<E>(__builtin_bit_cast(u32x4, kf[ks]), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += f[j] * f[j];
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    kbias = -0.5f * p.scale_log2 * part;
+  }
 
   for (int qc = 0; qc < p.N; qc += 64) {
     __syncthreads();
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
         float pr[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = kdead ? 0.f : fast_exp2(s[r] * p.scale_log2 - ll[r]);
+          pr[r] = kdead ? 0.f : fast_exp2(fmaf(s[r], p.scale_log2, kbias) - ll[r]);
           float dpr = dp[r];
           float km = 1.f;
           if (DR) {
@@ -323,6 +358,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
             dpr *= km;
           }
           ds[r] = pr[r] * (dpr - dd[r]);
+          if (KB) dscol += ds[r];
           if (DR) pr[r] *= km;
         }
         pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
@@ -343,12 +379,27 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
       }
     }
   }
+  if (KB) {
+    dscol += __shfl_xor(dscol, 16);
+    dscol += __shfl_xor(dscol, 32);
+  }
   if (kvalid) {
     float fk[DQ], fv[DQ];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+    if (KB) {
+      // d/dk_j of -s |k_j|^2 / 2 summed over the queries: -s k_j sum_i dS_ij (this lane's channels)
+      const char* krow = p.k.p + (b * p.k.sb + h * p.k.sh + ktok * p.k.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) {
+        float kv8[8];
+        unpack8<E>(ldg16(krow + c * 16), kv8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fk[8 * c + j] -= p.scale * dscol * kv8[j];
+      }
+    }
     char* d1 = p.dk.p + (b * p.dk.sb + h * p.dk.sh + ktok * p.dk.sn + DQ * g) * 2;
     char* d2 = p.dv.p + (b * p.dv.sb + h * p.dv.sh + ktok * p.dv.sn + DQ * g) * 2;
 #pragma unroll
@@ -359,19 +410,96 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D, bool DR>
+// ---- one key index per query drawn from softmax(s q.k) (randomized_attention.py:35-37) ----------
+// Gumbel-max: argmax_j (logit_ij + G_ij), G_ij = -ln(-ln u_ij) with u from a counter-based hash of
+// (seed, b*h, query, key) -- no [N,N] probability matrix, no normalisation, one streaming pass over K.
+EA_DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+template <typename E, int D>
+__global__ __launch_bounds__(256) void sm_sample_kernel(const SmP p) {
+  constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nqb = (p.N + 63) / 64;
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const char* qbase = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* kbase = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const int qtok = qb * 64 + wave * 16 + li;
+  const bool qvalid = qtok < p.N;
+  typename E::x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 w = {0u, 0u, 0u, 0u};
+    if (qvalid) w = ldg16(qbase + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
+    qf[ks] = as_x8<E>(w);
+  }
+  const unsigned long long seed = *p.seed;
+  const uint32_t base = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9e3779b9u * (uint32_t)bh)) ^
+                        (0x85ebca77u * (uint32_t)qtok);
+  float best = -INFINITY;
+  int best_j = 0;
+  for (int kc = 0; kc < p.N; kc += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = kc + row;
+      u32x4 kw = {0u, 0u, 0u, 0u};
+      if (tok < p.N) kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
+      sts16(Ks + lds_off<D>(row, c), kw);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int row = tt * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kc + tt * 16 + 4 * g + r;
+        const uint32_t hsh = mix32(base + 0xc2b2ae3du * (uint32_t)j);
+        const float u = ((float)(hsh >> 8) + 0.5f) * (1.f / 16777216.f);
+        const float gum = -LN2 * fast_log2(-LN2 * fast_log2(u));      // -ln(-ln u)
+        const float val = j < p.N ? acc[r] * p.scale + gum : -INFINITY;
+        if (val > best) { best = val; best_j = j; }
+      }
+    }
+  }
+  // the four lane groups hold disjoint key subsets of the same query
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oj = __shfl_xor(best_j, o);
+    if (ov > best || (ov == best && oj < best_j)) { best = ov; best_j = oj; }
+  }
+  if (qvalid && g == 0) p.sample_out[(size_t)bh * p.N + qtok] = best_j;
+}
+template <typename E, int D>
+static int launch_sample(const SmP& p, hipStream_t st) {
+  const dim3 grid((unsigned)((long)p.B * p.H * ((p.N + 63) / 64))), block(256);
+  hipLaunchKernelGGL((sm_sample_kernel<E, D>), grid, block, 0, st, p);
+  return (int)hipGetLastError();
+}
+
+template <typename E, int D, bool DR, bool KB>
 static int launch_sm_dr(int which, const SmP& p, hipStream_t st) {
   const dim3 grid((unsigned)((long)p.B * p.H * ((p.N + 63) / 64))), block(256);
-  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR>), grid, block, 0, st, p);
+  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB>), grid, block, 0, st, p);
   else {
-    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR>), grid, block, 0, st, p);
-    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR, KB>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR, KB>), grid, block, 0, st, p);
   }
   return (int)hipGetLastError();
 }
 template <typename E, int D>
 static int launch_sm(int which, const SmP& p, hipStream_t st) {
-  return p.keep ? launch_sm_dr<E, D, true>(which, p, st) : launch_sm_dr<E, D, false>(which, p, st);
+  if (which == 2) return launch_sample<E, D>(p, st);
+  if (p.key_norm_bias) return p.keep ? EA_E_UNSUPPORTED : launch_sm_dr<E, D, false, true>(which, p, st);
+  return p.keep ? launch_sm_dr<E, D, true, false>(which, p, st) : launch_sm_dr<E, D, false, false>(which, p, st);
 }
 
 int softmax_dispatch(int which, const SmP& p, int dtype, int D, hipStream_t st) {

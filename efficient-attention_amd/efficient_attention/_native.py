@@ -97,8 +97,9 @@ SIGNATURES = {
     "ea_performer_bwd_q": [_PG, _T, _T, _T, _P, _P, _P, _T, _P, _P, _P, _P],
     "ea_performer_bwd_qstats": [_PG, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_performer_bwd_k": [_PG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
-    "ea_softmax_attn_fwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _P, _P, _F, _P],
-    "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P, _F, _P],
+    "ea_softmax_attn_fwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _P, _P, _F, _I, _P],
+    "ea_softmax_sample": [_I, _I, _I, _I, _I, _F, _T, _T, _P, _P, _P],
+    "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P, _F, _I, _P],
     "ea_window_bias_ld": [_G],
     "ea_window_bwd_parts": [_G],
     "ea_window_bwd_needs_bias_t": [_G],

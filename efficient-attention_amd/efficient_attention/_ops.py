@@ -724,7 +724,7 @@ class SoftmaxAttnFn(torch.autograd.Function):
         tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
         nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(tq),
                 ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse),
-                nv.ptr(keep), float(keep_scale), nv.stream())
+                nv.ptr(keep), float(keep_scale), 0, nv.stream())
         ctx.save_for_backward(qkv5, mask_u8, out, lse, keep)
         ctx.keep_scale = keep_scale
         return out
@@ -742,8 +742,58 @@ class SoftmaxAttnFn(torch.autograd.Function):
         nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(ts[0]),
                 ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8), ctypes.byref(ts[3]),
                 ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
-                ctypes.byref(ts[7]), nv.ptr(keep), float(ctx.keep_scale), nv.stream())
+                ctypes.byref(ts[7]), nv.ptr(keep), float(ctx.keep_scale), 0, nv.stream())
         return dqkv5, None, None, None
+
+
+class SoftmaxQKVFn(torch.autograd.Function):
+    """out[B,N,h,d] = softmax_j(s q.k_j [- s |k_j|^2 / 2]) v_j for separate q, k, v [B,h,N,d] (any
+    strides, rows contiguous; k and v may be the same tensor).  key_norm_bias = 1 is the second softmax
+    of randomized attention (randomized_attention.py:44-51)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_norm_bias):
+        nv.require_cuda(q, "q")
+        B, h, N, d = q.shape
+        q, k, v = [t if (t.stride(-1) == 1 and all(st % 8 == 0 for st in t.stride()[:-1])) else t.contiguous()
+                   for t in (q, k, v)]
+        out = torch.empty((B, N, h, d), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B * h, N), dtype=torch.float32, device=q.device)
+        tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
+        nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(q), float(d) ** -0.5, ctypes.byref(tq),
+                ctypes.byref(tk), ctypes.byref(tv), None, ctypes.byref(to), nv.ptr(lse), None, 1.0,
+                int(key_norm_bias), nv.stream())
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.key_norm_bias = int(key_norm_bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, h, N, d = q.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty((B, N, 3, h, d), dtype=q.dtype, device=q.device)
+        delta = torch.empty_like(lse)
+        dq, dk, dv = _qkv_views(dqkv)
+        ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
+        nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(q), float(d) ** -0.5, ctypes.byref(ts[0]),
+                ctypes.byref(ts[1]), ctypes.byref(ts[2]), None, ctypes.byref(ts[3]),
+                ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
+                ctypes.byref(ts[7]), None, 1.0, ctx.key_norm_bias, nv.stream())
+        return dq, dk, dv, None
+
+
+def softmax_sample(q, k):
+    """One key index per query, drawn from softmax(s q k^T) without forming it (Gumbel-max in
+    ea_softmax_sample; the seed comes from torch's generator on the device): int64 [B,h,N]."""
+    nv.require_cuda(q, "q")
+    B, h, N, d = q.shape
+    seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=q.device)
+    index = torch.empty((B * h, N), dtype=torch.int64, device=q.device)
+    tq, tk = nv.t4(q), nv.t4(k)
+    nv.call("ea_softmax_sample", B, h, N, d, nv.io_dtype(q), float(d) ** -0.5, ctypes.byref(tq),
+            ctypes.byref(tk), nv.ptr(seed), nv.ptr(index), nv.stream())
+    return index.view(B, h, N)
 
 
 # ------------------------------------------------------------------------------------------

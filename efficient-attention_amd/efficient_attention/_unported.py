@@ -1,5 +1,5 @@
 """Factory entries of the reference that are outside this build's hot-path scope (SURVEY.md 8:
-`ra` and `scatterbrain` are marked "next").  They keep the names importable and fail
+`scatterbrain` is marked "next").  It keeps the name importable and fails
 loudly on construction instead of silently running something else."""
 import torch.nn as nn
 
@@ -11,10 +11,6 @@ class _Unported(nn.Module):
         super().__init__()
         raise NotImplementedError(
             "%s is not part of the MI355X hot-path build yet (SURVEY.md 8f)" % self._what)
-
-
-class RandomizedAttention(_Unported):
-    _what = "RandomizedAttention ('ra')"
 
 
 class ScatterBrain(_Unported):

@@ -1,0 +1,55 @@
+"""Randomized attention (RA, arXiv 2204.04667), MI355X build.
+
+Mirrors efficient_attention/randomized_attention.py:10-63 of the reference: `num_samples` kwarg /
+flag, same parameters as the softmax baseline, `forward(x, key_padding_mask=None)` -- and, like the
+reference's `_apply_attention`, the padding mask is not used by either softmax.  Per query i:
+
+    num_samples ==  0 : mu_i = q_i + mean_j k_j
+    num_samples == -1 : mu_i = q_i + sum_j softmax_j(s q_i.k_j) k_j
+    otherwise         : mu_i = q_i + k_J,  J ~ softmax_j(s q_i.k_j)        (one draw, no gradient)
+    w_i = mu_i (+ N(0, I) in training);   out_i = sum_j softmax_j(s w_i.k_j - s |k_j|^2 / 2) v_j
+
+Both softmaxes run in the streaming HIP kernels of the softmax baseline (`_ops.SoftmaxQKVFn`: the
+first with the keys as values, the second with the per-key norm term and its gradient); the draw is a
+Gumbel-max pass over the keys (`_ops.softmax_sample`) instead of `torch.multinomial` on a
+materialised [N, N] matrix.  There is no CPU fallback.
+"""
+import torch
+
+from . import add_nested_argument
+from . import _ops
+from .abstract_attention import MultiheadAttention
+
+
+class RandomizedAttention(MultiheadAttention):
+    def __init__(self, num_samples=1, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.num_samples = num_samples
+        self._sample_index_fn = None                   # tests: injected draws
+        self.apply(self._init_weights)
+
+    def _attend(self, qkv5, key_padding_mask, seq_shape):
+        q, k, v = _ops._qkv_views(qkv5)                 # [B,h,N,d] views of the projection output
+        B, h, N, d = q.shape
+        if self.num_samples == 0:
+            mu = q.float() + k.float().mean(dim=-2, keepdim=True)
+        elif self.num_samples == -1:
+            mu = q.float() + _ops.SoftmaxQKVFn.apply(q, k, k, 0).permute(0, 2, 1, 3).float()
+        else:
+            with torch.no_grad():
+                if self._sample_index_fn is not None:
+                    index = self._sample_index_fn((B, h, N)).to(device=q.device, dtype=torch.int64)
+                else:
+                    index = _ops.softmax_sample(q, k)
+            mu = q.float() + torch.gather(k, 2, index.unsqueeze(-1).expand(B, h, N, d)).float()
+        w = mu + torch.randn_like(mu) if self.training else mu
+        return _ops.SoftmaxQKVFn.apply(w.to(qkv5.dtype), k, v, 1)
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        parent_parser = MultiheadAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)
+        group = parent_parser.add_argument_group("Attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        add_nested_argument(group, "--%snum-samples" % fp, struct_name=struct_name, prefix=prefix, default=1,
+                            type=int, help="number of random features")
+        return parent_parser

@@ -209,15 +209,24 @@ int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, 
  * pass and read by the dK/dV pass of ea_softmax_attn_bwd.
  * keep: attention dropout (`attn = self.attn_drop(attn)`, :131): uint8 [B,H,N, 64*ceil(N/64)], entry
  * (n, j) non-zero = probability of key j for query n is kept and multiplied by keep_scale = 1/(1-p);
- * NULL = no dropout. */
+ * NULL = no dropout.  q, k, v may be views of different tensors (any strides, rows contiguous). */
 int ea_softmax_attn_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
-                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale, void* stream);
+                        const ea_t4* out, float* lse, const uint8_t* keep, float keep_scale,
+                        int32_t key_norm_bias, void* stream);
 int ea_softmax_attn_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
                         const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                         const ea_t4* out, const ea_t4* dout, const float* lse, float* delta,
                         const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
-                        const uint8_t* keep, float keep_scale, void* stream);
+                        const uint8_t* keep, float keep_scale, int32_t key_norm_bias, void* stream);
+/* Randomized attention (randomized_attention.py:21-52) is two passes of the kernels above:
+ *   mu = q + softmax(s q k^T) k (num_samples = -1) or q + k[index] with one index per query drawn
+ *   from softmax(s q k^T) (ea_softmax_sample: Gumbel-max with counter-based noise from the 64-bit
+ *   device scalar `seed`; index: int64 [B*H, N]); then out = softmax_j(s w.k_j - s |k_j|^2 / 2) v_j
+ *   with w = mu (+ noise): key_norm_bias = 1 adds the per-key term and its gradient to dk
+ *   (not combined with `keep`). */
+int ea_softmax_sample(int32_t B, int32_t H, int32_t N, int32_t D, int32_t dtype, float scale,
+                      const ea_t4* q, const ea_t4* k, const uint64_t* seed, int64_t* index, void* stream);
 
 /* ---- Performer / FAVOR+ baseline (kernelized_attention.py:20-56,116-121,326-346) ---------------
  * phi(x)[j] = M^-1/2 exp(d^-1/4 W_j.x - d^-1/2 |x|^2/2 - stab) + 1e-4 with W fp32 [H, M, D] (fresh

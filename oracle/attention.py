@@ -30,6 +30,8 @@ def default_args(attn):
         base.update(num_landmarks=49, kernel_size=None, proposal_gen="pool",
                     use_antithetics=False, use_multisample=False, pool_module_type="light",
                     mis_type="mis-opt", alpha_coeff=1.0)
+    if attn == "ra":
+        base.update(num_samples=1)
     if attn == "performer":
         base.update(approx_attn_dim=64, proj_method="favorp", cos_weighting=False,
                     sample_scheme="default")
@@ -106,6 +108,21 @@ def softmax_core(q, k, v, mask=None, scale=None, drop_keep=None, p_drop=0.0):
     if drop_keep is not None:
         p = p * drop_keep.reshape(p.shape).to(p.dtype) / (1.0 - p_drop)
     return torch.einsum("bhij,bhjd->bhid", p, v)
+
+
+def ra_core(q, k, v, num_samples=1, noise=None, index=None, scale=None):
+    """Randomized attention (randomized_attention.py:21-52).  index: the [B,h,N] draws of
+    torch.multinomial(pi, 1) when num_samples is neither 0 nor -1; noise: None or [B,h,N,d]."""
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    if num_samples == 0:
+        mu = q + k.mean(dim=-2, keepdim=True)
+    elif num_samples == -1:
+        mu = q + torch.einsum("bhnm,bhmd->bhnd", torch.softmax(scale * torch.einsum("bhnd,bhmd->bhnm", q, k), -1), k)
+    else:
+        mu = q + torch.gather(k, 2, index.unsqueeze(-1).expand_as(q))
+    w = mu if noise is None else mu + noise
+    logits = scale * torch.einsum("bhnd,bhmd->bhnm", w, k) - 0.5 * scale * (k * k).sum(-1).unsqueeze(-2)
+    return torch.einsum("bhnm,bhmd->bhnd", torch.softmax(logits, -1), v)
 
 
 # --------------------------------------------------------------------------------------
@@ -460,14 +477,15 @@ def _local_bias(params, args, h, e, scale, Wq=None, Wk=None):
     return None
 
 
-def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None, keep_fn=None):
+def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None, keep_fn=None,
+                   index_fn=None):
     """y = module(x, key_padding_mask) for attn in {softmax, local, eva, lara, performer,
     causal_eva (batch-first x; training/evaluation path)}.
 
     args: constructor kwargs (missing ones take default_args); params: dict of tensors with
     the reference's state_dict keys; noise_fn(shape) -> standard-normal tensor for the i-th
-    sampling call of a training-mode forward; keep_fn(shape) -> 0/1 keep decisions of causal_eva's
-    attention dropout."""
+    sampling call of a training-mode forward; keep_fn(shape) -> 0/1 keep decisions of an attention
+    dropout; index_fn(shape) -> the key indices randomized attention draws."""
     if attn == "causal_eva":
         return _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn)
     a = default_args(attn)
@@ -483,6 +501,14 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
         p_drop = float(a["attn_drop"])
         keep = keep_fn((B, h, n, n)) if (training and p_drop > 0) else None
         return _merge_proj(softmax_core(q, k, v, mask, scale, keep, p_drop), params, B, seq_shape, C)
+
+    if attn == "ra":
+        n = int(math.prod(seq_shape))
+        q, k, v = _split_heads(x.reshape(B, n, C), params, h)
+        ns = a["num_samples"]
+        index = index_fn((B, h, n)) if ns not in (0, -1) else None
+        noise = noise_fn((B, h, n, d)).to(x.dtype) if training else None
+        return _merge_proj(ra_core(q, k, v, ns, noise, index, scale), params, B, seq_shape, C)
 
     if attn == "performer":
         n = int(math.prod(seq_shape))

@@ -91,6 +91,13 @@ CASES = {
     "softmax_2d": dict(
         attn="softmax", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2)),
+    # ---------------- randomized attention (randomized_attention.py:10-63) -------------
+    "ra_exact_2d": dict(  # num_samples = -1: mu = q + softmax(s q k^T) k
+        attn="ra", x_shape=(1, 14, 14, 128), mask=None, args=dict(dim=128, num_heads=2, num_samples=-1)),
+    "ra_mean_1d": dict(  # num_samples = 0: mu = q + mean(k); the pad mask is ignored by the reference
+        attn="ra", x_shape=(2, 50, 128), mask=("tail", [0, 9]), args=dict(dim=128, num_heads=2, num_samples=0)),
+    "ra_sampled_1d": dict(  # num_samples = 1: one key index per query (injected draws)
+        attn="ra", x_shape=(2, 70, 128), mask=None, args=dict(dim=128, num_heads=2, num_samples=1)),
     # ---------------- local baseline (local_attention.py:25-194) -----------------------
     "local_2d_rpe": dict(
         attn="local", x_shape=(1, 14, 14, 128), mask=None,
@@ -211,6 +218,11 @@ def make_noise(name, shape, call_idx=0):
     """Standard-normal sampling noise for training mode: the i-th randn/randn_like call
     inside one forward gets stream (name, 'noise<i>')."""
     return rng_for(name, "noise%d" % call_idx).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def make_index(name, shape, high, call_idx=0):
+    """Key indices standing in for torch.multinomial draws (any index has positive probability)."""
+    return rng_for(name, "index%d" % call_idx).integers(0, high, size=tuple(shape)).astype(np.int64)
 
 
 def make_keep(name, shape, p_drop, call_idx=0):

@@ -68,6 +68,17 @@ class _NoisePatch:
             return x * keep.reshape(x.shape).to(x.dtype) / (1.0 - p)
 
         torch.nn.functional.dropout = dropout
+        self._multinomial = torch.multinomial
+        self.draws = []
+
+        def multinomial(probs, num_samples, replacement=False, **kw):
+            # RA: torch.multinomial(pi.reshape(b*h*n, n), 1, replacement=True) (randomized_attention.py:36)
+            assert num_samples == 1
+            idx = cases.make_index(self.name, (probs.shape[0], 1), probs.shape[1], len(self.draws))
+            self.draws.append(tuple(probs.shape))
+            return torch.from_numpy(idx)
+
+        torch.multinomial = multinomial
 
         def randn(*size, **kw):
             if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
@@ -87,6 +98,7 @@ class _NoisePatch:
     def __exit__(self, *exc):
         torch.randn, torch.randn_like = self._randn, self._randn_like
         torch.nn.functional.dropout = self._dropout
+        torch.multinomial = self._multinomial
 
 
 def run_case(ref, name):
@@ -122,6 +134,7 @@ def run_case(ref, name):
         out["%s.dx" % mode] = x.grad.numpy()
         out["%s.noise_shapes" % mode] = np.array(json.dumps(np_patch.calls))
         out["%s.drop_shapes" % mode] = np.array(json.dumps(np_patch.drops))
+        out["%s.draw_shapes" % mode] = np.array(json.dumps(np_patch.draws))
         for k, p in mod.named_parameters():
             gnp = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
             for suffix, arr in cases.pack_grad(name, k, gnp).items():

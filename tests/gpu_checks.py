@@ -80,6 +80,8 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
     keep_fn = fx.keep_fn(device="cuda")
     if hasattr(mod, "_keep_mask_fn"):
         mod._keep_mask_fn = keep_fn                      # attention dropout: the fixture's decisions
+    if hasattr(mod, "_sample_index_fn"):
+        mod._sample_index_fn = fx.index_fn(device="cuda")  # randomized attention: the fixture's draws
     x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)
     mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np).cuda()
     with injected_noise(fx, mode, "cuda") as calls:

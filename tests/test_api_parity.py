@@ -42,7 +42,7 @@ def test_factory_names_and_errors():
     with pytest.raises(NotImplementedError):
         ea.AttentionFactory.build_attention("eva", dict(dim=64, num_heads=2, use_rpe=True, use_t5_rpe=True,
                                                         window_size=4))
-    for name in ("ra", "scatterbrain"):
+    for name in ("scatterbrain",):
         with pytest.raises(NotImplementedError):
             ea.AttentionFactory.build_attention(name, dict(dim=64, num_heads=2))
 
@@ -56,6 +56,7 @@ DEFAULTS = {
                  proposal_gen="pool", use_antithetics=False, use_multisample=False, alpha_coeff=1.0),
     "performer": dict(fp32=False, approx_attn_dim=64, proj_method="favorp", cos_weighting=False,
                       sample_scheme="default"),
+    "ra": dict(fp32=False, num_samples=1),
 }
 
 
@@ -91,7 +92,7 @@ def test_remove_argument_and_helpers():
     assert ea.remove_prefix("--enc-x", "--enc-") == "x" and ea.remove_prefix("abc", "zz") == "abc"
 
 
-@pytest.mark.parametrize("attn", ["softmax", "local", "eva", "lara", "performer"])
+@pytest.mark.parametrize("attn", ["softmax", "local", "eva", "lara", "performer", "ra"])
 def test_no_cpu_fallback(attn):
     """A CPU tensor must never be silently computed by something else."""
     args = dict(dim=64, num_heads=2)

@@ -51,6 +51,20 @@ class Fixture:
         fn.calls = calls
         return fn
 
+    def index_fn(self, device="cpu"):
+        """i-th multinomial call of randomized attention -> the draws the generator fed to the reference
+        (there as [B*h*N, 1] of N-way draws, here as [B,h,N])."""
+        calls = []
+
+        def fn(shape):
+            n = int(np.prod(shape))
+            arr = cases.make_index(self.name, (n, 1), shape[-1], len(calls)).reshape(shape)
+            calls.append(tuple(shape))
+            return torch.from_numpy(arr).to(device)
+
+        fn.calls = calls
+        return fn
+
     def expected_drop_elems(self, mode):
         key = "%s.drop_shapes" % mode
         if key not in self.z.files:
