@@ -51,7 +51,7 @@ def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None, keep=None, p_drop
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_mask", "recipe_d128_dropout",
-                                     "overlap_dropout"])
+                                     "overlap_dropout", "overlap_w128_d64", "overlap_w64_d128"])
 def test_recipe_geometry_matches_oracle(variant, dtype):
     from gpu_checks import MODULE_TOL, FP16_TOL
     from util import scaled_err
@@ -62,6 +62,11 @@ def test_recipe_geometry_matches_oracle(variant, dtype):
         embed, heads, T, B, aa, pads = 512, 8, 512, 4, dict(RECIPE), None
     elif variant == "recipe_d128_dropout":
         embed, heads, T, B, aa, pads = 1024, 8, 512, 2, dict(RECIPE), None
+    elif variant == "overlap_w128_d64":
+        # overlapping 128-token windows (256 keys): 4 query blocks x 2 colour classes, launched in turn
+        embed, heads, T, B, aa, pads = 512, 8, 512, 2, dict(RECIPE, overlap_window=True), [0, 40]
+    elif variant == "overlap_w64_d128":
+        embed, heads, T, B, aa, pads = 1024, 8, 512, 2, dict(RECIPE, window_size=64, overlap_window=True), None
     elif variant == "overlap_dropout":
         embed, heads, T, B, pads = 128, 2, 100, 2, [0, 11]
         aa = dict(RECIPE, window_size=24, chunk_size=8, overlap_window=True)   # Wk = 48, L = 15: padded mask columns

@@ -36,6 +36,14 @@ CONFIGS = {
                       [0, 410, 0, 17]),
     "cfg5_performer": ("performer", (4, 4096, 512), dict(dim=512, num_heads=8, approx_attn_dim=64, proj_method="favorp"),
                        [0, 410, 0, 17]),
+    # windows larger than one LDS image in backward: query blocks, run one after the other because the
+    # windows overlap or the causal key lists do not apply (ea_window_bwd_query_blocks > 1, acc_slices = 1)
+    "big_eva_1d_overlap": ("eva", (2, 512, 512), dict(dim=512, num_heads=8, window_size=128, attn_2d=False, use_t5_rpe=True,
+                                                      overlap_window=True, num_landmarks=8, adaptive_proj="default"), [0, 50]),
+    "big_eva_1d_w256": ("eva", (2, 512, 512), dict(dim=512, num_heads=8, window_size=256, attn_2d=False, use_rpe=True,
+                                                   num_landmarks=8, adaptive_proj="no-ln"), [0, 50]),
+    "big_local_1d": ("local", (2, 1024, 256), dict(dim=256, num_heads=4, window_size=128, attn_2d=False, use_rpe=True,
+                                                   overlap_window=True), [0, 100]),
 }
 
 
