@@ -156,7 +156,17 @@ inline int win_bwd_launches(const ea_geom& g, const WinTiling& base, F&& f) {
 }
 // leading dimension of dbias_part
 inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t);
-inline int win_bwd_acc_slices(const WinTiling& t) { return win_bwd_single(t) ? 0 : (win_bwd_merged(t) ? t.qsplit : 1); }
+// Overlapping 1-D windows: a token is a key of up to ncx consecutive windows, one per colour class.
+// Each class stores into its own scratch slice (plain stores: a read-modify-write is a dependent
+// global round trip per key tile, 20 % of the kernel at N = 4096) and the finish pass sums the
+// slices of the windows that cover a token.
+inline bool win_bwd_colour_slices(const WinTiling& t) { return t.qsplit == 1 && t.ncy == 1 && t.ncx > 1; }
+// fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
+inline int win_bwd_acc_slices(const WinTiling& t) {
+  if (win_bwd_single(t)) return 0;
+  if (win_bwd_merged(t)) return t.qsplit;
+  return win_bwd_colour_slices(t) ? t.ncx : 1;
+}
 
 inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t) {
   if (!win_bwd_merged(t)) return t.parts_total;
@@ -240,7 +250,8 @@ struct WinP {
   float keep_scale;
   int bias_lds;                              // bwd: the bias table of the head is staged in LDS
   // bwd, how local dk/dv leave the kernel: 0 = stored to dk/dv; 1 = fp32 read-modify-write into dk32/dv32
-  // (launches ordered by the stream); 2 = plain fp32 stores into slice t.slice of dk32/dv32
+  // (launches ordered by the stream); 2 / 3 = plain fp32 stores into slice t.slice of dk32/dv32 (2: one
+  // slice per query block, 3: one per colour class -- they differ in the finish pass)
   int acc_mode;
   // bwd, merged query-block launch: workgroups [qstart[i], qstart[i+1]) run tiling tv[i] (nq > 1)
   int nq;

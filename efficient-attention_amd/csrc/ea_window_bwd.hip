@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
               stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
               stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
             }
-          } else if (p.acc_mode == 2) {
+          } else if (p.acc_mode >= 2) {
             // merged query blocks: this block's own slice, every (token, channel) written once
             const size_t row = ((size_t)t.slice * p.B * p.H + bh) * p.G.N + tok;
             float4* a1 = reinterpret_cast<float4*>(p.dk32 + row * D + DQ * g);
@@ -596,15 +596,24 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
     for (int i = 0; i < 8; ++i) f[i] = f2[i] = 0.f;
     // slices that hold this token: all of them, or (causal masks: a query block's key list ends at
     // its own last query) the blocks from the token's own on
-    int s0 = 0, s1n = 1;
+    int s0 = 0, s1n = 1, ncol = 1;
     if (p.acc_mode == 2) {
       s1n = p.t.qsplit;
       if (p.causal == 2) s0 = (tok % p.w) / p.t.Wq;
+    } else if (p.acc_mode == 3) {
+      // windows g whose key range [g w - e, g w + w + e_right) holds the token; slice = g mod ncx
+      const int er = p.causal ? 0 : p.e;
+      const int nwin = (p.G.N + p.w - 1) / p.w;
+      const int tl = tok - p.w - er;
+      s0 = (tl >= 0 ? tl / p.w : -1) + 1;
+      s1n = min((tok + p.e) / p.w, nwin - 1) + 1;
+      ncol = p.t.ncx;
     }
     const size_t slice = (size_t)p.B * p.H * p.G.N * D;
     for (int sl = s0; sl < s1n; ++sl) {
-      const float* s1 = p.dk32 + sl * slice + row * D + c * 8;
-      const float* s2 = p.dv32 + sl * slice + row * D + c * 8;
+      const int si = p.acc_mode == 3 ? sl % ncol : sl;
+      const float* s1 = p.dk32 + si * slice + row * D + c * 8;
+      const float* s2 = p.dv32 + si * slice + row * D + c * 8;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { f[i] += s1[i]; f2[i] += s2[i]; }
     }
@@ -659,7 +668,8 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
     p.qstart[n] = start;
     rc = launch(p, lds, (unsigned)start);
   } else {
-    if (!single) {
+    const bool cslices = win_bwd_colour_slices(p0.t);
+    if (!single && !cslices) {
       const size_t bytes = (size_t)p0.B * p0.H * p0.G.N * D * sizeof(float);
       hipError_t e = hipMemsetAsync(p0.dk32, 0, bytes, st);
       if (e == hipSuccess) e = hipMemsetAsync(p0.dv32, 0, bytes, st);
@@ -670,7 +680,8 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
       if (rc != EA_OK) return;
       WinP p = p0;
       p.t = t;
-      p.acc_mode = single ? 0 : 1;
+      p.t.slice = t.col_x;
+      p.acc_mode = single ? 0 : (cslices ? 3 : 1);
       p.nq = 0;
       // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
       // every window; from global memory those loads sit exposed in the inner loops)
@@ -681,7 +692,7 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
   if (rc != EA_OK) return rc;
   if (!single) {
     WinP pf = p0;
-    pf.acc_mode = merged ? 2 : 1;
+    pf.acc_mode = merged ? 2 : (win_bwd_colour_slices(p0.t) ? 3 : 1);
     hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, pf);
   }
   return (int)hipGetLastError();
