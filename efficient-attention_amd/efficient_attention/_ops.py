@@ -913,6 +913,17 @@ def _mm_out(a, b, out_dtype):
     return (a @ b).to(out_dtype)
 
 
+_ONES = {}
+
+
+def _ones_row(S, dtype, device):
+    """Cached [1, S] row of ones (a constant: not re-filled every step)."""
+    key = (S, dtype, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones((1, S), dtype=dtype, device=device)
+    return _ONES[key]
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b in the autocast dtype.  dW = dY^T X contracts over all B*N tokens with a
     [out, in] result of a few tiles: left to a single library GEMM it occupies ~9 of 256 CUs
@@ -946,8 +957,7 @@ class LinearFn(torch.autograd.Function):
             if S > 1:
                 part = torch.bmm(dy2.view(S, rows // S, -1).transpose(1, 2), xl.view(S, rows // S, -1))
                 # sum over the slices as a [1,S] x [S, out*in] GEMM (fp32 accumulation inside the GEMM)
-                ones = torch.ones((1, S), dtype=part.dtype, device=part.device)
-                dw = (ones @ part.view(S, -1)).view(part.shape[1:]).to(wdtype)
+                dw = (_ones_row(S, part.dtype, part.device) @ part.view(S, -1)).view(part.shape[1:]).to(wdtype)
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:
