@@ -5,8 +5,8 @@ Mirrors the in-scope part of efficient_attention/kernelized_attention.py:223-359
 buffer of per-head orthogonal random features (fresh Gaussian features on every training
 call), and the argparse flags.  phi(q), phi(k), phi(K)^T V and the normalised read-out run in
 libea_hip.so (_ops.PerformerAttnFn).  Other feature maps of the reference
-(fourier / relu / dpfp / mlp-fourier / cos-weighting) are outside this build's scope and
-raise NotImplementedError.
+(fourier / relu / dpfp / mlp-fourier / cos-weighting) and learnable features
+(`sample_scheme='learnable'`) are outside this build's scope and raise NotImplementedError.
 """
 import math
 
@@ -59,7 +59,9 @@ class KernelizedAttention(MultiheadAttention):
         elif sample_scheme == 'fixed':
             self.register_buffer('random_proj', mat)
         elif sample_scheme == 'learnable':
-            self.random_proj = nn.Parameter(mat)
+            # the kernels return no gradient for the feature matrix: refuse rather than silently freeze it
+            raise NotImplementedError("sample_scheme='learnable' (gradient with respect to the random "
+                                      "features) is not built for MI355X")
         else:
             raise NotImplementedError('other sample schemes are not implemented yet.')
         self.apply(self._init_weights)
