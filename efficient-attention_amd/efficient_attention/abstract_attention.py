@@ -114,7 +114,7 @@ class MultiheadAttention(nn.Module):
             if ld != N:
                 keep = torch.nn.functional.pad(keep, (0, ld - N))
         else:
-            keep = torch.empty((B, h, N, ld), device=device, dtype=torch.float32).bernoulli_(1 - p).to(torch.uint8)
+            keep = torch.empty((B, h, N, ld), device=device, dtype=torch.uint8).bernoulli_(1 - p)
         return (keep.contiguous(), 1.0 / (1.0 - p))
 
     @staticmethod

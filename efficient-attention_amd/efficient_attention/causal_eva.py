@@ -199,7 +199,7 @@ class CausalEVAttention(nn.Module):
         if self._keep_mask_fn is not None:                         # tests: the fixture's decisions
             keep = self._keep_mask_fn((B, h, N, Wk + L)).to(device=device, dtype=torch.uint8)
         else:
-            keep = torch.empty((B, h, N, Wk + L), device=device, dtype=torch.float32).bernoulli_(1 - p).to(torch.uint8)
+            keep = torch.empty((B, h, N, Wk + L), device=device, dtype=torch.uint8).bernoulli_(1 - p)
         # kernel layout: local columns padded to whole 16-key tiles, then the landmarks
         ld_local, ld_lm = -(-Wk // 16) * 16, -(-L // 16) * 16
         if ld_local != Wk or ld_lm != L:
