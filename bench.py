@@ -345,6 +345,23 @@ def main():
     ktimes = _ops.KERNEL_TIMER.summary()
     _ops.KERNEL_TIMER.disable()
 
+    # achievable HBM bandwidth of this GPU, babel-stream style: a device-to-device copy of 512 MB
+    # (read + write counted), the yardstick SURVEY 8d asks for next to the nominal 8 TB/s
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         tokens = B * N * world * a.steps
         value = tokens / el
@@ -399,6 +416,9 @@ def main():
                        "parallelism": "dp%d" % world, "hipgraph": graphed,
                        "gemm_tunableop": tune},
             "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H * d / 64),
+            # whole layer priced on the op-level q,k,v -> out traffic (1536*h bytes per token at d = 64)
+            "layer_algorithmic_gbs": value / world * BYTES_PER_TOKEN_HEAD * H * d / 64 / 1e9,
+            "hbm_measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
