@@ -40,15 +40,19 @@ def _run(cmd):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
-    objs = []
+    objs, jobs = [], []
     for src in LIB_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
             if verbose:
                 print("hipcc -c", src, flush=True)
-            _run([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
         objs.append(o)
+    if jobs:                                             # translation units are independent: compile in parallel
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(_run, jobs))
     lib = os.path.join(LIBDIR, "libea_hip.so")
     if force or _newer(lib, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
