@@ -50,6 +50,23 @@ EA_DEV void tile_mm(f32x4& acc, const float* A, int lda, const float* B, int ldb
   acc += acc2;
 }
 
+// W [D, D] -> LDS rows of stride D + 1; batches of eight 16-B loads in flight per thread (a load per
+// loop trip would be a global round trip per trip)
+template <int D> EA_DEV void stage_weight(float* Ws, const float* W, int tid) {
+  constexpr int LD = D + 1, N4 = D * D / 4, NB = N4 / 256 < 8 ? N4 / 256 : 8;
+  for (int base = 0; base < N4; base += 256 * NB) {
+    float4 v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v[i] = reinterpret_cast<const float4*>(W)[base + i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = base + i * 256 + tid;
+      float* d = Ws + (idx * 4 / D) * LD + (idx * 4) % D;
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    }
+  }
+}
+
 template <int TPR> EA_DEV float row_sum(float v) {
 #pragma unroll
   for (int o = 1; o < TPR; o <<= 1) v += __shfl_xor(v, o);
@@ -71,11 +88,7 @@ __global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
   const float* x = p.x[s];
   const float* W = p.W[s];
   const float* bias = p.b[s];
-  for (int idx = tid; idx < D * D / 4; idx += 256) {
-    const float4 v = reinterpret_cast<const float4*>(W)[idx];
-    float* d = Ws + (idx * 4 / D) * LD + (idx * 4) % D;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
+  stage_weight<D>(Ws, W, tid);
   const int ntile = (p.R + RB - 1) / RB;
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int r0 = tile * RB;
@@ -144,11 +157,7 @@ __global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
   const float* x = p.x[s];
   const float* W = p.W[s];
   const float* dy = p.dy[s];
-  for (int idx = tid; idx < D * D / 4; idx += 256) {
-    const float4 v = reinterpret_cast<const float4*>(W)[idx];
-    float* d = Ws + (idx * 4 / D) * LD + (idx * 4) % D;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
+  stage_weight<D>(Ws, W, tid);
   f32x4 dW[WT];
 #pragma unroll
   for (int i = 0; i < WT; ++i) dW[i] = f32x4{0.f, 0.f, 0.f, 0.f};
