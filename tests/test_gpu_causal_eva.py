@@ -179,3 +179,29 @@ def test_unsupported_backward_geometry_is_loud():
         y = m(xt, xt, xt)[0]
     with pytest.raises(RuntimeError, match="unsupported geometry"):
         y.float().sum().backward()
+
+
+@pytest.mark.gpu
+def test_separate_key_value_inputs():
+    """self_attention=False with key = value = query goes through three projections and a stacked
+    buffer; it must agree with the fused self-attention path on the same weights."""
+    import efficient_attention as ea
+    aa = dict(RECIPE, window_size=32, chunk_size=8)
+    m1 = _build(128, 2, aa)
+    torch.manual_seed(3)
+    m2 = ea.AttentionFactory.build_attention(
+        "causal_eva", dict(embed_dim=128, num_heads=2, self_attention=False,
+                           attn_args=argparse.Namespace(**aa))).cuda().eval()
+    m2.load_state_dict(m1.state_dict())
+    x = torch.randn(100, 3, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = m1(xa, xa, xa)[0]
+        y2 = m2(xb, xb, xb)[0]
+    assert torch.equal(y1, y2)
+    y1.float().square().sum().backward()
+    y2.float().square().sum().backward()
+    scale = xa.grad.abs().max().item()
+    assert (xa.grad - xb.grad).abs().max().item() <= 2e-2 * scale      # three bf16 dgrad GEMMs summed vs one
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1.grad - p2.grad).abs().max().item() <= 2e-2 * max(p1.grad.abs().max().item(), 1e-6), k
