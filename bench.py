@@ -13,7 +13,7 @@ resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Default workload (config.workload): BASELINE.json configs[2] geometry, the one the metric is
 quoted on -- DeiT-tiny-p8 tokens (N = 28x28 = 784, 3 heads, d = 64), per-GPU batch 128.
-`--attn eva|lara|softmax|local|performer|ra` selects the attention (default: see DEFAULT_ATTN);
+`--attn eva|lara|softmax|local|performer|ra|scatterbrain` selects the attention (default: see DEFAULT_ATTN);
 `--attn causal_eva --workload lm` is the wikitext-103 decoder self-attention.
 """
 import argparse
@@ -61,6 +61,8 @@ def _attn_args(attn, dim, heads, seq):
                         adaptive_proj="default")
     elif attn == "local":
         base.update(window_size=7 if two_d else 16, attn_2d=two_d, use_rpe=True)
+    elif attn == "scatterbrain":
+        base.update(window_size=7 if two_d else 16, attn_2d=two_d, use_rpe=True, approx_attn_dim=64)
     elif attn == "lara":
         if two_d:
             base.update(num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)

@@ -120,10 +120,11 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
                        float* dk_acc, float* dv_acc, const float* bias_t,
-                       const uint8_t* keep, float keep_scale, void* stream) {
+                       const uint8_t* keep, float keep_scale, const float* dlse, void* stream) {
   WinP p = {};
   int rc = fill_win(g, p, true);
   if (rc != EA_OK) return rc;
+  p.dlse = dlse;
   if (keep && !g->causal) return EA_E_UNSUPPORTED;
   p.keep = keep; p.keep_scale = keep_scale; p.keep_ld = p.t.biasLd + p.t.nCT * 16;
   const int N = g->N;

@@ -235,6 +235,7 @@ struct WinP {
   const float *lk, *lv, *bias;
   const uint8_t* mask;
   float* lse;
+  const float* dlse;                         // bwd, optional: gradient of the returned lse [B,H,N]
   float *dlk_part, *dlv_part, *dbias_part;   // bwd only
   float *dk32, *dv32;                        // bwd, overlap (e > 0): fp32 atomics scratch [B,H,N,D]
   Geo G;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     // staging costs ~one memory round trip per iteration instead of one per 256-slot sweep. ----
     constexpr int NB = 2;
     struct KVb { u32x4 kr[NB], vr[NB]; int rowv[NB]; float mulv[NB], addv[NB]; };
-    struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB]; int rowv[NB]; QLim lim[NB]; };
+    struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB], dls[NB]; int rowv[NB]; QLim lim[NB]; };
     auto issueKV = [&](KVb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
         x.qr[i] = x.dr[i] = x.orr[i] = u32x4{0u, 0u, 0u, 0u};
-        x.rowv[i] = -1; x.lsv[i] = INFINITY;
+        x.rowv[i] = -1; x.lsv[i] = INFINITY; x.dls[i] = 0.f;
         if (idx < rowsQ * CPR) {
           const int row = idx / CPR, c = idx - row * CPR;
           const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             x.qr[i] = ldg16(qb + (tok * qsn + c * 8) * 2);
             x.dr[i] = ldg16(dob + (tok * dosn + c * 8) * 2);
             x.orr[i] = ldg16(ob + (tok * osn + c * 8) * 2);
-            if (c == 0) x.lsv[i] = lse_g[tok] * LOG2E;
+            if (c == 0) {
+              x.lsv[i] = lse_g[tok] * LOG2E;
+              if (p.dlse) x.dls[i] = p.dlse[(size_t)bh * p.G.N + tok];
+            }
           }
         }
       }
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           sts16(Qs + lds_off<D>(x.rowv[i], c), x.qr[i]);
           sts16(dOs + lds_off<D>(x.rowv[i], c), x.dr[i]);
           if (c == 0) {
-            delta_s[x.rowv[i]] = part; lse_s[x.rowv[i]] = x.lsv[i];
+            // a loss that also reads lse adds P o dlse to dS: dS = P o (dP - (delta - dlse))
+            delta_s[x.rowv[i]] = part - x.dls[i]; lse_s[x.rowv[i]] = x.lsv[i];
             if (CA) { qlim_s[x.rowv[i]] = x.lim[i].local; clim_s[x.rowv[i]] = x.lim[i].lm; }
           }
         }

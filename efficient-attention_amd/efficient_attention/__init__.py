@@ -61,7 +61,7 @@ from .lara import LinearRA  # noqa: E402
 from .eva import EVA  # noqa: E402
 from .causal_eva import CausalEVAttention  # noqa: E402
 from .randomized_attention import RandomizedAttention  # noqa: E402
-from ._unported import ScatterBrain  # noqa: E402
+from .scatterbrain_attention import ScatterBrain  # noqa: E402
 
 
 class AttentionFactory(object):

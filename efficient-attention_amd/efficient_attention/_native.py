@@ -66,7 +66,7 @@ SIGNATURES = {
     "ea_eva_beta_fwd": [_G, _T, _T, _P, _P, _P, _P],
     "ea_eva_beta_bwd": [_G, _T, _T, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_window_attn_fwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _P, _P, _F, _P],
-    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P, _F, _P],
+    "ea_window_attn_bwd": [_G, _T, _T, _T, _P, _P, _P, _P, _T, _T, _P, _T, _T, _T, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P],
     "ea_window_keep_ld": [_G],
     "ea_rows_mlp_parts": [_I, _I],
     "ea_rows_mlp_fwd": [_I] * 4 + [_P] * 15,

@@ -134,7 +134,7 @@ def _rows_contiguous(t):
     return t.contiguous()
 
 
-def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep=None, keep_scale=1.0):
+def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep=None, keep_scale=1.0, dlse=None):
     """out, dout: [B,N,h,d] with contiguous rows.  Writes dq,dk,dv into dqkv5; returns dlk, dlv, dbias_padded."""
     B, N, _, h, d = qkv5.shape
     q, k, v = _qkv_views(qkv5)
@@ -165,7 +165,8 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
             ctypes.byref(ts[2]), nv.ptr(lk), nv.ptr(lv), nv.ptr(bias_p), nv.ptr(mask_u8),
             ctypes.byref(ts[3]), ctypes.byref(ts[4]), nv.ptr(lse), ctypes.byref(ts[5]),
             ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(dlk_p), nv.ptr(dlv_p), nv.ptr(dbias_p),
-            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.ptr(keep), float(keep_scale), nv.stream())
+            nv.ptr(dk_acc), nv.ptr(dv_acc), nv.ptr(bias_t), nv.ptr(keep), float(keep_scale), nv.ptr(dlse),
+            nv.stream())
     dlk = dlv = dbias = None
     if L > 0:
         # per-workgroup partials [parts, B*h*L*d] -> one pass each (fixed summation order)
@@ -203,6 +204,33 @@ class LocalAttnFn(torch.autograd.Function):
         dqkv5 = torch.empty_like(qkv5)
         _, _, dbias = _window_bwd(ctx.geom, qkv5, None, None, bias_p, mask_u8, out,
                                   dout.contiguous(), lse, dqkv5)
+        if dbias is not None:
+            dbias = dbias[..., :ctx.bias_cols]
+        return dqkv5, dbias, None, None, None, None, None
+
+
+class LocalAttnLseFn(torch.autograd.Function):
+    """LocalAttnFn that also returns the per-query log-sum-exp [B,h,N] (natural log) as a
+    differentiable output, for callers that merge further softmax columns with the window's."""
+
+    @staticmethod
+    def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, 0, 0)
+        bias_p = _bias_padded(bias, geom)
+        out, lse = _window_fwd(geom, qkv5, None, None, bias_p, mask_u8)
+        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out)
+        ctx.geom = geom
+        ctx.bias_cols = None if bias is None else bias.shape[-1]
+        return out, lse.clone()
+
+    @staticmethod
+    def backward(ctx, dout, dlse):
+        qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
+        dqkv5 = torch.empty_like(qkv5)
+        _, _, dbias = _window_bwd(ctx.geom, qkv5, None, None, bias_p, mask_u8, out, dout.contiguous(), lse, dqkv5,
+                                  dlse=dlse.float().contiguous())
         if dbias is not None:
             dbias = dbias[..., :ctx.bias_cols]
         return dqkv5, dbias, None, None, None, None, None

@@ -1,0 +1,128 @@
+"""ScatterBrain (sparse local windows + low-rank random features under one softmax, arXiv
+2110.15343), MI355X build.
+
+Mirrors efficient_attention/scatterbrain_attention.py:46-180 of the reference: the class is
+`KernelizedAttention` x `LocalAttention` (constructor kwargs, `eval_proj` buffer, relative-position
+table, argparse flags of both), `forward(x, key_padding_mask=None)` with the 1-D padding rule of
+LocalAttention._process_input.  Per window g and query i the softmax runs over the window's keys and
+m feature columns with logits `log phi(q_i)[c] + log(sum_{j outside g} phi(k_j)[c])` and values the
+phi-weighted mean of v outside the window (reference :99-160).
+
+Split of the work in this build: the window part -- logits, mask, relative-position bias, softmax
+statistics, P.V and its backward -- is the HIP window kernel (`_ops.LocalAttnLseFn`, which hands back
+the per-query log-sum-exp); the feature columns are merged with it exactly through that log-sum-exp
+(out = e^{lse_loc - Z} o_loc + e^{R - Z} o_rfa, Z = logaddexp(lse_loc, R)).  The feature statistics
+themselves (global-minus-window sums) are batched GEMMs and reductions on torch device ops in fp32 --
+a dedicated kernel for them is the next step.  Window overlap is not built: the
+reference partitions the log-features with zero padding there, which makes out-of-range slots count
+as phi = 1.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import add_nested_argument
+from . import _ops
+from .kernelized_attention import KernelizedAttention
+from .local_attention import LocalAttention
+
+
+class ScatterBrain(KernelizedAttention, LocalAttention):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.ext_size > 0:
+            raise NotImplementedError("ScatterBrain with overlapping windows is not built for MI355X")
+        self.apply(self._init_weights)
+
+    def forward(self, x, key_padding_mask=None):
+        B, *seq_shape, C = x.shape
+        orig_n = int(math.prod(seq_shape))
+        w = self.window_size
+        if self.attn_2d:
+            assert len(seq_shape) == 2 and seq_shape[0] % w == 0 and seq_shape[1] % w == 0
+            N, xs, mask = orig_n, x.reshape(B, orig_n, C), key_padding_mask
+        else:
+            N = int(math.ceil(orig_n / w) * w)
+            xs = F.pad(x, (0, 0, 0, N - orig_n)) if N != orig_n else x
+            mask = None
+            if key_padding_mask is not None or N != orig_n:
+                mask = torch.zeros(B, N, dtype=torch.bool, device=x.device)
+                if key_padding_mask is not None:
+                    mask[:, :orig_n] = key_padding_mask.to(torch.bool)
+                mask[:, orig_n:] = True
+            seq_shape = [N]
+        qkv5 = self.project_qkv(xs)
+        out = self._scatter(qkv5, mask, seq_shape)
+        y = self.merge_and_project(out, B, seq_shape, C, x.dtype)
+        return y if self.attn_2d else y[..., :orig_n, :]
+
+    def _scatter(self, qkv5, mask, seq_shape):
+        B, N, _, h, d = qkv5.shape
+        w = self.window_size
+        proj = self.get_proj_matrix(device=qkv5.device, dtype=torch.float32)      # [h, m, d]
+        m = proj.shape[1]
+        o_loc, lse_loc = _ops.LocalAttnLseFn.apply(
+            qkv5, self._table_bias(), _ops._mask_u8(mask, B, N, qkv5.device), self.attn_2d, tuple(seq_shape), w, 0)
+
+        if self.attn_2d:
+            H, W = seq_shape
+            G, Wq = (H // w) * (W // w), w * w
+
+            def win(t):                                   # [B,h,N,c] -> [B,h,G,Wq,c]
+                c = t.shape[-1]
+                return t.reshape(B, h, H // w, w, W // w, w, c).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, h, G, Wq, c)
+
+            def unwin(t):                                 # [B,h,G,Wq,c] -> [B,h,N,c]
+                c = t.shape[-1]
+                return t.reshape(B, h, H // w, W // w, w, w, c).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, h, N, c)
+        else:
+            G, Wq = N // w, w
+
+            def win(t):
+                return t.reshape(B, h, G, Wq, t.shape[-1])
+
+            def unwin(t):
+                return t.reshape(B, h, N, t.shape[-1])
+
+        with torch.autocast(device_type="cuda", enabled=False):
+            q, k, v = [t.float() for t in _ops._qkv_views(qkv5)]
+
+            def log_phi(x):
+                return d ** -0.25 * torch.einsum("bhnd,hmd->bhnm", x, proj) \
+                    - 0.5 * d ** -0.5 * (x * x).sum(-1, keepdim=True) - math.log(m) / 2
+            lq, lk = log_phi(q), log_phi(k)
+            if mask is not None:
+                lk = lk.masked_fill(mask.to(torch.bool)[:, None, :, None], float("-inf"))
+            # phi(k) sums over all keys minus those of the window, one (detached) stabiliser per feature
+            mx = lk.amax(dim=-2, keepdim=True).detach()
+            pk = torch.exp(lk - mx)                                                 # [B,h,N,m]
+            w_pk, w_v = win(pk), win(v)
+            num = torch.einsum("bhnc,bhnd->bhcd", pk, v).unsqueeze(2) - torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)
+            den = (pk.sum(-2).unsqueeze(2) - w_pk.sum(-2)).unsqueeze(-1).clamp(min=1e-3)
+            kv_stats = num / den                                                    # [B,h,G,m,d]
+            lse_all = torch.logsumexp(lk, dim=-2).unsqueeze(2)                      # [B,h,1,m]
+            lse_win = torch.logsumexp(win(lk), dim=-2)                              # [B,h,G,m]
+            a = torch.maximum(lse_all, lse_win)
+            nonlocal_ = a + ((lse_all - a).exp() - (lse_win - a).exp() + 1e-5).log()
+            log_rfa = win(lq) + nonlocal_.unsqueeze(-2)                             # [B,h,G,Wq,m]
+            r = torch.logsumexp(log_rfa, dim=-1, keepdim=True)                      # [B,h,G,Wq,1]
+            o_rfa = torch.einsum("bhgwc,bhgcd->bhgwd", torch.exp(log_rfa - r), kv_stats)
+            r_t, o_rfa_t = unwin(r).squeeze(-1), unwin(o_rfa)                       # [B,h,N], [B,h,N,d]
+            z = torch.logaddexp(lse_loc, r_t)
+            out = torch.exp(lse_loc - z).unsqueeze(-1) * o_loc.permute(0, 2, 1, 3).float() \
+                + torch.exp(r_t - z).unsqueeze(-1) * o_rfa_t
+        return out.permute(0, 2, 1, 3).to(qkv5.dtype).contiguous()
+
+    @staticmethod
+    def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
+        parent_parser = LocalAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)
+        group = parent_parser.add_argument_group("Attention")
+        fp = prefix + "-" if len(prefix) > 1 else ""
+        kw = dict(struct_name=struct_name, prefix=prefix)
+        add_nested_argument(group, "--%sapprox-attn-dim" % fp, default=64, type=int, help="number of random features", **kw)
+        add_nested_argument(group, "--%sproj-method" % fp, default="favorp", type=str,
+                            help="which attention method is used for RFA", **kw)
+        add_nested_argument(group, "--%scos-weighting" % fp, action="store_true", default=False, help="", **kw)
+        add_nested_argument(group, "--%ssample-scheme" % fp, default="default", type=str, **kw)
+        return parent_parser

@@ -100,7 +100,9 @@ int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
  *   lk, lv : fp32 [B,H,L,D] (rf_k_bar and beta), may be NULL iff L == 0
  *   bias   : fp32 [H, Wq, ea_window_bias_ld(g)] dense per-head bias MULTIPLIED BY log2(e) (the
  *            softmax runs in the log2 domain), rows padded, or NULL; dbias_part is d/d(natural bias)
- *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward
+ *   lse    : fp32 [B,H,N] joint log-sum-exp (natural log), saved for backward; a caller that merges this
+ *            attention with further softmax columns of its own (ScatterBrain's low-rank part) uses it
+ *            as an output and passes its gradient `dlse` [B,H,N] to the backward (NULL otherwise)
  * With ea_geom.causal the windows, masks and chunk visibility follow causal_eva.py:666-783 (see the
  * field's comment); Wk = window + ext there.
  *   keep   : attention dropout of causal_eva.py:778 (`attn = dropout(attn)` on the joint softmax):
@@ -142,7 +144,7 @@ int ea_window_attn_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const e
                        const ea_t4* dq, const ea_t4* dk, const ea_t4* dv,
                        float* dlk_part, float* dlv_part, float* dbias_part,
                        float* dk_acc, float* dv_acc, const float* bias_t,
-                       const uint8_t* keep, float keep_scale, void* stream);
+                       const uint8_t* keep, float keep_scale, const float* dlse, void* stream);
 
 /* ---- LARA: linear randomized attention (lara.py:177-251) -------------------------------------
  * C landmark samples omega_c (C = L, or 2L with antithetic / multi-sample noise), each token n:

@@ -19,9 +19,9 @@ gradient for all cases in eval and training mode (injected noise) at fp32 tolera
 from .geometry import (window_index_1d, window_index_2d, rpe_index_2d, t5_bucket,
                        adaptive_pool_matrix, causal_window_index_1d, t5_bucket_causal)
 from .attention import (softmax_core, local_core, eva_core, lara_core, performer_core,
-                        causal_eva_core, ra_core, module_forward, default_args)
+                        causal_eva_core, ra_core, scatterbrain_core, module_forward, default_args)
 
 __all__ = ["window_index_1d", "window_index_2d", "rpe_index_2d", "t5_bucket",
            "adaptive_pool_matrix", "causal_window_index_1d", "t5_bucket_causal", "softmax_core",
-           "local_core", "eva_core", "lara_core", "performer_core", "causal_eva_core", "ra_core",
+           "local_core", "eva_core", "lara_core", "performer_core", "causal_eva_core", "ra_core", "scatterbrain_core",
            "module_forward", "default_args"]

@@ -32,6 +32,9 @@ def default_args(attn):
                     mis_type="mis-opt", alpha_coeff=1.0)
     if attn == "ra":
         base.update(num_samples=1)
+    if attn == "scatterbrain":
+        base.update(use_rpe=False, window_size=2, attn_2d=False, overlap_window=False,
+                    approx_attn_dim=64, proj_method="favorp", cos_weighting=False, sample_scheme="default")
     if attn == "performer":
         base.update(approx_attn_dim=64, proj_method="favorp", cos_weighting=False,
                     sample_scheme="default")
@@ -462,6 +465,63 @@ def performer_core(q, k, v, mask, proj):
 # --------------------------------------------------------------------------------------
 # module-level forwards (x -> y), parameters as a dict keyed like the reference state_dict
 # --------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------
+# ScatterBrain (local windows + low-rank random features under one softmax)
+# --------------------------------------------------------------------------------------
+def scatterbrain_core(q, k, v, mask, attn_2d, seq_shape, window_size, proj, bias=None, scale=None):
+    """ScatterBrain's q,k,v -> out core without window overlap (scatterbrain_attention.py:10-44,
+    71-160).  q,k,v [B,h,N,d] with N covered by whole windows; mask [B,N] bool or None; proj [h,m,d]
+    random features; bias None or [h, Wq, Wk].
+
+    log phi(x)[c] = d^-1/4 <W_c, x> - |x|^2 d^-1/2 / 2 - ln(m) / 2 (-inf for padded keys).  Per window
+    g the m features act as extra softmax columns with logits log phi(q_i)[c] + log(sum over the keys
+    OUTSIDE the window of phi(k_j)[c]) and values the phi-weighted mean of v over those keys."""
+    B, h, n, d = q.shape
+    scale = d ** -0.5 if scale is None else scale
+    m = proj.shape[1]
+    w = window_size
+    if mask is None:
+        mask = torch.zeros(B, n, dtype=torch.bool)
+    mask = mask.bool()
+
+    def log_phi(x):
+        dash = d ** -0.25 * torch.einsum("bhnd,hmd->bhnm", x, proj)
+        return dash - 0.5 * d ** -0.5 * (x * x).sum(-1, keepdim=True) - math.log(m) / 2
+    lq = log_phi(q)
+    lk = log_phi(k).masked_fill(mask[:, None, :, None], float("-inf"))
+    if attn_2d:
+        idx = window_index_2d(seq_shape[0], seq_shape[1], w, 0)
+    else:
+        idx = window_index_1d(n, w, 0)
+    G, Wq = idx.shape
+    flat = idx.reshape(-1)
+    w_q, w_k, w_v = (t[:, :, flat].reshape(B, h, G, Wq, d) for t in (q, k, v))
+    w_lq = lq[:, :, flat].reshape(B, h, G, Wq, m)
+    w_lk = lk[:, :, flat].reshape(B, h, G, Wq, m)
+    # feature sums over all keys minus those of the window, with a shared (detached) stabiliser
+    mx = torch.maximum(lk.amax(dim=-2, keepdim=True).unsqueeze(-3),
+                       w_lk.amax(dim=(-2, -3), keepdim=True)).detach()             # [B,h,1,1,m]
+    pk = torch.exp(lk.unsqueeze(-3) - mx)                                          # [B,h,1,N,m]
+    w_pk = torch.exp(w_lk - mx)                                                    # [B,h,G,Wq,m]
+    num = torch.einsum("bhtnc,bhnd->bhtcd", pk, v) - torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)
+    den = (pk.sum(-2) - w_pk.sum(-2)).unsqueeze(-1).clamp(min=1e-3)
+    kv_stats = num / den                                                           # [B,h,G,m,d]
+    lse_all = torch.logsumexp(lk.unsqueeze(-3), dim=-2, keepdim=True)              # [B,h,1,1,m]
+    lse_win = torch.logsumexp(w_lk, dim=-2, keepdim=True)                          # [B,h,G,1,m]
+    a = torch.maximum(lse_all, lse_win)
+    nonlocal_ = a + ((lse_all - a).exp() - (lse_win - a).exp() + 1e-5).log()       # attn_utils.log_add_exp, mask (1,-1)
+    log_rfa = w_lq + nonlocal_                                                     # [B,h,G,Wq,m]
+    dots = scale * torch.einsum("bhwie,bhwje->bhwij", w_q, w_k)
+    if bias is not None:
+        dots = dots + bias[None, :, None]
+    wmask = mask[:, flat].reshape(B, 1, G, 1, Wq)
+    dots = dots.masked_fill(wmask, float("-inf"))
+    p = torch.softmax(torch.cat([dots, log_rfa], -1), -1)
+    out_w = torch.einsum("bhwij,bhwjd->bhwid", p[..., :Wq], w_v) \
+        + torch.einsum("bhwic,bhwcd->bhwid", p[..., Wq:], kv_stats)
+    return _scatter_windows(out_w, idx, n)
+
+
 def _local_bias(params, args, h, e, scale, Wq=None, Wk=None):
     w = args["window_size"]
     if args.get("use_t5_rpe", False):
@@ -501,6 +561,29 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
         p_drop = float(a["attn_drop"])
         keep = keep_fn((B, h, n, n)) if (training and p_drop > 0) else None
         return _merge_proj(softmax_core(q, k, v, mask, scale, keep, p_drop), params, B, seq_shape, C)
+
+    if attn == "scatterbrain":
+        w = a["window_size"]
+        assert not a["overlap_window"], "the restatement covers ScatterBrain without window overlap"
+        orig_n = int(math.prod(seq_shape))
+        if a["attn_2d"]:
+            n, xs = orig_n, x.reshape(B, orig_n, C)
+        else:
+            n = int(math.ceil(orig_n / w) * w)                   # _process_input: pad x, extend the mask
+            xs = F.pad(x, (0, 0, 0, n - orig_n))
+            pad_mask = torch.zeros(B, n, dtype=torch.bool)
+            pad_mask[:, orig_n:] = True
+            if mask is not None:
+                pad_mask[:, :orig_n] = mask.bool()
+            mask = pad_mask
+            seq_shape = [n]
+        q, k, v = _split_heads(xs, params, h)
+        proj = noise_fn((h, a["approx_attn_dim"], d)).to(x.dtype) if training else params["eval_proj"]
+        bias = _local_bias(params, a, h, 0, scale)
+        out = scatterbrain_core(q, k, v, mask, a["attn_2d"], seq_shape, w, proj, bias, scale)
+        y = F.linear(out.permute(0, 2, 1, 3).reshape((B,) + tuple(seq_shape) + (C,)),
+                     params["proj.weight"], params["proj.bias"])
+        return y if a["attn_2d"] else y[..., :orig_n, :]
 
     if attn == "ra":
         n = int(math.prod(seq_shape))

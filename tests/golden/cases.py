@@ -98,6 +98,13 @@ CASES = {
         attn="ra", x_shape=(2, 50, 128), mask=("tail", [0, 9]), args=dict(dim=128, num_heads=2, num_samples=0)),
     "ra_sampled_1d": dict(  # num_samples = 1: one key index per query (injected draws)
         attn="ra", x_shape=(2, 70, 128), mask=None, args=dict(dim=128, num_heads=2, num_samples=1)),
+    # ---------------- ScatterBrain (scatterbrain_attention.py:46-180), no window overlap --
+    "scatterbrain_1d_mask": dict(  # N = 50 -> padded to 56 (7 windows of 8), pad mask, 1-D rpe table
+        attn="scatterbrain", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True, approx_attn_dim=32)),
+    "scatterbrain_2d": dict(
+        attn="scatterbrain", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_rpe=True, approx_attn_dim=64)),
     # ---------------- local baseline (local_attention.py:25-194) -----------------------
     "local_2d_rpe": dict(
         attn="local", x_shape=(1, 14, 14, 128), mask=None,

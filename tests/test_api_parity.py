@@ -42,9 +42,8 @@ def test_factory_names_and_errors():
     with pytest.raises(NotImplementedError):
         ea.AttentionFactory.build_attention("eva", dict(dim=64, num_heads=2, use_rpe=True, use_t5_rpe=True,
                                                         window_size=4))
-    for name in ("scatterbrain",):
-        with pytest.raises(NotImplementedError):
-            ea.AttentionFactory.build_attention(name, dict(dim=64, num_heads=2))
+    with pytest.raises(NotImplementedError):                     # window overlap is not built for ScatterBrain
+        ea.AttentionFactory.build_attention("scatterbrain", dict(dim=64, num_heads=2, window_size=4, overlap_window=True))
 
 
 DEFAULTS = {
@@ -57,6 +56,8 @@ DEFAULTS = {
     "performer": dict(fp32=False, approx_attn_dim=64, proj_method="favorp", cos_weighting=False,
                       sample_scheme="default"),
     "ra": dict(fp32=False, num_samples=1),
+    "scatterbrain": dict(fp32=False, use_rpe=False, window_size=4, attn_2d=False, overlap_window=False,
+                         approx_attn_dim=64, proj_method="favorp", cos_weighting=False, sample_scheme="default"),
 }
 
 
@@ -92,11 +93,11 @@ def test_remove_argument_and_helpers():
     assert ea.remove_prefix("--enc-x", "--enc-") == "x" and ea.remove_prefix("abc", "zz") == "abc"
 
 
-@pytest.mark.parametrize("attn", ["softmax", "local", "eva", "lara", "performer", "ra"])
+@pytest.mark.parametrize("attn", ["softmax", "local", "eva", "lara", "performer", "ra", "scatterbrain"])
 def test_no_cpu_fallback(attn):
     """A CPU tensor must never be silently computed by something else."""
     args = dict(dim=64, num_heads=2)
-    if attn in ("local", "eva"):
+    if attn in ("local", "eva", "scatterbrain"):
         args.update(window_size=4, num_landmarks=4) if attn == "eva" else args.update(window_size=4)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -36,6 +36,10 @@ CONFIGS = {
                       [0, 410, 0, 17]),
     "cfg5_performer": ("performer", (4, 4096, 512), dict(dim=512, num_heads=8, approx_attn_dim=64, proj_method="favorp"),
                        [0, 410, 0, 17]),
+    "cfg2_scatterbrain": ("scatterbrain", (16, 14, 14, 192), dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True,
+                                                                  approx_attn_dim=64), None),
+    "cfg5_scatterbrain": ("scatterbrain", (2, 1000, 512), dict(dim=512, num_heads=8, window_size=16, attn_2d=False, use_rpe=True,
+                                                               approx_attn_dim=64), [0, 130]),
     # windows larger than one LDS image in backward: query blocks, run one after the other because the
     # windows overlap or the causal key lists do not apply (ea_window_bwd_query_blocks > 1, acc_slices = 1)
     "big_eva_1d_overlap": ("eva", (2, 512, 512), dict(dim=512, num_heads=8, window_size=128, attn_2d=False, use_t5_rpe=True,

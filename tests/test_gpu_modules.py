@@ -5,7 +5,7 @@ import pytest
 import cases
 from gpu_checks import check_module_case
 
-READY = ("eva_", "local_", "lara_", "softmax_", "performer_", "causal_eva_", "ra_")       # variants whose HIP cores have landed
+READY = ("eva_", "local_", "lara_", "softmax_", "performer_", "causal_eva_", "ra_", "scatterbrain_")       # variants whose HIP cores have landed
 
 
 @pytest.mark.gpu
