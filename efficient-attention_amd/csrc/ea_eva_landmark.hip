@@ -136,6 +136,51 @@ __global__ __launch_bounds__(256) void chunk_mean_bwd_kernel(const LmP p, int co
   }
 }
 
+// Overlapping chunks (e > 0): token-centric form of the same update -- a thread owns one 16-B piece of
+// one token, sums dmean / J over the (at most nc per axis) chunks that contain the token and does a
+// single read-modify-write.  One launch instead of one per colour class, one rounding per token.
+template <typename E, int D>
+__global__ __launch_bounds__(256) void chunk_mean_bwd_gather_kernel(const LmP p) {
+  constexpr int CPR = D / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.B * p.H * p.G.N * CPR;
+  if (idx >= total) return;
+  const int c = (int)(idx % CPR);
+  const long row = idx / CPR;
+  const int tok = (int)(row % p.G.N);
+  const int bh = (int)(row / p.G.N), b = bh / p.H, h = bh - b * p.H;
+  if (p.mask && p.mask[(size_t)b * p.G.N + tok]) return;       // masked slots count as zeros in the mean
+  const float inv = 1.f / (float)p.J;
+  float gq[8], gk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gq[i] = gk[i] = 0.f;
+  // chunks cy x cx whose extended range [c r - e, c r + r + e) holds the token coordinate
+  const int ty = p.G.attn2d ? tok / p.G.gw : 0, tx = p.G.attn2d ? tok - ty * p.G.gw : tok;
+  const int per_row = p.G.attn2d ? p.G.gw / p.r : p.L, rows = p.G.attn2d ? p.G.gh / p.r : 1;
+  auto lo = [&](int t) { const int v = t - p.r - p.e; return (v >= 0 ? v / p.r : -1) + 1; };
+  const int cx0 = lo(tx), cx1 = min((tx + p.e) / p.r, per_row - 1);
+  const int cy0 = p.G.attn2d ? lo(ty) : 0, cy1 = p.G.attn2d ? min((ty + p.e) / p.r, rows - 1) : 0;
+  for (int cy = cy0; cy <= cy1; ++cy)
+    for (int cx = cx0; cx <= cx1; ++cx) {
+      const size_t chunk_id = (size_t)bh * p.L + cy * per_row + cx;
+      const float* s1 = p.dqmean + chunk_id * D + c * 8;
+      const float* s2 = p.dkmean + chunk_id * D + c * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { gq[i] += s1[i] * inv; gk[i] += s2[i] * inv; }
+    }
+  float f[8];
+  char* a = p.dq + (b * p.dq_sb + h * p.dq_sh + tok * p.dq_sn + c * 8) * 2;
+  unpack8<E>(ldg16(a), f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] += gq[i];
+  stg16(a, pack8<E>(f));
+  a = p.dk + (b * p.dk_sb + h * p.dk_sh + tok * p.dk_sn + c * 8) * 2;
+  unpack8<E>(ldg16(a), f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] += gk[i];
+  stg16(a, pack8<E>(f));
+}
+
 // ------------------------------------------------------------------------------------------
 // beta forward: online softmax over the chunk's rows per row-group, merged across row-groups.
 template <typename E, int D, int WPC>
@@ -387,10 +432,11 @@ static int launch_lm(int which, const LmP& p, hipStream_t st) {
       else hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D, 1>), grid, block, 0, st, p);
       break;
     case 1:
-      for (int col = 0; col < ncolour; ++col) {
-        if (coop) hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 4>), grid, block, 0, st, p, col, nc);
-        else hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 1>), grid, block, 0, st, p, col, nc);
-      }
+      if (ncolour > 1) {
+        const long pieces = (long)p.B * p.H * p.G.N * (D / 8);
+        hipLaunchKernelGGL((chunk_mean_bwd_gather_kernel<E, D>), dim3((unsigned)((pieces + 255) / 256)), block, 0, st, p);
+      } else if (coop) hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 4>), grid, block, 0, st, p, 0, 1);
+      else hipLaunchKernelGGL((chunk_mean_bwd_kernel<E, D, 1>), grid, block, 0, st, p, 0, 1);
       break;
     case 2:
       if (coop) hipLaunchKernelGGL((beta_fwd_kernel<E, D, 4>), grid, block, 0, st, p);
