@@ -98,11 +98,14 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
             mx = lk.amax(dim=-2, keepdim=True).detach()
             pk = torch.exp(lk - mx)                                                 # [B,h,N,m]
             w_pk, w_v = win(pk), win(v)
-            num = torch.einsum("bhnc,bhnd->bhcd", pk, v).unsqueeze(2) - torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)
-            den = (pk.sum(-2).unsqueeze(2) - w_pk.sum(-2)).unsqueeze(-1).clamp(min=1e-3)
-            kv_stats = num / den                                                    # [B,h,G,m,d]
-            lse_all = torch.logsumexp(lk, dim=-2).unsqueeze(2)                      # [B,h,1,m]
-            lse_win = torch.logsumexp(win(lk), dim=-2)                              # [B,h,G,m]
+            s_win = torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)                   # [B,h,G,m,d]
+            z_win = w_pk.sum(-2)                                                    # [B,h,G,m]
+            # the global sums are the sums of the window sums (windows partition the sequence)
+            s_all, z_all = s_win.sum(2, keepdim=True), z_win.sum(2, keepdim=True)
+            kv_stats = (s_all - s_win) / (z_all - z_win).unsqueeze(-1).clamp(min=1e-3)
+            # log-sum-exp of the log-features from the same sums: log z + stabiliser
+            lse_all = torch.log(z_all) + mx                                         # [B,h,1,m]
+            lse_win = torch.log(z_win) + mx                                         # [B,h,G,m]
             a = torch.maximum(lse_all, lse_win)
             nonlocal_ = a + ((lse_all - a).exp() - (lse_win - a).exp() + 1e-5).log()
             log_rfa = win(lq) + nonlocal_.unsqueeze(-2)                             # [B,h,G,Wq,m]
