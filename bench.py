@@ -265,11 +265,24 @@ def main():
         # gradients are packed into ONE flat fp32 bucket (0.16 M values), all-reduced over RCCL, and
         # applied as plain SGD with the 1/world averaging folded into the step size -- what
         # DistributedDataParallel + optim.SGD compute, without DDP's per-iteration host work
-        # (measured: the DDP wrapper makes this 0.9 ms step host-bound at 1.44 ms).  The all-reduce
-        # sits between two captured hipGraphs, so a step costs three host calls.
+        # (measured: the DDP wrapper makes this 0.9 ms step host-bound at 1.44 ms).
         from efficient_attention.data_parallel import FlatGradBucket
         bucket = FlatGradBucket(params, dev)
         bucket.broadcast_parameters(0)
+
+        # Two equivalent schedules of a step; which one runs is MEASURED below, on every launch:
+        #   pipelined : [update + forward/backward + pack] as ONE captured hipGraph, then the all-reduce
+        #               (the update applies the previous step's summed gradients -- zeros before the
+        #               first step -- so every step still holds one update, one forward/backward and
+        #               one all-reduce: two host calls and one stream hand-over per step);
+        #   three_part: [forward/backward + pack] | all-reduce | [update]  (three calls, two hand-overs).
+        # On a single-rank RCCL group the pipelined form costs 0.83 ms against 0.89 ms; with two
+        # ranks time-slicing ONE device over gloo (the dev configuration) it was 100x slower, so the
+        # choice is not hard-wired.
+        def update_and_pack():
+            bucket.sgd_step(LR)
+            fwd_bwd()
+            bucket.pack()
 
         def pack():
             fwd_bwd()
@@ -280,7 +293,11 @@ def main():
 
         def apply():
             bucket.sgd_step(LR)
-        parts = [pack, reduce, apply]
+        schemes = {"pipelined": [update_and_pack, reduce], "three_part": [pack, reduce, apply]}
+        forced = os.environ.get("EA_BENCH_DDP_SCHEME")
+        if forced:
+            schemes = {forced: schemes[forced]}
+        parts = schemes.get("three_part", list(schemes.values())[0])
 
     def step():
         for f in parts:
@@ -303,20 +320,47 @@ def main():
             fn()
         return gr
 
-    graphed = False
-    run_parts = parts
-    if not a.no_graph:
+    def prepare(fns):
+        """-> (callables of one step, captured?)"""
+        if a.no_graph:
+            return fns, False
         try:
-            run_parts = [f if f.__name__ == "reduce" else capture(f).replay for f in parts]
-            for f in run_parts:
+            out = [f if f.__name__ == "reduce" else capture(f).replay for f in fns]
+            for f in out:
                 f()
             torch.cuda.synchronize()
-            graphed = True
+            return out, True
         except Exception as ex:  # capture is an optimisation, never a requirement
             if rank == 0:
                 print("graph capture unavailable (%s); timing eager" % str(ex).split("\n")[0], file=sys.stderr)
-            run_parts = parts
             torch.cuda.synchronize()
+            return fns, False
+
+    ddp_scheme = None
+    if not ddp:
+        run_parts, graphed = prepare(parts)
+    else:
+        # time a few steps of every schedule (max over ranks, so all ranks take the same decision)
+        best = None
+        for name, fns in schemes.items():
+            rp, gr = prepare(fns)
+            for _ in range(3):
+                for f in rp:
+                    f()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(5):
+                for f in rp:
+                    f()
+            torch.cuda.synchronize()
+            tsel = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tsel, op=dist.ReduceOp.MAX)
+            tsel = float(tsel.item())
+            if best is None or tsel < best[0]:
+                best = (tsel, name, rp, gr)
+        _, ddp_scheme, run_parts, graphed = best
 
     def run():
         for f in run_parts:
@@ -415,7 +459,7 @@ def main():
                                    "bf16 autocast%s" % (a.attn, ",".join(str(v) for v in (B,) + tuple(seq) + (C,)), N, H, d,
                                                         ", data-parallel flat-bucket all-reduce" if ddp else ""),
                        "attn": a.attn, "global_batch": B * world, "seq_len": N, "heads": H, "head_dim": d,
-                       "parallelism": "dp%d" % world, "hipgraph": graphed,
+                       "parallelism": "dp%d" % world, "hipgraph": graphed, "ddp_schedule": ddp_scheme,
                        "gemm_tunableop": tune},
             "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H * d / 64),
             # whole layer priced on the op-level q,k,v -> out traffic (1536*h bytes per token at d = 64)
