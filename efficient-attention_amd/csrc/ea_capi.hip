@@ -20,6 +20,7 @@ int rows_mlp_dispatch(const RowsP& p, int D, int sides, int layer_norm, bool bwd
 int rows_mlp_blocks(int R, int D);
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
+int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
 }
 
 using namespace ea;
@@ -46,7 +47,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 2; }
+int32_t ea_abi_version(void) { return 3; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -343,6 +344,71 @@ int ea_lara_bwd_kstats(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, co
   p.k = mkl(k); p.v = mkl(v); p.mask = mask; p.omega = omega; p.dkv = dkv; p.lse_k = lse_k;
   p.dkk = dkk; p.rsum = rsum; p.p_acc0 = p_dom;
   return lara_y_dispatch(LY_BWDK, p, g->dtype, (hipStream_t)stream);
+}
+
+// ---- fused backward (ea_lara_f.hip): one pass per side + one finish pass ----
+int32_t ea_lara_fused_parts(const ea_lara_geom* g) {
+  LaraP p = {};
+  if (fill_lara(g, p, false) != EA_OK) return EA_E_BADARG;
+  if (p.NCT > 4) return EA_E_UNSUPPORTED;
+  return p.nsplit * (p.NCT <= 2 ? 2 : 1);
+}
+
+int ea_lara_bwd_q_fused(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                        const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                        const float* cst, const ea_t4* dq, float* p_ml, float* p_dkv, float* p_dom,
+                        float* p_m1, float* p_m2, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (p.NCT > 4) return EA_E_UNSUPPORTED;
+  if (!t4_ok(q, g->D) || !t4_ok(dout, g->D) || !t4_ok(dq, g->D) || !omega || !kv || !cst || !p_ml ||
+      !p_dkv || !p_dom) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv || !p_m1 || !p_m2)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  p.q = mkl(q); p.dout = mkl(dout); p.dq = mkl(dq); p.omega = omega; p.qbar = qbar; p.kv = kv;
+  p.lse_t = lse_t; p.bhv = bhv; p.cst = cst;
+  p.p_ml = p_ml; p.p_acc0 = p_dkv; p.p_acc1 = p_dom; p.p_acc2 = p_m1; p.p_acc3 = p_m2;
+  return lara_f_dispatch(0, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_k_fused(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                        const float* rsum, const ea_t4* dk, const ea_t4* dv, float* p_dom, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (p.NCT > 4) return EA_E_UNSUPPORTED;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !omega ||
+      !dkv || !lse_k || !dkk || !rsum || !p_dom) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.dk = mkl(dk); p.dv = mkl(dv); p.mask = mask; p.omega = omega;
+  p.dkv = dkv; p.lse_k = lse_k; p.dkk = dkk; p.rsum = rsum; p.p_acc0 = p_dom;
+  return lara_f_dispatch(1, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_finish(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
+                       const float* lse_t, const float* dpq, const float* dpk, int32_t pool_r,
+                       int32_t gh, int32_t gw, const ea_t4* dq, const ea_t4* dk, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (p.NCT > 4) return EA_E_UNSUPPORTED;
+  if (!t4_ok(dq, g->D)) return EA_E_BADARG;
+  const bool has_t = uq != nullptr;
+  if (has_t && (g->mis != EA_MIS_OPT || !t4_ok(q, g->D) || !qbar || !lse_t)) return EA_E_BADARG;
+  if (pool_r > 0) {
+    if (!dpq || !dpk || !t4_ok(dk, g->D) || gh <= 0 || gw <= 0 || gh * gw != g->N || gh % pool_r || gw % pool_r)
+      return EA_E_BADARG;
+    p.dpq = dpq; p.dpk = dpk; p.pool_r = pool_r; p.pool_gw = gw;
+    p.pool_L = (gh / pool_r) * (gw / pool_r);
+    p.pool_inv = 1.f / (float)(pool_r * pool_r);
+    p.dk = mkl(dk);
+  } else if (!has_t) {
+    return EA_OK;                                   // nothing to do
+  }
+  if (has_t) { p.q = mkl(q); p.qbar = qbar; p.uq = uq; p.lse_t = lse_t; }
+  p.dq = mkl(dq);
+  return lara_f_dispatch(2, p, g->dtype, (hipStream_t)stream);
 }
 
 int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,

@@ -51,6 +51,11 @@ struct LaraP {
   float norm_coef2;             // log2-domain coefficient of |x|^2 in the logits
   float knorm_coef;             // coefficient of x * (sum of logit grads) in dk / dq
   float ratio, feps;
+  // finish pass (ea_lara_f.hip): gradients of the pooled q / k rows, fp32 [BH, pool_L, D], spread back
+  // over the pool_r x pool_r token blocks of a pool_gw-wide grid (pool_r = 0: no pooling term)
+  const float *dpq, *dpk;
+  int pool_r, pool_gw, pool_L;
+  float pool_inv;
   long long* prof;              // dev builds (-DEA_PROFILE): phase time stamps
 };
 

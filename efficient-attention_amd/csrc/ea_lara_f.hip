@@ -1,0 +1,813 @@
+// ea_lara_f.hip -- fused LARA backward passes (lara.py:201-246 differentiated): each token tensor is
+// read ONCE per side.
+//
+//   lara_fq_kernel  (q, dout -> dq, per-landmark sums)   replaces  LX_BWDQ + LY_BWDQ
+//   lara_fk_kernel  (k, v    -> dk, dv, d omega partial)  replaces  LX_BWDK + LY_BWDK
+//   lara_fin_kernel (q, dq, dk -> dq, dk)                 replaces  LX_QCORR + the pooling backward
+//
+// The estimator couples token n and landmark sample c through [C x N] matrices (W, dZ, t dt, t / dB).
+// Their per-token contractions (over c: dq, dk, dv) want the token-column register layout
+// D[c = 4g+r][n = li] -- reductions over c are in-lane + one 4-lane step -- and their per-landmark
+// contractions (over n: d kv_stats, d omega, d q_bar, the scalar sums) want the token-row layout.
+// Round 1 evaluated the elementwise stage twice, once per layout, in two passes over q/dout (k/v).
+// Here it is evaluated once, in the token-column layout; every wave then drops its 16-token slab of
+// the weight matrices (rounded to the MFMA element type, exactly as the token-row pass rounded them)
+// and its token rows into LDS, and after one barrier wave w contracts landmark tile w over the 64
+// tokens of the chunk: the B operand is a ds_read_b64_tr_b16 of the [n][c] weight slab, the A operand
+// a ds_read_b64_tr_b16 of the [n][d] token rows.  The second barrier of a chunk sits right before
+// the next slab is written, so the next chunk's score MFMAs and elementwise stage overlap the
+// slower waves' contraction.  Per-(b,h) partial results leave in the layout the token-row pass
+// used (ea_lara_merge_bwd is unchanged).
+//
+// The transposed landmark matrices of the contraction over c are ds_read_b64_tr_b16 reads of the
+// row-major staging (no second, transposed copy in LDS): 73 KB per workgroup at C <= 64, d = 64,
+// two workgroups per CU.
+#include "ea_lara.h"
+
+namespace ea {
+
+// byte offset of element (row, c) of a bf16/fp16 LDS tile [rows][W] whose 16-byte chunks are
+// XOR-swizzled by the row (same scheme as the token tiles, lds_off<>)
+template <int W> EA_DEV int wt_off(int row, int c) { return lds_off<W>(row, c >> 3) + ((c & 7) << 1); }
+
+// all global loads of up to three [C][D] fp32 landmark matrices in flight, then convert + store as
+// swizzled element-type rows (zero rows beyond C)
+template <typename E, int D, int Cp>
+EA_DEV void stage_rows3(char* const dst[3], const float* const src[3], int C, int tid) {
+  constexpr int CPRs = D / 8;
+  constexpr int SL = (Cp * CPRs + 255) / 256;
+  float4 rb[3][SL][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int idx = tid + sl * 256;
+      const int row = idx / CPRs, c = idx - row * CPRs;
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (src[j] && idx < Cp * CPRs && row < C) {
+        lo = *reinterpret_cast<const float4*>(src[j] + (size_t)row * D + c * 8);
+        hi = *reinterpret_cast<const float4*>(src[j] + (size_t)row * D + c * 8 + 4);
+      }
+      rb[j][sl][0] = lo; rb[j][sl][1] = hi;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int idx = tid + sl * 256;
+      const int row = idx / CPRs, c = idx - row * CPRs;
+      if (!src[j] || idx >= Cp * CPRs) continue;
+      const float4 lo = rb[j][sl][0], hi = rb[j][sl][1];
+      const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      sts16(dst[j] + lds_off<D>(row, c), pack8<E>(f));
+    }
+  }
+}
+
+template <typename E> EA_DEV typename E::x8 ones_x8() {
+  const uint32_t o = (uint32_t)E::from_f(1.f) * 0x00010001u;
+  return as_x8<E>(u32x4{o, o, o, o});
+}
+
+// ------------------------------------------------------------------------------------------
+// query side
+// ------------------------------------------------------------------------------------------
+template <typename E, int D, int NCT>
+__global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
+  constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int Cp = NCT * 16, ROWW = Cp * 2, NSUB = 4 / NCT;
+  constexpr int WSW = (Cp / 8) >= 8 ? 7 : (Cp / 8) - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R1 = smem;                                  // omega rows
+  char* R2 = R1 + Cp * ROWB;                        // qbar rows
+  char* R3 = R2 + Cp * ROWB;                        // kv rows
+  char* TQ = R3 + Cp * ROWB;                        // q rows of the chunk   [64][D]
+  char* TD = TQ + 64 * ROWB;                        // dout rows of the chunk
+  char* WT = TD + 64 * ROWB;                        // weight slabs [4][64][Cp]: W, dZ, t dt, t
+  float* SC0 = reinterpret_cast<float*>(WT + 4 * 64 * ROWW);
+  float* SC1 = SC0 + Cp;
+  float* SC2 = SC1 + Cp;
+  float* DB = SC2 + Cp;                             // [4][Cp] per-wave sums of d alpha
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nbh = p.B * p.H;
+  const int blk = blockIdx.x / nbh, bh = blockIdx.x - blk * nbh;      // slice-major (see lara_f_plan)
+  const int b = bh / p.H, h = bh - b * p.H;
+  const size_t lm = (size_t)bh * p.C;
+  const bool opt = p.mis == MIS_OPT;
+  const bool use_t = p.mis != MIS_BH;
+  const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
+  const char* dob = p.dout.p + (b * p.dout.sb + h * p.dout.sh) * 2;
+  const float invC = 1.f / (float)p.C;
+  const int n0 = p.nsplit == 2 ? p.tok_begin[blk] : blk * p.tok_per_block;
+  const int n1 = p.nsplit == 2 ? p.tok_begin[blk + 1] : min(p.N, n0 + p.tok_per_block);
+  const int last_tok = n1 - 1;
+
+  EA_BLK(p, 0);
+  u32x4 nx1[KS], nx2[KS];
+  auto issue = [&](int cb_) {
+    const int tok_ = min(cb_ + wave * 16 + li, last_tok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(qb + (tok_ * p.q.sn + eo) * 2);
+      nx2[ks] = ldg16(dob + (tok_ * p.dout.sn + eo) * 2);
+    }
+  };
+  issue(n0);
+  float sc_v0 = -INFINITY, sc_v1 = INFINITY, sc_v2 = 1.f;
+  if (tid < p.C) {
+    sc_v0 = p.cst[lm + tid] * LOG2E;
+    if (opt) { sc_v2 = p.bhv[lm + tid]; sc_v1 = p.lse_t[lm + tid] * LOG2E; }
+  }
+  {
+    char* const dst[3] = {R1, R2, R3};
+    const float* const src[3] = {p.omega + lm * D, use_t ? p.qbar + lm * D : nullptr, p.kv + lm * D};
+    stage_rows3<E, D, Cp>(dst, src, p.C, tid);
+  }
+  if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
+  LaneOff<D> lo;
+  lo.init(lane);
+  // tr-read offset into a weight slab: rows 4g + (li >> 2), column segment 4 (li & 3) of a landmark tile
+  const int wr = 4 * g + (li >> 2);
+  const int yct = wave % NCT, ysub = wave / NCT;       // token-row phase: landmark tile / 32-token half
+  const bool ywave = wave < NCT * NSUB;
+  int wtr;
+  {
+    const int colb = (16 * yct + 4 * (li & 3)) * 2;
+    wtr = wr * ROWW + ((((colb >> 4)) ^ (wr & WSW)) << 4) + (colb & 15);
+  }
+  f32x4 acc0[DT], acc1[DT], acc2[DT], acc3[DT], accR = {0.f, 0.f, 0.f, 0.f}, accU = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc0[dt] = acc1[dt] = acc2[dt] = acc3[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 sdbh[NCT][2];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) sdbh[ct][0] = sdbh[ct][1] = f32x2{0.f, 0.f};
+  const typename E::x8 ones = ones_x8<E>();
+  __syncthreads();
+
+  for (int cb = n0; cb < n1; cb += 64) {
+    const int tok = cb + wave * 16 + li;
+    const bool valid = tok < n1;
+    typename E::x8 f1[KS], f2[KS];
+    u32x4 raw1[KS], raw2[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      raw1[ks] = nx1[ks]; raw2[ks] = nx2[ks];
+      f1[ks] = as_x8<E>(nx1[ks]);
+      f2[ks] = as_x8<E>(nx2[ks]);
+    }
+    issue(cb + 64);
+    // ---- score tiles: A = s omega.q, T = s qbar.q, dW = kv.dout  (D[c = 4g+r][n = li]) ----
+    f32x4 a[NCT], tt[NCT], dw[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      a[ct] = tt[ct] = dw[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = ct * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
+        if (use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt[ct]);
+        dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+      }
+    }
+    // ---- elementwise stage (same algebra as LX_BWDQ, ea_lara_x.hip) ----
+    const float s2 = p.scale_log2;
+    const f32x2 s22 = {s2, s2};
+    f32x2 tv[NCT][2], ez[NCT][2], wv[NCT][2];
+    f32x2 tl2 = {0.f, 0.f};
+    if (opt) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const float4 ls = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
+        const f32x2 x0 = f32x2{tt[ct][0], tt[ct][1]} * s22 - f32x2{ls.x, ls.y};
+        const f32x2 x1 = f32x2{tt[ct][2], tt[ct][3]} * s22 - f32x2{ls.z, ls.w};
+        tv[ct][0] = f32x2{fast_exp2(x0[0]), fast_exp2(x0[1])};
+        tv[ct][1] = f32x2{fast_exp2(x1[0]), fast_exp2(x1[1])};
+        tl2 += tv[ct][0] + tv[ct][1];
+      }
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) tv[ct][0] = tv[ct][1] = f32x2{0.f, 0.f};
+    }
+    const float tmean = quad_sum(tl2[0] + tl2[1]) * invC;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 cs = *reinterpret_cast<const float4*>(SC0 + ct * 16 + 4 * g);
+      f32x2 z0 = f32x2{a[ct][0], a[ct][1]} * s22 + f32x2{cs.x, cs.y};
+      f32x2 z1 = f32x2{a[ct][2], a[ct][3]} * s22 + f32x2{cs.z, cs.w};
+      if (p.mis == MIS_BIASED) {
+        z0 += f32x2{tt[ct][0], tt[ct][1]} * s22;
+        z1 += f32x2{tt[ct][2], tt[ct][3]} * s22;
+      }
+      ez[ct][0] = z0; ez[ct][1] = z1;
+      mx = fmaxf(fmaxf(mx, fmaxf(z0[0], z0[1])), fmaxf(z1[0], z1[1]));
+    }
+    mx = quad_max(mx);
+    const f32x2 mx2 = {mx, mx};
+    f32x2 ss2 = {0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2 x = ez[ct][hh] - mx2;
+        ez[ct][hh] = f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
+      }
+      if (opt) {
+        const float4 bv = *reinterpret_cast<const float4*>(SC2 + ct * 16 + 4 * g);
+        const float kt = -p.kappa * tmean;
+        const f32x2 kap = {p.kappa, p.kappa};
+        const f32x2 a0 = kap * tv[ct][0] + f32x2{bv.x + kt, bv.y + kt};
+        const f32x2 a1 = kap * tv[ct][1] + f32x2{bv.z + kt, bv.w + kt};
+        wv[ct][0] = ez[ct][0] * f32x2{fmaxf(a0[0], 1e-8f), fmaxf(a0[1], 1e-8f)};
+        wv[ct][1] = ez[ct][1] * f32x2{fmaxf(a1[0], 1e-8f), fmaxf(a1[1], 1e-8f)};
+        ez[ct][0] = f32x2{a0[0] > 1e-8f ? ez[ct][0][0] : 0.f, a0[1] > 1e-8f ? ez[ct][0][1] : 0.f};
+        ez[ct][1] = f32x2{a1[0] > 1e-8f ? ez[ct][1][0] : 0.f, a1[1] > 1e-8f ? ez[ct][1][1] : 0.f};
+      } else {
+        wv[ct][0] = ez[ct][0];
+        wv[ct][1] = ez[ct][1];
+      }
+      ss2 += wv[ct][0] + wv[ct][1];
+    }
+    const float ssum = quad_sum(ss2[0] + ss2[1]);
+    // tokens beyond the block contribute nothing to the per-landmark sums: W = dZ = d alpha = 0
+    const float inv = valid ? fast_rcp(ssum) : 0.f;
+    const f32x2 inv2 = {inv, inv};
+    f32x2 rd2 = {0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      wv[ct][0] *= inv2; wv[ct][1] *= inv2;                               // W
+      rd2 += wv[ct][0] * f32x2{dw[ct][0], dw[ct][1]} + wv[ct][1] * f32x2{dw[ct][2], dw[ct][3]};
+    }
+    const float rd = quad_sum(rd2[0] + rd2[1]);                            // = dout_n . out_n
+    const f32x2 rdv = {rd, rd};
+    f32x2 sda2 = {0.f, 0.f};
+    f32x2 da[NCT][2];
+    // W and dZ are rounded to the element type as soon as they exist (the contraction over c and the
+    // slabs both take them in that form): half the registers from here on
+    u32x2 Wp[NCT], dZp[NCT], tdp[NCT], tp[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x2 dz[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x2 dd = f32x2{dw[ct][2 * hh], dw[ct][2 * hh + 1]} - rdv;  // dW - rd
+        dz[hh] = wv[ct][hh] * dd;
+        if (opt) {
+          da[ct][hh] = ez[ct][hh] * inv2 * dd;                             // dZ / alpha
+          sda2 += da[ct][hh];
+          sdbh[ct][hh] += da[ct][hh];
+        }
+      }
+      Wp[ct] = u32x2{pack2<E>(wv[ct][0][0], wv[ct][0][1]), pack2<E>(wv[ct][1][0], wv[ct][1][1])};
+      dZp[ct] = u32x2{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[1][0], dz[1][1])};
+    }
+    const float sda = quad_sum(sda2[0] + sda2[1]);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (opt) {
+        const float m = sda * invC;
+        const f32x2 kap = {p.kappa, p.kappa};
+        const f32x2 t0 = tv[ct][0] * kap * (da[ct][0] - f32x2{m, m});      // t * dt
+        const f32x2 t1 = tv[ct][1] * kap * (da[ct][1] - f32x2{m, m});
+        tdp[ct] = u32x2{pack2<E>(t0[0], t0[1]), pack2<E>(t1[0], t1[1])};
+        tp[ct] = u32x2{pack2<E>(tv[ct][0][0], tv[ct][0][1]), pack2<E>(tv[ct][1][0], tv[ct][1][1])};
+      } else {
+        tdp[ct] = dZp[ct];                                                 // mis-biased: dT = dZ
+        tp[ct] = u32x2{0u, 0u};
+      }
+    }
+    // ---- contraction over c: dq^T[d][n] = omega^T . dZ (+ qbar^T . t dt) ----
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NCT / 2; ++kk) {
+      const u32x4 p1 = {dZp[2 * kk][0], dZp[2 * kk][1], dZp[2 * kk + 1][0], dZp[2 * kk + 1][1]};
+      const u32x4 p2 = {tdp[2 * kk][0], tdp[2 * kk][1], tdp[2 * kk + 1][0], tdp[2 * kk + 1][1]};
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* r1 = R1 + (32 * kk) * ROWB + lo.tr[dt];
+        acc[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * ROWB)), as_x8<E>(p1), acc[dt]);
+        if (use_t) {
+          const char* r2 = R2 + (32 * kk) * ROWB + lo.tr[dt];
+          acc[dt] = E::mma(as_x8<E>(E::tr4(r2), E::tr4(r2 + 16 * ROWB)), as_x8<E>(p2), acc[dt]);
+        }
+      }
+    }
+    if (valid) {
+      float f[DQ];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
+      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    }
+    // ---- hand the slab to the token-row phase ----
+    __syncthreads();                        // the previous chunk's readers are done
+    {
+      const int row = wave * 16 + li;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sts16(TQ + lds_off<D>(row, g * KS + ks), valid ? raw1[ks] : z);
+        sts16(TD + lds_off<D>(row, g * KS + ks), valid ? raw2[ks] : z);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int o = wt_off<Cp>(row, 16 * ct + 4 * g);
+        *reinterpret_cast<u32x2*>(WT + o) = Wp[ct];
+        *reinterpret_cast<u32x2*>(WT + 64 * ROWW + o) = dZp[ct];
+        if (opt) {
+          *reinterpret_cast<u32x2*>(WT + 2 * 64 * ROWW + o) = tdp[ct];
+          *reinterpret_cast<u32x2*>(WT + 3 * 64 * ROWW + o) = tp[ct];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- token-row phase: landmark tile yct over the chunk's tokens ----
+    if (ywave) {
+#pragma unroll
+      for (int kq = 0; kq < 2 / NSUB; ++kq) {
+        const int kb = (NSUB == 1 ? kq : ysub) * 32;
+        const char* w0 = WT + kb * ROWW + wtr;
+        const typename E::x8 b0 = as_x8<E>(E::tr4(w0), E::tr4(w0 + 16 * ROWW));
+        const typename E::x8 b1 = as_x8<E>(E::tr4(w0 + 64 * ROWW), E::tr4(w0 + 64 * ROWW + 16 * ROWW));
+        typename E::x8 b2 = b1, b3 = b1;
+        if (opt) {
+          b2 = as_x8<E>(E::tr4(w0 + 2 * 64 * ROWW), E::tr4(w0 + 2 * 64 * ROWW + 16 * ROWW));
+          b3 = as_x8<E>(E::tr4(w0 + 3 * 64 * ROWW), E::tr4(w0 + 3 * 64 * ROWW + 16 * ROWW));
+        }
+        accR = E::mma(ones, b1, accR);
+        if (opt) accU = E::mma(ones, b2, accU);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* td = TD + kb * ROWB + lo.tr[dt];
+          const char* tq = TQ + kb * ROWB + lo.tr[dt];
+          const typename E::x8 ado = as_x8<E>(E::tr4(td), E::tr4(td + 16 * ROWB));
+          const typename E::x8 aq = as_x8<E>(E::tr4(tq), E::tr4(tq + 16 * ROWB));
+          acc0[dt] = E::mma(ado, b0, acc0[dt]);           // d kv_stats
+          acc1[dt] = E::mma(aq, b1, acc1[dt]);            // sum dZ q
+          if (opt) {
+            acc2[dt] = E::mma(aq, b2, acc2[dt]);          // sum t dt q
+            acc3[dt] = E::mma(aq, b3, acc3[dt]);          // sum t q
+          }
+        }
+      }
+    }
+  }
+  // ---- per-landmark sums of d alpha: over the 16 token lanes, then over the four waves ----
+  if (opt) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float v = sdbh[ct][hh][e];
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (li == 0) DB[wave * Cp + 16 * ct + 4 * g + 2 * hh + e] = v;
+        }
+  }
+  __syncthreads();
+  const int c = yct * 16 + li;
+  if (!ywave || c >= p.C) { EA_BLK(p, 1); return; }
+  const int S = p.nsplit * NSUB;
+  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub) * p.C + c;
+  if (g == 0) {
+    float* ml = p.p_ml + slot * 4;
+    float dbh = 0.f;
+    if (opt && ysub == 0) dbh = DB[c] + DB[Cp + c] + DB[2 * Cp + c] + DB[3 * Cp + c];
+    ml[0] = accR[0]; ml[1] = dbh; ml[2] = accU[0]; ml[3] = 0.f;
+  }
+  auto put = [&](float* base, const f32x4* av) {
+    float* d = base + slot * D + DQ * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
+  };
+  put(p.p_acc0, acc0);
+  put(p.p_acc1, acc1);
+  if (opt) { put(p.p_acc2, acc2); put(p.p_acc3, acc3); }
+  EA_BLK(p, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// key side
+// ------------------------------------------------------------------------------------------
+template <typename E, int D, int NCT>
+__global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
+  constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int Cp = NCT * 16, ROWW = Cp * 2, NSUB = 4 / NCT;
+  constexpr int WSW = (Cp / 8) >= 8 ? 7 : (Cp / 8) - 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R1 = smem;                                  // omega rows
+  char* R3 = R1 + Cp * ROWB;                        // d kv_stats rows
+  char* TK = R3 + Cp * ROWB;                        // k rows of the chunk [64][D]
+  char* WT = TK + 64 * ROWB;                        // dB slab [64][Cp]
+  float* SC0 = reinterpret_cast<float*>(WT + 64 * ROWW);
+  float* SC1 = SC0 + Cp;
+  float* SC2 = SC1 + Cp;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nbh = p.B * p.H;
+  const int blk = blockIdx.x / nbh, bh = blockIdx.x - blk * nbh;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const size_t lm = (size_t)bh * p.C;
+  const char* kb_ = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
+  const char* vb_ = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
+  const int n0 = p.nsplit == 2 ? p.tok_begin[blk] : blk * p.tok_per_block;
+  const int n1 = p.nsplit == 2 ? p.tok_begin[blk + 1] : min(p.N, n0 + p.tok_per_block);
+  const int last_tok = n1 - 1;
+
+  EA_BLK(p, 0);
+  u32x4 nx1[KS], nx2[KS];
+  auto issue = [&](int cb_) {
+    const int tok_ = min(cb_ + wave * 16 + li, last_tok);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(kb_ + (tok_ * p.k.sn + eo) * 2);
+      nx2[ks] = ldg16(vb_ + (tok_ * p.v.sn + eo) * 2);
+    }
+  };
+  issue(n0);
+  float sc_v0 = INFINITY, sc_v1 = 0.f, sc_v2 = 0.f;
+  if (tid < p.C) { sc_v0 = p.lse_k[lm + tid] * LOG2E; sc_v1 = p.dkk[lm + tid]; sc_v2 = p.rsum[lm + tid]; }
+  {
+    char* const dst[3] = {R1, nullptr, R3};
+    const float* const src[3] = {p.omega + lm * D, nullptr, p.dkv + lm * D};
+    stage_rows3<E, D, Cp>(dst, src, p.C, tid);
+  }
+  if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
+  LaneOff<D> lo;
+  lo.init(lane);
+  const int wr = 4 * g + (li >> 2);
+  const int yct = wave % NCT, ysub = wave / NCT;
+  const bool ywave = wave < NCT * NSUB;
+  int wtr;
+  {
+    const int colb = (16 * yct + 4 * (li & 3)) * 2;
+    wtr = wr * ROWW + ((((colb >> 4)) ^ (wr & WSW)) << 4) + (colb & 15);
+  }
+  f32x4 acc0[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc0[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int cb = n0; cb < n1; cb += 64) {
+    const int tok = cb + wave * 16 + li;
+    const bool valid = tok < n1;
+    typename E::x8 f1[KS], f2[KS];
+    u32x4 raw1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      raw1[ks] = nx1[ks];
+      f1[ks] = as_x8<E>(nx1[ks]);
+      f2[ks] = as_x8<E>(nx2[ks]);
+    }
+    issue(cb + 64);
+    f32x4 a[NCT], dw[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      a[ct] = dw[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = ct * 16 + li;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
+        dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+      }
+    }
+    float nrm = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float kf[8];
+      unpack8<E>(raw1[ks], kf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) nrm += kf[i] * kf[i];
+    }
+    nrm = quad_sum(nrm);
+    const bool dead = !valid || (p.mask && p.mask[(size_t)b * p.N + (valid ? tok : 0)]);
+    float w1[NCT][4], w2[NCT][4];
+    float sdb = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float4 lk = *reinterpret_cast<const float4*>(SC0 + ct * 16 + 4 * g);
+      const float4 dk4 = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
+      const float4 rs4 = *reinterpret_cast<const float4*>(SC2 + ct * 16 + 4 * g);
+      const float lkv[4] = {lk.x, lk.y, lk.z, lk.w}, dkv4[4] = {dk4.x, dk4.y, dk4.z, dk4.w}, rsv[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bk2 = a[ct][r] * p.scale_log2 - 0.5f * p.scale_log2 * nrm;
+        const float pk = dead ? 0.f : fast_exp2(bk2 - lkv[r]);
+        const float db = pk * (dw[ct][r] - dkv4[r] + rsv[r]);
+        w1[ct][r] = pk;
+        w2[ct][r] = db;
+        sdb += db;
+      }
+    }
+    sdb = quad_sum(sdb);
+    // ---- contraction over c: dv^T = dkv^T . Pk,  dk^T = omega^T . dB ----
+    f32x4 acc[DT], acc2[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = acc2[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NCT / 2; ++kk) {
+      u32x4 p1, p2;
+      p1[0] = pack2<E>(w1[2 * kk][0], w1[2 * kk][1]); p1[1] = pack2<E>(w1[2 * kk][2], w1[2 * kk][3]);
+      p1[2] = pack2<E>(w1[2 * kk + 1][0], w1[2 * kk + 1][1]); p1[3] = pack2<E>(w1[2 * kk + 1][2], w1[2 * kk + 1][3]);
+      p2[0] = pack2<E>(w2[2 * kk][0], w2[2 * kk][1]); p2[1] = pack2<E>(w2[2 * kk][2], w2[2 * kk][3]);
+      p2[2] = pack2<E>(w2[2 * kk + 1][0], w2[2 * kk + 1][1]); p2[3] = pack2<E>(w2[2 * kk + 1][2], w2[2 * kk + 1][3]);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* r3 = R3 + (32 * kk) * ROWB + lo.tr[dt];
+        const char* r1 = R1 + (32 * kk) * ROWB + lo.tr[dt];
+        acc[dt] = E::mma(as_x8<E>(E::tr4(r3), E::tr4(r3 + 16 * ROWB)), as_x8<E>(p1), acc[dt]);
+        acc2[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * ROWB)), as_x8<E>(p2), acc2[dt]);
+      }
+    }
+    if (valid) {
+      float f[DQ];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
+      char* dstv = p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
+      // dk: the lane's B-fragment chunks of k hold channels 8 (g KS + ks) ..; its D rows hold DQ g + ..
+      // -> the k factor is applied in the D layout through the packed store below
+      char* dstk = p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + DQ * g) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float kf[8], o8[8];
+        unpack8<E>(raw1[ks], kf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = 8 * ks + i;
+          o8[i] = p.scale * acc2[j >> 2][j & 3] - p.knorm_coef * kf[i] * sdb;
+        }
+        stg16(dstk + ks * 16, pack8<E>(o8));
+      }
+    }
+    __syncthreads();
+    {
+      const int row = wave * 16 + li;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) sts16(TK + lds_off<D>(row, g * KS + ks), valid ? raw1[ks] : z);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        *reinterpret_cast<u32x2*>(WT + wt_off<Cp>(row, 16 * ct + 4 * g)) =
+            u32x2{pack2<E>(w2[ct][0], w2[ct][1]), pack2<E>(w2[ct][2], w2[ct][3])};
+    }
+    __syncthreads();
+    if (ywave) {
+#pragma unroll
+      for (int kq = 0; kq < 2 / NSUB; ++kq) {
+        const int kb = (NSUB == 1 ? kq : ysub) * 32;
+        const char* w0 = WT + kb * ROWW + wtr;
+        const typename E::x8 b0 = as_x8<E>(E::tr4(w0), E::tr4(w0 + 16 * ROWW));
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* tk = TK + kb * ROWB + lo.tr[dt];
+          acc0[dt] = E::mma(as_x8<E>(E::tr4(tk), E::tr4(tk + 16 * ROWB)), b0, acc0[dt]);     // sum dB k
+        }
+      }
+    }
+  }
+  const int c = yct * 16 + li;
+  if (!ywave || c >= p.C) { EA_BLK(p, 1); return; }
+  const int S = p.nsplit * NSUB;
+  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub) * p.C + c;
+  float* d = p.p_acc0 + slot * D + DQ * g;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(acc0[dt][0], acc0[dt][1], acc0[dt][2], acc0[dt][3]);
+  EA_BLK(p, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// finish: dq -= s sum_c t[c,n] (u_c qbar_c)  (the softmax-over-sequence correction of t, lara.py:223)
+//         dq += d(pooled q)[chunk(n)] / r^2,  dk += d(pooled k)[chunk(n)] / r^2   (lara.py:43,48,145-151)
+// ------------------------------------------------------------------------------------------
+template <typename E, int D, int NCT>
+__global__ __launch_bounds__(256, 3) void lara_fin_kernel(const LaraP p) {
+  constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
+  constexpr int Cp = NCT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* R1 = smem;                                  // (u qbar) rows
+  char* R2 = R1 + Cp * ROWB;                        // qbar rows
+  float* SC1 = reinterpret_cast<float*>(R2 + Cp * ROWB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nbh = p.B * p.H;
+  const int blk = blockIdx.x / nbh, bh = blockIdx.x - blk * nbh;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const size_t lm = (size_t)bh * p.C;
+  const bool has_t = p.uq != nullptr;
+  const bool pool = p.pool_r > 0;
+  const char* qb = p.q.p ? p.q.p + (b * p.q.sb + h * p.q.sh) * 2 : nullptr;
+  char* dqb = p.dq.p + (b * p.dq.sb + h * p.dq.sh) * 2;
+  char* dkb = p.dk.p ? p.dk.p + (b * p.dk.sb + h * p.dk.sh) * 2 : nullptr;
+  const int n0 = p.nsplit == 2 ? p.tok_begin[blk] : blk * p.tok_per_block;
+  const int n1 = p.nsplit == 2 ? p.tok_begin[blk + 1] : min(p.N, n0 + p.tok_per_block);
+  const int last_tok = n1 - 1;
+  const int cpr = pool ? p.pool_gw / p.pool_r : 1;  // chunks per grid row
+
+  u32x4 nx1[KS], nq[DQ / 8], nk[DQ / 8];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) nx1[ks] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int c = 0; c < DQ / 8; ++c) nk[c] = u32x4{0u, 0u, 0u, 0u};
+  auto issue = [&](int tile_) {
+    const int tok_ = min(n0 + tile_ * 16 + li, last_tok);
+    if (has_t) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) nx1[ks] = ldg16(qb + (tok_ * p.q.sn + (g * KS + ks) * 8) * 2);
+    }
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) {
+      nq[c] = ldg16(dqb + (tok_ * p.dq.sn + DQ * g + 8 * c) * 2);
+      if (pool) nk[c] = ldg16(dkb + (tok_ * p.dk.sn + DQ * g + 8 * c) * 2);
+    }
+  };
+  if (n0 + wave * 16 < n1) issue(wave);
+  float sc_v1 = INFINITY;
+  if (has_t && tid < p.C) sc_v1 = p.lse_t[lm + tid] * LOG2E;
+  if (has_t) {
+    char* const dst[3] = {R1, R2, nullptr};
+    const float* const src[3] = {p.uq + lm * D, p.qbar + lm * D, nullptr};
+    stage_rows3<E, D, Cp>(dst, src, p.C, tid);
+  }
+  if (tid < Cp) SC1[tid] = sc_v1;
+  LaneOff<D> lo;
+  lo.init(lane);
+  __syncthreads();
+
+  for (int tile = wave; n0 + tile * 16 < n1; tile += 4) {
+    const int tok = n0 + tile * 16 + li;
+    const bool valid = tok < n1;
+    typename E::x8 f1[KS];
+    u32x4 oq[DQ / 8], ok[DQ / 8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) f1[ks] = as_x8<E>(nx1[ks]);
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) { oq[c] = nq[c]; ok[c] = nk[c]; }
+    issue(tile + 4);
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_t) {
+      float w1[NCT][4];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+        const int row = ct * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) tt = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt);
+        const float4 ls = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
+        w1[ct][0] = fast_exp2(tt[0] * p.scale_log2 - ls.x); w1[ct][1] = fast_exp2(tt[1] * p.scale_log2 - ls.y);
+        w1[ct][2] = fast_exp2(tt[2] * p.scale_log2 - ls.z); w1[ct][3] = fast_exp2(tt[3] * p.scale_log2 - ls.w);
+      }
+#pragma unroll
+      for (int kk = 0; kk < NCT / 2; ++kk) {
+        u32x4 p1;
+        p1[0] = pack2<E>(w1[2 * kk][0], w1[2 * kk][1]); p1[1] = pack2<E>(w1[2 * kk][2], w1[2 * kk][3]);
+        p1[2] = pack2<E>(w1[2 * kk + 1][0], w1[2 * kk + 1][1]); p1[3] = pack2<E>(w1[2 * kk + 1][2], w1[2 * kk + 1][3]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const char* r1 = R1 + (32 * kk) * ROWB + lo.tr[dt];
+          acc[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * ROWB)), as_x8<E>(p1), acc[dt]);
+        }
+      }
+    }
+    if (!valid) continue;
+    int chunk = 0;
+    if (pool) {
+      const int y = tok / p.pool_gw, x = tok - y * p.pool_gw;
+      chunk = (y / p.pool_r) * cpr + x / p.pool_r;
+    }
+    const float* pq = pool ? p.dpq + ((size_t)bh * p.pool_L + chunk) * D + DQ * g : nullptr;
+    const float* pk = pool ? p.dpk + ((size_t)bh * p.pool_L + chunk) * D + DQ * g : nullptr;
+#pragma unroll
+    for (int c = 0; c < DQ / 8; ++c) {
+      float old[8];
+      unpack8<E>(oq[c], old);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = 8 * c + i;
+        old[i] -= acc[j >> 2][j & 3] * p.scale;
+      }
+      if (pool) {
+        const float4 a0 = *reinterpret_cast<const float4*>(pq + 8 * c), a1 = *reinterpret_cast<const float4*>(pq + 8 * c + 4);
+        old[0] += a0.x * p.pool_inv; old[1] += a0.y * p.pool_inv; old[2] += a0.z * p.pool_inv; old[3] += a0.w * p.pool_inv;
+        old[4] += a1.x * p.pool_inv; old[5] += a1.y * p.pool_inv; old[6] += a1.z * p.pool_inv; old[7] += a1.w * p.pool_inv;
+      }
+      stg16(dqb + (tok * p.dq.sn + DQ * g + 8 * c) * 2, pack8<E>(old));
+      if (pool) {
+        float kk8[8];
+        unpack8<E>(ok[c], kk8);
+        const float4 b0 = *reinterpret_cast<const float4*>(pk + 8 * c), b1 = *reinterpret_cast<const float4*>(pk + 8 * c + 4);
+        kk8[0] += b0.x * p.pool_inv; kk8[1] += b0.y * p.pool_inv; kk8[2] += b0.z * p.pool_inv; kk8[3] += b0.w * p.pool_inv;
+        kk8[4] += b1.x * p.pool_inv; kk8[5] += b1.y * p.pool_inv; kk8[6] += b1.z * p.pool_inv; kk8[7] += b1.w * p.pool_inv;
+        stg16(dkb + (tok * p.dk.sn + DQ * g + 8 * c) * 2, pack8<E>(kk8));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+size_t lara_f_lds(int which, int D, int Cp) {
+  if (which == 0) return (size_t)3 * Cp * D * 2 + (size_t)2 * 64 * D * 2 + (size_t)4 * 64 * Cp * 2 + (size_t)7 * Cp * sizeof(float);
+  if (which == 1) return (size_t)2 * Cp * D * 2 + (size_t)64 * D * 2 + (size_t)64 * Cp * 2 + (size_t)3 * Cp * sizeof(float);
+  return (size_t)2 * Cp * D * 2 + (size_t)Cp * sizeof(float);
+}
+
+// Two slices per (b,h): equal halves unless the 2 BH workgroups do not fit on the chip at once
+// (BH < slots < 2 BH) -- then the second "round" would run on a mostly idle chip.  With slice-major
+// dispatch the BH first slices start next to slots - BH second slices and the remaining second slices
+// follow in rb = ceil(BH / (slots - BH)) rounds, so first : second = rb : 1 keeps every slot busy to
+// the end (B*h = 384 on 256 CUs x 2 workgroups: 592 + 192 tokens instead of 448 + 336).
+static void lara_f_plan(LaraP& p, int slots) {
+  if (p.nsplit != 2) return;
+  const int BH = p.B * p.H, gran = 64;
+  p.tok_begin[0] = 0; p.tok_begin[1] = p.tok_per_block < p.N ? p.tok_per_block : p.N; p.tok_begin[2] = p.N;
+  if (BH < slots && slots < 2 * BH) {
+    const int rb = (BH + (slots - BH) - 1) / (slots - BH);
+    const int F = 96;                       // fixed prologue / epilogue of a workgroup, in token-times
+    int b = ((p.N - (rb - 1) * F) / (1 + rb) + gran / 2) / gran * gran;
+    if (b >= gran && b < p.N) p.tok_begin[1] = p.N - b;
+  }
+}
+
+static int f_device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename K>
+static int f_occupancy(K kern, size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || n <= 0) n = 2;
+  return n;
+}
+
+template <typename E, int D, int NCT>
+static int launch_f(int which, LaraP& p, hipStream_t st) {
+  const size_t lds = lara_f_lds(which, D, NCT * 16);
+  const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
+  static int occ[3] = {0, 0, 0};            // resident workgroups per CU of the three instantiations
+#define EA_LF(K)                                                                                      \
+  do {                                                                                                \
+    if (lds > 64 * 1024) {                                                                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K<E, D, NCT>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                             \
+    }                                                                                                 \
+    if (!occ[which]) occ[which] = f_occupancy(&K<E, D, NCT>, lds);                                    \
+    lara_f_plan(p, occ[which] * f_device_cus());                                                      \
+    hipLaunchKernelGGL((K<E, D, NCT>), grid, block, lds, st, p);                                      \
+  } while (0)
+  if (which == 0) EA_LF(lara_fq_kernel);
+  else if (which == 1) EA_LF(lara_fk_kernel);
+  else EA_LF(lara_fin_kernel);
+#undef EA_LF
+  return (int)hipGetLastError();
+}
+
+template <typename E, int D>
+static int launch_f_nct(int which, LaraP& p, hipStream_t st) {
+  if (p.NCT <= 2) return launch_f<E, D, 2>(which, p, st);
+  if (p.NCT <= 4) return launch_f<E, D, 4>(which, p, st);
+  return EA_E_UNSUPPORTED;
+}
+
+// which: 0 query side, 1 key side, 2 finish
+int lara_f_dispatch(int which, const LaraP& p0, int dtype, hipStream_t st) {
+  LaraP p = p0;
+  p.prof = nullptr;
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "lara_f", which);
+#endif
+  if (dtype == EA_BF16) {
+    if (p.D == 64) return launch_f_nct<BF16, 64>(which, p, st);
+    if (p.D == 32) return launch_f_nct<BF16, 32>(which, p, st);
+  } else if (dtype == EA_F16) {
+    if (p.D == 64) return launch_f_nct<F16, 64>(which, p, st);
+    if (p.D == 32) return launch_f_nct<F16, 32>(which, p, st);
+  }
+  return EA_E_UNSUPPORTED;
+}
+
+}  // namespace ea

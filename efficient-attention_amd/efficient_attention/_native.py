@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 2          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 3          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -90,6 +90,10 @@ SIGNATURES = {
     "ea_lara_bwd_k": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_lara_bwd_kstats": [_LG, _T, _T] + [_P] * 8,
     "ea_lara_bwd_qcorr": [_LG, _T, _P, _P, _P, _T, _P],
+    "ea_lara_fused_parts": [_LG],
+    "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
+    "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
+    "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
     "ea_performer_parts": [_PG],
     "ea_performer_kmax": [_PG, _T, _P, _P, _P],
     "ea_performer_kv": [_PG, _T, _T, _P, _P, _P, _P, _P, _P],

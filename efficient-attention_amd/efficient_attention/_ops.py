@@ -8,6 +8,8 @@ in place through strides, and the backward kernels write dq/dk/dv straight into 
 copies exist here.
 """
 import ctypes
+import os
+import warnings
 
 import torch
 import torch.nn.functional as F
@@ -78,6 +80,9 @@ KERNEL_ALGO_UNITS = {
     "ea_lara_bwd_k": 4,           # read k,v; write dk,dv
     "ea_lara_bwd_kstats": 2,      # read k,v
     "ea_lara_bwd_qcorr": 3,       # read q; read+write dq
+    "ea_lara_bwd_q_fused": 3,     # read q,dout; write dq
+    "ea_lara_bwd_k_fused": 4,     # read k,v; write dk,dv
+    "ea_lara_bwd_finish": 5,      # read q; read+write dq,dk
 }
 
 
@@ -95,6 +100,28 @@ def _mask_u8(mask, B, N, device):
 
 
 _LOG2E = 1.4426950408889634
+
+_FP32_WARNED = [False]
+
+
+def to_io_dtype(t):
+    """Tensor entering an attention core -> the kernels' I/O dtype (bf16 / fp16 operands, fp32
+    accumulation and softmax).  Under autocast the projection already emits it.  An fp32 tensor
+    outside autocast is where this build departs from the reference, which computes attention in
+    fp32 there (abstract_attention.py:120-133): it is rounded to bf16 and the caller is told once
+    (EA_STRICT_FP32=1 turns the warning into an error)."""
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t
+    if os.environ.get("EA_STRICT_FP32", "0") == "1":
+        raise RuntimeError("efficient_attention (MI355X build): %s activations reached an attention core outside "
+                           "torch.autocast; the HIP cores take bf16/fp16 operands (EA_STRICT_FP32=1)" % t.dtype)
+    if not _FP32_WARNED[0]:
+        _FP32_WARNED[0] = True
+        warnings.warn("efficient_attention (MI355X build): %s activations outside torch.autocast are rounded to "
+                      "bf16 for the attention cores (bf16 operands, fp32 accumulation / softmax); the reference "
+                      "computes fp32 here. Wrap the call in torch.autocast('cuda', dtype=torch.bfloat16 | "
+                      "torch.float16) to choose the operand type explicitly." % t.dtype, stacklevel=3)
+    return t.to(torch.bfloat16)
 
 
 def _bias_padded(bias, geom):
@@ -517,6 +544,121 @@ def pool2d_qkv(qkv5, H, W, side, slot=None, need_v=False):
     return pooled[0], pooled[1], (pooled[2] if need_v else None)
 
 
+def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c):
+    """Estimator forward (ea_lara_stats_fwd -> ea_lara_merge_fwd -> ea_lara_out_fwd) on contiguous fp32
+    landmark tensors [BH,C,d] / [BH,C].  Returns out [B,N,h,d] and (cst, kv, lse_k, lse_t)."""
+    B, N, _, h, d = qkv5.shape
+    C, BH, dev, mis = geom.C, B * h, qkv5.device, geom.mis
+    q, k, v = _qkv_views(qkv5)
+    tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+    S = nv.lib().ea_lara_parts(ctypes.byref(geom))
+    p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
+    p_kv = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
+    nv.call("ea_lara_stats_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+            ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(p_ml),
+            nv.ptr(p_kv), nv.stream())
+    # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
+    kv = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+    sc = torch.empty((3, BH, C), dtype=torch.float32, device=dev)
+    lse_k, cst = sc[0], sc[1]
+    lse_t = sc[2] if mis == 0 else None
+    nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
+            nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+    to = nv.t4(out.permute(0, 2, 1, 3))
+    nv.call("ea_lara_out_fwd", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c),
+            nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to), nv.stream())
+    return out, (cst, kv, lse_k, lse_t)
+
+
+def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, lse_k, lse_t):
+    """Estimator backward up to (not including) the softmax-over-sequence correction of dq.
+    Writes dq (uncorrected), dk, dv into dqkv5; returns d_omega [BH,C,d], d_qbar, d_bhv, d_lp and uq
+    (the u_c q_bar_c rows of the correction, mis-opt only).
+    C <= 64: one fused pass per side (ea_lara_bwd_q_fused / ea_lara_bwd_k_fused); larger sample counts
+    take the round-1 two-pass kernels."""
+    B, N, _, h, d = qkv5.shape
+    C, BH, dev, mis = geom.C, B * h, qkv5.device, geom.mis
+    scale = geom.scale
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    tq, tk, tv, tdo = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(dout.permute(0, 2, 1, 3))
+    tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
+    fused = C <= 64
+    if fused:
+        S = nv.lib().ea_lara_fused_parts(ctypes.byref(geom))
+        if S <= 0:
+            raise RuntimeError("ea_lara_fused_parts: %d" % S)
+    else:
+        S = nv.lib().ea_lara_parts(ctypes.byref(geom))
+    p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
+    p_acc = torch.empty((4, BH, S, C, d), dtype=torch.float32, device=dev)
+    if fused:
+        nv.call("ea_lara_bwd_q_fused", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(omega),
+                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), ctypes.byref(tdq),
+                nv.ptr(p_ml), nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
+    else:
+        tok = torch.empty((4, BH, N), dtype=torch.float32, device=dev)
+        lseZ, tmean, rowdot, sda = tok[0], tok[1], tok[2], tok[3]
+        nv.call("ea_lara_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(omega),
+                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), ctypes.byref(tdq),
+                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.stream())
+        nv.call("ea_lara_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo),
+                nv.ptr(omega), nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst),
+                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.ptr(p_ml),
+                nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
+    # sums over the slices + derived per-landmark quantities (one tiny kernel)
+    big = torch.empty((4, BH, C, d), dtype=torch.float32, device=dev)
+    dkv, dom_q, dqbar_m, uq = big[0], big[1], big[2], big[3]
+    small = torch.empty((4, BH, C), dtype=torch.float32, device=dev)
+    r, dbh, dlp_m, dkk = small[0], small[1], small[2], small[3]
+    want_dqbar = mis in (0, 1)
+    nv.call("ea_lara_merge_bwd", BH, S, C, d, 1 if mis == 0 else 0, float(scale), nv.ptr(p_ml),
+            nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.ptr(kv), nv.ptr(qbar),
+            nv.ptr(r), nv.ptr(dbh), nv.ptr(dlp_m), nv.ptr(dkk), nv.ptr(dkv), nv.ptr(dom_q),
+            nv.ptr(dqbar_m) if want_dqbar else None, nv.ptr(uq) if mis == 0 else None, nv.stream())
+    p_domk = p_acc[1]                                      # (its contents were consumed by the merge)
+    if fused:
+        nv.call("ea_lara_bwd_k_fused", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r), ctypes.byref(tdk),
+                ctypes.byref(tdv), nv.ptr(p_domk), nv.stream())
+    else:
+        nv.call("ea_lara_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r), ctypes.byref(tdk),
+                ctypes.byref(tdv), nv.stream())
+        nv.call("ea_lara_bwd_kstats", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r),
+                nv.ptr(p_domk), nv.stream())
+    d_omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+    nv.call("ea_slice_sum", BH, S, C * d, float(scale), nv.ptr(dom_q), nv.ptr(p_domk), nv.ptr(d_omega), nv.stream())
+    d_qbar = dqbar_m if want_dqbar else None
+    d_bhv = dbh if mis == 0 else None
+    return d_omega, d_qbar, d_bhv, dlp_m, (uq if mis == 0 else None)
+
+
+def _lara_finish(geom, qkv5, dqkv5, qbar, uq, lse_t, dpq=None, dpk=None, pool=None):
+    """dq -= s sum_c t[c,n] (u q_bar)_c and, with pool = (r, H, W), the pooling backward
+    dq += dpq[chunk]/r^2, dk += dpk[chunk]/r^2 -- one pass (ea_lara_bwd_finish)."""
+    if uq is None and pool is None:
+        return
+    q, _, _ = _qkv_views(qkv5)
+    dq, dk, _ = _qkv_views(dqkv5)
+    tq, tdq, tdk = nv.t4(q), nv.t4(dq), nv.t4(dk)
+    r, H, W = pool if pool is not None else (0, 0, 0)
+    if geom.C <= 64:
+        nv.call("ea_lara_bwd_finish", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq), nv.ptr(lse_t),
+                nv.ptr(dpq), nv.ptr(dpk), int(r), int(H), int(W), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+        return
+    if uq is not None:
+        nv.call("ea_lara_bwd_qcorr", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq),
+                nv.ptr(lse_t), ctypes.byref(tdq), nv.stream())
+    if pool is not None:
+        B, N, _, h, d = qkv5.shape
+        pg = nv.make_geom(B, h, N, d, geom.dtype, True, (H, W), r, 0, r, (H // r) * (W // r))
+        nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(pg), nv.ptr(dpq), nv.ptr(dpk), None,
+                ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+
+
 class LaraAttnFn(torch.autograd.Function):
     """LARA estimator on a fused qkv tensor given the landmark-side tensors (all fp32):
     omega [B,h,C,d], qbar [B,h,C,d] (q_bar rows for mis-opt, mu rows for mis-biased; rows already
@@ -529,32 +671,13 @@ class LaraAttnFn(torch.autograd.Function):
         B, N, _, h, d = qkv5.shape
         C = omega.shape[2]
         ctx.slot = slot
-        dev = qkv5.device
         geom = nv.ea_lara_geom(B, h, N, d, nv.io_dtype(qkv5), C, mis, float(kappa), float(d) ** -0.5)
-        q, k, v = _qkv_views(qkv5)
-        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
         BH = B * h
         omega = omega.float().reshape(BH, C, d).contiguous()
         qbar_c = None if qbar is None else qbar.float().reshape(BH, C, d).contiguous()
-        S = nv.lib().ea_lara_parts(ctypes.byref(geom))
-        p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
-        p_kv = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
-        nv.call("ea_lara_stats_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
-                ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(p_ml),
-                nv.ptr(p_kv), nv.stream())
-        # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
-        kv = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
-        sc = torch.empty((3, BH, C), dtype=torch.float32, device=dev)
-        lse_k, cst = sc[0], sc[1]
-        lse_t = sc[2] if mis == 0 else None
         lp_c = lp.reshape(BH, C).float().contiguous()
-        nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
-                nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
         bhv_c = None if bhv is None else bhv.reshape(BH, C).float().contiguous()
-        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
-        to = nv.t4(out.permute(0, 2, 1, 3))
-        nv.call("ea_lara_out_fwd", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c),
-                nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to), nv.stream())
+        out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c)
         ctx.save_for_backward(qkv5, mask_u8, omega, qbar_c, bhv_c, cst, kv, lse_k, lse_t)
         ctx.geom = geom
         ctx.has = (qbar is not None, bhv is not None)
@@ -565,59 +688,94 @@ class LaraAttnFn(torch.autograd.Function):
         qkv5, mask_u8, omega, qbar, bhv, cst, kv, lse_k, lse_t = ctx.saved_tensors
         geom = ctx.geom
         B, N, _, h, d = qkv5.shape
-        C, BH, dev, mis = geom.C, B * h, qkv5.device, geom.mis
-        scale = geom.scale
+        C = geom.C
         dout = dout.contiguous()
         dqkv5 = torch.empty_like(qkv5)
-        q, k, v = _qkv_views(qkv5)
-        dq, dk, dv = _qkv_views(dqkv5)
-        tq, tk, tv, tdo = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(dout.permute(0, 2, 1, 3))
-        tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
-        tok = torch.empty((4, BH, N), dtype=torch.float32, device=dev)
-        lseZ, tmean, rowdot, sda = tok[0], tok[1], tok[2], tok[3]
-        nv.call("ea_lara_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(omega),
-                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), ctypes.byref(tdq),
-                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.stream())
-        S = nv.lib().ea_lara_parts(ctypes.byref(geom))
-        p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
-        p_acc = torch.empty((4, BH, S, C, d), dtype=torch.float32, device=dev)
-        nv.call("ea_lara_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo),
-                nv.ptr(omega), nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst),
-                nv.ptr(lseZ), nv.ptr(tmean), nv.ptr(rowdot), nv.ptr(sda), nv.ptr(p_ml),
-                nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
-        # sums over the slices + derived per-landmark quantities (one tiny kernel)
-        big = torch.empty((4, BH, C, d), dtype=torch.float32, device=dev)
-        dkv, dom_q, dqbar_m, uq = big[0], big[1], big[2], big[3]
-        small = torch.empty((4, BH, C), dtype=torch.float32, device=dev)
-        r, dbh, dlp_m, dkk = small[0], small[1], small[2], small[3]
-        want_dqbar = mis in (0, 1)
-        nv.call("ea_lara_merge_bwd", BH, S, C, d, 1 if mis == 0 else 0, float(scale), nv.ptr(p_ml),
-                nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.ptr(kv), nv.ptr(qbar),
-                nv.ptr(r), nv.ptr(dbh), nv.ptr(dlp_m), nv.ptr(dkk), nv.ptr(dkv), nv.ptr(dom_q),
-                nv.ptr(dqbar_m) if want_dqbar else None, nv.ptr(uq) if mis == 0 else None, nv.stream())
-        nv.call("ea_lara_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
-                nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r), ctypes.byref(tdk),
-                ctypes.byref(tdv), nv.stream())
-        p_domk = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
-        nv.call("ea_lara_bwd_kstats", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
-                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(dkv), nv.ptr(lse_k), nv.ptr(dkk), nv.ptr(r),
-                nv.ptr(p_domk), nv.stream())
-        d_omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
-        nv.call("ea_slice_sum", BH, S, C * d, float(scale), nv.ptr(dom_q), nv.ptr(p_domk), nv.ptr(d_omega), nv.stream())
-        d_qbar = d_bhv = None
-        if mis == 0:
-            nv.call("ea_lara_bwd_qcorr", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq),
-                    nv.ptr(lse_t), ctypes.byref(tdq), nv.stream())
-            d_qbar = dqbar_m.view(B, h, C, d)
-            d_bhv = dbh.reshape(B, h, C)
-        elif mis == 1:
-            d_qbar = dqbar_m.view(B, h, C, d)
-        d_lp = dlp_m.view(B, h, C)
+        d_omega, d_qbar, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv,
+                                                          cst, kv, lse_k, lse_t)
+        _lara_finish(geom, qkv5, dqkv5, qbar, uq, lse_t)
         has_qbar, has_bhv = ctx.has
         if ctx.slot is not None:
             ctx.slot.buf = dqkv5          # the pooling backward accumulates into this buffer in place
-        return (dqkv5, None, d_omega, d_qbar if has_qbar else None, d_bhv if has_bhv else None,
-                d_lp, None, None, None)
+        return (dqkv5, None, d_omega.view(B, h, C, d),
+                d_qbar.view(B, h, C, d) if (has_qbar and d_qbar is not None) else None,
+                d_bhv.reshape(B, h, C) if (has_bhv and d_bhv is not None) else None,
+                d_lp.view(B, h, C), None, None, None)
+
+
+class LaraPooledFn(torch.autograd.Function):
+    """The whole 2-D LARA core as ONE autograd node (no gradient side channels between nodes): uniform
+    r x r average pooling of q, k (lara.py:43,48,145-151) -> fused landmark pipeline (:45-54,157-198,
+    214-238) -> estimator (:201-246).  cfg = (H, W, r, has_mlp, mixed, mis, dup, kappa, scale);
+    params = (Wq, bq, gq, cq, Wk, bk, gk, ck) when has_mlp.  Returns out [B,N,h,d].
+    Backward: one fused pass per side, the landmark backward, and ONE finish pass that applies the
+    softmax-over-sequence correction of dq together with the pooling backward of dq and dk."""
+
+    @staticmethod
+    def forward(ctx, qkv5, mask_u8, noise, cfg, *params):
+        H, W, r, has_mlp, mixed, mis, dup, kappa, scale = cfg
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        L = (H // r) * (W // r)
+        C = L * (2 if dup else 1)
+        BH, dev = B * h, qkv5.device
+        io = nv.io_dtype(qkv5)
+        pgeom = nv.make_geom(B, h, N, d, io, True, (H, W), r, 0, r, L)
+        q, k, _ = _qkv_views(qkv5)
+        tq, tk = nv.t4(q), nv.t4(k)
+        pq = torch.empty((BH, L, d), dtype=torch.float32, device=dev)
+        pk = torch.empty_like(pq)
+        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
+                nv.ptr(pq), nv.ptr(pk), nv.stream())
+        noise_c = None if noise is None else noise.float().contiguous()
+        ps = [t.detach().float().contiguous() for t in params]
+        lg = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale), 0)
+        global LAST_LMK_GEOM
+        LAST_LMK_GEOM = (BH, L, C, d, int(has_mlp), int(mixed), 0)
+        omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+        qrows = torch.empty_like(omega) if mis != 2 else None
+        bhv = torch.empty((BH, C), dtype=torch.float32, device=dev) if mis == 0 else None
+        lp = torch.empty((BH, C), dtype=torch.float32, device=dev)
+        pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+        need_grad = any(ctx.needs_input_grad)
+        saved = _lmk_saved(lg, dev) if need_grad else None
+        nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
+        geom = nv.ea_lara_geom(B, h, N, d, io, C, mis, float(kappa), float(scale))
+        out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp)
+        ctx.save_for_backward(qkv5, mask_u8, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved, *ps)
+        ctx.geom, ctx.lg, ctx.cfg = geom, lg, cfg
+        ctx.pdtypes = [t.dtype for t in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, mask_u8, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved, *ps = ctx.saved_tensors
+        geom, lg = ctx.geom, ctx.lg
+        H, W, r, has_mlp, mixed, mis, dup, kappa, scale = ctx.cfg
+        B, N, _, h, d = qkv5.shape
+        BH, dev = B * h, qkv5.device
+        dout = dout.contiguous()
+        dqkv5 = torch.empty_like(qkv5)
+        d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
+                                                           cst, kv, lse_k, lse_t)
+        dpq = torch.empty_like(pq)
+        dpk = torch.empty_like(pk)
+        dW = dvec = None
+        if has_mlp:
+            dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
+            dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
+        pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+        nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+                nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
+        _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
+        pgrads = []
+        if has_mlp:
+            dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
+            raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+            pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
+        return (dqkv5, None, None, None) + tuple(pgrads)
 
 
 def _lmk_saved(geom, device):
@@ -952,6 +1110,15 @@ def _ones_row(S, dtype, device):
     return _ONES[key]
 
 
+def slice_sum(part):
+    """part [S, ...] fp32 -> sum over S in a fixed order (ea_slice_sum)."""
+    S = part.shape[0]
+    n = part[0].numel()
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    nv.call("ea_slice_sum", 1, S, n, 1.0, None, nv.ptr(part), nv.ptr(out), nv.stream())
+    return out
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b in the autocast dtype.  dW = dY^T X contracts over all B*N tokens with a
     [out, in] result of a few tiles: left to a single library GEMM it occupies ~9 of 256 CUs
@@ -983,9 +1150,12 @@ class LinearFn(torch.autograd.Function):
             rows = xl.shape[0]
             S = _split_k(rows)
             if S > 1:
-                part = torch.bmm(dy2.view(S, rows // S, -1).transpose(1, 2), xl.view(S, rows // S, -1))
-                # sum over the slices as a [1,S] x [S, out*in] GEMM (fp32 accumulation inside the GEMM)
-                dw = (_ones_row(S, part.dtype, part.device) @ part.view(S, -1)).view(part.shape[1:]).to(wdtype)
+                dy3 = (dy2 if dy2.is_contiguous() else dy2.contiguous()).view(S, rows // S, -1)
+                part = torch.bmm(dy3.transpose(1, 2), xl.view(S, rows // S, -1))     # [S, out, in]
+                # sum over the slices as a [1,S] x [S, out*in] GEMM (fp32 accumulation inside the GEMM,
+                # fp32 result: the partials are rounded once each, their sum once)
+                dw = _mm_out(_ones_row(S, part.dtype, part.device), part.view(S, -1), torch.float32).view(part.shape[1:])
+                dw = dw.to(wdtype)
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
         if bdtype is not None and ctx.needs_input_grad[2]:

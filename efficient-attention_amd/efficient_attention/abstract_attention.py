@@ -68,8 +68,7 @@ class MultiheadAttention(nn.Module):
         kernels compute bf16 x bf16 -> fp32, the autocast contract of vit/engine.py:47)."""
         B, N, C = x.shape
         qkv = _ops.linear(x, self.qkv)
-        if qkv.dtype not in (torch.bfloat16, torch.float16):
-            qkv = qkv.to(torch.bfloat16)
+        qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
 
     def proj_and_split_heads(self, x):

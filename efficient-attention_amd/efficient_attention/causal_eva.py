@@ -125,8 +125,7 @@ class CausalEVAttention(nn.Module):
                 "the windowed path needs keys/values aligned with the queries"
             qkv = torch.stack([_ops.linear(query, self.q_proj), _ops.linear(key, self.k_proj),
                                _ops.linear(value, self.v_proj)], dim=2)
-        if qkv.dtype not in (torch.bfloat16, torch.float16):
-            qkv = qkv.to(torch.bfloat16)
+        qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(N, B, 3, self.num_heads, self.head_dim)
 
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None,

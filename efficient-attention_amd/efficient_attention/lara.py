@@ -126,8 +126,7 @@ class LinearRA(MultiheadAttention):
             if self.qkv.bias is not None:
                 b_ext = torch.cat([self.qkv.bias.float(), self.qkv.bias.new_zeros(2 * C, dtype=torch.float32)])
         qkv = _ops.linear_wb(x, w_ext, b_ext)
-        if qkv.dtype not in (torch.bfloat16, torch.float16):
-            qkv = qkv.to(torch.bfloat16)
+        qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 5, h, d)
 
     def _proposal_gen_1d_folded(self, qkvE, key_padding_mask, mask_u8, slot):
@@ -179,31 +178,34 @@ class LinearRA(MultiheadAttention):
                    and not gen.endswith('-vmixed') and (gen.startswith('pool') or gen.startswith('no-param-pool'))
                    and seq_shape[0] % side == 0 and seq_shape[1] % side == 0
                    and seq_shape[0] // side == seq_shape[1] // side)
-        if fused_a:
-            pq, pk, _ = _ops.pool2d_qkv(qkv5, seq_shape[0], seq_shape[1], side, slot)
-            params = self._mlp_params() if gen.startswith('pool') else None
-            mixed = gen.endswith('mixed')
-        else:
-            if len(seq_shape) == 2:
-                pq, pk = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
-            elif fold_1d:
-                pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
-            elif len(seq_shape) == 1:
-                pq, pk, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
-            else:
-                raise ValueError("LinearRA expects x of rank 3 or 4")
-            params, mixed = None, False
 
-        noise = None
-        if self.training:
-            nl = pq.shape[-2]
+        def draw_noise(nl):
+            if not self.training:
+                return None
             if self.use_multisample:
-                noise = torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=x.device)
-            else:
-                noise = torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=x.device))
+                return torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=x.device)
+            return torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=x.device))
+
+        if fused_a:
+            # pooling + landmark pipeline + estimator as one autograd node (_ops.LaraPooledFn)
+            params = self._mlp_params() if gen.startswith('pool') else ()
+            noise = draw_noise(n_lm)
+            cfg = (seq_shape[0], seq_shape[1], seq_shape[0] // side, bool(params), gen.endswith('mixed'),
+                   _ops.MIS[self.mis_type], mode if noise is not None else 0, float(self.alpha_coeff), float(self.scale))
+            out = _ops.LaraPooledFn.apply(qkv5, mask, noise, cfg, *params)
+            return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+        if len(seq_shape) == 2:
+            pq, pk = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
+        elif fold_1d:
+            pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
+        elif len(seq_shape) == 1:
+            pq, pk, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
+        else:
+            raise ValueError("LinearRA expects x of rank 3 or 4")
+        noise = draw_noise(pq.shape[-2])
         if fused_b:
-            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, self.mis_type, mode, self.scale,
-                                                        params, mixed)
+            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, self.mis_type, mode, self.scale, None, False)
             out = _ops.LaraAttnFn.apply(qkv5, mask, omega, qrows, bhv, lp, _ops.MIS[self.mis_type],
                                         float(self.alpha_coeff), slot)
         else:

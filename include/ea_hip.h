@@ -205,6 +205,26 @@ int ea_lara_bwd_kstats(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, co
 int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
                       const float* lse_t, const ea_t4* dq, void* stream);
 
+/* Fused backward (round 2): the elementwise stage of the estimator is evaluated once per side and its
+ * [C x N] weight matrices are transposed through LDS, so q/dout and k/v are each read ONCE
+ * (ea_lara_bwd_q + ea_lara_bwd_qstats, ea_lara_bwd_k + ea_lara_bwd_kstats of round 1 read them
+ * twice).  C <= 64.  Partial outputs [BH, ea_lara_fused_parts(g), C, *] feed ea_lara_merge_bwd /
+ * ea_slice_sum unchanged.  Replaces the autograd of lara.py:201-246.
+ * ea_lara_bwd_finish: dq -= s sum_c t[c,n] (u q_bar)_c (softmax-over-sequence correction, uq may be
+ * NULL) and, with pool_r > 0, the backward of the uniform pool_r x pool_r average pooling of q and k
+ * over the gh x gw token grid (lara.py:43,48,145-151): dq += dpq[chunk(n)] / r^2, dk += dpk[...] / r^2. */
+int32_t ea_lara_fused_parts(const ea_lara_geom* g);
+int ea_lara_bwd_q_fused(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
+                        const float* qbar, const float* kv, const float* lse_t, const float* bhv,
+                        const float* cst, const ea_t4* dq, float* p_ml, float* p_dkv, float* p_dom,
+                        float* p_m1, float* p_m2, void* stream);
+int ea_lara_bwd_k_fused(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                        const float* omega, const float* dkv, const float* lse_k, const float* dkk,
+                        const float* rsum, const ea_t4* dk, const ea_t4* dv, float* p_dom, void* stream);
+int ea_lara_bwd_finish(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
+                       const float* lse_t, const float* dpq, const float* dpk, int32_t pool_r,
+                       int32_t gh, int32_t gw, const ea_t4* dq, const ea_t4* dk, void* stream);
+
 /* ---- softmax baseline (abstract_attention.py:120-133) ----------------------------------------
  * out = dropout(softmax(s Q K^T, -inf on padded keys)) V, streamed (no [N,N] score matrix).
  * lse: fp32 [B*H, N] saved for backward; delta: fp32 [B*H, N] scratch (dO.O) written by the dQ

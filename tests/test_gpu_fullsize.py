@@ -1,0 +1,167 @@
+"""-m gpu: the benchmark's own launch geometries, WHOLE batch, TRAINING mode with shared sampling
+noise, every output compared with the CPU oracle: y, dL/dx and EVERY parameter gradient.
+
+These are the code paths that only exist at full size: per-workgroup
+partial merges with parts > 1 (ea_slice_sum, ea_colsum_f32), the split-K weight gradient,
+ea_bias_grad over B*h = 384 (b,h) pairs, the landmark dW / dvec sums.  The oracle runs the whole
+[128,28,28,192] batch in a few seconds of CPU time.
+
+Tolerances: the norm-wise figures of tests/gpu_checks.py (max|err|/max|ref|, rms/rms) in bf16 and
+fp16, and -- in fp16, where operand rounding is 8x finer -- an ELEMENTWISE bound
+|err| <= atol + rtol |ref| with atol = FP16_ELEM[0] * rms(ref), rtol = FP16_ELEM[1]."""
+import contextlib
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "efficient-attention_amd"), os.path.join(ROOT, "tests")]
+
+# elementwise fp16 bound: |err| <= FP16_ELEM[0] * rms(ref) + FP16_ELEM[1] * |ref|
+FP16_ELEM = (3e-2, 3e-2)
+
+EVA2D = dict(attn_2d=True, use_rpe=True, adaptive_proj="default")
+FULL = {
+    # cfg3, the configuration the headline metric is quoted on
+    "cfg3_lara": ("lara", (128, 28, 28, 192), dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                                                    mis_type="mis-opt", alpha_coeff=2.0), None),
+    "cfg3_eva": ("eva", (128, 28, 28, 192), dict(dim=192, num_heads=3, window_size=7, num_landmarks=49, **EVA2D), None),
+    "cfg3_local": ("local", (128, 28, 28, 192), dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True), None),
+    "cfg3_performer": ("performer", (128, 28, 28, 192), dict(dim=192, num_heads=3, approx_attn_dim=64,
+                                                              proj_method="favorp"), None),
+    # cfg2 (N = 196) at the DeiT batch
+    "cfg2_lara": ("lara", (128, 14, 14, 192), dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                                                    mis_type="mis-opt", alpha_coeff=2.0), None),
+    "cfg2_eva": ("eva", (128, 14, 14, 192), dict(dim=192, num_heads=3, window_size=7, num_landmarks=49, **EVA2D), None),
+    # cfg5: 1-D N = 4096, h = 8, pad mask
+    "cfg5_lara": ("lara", (4, 4096, 512), dict(dim=512, num_heads=8, num_landmarks=49, proposal_gen="adaptive-1d",
+                                                mis_type="mis-opt"), [0, 410, 0, 17]),
+    "cfg5_eva": ("eva", (4, 4096, 512), dict(dim=512, num_heads=8, window_size=16, attn_2d=False, use_t5_rpe=True,
+                                              overlap_window=True, num_landmarks=8, adaptive_proj="default"), [0, 410, 0, 17]),
+    "cfg5_performer": ("performer", (4, 4096, 512), dict(dim=512, num_heads=8, approx_attn_dim=64, proj_method="favorp"),
+                       [0, 410, 0, 17]),
+}
+
+
+_REAL_RANDN = torch.randn
+
+
+def _noise(shape, call):
+    g = torch.Generator().manual_seed(9000 + call)
+    return _REAL_RANDN(tuple(shape), generator=g)
+
+
+@contextlib.contextmanager
+def shared_noise(device):
+    """torch.randn / randn_like -> the call-indexed CPU stream the oracle's noise_fn replays."""
+    calls = []
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def randn(*size, **kw):
+        if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+            size = tuple(size[0])
+        t = _noise(size, len(calls))
+        calls.append(tuple(size))
+        return t.to(device=kw.get("device", device), dtype=kw.get("dtype") or torch.float32)
+
+    def randn_like(t, **kw):
+        n = _noise(t.shape, len(calls))
+        calls.append(tuple(t.shape))
+        return n.to(device=t.device, dtype=t.dtype)
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        yield calls
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+def _mask(shape, pads, device):
+    if pads is None:
+        return None
+    n = int(np.prod(shape[1:-1]))
+    mask = torch.zeros(shape[0], n, dtype=torch.bool, device=device)
+    for b, k in enumerate(pads):
+        if k:
+            mask[b, n - k:] = True
+    return mask
+
+
+def _run_case(name, dtype):
+    import efficient_attention as ea
+    import oracle
+    from gpu_checks import MODULE_TOL, LARA_TOL, FP16_TOL
+    from util import scaled_err
+    attn, shape, args, pads = FULL[name]
+    torch.manual_seed(21)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ea.AttentionFactory.build_attention(attn, dict(args)).cuda()
+    m.train()
+    with torch.no_grad():
+        for p in m.parameters():                      # make zero-initialised tables / biases matter
+            p.add_(0.02 * torch.randn_like(p))
+    xs = 0.25 if attn == "performer" else 1.0         # away from Performer's clamp kink (test_gpu_configs._xscale)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = (xs * torch.randn(*shape, device="cuda", generator=gen)).requires_grad_(True)
+    gy = torch.randn(*shape, device="cuda", generator=gen)
+    mask = _mask(shape, pads, "cuda")
+    with shared_noise("cuda") as calls:
+        with torch.autocast("cuda", dtype=dtype):
+            y = m(x, mask) if mask is not None else m(x)
+    (y.float() * gy).sum().backward()
+
+    params = {k: v.detach().float().cpu().clone().requires_grad_(v.dtype.is_floating_point)
+              for k, v in m.state_dict().items()}
+    xr = x.detach().cpu().requires_grad_(True)
+    ocalls = []
+
+    def noise_fn(shp):
+        t = _noise(shp, len(ocalls))
+        ocalls.append(tuple(shp))
+        return t
+    ref = oracle.module_forward(attn, dict(args), params, xr, None if mask is None else mask.cpu(),
+                                training=True, noise_fn=noise_fn)
+    assert [int(np.prod(s)) for s in calls] == [int(np.prod(s)) for s in ocalls], (calls, ocalls)
+    (ref * gy.cpu()).sum().backward()
+
+    if dtype == torch.float16:
+        tol = FP16_TOL
+    else:
+        tol = LARA_TOL if attn == "lara" else MODULE_TOL
+    pairs = [("y", y.detach().float().cpu().numpy(), ref.detach().numpy()),
+             ("dx", x.grad.float().cpu().numpy(), xr.grad.numpy())]
+    for k, p in m.named_parameters():
+        rg = params[k].grad
+        want = np.zeros(tuple(p.shape), np.float32) if rg is None else rg.numpy()
+        got = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.float().cpu().numpy()
+        pairs.append(("d" + k, got, want))
+    errs, bad = {}, {}
+    for what, got, want in pairs:
+        assert np.isfinite(got).all(), (name, what)
+        if np.abs(want).max() == 0:
+            assert np.abs(got).max() == 0, (name, what)
+            continue
+        e = scaled_err(got, want)
+        errs[what] = e
+        if not (e[0] <= tol[0] and e[1] <= tol[1]):
+            bad[what] = e
+        if dtype == torch.float16:
+            rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+            excess = np.abs(got.astype(np.float64) - want) / (FP16_ELEM[0] * rms + FP16_ELEM[1] * np.abs(want))
+            errs[what] = e + (float(excess.max()),)
+            if excess.max() > 1.0:
+                bad[what + "[elementwise]"] = float(excess.max())
+    print(name, dtype, {k: tuple(round(float(x), 5) for x in v) for k, v in errs.items()})
+    assert not bad, "%s %s out of tolerance %s: %s (all: %s)" % (name, dtype, tol, bad, errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_batch_train_all_gradients(name, dtype):
+    _run_case(name, torch.bfloat16 if dtype == "bf16" else torch.float16)
