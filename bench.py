@@ -167,10 +167,13 @@ def main():
     ap.add_argument("--heads", type=int, default=3)
     ap.add_argument("--window", type=int, default=None, help="override window_size (eva / local), e.g. 8 for the PvT stages")
     ap.add_argument("--landmarks", type=int, default=None, help="override num_landmarks (eva / lara), e.g. 36 for the PvT stages")
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5", "lm"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5", "lm", "model_cfg2", "model_cfg3",
+                                                           "model_cfg4", "model_cfg5"],
                     help="cfg3 (default, the metric's config): [128,28,28,192] h=3; cfg2: [128,14,14,192] h=3; "
                          "cfg5: 1-D [16,4096,512] h=8 (BASELINE.json configs / SURVEY.md 8d); lm: the wikitext-103 "
-                         "decoder self-attention, [18,512,1024] h=8 (use with --attn causal_eva)")
+                         "decoder self-attention, [18,512,1024] h=8 (use with --attn causal_eva); model_cfg2..5: the WHOLE "
+                         "models of BASELINE.json configs 2-5 (ea_harness: DeiT-tiny-p16 EVA, DeiT-tiny-p8 LARA, PvTv2-b2 "
+                         "EVA, wmt_en_de encoder LARA) as a synthetic training step, eager and captured")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-tune", action="store_true",
@@ -178,6 +181,8 @@ def main():
     ap.add_argument("--gemm-tune-file", default=None,
                     help="TunableOp results file: read (no tuning) if it exists, else tuned and written at exit")
     a = ap.parse_args()
+    if a.workload.startswith("model_"):
+        return main_model(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -383,6 +388,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # ---- the same step run EAGERLY (the reference's call sites run eagerly, vit/engine.py:47-64) ----
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    n_eager = min(a.steps, 20)
+    for _ in range(n_eager):
+        step()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - te) / n_eager * 1e3
+
     # ---- instrumented eager pass: HIP events around every launch of the dominant kernel ----
     _ops.KERNEL_TIMER.enable()
     for _ in range(min(a.steps, 10)):
@@ -453,7 +469,8 @@ def main():
         line = {
             "metric": "attn fwd+bwd tokens/s per GPU at N=784, d=64; 1/2/4/8-GPU DDP scaling",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": el / a.steps * 1e3, "eager_ms_per_step": round(eager_ms, 4),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s attention layer fwd+bwd+SGD, x=[%s] per GPU (N=%d, h=%d, d=%d), "
                                    "bf16 autocast%s" % (a.attn, ",".join(str(v) for v in (B,) + tuple(seq) + (C,)), N, H, d,
@@ -469,6 +486,94 @@ def main():
         }
         print(json.dumps(line))
     if ddp:
+        dist.destroy_process_group()
+
+
+def main_model(a):
+    """Whole-model workloads: one synthetic training step of ea_harness's stacks --
+    autocast forward + loss, backward, SGD(momentum) -- timed eagerly (what the reference's call sites
+    do) and captured in a hipGraph.  N > 1: DistributedDataParallel over RCCL (bucketed all-reduce
+    overlapped with backward), weak scaling."""
+    from ea_harness import trainer
+    from efficient_attention import _ops
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(os.environ.get("EA_BENCH_BACKEND", "nccl"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wl = trainer.build_workload(a.workload, dev, batch=None if a.batch == 128 else a.batch, seed=1234 + rank)
+    if not a.no_gemm_tune:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.set_filename(a.gemm_tune_file or os.path.join(tempfile.gettempdir(), "ea_bench_tunableop_%d.csv" % os.getpid()))
+        tunable.tuning_enable(not (a.gemm_tune_file and os.path.exists(a.gemm_tune_file)))
+    ddp_model = trainer.wrap_ddp(wl.model, dev) if world > 1 else None
+    step = trainer.make_step(wl, ddp_model=ddp_model)
+    for _ in range(max(a.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    if not a.no_gemm_tune:
+        tunable.tuning_enable(False)
+
+    def timed(fn, n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for _ in range(a.warmup):
+        step()
+    eager_el = timed(step, a.steps)
+    graph_ms = None
+    if not a.no_graph and world == 1:
+        try:
+            replay = trainer.capture_step(step)
+            for _ in range(3):
+                replay()
+            graph_ms = timed(replay, a.steps) / a.steps * 1e3
+        except Exception as ex:
+            print("graph capture unavailable (%s)" % str(ex).split("\n")[0], file=sys.stderr)
+            torch.cuda.synchronize()
+    _ops.KERNEL_TIMER.enable()
+    for _ in range(min(a.steps, 5)):
+        step()
+    torch.cuda.synchronize()
+    ktimes = _ops.KERNEL_TIMER.summary()
+    _ops.KERNEL_TIMER.disable()
+    if rank == 0:
+        tokens = wl.tokens * world
+        hip_ms = sum(v["total_ms"] for v in ktimes.values()) / max(min(a.steps, 5), 1)
+        line = {
+            "metric": "attn fwd+bwd tokens/s per GPU at N=784, d=64; 1/2/4/8-GPU DDP scaling",
+            "value": tokens * a.steps / eager_el, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": eager_el / a.steps * 1e3, "eager_ms_per_step": eager_el / a.steps * 1e3,
+            "graph_ms_per_step": graph_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s: %s; whole-model training step (fwd + loss + bwd + SGD momentum), eager, bf16 "
+                                   "autocast%s" % (a.workload, wl.desc, ", DistributedDataParallel" if world > 1 else ""),
+                       "tokens_per_step_per_gpu": wl.tokens, "parallelism": "dp%d" % world, "hipgraph": False,
+                       "params_M": round(sum(p.numel() for p in wl.model.parameters()) / 1e6, 2)},
+            "attention_core_ms_per_step": round(hip_ms, 4),
+            "attention_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    if world > 1:
         dist.destroy_process_group()
 
 
