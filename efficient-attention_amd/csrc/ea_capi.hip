@@ -21,6 +21,9 @@ int rows_mlp_blocks(int R, int D);
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
+int wgrad_slices(int rows, int M, int K);
+int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, int rows, int M, int K,
+                   hipStream_t st);
 }
 
 using namespace ea;
@@ -788,6 +791,21 @@ int ea_rows_mlp_bwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
   p.g[0] = g0; p.g[1] = g1; p.zhat = const_cast<float*>(zhat); p.rstd = const_cast<float*>(rstd);
   p.dx[0] = dx0; p.dx[1] = dx1; p.feed = feed; p.dW_part = dW_part;
   return ea::rows_mlp_dispatch(p, D, sides, layer_norm, true, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- projection weight + bias gradient (ea_wgrad.hip) ----
+extern "C" {
+
+int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features) {
+  return wgrad_slices(rows, out_features, in_features);
+}
+
+int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
+             float* dw_part, float* db_part, void* stream) {
+  if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EA_E_BADARG;
+  return wgrad_dispatch(dtype, dy, x, dw_part, db_part, rows, out_features, in_features, (hipStream_t)stream);
 }
 
 }  // extern "C"

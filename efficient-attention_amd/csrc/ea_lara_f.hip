@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   const int last_tok = n1 - 1;
 
   EA_BLK(p, 0);
+  EA_STAMP(p, 0);
   u32x4 nx1[KS], nx2[KS];
   auto issue = [&](int cb_) {
     const int tok_ = min(cb_ + wave * 16 + li, last_tok);
@@ -146,8 +147,12 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   for (int ct = 0; ct < NCT; ++ct) sdbh[ct][0] = sdbh[ct][1] = f32x2{0.f, 0.f};
   const typename E::x8 ones = ones_x8<E>();
   __syncthreads();
+  EA_STAMP(p, 1);
+  int prof_it = 0;
+  (void)prof_it;
 
   for (int cb = n0; cb < n1; cb += 64) {
+    if (prof_it < 8) EA_STAMP(p, 2 + prof_it * 7);
     const int tok = cb + wave * 16 + li;
     const bool valid = tok < n1;
     typename E::x8 f1[KS], f2[KS];
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 3 + prof_it * 7);
     // ---- elementwise stage (same algebra as LX_BWDQ, ea_lara_x.hip) ----
     const float s2 = p.scale_log2;
     const f32x2 s22 = {s2, s2};
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         tp[ct] = u32x2{0u, 0u};
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 4 + prof_it * 7);
     // ---- contraction over c: dq^T[d][n] = omega^T . dZ (+ qbar^T . t dt) ----
     f32x4 acc[DT];
 #pragma unroll
@@ -307,8 +314,10 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
     }
+    if (prof_it < 8) EA_STAMP(p, 5 + prof_it * 7);
     // ---- hand the slab to the token-row phase ----
     __syncthreads();                        // the previous chunk's readers are done
+    if (prof_it < 8) EA_STAMP(p, 6 + prof_it * 7);
     {
       const int row = wave * 16 + li;
       const u32x4 z = {0u, 0u, 0u, 0u};
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       }
     }
     __syncthreads();
+    if (prof_it < 8) EA_STAMP(p, 7 + prof_it * 7);
     // ---- token-row phase: landmark tile yct over the chunk's tokens ----
     if (ywave) {
 #pragma unroll
@@ -359,7 +369,10 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         }
       }
     }
+    if (prof_it < 8) EA_STAMP(p, 8 + prof_it * 7);
+    ++prof_it;
   }
+  EA_STAMP(p, 60);
   // ---- per-landmark sums of d alpha: over the 16 token lanes, then over the four waves ----
   if (opt) {
 #pragma unroll

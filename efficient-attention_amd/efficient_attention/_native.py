@@ -94,6 +94,8 @@ SIGNATURES = {
     "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
+    "ea_wgrad_parts": [_I, _I, _I],
+    "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "ea_performer_parts": [_PG],
     "ea_performer_kmax": [_PG, _T, _P, _P, _P],
     "ea_performer_kv": [_PG, _T, _T, _P, _P, _P, _P, _P, _P],

@@ -1119,6 +1119,37 @@ def slice_sum(part):
     return out
 
 
+def wgrad_supported(dy2, x2):
+    """ea_wgrad takes contiguous bf16 / fp16 [rows, out] and [rows, in] with out, in multiples of 64."""
+    return (dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float16) and x2.dtype == dy2.dtype
+            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 64)
+
+
+# The hand-written one-pass weight + bias gradient (ea_wgrad) reads dY and X exactly once from HBM
+# (rocprofv3 FETCH_SIZE = algorithmic) but, with one 32 KB stage in flight per CU, is latency-bound at
+# 87 us / 45 us for the two cfg3 projections -- on par with the library split-K GEMM + ea_bias_grad it
+# would replace (DESIGN.md 5).  It stays an opt-in path (EA_WGRAD=1) until its loads are pipelined deeper.
+USE_WGRAD = os.environ.get("EA_WGRAD", "0") == "1"
+
+
+def wgrad(dy2, x2, with_bias=True):
+    """dW [out, in] = dY^T X and db [out] = dY.sum(0), both fp32, from one pass over dY and X (ea_wgrad:
+    token slices x output tiles, slice partials summed in a fixed order)."""
+    dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    rows, M = dy2.shape
+    K = x2.shape[1]
+    S = nv.lib().ea_wgrad_parts(rows, M, K)
+    if S <= 0:
+        raise RuntimeError("ea_wgrad_parts: %d" % S)
+    part = torch.empty((S, M, K), dtype=torch.float32, device=dy2.device)
+    db_part = torch.empty((S, M), dtype=torch.float32, device=dy2.device) if with_bias else None
+    nv.call("ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), nv.ptr(db_part), nv.stream())
+    dw = slice_sum(part)
+    db = colsum_f32(db_part) if with_bias else None
+    return dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b in the autocast dtype.  dW = dY^T X contracts over all B*N tokens with a
     [out, in] result of a few tiles: left to a single library GEMM it occupies ~9 of 256 CUs
@@ -1146,7 +1177,15 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _mm_out(dy2, wl, xdtype).view(xshape)
-        if ctx.needs_input_grad[1]:
+        need_w, need_b = ctx.needs_input_grad[1], (bdtype is not None and ctx.needs_input_grad[2])
+        if need_w and USE_WGRAD and wgrad_supported(dy2, xl):
+            # one pass over dY and X: weight gradient (+ bias gradient riding along) -- ea_wgrad
+            dw, db32 = wgrad(dy2, xl, need_b)
+            dw = dw.to(wdtype)
+            if need_b:
+                db = db32.to(bdtype)
+            return dx, dw, db, None
+        if need_w:
             rows = xl.shape[0]
             S = _split_k(rows)
             if S > 1:
@@ -1158,7 +1197,7 @@ class LinearFn(torch.autograd.Function):
                 dw = dw.to(wdtype)
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
-        if bdtype is not None and ctx.needs_input_grad[2]:
+        if need_b:
             db = bias_grad(dy2).to(bdtype)
         return dx, dw, db, None
 

@@ -400,6 +400,17 @@ int ea_rows_mlp_bwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
                     const float* zhat, const float* rstd, float* dx0, float* dx1,
                     float* feed, float* dW_part, void* stream);
 
+/* Weight and bias gradient of a projection in one pass over the activations (ea_wgrad.hip): the autograd
+ * of `qkv = self.qkv(x)` / `x = self.proj(x)` (abstract_attention.py:72-78,86-87) with respect to the
+ * Linear's parameters.  dy [rows, out_features], x [rows, in_features]: contiguous, EA_BF16 / EA_F16;
+ * out_features and in_features multiples of 64 (EA_E_UNSUPPORTED otherwise).
+ *   dw_part [S, out_features, in_features] fp32, db_part [S, out_features] fp32 or NULL,
+ *   S = ea_wgrad_parts(rows, out_features, in_features): per-token-slice partial sums; the caller adds
+ *   the S slices (ea_slice_sum / ea_colsum_f32: fixed order, deterministic). */
+int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
+int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
+             float* dw_part, float* db_part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,3 +122,28 @@ def test_rows_mlp_matches_fp64(R, D, sides, ln):
         if ln:
             close(vec[1, s], g.grad, "dgamma")
             close(vec[2, s], c.grad, "dbeta")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,M,K", [(100352, 576, 192), (100352, 192, 192), (25088, 576, 192), (4096, 1536, 512),
+                                      (1000, 64, 64), (777, 128, 320), (294912, 192, 64), (65, 960, 320)])
+def test_wgrad_matches_fp64(rows, M, K, dtype):
+    """ea_wgrad (weight + bias gradient of a projection in one pass) against fp64 on the same bf16/fp16 data:
+    fp32 accumulation of exact products -> error far below one operand ulp of the result; deterministic."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(rows + M + K)
+    dy = (torch.randn(rows, M, device="cuda", generator=g) * 0.5 + 0.1).to(td)
+    x = torch.randn(rows, K, device="cuda", generator=g).to(td)
+    assert _ops.wgrad_supported(dy, x)
+    dw, db = _ops.wgrad(dy, x, True)
+    assert dw.shape == (M, K) and db.shape == (M,) and dw.dtype == torch.float32
+    ref = dy.double().t() @ x.double()
+    refb = dy.double().sum(0)
+    scale = (dy.double().abs().t() @ x.double().abs())
+    assert bool(((dw.double() - ref).abs() <= 4e-6 * scale + 1e-6).all()), float((dw.double() - ref).abs().max())
+    assert bool(((db.double() - refb).abs() <= 4e-6 * dy.double().abs().sum(0) + 1e-6).all())
+    dw2, db2 = _ops.wgrad(dy, x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
