@@ -54,6 +54,7 @@ class NestedNamespace(argparse.Namespace):
         self.__dict__[head] = child
 
 
+from . import _dispatch  # noqa: E402,F401  (registers torch.ops.ea.*)
 from .abstract_attention import MultiheadAttention  # noqa: E402
 from .local_attention import LocalAttention  # noqa: E402
 from .kernelized_attention import KernelizedAttention  # noqa: E402

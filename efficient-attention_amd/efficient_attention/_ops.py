@@ -210,30 +210,62 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
 # ------------------------------------------------------------------------------------------
 # local window attention  (reference local_attention.py:134-182)
 # ------------------------------------------------------------------------------------------
+def _opt(t):
+    """Dispatcher ops carry `None` tensors of a Tensor[] as empty tensors."""
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _e(t, like):
+    return like.new_empty(0) if t is None else t
+
+
+def local_fwd_impl(qkv5, bias, mask_u8, geo):
+    """torch.ops.ea.local_fwd: geo = [attn_2d, s0, s1, window, ext] -> [out, lse, bias_padded | empty]."""
+    nv.require_cuda(qkv5, "qkv")
+    B, N, _, h, d = qkv5.shape
+    attn_2d, s0, s1, window, ext = [int(v) for v in geo]
+    geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), bool(attn_2d), (s0, s1) if attn_2d else (s0,), window, ext, 0, 0)
+    bias_p = _bias_padded(bias, geom)
+    out, lse = _window_fwd(geom, qkv5, None, None, bias_p, mask_u8)
+    return [out, lse, _e(bias_p, lse)]
+
+
+def local_bwd_impl(dout, dlse, qkv5, bias_p, mask_u8, out, lse, geo, bias_cols):
+    """torch.ops.ea.local_bwd -> [dqkv, dbias | empty]."""
+    B, N, _, h, d = qkv5.shape
+    attn_2d, s0, s1, window, ext = [int(v) for v in geo]
+    geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), bool(attn_2d), (s0, s1) if attn_2d else (s0,), window, ext, 0, 0)
+    dqkv5 = torch.empty_like(qkv5)
+    _, _, dbias = _window_bwd(geom, qkv5, None, None, bias_p, mask_u8, out, dout.contiguous(), lse, dqkv5,
+                              dlse=None if dlse is None else dlse.float().contiguous())
+    if dbias is not None:
+        dbias = dbias[..., :bias_cols]
+    return [dqkv5, _e(dbias, lse)]
+
+
+def _geo(attn_2d, seq_shape, window, ext):
+    seq_shape = tuple(int(v) for v in seq_shape)
+    return [1 if attn_2d else 0, seq_shape[0], seq_shape[1] if len(seq_shape) > 1 else 0, int(window), int(ext)]
+
+
 class LocalAttnFn(torch.autograd.Function):
-    """out[B,N,h,d] = per-window softmax(s QK^T + bias, -5e4 mask) V on a fused qkv tensor."""
+    """out[B,N,h,d] = per-window softmax(s QK^T + bias, -5e4 mask) V on a fused qkv tensor
+    (torch.ops.ea.local_fwd / local_bwd)."""
 
     @staticmethod
     def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
-        nv.require_cuda(qkv5, "qkv")
-        B, N, _, h, d = qkv5.shape
-        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, 0, 0)
-        bias_p = _bias_padded(bias, geom)
-        out, lse = _window_fwd(geom, qkv5, None, None, bias_p, mask_u8)
-        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out)
-        ctx.geom = geom
-        ctx.bias_cols = None if bias is None else bias.shape[-1]
+        geo = _geo(attn_2d, seq_shape, window, ext)
+        out, lse, bias_p = torch.ops.ea.local_fwd(qkv5, bias, mask_u8, geo)
+        ctx.save_for_backward(qkv5, _opt(bias_p), mask_u8, lse, out)
+        ctx.geo = geo
+        ctx.bias_cols = 0 if bias is None else bias.shape[-1]
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
-        dqkv5 = torch.empty_like(qkv5)
-        _, _, dbias = _window_bwd(ctx.geom, qkv5, None, None, bias_p, mask_u8, out,
-                                  dout.contiguous(), lse, dqkv5)
-        if dbias is not None:
-            dbias = dbias[..., :ctx.bias_cols]
-        return dqkv5, dbias, None, None, None, None, None
+        dqkv5, dbias = torch.ops.ea.local_bwd(dout, None, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
+        return dqkv5, _opt(dbias), None, None, None, None, None
 
 
 class LocalAttnLseFn(torch.autograd.Function):
@@ -242,182 +274,197 @@ class LocalAttnLseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
-        nv.require_cuda(qkv5, "qkv")
-        B, N, _, h, d = qkv5.shape
-        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, 0, 0)
-        bias_p = _bias_padded(bias, geom)
-        out, lse = _window_fwd(geom, qkv5, None, None, bias_p, mask_u8)
-        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out)
-        ctx.geom = geom
-        ctx.bias_cols = None if bias is None else bias.shape[-1]
+        geo = _geo(attn_2d, seq_shape, window, ext)
+        out, lse, bias_p = torch.ops.ea.local_fwd(qkv5, bias, mask_u8, geo)
+        ctx.save_for_backward(qkv5, _opt(bias_p), mask_u8, lse, out)
+        ctx.geo = geo
+        ctx.bias_cols = 0 if bias is None else bias.shape[-1]
         return out, lse.clone()
 
     @staticmethod
     def backward(ctx, dout, dlse):
         qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
-        dqkv5 = torch.empty_like(qkv5)
-        _, _, dbias = _window_bwd(ctx.geom, qkv5, None, None, bias_p, mask_u8, out, dout.contiguous(), lse, dqkv5,
-                                  dlse=dlse.float().contiguous())
-        if dbias is not None:
-            dbias = dbias[..., :ctx.bias_cols]
-        return dqkv5, dbias, None, None, None, None, None
+        dqkv5, dbias = torch.ops.ea.local_bwd(dout, dlse, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
+        return dqkv5, _opt(dbias), None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------
 # EVA  (reference eva.py:145-227)
 # ------------------------------------------------------------------------------------------
+def _eva_cfg(qkv5, icfg, fcfg, adaptive_proj):
+    attn_2d, s0, s1, window, ext, chunk, L, causal = [int(v) for v in icfg[:8]]
+    mu_scale, keep_scale = [float(v) for v in fcfg]
+    B, N, _, h, d = qkv5.shape
+    geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), bool(attn_2d), (s0, s1) if attn_2d else (s0,), window, ext,
+                        chunk, L, causal)
+    fused_mu = adaptive_proj == "default" and L <= 64 and d in (32, 64) and mu_scale == 0.5
+    return geom, L, mu_scale, keep_scale, fused_mu
+
+
+def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, mlp_params):
+    """torch.ops.ea.eva_fwd: chunk means -> mu MLP -> omega -> beta -> window attention with control-variate
+    columns (eva.py:145-227).  icfg = [attn_2d, s0, s1, window, ext, chunk, L, causal(, keep_for_backward = 1)],
+    fcfg = [mu_scale, keep_scale].  -> [out, bias_padded, lse, qmean, kmean, omega, beta, rf_k_bar, noise, lmk_saved, zhat, rstd]
+    (absent tensors are empty)."""
+    nv.require_cuda(qkv5, "qkv")
+    geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
+    need_grad = len(icfg) < 9 or bool(icfg[8])
+    B, N, _, h, d = qkv5.shape
+    dev = qkv5.device
+    q, k, v = _qkv_views(qkv5)
+    tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+    qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
+    kmean = torch.empty_like(qmean)
+    nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+            nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
+    ps = [p.detach().float().contiguous() for p in mlp_params]
+    noise_c = saved = zhat = rstd = None
+    if fused_mu:
+        # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
+        lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
+        global LAST_LMK_GEOM
+        LAST_LMK_GEOM = (B * h, L, L, d, 1, 0, 1)
+        noise_c = None if noise is None else noise.float().contiguous()
+        omega = torch.empty_like(qmean)
+        rf_k_bar = torch.empty_like(qmean)
+        saved = _lmk_saved(lg, dev) if need_grad else None
+        nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
+                *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(omega), nv.ptr(rf_k_bar), None, None,
+                nv.ptr(saved), nv.stream())
+    else:
+        # Linear (+ LayerNorm) of both sides in one exact-fp32 HIP pass (ea_rows_mlp_fwd)
+        sides = 1 if adaptive_proj == "none" else 2
+        ln = adaptive_proj != "no-ln"
+        per = 4 if ln else 2
+        side_p = [ps[i * per:(i + 1) * per] for i in range(sides)]          # (W, b[, gamma, beta]) per side
+        xs = [qmean, kmean] if sides == 2 else [kmean]
+        ys = [torch.empty_like(kmean) for _ in range(sides)]
+        R = B * h * L
+        if ln and need_grad:
+            zhat = torch.empty((sides, R, d), dtype=torch.float32, device=dev)
+            rstd = torch.empty((sides, R), dtype=torch.float32, device=dev)
+
+        def pick(i):                                                      # i-th tensor of each side
+            col = [sp[i] if i < len(sp) else None for sp in side_p] + [None]
+            return [nv.ptr(col[0]), nv.ptr(col[1])]
+        nv.call("ea_rows_mlp_fwd", R, d, sides, 1 if ln else 0,
+                nv.ptr(xs[0]), nv.ptr(xs[1] if sides == 2 else None), *pick(0), *pick(1), *pick(2), *pick(3),
+                nv.ptr(ys[0]), nv.ptr(ys[1] if sides == 2 else None), nv.ptr(zhat), nv.ptr(rstd), nv.stream())
+        rf_k_bar = ys[-1]
+        mu = mu_scale * (ys[0] + ys[1]) if sides == 2 else torch.zeros_like(rf_k_bar)
+        omega = (mu if noise is None else mu + noise.float()).contiguous()
+    beta = torch.empty_like(qmean)
+    nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+            nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
+    bias_p = _bias_padded(bias, geom)
+    out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, keep, keep_scale)
+    e = lse
+    return [out, _e(bias_p, e), lse, qmean, kmean, omega, beta, rf_k_bar, _e(noise_c, e), _e(saved, e), _e(zhat, e),
+            _e(rstd, e)]
+
+
+def eva_bwd_impl(dout, qkv5, mask_u8, keep, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params):
+    """torch.ops.ea.eva_bwd -> [dqkv, dbias | empty, *parameter gradients (fp32, in the order of mlp_params)]."""
+    geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
+    bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, noise_c, saved, zhat, rstd = [_opt(t) for t in saved_list]
+    B, N, _, h, d = qkv5.shape
+    dqkv5 = torch.empty_like(qkv5)
+    d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
+                                       _rows_contiguous(dout), lse, dqkv5, keep, keep_scale)
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    tk, tv, tdq, tdk, tdv = nv.t4(k), nv.t4(v), nv.t4(dq), nv.t4(dk), nv.t4(dv)
+    d_omega = torch.empty_like(omega)
+    d_beta = d_beta.contiguous()
+    nv.call("ea_eva_beta_bwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
+            nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
+            ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
+    ps = [p.detach().float().contiguous() for p in mlp_params]
+    if dbias is not None:
+        dbias = dbias[..., :bias_cols]
+    if fused_mu:
+        lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
+        dqm = torch.empty_like(qmean)
+        dkm = torch.empty_like(kmean)
+        dW = torch.empty((lg.BH, 2, d, d), dtype=torch.float32, device=qmean.device)
+        dvec = torch.empty((lg.BH, 2, 3, d), dtype=torch.float32, device=qmean.device)
+        nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
+                *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(d_omega), nv.ptr(d_rfk.contiguous()),
+                None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
+        nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
+                nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+        dWs = colsum_f32(dW.view(lg.BH, -1)).view(2, d, d)
+        dvs = colsum_f32(dvec.view(lg.BH, -1)).view(2, 3, d)
+        raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+        return [dqkv5, _e(dbias, lse)] + raw
+    # mu networks backward (ea_rows_mlp_bwd): dz, dx = d(chunk means), per-workgroup dW partials
+    # and the feed buffer whose column sums are the bias / gamma / beta gradients
+    sides = 1 if adaptive_proj == "none" else 2
+    ln = adaptive_proj != "no-ln"
+    per = 4 if ln else 2
+    side_p = [ps[i * per:(i + 1) * per] for i in range(sides)]
+    R = B * h * L
+    d_rfk = d_rfk.contiguous()
+    if sides == 2:
+        d_rq = (mu_scale * d_omega).contiguous()
+        dys = [d_rq, d_rq + d_rfk]
+        xs = [qmean, kmean]
+    else:
+        dys, xs = [d_rfk], [kmean]
+    dxs = [torch.empty_like(kmean) for _ in range(sides)]
+    planes = 3 if ln else 1
+    parts = nv.lib().ea_rows_mlp_parts(R, d)
+    feed = torch.empty((R, planes, sides, d), dtype=torch.float32, device=kmean.device)
+    dW_part = torch.empty((parts, sides, d, d), dtype=torch.float32, device=kmean.device)
+
+    def two(ts):
+        ts = list(ts) + [None]
+        return [nv.ptr(ts[0]), nv.ptr(ts[1])]
+    nv.call("ea_rows_mlp_bwd", R, d, sides, 1 if ln else 0, *two(dys), *two(xs),
+            *two([sp[0] for sp in side_p]), *two([sp[2] if ln else None for sp in side_p]),
+            nv.ptr(zhat), nv.ptr(rstd), *two(dxs), nv.ptr(feed), nv.ptr(dW_part), nv.stream())
+    dkm = dxs[-1]
+    dqm = dxs[0] if sides == 2 else torch.zeros_like(qmean)
+    nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
+            nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+    dW = colsum_f32(dW_part.view(parts, -1)).view(sides, d, d)
+    vec = colsum_f32(feed.view(R, -1)).view(planes, sides, d)
+    raw = []
+    for i in range(sides):
+        raw += [dW[i], vec[0, i]] + ([vec[1, i], vec[2, i]] if ln else [])
+    return [dqkv5, _e(dbias, lse)] + raw
+
+
 class EvaAttnFn(torch.autograd.Function):
-    """EVA core on a fused qkv tensor: chunk means -> mu MLP -> omega -> beta -> window attention
-    with control-variate columns.  Returns out [B,N,h,d].
-    cfg = (attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj[, causal, mu_scale]); the last
-    two select causal_eva.py's geometry/masks (ea_geom.causal) and its mu = rq + rk."""
+    """EVA core on a fused qkv tensor (torch.ops.ea.eva_fwd / eva_bwd): chunk means -> mu MLP -> omega ->
+    beta -> window attention with control-variate columns.  Returns out [B,N,h,d].
+    cfg = (attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj[, causal, mu_scale[, keep, keep_scale]]);
+    causal / mu_scale select causal_eva.py's geometry, masks (ea_geom.causal) and its mu = rq + rk; keep is
+    the uint8 keep mask of the attention dropout (causal_eva only), scaled by keep_scale = 1 / (1 - p)."""
 
     @staticmethod
     def forward(ctx, qkv5, bias, noise, mask_u8, cfg, *mlp_params):
-        nv.require_cuda(qkv5, "qkv")
         attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg[:7]
         causal, mu_scale = cfg[7:9] if len(cfg) > 7 else (0, 0.5)
-        # attention dropout (causal_eva only): uint8 keep mask in the kernel's column layout + 1/(1-p)
         keep, keep_scale = cfg[9:11] if len(cfg) > 9 else (None, 1.0)
-        B, N, _, h, d = qkv5.shape
-        dev = qkv5.device
-        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, chunk, L,
-                            causal)
-        q, k, v = _qkv_views(qkv5)
-        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
-        qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
-        kmean = torch.empty_like(qmean)
-        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
-                nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
-        fused_mu = adaptive_proj == "default" and L <= 64 and d in (32, 64) and mu_scale == 0.5
-        if fused_mu:
-            # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
-            lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
-            global LAST_LMK_GEOM
-            LAST_LMK_GEOM = (B * h, L, L, d, 1, 0, 1)
-            ps = [p.float().contiguous() for p in mlp_params]
-            noise_c = None if noise is None else noise.float().contiguous()
-            omega = torch.empty_like(qmean)
-            rf_k_bar = torch.empty_like(qmean)
-            saved = _lmk_saved(lg, qmean.device) if any(ctx.needs_input_grad) else None
-            nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
-                    *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(omega), nv.ptr(rf_k_bar), None, None,
-                    nv.ptr(saved), nv.stream())
-            ctx.lmk = (lg, noise_c, saved)
-        else:
-            # Linear (+ LayerNorm) of both sides in one exact-fp32 HIP pass (ea_rows_mlp_fwd)
-            sides = 1 if adaptive_proj == "none" else 2
-            ln = adaptive_proj != "no-ln"
-            ps = [p.float().contiguous() for p in mlp_params]
-            per = 4 if ln else 2
-            side_p = [ps[i * per:(i + 1) * per] for i in range(sides)]          # (W, b[, gamma, beta]) per side
-            xs = [qmean, kmean] if sides == 2 else [kmean]
-            ys = [torch.empty_like(kmean) for _ in range(sides)]
-            R = B * h * L
-            zhat = rstd = None
-            if ln and any(ctx.needs_input_grad):
-                zhat = torch.empty((sides, R, d), dtype=torch.float32, device=dev)
-                rstd = torch.empty((sides, R), dtype=torch.float32, device=dev)
-
-            def pick(i):                                                      # i-th tensor of each side
-                col = [sp[i] if i < len(sp) else None for sp in side_p] + [None]
-                return [nv.ptr(col[0]), nv.ptr(col[1])]
-            nv.call("ea_rows_mlp_fwd", R, d, sides, 1 if ln else 0,
-                    nv.ptr(xs[0]), nv.ptr(xs[1] if sides == 2 else None), *pick(0), *pick(1), *pick(2), *pick(3),
-                    nv.ptr(ys[0]), nv.ptr(ys[1] if sides == 2 else None), nv.ptr(zhat), nv.ptr(rstd), nv.stream())
-            rf_k_bar = ys[-1]
-            with torch.no_grad():
-                mu = mu_scale * (ys[0] + ys[1]) if sides == 2 else torch.zeros_like(rf_k_bar)
-                omega = (mu if noise is None else mu + noise.float()).contiguous()
-            ctx.mu_mlp = (sides, ln, zhat, rstd, side_p)
-            ctx.lmk = None
-        beta = torch.empty_like(qmean)
-        nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
-                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
-        bias_p = _bias_padded(bias, geom)
-        out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, keep, keep_scale)
-        ctx.save_for_backward(qkv5, bias_p, mask_u8, lse, out, qmean, kmean, omega, beta, rf_k_bar,
-                              *mlp_params)
-        ctx.keep = (keep, keep_scale)
-        ctx.geom = geom
-        ctx.adaptive_proj = adaptive_proj
-        ctx.mu_scale = mu_scale
-        ctx.bias_cols = None if bias is None else bias.shape[-1]
-        return out
+        icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), int(causal), int(any(ctx.needs_input_grad))]
+        fcfg = [float(mu_scale), float(keep_scale)]
+        outs = torch.ops.ea.eva_fwd(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
+        ctx.save_for_backward(qkv5, mask_u8, keep, *outs, *mlp_params)
+        ctx.nsaved = len(outs) - 1
+        ctx.cfg = (icfg, fcfg, adaptive_proj, 0 if bias is None else bias.shape[-1])
+        ctx.pdtypes = [p.dtype for p in mlp_params]
+        return outs[0]
 
     @staticmethod
     def backward(ctx, dout):
-        (qkv5, bias_p, mask_u8, lse, out, qmean, kmean, omega, beta, rf_k_bar,
-         *mlp_params) = ctx.saved_tensors
-        geom = ctx.geom
-        dqkv5 = torch.empty_like(qkv5)
-        d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
-                                           _rows_contiguous(dout), lse, dqkv5, *ctx.keep)
-        q, k, v = _qkv_views(qkv5)
-        dq, dk, dv = _qkv_views(dqkv5)
-        tk, tv, tdq, tdk, tdv = nv.t4(k), nv.t4(v), nv.t4(dq), nv.t4(dk), nv.t4(dv)
-        d_omega = torch.empty_like(omega)
-        d_beta = d_beta.contiguous()
-        nv.call("ea_eva_beta_bwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
-                nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
-                ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
-        if ctx.lmk is not None:
-            lg, noise_c, saved = ctx.lmk
-            L_, d_ = lg.L, lg.D
-            ps = [p.float().contiguous() for p in mlp_params]
-            dqm = torch.empty_like(qmean)
-            dkm = torch.empty_like(kmean)
-            dW = torch.empty((lg.BH, 2, d_, d_), dtype=torch.float32, device=qmean.device)
-            dvec = torch.empty((lg.BH, 2, 3, d_), dtype=torch.float32, device=qmean.device)
-            nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(qmean), nv.ptr(kmean),
-                    *[nv.ptr(t) for t in ps], nv.ptr(noise_c), nv.ptr(d_omega), nv.ptr(d_rfk.contiguous()),
-                    None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
-            nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
-                    nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
-            dWs = colsum_f32(dW.view(lg.BH, -1)).view(2, d_, d_)
-            dvs = colsum_f32(dvec.view(lg.BH, -1)).view(2, 3, d_)
-            raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
-            pgrads = [g.to(p.dtype) for g, p in zip(raw, mlp_params)]
-            if dbias is not None:
-                dbias = dbias[..., :ctx.bias_cols]
-            return (dqkv5, dbias, None, None, None) + tuple(pgrads)
-        # mu networks backward (ea_rows_mlp_bwd): dz, dx = d(chunk means), per-workgroup dW partials
-        # and the feed buffer whose column sums are the bias / gamma / beta gradients
-        sides, ln, zhat, rstd, side_p = ctx.mu_mlp
-        B_, h_, L_, d_ = kmean.shape
-        R = B_ * h_ * L_
-        d_rfk = d_rfk.contiguous()
-        if sides == 2:
-            d_rq = (ctx.mu_scale * d_omega).contiguous()
-            dys = [d_rq, d_rq + d_rfk]
-            xs = [qmean, kmean]
-        else:
-            dys, xs = [d_rfk], [kmean]
-        dxs = [torch.empty_like(kmean) for _ in range(sides)]
-        planes = 3 if ln else 1
-        parts = nv.lib().ea_rows_mlp_parts(R, d_)
-        feed = torch.empty((R, planes, sides, d_), dtype=torch.float32, device=kmean.device)
-        dW_part = torch.empty((parts, sides, d_, d_), dtype=torch.float32, device=kmean.device)
-
-        def two(ts):
-            ts = list(ts) + [None]
-            return [nv.ptr(ts[0]), nv.ptr(ts[1])]
-        nv.call("ea_rows_mlp_bwd", R, d_, sides, 1 if ln else 0, *two(dys), *two(xs),
-                *two([sp[0] for sp in side_p]), *two([sp[2] if ln else None for sp in side_p]),
-                nv.ptr(zhat), nv.ptr(rstd), *two(dxs), nv.ptr(feed), nv.ptr(dW_part), nv.stream())
-        dkm = dxs[-1]
-        dqm = dxs[0] if sides == 2 else torch.zeros_like(qmean)
-        nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
-                nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
-        dW = colsum_f32(dW_part.view(parts, -1)).view(sides, d_, d_)
-        vec = colsum_f32(feed.view(R, -1)).view(planes, sides, d_)
-        raw = []
-        for i in range(sides):
-            raw += [dW[i], vec[0, i]] + ([vec[1, i], vec[2, i]] if ln else [])
-        pgrads = [g.to(p.dtype) for g, p in zip(raw, mlp_params)]
-        if dbias is not None:
-            dbias = dbias[..., :ctx.bias_cols]
-        return (dqkv5, dbias, None, None, None) + tuple(pgrads)
+        qkv5, mask_u8, keep, out, *rest = ctx.saved_tensors
+        saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
+        icfg, fcfg, adaptive_proj, bias_cols = ctx.cfg
+        g = torch.ops.ea.eva_bwd(dout, qkv5, mask_u8, keep, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols,
+                                 list(params))
+        pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
+        return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
 
 
 # ------------------------------------------------------------------------------------------
@@ -703,79 +750,109 @@ class LaraAttnFn(torch.autograd.Function):
                 d_lp.view(B, h, C), None, None, None)
 
 
+def _lara_cfg(qkv5, icfg, fcfg):
+    H, W, r, has_mlp, mixed, mis, dup = [int(v) for v in icfg[:7]]
+    kappa, scale = [float(v) for v in fcfg]
+    B, N, _, h, d = qkv5.shape
+    L = (H // r) * (W // r)
+    C = L * (2 if dup else 1)
+    io = nv.io_dtype(qkv5)
+    pgeom = nv.make_geom(B, h, N, d, io, True, (H, W), r, 0, r, L)
+    lg = nv.ea_lmk_geom(B * h, L, C, d, has_mlp, mixed, mis, dup, scale, 0)
+    geom = nv.ea_lara_geom(B, h, N, d, io, C, mis, kappa, scale)
+    return (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom
+
+
+def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
+    """torch.ops.ea.lara_fwd: uniform r x r pooling of q, k -> fused landmark pipeline -> estimator.
+    icfg = [H, W, r, has_mlp, mixed, mis, dup(, keep_for_backward = 1)], fcfg = [kappa, scale], params = (Wq,
+    bq, gq, cq, Wk, bk, gk, ck) when has_mlp.  -> [out, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise, lmk_saved]
+    (absent tensors are empty)."""
+    nv.require_cuda(qkv5, "qkv")
+    (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
+    need_grad = len(icfg) < 8 or bool(icfg[7])
+    B, N, _, h, d = qkv5.shape
+    BH, dev = B * h, qkv5.device
+    q, k, _ = _qkv_views(qkv5)
+    tq, tk = nv.t4(q), nv.t4(k)
+    pq = torch.empty((BH, L, d), dtype=torch.float32, device=dev)
+    pk = torch.empty_like(pq)
+    nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
+            nv.ptr(pq), nv.ptr(pk), nv.stream())
+    noise_c = None if noise is None else noise.float().contiguous()
+    ps = [t.detach().float().contiguous() for t in params]
+    global LAST_LMK_GEOM
+    LAST_LMK_GEOM = (BH, L, C, d, has_mlp, mixed, 0)
+    omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+    qrows = torch.empty_like(omega) if mis != 2 else None
+    bhv = torch.empty((BH, C), dtype=torch.float32, device=dev) if mis == 0 else None
+    lp = torch.empty((BH, C), dtype=torch.float32, device=dev)
+    pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+    saved = _lmk_saved(lg, dev) if need_grad else None
+    nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+            nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
+    out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp)
+    e = lp
+    return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(noise_c, e), _e(saved, e)]
+
+
+def lara_bwd_impl(dout, qkv5, mask_u8, saved_list, icfg, fcfg, params):
+    """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)]."""
+    (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
+    omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved = [_opt(t) for t in saved_list]
+    B, N, _, h, d = qkv5.shape
+    BH, dev = B * h, qkv5.device
+    ps = [t.detach().float().contiguous() for t in params]
+    dout = dout.contiguous()
+    dqkv5 = torch.empty_like(qkv5)
+    d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
+                                                       cst, kv, lse_k, lse_t)
+    dpq = torch.empty_like(pq)
+    dpk = torch.empty_like(pk)
+    dW = dvec = None
+    if has_mlp:
+        dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
+        dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
+    pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
+    nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+            nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+            nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
+    _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
+    grads = [dqkv5]
+    if has_mlp:
+        dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
+        grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+    return grads
+
+
 class LaraPooledFn(torch.autograd.Function):
     """The whole 2-D LARA core as ONE autograd node (no gradient side channels between nodes): uniform
     r x r average pooling of q, k (lara.py:43,48,145-151) -> fused landmark pipeline (:45-54,157-198,
-    214-238) -> estimator (:201-246).  cfg = (H, W, r, has_mlp, mixed, mis, dup, kappa, scale);
-    params = (Wq, bq, gq, cq, Wk, bk, gk, ck) when has_mlp.  Returns out [B,N,h,d].
+    214-238) -> estimator (:201-246), through the dispatcher ops torch.ops.ea.lara_fwd / lara_bwd.
+    cfg = (H, W, r, has_mlp, mixed, mis, dup, kappa, scale); params = (Wq, bq, gq, cq, Wk, bk, gk, ck)
+    when has_mlp.  Returns out [B,N,h,d].
     Backward: one fused pass per side, the landmark backward, and ONE finish pass that applies the
     softmax-over-sequence correction of dq together with the pooling backward of dq and dk."""
 
     @staticmethod
     def forward(ctx, qkv5, mask_u8, noise, cfg, *params):
         H, W, r, has_mlp, mixed, mis, dup, kappa, scale = cfg
-        nv.require_cuda(qkv5, "qkv")
-        B, N, _, h, d = qkv5.shape
-        L = (H // r) * (W // r)
-        C = L * (2 if dup else 1)
-        BH, dev = B * h, qkv5.device
-        io = nv.io_dtype(qkv5)
-        pgeom = nv.make_geom(B, h, N, d, io, True, (H, W), r, 0, r, L)
-        q, k, _ = _qkv_views(qkv5)
-        tq, tk = nv.t4(q), nv.t4(k)
-        pq = torch.empty((BH, L, d), dtype=torch.float32, device=dev)
-        pk = torch.empty_like(pq)
-        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
-                nv.ptr(pq), nv.ptr(pk), nv.stream())
-        noise_c = None if noise is None else noise.float().contiguous()
-        ps = [t.detach().float().contiguous() for t in params]
-        lg = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale), 0)
-        global LAST_LMK_GEOM
-        LAST_LMK_GEOM = (BH, L, C, d, int(has_mlp), int(mixed), 0)
-        omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
-        qrows = torch.empty_like(omega) if mis != 2 else None
-        bhv = torch.empty((BH, C), dtype=torch.float32, device=dev) if mis == 0 else None
-        lp = torch.empty((BH, C), dtype=torch.float32, device=dev)
-        pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
-        need_grad = any(ctx.needs_input_grad)
-        saved = _lmk_saved(lg, dev) if need_grad else None
-        nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
-        geom = nv.ea_lara_geom(B, h, N, d, io, C, mis, float(kappa), float(scale))
-        out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp)
-        ctx.save_for_backward(qkv5, mask_u8, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved, *ps)
-        ctx.geom, ctx.lg, ctx.cfg = geom, lg, cfg
+        icfg = [int(H), int(W), int(r), int(bool(has_mlp)), int(bool(mixed)), int(mis), int(dup),
+                int(any(ctx.needs_input_grad))]
+        fcfg = [float(kappa), float(scale)]
+        outs = torch.ops.ea.lara_fwd(qkv5, mask_u8, noise, icfg, fcfg, list(params))
+        ctx.save_for_backward(qkv5, mask_u8, *outs[1:], *params)
+        ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
         ctx.pdtypes = [t.dtype for t in params]
-        return out
+        return outs[0]
 
     @staticmethod
     def backward(ctx, dout):
-        qkv5, mask_u8, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved, *ps = ctx.saved_tensors
-        geom, lg = ctx.geom, ctx.lg
-        H, W, r, has_mlp, mixed, mis, dup, kappa, scale = ctx.cfg
-        B, N, _, h, d = qkv5.shape
-        BH, dev = B * h, qkv5.device
-        dout = dout.contiguous()
-        dqkv5 = torch.empty_like(qkv5)
-        d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
-                                                           cst, kv, lse_k, lse_t)
-        dpq = torch.empty_like(pq)
-        dpk = torch.empty_like(pk)
-        dW = dvec = None
-        if has_mlp:
-            dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
-            dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
-        pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
-        nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-                nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
-                nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
-        _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
-        pgrads = []
-        if has_mlp:
-            dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
-            raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
-            pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
-        return (dqkv5, None, None, None) + tuple(pgrads)
+        qkv5, mask_u8, *rest = ctx.saved_tensors
+        saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
+        grads = torch.ops.ea.lara_bwd(dout, qkv5, mask_u8, list(saved), ctx.icfg, ctx.fcfg, list(params))
+        pgrads = [g.to(dt) for g, dt in zip(grads[1:], ctx.pdtypes)]
+        return (grads[0], None, None, None) + tuple(pgrads)
 
 
 def _lmk_saved(geom, device):
@@ -896,40 +973,52 @@ def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode,
 # ------------------------------------------------------------------------------------------
 # softmax baseline  (reference abstract_attention.py:120-133)
 # ------------------------------------------------------------------------------------------
+def softmax_fwd_impl(qkv5, mask_u8, keep, keep_scale):
+    """torch.ops.ea.softmax_fwd -> [out [B,N,h,d], lse [B*h,N]]."""
+    nv.require_cuda(qkv5, "qkv")
+    B, N, _, h, d = qkv5.shape
+    q, k, v = _qkv_views(qkv5)
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
+    lse = torch.empty((B * h, N), dtype=torch.float32, device=qkv5.device)
+    tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
+    nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(tq),
+            ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse),
+            nv.ptr(keep), float(keep_scale), 0, nv.stream())
+    return [out, lse]
+
+
+def softmax_bwd_impl(dout, qkv5, mask_u8, out, lse, keep, keep_scale):
+    """torch.ops.ea.softmax_bwd -> dqkv [B,N,3,h,d]."""
+    B, N, _, h, d = qkv5.shape
+    dout = dout.contiguous()
+    dqkv5 = torch.empty_like(qkv5)
+    delta = torch.empty_like(lse)
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
+    nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(ts[0]),
+            ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8), ctypes.byref(ts[3]),
+            ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
+            ctypes.byref(ts[7]), nv.ptr(keep), float(keep_scale), 0, nv.stream())
+    return dqkv5
+
+
 class SoftmaxAttnFn(torch.autograd.Function):
     """out[B,N,h,d] = dropout(softmax(s QK^T, -inf on padded keys)) V on a fused qkv tensor; keep: None
-    or the uint8 keep decisions [B,h,N,64*ceil(N/64)] of the attention dropout, scaled by keep_scale."""
+    or the uint8 keep decisions [B,h,N,64*ceil(N/64)] of the attention dropout, scaled by keep_scale
+    (torch.ops.ea.softmax_fwd / softmax_bwd)."""
 
     @staticmethod
     def forward(ctx, qkv5, mask_u8, keep=None, keep_scale=1.0):
-        nv.require_cuda(qkv5, "qkv")
-        B, N, _, h, d = qkv5.shape
-        q, k, v = _qkv_views(qkv5)
-        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
-        lse = torch.empty((B * h, N), dtype=torch.float32, device=qkv5.device)
-        tq, tk, tv, to = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(out.permute(0, 2, 1, 3))
-        nv.call("ea_softmax_attn_fwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(tq),
-                ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), ctypes.byref(to), nv.ptr(lse),
-                nv.ptr(keep), float(keep_scale), 0, nv.stream())
+        out, lse = torch.ops.ea.softmax_fwd(qkv5, mask_u8, keep, float(keep_scale))
         ctx.save_for_backward(qkv5, mask_u8, out, lse, keep)
-        ctx.keep_scale = keep_scale
+        ctx.keep_scale = float(keep_scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv5, mask_u8, out, lse, keep = ctx.saved_tensors
-        B, N, _, h, d = qkv5.shape
-        dout = dout.contiguous()
-        dqkv5 = torch.empty_like(qkv5)
-        delta = torch.empty_like(lse)
-        q, k, v = _qkv_views(qkv5)
-        dq, dk, dv = _qkv_views(dqkv5)
-        ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
-        nv.call("ea_softmax_attn_bwd", B, h, N, d, nv.io_dtype(qkv5), float(d) ** -0.5, ctypes.byref(ts[0]),
-                ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8), ctypes.byref(ts[3]),
-                ctypes.byref(ts[4]), nv.ptr(lse), nv.ptr(delta), ctypes.byref(ts[5]), ctypes.byref(ts[6]),
-                ctypes.byref(ts[7]), nv.ptr(keep), float(ctx.keep_scale), 0, nv.stream())
-        return dqkv5, None, None, None
+        return torch.ops.ea.softmax_bwd(dout, qkv5, mask_u8, out, lse, keep, ctx.keep_scale), None, None, None
 
 
 class SoftmaxQKVFn(torch.autograd.Function):
@@ -985,65 +1074,78 @@ def softmax_sample(q, k):
 # ------------------------------------------------------------------------------------------
 # Performer / FAVOR+  (reference kernelized_attention.py:20-56,116-121,326-346)
 # ------------------------------------------------------------------------------------------
+def performer_fwd_impl(qkv5, mask_u8, W):
+    """torch.ops.ea.performer_fwd -> [out, stab [BH], kv [BH,m,d], ksum [BH,m]]."""
+    nv.require_cuda(qkv5, "qkv")
+    B, N, _, h, d = qkv5.shape
+    m = W.shape[1]
+    BH, dev = B * h, qkv5.device
+    W = W.float().contiguous()
+    geom = nv.ea_perf_geom(B, h, N, d, nv.io_dtype(qkv5), m)
+    q, k, v = _qkv_views(qkv5)
+    tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+    S = nv.lib().ea_performer_parts(ctypes.byref(geom))
+    p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_kmax", ctypes.byref(geom), ctypes.byref(tk), nv.ptr(W), nv.ptr(p_ml), nv.stream())
+    stab = p_ml[..., 0].amax((1, 2)).contiguous()                     # [BH]
+    p_kv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_kv", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+            nv.ptr(W), nv.ptr(stab), nv.ptr(p_ml), nv.ptr(p_kv), nv.stream())
+    kv = p_kv.sum(1).contiguous()                                     # [BH, m, d]
+    ksum = p_ml[..., 0].sum(1).contiguous()                           # [BH, m]
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+    to = nv.t4(out.permute(0, 2, 1, 3))
+    nv.call("ea_performer_out", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(W), nv.ptr(kv), nv.ptr(ksum),
+            ctypes.byref(to), nv.stream())
+    return [out, stab, kv, ksum]
+
+
+def performer_bwd_impl(dout, qkv5, mask_u8, W, stab, kv, ksum, out):
+    """torch.ops.ea.performer_bwd -> dqkv."""
+    B, N, _, h, d = qkv5.shape
+    m = W.shape[1]
+    W = W.float().contiguous()
+    geom = nv.ea_perf_geom(B, h, N, d, nv.io_dtype(qkv5), m)
+    BH, dev = B * h, qkv5.device
+    dout = dout.contiguous()
+    dqkv5 = torch.empty_like(qkv5)
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+    to, tdo = nv.t4(out.permute(0, 2, 1, 3)), nv.t4(dout.permute(0, 2, 1, 3))
+    tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
+    tok = torch.empty((3, BH, N), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(to), ctypes.byref(tdo),
+            nv.ptr(W), nv.ptr(kv), nv.ptr(ksum), ctypes.byref(tdq), nv.ptr(tok[0]), nv.ptr(tok[1]),
+            nv.ptr(tok[2]), nv.stream())
+    S = nv.lib().ea_performer_parts(ctypes.byref(geom))
+    p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
+    p_dkv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(W),
+            nv.ptr(tok[0]), nv.ptr(tok[1]), nv.ptr(tok[2]), nv.ptr(p_ml), nv.ptr(p_dkv), nv.stream())
+    dkv = p_dkv.sum(1).contiguous()
+    dksum = p_ml[..., 0].sum(1).contiguous()
+    nv.call("ea_performer_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+            nv.ptr(W), nv.ptr(stab), nv.ptr(dkv), nv.ptr(dksum), ctypes.byref(tdk), ctypes.byref(tdv),
+            nv.stream())
+    return dqkv5
+
+
 class PerformerAttnFn(torch.autograd.Function):
     """out[B,N,h,d] = phi(q) (phi(k)^T v) / clamp(phi(q) . sum phi(k), 1e-2) with positive random
-    features W [h, m, d] (no gradient to W: the default sample scheme redraws / fixes it)."""
+    features W [h, m, d] (no gradient to W: the default sample scheme redraws / fixes it)
+    (torch.ops.ea.performer_fwd / performer_bwd)."""
 
     @staticmethod
     def forward(ctx, qkv5, mask_u8, W):
-        nv.require_cuda(qkv5, "qkv")
-        B, N, _, h, d = qkv5.shape
-        m = W.shape[1]
-        BH, dev = B * h, qkv5.device
-        W = W.float().contiguous()
-        geom = nv.ea_perf_geom(B, h, N, d, nv.io_dtype(qkv5), m)
-        q, k, v = _qkv_views(qkv5)
-        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
-        S = nv.lib().ea_performer_parts(ctypes.byref(geom))
-        p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
-        nv.call("ea_performer_kmax", ctypes.byref(geom), ctypes.byref(tk), nv.ptr(W), nv.ptr(p_ml), nv.stream())
-        stab = p_ml[..., 0].amax((1, 2)).contiguous()                     # [BH]
-        p_kv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
-        nv.call("ea_performer_kv", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
-                nv.ptr(W), nv.ptr(stab), nv.ptr(p_ml), nv.ptr(p_kv), nv.stream())
-        kv = p_kv.sum(1).contiguous()                                     # [BH, m, d]
-        ksum = p_ml[..., 0].sum(1).contiguous()                           # [BH, m]
-        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
-        to = nv.t4(out.permute(0, 2, 1, 3))
-        nv.call("ea_performer_out", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(W), nv.ptr(kv), nv.ptr(ksum),
-                ctypes.byref(to), nv.stream())
+        out, stab, kv, ksum = torch.ops.ea.performer_fwd(qkv5, mask_u8, W)
         ctx.save_for_backward(qkv5, mask_u8, W, stab, kv, ksum, out)
-        ctx.geom = geom
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv5, mask_u8, W, stab, kv, ksum, out = ctx.saved_tensors
-        geom = ctx.geom
-        B, N, _, h, d = qkv5.shape
-        m, BH, dev = geom.M, B * h, qkv5.device
-        dout = dout.contiguous()
-        dqkv5 = torch.empty_like(qkv5)
-        q, k, v = _qkv_views(qkv5)
-        dq, dk, dv = _qkv_views(dqkv5)
-        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
-        to, tdo = nv.t4(out.permute(0, 2, 1, 3)), nv.t4(dout.permute(0, 2, 1, 3))
-        tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
-        tok = torch.empty((3, BH, N), dtype=torch.float32, device=dev)
-        nv.call("ea_performer_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(to), ctypes.byref(tdo),
-                nv.ptr(W), nv.ptr(kv), nv.ptr(ksum), ctypes.byref(tdq), nv.ptr(tok[0]), nv.ptr(tok[1]),
-                nv.ptr(tok[2]), nv.stream())
-        S = nv.lib().ea_performer_parts(ctypes.byref(geom))
-        p_ml = torch.empty((BH, S, m, 4), dtype=torch.float32, device=dev)
-        p_dkv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
-        nv.call("ea_performer_bwd_qstats", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(W),
-                nv.ptr(tok[0]), nv.ptr(tok[1]), nv.ptr(tok[2]), nv.ptr(p_ml), nv.ptr(p_dkv), nv.stream())
-        dkv = p_dkv.sum(1).contiguous()
-        dksum = p_ml[..., 0].sum(1).contiguous()
-        nv.call("ea_performer_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
-                nv.ptr(W), nv.ptr(stab), nv.ptr(dkv), nv.ptr(dksum), ctypes.byref(tdk), ctypes.byref(tdv),
-                nv.stream())
-        return dqkv5, None, None
+        return torch.ops.ea.performer_bwd(dout, qkv5, mask_u8, W, stab, kv, ksum, out), None, None
 
 
 def performer_attention(qkv5, mask_u8, proj):
