@@ -29,11 +29,11 @@ _SCHEMAS = {
     "performer_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor W, Tensor stab, Tensor kv, Tensor ksum, "
                      "Tensor out) -> Tensor",
     "lara_fwd": "(Tensor qkv, Tensor? mask, Tensor? noise, int[] icfg, float[] fcfg, Tensor[] params) -> Tensor[]",
-    "lara_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor[] saved, int[] icfg, float[] fcfg, Tensor[] params) "
+    "lara_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor? noise, Tensor[] saved, int[] icfg, float[] fcfg, Tensor[] params) "
                 "-> Tensor[]",
     "eva_fwd": "(Tensor qkv, Tensor? bias, Tensor? noise, Tensor? mask, Tensor? keep, int[] icfg, float[] fcfg, "
                "str adaptive_proj, Tensor[] params) -> Tensor[]",
-    "eva_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor? keep, Tensor out, Tensor[] saved, int[] icfg, float[] fcfg, "
+    "eva_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor? keep, Tensor? noise, Tensor out, Tensor[] saved, int[] icfg, float[] fcfg, "
                "str adaptive_proj, int bias_cols, Tensor[] params) -> Tensor[]",
 }
 _IMPLS = {
@@ -107,12 +107,11 @@ def _(qkv, mask, noise, icfg, fcfg, params):
     return [qkv.new_empty((B, N, h, d)), _f32(qkv, BH, C, d), _f32(qkv, BH, C, d) if mis != 2 else _none(qkv),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, C), _f32(qkv, BH, C, d), _f32(qkv, BH, C),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, L, d), _f32(qkv, BH, L, d),
-            _none(qkv) if noise is None else torch.empty_like(noise, dtype=torch.float32),
-            _f32(qkv, BH * (3 * L * d + L * 64 + 128))]
+            _f32(qkv, BH * (3 * L * d + L * 64 + 128)) if (len(icfg) < 8 or icfg[7]) else _none(qkv)]
 
 
 @torch.library.register_fake("ea::lara_bwd")
-def _(dout, qkv, mask, saved, icfg, fcfg, params):
+def _(dout, qkv, mask, noise, saved, icfg, fcfg, params):
     return [torch.empty_like(qkv)] + [torch.empty_like(p, dtype=torch.float32) for p in params]
 
 
@@ -123,18 +122,18 @@ def _(qkv, bias, noise, mask, keep, icfg, fcfg, adaptive_proj, params):
     lm = _f32(qkv, B, h, L, d)
     bias_p = _none(qkv) if bias is None else _f32(qkv, bias.shape[0], bias.shape[1], -(-bias.shape[2] // 16) * 16)
     fused = adaptive_proj == "default" and L <= 64 and d in (32, 64) and float(fcfg[0]) == 0.5
-    noise_c = torch.empty_like(noise, dtype=torch.float32) if (fused and noise is not None) else _none(qkv)
-    saved = _f32(qkv, B * h * (3 * L * d + L * 64 + 128)) if fused else _none(qkv)
+    need = len(icfg) < 9 or bool(icfg[8])
+    saved = _f32(qkv, B * h * (3 * L * d + L * 64 + 128)) if (fused and need) else _none(qkv)
     sides = 1 if adaptive_proj == "none" else 2
-    ln = (not fused) and adaptive_proj != "no-ln"
+    ln = (not fused) and need and adaptive_proj != "no-ln"
     zhat = _f32(qkv, sides, B * h * L, d) if ln else _none(qkv)
     rstd = _f32(qkv, sides, B * h * L) if ln else _none(qkv)
     return [qkv.new_empty((B, N, h, d)), bias_p, _f32(qkv, B, h, N), lm, torch.empty_like(lm), torch.empty_like(lm),
-            torch.empty_like(lm), torch.empty_like(lm), noise_c, saved, zhat, rstd]
+            torch.empty_like(lm), torch.empty_like(lm), saved, zhat, rstd]
 
 
 @torch.library.register_fake("ea::eva_bwd")
-def _(dout, qkv, mask, keep, out, saved, icfg, fcfg, adaptive_proj, bias_cols, params):
+def _(dout, qkv, mask, keep, noise, out, saved, icfg, fcfg, adaptive_proj, bias_cols, params):
     bias_p = saved[0]
     dbias = _none(qkv) if bias_p.numel() == 0 else _f32(qkv, bias_p.shape[0], bias_p.shape[1], bias_cols)
     return [torch.empty_like(qkv), dbias] + [torch.empty_like(p, dtype=torch.float32) for p in params]

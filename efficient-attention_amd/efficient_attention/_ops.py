@@ -239,7 +239,7 @@ def local_bwd_impl(dout, dlse, qkv5, bias_p, mask_u8, out, lse, geo, bias_cols):
     _, _, dbias = _window_bwd(geom, qkv5, None, None, bias_p, mask_u8, out, dout.contiguous(), lse, dqkv5,
                               dlse=None if dlse is None else dlse.float().contiguous())
     if dbias is not None:
-        dbias = dbias[..., :bias_cols]
+        dbias = dbias[..., :bias_cols].contiguous()
     return [dqkv5, _e(dbias, lse)]
 
 
@@ -359,14 +359,14 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
     bias_p = _bias_padded(bias, geom)
     out, lse = _window_fwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, keep, keep_scale)
     e = lse
-    return [out, _e(bias_p, e), lse, qmean, kmean, omega, beta, rf_k_bar, _e(noise_c, e), _e(saved, e), _e(zhat, e),
-            _e(rstd, e)]
+    return [out, _e(bias_p, e), lse, qmean, kmean, omega, beta, rf_k_bar, _e(saved, e), _e(zhat, e), _e(rstd, e)]
 
 
-def eva_bwd_impl(dout, qkv5, mask_u8, keep, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params):
+def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params):
     """torch.ops.ea.eva_bwd -> [dqkv, dbias | empty, *parameter gradients (fp32, in the order of mlp_params)]."""
     geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
-    bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, noise_c, saved, zhat, rstd = [_opt(t) for t in saved_list]
+    bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, saved, zhat, rstd = [_opt(t) for t in saved_list]
+    noise_c = None if noise is None else noise.float().contiguous()
     B, N, _, h, d = qkv5.shape
     dqkv5 = torch.empty_like(qkv5)
     d_rfk, d_beta, dbias = _window_bwd(geom, qkv5, rf_k_bar, beta, bias_p, mask_u8, out,
@@ -381,7 +381,7 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, out, saved_list, icfg, fcfg, adaptiv
             ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
     ps = [p.detach().float().contiguous() for p in mlp_params]
     if dbias is not None:
-        dbias = dbias[..., :bias_cols]
+        dbias = dbias[..., :bias_cols].contiguous()
     if fused_mu:
         lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
         dqm = torch.empty_like(qmean)
@@ -450,7 +450,7 @@ class EvaAttnFn(torch.autograd.Function):
         icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), int(causal), int(any(ctx.needs_input_grad))]
         fcfg = [float(mu_scale), float(keep_scale)]
         outs = torch.ops.ea.eva_fwd(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
-        ctx.save_for_backward(qkv5, mask_u8, keep, *outs, *mlp_params)
+        ctx.save_for_backward(qkv5, mask_u8, keep, noise, *outs, *mlp_params)
         ctx.nsaved = len(outs) - 1
         ctx.cfg = (icfg, fcfg, adaptive_proj, 0 if bias is None else bias.shape[-1])
         ctx.pdtypes = [p.dtype for p in mlp_params]
@@ -458,11 +458,11 @@ class EvaAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        qkv5, mask_u8, keep, out, *rest = ctx.saved_tensors
+        qkv5, mask_u8, keep, noise, out, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         icfg, fcfg, adaptive_proj, bias_cols = ctx.cfg
-        g = torch.ops.ea.eva_bwd(dout, qkv5, mask_u8, keep, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols,
-                                 list(params))
+        g = torch.ops.ea.eva_bwd(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
+                                 bias_cols, list(params))
         pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
         return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
 
@@ -606,9 +606,9 @@ def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c):
             nv.ptr(p_kv), nv.stream())
     # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
     kv = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
-    sc = torch.empty((3, BH, C), dtype=torch.float32, device=dev)
-    lse_k, cst = sc[0], sc[1]
-    lse_t = sc[2] if mis == 0 else None
+    lse_k = torch.empty((BH, C), dtype=torch.float32, device=dev)     # (separate allocations: they leave the
+    cst = torch.empty_like(lse_k)                                     #  dispatcher op as distinct outputs)
+    lse_t = torch.empty_like(lse_k) if mis == 0 else None
     nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
             nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
     out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
@@ -793,13 +793,14 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
             nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
     out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp)
     e = lp
-    return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(noise_c, e), _e(saved, e)]
+    return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(saved, e)]
 
 
-def lara_bwd_impl(dout, qkv5, mask_u8, saved_list, icfg, fcfg, params):
+def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
     """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)]."""
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
-    omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise_c, saved = [_opt(t) for t in saved_list]
+    omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, saved = [_opt(t) for t in saved_list]
+    noise_c = None if noise is None else noise.float().contiguous()
     B, N, _, h, d = qkv5.shape
     BH, dev = B * h, qkv5.device
     ps = [t.detach().float().contiguous() for t in params]
@@ -841,16 +842,16 @@ class LaraPooledFn(torch.autograd.Function):
                 int(any(ctx.needs_input_grad))]
         fcfg = [float(kappa), float(scale)]
         outs = torch.ops.ea.lara_fwd(qkv5, mask_u8, noise, icfg, fcfg, list(params))
-        ctx.save_for_backward(qkv5, mask_u8, *outs[1:], *params)
+        ctx.save_for_backward(qkv5, mask_u8, noise, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
         ctx.pdtypes = [t.dtype for t in params]
         return outs[0]
 
     @staticmethod
     def backward(ctx, dout):
-        qkv5, mask_u8, *rest = ctx.saved_tensors
+        qkv5, mask_u8, noise, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
-        grads = torch.ops.ea.lara_bwd(dout, qkv5, mask_u8, list(saved), ctx.icfg, ctx.fcfg, list(params))
+        grads = torch.ops.ea.lara_bwd(dout, qkv5, mask_u8, noise, list(saved), ctx.icfg, ctx.fcfg, list(params))
         pgrads = [g.to(dt) for g, dt in zip(grads[1:], ctx.pdtypes)]
         return (grads[0], None, None, None) + tuple(pgrads)
 
