@@ -14,6 +14,7 @@
 // All of it exact fp32 like the reference's autocast-exempt LayerNorm/softmax.  The step is
 // latency-bound (a few MB of traffic in total), so the design goal is few, short barrier phases:
 // 9 forward, 16 backward.  Parameter gradients leave as per-(b,h) partials that the caller sums.
+#include <stdlib.h>
 #include "ea_common.h"
 #include "ea_lara_lmk.h"
 
@@ -694,9 +695,16 @@ static int launch_lmk(bool bwd, const LmkP& p, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+bool lmk2_supported(bool bwd, const LmkP& p);
+int lmk2_dispatch(bool bwd, const LmkP& p, hipStream_t st);
+
 int lara_lmk_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
   LmkP p = p0;
   p.prof = nullptr;
+  // second-generation kernels (ea_lmk2.hip: fp16 operand tiles, strips in registers, 2 workgroups per CU);
+  // EA_LMK_V1=1 keeps the round-1 kernels below (fp32 matrices in LDS) for A/B comparison
+  static const bool v1 = getenv("EA_LMK_V1") && getenv("EA_LMK_V1")[0] == '1';
+  if (!v1 && lmk2_supported(bwd, p)) return lmk2_dispatch(bwd, p, st);
 #ifdef EA_PROFILE
   ProfReport rep;
   p.prof = rep.arm(st, "lara_lmk", bwd ? 1 : 0);
