@@ -80,13 +80,31 @@ template <int NT> EA_DEV void store_t(char* tile, const f32x4* s, float scale, i
 }
 
 // fp32 [rows][ld] matrix <-> strip
+// (loads are unconditional -- clamped indices, zero selected afterwards: a predicated load costs an
+//  exec-mask branch and a full memory round trip EACH, which made the first version latency-bound)
 template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
+  if (!src) { zero<NT>(s); return; }                 // (uniform)
   const int r0 = 16 * l.w + 4 * l.g;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li;
+    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[ct][r] = (src && r0 + r < rows && col < cols) ? src[(size_t)(r0 + r) * ld + col] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const float v = src[(size_t)min(r0 + r, rows - 1) * ld + cc];
+      s[ct][r] = (r0 + r < rows && col < cols) ? v : 0.f;
+    }
+  }
+}
+// rows given explicitly (ri[r] valid indices), zero where !ok[r]
+template <int NT> EA_DEV void gather_strip(f32x4* s, const float* src, int ld, const int* ri, const bool* ok, int cols, const Lane& l) {
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = src[(size_t)ri[r] * ld + cc];
+      s[ct][r] = (ok[r] && col < cols) ? v : 0.f;
+    }
   }
 }
 template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
@@ -146,18 +164,30 @@ template <int NT> EA_DEV void colsum_part(float* part, const f32x4* s, int rows,
   }
 }
 
-// fp32 global [rows][D] -> fp16 row-major tile [64][D] (zero beyond rows), all 256 threads
-template <int D> EA_DEV void stage_rows(char* tile, const float* src, int rows, int tid) {
-  constexpr int CPR = D / 8;
-  for (int idx = tid; idx < 64 * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    float f[8];
+// fp32 global [rows][D] -> fp16 row-major tile [64][D] (zero beyond rows), all 256 threads; in two steps so
+// that the loads of several matrices are in flight together
+template <int D> struct StageRegs { float4 v[(64 * D / 8 + 255) / 256][2]; };
+template <int D> EA_DEV void issue_rows(StageRegs<D>& b, const float* src, int rows, int tid) {
+  constexpr int CPR = D / 8, NI = (64 * CPR + 255) / 256;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = 0.f;
-    if (src && row < rows) {
-      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
-      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
-    }
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + i * 256;
+    const int row = min(idx / CPR, rows - 1), c = idx % CPR;
+    b.v[i][0] = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
+    b.v[i][1] = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
+  }
+}
+template <int D> EA_DEV void commit_rows(char* tile, const StageRegs<D>& b, int rows, int tid) {
+  constexpr int CPR = D / 8, NI = (64 * CPR + 255) / 256;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx / CPR, c = idx % CPR;
+    if (idx >= 64 * CPR) continue;
+    const bool ok = row < rows;
+    const float4 lo = b.v[i][0], hi = b.v[i][1];
+    const float f[8] = {ok ? lo.x : 0.f, ok ? lo.y : 0.f, ok ? lo.z : 0.f, ok ? lo.w : 0.f,
+                        ok ? hi.x : 0.f, ok ? hi.y : 0.f, ok ? hi.z : 0.f, ok ? hi.w : 0.f};
     sts16(tile + lds_off<D>(row, c), pack8<H>(f));
   }
 }
@@ -224,24 +254,42 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       pv[4 * D + i] = p.bq[i]; pv[5 * D + i] = p.bk[i];
     }
   __syncthreads();
-  // sample row c -> its landmark row and noise (omega_c = mu[c mod L] +- eps)
-  auto noise_at = [&](int c, int col) -> float {
-    if (!p.noise) return 0.f;
-    if (p.dup == 1) return (c >= L ? -1.f : 1.f) * p.noise[(size_t)bh * L * D + (size_t)(c % L) * D + col];
-    return p.noise[oC + (size_t)c * D + col];
+  // noise of the sample rows c of this strip (omega_c = mu[c mod L] +- eps): antithetic rows c >= L re-use
+  // the first L rows with the opposite sign
+  auto noise_strip = [&](f32x4* n, int nrows) {
+    if (!p.noise) { zero<NT>(n); return; }
+    int ri[4]; bool ok[4]; float sg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = min(r0 + r, nrows - 1);
+      ok[r] = r0 + r < nrows;
+      ri[r] = p.dup == 1 ? c % L : c;
+      sg[r] = (p.dup == 1 && c >= L) ? -1.f : 1.f;
+    }
+    gather_strip<NT>(n, p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC, D, ri, ok, D, l);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) n[ct][r] *= sg[r];
   };
-
   f32x4 xq[NT], xk[NT], qb[NT], k0[NT], mu[NT], om[NT];
   float rsq[4] = {0.f, 0.f, 0.f, 0.f}, rsk[4] = {0.f, 0.f, 0.f, 0.f};
 
   if (!BWD) {
     // =========================================== forward ===========================================
     // F0: operands of the two Linear layers
+    f32x4 nz[NT];
+    noise_strip(nz, p.eva ? L : C);
     if (p.has_mlp) {
-      stage_rows<D>(T0, p.pq + oL, L, tid);
-      stage_rows<D>(T1, p.pk + oL, L, tid);
-      stage_rows<D>(T2, p.Wq, D, tid);
-      stage_rows<D>(T3, p.Wk, D, tid);
+      StageRegs<D> b0, b1, b2, b3;
+      issue_rows<D>(b0, p.pq + oL, L, tid);
+      issue_rows<D>(b1, p.pk + oL, L, tid);
+      issue_rows<D>(b2, p.Wq, D, tid);
+      issue_rows<D>(b3, p.Wk, D, tid);
+      commit_rows<D>(T0, b0, L, tid);
+      commit_rows<D>(T1, b1, L, tid);
+      commit_rows<D>(T2, b2, D, tid);
+      commit_rows<D>(T3, b3, D, tid);
     }
     __syncthreads();
     // F1: H = P W^T + b, LayerNorm, affine  (strip w of both sides)
@@ -280,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (r0 + r < L) om[ct][r] = 0.5f * (qb[ct][r] + k0[ct][r]) + noise_at(r0 + r, 16 * ct + l.li);
+          om[ct][r] = 0.5f * (qb[ct][r] + k0[ct][r]) + nz[ct][r];
       save_strip<NT>(p.qbar_rows + oC, k0, D, L, D, l);
       save_strip<NT>(p.omega + oC, om, D, L, D, l);
       return;
@@ -346,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
         const int c = r0 + r, col = 16 * ct + l.li;
         float m = 0.f, q = 0.f;
         if (c < C) { m = XMU[(c % L) * D + col]; q = XQB[(c % L) * D + col]; }
-        om[ct][r] = c < C ? m + noise_at(c, col) : 0.f;
+        om[ct][r] = c < C ? m + nz[ct][r] : 0.f;
         qr[ct][r] = p.mis == 0 ? q : m;
       }
     save_strip<NT>(p.omega + oC, om, D, C, D, l);
@@ -388,44 +436,91 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
   }
 
   // =========================================== backward ===========================================
-  // B0: reload the forward's intermediates into strips; operand tiles MUT, OMT, K0T, AST
+  EA_STAMP(p, 0);
+  EA_BLK(p, 0);
+  // B0: EVERY global load of the backward is issued here, unconditionally, so the workgroup pays one
+  // memory round trip: the operand tiles of the tail (W, P), the forward's saved strips, the incoming
+  // gradients.
   char* WQt = T5, *WKt = T5 + RB, *PQt = T5 + 2 * RB, *PKt = T5 + 3 * RB;
+  StageRegs<D> sb0, sb1, sb2, sb3;
   if (p.has_mlp) {
+    issue_rows<D>(sb0, p.Wq, D, tid);
+    issue_rows<D>(sb1, p.Wk, D, tid);
+    issue_rows<D>(sb2, p.pq + oL, L, tid);
+    issue_rows<D>(sb3, p.pk + oL, L, tid);
     load_strip<NT>(xq, sv_xq, D, L, D, l);
     load_strip<NT>(xk, sv_xk, D, L, D, l);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { rsq[r] = r0 + r < 64 ? sv_rstd[r0 + r] : 0.f; rsk[r] = r0 + r < 64 ? sv_rstd[64 + r0 + r] : 0.f; }
+    for (int r = 0; r < 4; ++r) { rsq[r] = sv_rstd[min(r0 + r, 63)]; rsk[r] = sv_rstd[64 + min(r0 + r, 63)]; }
   }
   f32x4 dqb[NT], dk0[NT];                              // gradients of q_bar and k0 rows of this strip
+  f32x4 gin[NT], gqr[NT];                              // incoming: d omega rows, d (q_bar | mu) rows of this strip
+  int rl[4]; bool rok[4];                              // landmark row of sample row c = r0 + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { rok[r] = r0 + r < C; rl[r] = min(r0 + r, C - 1) % L; }
+  load_strip<NT>(gin, p.d_omega + oC, D, p.eva ? L : C, D, l);
   if (p.eva) {
     // d rf_q_bar = d omega / 2, d rf_k_bar = d omega / 2 + d (rf_k_bar output)
-    f32x4 dom[NT], dqr[NT];
-    load_strip<NT>(dom, p.d_omega + oC, D, L, D, l);
-    load_strip<NT>(dqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, D, L, D, l);
+    load_strip<NT>(gqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, D, L, D, l);
+    if (p.has_mlp) {
+      commit_rows<D>(WQt, sb0, D, tid); commit_rows<D>(WKt, sb1, D, tid);
+      commit_rows<D>(PQt, sb2, L, tid); commit_rows<D>(PKt, sb3, L, tid);
+    }
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { dqb[ct][r] = 0.5f * dom[ct][r]; dk0[ct][r] = 0.5f * dom[ct][r] + dqr[ct][r]; }
+      for (int r = 0; r < 4; ++r) { dqb[ct][r] = 0.5f * gin[ct][r]; dk0[ct][r] = 0.5f * gin[ct][r] + gqr[ct][r]; }
     __syncthreads();
   } else {
-    load_strip<NT>(mu, p.has_mlp || p.mixed ? sv_mu : nullptr, D, L, D, l);
-    if (!(p.has_mlp || p.mixed)) {
+    const bool have_mu = p.has_mlp || p.mixed;
+    f32x4 nz[NT], muc[NT], dqs[NT], asm_[4];
+    float pre_dlp[4], pre_dbh[4];
+    noise_strip(nz, C);
+    load_strip<NT>(gqr, (p.mis == 1 && p.d_qbar_rows) ? p.d_qbar_rows + oC : nullptr, D, C, D, l);
+    zero<NT>(dqs);
+    if (p.mis == 0 && p.d_qbar_rows) {                 // sum_k d q_bar rows [l + k L] of this strip's landmark rows
+      for (int k = 0; k < nrep; ++k) {
+        int ri[4]; bool ok[4];
+        f32x4 t[NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok[r] = r0 + r < L; ri[r] = min(r0 + r, L - 1) + k * L; }
+        gather_strip<NT>(t, p.d_qbar_rows + oC, D, ri, ok, D, l);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) dqs[ct] = dqs[ct] + t[ct];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = (size_t)bh * C + min(r0 + r, C - 1);
+      pre_dlp[r] = p.d_lp[o];
+      pre_dbh[r] = (p.mis == 0 && p.d_bhv) ? p.d_bhv[o] : 0.f;
+    }
+    if (have_mu) {
+      load_strip<NT>(mu, sv_mu, D, L, D, l);
+      gather_strip<NT>(muc, sv_mu, D, rl, rok, D, l);
+    } else {
       // no saved mu: mu = q_bar + k_bar with both given
       f32x4 a[NT], b[NT];
       load_strip<NT>(a, p.pq + oL, D, L, D, l);
       load_strip<NT>(b, p.pk + oL, D, L, D, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) mu[ct] = a[ct] + b[ct];
+      gather_strip<NT>(a, p.pq + oL, D, rl, rok, D, l);
+      gather_strip<NT>(b, p.pk + oL, D, rl, rok, D, l);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) muc[ct] = a[ct] + b[ct];
     }
+    if (p.mixed) load_strip<4>(asm_, sv_a, 64, L, L, l);
     if (p.has_mlp) {
+      commit_rows<D>(WQt, sb0, D, tid); commit_rows<D>(WKt, sb1, D, tid);
+      commit_rows<D>(PQt, sb2, L, tid); commit_rows<D>(PKt, sb3, L, tid);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) k0[ct][r] = pv[2 * D + 16 * ct + l.li] * xk[ct][r] + pv[3 * D + 16 * ct + l.li];
-    } else {
+    } else if (p.mixed) {
       load_strip<NT>(k0, p.pk + oL, D, L, D, l);
     }
-    // (pv is read above before any barrier only when has_mlp: make it visible first)
     float m2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
@@ -433,26 +528,17 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int r = 0; r < 4; ++r) m2[r] += mu[ct][r] * mu[ct][r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m2[r] = row16_sum(m2[r]); if (l.li == 0 && r0 + r < 64) musq[r0 + r] = m2[r]; }
-    // omega rows of this strip: mu[c mod L] comes from the saved MU of the forward (fp32)
-    const float* mu_src = (p.has_mlp || p.mixed) ? sv_mu : nullptr;
+    // omega rows of this strip: mu[c mod L] +- eps
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = r0 + r, col = 16 * ct + l.li;
-        float m = 0.f;
-        if (c < C) m = mu_src ? mu_src[(size_t)(c % L) * D + col] : p.pq[oL + (size_t)(c % L) * D + col] + p.pk[oL + (size_t)(c % L) * D + col];
-        om[ct][r] = c < C ? m + noise_at(c, col) : 0.f;
-      }
+    for (int ct = 0; ct < NT; ++ct) om[ct] = muc[ct] + nz[ct];
     store_t<NT>(T0, mu, 1.f, L, D, l);               // MUT
     store_t<NT>(T1, om, 1.f, C, D, l);               // OMT
-    f32x4 asm_[4];
     if (p.mixed) {
       store_t<NT>(T2, k0, 1.f, L, D, l);             // K0T
-      load_strip<4>(asm_, sv_a, 64, L, L, l);
       store_t<4>(T3, asm_, 1.f, L, L, l);            // AST [l'][l]
     }
     __syncthreads();
+    EA_STAMP(p, 1);
     // B1: M (recomputed), proposal densities, dM in registers
     f32x4 dM[4];
     {
@@ -483,15 +569,12 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
         const float lse = mx[r] + __logf(dn);
         const int c = r0 + r;
         float dlp = 0.f, dlse = 0.f;
-        if (c < C) {
-          const float pre_dlp = p.d_lp[(size_t)bh * C + c];
-          if (p.mis == 0) {
-            const float dbh = (p.d_bhv ? p.d_bhv[(size_t)bh * C + c] : 0.f) * __expf(d0[r] - lse);
-            dlp = pre_dlp + dbh;
-            dlse = -dbh;
-          } else {
-            dlse = pre_dlp;
-          }
+        if (p.mis == 0) {
+          const float dbh = pre_dbh[r] * __expf(d0[r] - lse);
+          dlp = pre_dlp[r] + dbh;
+          dlse = -dbh;
+        } else {
+          dlse = pre_dlp[r];
         }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -504,20 +587,19 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       const float gm = strip_absmax<4>(dM, C, L, l);
       if (lane == 0) gmx[l.w] = gm;
     }
+    EA_STAMP(p, 2);
     colsum_part<4>(cpart, dM, C, l);                  // column sums of dM
     __syncthreads();
     const float sdm = pow2_scale(gmx);
     store_t<4>(T4, dM, sdm, C, L, l);                 // DMT [l][c]
     __syncthreads();
+    EA_STAMP(p, 3);
     // B2: dMU = s dM^T OM - s colsum(dM) mu ;  dOM = d omega (+ d mu rows) + s dM MU
     f32x4 dmu[NT], dom[NT];
     zero<NT>(dmu); zero<NT>(dom);
     mm<64, false, 64, true, NT>(dmu, T4, T1, 2, l);   // A = dM^T rows l (DMT row-major), B = OM (OMT = [n][k])
     mm<64, true, 64, true, NT>(dom, T4, T0, 2, l);    // A = dM rows c (DMT = [k][m]),   B = MU (MUT = [n][k])
     {
-      f32x4 gin[NT], gqr[NT];
-      load_strip<NT>(gin, p.d_omega + oC, D, C, D, l);
-      load_strip<NT>(gqr, (p.mis == 1 && p.d_qbar_rows) ? p.d_qbar_rows + oC : nullptr, D, C, D, l);
       const float al = s / sdm;
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -529,9 +611,10 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
           dom[ct][r] = gin[ct][r] + gqr[ct][r] + al * dom[ct][r];
         }
     }
+    EA_STAMP(p, 4);
     // B3: fold the sample rows onto the landmarks: d mu[l] += sum_k dOM[l + k L]  (fp32 exchange through LDS)
     __syncthreads();                                  // DMT / cpart readers done; T4.. reused below
-    float* XOM = reinterpret_cast<float*>(T5);        // [64][D] fp32 (the W / P tiles are staged later, in the tail)
+    float* XOM = reinterpret_cast<float*>(T0);        // [64][D] fp32 over T0..T1 (MUT, OMT are dead)
     if (nrep > 1) {
       save_strip<NT>(XOM, dom, D, 64, D, l);
       __syncthreads();
@@ -541,16 +624,15 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r0 + r, col = 16 * ct + l.li;
-        float d = 0.f, dq = 0.f;
+        float d = 0.f;
         if (row < L) {
           d = dmu[ct][r] + dom[ct][r];
           for (int k = 1; k < nrep; ++k) d += XOM[(row + k * L) * D + col];
-          if (p.mis == 0 && p.d_qbar_rows)
-            for (int k = 0; k < nrep; ++k) dq += p.d_qbar_rows[oC + (size_t)(row + k * L) * D + col];
         }
         dk0[ct][r] = d;                               // = d k_bar (before the mixing backward)
-        dqb[ct][r] = d + dq;
+        dqb[ct][r] = d + dqs[ct][r];
       }
+    EA_STAMP(p, 5);
     // B4..B6: mixing backward
     if (p.mixed) {
       {
@@ -596,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
         for (int r = 0; r < 4; ++r) dk0[ct][r] = (r0 + r < L) ? a1 * dkk[ct][r] + a2 * t1[ct][r] : 0.f;
     }
   }
+  EA_STAMP(p, 6);
   // ---- tail: LayerNorm + Linear backward of both sides (dY = dqb / dk0 in registers) ----
   if (!p.has_mlp) {
     save_strip<NT>(p.dpq + oL, dqb, D, L, D, l);
@@ -603,10 +686,6 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     return;
   }
   __syncthreads();                                    // cpart / tiles of the mixing backward / the exchange buffer are free
-  stage_rows<D>(WQt, p.Wq, D, tid);                   // operands of dP = dH W and dW = dH^T P (T5 region)
-  stage_rows<D>(WKt, p.Wk, D, tid);
-  stage_rows<D>(PQt, p.pq + oL, L, tid);
-  stage_rows<D>(PKt, p.pk + oL, L, tid);
   f32x4 dhq[NT], dhk[NT];
   {
     // d gamma = sum_l dY xhat, d beta = sum_l dY
@@ -653,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     ln_bwd(dhq, dqb, xq, pv, rsq);
     ln_bwd(dhk, dk0, xk, pv + 2 * D, rsk);
   }
+  EA_STAMP(p, 7);
   __syncthreads();                                    // cpart readers done
   colsum_part<NT>(cpart, dhq, L, l);                  // d bias of the Linear
   colsum_part<NT>(cpart2, dhk, L, l);
@@ -666,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     p.dvec_part[((size_t)bh * 2 + 1) * 3 * D + tid] = cpart2[tid] + cpart2[64 + tid] + cpart2[128 + tid] + cpart2[192 + tid];
   }
   const float shq = pow2_scale(gmx), shk = pow2_scale(gmx + 4);
+  EA_STAMP(p, 8);
   store_t<NT>(T0, dhq, shq, L, D, l);                 // DHT (q) [o][l]
   store_t<NT>(T3, dhk, shk, L, D, l);                 // DHT (k)
   __syncthreads();
@@ -696,6 +777,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       save_strip<NT>(p.dW_part + ((size_t)bh * 2 + 1) * D * D, dw, D, D, D, l);
     }
   }
+  EA_STAMP(p, 9);
+  EA_BLK(p, 1);
 }
 
 }  // namespace lmk2
@@ -727,7 +810,13 @@ bool lmk2_supported(bool bwd, const LmkP& p) {
   return true;
 }
 
-int lmk2_dispatch(bool bwd, const LmkP& p, hipStream_t st) {
+int lmk2_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
+  LmkP p = p0;
+  p.prof = nullptr;
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "lmk2", bwd ? 1 : 0);
+#endif
   if (p.D == 64) return launch_lmk2<64>(bwd, p, st);
   if (p.D == 32) return launch_lmk2<32>(bwd, p, st);
   return EA_E_UNSUPPORTED;

@@ -14,6 +14,8 @@ import sys
 KERNEL_TO_ENTRY = [
     ("lara_fq_kernel<", "ea_lara_bwd_q_fused"), ("lara_fk_kernel<", "ea_lara_bwd_k_fused"),
     ("lara_fin_kernel<", "ea_lara_bwd_finish"),
+    ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
+    ("wgrad_kernel<", "ea_wgrad"),
     ("lara_x_kernel<ea::BF16, 64, 4, 0>", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1>", "ea_lara_bwd_q"),
     ("lara_x_kernel<ea::BF16, 64, 4, 2>", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3>", "ea_lara_bwd_qcorr"),
     ("lara_y_kernel<ea::BF16, 64, 0>", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1>", "ea_lara_bwd_qstats"),
