@@ -14,6 +14,7 @@ int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, cons
 #include "ea_lara_lmk.h"
 #include "ea_lara_merge.h"
 #include "ea_lara_segment.h"
+#include "ea_scatter.h"
 #include "ea_rows_mlp.h"
 namespace ea {
 int rows_mlp_dispatch(const RowsP& p, int D, int sides, int layer_norm, bool bwd, hipStream_t st);
@@ -806,6 +807,128 @@ int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_featu
              float* dw_part, float* db_part, void* stream) {
   if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EA_E_BADARG;
   return wgrad_dispatch(dtype, dy, x, dw_part, db_part, rows, out_features, in_features, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- ScatterBrain feature half (ea_scatter.hip) ----
+static T4s mks(const ea_t4* t) {
+  T4s r;
+  r.p = t ? (char*)t->ptr : nullptr;
+  r.sb = t ? t->sb : 0; r.sh = t ? t->sh : 0; r.sn = t ? t->sn : 0;
+  return r;
+}
+static int fill_sb(const ea_sb_geom* g, SbP& p) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->N <= 0 || g->window <= 0 || (g->dtype != EA_BF16 && g->dtype != EA_F16))
+    return EA_E_BADARG;
+  if (g->D != 64 || g->M <= 0 || g->M > 64) return EA_E_UNSUPPORTED;
+  p.B = g->B; p.H = g->H; p.N = g->N; p.M = g->M; p.w = g->window;
+  p.G.N = g->N; p.G.attn2d = g->attn_2d; p.G.gh = g->attn_2d ? g->gh : 1; p.G.gw = g->attn_2d ? g->gw : g->N;
+  if (g->attn_2d) {
+    if (g->gh % g->window || g->gw % g->window || g->gh * g->gw != g->N) return EA_E_BADARG;
+    p.Wq = g->window * g->window;
+    p.nwin = (g->gh / g->window) * (g->gw / g->window);
+  } else {
+    if (g->N % g->window) return EA_E_BADARG;
+    p.Wq = g->window;
+    p.nwin = g->N / g->window;
+  }
+  if (p.Wq > 64) return EA_E_UNSUPPORTED;
+  p.a = 1.f / sqrtf(sqrtf(64.f));
+  p.b = 0.5f / sqrtf(64.f);
+  p.lconst = 0.5f * logf((float)g->M);
+  p.wpb = 1;
+  for (int d = 2; d <= 4; ++d)                      // windows per workgroup of the backward window pass
+    if (p.nwin % d == 0) p.wpb = d;
+  return EA_OK;
+}
+static int fill_sb_stats(const ea_sb_geom* g, LaraP& p) {
+  ea_perf_geom pg;
+  pg.B = g->B; pg.H = g->H; pg.N = g->N; pg.D = g->D; pg.dtype = g->dtype; pg.M = g->M;
+  int rc = fill_perf(&pg, p, true);
+  if (rc != EA_OK) return rc;
+  p.ratio = 1.f; p.feps = 0.f; p.stab_per_feature = 1;
+  return EA_OK;
+}
+
+extern "C" {
+
+int32_t ea_scatter_parts(const ea_sb_geom* g) {
+  LaraP p = {};
+  if (!g || fill_sb_stats(g, p) != EA_OK) return EA_E_BADARG;
+  return p.nsplit * lara_nsub(p.NCT);
+}
+
+int ea_scatter_kmax(const ea_sb_geom* g, const ea_t4* k, const uint8_t* mask, const float* W, float* p_ml, void* stream) {
+  LaraP p = {};
+  if (!g) return EA_E_BADARG;
+  int rc = fill_sb_stats(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !W || !p_ml) return EA_E_BADARG;
+  p.k = mkl(k); p.mask = mask; p.omega = W; p.p_ml = p_ml;
+  return lara_y_dispatch(LY_PMAX, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_scatter_kv(const ea_sb_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                  const float* mx, float* p_ml, float* p_kv, void* stream) {
+  LaraP p = {};
+  if (!g) return EA_E_BADARG;
+  int rc = fill_sb_stats(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !W || !mx || !p_ml || !p_kv) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.mask = mask; p.omega = W; p.stab = mx; p.p_ml = p_ml; p.p_acc0 = p_kv;
+  return lara_y_dispatch(LY_PKV, p, g->dtype, (hipStream_t)stream);
+}
+
+int32_t ea_scatter_bwd_parts(const ea_sb_geom* g) {
+  SbP p = {};
+  if (fill_sb(g, p) != EA_OK) return EA_E_BADARG;
+  return p.nwin / p.wpb;
+}
+
+int ea_scatter_bwd_window(const ea_sb_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                          const float* W, const float* mx, const float* zall, const float* sall, const ea_t4* oloc,
+                          const float* lse_loc, const float* r, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                          const ea_t4* dv, const ea_t4* doloc, float* dlse, float* p_dsall, float* p_dzall,
+                          void* stream) {
+  SbP p = {};
+  int rc = fill_sb(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, 64) || !t4_ok(k, 64) || !t4_ok(v, 64) || !t4_ok(oloc, 64) || !t4_ok(dout, 64) || !t4_ok(dq, 64) ||
+      !t4_ok(dk, 64) || !t4_ok(dv, 64) || !t4_ok(doloc, 64) || !W || !mx || !zall || !sall || !lse_loc || !r || !dlse ||
+      !p_dsall || !p_dzall) return EA_E_BADARG;
+  p.q = mks(q); p.k = mks(k); p.v = mks(v); p.oloc = mks(oloc); p.dout = mks(dout); p.dq = mks(dq); p.dk = mks(dk);
+  p.dv = mks(dv); p.doloc = mks(doloc); p.mask = mask; p.Wf = W; p.mx = mx; p.zall = zall; p.sall = sall;
+  p.lse_loc = lse_loc; p.r = const_cast<float*>(r); p.dlse = dlse; p.p_dsall = p_dsall; p.p_dzall = p_dzall;
+  return sb_bwd_dispatch(0, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_scatter_bwd_global(const ea_sb_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                          const float* mx, const float* dsall, const float* dzall, const ea_t4* dk, const ea_t4* dv,
+                          void* stream) {
+  SbP p = {};
+  int rc = fill_sb(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(k, 64) || !t4_ok(v, 64) || !t4_ok(dk, 64) || !t4_ok(dv, 64) || !W || !mx || !dsall || !dzall)
+    return EA_E_BADARG;
+  p.k = mks(k); p.v = mks(v); p.dk = mks(dk); p.dv = mks(dv); p.mask = mask; p.Wf = W; p.mx = mx;
+  p.zall = mx; p.sall = dsall;                       // (unused in the global pass; kept valid)
+  p.dsall = dsall; p.dzall = dzall;
+  p.wpb = 1;
+  return sb_bwd_dispatch(1, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_scatter_fwd(const ea_sb_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                   const float* W, const float* mx, const float* zall, const float* sall, const ea_t4* oloc,
+                   const float* lse_loc, const ea_t4* out, float* r, void* stream) {
+  SbP p = {};
+  int rc = fill_sb(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok(q, 64) || !t4_ok(k, 64) || !t4_ok(v, 64) || !t4_ok(oloc, 64) || !t4_ok(out, 64) || !W || !mx || !zall ||
+      !sall || !lse_loc || !r) return EA_E_BADARG;
+  p.q = mks(q); p.k = mks(k); p.v = mks(v); p.oloc = mks(oloc); p.out = mks(out); p.mask = mask; p.Wf = W;
+  p.mx = mx; p.zall = zall; p.sall = sall; p.lse_loc = lse_loc; p.r = r;
+  return sb_fwd_dispatch(p, g->dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -48,6 +48,9 @@ struct LaraP {
   // Performer: omega = W indexed per head, stab [BH] key stabiliser (natural units)
   int w_per_head;
   const float* stab;
+  // ScatterBrain's feature statistics (scatterbrain_attention.py:99-131) on the Performer modes: the
+  // stabiliser is per FEATURE (stab [BH, C]) and the key max includes the -|k|^2 term and the padding mask
+  int stab_per_feature;
   float norm_coef2;             // log2-domain coefficient of |x|^2 in the logits
   float knorm_coef;             // coefficient of x * (sum of logit grads) in dk / dq
   float ratio, feps;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   const float* r3src = MODE == LY_BWDQ ? p.kv : p.dkv;
   constexpr bool HAS_R3 = MODE == LY_BWDQ || MODE == LY_BWDK;
   load_lm_raw<D>(raw3, HAS_R3 ? r3src + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && HAS_R3, g);
-  const float stabk2 = (MODE == LY_PKV) ? p.stab[bh] * LOG2E : 0.f;
+  const float stabk2 = (MODE == LY_PKV) ? (p.stab_per_feature ? (c_ok ? p.stab[lm + c] : 0.f) : p.stab[bh]) * LOG2E : 0.f;
   float cst2 = -INFINITY, lset2 = INFINITY, bhc = 1.f, lsek2 = INFINITY, dkkc = 0.f, rsc = 0.f;
   if (c_ok) {
     if (MODE == LY_BWDQ) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
             ps0[i] = p.lseZ[o]; ps1[i] = p.tmean[o]; ps2[i] = p.rowdot[o];
             if (MODE == LY_BWDQ) ps3[i] = p.sda[o];
           }
-          if (cc == 0 && keys && MODE != LY_PMAX) ps0[i] = (p.mask && p.mask[(size_t)b * p.N + tok]) ? 1.f : 0.f;
+          if (cc == 0 && keys && (MODE != LY_PMAX || p.stab_per_feature)) ps0[i] = (p.mask && p.mask[(size_t)b * p.N + tok]) ? 1.f : 0.f;
         }
       }
     };
@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
 #pragma unroll
           for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
           if (cc == 0) {
-            if (MODE == LY_PMAX) {
+            if (MODE == LY_PMAX && p.stab_per_feature) {
+              sc[row] = (!valid || ps0[i] != 0.f) ? -INFINITY : -p.norm_coef2 * part;   // max of the whole log-feature
+            } else if (MODE == LY_PMAX) {
               sc[row] = valid ? 0.f : -INFINITY;          // stabiliser: max over ALL keys, no diagonal term
             } else if (MODE == LY_PBWDQ) {
               sc[row] = valid ? -p.norm_coef2 * part - ps0[i] : -INFINITY;

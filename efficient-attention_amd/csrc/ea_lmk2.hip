@@ -18,151 +18,15 @@
 //     (loss scaling cannot push them out of fp16 range), exactly as before.
 // Peak LDS: 40 KB + 33 KB fp32 exchange (forward), 73 KB (backward): 2 workgroups per CU, 4 forward /
 // 9 backward barrier phases instead of 9 / 16.
-#include "ea_common.h"
+#include "ea_strip.h"
 #include "ea_lara_lmk.h"
 
 namespace ea {
 
 namespace lmk2 {
 
+using namespace strip;
 typedef F16 H;
-typedef typename H::x8 hx8;
-
-template <int W> EA_DEV int toff(int row, int col) { return lds_off<W>(row, col >> 3) + ((col & 7) << 1); }
-
-struct Lane { int g, li, w; };
-
-// fragment whose 16 indexed lanes run over ROWS 16 t + li of the tile and whose k-slots run over the columns
-template <int W> EA_DEV hx8 rowfrag(const char* tile, int t, int ks, const Lane& l) {
-  const int row = 16 * t + l.li;
-  const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + toff<W>(row, 32 * ks + 4 * l.g));
-  const u32x2 hi = *reinterpret_cast<const u32x2*>(tile + toff<W>(row, 32 * ks + 16 + 4 * l.g));
-  return as_x8<H>(lo, hi);
-}
-// fragment whose 16 indexed lanes run over COLUMNS 16 t + li and whose k-slots run over the rows
-template <int W> EA_DEV hx8 colfrag(const char* tile, int t, int ks, const Lane& l) {
-  const int r = 32 * ks + 4 * l.g + (l.li >> 2);
-  const int col = 16 * t + 4 * (l.li & 3);
-  return as_x8<H>(H::tr4(tile + toff<W>(r, col)), H::tr4(tile + toff<W>(r + 16, col)));
-}
-
-// out[ct] += sum_k A(row 16 w + ., k) B(k, col 16 ct + .): AT = A is stored [k][m] (else [m][k]);
-// BT = B is stored [n][k] (else [k][n]); KS 32-deep steps; NT column tiles
-template <int WA, bool AT, int WB, bool BT, int NT>
-EA_DEV void mm(f32x4* out, const char* A, const char* B, int KS, const Lane& l) {
-  for (int ks = 0; ks < KS; ++ks) {
-    const hx8 a = AT ? colfrag<WA>(A, l.w, ks, l) : rowfrag<WA>(A, l.w, ks, l);
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-      const hx8 b = BT ? rowfrag<WB>(B, ct, ks, l) : colfrag<WB>(B, ct, ks, l);
-      out[ct] = H::mma(a, b, out[ct]);
-    }
-  }
-}
-
-template <int NT> EA_DEV void zero(f32x4* s) {
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) s[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-// strip (rows 16 w + 4 g + r, columns 16 ct + li) -> TRANSPOSED fp16 tile T[col][row] ([*][64]); entries
-// outside [rows, cols) are stored as zero
-template <int NT> EA_DEV void store_t(char* tile, const f32x4* s, float scale, int rows, int cols, const Lane& l) {
-  const int r0 = 16 * l.w + 4 * l.g;
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (r0 + r < rows && col < cols) ? s[ct][r] * scale : 0.f;
-    *reinterpret_cast<u32x2*>(tile + toff<64>(col, r0)) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
-  }
-}
-
-// fp32 [rows][ld] matrix <-> strip
-// (loads are unconditional -- clamped indices, zero selected afterwards: a predicated load costs an
-//  exec-mask branch and a full memory round trip EACH, which made the first version latency-bound)
-template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
-  if (!src) { zero<NT>(s); return; }                 // (uniform)
-  const int r0 = 16 * l.w + 4 * l.g;
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = src[(size_t)min(r0 + r, rows - 1) * ld + cc];
-      s[ct][r] = (r0 + r < rows && col < cols) ? v : 0.f;
-    }
-  }
-}
-// rows given explicitly (ri[r] valid indices), zero where !ok[r]
-template <int NT> EA_DEV void gather_strip(f32x4* s, const float* src, int ld, const int* ri, const bool* ok, int cols, const Lane& l) {
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = src[(size_t)ri[r] * ld + cc];
-      s[ct][r] = (ok[r] && col < cols) ? v : 0.f;
-    }
-  }
-}
-template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
-  const int r0 = 16 * l.w + 4 * l.g;
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r0 + r < rows && col < cols) dst[(size_t)(r0 + r) * ld + col] = s[ct][r];
-  }
-}
-
-EA_DEV float row16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-EA_DEV float row16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-EA_DEV float wave_maxf(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-template <int NT> EA_DEV float strip_absmax(const f32x4* s, int rows, int cols, const Lane& l) {
-  const int r0 = 16 * l.w + 4 * l.g;
-  float m = 0.f;
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r0 + r < rows && 16 * ct + l.li < cols) m = fmaxf(m, fabsf(s[ct][r]));
-  return wave_maxf(m);
-}
-// power-of-two 1/scale: max * scale in [0.5, 1)
-EA_DEV float pow2_scale(const float* gm) {
-  const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
-  if (!(m > 0.f) || m > 3e38f) return 1.f;
-  int e;
-  (void)frexpf(m, &e);
-  return ldexpf(1.f, -e);
-}
-// column sums of a strip over its rows -> part[w][col] (the caller adds the four waves after a barrier)
-template <int NT> EA_DEV void colsum_part(float* part, const f32x4* s, int rows, const Lane& l) {
-  const int r0 = 16 * l.w + 4 * l.g;
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-    float a = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a += (r0 + r < rows) ? s[ct][r] : 0.f;
-    a = quad_sum(a);
-    if (l.g == 0) part[l.w * 64 + 16 * ct + l.li] = a;
-  }
-}
 
 // fp32 global [rows][D] -> fp16 row-major tile [64][D] (zero beyond rows), all 256 threads; in two steps so
 // that the loads of several matrices are in flight together
@@ -295,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     // F1: H = P W^T + b, LayerNorm, affine  (strip w of both sides)
     if (p.has_mlp) {
       zero<NT>(xq); zero<NT>(xk);
-      mm<D, false, D, true, NT>(xq, T0, T2, KD, l);
-      mm<D, false, D, true, NT>(xk, T1, T3, KD, l);
+      mm<H, D, false, D, true, NT>(xq, T0, T2, KD, l);
+      mm<H, D, false, D, true, NT>(xk, T1, T3, KD, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -336,12 +200,12 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     __syncthreads();                                 // every wave is done with PQ / PK / WQ / WK
     f32x4 kb[NT];
     if (p.mixed) {
-      store_t<NT>(T0, k0, 1.f, L, D, l);             // K0T [o][l]
+      store_t<H, NT>(T0, k0, 1.f, L, D, l);             // K0T [o][l]
       __syncthreads();
       // F2: G = s k0 k0^T, A = softmax over the L columns, k_bar = A k0
       f32x4 a[4];
       zero<4>(a);
-      mm<64, true, 64, false, 4>(a, T0, T0, KD, l);
+      mm<H, 64, true, 64, false, 4>(a, T0, T0, KD, l);
       float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, den[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -363,9 +227,9 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[ct][r] *= den[r];
       if (sv) save_strip<4>(sv_a, a, 64, L, L, l);
-      store_t<4>(T1, a, 1.f, L, L, l);               // AST [l'][l]: read back by this wave only (its own columns)
+      store_t<H, 4>(T1, a, 1.f, L, L, l);               // AST [l'][l]: read back by this wave only (its own columns)
       zero<NT>(kb);
-      mm<64, true, 64, true, NT>(kb, T1, T0, 2, l);
+      mm<H, 64, true, 64, true, NT>(kb, T1, T0, 2, l);
     } else {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) kb[ct] = k0[ct];
@@ -383,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     float* XQB = XMU + 64 * D;
     save_strip<NT>(XMU, mu, D, 64, D, l);
     save_strip<NT>(XQB, qb, D, 64, D, l);
-    store_t<NT>(T2, mu, 1.f, L, D, l);               // MUT [o][l]  (WQ is dead: barrier above)
+    store_t<H, NT>(T2, mu, 1.f, L, D, l);               // MUT [o][l]  (WQ is dead: barrier above)
     __syncthreads();
     // F4: omega rows of this strip (sample rows c), outputs
     f32x4 qr[NT];
@@ -399,12 +263,12 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       }
     save_strip<NT>(p.omega + oC, om, D, C, D, l);
     if (p.mis != 2) save_strip<NT>(p.qbar_rows + oC, qr, D, C, D, l);
-    store_t<NT>(T3, om, 1.f, C, D, l);               // OMT [o][c]
+    store_t<H, NT>(T3, om, 1.f, C, D, l);               // OMT [o][c]
     __syncthreads();
     // F5: M = s omega mu^T - s |mu_l|^2 / 2 ; proposal densities per sample row
     f32x4 M[4];
     zero<4>(M);
-    mm<64, true, 64, false, 4>(M, T3, T2, KD, l);
+    mm<H, 64, true, 64, false, 4>(M, T3, T2, KD, l);
     float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, d0[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
@@ -531,11 +395,11 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     // omega rows of this strip: mu[c mod L] +- eps
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) om[ct] = muc[ct] + nz[ct];
-    store_t<NT>(T0, mu, 1.f, L, D, l);               // MUT
-    store_t<NT>(T1, om, 1.f, C, D, l);               // OMT
+    store_t<H, NT>(T0, mu, 1.f, L, D, l);               // MUT
+    store_t<H, NT>(T1, om, 1.f, C, D, l);               // OMT
     if (p.mixed) {
-      store_t<NT>(T2, k0, 1.f, L, D, l);             // K0T
-      store_t<4>(T3, asm_, 1.f, L, L, l);            // AST [l'][l]
+      store_t<H, NT>(T2, k0, 1.f, L, D, l);             // K0T
+      store_t<H, 4>(T3, asm_, 1.f, L, L, l);            // AST [l'][l]
     }
     __syncthreads();
     EA_STAMP(p, 1);
@@ -544,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     {
       f32x4 M[4];
       zero<4>(M);
-      mm<64, true, 64, false, 4>(M, T1, T0, KD, l);
+      mm<H, 64, true, 64, false, 4>(M, T1, T0, KD, l);
       float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, d0[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -591,14 +455,14 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     colsum_part<4>(cpart, dM, C, l);                  // column sums of dM
     __syncthreads();
     const float sdm = pow2_scale(gmx);
-    store_t<4>(T4, dM, sdm, C, L, l);                 // DMT [l][c]
+    store_t<H, 4>(T4, dM, sdm, C, L, l);                 // DMT [l][c]
     __syncthreads();
     EA_STAMP(p, 3);
     // B2: dMU = s dM^T OM - s colsum(dM) mu ;  dOM = d omega (+ d mu rows) + s dM MU
     f32x4 dmu[NT], dom[NT];
     zero<NT>(dmu); zero<NT>(dom);
-    mm<64, false, 64, true, NT>(dmu, T4, T1, 2, l);   // A = dM^T rows l (DMT row-major), B = OM (OMT = [n][k])
-    mm<64, true, 64, true, NT>(dom, T4, T0, 2, l);    // A = dM rows c (DMT = [k][m]),   B = MU (MUT = [n][k])
+    mm<H, 64, false, 64, true, NT>(dmu, T4, T1, 2, l);   // A = dM^T rows l (DMT row-major), B = OM (OMT = [n][k])
+    mm<H, 64, true, 64, true, NT>(dom, T4, T0, 2, l);    // A = dM rows c (DMT = [k][m]),   B = MU (MUT = [n][k])
     {
       const float al = s / sdm;
 #pragma unroll
@@ -641,12 +505,12 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       }
       __syncthreads();
       const float skb = pow2_scale(gmx);
-      store_t<NT>(T4, dk0, skb, L, D, l);             // DKBT [o][l]  (DMT is dead: barrier at B3)
+      store_t<H, NT>(T4, dk0, skb, L, D, l);             // DKBT [o][l]  (DMT is dead: barrier at B3)
       __syncthreads();
       f32x4 dkk[NT], dA[4];
       zero<NT>(dkk); zero<4>(dA);
-      mm<64, false, 64, true, NT>(dkk, T3, T4, 2, l); // dK0 = A^T dKb : A-op = AST rows l' (row-major), B = dKb (DKBT = [n][k])
-      mm<64, true, 64, false, 4>(dA, T4, T2, KD, l);  // dA = dKb K0^T : A-op = dKb rows l (DKBT = [k][m]), B[k=o][n=l'] = K0T
+      mm<H, 64, false, 64, true, NT>(dkk, T3, T4, 2, l); // dK0 = A^T dKb : A-op = AST rows l' (row-major), B = dKb (DKBT = [n][k])
+      mm<H, 64, true, 64, false, 4>(dA, T4, T2, KD, l);  // dA = dKb K0^T : A-op = dKb rows l (DKBT = [k][m]), B[k=o][n=l'] = K0T
       float rs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -665,12 +529,12 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       }
       __syncthreads();
       const float sdg = pow2_scale(gmx);
-      store_t<4>(T1, dA, sdg, L, L, l);               // DGT [l'][l]  (OMT is dead)
+      store_t<H, 4>(T1, dA, sdg, L, L, l);               // DGT [l'][l]  (OMT is dead)
       __syncthreads();
       f32x4 t1[NT];
       zero<NT>(t1);
-      mm<64, true, 64, true, NT>(t1, T1, T2, 2, l);   // dG K0  : A-op = dG rows l (DGT = [k][m]), B = K0 (K0T = [n][k])
-      mm<64, false, 64, true, NT>(t1, T1, T2, 2, l);  // dG^T K0: A-op = dG^T rows l (DGT row-major)
+      mm<H, 64, true, 64, true, NT>(t1, T1, T2, 2, l);   // dG K0  : A-op = dG rows l (DGT = [k][m]), B = K0 (K0T = [n][k])
+      mm<H, 64, false, 64, true, NT>(t1, T1, T2, 2, l);  // dG^T K0: A-op = dG^T rows l (DGT row-major)
       const float a2 = s / sdg, a1 = 1.f / skb;
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
@@ -747,31 +611,31 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
   }
   const float shq = pow2_scale(gmx), shk = pow2_scale(gmx + 4);
   EA_STAMP(p, 8);
-  store_t<NT>(T0, dhq, shq, L, D, l);                 // DHT (q) [o][l]
-  store_t<NT>(T3, dhk, shk, L, D, l);                 // DHT (k)
+  store_t<H, NT>(T0, dhq, shq, L, D, l);                 // DHT (q) [o][l]
+  store_t<H, NT>(T3, dhk, shk, L, D, l);                 // DHT (k)
   __syncthreads();
   {
     // dP = dH W (rows l) -> global;  dW = dH^T P (rows o) -> per-(b,h) partial
     f32x4 dp[NT];
     zero<NT>(dp);
-    mm<64, true, D, false, NT>(dp, T0, WQt, KD, l);   // A-op = dH rows l (DHT = [k][m]); B[k=o][n=i] = W row-major
+    mm<H, 64, true, D, false, NT>(dp, T0, WQt, KD, l);   // A-op = dH rows l (DHT = [k][m]); B[k=o][n=i] = W row-major
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) dp[ct] = dp[ct] * (1.f / shq);
     save_strip<NT>(p.dpq + oL, dp, D, L, D, l);
     zero<NT>(dp);
-    mm<64, true, D, false, NT>(dp, T3, WKt, KD, l);
+    mm<H, 64, true, D, false, NT>(dp, T3, WKt, KD, l);
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) dp[ct] = dp[ct] * (1.f / shk);
     save_strip<NT>(p.dpk + oL, dp, D, L, D, l);
     if (16 * l.w < D) {                               // rows o of dW: D / 16 strips
       f32x4 dw[NT];
       zero<NT>(dw);
-      mm<64, false, D, false, NT>(dw, T0, PQt, 2, l); // A-op = dH^T rows o (DHT row-major); B[k=l][n=i] = P row-major
+      mm<H, 64, false, D, false, NT>(dw, T0, PQt, 2, l); // A-op = dH^T rows o (DHT row-major); B[k=l][n=i] = P row-major
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) dw[ct] = dw[ct] * (1.f / shq);
       save_strip<NT>(p.dW_part + ((size_t)bh * 2 + 0) * D * D, dw, D, D, D, l);
       zero<NT>(dw);
-      mm<64, false, D, false, NT>(dw, T3, PKt, 2, l);
+      mm<H, 64, false, D, false, NT>(dw, T3, PKt, 2, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) dw[ct] = dw[ct] * (1.f / shk);
       save_strip<NT>(p.dW_part + ((size_t)bh * 2 + 1) * D * D, dw, D, D, D, l);

@@ -1,0 +1,154 @@
+// ea_strip.h -- small dense matrix algebra on 64 x 64 tiles for 4-wave workgroups (ea_lmk2.hip,
+// ea_scatter.hip): wave w owns the 16-row strip w of every matrix product and keeps it in registers in the
+// MFMA result layout (row 16 w + 4 g + r, column 16 ct + li); LDS holds only MFMA operands, as 16-bit
+// [*][64] tiles with the XOR swizzle of ea_common.h.  A strip is stored TRANSPOSED (four consecutive rows
+// of one column = one 8-byte store); both operand orientations of a stored matrix are then available --
+// index along the rows by two 8-byte reads (rowfrag), index along the columns by two ds_read_b64_tr_b16
+// (colfrag) -- in the same k-slot order, so no product needs a second copy of an operand.
+#pragma once
+#include "ea_common.h"
+
+namespace ea {
+namespace strip {
+
+
+
+template <int W> EA_DEV int toff(int row, int col) { return lds_off<W>(row, col >> 3) + ((col & 7) << 1); }
+
+struct Lane { int g, li, w; };
+
+// fragment whose 16 indexed lanes run over ROWS 16 t + li of the tile and whose k-slots run over the columns
+template <typename H, int W> EA_DEV typename H::x8 rowfrag(const char* tile, int t, int ks, const Lane& l) {
+  const int row = 16 * t + l.li;
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(tile + toff<W>(row, 32 * ks + 4 * l.g));
+  const u32x2 hi = *reinterpret_cast<const u32x2*>(tile + toff<W>(row, 32 * ks + 16 + 4 * l.g));
+  return as_x8<H>(lo, hi);
+}
+// fragment whose 16 indexed lanes run over COLUMNS 16 t + li and whose k-slots run over the rows
+template <typename H, int W> EA_DEV typename H::x8 colfrag(const char* tile, int t, int ks, const Lane& l) {
+  const int r = 32 * ks + 4 * l.g + (l.li >> 2);
+  const int col = 16 * t + 4 * (l.li & 3);
+  return as_x8<H>(H::tr4(tile + toff<W>(r, col)), H::tr4(tile + toff<W>(r + 16, col)));
+}
+
+// out[ct] += sum_k A(row 16 w + ., k) B(k, col 16 ct + .): AT = A is stored [k][m] (else [m][k]);
+// BT = B is stored [n][k] (else [k][n]); KS 32-deep steps; NT column tiles
+template <typename H, int WA, bool AT, int WB, bool BT, int NT>
+EA_DEV void mm(f32x4* out, const char* A, const char* B, int KS, const Lane& l) {
+  for (int ks = 0; ks < KS; ++ks) {
+    const typename H::x8 a = AT ? colfrag<H, WA>(A, l.w, ks, l) : rowfrag<H, WA>(A, l.w, ks, l);
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+      const typename H::x8 b = BT ? rowfrag<H, WB>(B, ct, ks, l) : colfrag<H, WB>(B, ct, ks, l);
+      out[ct] = H::mma(a, b, out[ct]);
+    }
+  }
+}
+
+template <int NT> EA_DEV void zero(f32x4* s) {
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) s[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// strip (rows 16 w + 4 g + r, columns 16 ct + li) -> TRANSPOSED fp16 tile T[col][row] ([*][64]); entries
+// outside [rows, cols) are stored as zero
+template <typename H, int NT> EA_DEV void store_t(char* tile, const f32x4* s, float scale, int rows, int cols, const Lane& l) {
+  const int r0 = 16 * l.w + 4 * l.g;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int col = 16 * ct + l.li;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (r0 + r < rows && col < cols) ? s[ct][r] * scale : 0.f;
+    *reinterpret_cast<u32x2*>(tile + toff<64>(col, r0)) = u32x2{pack2<H>(v[0], v[1]), pack2<H>(v[2], v[3])};
+  }
+}
+
+// fp32 [rows][ld] matrix <-> strip
+// (loads are unconditional -- clamped indices, zero selected afterwards: a predicated load costs an
+//  exec-mask branch and a full memory round trip EACH, which made the first version latency-bound)
+template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
+  if (!src) { zero<NT>(s); return; }                 // (uniform)
+  const int r0 = 16 * l.w + 4 * l.g;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = src[(size_t)min(r0 + r, rows - 1) * ld + cc];
+      s[ct][r] = (r0 + r < rows && col < cols) ? v : 0.f;
+    }
+  }
+}
+// rows given explicitly (ri[r] valid indices), zero where !ok[r]
+template <int NT> EA_DEV void gather_strip(f32x4* s, const float* src, int ld, const int* ri, const bool* ok, int cols, const Lane& l) {
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = src[(size_t)ri[r] * ld + cc];
+      s[ct][r] = (ok[r] && col < cols) ? v : 0.f;
+    }
+  }
+}
+template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
+  const int r0 = 16 * l.w + 4 * l.g;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const int col = 16 * ct + l.li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r0 + r < rows && col < cols) dst[(size_t)(r0 + r) * ld + col] = s[ct][r];
+  }
+}
+
+EA_DEV float row16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+EA_DEV float row16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+EA_DEV float wave_maxf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+template <int NT> EA_DEV float strip_absmax(const f32x4* s, int rows, int cols, const Lane& l) {
+  const int r0 = 16 * l.w + 4 * l.g;
+  float m = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r0 + r < rows && 16 * ct + l.li < cols) m = fmaxf(m, fabsf(s[ct][r]));
+  return wave_maxf(m);
+}
+// power-of-two 1/scale: max * scale in [0.5, 1)
+EA_DEV float pow2_scale(const float* gm) {
+  const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+  if (!(m > 0.f) || m > 3e38f) return 1.f;
+  int e;
+  (void)frexpf(m, &e);
+  return ldexpf(1.f, -e);
+}
+// column sums of a strip over its rows -> part[w][col] (the caller adds the four waves after a barrier)
+template <int NT> EA_DEV void colsum_part(float* part, const f32x4* s, int rows, const Lane& l) {
+  const int r0 = 16 * l.w + 4 * l.g;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a += (r0 + r < rows) ? s[ct][r] : 0.f;
+    a = quad_sum(a);
+    if (l.g == 0) part[l.w * 64 + 16 * ct + l.li] = a;
+  }
+}
+
+
+}  // namespace strip
+}  // namespace ea

@@ -38,6 +38,12 @@ class ea_perf_geom(ctypes.Structure):
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("M", ctypes.c_int32)]
 
 
+class ea_sb_geom(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("dtype", ctypes.c_int32), ("M", ctypes.c_int32), ("attn_2d", ctypes.c_int32),
+                ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32)]
+
+
 class ea_lmk_geom(ctypes.Structure):
     _fields_ = [("BH", ctypes.c_int32), ("L", ctypes.c_int32), ("C", ctypes.c_int32), ("D", ctypes.c_int32),
                 ("has_mlp", ctypes.c_int32), ("mixed", ctypes.c_int32), ("mis", ctypes.c_int32),
@@ -58,6 +64,7 @@ _LG = ctypes.POINTER(ea_lara_geom)
 _PG = ctypes.POINTER(ea_perf_geom)
 _MG = ctypes.POINTER(ea_lmk_geom)
 _T = ctypes.POINTER(ea_t4)
+_SG = ctypes.POINTER(ea_sb_geom)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
 SIGNATURES = {
@@ -96,6 +103,13 @@ SIGNATURES = {
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "ea_scatter_parts": [_SG],
+    "ea_scatter_kmax": [_SG, _T, _P, _P, _P, _P],
+    "ea_scatter_kv": [_SG, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_scatter_fwd": [_SG, _T, _T, _T, _P, _P, _P, _P, _P, _T, _P, _T, _P, _P],
+    "ea_scatter_bwd_parts": [_SG],
+    "ea_scatter_bwd_window": [_SG, _T, _T, _T, _P, _P, _P, _P, _P, _T, _P, _P, _T, _T, _T, _T, _T, _P, _P, _P, _P],
+    "ea_scatter_bwd_global": [_SG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_performer_parts": [_PG],
     "ea_performer_kmax": [_PG, _T, _P, _P, _P],
     "ea_performer_kv": [_PG, _T, _T, _P, _P, _P, _P, _P, _P],

@@ -1149,6 +1149,102 @@ class PerformerAttnFn(torch.autograd.Function):
         return torch.ops.ea.performer_bwd(dout, qkv5, mask_u8, W, stab, kv, ksum, out), None, None
 
 
+# ------------------------------------------------------------------------------------------
+# ScatterBrain, low-rank half  (reference scatterbrain_attention.py:99-160)
+# ------------------------------------------------------------------------------------------
+SCATTER_TORCH = os.environ.get("EA_SCATTER_TORCH", "0") == "1"     # dev switch: feature half on torch ops
+
+
+def scatter_supported(qkv5, W, attn_2d, seq_shape, window):
+    B, N, _, h, d = qkv5.shape
+    wq = window * window if attn_2d else window
+    return d == 64 and W.shape[1] <= 64 and wq <= 64
+
+
+def _sb_geom(qkv5, W, attn_2d, seq_shape, window):
+    B, N, _, h, d = qkv5.shape
+    gh, gw = (seq_shape if attn_2d else (1, N))
+    return nv.ea_sb_geom(B, h, N, d, nv.io_dtype(qkv5), W.shape[1], 1 if attn_2d else 0, int(gh), int(gw), int(window))
+
+
+def scatter_stats(geom, qkv5, mask_u8, W):
+    """Sequence-wide feature statistics of the keys: mx [BH,M], z_all [BH,M], S_all [BH,M,d] (fp32)."""
+    B, N, _, h, d = qkv5.shape
+    BH, M, dev = B * h, W.shape[1], qkv5.device
+    _, k, v = _qkv_views(qkv5)
+    tk, tv = nv.t4(k), nv.t4(v)
+    S = nv.lib().ea_scatter_parts(ctypes.byref(geom))
+    p_ml = torch.empty((BH, S, M, 4), dtype=torch.float32, device=dev)
+    nv.call("ea_scatter_kmax", ctypes.byref(geom), ctypes.byref(tk), nv.ptr(mask_u8), nv.ptr(W), nv.ptr(p_ml), nv.stream())
+    mx = p_ml[..., 0].amax(1).contiguous()                                 # [BH, M]
+    p_kv = torch.empty((BH, S, M, d), dtype=torch.float32, device=dev)
+    nv.call("ea_scatter_kv", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(W),
+            nv.ptr(mx), nv.ptr(p_ml), nv.ptr(p_kv), nv.stream())
+    return mx, p_ml[..., 0].sum(1).contiguous(), p_kv.sum(1).contiguous()
+
+
+def scatter_feature_fwd(qkv5, mask_u8, W, o_loc, lse_loc, attn_2d, seq_shape, window):
+    """out [B,N,h,d] = merge of the window half (o_loc [B,N,h,d], lse_loc [B,h,N]) with the m feature columns;
+    also returns r [B,h,N] and the statistics (for the backward)."""
+    B, N, _, h, d = qkv5.shape
+    W = W.float().contiguous()
+    geom = _sb_geom(qkv5, W, attn_2d, seq_shape, window)
+    mx, zall, sall = scatter_stats(geom, qkv5, mask_u8, W)
+    q, k, v = _qkv_views(qkv5)
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=qkv5.device)
+    r = torch.empty((B, h, N), dtype=torch.float32, device=qkv5.device)
+    lse_loc = lse_loc.float().contiguous()
+    ts = [nv.t4(t) for t in (q, k, v, o_loc.permute(0, 2, 1, 3), out.permute(0, 2, 1, 3))]
+    nv.call("ea_scatter_fwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+            nv.ptr(mask_u8), nv.ptr(W), nv.ptr(mx), nv.ptr(zall), nv.ptr(sall), ctypes.byref(ts[3]), nv.ptr(lse_loc),
+            ctypes.byref(ts[4]), nv.ptr(r), nv.stream())
+    return out, r, (mx, zall, sall)
+
+
+class ScatterFeatureFn(torch.autograd.Function):
+    """ScatterBrain's feature half + the merge with the window half, on HIP (ea_scatter_*):
+    (qkv5, o_loc [B,N,h,d], lse_loc [B,h,N], W [h,m,d]) -> out [B,N,h,d].  The backward returns the feature
+    half's dq / dk / dv and the cotangents of the window half (d o_loc, d lse_loc), which flow on into
+    LocalAttnLseFn; no gradient reaches W (redrawn / fixed, like PerformerAttnFn)."""
+
+    @staticmethod
+    def forward(ctx, qkv5, o_loc, lse_loc, mask_u8, W, attn_2d, seq_shape, window):
+        nv.require_cuda(qkv5, "qkv")
+        out, r, (mx, zall, sall) = scatter_feature_fwd(qkv5, mask_u8, W, o_loc, lse_loc, attn_2d, seq_shape, window)
+        Wc = W.float().contiguous()
+        ctx.save_for_backward(qkv5, o_loc, lse_loc.float().contiguous(), mask_u8, Wc, r, mx, zall, sall)
+        ctx.geo = (attn_2d, tuple(seq_shape), window)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, o_loc, lse_loc, mask_u8, W, r, mx, zall, sall = ctx.saved_tensors
+        attn_2d, seq_shape, window = ctx.geo
+        B, N, _, h, d = qkv5.shape
+        BH, M, dev = B * h, W.shape[1], qkv5.device
+        geom = _sb_geom(qkv5, W, attn_2d, seq_shape, window)
+        dout = dout.contiguous()
+        dqkv5 = torch.empty_like(qkv5)
+        d_oloc = torch.empty_like(o_loc)
+        dlse = torch.empty_like(lse_loc)
+        P = nv.lib().ea_scatter_bwd_parts(ctypes.byref(geom))
+        p_ds = torch.empty((BH, P, M, d), dtype=torch.float32, device=dev)
+        p_dz = torch.empty((BH, P, M), dtype=torch.float32, device=dev)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        ts = [nv.t4(t) for t in (q, k, v, o_loc.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv,
+                                 d_oloc.permute(0, 2, 1, 3))]
+        nv.call("ea_scatter_bwd_window", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+                nv.ptr(mask_u8), nv.ptr(W), nv.ptr(mx), nv.ptr(zall), nv.ptr(sall), ctypes.byref(ts[3]), nv.ptr(lse_loc),
+                nv.ptr(r), ctypes.byref(ts[4]), ctypes.byref(ts[5]), ctypes.byref(ts[6]), ctypes.byref(ts[7]),
+                ctypes.byref(ts[8]), nv.ptr(dlse), nv.ptr(p_ds), nv.ptr(p_dz), nv.stream())
+        dsall = p_ds.sum(1).contiguous()
+        dzall = p_dz.sum(1).contiguous()
+        nv.call("ea_scatter_bwd_global", ctypes.byref(geom), ctypes.byref(ts[1]), ctypes.byref(ts[2]), nv.ptr(mask_u8),
+                nv.ptr(W), nv.ptr(mx), nv.ptr(dsall), nv.ptr(dzall), ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.stream())
+        return dqkv5, d_oloc, dlse, None, None, None, None, None
+
+
 def performer_attention(qkv5, mask_u8, proj):
     return PerformerAttnFn.apply(qkv5, mask_u8, proj)
 

@@ -62,8 +62,12 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
         w = self.window_size
         proj = self.get_proj_matrix(device=qkv5.device, dtype=torch.float32)      # [h, m, d]
         m = proj.shape[1]
+        mask_u8 = _ops._mask_u8(mask, B, N, qkv5.device)
         o_loc, lse_loc = _ops.LocalAttnLseFn.apply(
-            qkv5, self._table_bias(), _ops._mask_u8(mask, B, N, qkv5.device), self.attn_2d, tuple(seq_shape), w, 0)
+            qkv5, self._table_bias(), mask_u8, self.attn_2d, tuple(seq_shape), w, 0)
+        if _ops.scatter_supported(qkv5, proj, self.attn_2d, seq_shape, w) and not _ops.SCATTER_TORCH:
+            # feature half + merge on HIP (ea_scatter.hip); wider windows / more features fall through to torch ops
+            return _ops.ScatterFeatureFn.apply(qkv5, o_loc, lse_loc, mask_u8, proj, self.attn_2d, tuple(seq_shape), w)
 
         if self.attn_2d:
             H, W = seq_shape

@@ -411,6 +411,46 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
              float* dw_part, float* db_part, void* stream);
 
+/* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
+ * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);
+ * these entry points evaluate the m random-feature columns of the same softmax and merge the two halves:
+ *   ea_scatter_kmax / ea_scatter_kv : mx[c] = max_j log phi(k_j)[c] and the partial sums of
+ *       z_all[c] = sum_j exp(lk_jc - mx_c), S_all[c] = sum_j exp(lk_jc - mx_c) v_j  over sequence slices
+ *       (p_ml [BH,S,M,4] (first field), p_kv [BH,S,M,64], S = ea_scatter_parts(g)); padded keys excluded;
+ *   ea_scatter_fwd : per window, statistics of the window's own keys, KV = (S_all - S_win) / clamp(z_all -
+ *       z_win, 1e-3), joint weights of the feature columns, and out = sigma(lse_loc - r) o_loc + sigma(r -
+ *       lse_loc) O with r [B,H,N] = log-sum-exp of the feature logits (returned for the backward).
+ * D = 64, M <= 64 features, windows of <= 64 tokens, no window overlap.  W [H, M, 64] fp32. */
+typedef struct {
+  int32_t B, H, N, D;
+  int32_t dtype;
+  int32_t M;                 /* random features */
+  int32_t attn_2d, gh, gw;   /* token grid (2-D) */
+  int32_t window;            /* window side */
+} ea_sb_geom;
+int32_t ea_scatter_parts(const ea_sb_geom* g);
+int ea_scatter_kmax(const ea_sb_geom* g, const ea_t4* k, const uint8_t* mask, const float* W, float* p_ml, void* stream);
+int ea_scatter_kv(const ea_sb_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                  const float* mx, float* p_ml, float* p_kv, void* stream);
+int ea_scatter_fwd(const ea_sb_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                   const float* W, const float* mx, const float* zall, const float* sall, const ea_t4* oloc,
+                   const float* lse_loc, const ea_t4* out, float* r, void* stream);
+/* Backward of ea_scatter_fwd (mx is a detached stabiliser, as in the reference):
+ *   ea_scatter_bwd_window: per window -- dq, the window's own contributions to dk / dv (written, not
+ *       accumulated), d o_loc = alpha dout and d lse_loc [B,H,N] (the cotangents of the window half, to be fed to
+ *       ea_window_attn_bwd), and partial sums p_dsall [BH, P, M, 64], p_dzall [BH, P, M] of d S_all, d z_all,
+ *       P = ea_scatter_bwd_parts(g);
+ *   ea_scatter_bwd_global: given the summed d S_all, d z_all, ADDS every key's share to dk, dv. */
+int32_t ea_scatter_bwd_parts(const ea_sb_geom* g);
+int ea_scatter_bwd_window(const ea_sb_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                          const float* W, const float* mx, const float* zall, const float* sall, const ea_t4* oloc,
+                          const float* lse_loc, const float* r, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                          const ea_t4* dv, const ea_t4* doloc, float* dlse, float* p_dsall, float* p_dzall,
+                          void* stream);
+int ea_scatter_bwd_global(const ea_sb_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                          const float* mx, const float* dsall, const float* dzall, const ea_t4* dk, const ea_t4* dv,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,12 @@ accumulation; every figure is relative to the reference tensor's own scale):
        importance weights, d(log alpha)/alpha and the softmax-over-sequence term t(dt - u), whose
        two halves cancel, and the landmark matrices are rounded to bf16 exactly as autocast
        rounds einsum operands; observed <= 2.3e-2, 8x smaller in fp16)
+  ScatterBrain module level  : max|err| <= 8e-2 * max|ref|  and  rms(err) <= 4e-2 * rms(ref)   (bf16 only)
+      (its feature half multiplies bf16-rounded exponentials five deep -- phi(k), the joint weights A, the
+       window statistics KV, dR, d phi(k) -- through three softmax-like normalisations; observed <= 6.6e-2 /
+       3.3e-2 against the fp32 reference, and 1e-3 in fp16, where it shares the common bound below: the
+       deviation is operand rounding; the kernels agree with an fp32 evaluation of the same bf16 qkv to
+       6e-3, tools/sb_check.py)
   fp16 autocast (the reference's own AMP dtype, 11 significant bits), every variant:
                                 max|err| <= 1e-2 * max|ref|  and  rms(err) <= 5e-3 * rms(ref)
   core level vs fp64 oracle   : max|err| <= 2e-2 * max|ref|  and  rms(err) <= 1e-2 * rms(ref)
@@ -27,6 +33,7 @@ from util import Fixture, scaled_err
 
 MODULE_TOL = (4e-2, 2e-2)
 LARA_TOL = (5e-2, 2.5e-2)
+SCATTER_TOL = (8e-2, 4e-2)
 FP16_TOL = (1e-2, 5e-3)
 CORE_TOL = (2e-2, 1e-2)
 
@@ -74,7 +81,7 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
         if dtype == torch.float16:
             tol = FP16_TOL
         else:
-            tol = LARA_TOL if fx.case["attn"] == "lara" else MODULE_TOL
+            tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(fx.case["attn"], MODULE_TOL)
     mod = build_module(fx)
     mod.train(mode == "train")
     keep_fn = fx.keep_fn(device="cuda")

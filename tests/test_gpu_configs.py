@@ -109,7 +109,7 @@ def test_constant_values_pass_through(name):
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_one_element_matches_oracle(name):
     import oracle
-    from gpu_checks import MODULE_TOL, LARA_TOL
+    from gpu_checks import MODULE_TOL, LARA_TOL, SCATTER_TOL
     from util import scaled_err
     attn, shape, args, pads = CONFIGS[name]
     m = _build(attn, args)
@@ -127,7 +127,7 @@ def test_one_element_matches_oracle(name):
     mr = None if mask is None else mask[sl].cpu()
     ref = oracle.module_forward(attn, dict(args), params, xr, mr, training=False)
     (ref * gy[sl].cpu()).sum().backward()
-    tol = LARA_TOL if attn == "lara" else MODULE_TOL
+    tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(attn, MODULE_TOL)
     for what, got, want in (("y", y.detach().float()[sl].cpu(), ref.detach()), ("dx", x.grad[sl].cpu(), xr.grad)):
         e = scaled_err(got.numpy(), want.numpy())
         assert e[0] <= tol[0] and e[1] <= tol[1], (name, what, e)
