@@ -432,9 +432,15 @@ def main():
         if dom[0] is not None:
             name, st = dom
             traffic = None
+            # HBM bytes per launch from the committed rocprofv3 PMC summary -- only while it describes THIS build
+            # of the library (tools/summarize_profile.py stamps the .so's sha256 into the file)
             pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.attn)
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get(name)
+                import hashlib
+                rec = json.load(open(pmc))
+                lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
+                sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+                traffic = rec.get(name) if rec.get("_lib_sha256") == sha else None
             common = {"kernel": name, "traffic": traffic, "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
                       "all_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}}
             if name in ("ea_lara_landmarks_fwd", "ea_lara_landmarks_bwd") and _ops.LAST_LMK_GEOM:

@@ -188,7 +188,13 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the launches go where torch's own would)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -228,7 +234,18 @@ class KernelTimer:
 KERNEL_TIMER = KernelTimer()
 
 
+_FN = {}
+
+
 def call(name, *args):
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    if not KERNEL_TIMER.enabled:
+        rc = fn(*args)
+        if rc != 0:
+            _check(rc, name)
+        return
     if KERNEL_TIMER.enabled:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)

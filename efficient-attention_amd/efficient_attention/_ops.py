@@ -101,6 +101,24 @@ def _mask_u8(mask, B, N, device):
 
 _LOG2E = 1.4426950408889634
 
+class DerivedCache:
+    """Derived weights (concatenations / products of parameters) re-used while nothing can have changed:
+    only when autograd is off (a cached tensor carries no graph) and no hipGraph is being captured (a
+    capture must record the producing kernels, or its replays would see stale values after an in-graph
+    optimizer step).  Keyed on the identity and `_version` of every source tensor."""
+
+    def __init__(self):
+        self.key, self.value = None, None
+
+    def get(self, sources, build):
+        if torch.is_grad_enabled() or (sources[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+            return build()
+        key = tuple((id(t), t._version, t.device, t.dtype) for t in sources if t is not None)
+        if key != self.key:
+            self.key, self.value = key, build()
+        return self.value
+
+
 _FP32_WARNED = [False]
 
 

@@ -115,9 +115,15 @@ class CausalEVAttention(nn.Module):
         N, B, C = query.shape
         if self.self_attention:
             # one GEMM over the stacked weights instead of three over the same activations
-            weight = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], 0)
             biases = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
-            bias = None if biases[0] is None else torch.cat(biases, 0)
+
+            def build():
+                return (torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], 0),
+                        None if biases[0] is None else torch.cat(biases, 0))
+            if not hasattr(self, "_stacked_cache"):
+                self._stacked_cache = _ops.DerivedCache()
+            weight, bias = self._stacked_cache.get(
+                [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight] + biases, build)
             qkv = _ops.linear_wb(query, weight, bias)
         else:
             assert key is not None and value is not None

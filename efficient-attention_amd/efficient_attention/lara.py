@@ -116,15 +116,22 @@ class LinearRA(MultiheadAttention):
         group of output columns of the same GEMM instead of a K = d GEMM over B*h*N strided rows)."""
         B, N, C = x.shape
         h, d = self.num_heads, self.head_dim
-        with torch.autocast(device_type="cuda", enabled=False):
-            W = self.qkv.weight.float()
-            Wq, Wk = W[:C].view(h, d, C), W[C:2 * C].view(h, d, C)
-            W2q = torch.matmul(self.q_bar_gen[0].weight.float(), Wq).reshape(C, C)
-            W2k = torch.matmul(self.k_bar_gen[0].weight.float(), Wk).reshape(C, C)
-            w_ext = torch.cat([W, W2q, W2k], 0)
-            b_ext = None
-            if self.qkv.bias is not None:
-                b_ext = torch.cat([self.qkv.bias.float(), self.qkv.bias.new_zeros(2 * C, dtype=torch.float32)])
+
+        def build():
+            with torch.autocast(device_type="cuda", enabled=False):
+                W = self.qkv.weight.float()
+                Wq, Wk = W[:C].view(h, d, C), W[C:2 * C].view(h, d, C)
+                W2q = torch.matmul(self.q_bar_gen[0].weight.float(), Wq).reshape(C, C)
+                W2k = torch.matmul(self.k_bar_gen[0].weight.float(), Wk).reshape(C, C)
+                w_ext = torch.cat([W, W2q, W2k], 0)
+                b_ext = None
+                if self.qkv.bias is not None:
+                    b_ext = torch.cat([self.qkv.bias.float(), self.qkv.bias.new_zeros(2 * C, dtype=torch.float32)])
+            return w_ext, b_ext
+        if not hasattr(self, "_folded_cache"):
+            self._folded_cache = _ops.DerivedCache()
+        w_ext, b_ext = self._folded_cache.get(
+            [self.qkv.weight, self.qkv.bias, self.q_bar_gen[0].weight, self.k_bar_gen[0].weight], build)
         qkv = _ops.linear_wb(x, w_ext, b_ext)
         qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 5, h, d)

@@ -34,6 +34,13 @@ KERNEL_TO_ENTRY = [
 ]
 
 
+def lib_sha():
+    """sha256 of the library the profile was taken with (the in-tree .so travels to the GPU box unchanged)."""
+    import hashlib
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "efficient-attention_amd", "lib", "libea_hip.so")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] if os.path.exists(path) else None
+
+
 def entry_of(kname):
     for k, v in KERNEL_TO_ENTRY:
         if k in kname:
@@ -67,6 +74,7 @@ def main(src, tag, attn, outdir, workload="default workload"):
         total = (2 * f + wv) * 1024
         out[e] = total
         lines.append("| %s | %.1f | %.0f | %.0f | %.1f |" % (e, avg_ns.get(e, 0) / 1e3, f, wv, total / 1e6))
+    out["_lib_sha256"] = lib_sha()            # bench.py ignores the file once the library has changed
     json.dump(out, open(os.path.join(outdir, "pmc_%s.json" % attn), "w"), indent=1)
     open(os.path.join(outdir, "%s_%s_hbm.md" % (tag, attn)), "w").write(
         "HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --attn %s "
