@@ -1316,17 +1316,6 @@ def _mm_out(a, b, out_dtype):
     return (a @ b).to(out_dtype)
 
 
-_ONES = {}
-
-
-def _ones_row(S, dtype, device):
-    """Cached [1, S] row of ones (a constant: not re-filled every step)."""
-    key = (S, dtype, str(device))
-    if key not in _ONES:
-        _ONES[key] = torch.ones((1, S), dtype=dtype, device=device)
-    return _ONES[key]
-
-
 def slice_sum(part):
     """part [S, ...] fp32 -> sum over S in a fixed order (ea_slice_sum)."""
     S = part.shape[0]
@@ -1408,10 +1397,8 @@ class LinearFn(torch.autograd.Function):
             if S > 1:
                 dy3 = (dy2 if dy2.is_contiguous() else dy2.contiguous()).view(S, rows // S, -1)
                 part = torch.bmm(dy3.transpose(1, 2), xl.view(S, rows // S, -1))     # [S, out, in]
-                # sum over the slices as a [1,S] x [S, out*in] GEMM (fp32 accumulation inside the GEMM,
-                # fp32 result: the partials are rounded once each, their sum once)
-                dw = _mm_out(_ones_row(S, part.dtype, part.device), part.view(S, -1), torch.float32).view(part.shape[1:])
-                dw = dw.to(wdtype)
+                # the slices are added with fp32 accumulation and rounded once (one streaming reduction)
+                dw = part.sum(0, dtype=torch.float32).to(wdtype)
             else:
                 dw = (dy2.t() @ xl).to(wdtype)
         if need_b:
