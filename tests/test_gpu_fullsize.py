@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "efficient-attention_amd"), os.path.join(ROOT, "tests")]
 
 # elementwise fp16 bound: |err| <= FP16_ELEM[0] * rms(ref) + FP16_ELEM[1] * |ref|
-FP16_ELEM = (3e-2, 3e-2)
+FP16_ELEM = (1.5e-2, 1.5e-2)
 
 EVA2D = dict(attn_2d=True, use_rpe=True, adaptive_proj="default")
 FULL = {

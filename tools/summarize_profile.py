@@ -16,6 +16,10 @@ KERNEL_TO_ENTRY = [
     ("lara_fin_kernel<", "ea_lara_bwd_finish"),
     ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("wgrad_kernel<", "ea_wgrad"),
+    ("sb_fwd_kernel<", "ea_scatter_fwd"), ("sb_bwd_kernel<ea::BF16, false>", "ea_scatter_bwd_window"),
+    ("sb_bwd_kernel<ea::BF16, true>", "ea_scatter_bwd_global"),
+    ("lara_y_kernel<ea::BF16, 64, 3>", "ea_scatter_kmax / ea_performer_kmax"),
+    ("lara_y_kernel<ea::BF16, 64, 4>", "ea_scatter_kv / ea_performer_kv"),
     ("lara_x_kernel<ea::BF16, 64, 4, 0>", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1>", "ea_lara_bwd_q"),
     ("lara_x_kernel<ea::BF16, 64, 4, 2>", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3>", "ea_lara_bwd_qcorr"),
     ("lara_y_kernel<ea::BF16, 64, 0>", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1>", "ea_lara_bwd_qstats"),
