@@ -90,10 +90,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     }
   };
 
-  LaneOff<64> lo;
-  lo.init(lane);
   const int wa = wave & 1, wb = wave >> 1;
   const int wr = 4 * g + (li >> 2);
+  // per-fragment LDS offsets, computed (not looked up: an array indexed by the runtime wave id lives in scratch,
+  // and a scratch access shares -- and drains -- the vmcnt queue of the prefetched global loads)
+  int aoff[NAF];
+#pragma unroll
+  for (int f = 0; f < NAF; ++f) {
+    const int fa = wa * NAF + f, dt = fa & 3;
+    const int colb = (16 * (li & 3) + 4 * dt) * 2;
+    aoff[f] = (fa >> 2) * (64 * 128) + wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
+  }
   int btr[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -122,8 +129,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
       }
 #pragma unroll
       for (int f = 0; f < NAF; ++f) {
-        const int fa = wa * NAF + f;                     // fragment index: sub-tile fa / 4, channel group fa % 4
-        const char* ap = cur + (fa >> 2) * (64 * 128) + kb * 128 + lo.tr[fa & 3];
+        const char* ap = cur + kb * 128 + aoff[f];       // fragment wa * NAF + f: sub-tile fa / 4, channel group fa % 4
         const typename E::x8 af = as_x8<E>(E::tr4(ap), E::tr4(ap + 16 * 128));
         acc[f][0] = E::mma(af, bf[0], acc[f][0]);
         acc[f][1] = E::mma(af, bf[1], acc[f][1]);
