@@ -40,6 +40,14 @@ BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv)
 OVERRIDES = {}      # --window / --landmarks
 
 
+def _emit(line):
+    """The JSON line goes out last: RCCL's banner sits in C stdio buffers until they are flushed."""
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+
+
 def attn_args(attn, dim, heads, seq):
     args = _attn_args(attn, dim, heads, seq)
     for k, v in OVERRIDES.items():
@@ -490,9 +498,10 @@ def main():
             "hbm_measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
     if ddp:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(line)
 
 
 def main_model(a):
@@ -578,9 +587,10 @@ def main_model(a):
             "attention_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        _emit(line)
 
 
 if __name__ == "__main__":
