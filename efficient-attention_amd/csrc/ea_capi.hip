@@ -22,6 +22,9 @@ int rows_mlp_blocks(int R, int D);
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
+int linear_supported(int K, int NO);
+int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const float* bias, void* y, int y_f32,
+                    void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
 int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, int rows, int M, int K,
                    hipStream_t st);
@@ -807,6 +810,24 @@ int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_featu
              float* dw_part, float* db_part, void* stream) {
   if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EA_E_BADARG;
   return wgrad_dispatch(dtype, dy, x, dw_part, db_part, rows, out_features, in_features, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- projections as streaming kernels (ea_linear.hip) ----
+extern "C" {
+
+int32_t ea_linear_supported(int32_t in_features, int32_t out_features) { return linear_supported(in_features, out_features); }
+
+int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
+              int64_t lda, const void* w, const float* bias, void* y, int32_t y_f32, int64_t ldy, void* a_cast,
+              void* stream) {
+  if (!a || !w || !y || ((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)a_cast & 15))
+    return EA_E_BADARG;
+  if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
+  return linear_dispatch(dtype, a, a_f32, w, bias, y, y_f32, a_cast, rows, in_features, out_features, (long)lda,
+                         (long)ldy, (hipStream_t)stream);
 }
 
 }  // extern "C"

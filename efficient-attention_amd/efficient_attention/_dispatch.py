@@ -12,6 +12,7 @@ implementation (no fallback).  The autograd Functions of _ops.py are thin shells
     ea::eva_fwd / eva_bwd                eva.py:145-227 (and causal_eva.py:666-788)
     ea::lara_fwd / lara_bwd              lara.py:129-175,187-246 (2-D pooled proposals)
     ea::performer_fwd / performer_bwd    kernelized_attention.py:20-56,116-121
+    ea::linear                           abstract_attention.py:72-78,86-87 (qkv / output projection, streaming kernel)
 """
 import torch
 
@@ -35,6 +36,7 @@ _SCHEMAS = {
                "str adaptive_proj, Tensor[] params) -> Tensor[]",
     "eva_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor? keep, Tensor? noise, Tensor out, Tensor[] saved, int[] icfg, float[] fcfg, "
                "str adaptive_proj, int bias_cols, Tensor[] params) -> Tensor[]",
+    "linear": "(Tensor a, Tensor w, Tensor? bias, bool y_f32, bool want_cast) -> Tensor[]",
 }
 _IMPLS = {
     "softmax_fwd": _ops.softmax_fwd_impl, "softmax_bwd": _ops.softmax_bwd_impl,
@@ -42,6 +44,7 @@ _IMPLS = {
     "performer_fwd": _ops.performer_fwd_impl, "performer_bwd": _ops.performer_bwd_impl,
     "lara_fwd": _ops.lara_fwd_impl, "lara_bwd": _ops.lara_bwd_impl,
     "eva_fwd": _ops.eva_fwd_impl, "eva_bwd": _ops.eva_bwd_impl,
+    "linear": _ops.linear_impl,
 }
 def _no_cpu(*args, **kwargs):
     _ops.nv.require_cuda(None, "every tensor of torch.ops.ea.*")       # raises: the cores have no CPU fallback
@@ -59,6 +62,13 @@ def _f32(like, *shape):
 
 def _none(like):
     return like.new_empty(0, dtype=torch.float32)
+
+
+@torch.library.register_fake("ea::linear")
+def _(a, w, bias, y_f32, want_cast):
+    y = a.new_empty((a.shape[0], w.shape[0]), dtype=torch.float32 if y_f32 else w.dtype)
+    ac = a.new_empty(a.shape if (want_cast and a.dtype == torch.float32) else (0,), dtype=w.dtype)
+    return [y, ac]
 
 
 @torch.library.register_fake("ea::softmax_fwd")

@@ -58,6 +58,7 @@ class ea_lara_geom(ctypes.Structure):
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int32
+_L = ctypes.c_int64
 _F = ctypes.c_float
 _G = ctypes.POINTER(ea_geom)
 _LG = ctypes.POINTER(ea_lara_geom)
@@ -101,6 +102,8 @@ SIGNATURES = {
     "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
+    "ea_linear_supported": [_I, _I],
+    "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "ea_scatter_parts": [_SG],

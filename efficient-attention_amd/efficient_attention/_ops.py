@@ -1325,6 +1325,49 @@ def slice_sum(part):
     return out
 
 
+USE_EA_LINEAR = os.environ.get("EA_LINEAR", "1") == "1"
+_ELEM = {torch.bfloat16: 0, torch.float16: 1}
+
+
+def _lin_geometry(K, NO):
+    """Mirror of ea_linear_supported (ea_linear.hip): in in {64,128,192,256}; out = 1..4 parts of 64/128/192/256 columns whose
+    weight rows fit 72 KB of LDS."""
+    if K not in (64, 128, 192, 256):
+        return False
+    for ns in (1, 2, 3, 4):
+        if NO % ns == 0 and NO // ns in (64, 128, 192, 256) and (NO // ns) * K * 2 <= 72 * 1024:
+            return True
+    return False
+
+
+def ea_linear_supported(a2, w):
+    """ea_linear: a [rows, in] (row-contiguous, bf16 / fp16 / fp32), w [out, in] contiguous in the 16-bit dtype."""
+    return (USE_EA_LINEAR and a2.is_cuda and a2.dim() == 2 and a2.stride(1) == 1 and a2.stride(0) % 8 == 0
+            and a2.shape[0] > 0 and (a2.storage_offset() * a2.element_size()) % 16 == 0
+            and w.dtype in _ELEM and w.is_contiguous() and a2.dtype in (w.dtype, torch.float32)
+            and _lin_geometry(w.shape[1], w.shape[0]))
+
+
+def linear_impl(a2, w, bias32, y_f32, want_cast):
+    """torch.ops.ea.linear: [y, rounded copy of a2 (empty unless asked for)]."""
+    nv.require_cuda(a2, "a")
+    y, ac = ea_linear(a2, w, bias32, torch.float32 if y_f32 else w.dtype, want_cast)
+    return [y, ac if ac is not None else a2.new_empty(0, dtype=w.dtype)]
+
+
+def ea_linear(a2, w, bias32, out_dtype, want_cast=False):
+    """y = a2 @ w.T (+ bias) by the streaming projection kernel (ea_linear.hip); fp32 `a2` is rounded to w.dtype on
+    the way in and, with want_cast, that rounded copy is returned as well."""
+    rows, K = a2.shape
+    NO = w.shape[0]
+    y = torch.empty((rows, NO), dtype=out_dtype, device=a2.device)
+    a_f32 = a2.dtype == torch.float32
+    a_cast = torch.empty((rows, K), dtype=w.dtype, device=a2.device) if (a_f32 and want_cast) else None
+    nv.call("ea_linear", _ELEM[w.dtype], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w), nv.ptr(bias32),
+            nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
+    return y, a_cast
+
+
 def wgrad_supported(dy2, x2):
     """ea_wgrad takes contiguous bf16 / fp16 [rows, out] and [rows, in] with out, in multiples of 64."""
     return (dy2.is_cuda and dy2.dtype in (torch.bfloat16, torch.float16) and x2.dtype == dy2.dtype
@@ -1365,10 +1408,18 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dtype):
         x2 = x.reshape(-1, x.shape[-1])
-        xl = x2 if x2.dtype == dtype else x2.to(dtype)
         wl = weight if weight.dtype == dtype else weight.to(dtype)
-        bl = None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype))
-        y = F.linear(xl, wl, bl)
+        if ea_linear_supported(x2, wl):
+            # streaming projection kernel: an fp32 x is rounded on the way in (no cast pass), its rounded copy comes
+            # back only when the weight gradient will need it
+            b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+            want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+            y, xc = torch.ops.ea.linear(x2, wl, b32, False, want)
+            xl = x2 if x2.dtype == dtype else (xc if want else None)
+        else:
+            xl = x2 if x2.dtype == dtype else x2.to(dtype)
+            bl = None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype))
+            y = F.linear(xl, wl, bl)
         ctx.save_for_backward(xl, wl)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y.view(x.shape[:-1] + (weight.shape[0],))
@@ -1382,7 +1433,11 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.to(xl.dtype)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _mm_out(dy2, wl, xdtype).view(xshape)
+            if wl.shape[0] <= 256 and xdtype in (torch.float32, wl.dtype) and ea_linear_supported(dy2, wl):
+                # dX = dY W as the same streaming kernel on the transposed weight (a [in, out] copy of <= 128 KB)
+                dx = torch.ops.ea.linear(dy2, wl.t().contiguous(), None, xdtype == torch.float32, False)[0].view(xshape)
+            else:
+                dx = _mm_out(dy2, wl, xdtype).view(xshape)
         need_w, need_b = ctx.needs_input_grad[1], (bdtype is not None and ctx.needs_input_grad[2])
         if need_w and USE_WGRAD and wgrad_supported(dy2, xl):
             # one pass over dY and X: weight gradient (+ bias gradient riding along) -- ea_wgrad

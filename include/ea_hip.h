@@ -411,6 +411,19 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
              float* dw_part, float* db_part, void* stream);
 
+/* The projections themselves as streaming kernels (ea_linear.hip): `qkv = self.qkv(x)`, `x = self.proj(x)`
+ * (abstract_attention.py:72-78,86-87) and, with the transposed weight, their input gradients.
+ *   y[rows, out] = a[rows, in] w[out, in]^T (+ bias[out])
+ * a: EA dtype, or fp32 when a_f32 != 0 (the autocast cast is folded into the load; a_cast, if not NULL, receives the
+ * rounded [rows, in] copy for the weight-gradient product); w: [out, in] contiguous in the EA dtype; bias fp32 or
+ * NULL (rounded to the EA dtype before the add, as F.linear under autocast does); y: EA dtype, or fp32 when
+ * y_f32 != 0; lda / ldy: row strides in elements.  ea_linear_supported(in, out) != 0 for the built geometries
+ * (in one of 64..768 in steps the models use, out a multiple of 64); EA_E_UNSUPPORTED otherwise. */
+int32_t ea_linear_supported(int32_t in_features, int32_t out_features);
+int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
+              int64_t lda, const void* w, const float* bias, void* y, int32_t y_f32, int64_t ldy, void* a_cast,
+              void* stream);
+
 /* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
  * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);
  * these entry points evaluate the m random-feature columns of the same softmax and merge the two halves:

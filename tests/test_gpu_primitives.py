@@ -147,3 +147,61 @@ def test_wgrad_matches_fp64(rows, M, K, dtype):
     assert bool(((db.double() - refb).abs() <= 4e-6 * dy.double().abs().sum(0) + 1e-6).all())
     dw2, db2 = _ops.wgrad(dy, x, True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,K,NO,a_f32,y_f32", [
+    (100352, 192, 576, 1, 0), (100352, 192, 192, 0, 0), (25088, 192, 768, 1, 0), (1001, 64, 128, 1, 1),
+    (50017, 128, 384, 0, 0), (30001, 256, 256, 1, 1), (77, 192, 576, 1, 0), (1, 64, 64, 0, 1), (4097, 256, 512, 0, 0)])
+def test_linear_matches_fp64(rows, K, NO, a_f32, y_f32, dtype):
+    """ea_linear (the qkv / output projection as a streaming kernel) against fp64 on the same rounded operands: fp32
+    accumulation of exact products, one rounding of the result; an fp32 input is rounded exactly like .to(dtype) and
+    the rounded copy handed back is that tensor."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(rows + K + NO)
+    a = torch.randn(rows, K, device="cuda", generator=g)
+    a = a if a_f32 else a.to(td)
+    w = (torch.randn(NO, K, device="cuda", generator=g) * K ** -0.5).to(td)
+    b = torch.randn(NO, device="cuda", generator=g)
+    assert _ops.ea_linear_supported(a, w)
+    y, ac = _ops.ea_linear(a, w, b, torch.float32 if y_f32 else td, want_cast=bool(a_f32))
+    a16 = a.to(td)
+    if a_f32:
+        assert torch.equal(ac, a16)
+    ref = a16.double() @ w.double().t() + b.to(td).double()
+    mag = a16.double().abs() @ w.double().abs().t() + b.double().abs()
+    tol = 4e-6 * mag + (0 if y_f32 else 1) * (2.0 ** (-8 if dtype == "bf16" else -11)) * ref.abs() + 1e-6
+    assert y.dtype == (torch.float32 if y_f32 else td)
+    assert bool(((y.double() - ref).abs() <= tol).all()), float((y.double() - ref).abs().max())
+    y2, _ = _ops.ea_linear(a, w, b, torch.float32 if y_f32 else td, want_cast=False)
+    assert torch.equal(y, y2)
+    # strided rows (a column slice of a wider tensor)
+    wide = torch.randn(rows, K + 64, device="cuda", generator=g).to(a.dtype)
+    av = wide[:, :K]
+    assert _ops.ea_linear_supported(av, w)
+    y3, _ = _ops.ea_linear(av, w, None, td)
+    ref3 = av.to(td).double() @ w.double().t()
+    mag3 = av.to(td).double().abs() @ w.double().abs().t()
+    assert bool(((y3.double() - ref3).abs() <= 4e-6 * mag3 + 2.0 ** (-8 if dtype == "bf16" else -11) * ref3.abs() + 1e-6).all())
+
+
+@pytest.mark.gpu
+def test_linear_unsupported_geometry_falls_to_library():
+    """Geometries the streaming kernel is not built for are refused by the C ABI (EA_E_UNSUPPORTED), and the autograd
+    Function routes them to the library GEMM."""
+    import torch
+    from efficient_attention import _ops
+    assert _ops.nv.lib().ea_linear_supported(576, 192) == 0 and not _ops._lin_geometry(576, 192)
+    assert _ops.nv.lib().ea_linear_supported(192, 576) != 0 and _ops._lin_geometry(192, 576)
+    for K in (64, 128, 192, 256, 320, 512):
+        for NO in (64, 96, 128, 192, 320, 384, 576, 768, 1024, 1536):
+            assert (_ops.nv.lib().ea_linear_supported(K, NO) != 0) == _ops._lin_geometry(K, NO), (K, NO)
+    x = torch.randn(300, 320, device="cuda", requires_grad=True)
+    lin = torch.nn.Linear(320, 960).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = _ops.linear(x, lin)
+    y.float().sum().backward()
+    assert x.grad is not None and lin.weight.grad is not None
