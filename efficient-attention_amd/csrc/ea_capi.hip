@@ -26,8 +26,9 @@ int linear_supported(int K, int NO);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
-int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, int rows, int M, int K,
-                   hipStream_t st);
+int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
+                   int K, hipStream_t st);
+int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipStream_t st);
 }
 
 using namespace ea;
@@ -807,9 +808,15 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features) 
 }
 
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
-             float* dw_part, float* db_part, void* stream) {
-  if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return EA_E_BADARG;
-  return wgrad_dispatch(dtype, dy, x, dw_part, db_part, rows, out_features, in_features, (hipStream_t)stream);
+             float* dw_part, float* db_part, int64_t part_ld, void* stream) {
+  if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw_part & 15)) return EA_E_BADARG;
+  if (part_ld < (int64_t)out_features * in_features || (part_ld & 3)) return EA_E_BADARG;
+  return wgrad_dispatch(dtype, dy, x, dw_part, db_part, (long)part_ld, rows, out_features, in_features, (hipStream_t)stream);
+}
+
+int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream) {
+  if (!parts || !out || ((uintptr_t)parts & 15) || ((uintptr_t)out & 15)) return EA_E_BADARG;
+  return part_sum_dispatch(parts, out, S, n, (long)ld, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -22,19 +22,20 @@ namespace ea {
 struct WgP {
   const char* dy;     // [rows, M] element type
   const char* x;      // [rows, K]
-  float* part;        // [S, M, K]
-  float* db_part;     // [S, M] or null
+  float* part;        // slice s: [M, K] at part + s * part_ld
+  float* db_part;     // slice s: [M] at db_part + s * part_ld, or null
+  long part_ld;
   int rows, M, K;
   int S, rows_per_slice, tiles_m, tiles_n;
 };
 
-template <typename E, int BM>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
-  constexpr int SA = BM / 64;                 // 64-channel sub-tiles of the dY stage
-  constexpr int NAF = SA * 2;                 // A fragments (16 out-channels each) per wave: half of SA*4
-  constexpr int NA = BM / 32;                 // 16-B staging chunks of dY per thread and stage
-  constexpr int CPRA = BM / 8;                // chunks per dY row
-  constexpr int STAGE = (SA + 1) * 64 * 128;  // bytes of one stage: SA + 1 sub-tiles of [64][64]
+template <typename E, int BM, int BN>
+__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
+  constexpr int SA = BM / 64, SB = BN / 64;   // 64-channel sub-tiles of the dY / X stage
+  constexpr int FA = BM / 64;                 // A fragments (16 out-channels) per wave: BM / 4 waves / 16
+  constexpr int FB = BN / 32;                 // B fragments (16 in-channels) per wave:  BN / 2 waves / 16
+  constexpr int CPRA = BM / 8, CPRB = BN / 8; // 16-B chunks per staged row
+  constexpr int STAGE = (SA + SB) * 64 * 128; // bytes of one stage: sub-tiles of [64 tokens][64 channels]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   // block -> (slice, tile): every tile of a slice on the same XCD (block id modulo 8)
@@ -43,37 +44,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
   const int tile = j % T, slice = (j / T) * 8 + xcd;
   if (slice >= p.S) return;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * 64;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int r0 = slice * p.rows_per_slice;
   const int r1 = min(p.rows, r0 + p.rows_per_slice);
   const bool with_bias = p.db_part != nullptr && tn == 0;
 
-  u32x4 pa[NA], pb[2];
+  u32x4 pa[SA], pb[SB];
   auto issue = [&](int rb) {
 #pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int idx = tid + k * 256;
+    for (int k = 0; k < SA; ++k) {
+      const int idx = tid + k * 512;
       const int row = idx / CPRA, ch = idx - row * CPRA;
       const int t = rb + row;
       pa[k] = t < r1 ? ldg16(p.dy + ((size_t)t * p.M + m0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + k * 256;
-      const int row = idx >> 3, ch = idx & 7;
+    for (int k = 0; k < SB; ++k) {
+      const int idx = tid + k * 512;
+      const int row = idx / CPRB, ch = idx - row * CPRB;
       const int t = rb + row;
       pb[k] = t < r1 ? ldg16(p.x + ((size_t)t * p.K + n0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  float accb[NA][8];
+  float accb[SA][8];
 #pragma unroll
-  for (int k = 0; k < NA; ++k)
+  for (int k = 0; k < SA; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) accb[k][e] = 0.f;
   auto commit = [&](char* st) {
 #pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int idx = tid + k * 256;
+    for (int k = 0; k < SA; ++k) {
+      const int idx = tid + k * 512;
       const int row = idx / CPRA, ch = idx - row * CPRA;
       sts16(st + (ch >> 3) * (64 * 128) + lds_off<64>(row, ch & 7), pa[k]);
       if (with_bias) {
@@ -84,32 +85,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
       }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + k * 256;
-      sts16(st + SA * (64 * 128) + lds_off<64>(idx >> 3, idx & 7), pb[k]);
+    for (int k = 0; k < SB; ++k) {
+      const int idx = tid + k * 512;
+      const int row = idx / CPRB, ch = idx - row * CPRB;
+      sts16(st + (SA + (ch >> 3)) * (64 * 128) + lds_off<64>(row, ch & 7), pb[k]);
     }
   };
 
-  const int wa = wave & 1, wb = wave >> 1;
+  // 8 waves as 4 (out channels) x 2 (in channels): wave (wa, wb) owns [BM / 4] x [BN / 2] of the tile
+  const int wa = wave & 3, wb = wave >> 2;
   const int wr = 4 * g + (li >> 2);
   // per-fragment LDS offsets, computed (not looked up: an array indexed by the runtime wave id lives in scratch,
   // and a scratch access shares -- and drains -- the vmcnt queue of the prefetched global loads)
-  int aoff[NAF];
+  int aoff[FA], boff[FB];
 #pragma unroll
-  for (int f = 0; f < NAF; ++f) {
-    const int fa = wa * NAF + f, dt = fa & 3;
+  for (int f = 0; f < FA; ++f) {
+    const int fa = wa * FA + f, dt = fa & 3;           // 16-channel group fa of the dY stage: sub-tile fa / 4
     const int colb = (16 * (li & 3) + 4 * dt) * 2;
     aoff[f] = (fa >> 2) * (64 * 128) + wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
   }
-  int btr[2];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int colb = (16 * (2 * wb + c) + 4 * (li & 3)) * 2;
-    btr[c] = wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
+  for (int c = 0; c < FB; ++c) {
+    const int fb = wb * FB + c;                        // 16-channel group fb of the X stage
+    const int colb = (16 * (fb & 3) + 4 * (li & 3)) * 2;
+    boff[c] = (SA + (fb >> 2)) * (64 * 128) + wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
   }
-  f32x4 acc[NAF][2];
+  f32x4 acc[FA][FB];
 #pragma unroll
-  for (int f = 0; f < NAF; ++f) acc[f][0] = acc[f][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < FA; ++f)
+#pragma unroll
+    for (int c = 0; c < FB; ++c) acc[f][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(r0);
   commit(smem);
@@ -121,53 +126,99 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     if (more) issue(rb + 64);
 #pragma unroll
     for (int kb = 0; kb < 64; kb += 32) {
-      typename E::x8 bf[2];
+      typename E::x8 af[FA];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const char* bp = cur + SA * (64 * 128) + kb * 128 + btr[c];
-        bf[c] = as_x8<E>(E::tr4(bp), E::tr4(bp + 16 * 128));
+      for (int f = 0; f < FA; ++f) {
+        const char* ap = cur + kb * 128 + aoff[f];
+        af[f] = as_x8<E>(E::tr4(ap), E::tr4(ap + 16 * 128));
       }
 #pragma unroll
-      for (int f = 0; f < NAF; ++f) {
-        const char* ap = cur + kb * 128 + aoff[f];       // fragment wa * NAF + f: sub-tile fa / 4, channel group fa % 4
-        const typename E::x8 af = as_x8<E>(E::tr4(ap), E::tr4(ap + 16 * 128));
-        acc[f][0] = E::mma(af, bf[0], acc[f][0]);
-        acc[f][1] = E::mma(af, bf[1], acc[f][1]);
+      for (int c = 0; c < FB; ++c) {
+        const char* bp = cur + kb * 128 + boff[c];
+        const typename E::x8 bf = as_x8<E>(E::tr4(bp), E::tr4(bp + 16 * 128));
+#pragma unroll
+        for (int f = 0; f < FA; ++f) acc[f][c] = E::mma(af[f], bf, acc[f][c]);
       }
     }
     if (more) commit(smem + (buf ^ 1) * STAGE);
     __syncthreads();
     buf ^= 1;
   }
-  // ---- partial tile -> part[slice][m][n]: D row 4g+r of fragment fa <-> out channel 64 sa + 16 g + 4 dt + r ----
-  float* out = p.part + (size_t)slice * p.M * p.K;
+  // ---- partial tile -> part[slice][m][n], through LDS so that it leaves in 16-byte row segments (D row 4g+r of
+  // fragment fa <-> out channel 64 sa + 16 g + 4 dt + r, D column li of fragment fb <-> in channel 16 fb + li): 72
+  // dword stores per lane straight from the accumulators would cost more than the whole stream.  The stage buffers
+  // are free; one half of the in-channels (the waves of one wb) at a time fits them.
+  float* out = p.part + (size_t)slice * p.part_ld;
+  float* ot = reinterpret_cast<float*>(smem);             // [BM][BN / 2]
+  constexpr int HN = BN / 2;
 #pragma unroll
-  for (int f = 0; f < NAF; ++f) {
-    const int fa = wa * NAF + f, sa = fa >> 2, dt = fa & 3;
+  for (int h = 0; h < 2; ++h) {
+    if (wb == h) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int n = n0 + 16 * (2 * wb + c) + li;
+      for (int f = 0; f < FA; ++f) {
+        const int fa = wa * FA + f, sa = fa >> 2, dt = fa & 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 64 * sa + 16 * g + 4 * dt + r;
-        out[(size_t)m * p.K + n] = acc[f][c][r];
+        for (int c = 0; c < FB; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[(64 * sa + 16 * g + 4 * dt + r) * HN + 16 * c + li] = acc[f][c][r];
       }
     }
+    __syncthreads();
+    for (int idx = tid; idx < BM * (HN / 4); idx += 512) {
+      const int m = idx / (HN / 4), c4 = idx - m * (HN / 4);
+      *reinterpret_cast<f32x4*>(out + (size_t)(m0 + m) * p.K + n0 + h * HN + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(ot + m * HN + c4 * 4);
+    }
+    __syncthreads();
   }
   if (!with_bias) return;
   // ---- bias partial: 64 staged rows per column group, summed through LDS in a fixed order ----
-  float* red = reinterpret_cast<float*>(smem);            // [NA * 256][8] (the stage buffers are free)
+  float* red = reinterpret_cast<float*>(smem);            // [SA * 512][8] (the stage buffers are free)
 #pragma unroll
-  for (int k = 0; k < NA; ++k)
+  for (int k = 0; k < SA; ++k)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[(size_t)(tid + k * 256) * 8 + e] = accb[k][e];
+    for (int e = 0; e < 8; ++e) red[(size_t)(tid + k * 512) * 8 + e] = accb[k][e];
   __syncthreads();
   if (tid < BM) {
     const int ch = tid >> 3, e = tid & 7;
     float s = 0.f;
     for (int row = 0; row < 64; ++row) s += red[(size_t)(row * CPRA + ch) * 8 + e];
-    p.db_part[(size_t)slice * p.M + m0 + tid] = s;
+    p.db_part[(size_t)slice * p.part_ld + m0 + tid] = s;
   }
+}
+
+// out[j] = sum_s part[s * ld + j], j < n (n, ld multiples of 4): the slice partials of a weight (+ bias) gradient, added
+// in a fixed order.  A block owns 32 float4 columns; its 8 slice lanes each add every 8th slice (four independent
+// loads in flight per thread), then lane 0 adds the 8 lane sums in order.
+__global__ __launch_bounds__(256) void part_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int n4,
+                                                       long ld4) {
+  __shared__ f32x4 red[8][32];
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + min(j, n4 - 1);
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = sl;
+  for (; s + 24 < S; s += 32) {
+    const f32x4 v0 = src[(size_t)s * ld4], v1 = src[(size_t)(s + 8) * ld4];
+    const f32x4 v2 = src[(size_t)(s + 16) * ld4], v3 = src[(size_t)(s + 24) * ld4];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < S; s += 8) a0 += src[(size_t)s * ld4];
+  red[sl][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && j < n4) {
+    f32x4 t = red[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][c];
+    reinterpret_cast<f32x4*>(out)[j] = t;
+  }
+}
+
+int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipStream_t st) {
+  if (S <= 0 || n <= 0 || (n & 3) || (ld & 3) || ld < n) return EA_E_BADARG;
+  const int n4 = n / 4;
+  hipLaunchKernelGGL(part_sum_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, part, out, S, n4, ld / 4);
+  return (int)hipGetLastError();
 }
 
 static int wg_cus() {
@@ -181,50 +232,58 @@ static int wg_cus() {
   return n;
 }
 
-static int wg_bm(int M) { return M % 192 == 0 ? 192 : (M % 128 == 0 ? 128 : 64); }
+static int wg_bt(int M) { return M % 192 == 0 ? 192 : (M % 128 == 0 ? 128 : 64); }
 
-// token slices: about one workgroup per CU in total, a multiple of 8 (one XCD each), >= 256 tokens each
+// token slices: one workgroup per CU (96 KB of LDS each), the tiles of a slice on one XCD (32 CUs), >= 256 tokens each
 int wgrad_slices(int rows, int M, int K) {
   if (rows <= 0 || M <= 0 || K <= 0 || (M & 63) || (K & 63)) return EA_E_UNSUPPORTED;
-  const int T = (M / wg_bm(M)) * (K / 64);
-  static const int per_cu = getenv("EA_WGRAD_PER_CU") ? atoi(getenv("EA_WGRAD_PER_CU")) : 1;
-  int S = (per_cu * wg_cus() + T / 2) / T;
-  S = (S + 4) / 8 * 8;
+  const int T = (M / wg_bt(M)) * (K / wg_bt(K));
+  const int per_xcd = wg_cus() / 8;
+  int S = per_xcd / T * 8;
   if (S < 8) S = 8;
   while (S > 8 && rows / S < 256) S -= 8;
-  if (S > 128) S = 128;
   return S;
 }
 
-template <typename E, int BM>
+template <typename E, int BM, int BN>
 static int launch_wg(const WgP& p, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM / 64 + 1) * 64 * 128;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<E, BM>),
+  const size_t lds = (size_t)2 * (BM / 64 + BN / 64) * 64 * 128;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<E, BM, BN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    attr_set = true;
   }
   const int T = p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * T)), block(256);
-  hipLaunchKernelGGL((wgrad_kernel<E, BM>), grid, block, lds, st, p);
+  const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * T)), block(512);
+  hipLaunchKernelGGL((wgrad_kernel<E, BM, BN>), grid, block, lds, st, p);
   return (int)hipGetLastError();
 }
 
-int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, int rows, int M, int K,
-                   hipStream_t st) {
+template <typename E, int BM>
+static int launch_wg_n(const WgP& p, int bn, hipStream_t st) {
+  if (bn == 192) return launch_wg<E, BM, 192>(p, st);
+  if (bn == 128) return launch_wg<E, BM, 128>(p, st);
+  return launch_wg<E, BM, 64>(p, st);
+}
+
+int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
+                   int K, hipStream_t st) {
   const int S = wgrad_slices(rows, M, K);
   if (S < 0) return S;
   WgP p;
   p.dy = (const char*)dy; p.x = (const char*)x; p.part = part; p.db_part = db_part;
   p.rows = rows; p.M = M; p.K = K; p.S = S;
-  p.rows_per_slice = ((rows + S - 1) / S + 63) / 64 * 64;
-  const int bm = wg_bm(M);
-  p.tiles_m = M / bm; p.tiles_n = K / 64;
+  p.part_ld = part_ld;
+  p.rows_per_slice = (rows + S - 1) / S;
+  const int bm = wg_bt(M), bn = wg_bt(K);
+  p.tiles_m = M / bm; p.tiles_n = K / bn;
 #define EA_WG(E)                                                        \
   do {                                                                  \
-    if (bm == 192) return launch_wg<E, 192>(p, st);                     \
-    if (bm == 128) return launch_wg<E, 128>(p, st);                     \
-    return launch_wg<E, 64>(p, st);                                     \
+    if (bm == 192) return launch_wg_n<E, 192>(p, bn, st);               \
+    if (bm == 128) return launch_wg_n<E, 128>(p, bn, st);               \
+    return launch_wg_n<E, 64>(p, bn, st);                               \
   } while (0)
   if (dtype == EA_BF16) EA_WG(BF16);
   if (dtype == EA_F16) EA_WG(F16);

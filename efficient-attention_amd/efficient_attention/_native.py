@@ -105,7 +105,8 @@ SIGNATURES = {
     "ea_linear_supported": [_I, _I],
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
-    "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
+    "ea_part_sum": [_I, _I, _L, _P, _P, _P],
     "ea_scatter_parts": [_SG],
     "ea_scatter_kmax": [_SG, _T, _P, _P, _P, _P],
     "ea_scatter_kv": [_SG, _T, _T, _P, _P, _P, _P, _P, _P],

@@ -1374,11 +1374,11 @@ def wgrad_supported(dy2, x2):
             and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 64)
 
 
-# The hand-written one-pass weight + bias gradient (ea_wgrad) reads dY and X exactly once from HBM
-# (rocprofv3 FETCH_SIZE = algorithmic) but re-reads every row three times out of L2, which delivers
-# ~5.3 TB/s for this pattern: 87 us / 45 us for the two cfg3 projections -- on par with the library
-# split-K GEMM + ea_bias_grad it would replace.  It stays an opt-in path (EA_WGRAD=1).
-USE_WGRAD = os.environ.get("EA_WGRAD", "0") == "1"
+# The hand-written one-pass weight + bias gradient (ea_wgrad): [192 x 192] tiles of dW per 8-wave workgroup, one workgroup
+# per CU, dY read once and X once per 192 output channels; slice partials (dW and db side by side) added by ea_part_sum.
+# 51 us / 31 us for the two cfg3 projections against 94 / 48 us for the library split-K GEMM + its reduction + the
+# bias-gradient pass.  EA_WGRAD=0 switches back to the library path.
+USE_WGRAD = os.environ.get("EA_WGRAD", "1") == "1"
 
 
 def wgrad(dy2, x2, with_bias=True):
@@ -1391,11 +1391,14 @@ def wgrad(dy2, x2, with_bias=True):
     S = nv.lib().ea_wgrad_parts(rows, M, K)
     if S <= 0:
         raise RuntimeError("ea_wgrad_parts: %d" % S)
-    part = torch.empty((S, M, K), dtype=torch.float32, device=dy2.device)
-    db_part = torch.empty((S, M), dtype=torch.float32, device=dy2.device) if with_bias else None
-    nv.call("ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), nv.ptr(db_part), nv.stream())
-    dw = slice_sum(part)
-    db = colsum_f32(db_part) if with_bias else None
+    n = M * K + (M if with_bias else 0)
+    part = torch.empty((S, n), dtype=torch.float32, device=dy2.device)      # slice s: dW partial, then db partial
+    db_ptr = ctypes.c_void_p(part.data_ptr() + M * K * 4) if with_bias else None
+    nv.call("ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), db_ptr, n, nv.stream())
+    out = torch.empty(n, dtype=torch.float32, device=dy2.device)
+    nv.call("ea_part_sum", S, n, n, nv.ptr(part), nv.ptr(out), nv.stream())
+    dw = out[:M * K].view(M, K)
+    db = out[M * K:] if with_bias else None
     return dw, db
 
 

@@ -404,12 +404,16 @@ int ea_rows_mlp_bwd(int32_t R, int32_t D, int32_t sides, int32_t layer_norm,
  * of `qkv = self.qkv(x)` / `x = self.proj(x)` (abstract_attention.py:72-78,86-87) with respect to the
  * Linear's parameters.  dy [rows, out_features], x [rows, in_features]: contiguous, EA_BF16 / EA_F16;
  * out_features and in_features multiples of 64 (EA_E_UNSUPPORTED otherwise).
- *   dw_part [S, out_features, in_features] fp32, db_part [S, out_features] fp32 or NULL,
- *   S = ea_wgrad_parts(rows, out_features, in_features): per-token-slice partial sums; the caller adds
- *   the S slices (ea_slice_sum / ea_colsum_f32: fixed order, deterministic). */
+ *   Slice s leaves its partial sums at dw_part + s * part_ld ([out_features, in_features] fp32) and, when db_part is not
+ *   NULL, db_part + s * part_ld ([out_features] fp32); S = ea_wgrad_parts(rows, out_features, in_features), part_ld >=
+ *   out_features * in_features and a multiple of 4.  With db_part = dw_part + out_features * in_features and part_ld =
+ *   out_features * (in_features + 1) one ea_part_sum adds both up.
+ * ea_part_sum: out[j] = sum_s parts[s * ld + j], j < n (n, ld multiples of 4), slices added in a fixed order
+ *   (deterministic; no atomics). */
 int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
-             float* dw_part, float* db_part, void* stream);
+             float* dw_part, float* db_part, int64_t part_ld, void* stream);
+int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream);
 
 /* The projections themselves as streaming kernels (ea_linear.hip): `qkv = self.qkv(x)`, `x = self.proj(x)`
  * (abstract_attention.py:72-78,86-87) and, with the transposed weight, their input gradients.
