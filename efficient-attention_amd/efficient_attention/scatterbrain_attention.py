@@ -13,9 +13,12 @@ statistics, P.V and its backward -- is the HIP window kernel (`_ops.LocalAttnLse
 the per-query log-sum-exp); the feature columns are merged with it exactly through that log-sum-exp
 (out = e^{lse_loc - Z} o_loc + e^{R - Z} o_rfa, Z = logaddexp(lse_loc, R)).  The feature statistics
 themselves (global-minus-window sums) are batched GEMMs and reductions on torch device ops in fp32 --
-a dedicated kernel for them is the next step.  Window overlap is not built: the
-reference partitions the log-features with zero padding there, which makes out-of-range slots count
-as phi = 1.
+on HIP as well when the windows do not overlap (ea_scatter.hip).  With window overlap the
+key side of a window is the extended patch and the reference's zero padding of the partitioned
+log-features makes every out-of-range slot count as a key with phi = 1 and v = 0 (reference :99-100); that
+variant keeps the window half on the HIP kernel and evaluates the feature half with torch device ops.
+(The reference returns NaN there as soon as a border window's padding outweighs the features of the keys
+outside it -- tests/golden/cases.py -- so it is a path for small-key regimes.)
 """
 import math
 
@@ -31,9 +34,28 @@ from .local_attention import LocalAttention
 class ScatterBrain(KernelizedAttention, LocalAttention):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if self.ext_size > 0:
-            raise NotImplementedError("ScatterBrain with overlapping windows is not built for MI355X")
+        self._slot_cache = {}
         self.apply(self._init_weights)
+
+    def _key_slots(self, seq_shape, device):
+        """[G, Wk] token index of every slot of every extended key window, N (one past the end) for the slots that
+        leave the sequence (attn_utils.py:155-166 / 190-210 as an index table)."""
+        key = (tuple(seq_shape), str(device))
+        if key not in self._slot_cache:
+            w, e = self.window_size, self.ext_size
+            t = w + 2 * e
+            if self.attn_2d:
+                H, W = seq_shape
+                y = (torch.arange(H // w, device=device) * w - e).view(-1, 1, 1, 1) + torch.arange(t, device=device).view(1, 1, -1, 1)
+                x = (torch.arange(W // w, device=device) * w - e).view(1, -1, 1, 1) + torch.arange(t, device=device).view(1, 1, 1, -1)
+                ok = (y >= 0) & (y < H) & (x >= 0) & (x < W)
+                tok = torch.where(ok, y * W + x, torch.full_like(y * W + x, H * W)).reshape(-1, t * t)
+            else:
+                N = seq_shape[0]
+                tok = (torch.arange(N // w, device=device) * w - e).view(-1, 1) + torch.arange(t, device=device).view(1, -1)
+                tok = torch.where((tok >= 0) & (tok < N), tok, torch.full_like(tok, N))
+            self._slot_cache[key] = tok
+        return self._slot_cache[key]
 
     def forward(self, x, key_padding_mask=None):
         B, *seq_shape, C = x.shape
@@ -64,8 +86,8 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
         m = proj.shape[1]
         mask_u8 = _ops._mask_u8(mask, B, N, qkv5.device)
         o_loc, lse_loc = _ops.LocalAttnLseFn.apply(
-            qkv5, self._table_bias(), mask_u8, self.attn_2d, tuple(seq_shape), w, 0)
-        if _ops.scatter_supported(qkv5, proj, self.attn_2d, seq_shape, w) and not _ops.SCATTER_TORCH:
+            qkv5, self._table_bias(), mask_u8, self.attn_2d, tuple(seq_shape), w, self.ext_size)
+        if self.ext_size == 0 and _ops.scatter_supported(qkv5, proj, self.attn_2d, seq_shape, w) and not _ops.SCATTER_TORCH:
             # feature half + merge on HIP (ea_scatter.hip); wider windows / more features fall through to torch ops
             return _ops.ScatterFeatureFn.apply(qkv5, o_loc, lse_loc, mask_u8, proj, self.attn_2d, tuple(seq_shape), w)
 
@@ -100,12 +122,25 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
                 lk = lk.masked_fill(mask.to(torch.bool)[:, None, :, None], float("-inf"))
             # phi(k) sums over all keys minus those of the window, one (detached) stabiliser per feature
             mx = lk.amax(dim=-2, keepdim=True).detach()
-            pk = torch.exp(lk - mx)                                                 # [B,h,N,m]
-            w_pk, w_v = win(pk), win(v)
-            s_win = torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)                   # [B,h,G,m,d]
-            z_win = w_pk.sum(-2)                                                    # [B,h,G,m]
-            # the global sums are the sums of the window sums (windows partition the sequence)
-            s_all, z_all = s_win.sum(2, keepdim=True), z_win.sum(2, keepdim=True)
+            if self.ext_size > 0:
+                # overlapping windows: sums over the extended patch, gathered; a slot outside the sequence is a key
+                # with log-feature 0 and v = 0 (the reference's zero padding), which also enters the stabiliser
+                mx = mx.clamp(min=0.0)
+                pk = torch.exp(lk - mx)
+                slots = self._key_slots(seq_shape, q.device)                            # [G, Wk], N = outside
+                w_pk = torch.cat([pk, torch.exp(-mx)], dim=2)[:, :, slots]              # [B,h,G,Wk,m]
+                w_v = torch.cat([v, v.new_zeros(B, h, 1, d)], dim=2)[:, :, slots]       # [B,h,G,Wk,d]
+                s_win = torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)
+                z_win = w_pk.sum(-2)
+                s_all = torch.einsum("bhnc,bhnd->bhcd", pk, v).unsqueeze(2)
+                z_all = pk.sum(-2).unsqueeze(2)
+            else:
+                pk = torch.exp(lk - mx)                                                 # [B,h,N,m]
+                w_pk, w_v = win(pk), win(v)
+                s_win = torch.einsum("bhgwc,bhgwd->bhgcd", w_pk, w_v)                   # [B,h,G,m,d]
+                z_win = w_pk.sum(-2)                                                    # [B,h,G,m]
+                # the global sums are the sums of the window sums (windows partition the sequence)
+                s_all, z_all = s_win.sum(2, keepdim=True), z_win.sum(2, keepdim=True)
             kv_stats = (s_all - s_win) / (z_all - z_win).unsqueeze(-1).clamp(min=1e-3)
             # log-sum-exp of the log-features from the same sums: log z + stabiliser
             lse_all = torch.log(z_all) + mx                                         # [B,h,1,m]

@@ -468,9 +468,8 @@ def performer_core(q, k, v, mask, proj):
 # --------------------------------------------------------------------------------------
 # ScatterBrain (local windows + low-rank random features under one softmax)
 # --------------------------------------------------------------------------------------
-def scatterbrain_core(q, k, v, mask, attn_2d, seq_shape, window_size, proj, bias=None, scale=None):
-    """ScatterBrain's q,k,v -> out core without window overlap (scatterbrain_attention.py:10-44,
-    71-160).  q,k,v [B,h,N,d] with N covered by whole windows; mask [B,N] bool or None; proj [h,m,d]
+def scatterbrain_core(q, k, v, mask, attn_2d, seq_shape, window_size, proj, bias=None, scale=None, ext_size=0):
+    """ScatterBrain's q,k,v -> out core (scatterbrain_attention.py:10-44, 71-160).  q,k,v [B,h,N,d] with N covered by whole windows; mask [B,N] bool or None; proj [h,m,d]
     random features; bias None or [h, Wq, Wk].
 
     log phi(x)[c] = d^-1/4 <W_c, x> - |x|^2 d^-1/2 / 2 - ln(m) / 2 (-inf for padded keys).  Per window
@@ -489,15 +488,23 @@ def scatterbrain_core(q, k, v, mask, attn_2d, seq_shape, window_size, proj, bias
         return dash - 0.5 * d ** -0.5 * (x * x).sum(-1, keepdim=True) - math.log(m) / 2
     lq = log_phi(q)
     lk = log_phi(k).masked_fill(mask[:, None, :, None], float("-inf"))
+    # With window overlap (ext_size > 0) the key side of a window is the extended patch; slots outside the sequence
+    # are zero padding of the reference's window_partition: v = 0 and, for the log-features, 0 as well (phi = 1, NOT
+    # -inf: the partition pads with pad_val = 0, scatterbrain_attention.py:99-100), masked in the local dots only
+    # (pad_val = 1, :139-144).
+    e = ext_size
     if attn_2d:
         idx = window_index_2d(seq_shape[0], seq_shape[1], w, 0)
+        idx_k = window_index_2d(seq_shape[0], seq_shape[1], w, e)
     else:
         idx = window_index_1d(n, w, 0)
+        idx_k = window_index_1d(n, w, e)
     G, Wq = idx.shape
     flat = idx.reshape(-1)
-    w_q, w_k, w_v = (t[:, :, flat].reshape(B, h, G, Wq, d) for t in (q, k, v))
+    w_q = q[:, :, flat].reshape(B, h, G, Wq, d)
+    w_k, w_v = _gather_tokens(k, idx_k), _gather_tokens(v, idx_k)
     w_lq = lq[:, :, flat].reshape(B, h, G, Wq, m)
-    w_lk = lk[:, :, flat].reshape(B, h, G, Wq, m)
+    w_lk = _gather_tokens(lk, idx_k)
     # feature sums over all keys minus those of the window, with a shared (detached) stabiliser
     mx = torch.maximum(lk.amax(dim=-2, keepdim=True).unsqueeze(-3),
                        w_lk.amax(dim=(-2, -3), keepdim=True)).detach()             # [B,h,1,1,m]
@@ -514,11 +521,12 @@ def scatterbrain_core(q, k, v, mask, attn_2d, seq_shape, window_size, proj, bias
     dots = scale * torch.einsum("bhwie,bhwje->bhwij", w_q, w_k)
     if bias is not None:
         dots = dots + bias[None, :, None]
-    wmask = mask[:, flat].reshape(B, 1, G, 1, Wq)
+    wmask = _gather_mask(mask, idx_k)[:, None, :, None, :]
     dots = dots.masked_fill(wmask, float("-inf"))
+    Wk = idx_k.shape[1]
     p = torch.softmax(torch.cat([dots, log_rfa], -1), -1)
-    out_w = torch.einsum("bhwij,bhwjd->bhwid", p[..., :Wq], w_v) \
-        + torch.einsum("bhwic,bhwcd->bhwid", p[..., Wq:], kv_stats)
+    out_w = torch.einsum("bhwij,bhwjd->bhwid", p[..., :Wk], w_v) \
+        + torch.einsum("bhwic,bhwcd->bhwid", p[..., Wk:], kv_stats)
     return _scatter_windows(out_w, idx, n)
 
 
@@ -564,7 +572,7 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
 
     if attn == "scatterbrain":
         w = a["window_size"]
-        assert not a["overlap_window"], "the restatement covers ScatterBrain without window overlap"
+        e = max(1, w // 2) if a["overlap_window"] else 0
         orig_n = int(math.prod(seq_shape))
         if a["attn_2d"]:
             n, xs = orig_n, x.reshape(B, orig_n, C)
@@ -579,8 +587,8 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
             seq_shape = [n]
         q, k, v = _split_heads(xs, params, h)
         proj = noise_fn((h, a["approx_attn_dim"], d)).to(x.dtype) if training else params["eval_proj"]
-        bias = _local_bias(params, a, h, 0, scale)
-        out = scatterbrain_core(q, k, v, mask, a["attn_2d"], seq_shape, w, proj, bias, scale)
+        bias = _local_bias(params, a, h, e, scale)
+        out = scatterbrain_core(q, k, v, mask, a["attn_2d"], seq_shape, w, proj, bias, scale, ext_size=e)
         y = F.linear(out.permute(0, 2, 1, 3).reshape((B,) + tuple(seq_shape) + (C,)),
                      params["proj.weight"], params["proj.bias"])
         return y if a["attn_2d"] else y[..., :orig_n, :]

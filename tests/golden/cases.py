@@ -98,13 +98,26 @@ CASES = {
         attn="ra", x_shape=(2, 50, 128), mask=("tail", [0, 9]), args=dict(dim=128, num_heads=2, num_samples=0)),
     "ra_sampled_1d": dict(  # num_samples = 1: one key index per query (injected draws)
         attn="ra", x_shape=(2, 70, 128), mask=None, args=dict(dim=128, num_heads=2, num_samples=1)),
-    # ---------------- ScatterBrain (scatterbrain_attention.py:46-180), no window overlap --
+    # ---------------- ScatterBrain (scatterbrain_attention.py:46-180) ------------------------
     "scatterbrain_1d_mask": dict(  # N = 50 -> padded to 56 (7 windows of 8), pad mask, 1-D rpe table
         attn="scatterbrain", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
         args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True, approx_attn_dim=32)),
     "scatterbrain_2d": dict(
         attn="scatterbrain", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_rpe=True, approx_attn_dim=64)),
+    # window overlap: the key side of a window is the extended patch, its out-of-range slots zero padding (phi = 1)
+    # The reference returns NaN here whenever a border window's padding slots (phi = 1 each) outweigh the features of
+    # the keys outside it, log(sum_all - sum_window + 1e-5) of a negative number: any masked / padded 1-D sequence, a
+    # grid of 2 x 2 windows, or simply keys of ordinary size (phi(k) << 1).  The two cases use small inputs (x_scale),
+    # for which it is finite.
+    "scatterbrain_1d_overlap": dict(
+        attn="scatterbrain", x_shape=(2, 128, 128), mask=None, x_scale=0.05,
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True, approx_attn_dim=32,
+                  overlap_window=True)),
+    "scatterbrain_2d_overlap": dict(
+        attn="scatterbrain", x_shape=(1, 28, 28, 128), mask=None, x_scale=0.05,
+        args=dict(dim=128, num_heads=2, window_size=4, attn_2d=True, use_rpe=True, approx_attn_dim=16,
+                  overlap_window=True)),
     # ---------------- local baseline (local_attention.py:25-194) -----------------------
     "local_2d_rpe": dict(
         attn="local", x_shape=(1, 14, 14, 128), mask=None,
@@ -207,7 +220,7 @@ def make_params(name, key_shapes):
 
 def make_inputs(name):
     case = CASES[name]
-    x = rng_for(name, "x").standard_normal(case["x_shape"]).astype(np.float32)
+    x = (case.get("x_scale", 1.0) * rng_for(name, "x").standard_normal(case["x_shape"])).astype(np.float32)
     g = rng_for(name, "g").standard_normal(case["x_shape"]).astype(np.float32)
     mask = None
     if case["mask"] is not None:

@@ -42,8 +42,8 @@ def test_factory_names_and_errors():
     with pytest.raises(NotImplementedError):
         ea.AttentionFactory.build_attention("eva", dict(dim=64, num_heads=2, use_rpe=True, use_t5_rpe=True,
                                                         window_size=4))
-    with pytest.raises(NotImplementedError):                     # window overlap is not built for ScatterBrain
-        ea.AttentionFactory.build_attention("scatterbrain", dict(dim=64, num_heads=2, window_size=4, overlap_window=True))
+    sb = ea.AttentionFactory.build_attention("scatterbrain", dict(dim=64, num_heads=2, window_size=4, overlap_window=True))
+    assert sb.ext_size == 2                                      # window overlap: extended key patch (local_attention.py:36-40)
 
 
 DEFAULTS = {
