@@ -22,6 +22,8 @@ int rows_mlp_blocks(int R, int D);
 int lara_x_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_y_dispatch(int mode, const LaraP& p, int dtype, hipStream_t st);
 int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
+int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long sn, float* mean, int B, int H, int gh, int gw,
+                    int side, int D, hipStream_t st);
 int linear_supported(int K, int NO);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
@@ -623,6 +625,25 @@ int ea_lara_landmarks_fwd(const ea_lmk_geom* g, const float* pq, const float* pk
   return lara_lmk_dispatch(false, p, (hipStream_t)stream);
 }
 
+int ea_lara_landmarks_fwd_cb(const ea_lmk_geom* g, const float* pq, const float* pk,
+                             const float* Wq, const float* bq, const float* gq, const float* cq,
+                             const float* Wk, const float* bk, const float* gk, const float* ck,
+                             const float* noise, const float* colbias, float* omega, float* qbar_rows, float* bhv,
+                             float* lp, float* saved, void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pq || !pk || !omega || !lp || g->eva || !g->mixed || !colbias) return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar_rows || !bhv)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar_rows) return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.omega = omega; p.qbar_rows = qbar_rows; p.bhv = bhv; p.lp = lp;
+  p.saved = saved; p.colbias = colbias;
+  return lara_lmk_dispatch(false, p, (hipStream_t)stream);
+}
+
 int64_t ea_lara_landmarks_saved_floats(const ea_lmk_geom* g) {
   LmkP p = {};
   if (fill_lmk(g, p) != EA_OK) return EA_E_BADARG;
@@ -647,6 +668,27 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
   p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
   p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
   p.saved = const_cast<float*>(saved);
+  return lara_lmk_dispatch(true, p, (hipStream_t)stream);
+}
+
+int ea_lara_landmarks_bwd_cb(const ea_lmk_geom* g, const float* pq, const float* pk,
+                             const float* Wq, const float* bq, const float* gq, const float* cq,
+                             const float* Wk, const float* bk, const float* gk, const float* ck,
+                             const float* noise, const float* colbias, const float* d_omega, const float* d_qbar_rows,
+                             const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                             float* dW_part, float* dvec_part, float* d_colbias, const float* saved, void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pq || !pk || !d_omega || !d_lp || !dpq || !dpk || g->eva || !g->mixed || !colbias || !d_colbias || !saved)
+    return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
+    return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
+  p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
+  p.saved = const_cast<float*>(saved); p.colbias = colbias; p.d_colbias = d_colbias;
   return lara_lmk_dispatch(true, p, (hipStream_t)stream);
 }
 
@@ -817,6 +859,25 @@ int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_featu
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream) {
   if (!parts || !out || ((uintptr_t)parts & 15) || ((uintptr_t)out & 15)) return EA_E_BADARG;
   return part_sum_dispatch(parts, out, S, n, (long)ld, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- adaptive 2-D pooling of a token grid that does not divide evenly (ea_lara_segment.hip) ----
+extern "C" {
+
+int ea_adaptive_pool2d_fwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int32_t gw, int32_t side, int32_t D,
+                           const ea_t4* x, float* mean, void* stream) {
+  if (!x || !x->ptr || !mean) return EA_E_BADARG;
+  return pool2d_dispatch(false, dtype, x->ptr, (long)x->sb, (long)x->sh, (long)x->sn, mean, B, H, gh, gw, side, D,
+                         (hipStream_t)stream);
+}
+
+int ea_adaptive_pool2d_bwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int32_t gw, int32_t side, int32_t D,
+                           const float* dmean, const ea_t4* dx, void* stream) {
+  if (!dx || !dx->ptr || !dmean) return EA_E_BADARG;
+  return pool2d_dispatch(true, dtype, dx->ptr, (long)dx->sb, (long)dx->sh, (long)dx->sn, const_cast<float*>(dmean), B, H, gh,
+                         gw, side, D, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -705,6 +705,7 @@ int lara_lmk_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
   // EA_LMK_V1=1 keeps the round-1 kernels below (fp32 matrices in LDS) for A/B comparison
   static const bool v1 = getenv("EA_LMK_V1") && getenv("EA_LMK_V1")[0] == '1';
   if (!v1 && lmk2_supported(bwd, p)) return lmk2_dispatch(bwd, p, st);
+  if (p.colbias || p.d_colbias) return EA_E_UNSUPPORTED;      // '-vmixed' column bias: second-generation kernels only
 #ifdef EA_PROFILE
   ProfReport rep;
   p.prof = rep.arm(st, "lara_lmk", bwd ? 1 : 0);

@@ -16,6 +16,8 @@ struct LmkP {
   int eva;                                                // EVA's mu pipeline (eva.py:178-190) instead of LARA's
   float scale;
   float* saved;                                           // forward intermediates (fwd writes, bwd reads), or null
+  const float* colbias;                                   // [BH, L] added to every row of the mixing logits ('-vmixed'), or null
+  float* d_colbias;                                       // backward: its gradient, or null
   long long* prof;                                        // dev builds (-DEA_PROFILE): phase time stamps
 };
 

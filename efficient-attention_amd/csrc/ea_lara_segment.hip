@@ -169,4 +169,76 @@ int lara_segment_dispatch(bool bwd, const SegP& p, int dtype, int D, hipStream_t
   return EA_E_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------
+// nn.AdaptiveAvgPool2d of one of q / k / v over the token grid when the grid does not divide evenly
+// (lara.py:43,48,145-151): bin o of an axis of n cells covers [floor(o n / side), ceil((o + 1) n / side)) --
+// neighbouring bins share a row / column.  (Evenly dividing grids take the chunk-mean kernels.)
+// ------------------------------------------------------------------------------------------
+struct PoolP {
+  const char* x;          // forward input [B,H,N,D] view (element type)
+  char* dx;               // backward: accumulated into
+  long sb, sh, sn;
+  float* mean;            // [B,H,side*side,D] fp32 (forward output / backward input)
+  int B, H, gh, gw, side, D;
+};
+EA_DEV int bin_lo(int o, int n, int side) { return (o * n) / side; }
+EA_DEV int bin_hi(int o, int n, int side) { return ((o + 1) * n + side - 1) / side; }
+
+template <typename E>
+__global__ __launch_bounds__(64) void pool2d_fwd_kernel(const PoolP p) {
+  const int L = p.side * p.side;
+  const int bin = blockIdx.x % L, bh = blockIdx.x / L, b = bh / p.H, h = bh - b * p.H;
+  const int oy = bin / p.side, ox = bin - oy * p.side;
+  const int y0 = bin_lo(oy, p.gh, p.side), y1 = bin_hi(oy, p.gh, p.side);
+  const int x0 = bin_lo(ox, p.gw, p.side), x1 = bin_hi(ox, p.gw, p.side);
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.x) + b * p.sb + h * p.sh;
+  const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+  for (int ch = threadIdx.x; ch < p.D; ch += 64) {
+    float a = 0.f;
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) a += E::to_f(src[(size_t)(y * p.gw + x) * p.sn + ch]);
+    p.mean[((size_t)bh * L + bin) * p.D + ch] = a * inv;
+  }
+}
+
+template <typename E>
+__global__ __launch_bounds__(64) void pool2d_bwd_kernel(const PoolP p) {
+  const int N = p.gh * p.gw, L = p.side * p.side;
+  const int n = blockIdx.x % N, bh = blockIdx.x / N, b = bh / p.H, h = bh - b * p.H;
+  const int y = n / p.gw, x = n - y * p.gw;
+  uint16_t* dst = reinterpret_cast<uint16_t*>(p.dx) + b * p.sb + h * p.sh + (size_t)n * p.sn;
+  for (int ch = threadIdx.x; ch < p.D; ch += 64) {
+    float a = 0.f;
+    for (int oy = 0; oy < p.side; ++oy) {
+      const int y0 = bin_lo(oy, p.gh, p.side), y1 = bin_hi(oy, p.gh, p.side);
+      if (y < y0 || y >= y1) continue;
+      for (int ox = 0; ox < p.side; ++ox) {
+        const int x0 = bin_lo(ox, p.gw, p.side), x1 = bin_hi(ox, p.gw, p.side);
+        if (x < x0 || x >= x1) continue;
+        a += p.mean[((size_t)bh * L + oy * p.side + ox) * p.D + ch] / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+    dst[ch] = E::from_f(E::to_f(dst[ch]) + a);
+  }
+}
+
+int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long sn, float* mean, int B, int H, int gh, int gw,
+                    int side, int D, hipStream_t st) {
+  if (B <= 0 || H <= 0 || gh <= 0 || gw <= 0 || side <= 0 || side > gh || side > gw || D <= 0) return EA_E_BADARG;
+  PoolP p;
+  p.x = (const char*)x; p.dx = (char*)const_cast<void*>(x); p.sb = sb; p.sh = sh; p.sn = sn; p.mean = mean;
+  p.B = B; p.H = H; p.gh = gh; p.gw = gw; p.side = side; p.D = D;
+  const unsigned grid = (unsigned)(B * H * (bwd ? gh * gw : side * side));
+  if (dtype == EA_BF16) {
+    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel<BF16>, dim3(grid), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(pool2d_fwd_kernel<BF16>, dim3(grid), dim3(64), 0, st, p);
+  } else if (dtype == EA_F16) {
+    if (bwd) hipLaunchKernelGGL(pool2d_bwd_kernel<F16>, dim3(grid), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(pool2d_fwd_kernel<F16>, dim3(grid), dim3(64), 0, st, p);
+  } else {
+    return EA_E_BADARG;
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace ea

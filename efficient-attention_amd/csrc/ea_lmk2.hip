@@ -207,11 +207,14 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       zero<4>(a);
       mm<H, 64, true, 64, false, 4>(a, T0, T0, KD, l);
       float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, den[4] = {0.f, 0.f, 0.f, 0.f};
+      float cb[4];                                     // '-vmixed': log(|v_bar_l'| + 1e-4) on column l' (lara.py:171-172)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) cb[ct] = (p.colbias && 16 * ct + l.li < L) ? p.colbias[(size_t)bh * L + 16 * ct + l.li] : 0.f;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a[ct][r] = (16 * ct + l.li < L) ? a[ct][r] * s : -INFINITY;
+          a[ct][r] = (16 * ct + l.li < L) ? a[ct][r] * s + cb[ct] : -INFINITY;
           mx[r] = fmaxf(mx[r], a[ct][r]);
         }
 #pragma unroll
@@ -522,12 +525,14 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dA[ct][r] = asm_[ct][r] * (dA[ct][r] - rs[r]);      // dG
+      if (p.d_colbias) colsum_part<4>(cpart, dA, L, l);  // d colbias = column sums of dG (cpart: free since the barrier at B3)
       {
         const float gm = strip_absmax<4>(dA, L, L, l);
         __syncthreads();                              // gmx readers (skb) are done
         if (lane == 0) gmx[l.w] = gm;
       }
       __syncthreads();
+      if (p.d_colbias && tid < L) p.d_colbias[(size_t)bh * L + tid] = cpart[tid] + cpart[64 + tid] + cpart[128 + tid] + cpart[192 + tid];
       const float sdg = pow2_scale(gmx);
       store_t<H, 4>(T1, dA, sdg, L, L, l);               // DGT [l'][l]  (OMT is dead)
       __syncthreads();

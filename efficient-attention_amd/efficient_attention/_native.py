@@ -81,6 +81,8 @@ SIGNATURES = {
     "ea_rows_mlp_bwd": [_I] * 4 + [_P] * 15,
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 17,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 21,
+    "ea_lara_landmarks_fwd_cb": [_MG] + [_P] * 18,
+    "ea_lara_landmarks_bwd_cb": [_MG] + [_P] * 23,
     "ea_lara_landmarks_saved_floats": [_MG],
     "ea_lara_merge_fwd": [_I] * 5 + [_P] * 8,
     "ea_lara_merge_bwd": [_I] * 5 + [_F] + [_P] * 16,
@@ -102,6 +104,8 @@ SIGNATURES = {
     "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
+    "ea_adaptive_pool2d_fwd": [_I, _I, _I, _I, _I, _I, _I, _T, _P, _P],
+    "ea_adaptive_pool2d_bwd": [_I, _I, _I, _I, _I, _I, _I, _P, _T, _P],
     "ea_linear_supported": [_I, _I],
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],

@@ -597,16 +597,43 @@ def pool2d_qkv(qkv5, H, W, side, slot=None, need_v=False):
             pv = x.mean(dim=(2, 4), dtype=torch.float32).reshape(B, side * side, h, d).permute(0, 2, 1, 3)
         return pq, pk, pv
 
-    def bins(n):
-        m = torch.zeros(side, n, device=qkv5.device, dtype=torch.float32)
-        for o in range(side):
-            s, e = (o * n) // side, -((-(o + 1) * n) // side)
-            m[o, s:e] = 1.0 / (e - s)
-        return m
-    x = qkv5.view(B, H, W, 3, h, d).float()
-    pooled = torch.einsum("iy,jx,byxthd->bijthd", bins(H), bins(W), x)
-    pooled = pooled.reshape(B, side * side, 3, h, d).permute(2, 0, 3, 1, 4)
-    return pooled[0], pooled[1], (pooled[2] if need_v else None)
+    # bins that overlap (the grid does not divide): adaptive-pool kernels, one launch per tensor
+    slot = slot if slot is not None else _GradSlot()
+    outs = AdaptivePoolFn.apply(qkv5, H, W, side, 3 if need_v else 2, slot)
+    return outs[0], outs[1], (outs[2] if need_v else None)
+
+
+class AdaptivePoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d of q, k (and v) over a token grid `side` does not divide (ea_adaptive_pool2d_fwd/bwd);
+    like PoolMeanFn its input gradient is added into the buffer the attention core publishes for qkv."""
+
+    @staticmethod
+    def forward(ctx, qkv5, H, W, side, n, slot):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        outs = []
+        for t in _qkv_views(qkv5)[:n]:
+            m = torch.empty((B, h, side * side, d), dtype=torch.float32, device=qkv5.device)
+            tt = nv.t4(t)
+            nv.call("ea_adaptive_pool2d_fwd", nv.io_dtype(qkv5), B, h, H, W, side, d, ctypes.byref(tt), nv.ptr(m), nv.stream())
+            outs.append(m)
+        ctx.cfg = (H, W, side, n, slot, qkv5.shape, qkv5.dtype)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dms):
+        H, W, side, n, slot, shape, dtype = ctx.cfg
+        B, N, _, h, d = shape
+        own = slot.buf is None
+        buf = torch.zeros(shape, dtype=dtype, device=dms[0].device) if own else slot.buf
+        for t, dm in zip(_qkv_views(buf)[:n], dms):
+            if dm is None:
+                continue
+            tt = nv.t4(t)
+            nv.call("ea_adaptive_pool2d_bwd", nv.io_dtype(buf), B, h, H, W, side, d, nv.ptr(dm.float().contiguous()),
+                    ctypes.byref(tt), nv.stream())
+        slot.buf = None
+        return (buf if own else None), None, None, None, None, None
 
 
 def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c):
@@ -885,10 +912,11 @@ def _lmk_saved(geom, device):
 class LaraLandmarkFn(torch.autograd.Function):
     """Fused landmark pipeline (ea_lara_landmarks_fwd/bwd): pooled q/k [B,h,L,d] (or ready q_bar/k_bar
     when has_mlp = mixed = 0) -> omega, qbar_rows [B,h,C,d], bhv, lp [B,h,C].  params = (Wq, bq,
-    gq, cq, Wk, bk, gk, ck) when has_mlp."""
+    gq, cq, Wk, bk, gk, ck) when has_mlp; colbias [B,h,L] (or None) is the '-vmixed' column bias of the
+    mixing logits."""
 
     @staticmethod
-    def forward(ctx, pq, pk, noise, cfg, *params):
+    def forward(ctx, pq, pk, noise, colbias, cfg, *params):
         has_mlp, mixed, mis, dup, scale = cfg
         nv.require_cuda(pq, "pooled q/k")
         B, h, L, d = pq.shape
@@ -897,6 +925,7 @@ class LaraLandmarkFn(torch.autograd.Function):
         pq = pq.float().contiguous()
         pk = pk.float().contiguous()
         noise_c = None if noise is None else noise.float().contiguous()
+        cb = None if colbias is None else colbias.float().contiguous()
         ps = [t.float().contiguous() for t in params]
         geom = nv.ea_lmk_geom(BH, L, C, d, int(has_mlp), int(mixed), mis, dup, float(scale), 0)
         global LAST_LMK_GEOM
@@ -907,9 +936,13 @@ class LaraLandmarkFn(torch.autograd.Function):
         lp = torch.empty((B, h, C), dtype=torch.float32, device=dev)
         pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
         saved = _lmk_saved(geom, dev) if any(ctx.needs_input_grad) else None
-        nv.call("ea_lara_landmarks_fwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
-        ctx.save_for_backward(pq, pk, noise_c, *ps)
+        if cb is None:
+            nv.call("ea_lara_landmarks_fwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                    nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
+        else:
+            nv.call("ea_lara_landmarks_fwd_cb", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c), nv.ptr(cb),
+                    nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
+        ctx.save_for_backward(pq, pk, noise_c, cb, *ps)
         ctx.lmk_saved = saved
         ctx.geom = geom
         ctx.pdtypes = [t.dtype for t in params]
@@ -917,7 +950,7 @@ class LaraLandmarkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_omega, d_qrows, d_bhv, d_lp):
-        pq, pk, noise_c, *ps = ctx.saved_tensors
+        pq, pk, noise_c, cb, *ps = ctx.saved_tensors
         geom = ctx.geom
         BH, L, C, d = geom.BH, geom.L, geom.C, geom.D
         dev = pq.device
@@ -931,27 +964,34 @@ class LaraLandmarkFn(torch.autograd.Function):
         d_bhv = None if d_bhv is None else d_bhv.float().contiguous()
         dpq = torch.empty_like(pq)
         dpk = torch.empty_like(pk)
-        dW = dvec = None
+        dW = dvec = d_cb = None
         if geom.has_mlp:
             dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
             dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
         pp = [nv.ptr(t) for t in ps] if geom.has_mlp else [None] * 8
-        nv.call("ea_lara_landmarks_bwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-                nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
-                nv.ptr(dW), nv.ptr(dvec), nv.ptr(ctx.lmk_saved), nv.stream())
+        if cb is None:
+            nv.call("ea_lara_landmarks_bwd", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                    nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+                    nv.ptr(dW), nv.ptr(dvec), nv.ptr(ctx.lmk_saved), nv.stream())
+        else:
+            d_cb = torch.empty_like(cb)
+            nv.call("ea_lara_landmarks_bwd_cb", ctypes.byref(geom), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c), nv.ptr(cb),
+                    nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+                    nv.ptr(dW), nv.ptr(dvec), nv.ptr(d_cb), nv.ptr(ctx.lmk_saved), nv.stream())
         pgrads = []
         if geom.has_mlp:
             dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
             raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
             pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
-        return (dpq, dpk, None, None) + tuple(pgrads)
+        return (dpq, dpk, None, d_cb, None) + tuple(pgrads)
 
 
-def lara_landmarks(pq, pk, noise, mis_type, mode, scale, params=None, mixed=False):
-    """-> omega, qbar_rows, bhv, lp through the fused HIP landmark kernels (L, C <= 64)."""
+def lara_landmarks(pq, pk, noise, mis_type, mode, scale, params=None, mixed=False, colbias=None):
+    """-> omega, qbar_rows, bhv, lp through the fused HIP landmark kernels (L, C <= 64).  mixed: the softmax mixing of
+    k_bar (lara.py:157-174) runs inside the kernel; colbias [B,h,L]: its '-vmixed' column bias."""
     has_mlp = params is not None
     cfg = (has_mlp, bool(mixed), MIS[mis_type], int(mode) if noise is not None else 0, float(scale))
-    return LaraLandmarkFn.apply(pq, pk, noise, cfg, *(params or ()))
+    return LaraLandmarkFn.apply(pq, pk, noise, colbias, cfg, *(params or ()))
 
 
 def _prm(data, proj, scale):

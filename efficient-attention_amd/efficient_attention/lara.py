@@ -52,9 +52,10 @@ class LinearRA(MultiheadAttention):
         self.apply(self._init_weights)
 
     # ---- landmark proposals (tiny [B,h,L,d] tensors; pooling reads q,k once) -------------
-    def _proposal_gen_2d(self, qkv5, H, W, slot=None):
+    def _proposal_gen_2d(self, qkv5, H, W, slot=None, mix=True):
         """Adaptive 2-D average pool of q,k -> [Linear+LN] -> optional softmax mixing of k_bar
-        (reference :129-175).  Returns q_bar, k_bar [B,h,L,d] fp32."""
+        (reference :129-175).  Returns q_bar, k_bar [B,h,L,d] fp32 and the '-vmixed' column bias of the
+        mixing logits (or None); with mix=False the mixing itself is left to the landmark kernel."""
         B, N, _, h, d = qkv5.shape
         side = int(math.sqrt(self.num_landmarks))
         gen = self.proposal_gen
@@ -72,12 +73,13 @@ class LinearRA(MultiheadAttention):
         else:
             q_bar, k_bar = pq, pk
         q_bar, k_bar = q_bar.float(), k_bar.float()
-        if gen.endswith('mixed'):
+        colbias = torch.log(pv.float().norm(dim=-1) + 1e-4) if gen.endswith('-vmixed') else None      # [B,h,L]
+        if gen.endswith('mixed') and mix:
             logits = self.scale * torch.einsum('bhpd,bhcd->bhpc', k_bar, k_bar)
-            if gen.endswith('-vmixed'):
-                logits = logits + torch.log(pv.norm(dim=-1) + 1e-4).unsqueeze(-2)
+            if colbias is not None:
+                logits = logits + colbias.unsqueeze(-2)
             k_bar = torch.einsum('bhpc,bhcd->bhpd', torch.softmax(logits, dim=-1), k_bar)
-        return q_bar, k_bar
+        return q_bar, k_bar, colbias
 
     def _proposal_gen_1d(self, qkv5, key_padding_mask):
         """Segment means of (optionally Linear+LN'd) q,k with the even / uneven split rule
@@ -202,8 +204,11 @@ class LinearRA(MultiheadAttention):
             out = _ops.LaraPooledFn.apply(qkv5, mask, noise, cfg, *params)
             return self.merge_and_project(out, B, seq_shape, C, x.dtype)
 
+        mixed_k = colbias = None
         if len(seq_shape) == 2:
-            pq, pk = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot)
+            # the softmax mixing of k_bar runs inside the landmark kernel whenever that kernel is used
+            pq, pk, colbias = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot, mix=not fused_b)
+            mixed_k = fused_b and gen.endswith('mixed')
         elif fold_1d:
             pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
         elif len(seq_shape) == 1:
@@ -212,7 +217,8 @@ class LinearRA(MultiheadAttention):
             raise ValueError("LinearRA expects x of rank 3 or 4")
         noise = draw_noise(pq.shape[-2])
         if fused_b:
-            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, self.mis_type, mode, self.scale, None, False)
+            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, self.mis_type, mode, self.scale, None,
+                                                        bool(mixed_k), colbias if mixed_k else None)
             out = _ops.LaraAttnFn.apply(qkv5, mask, omega, qrows, bhv, lp, _ops.MIS[self.mis_type],
                                         float(self.alpha_coeff), slot)
         else:

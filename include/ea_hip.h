@@ -318,6 +318,21 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
                           const float* noise, const float* d_omega, const float* d_qbar_rows,
                           const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
                           float* dW_part, float* dvec_part, const float* saved, void* stream);
+/* '-vmixed' proposals (lara.py:171-172): colbias [BH, L] = log(|v_bar_l'| + 1e-4) is added to column l' of the mixing
+ * logits s k0 k0^T before their softmax; the backward also returns d_colbias [BH, L] (column sums of the logit
+ * gradients).  g->mixed must be set and `saved` (the forward intermediates) is required in the backward; geometries
+ * outside the second-generation kernels (L, C <= 64, D in {32, 64}) return EA_E_UNSUPPORTED. */
+int ea_lara_landmarks_fwd_cb(const ea_lmk_geom* g, const float* pq, const float* pk,
+                             const float* Wq, const float* bq, const float* gq, const float* cq,
+                             const float* Wk, const float* bk, const float* gk, const float* ck,
+                             const float* noise, const float* colbias, float* omega, float* qbar_rows, float* bhv,
+                             float* lp, float* saved, void* stream);
+int ea_lara_landmarks_bwd_cb(const ea_lmk_geom* g, const float* pq, const float* pk,
+                             const float* Wq, const float* bq, const float* gq, const float* cq,
+                             const float* Wk, const float* bk, const float* gk, const float* ck,
+                             const float* noise, const float* colbias, const float* d_omega, const float* d_qbar_rows,
+                             const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                             float* dW_part, float* dvec_part, float* d_colbias, const float* saved, void* stream);
 
 /* ---- LARA: merging the sequence slices of the token-row passes (tiny, one workgroup per (b,h)) ----
  * merge_fwd: (p_ml, p_kv of ea_lara_stats_fwd over S slices, lp) -> kv_stats [BH,C,D], lse_k,
@@ -414,6 +429,14 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
              float* dw_part, float* db_part, int64_t part_ld, void* stream);
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream);
+
+/* nn.AdaptiveAvgPool2d of one of q / k / v over a gh x gw token grid that `side` does not divide (lara.py:43,48,145-151:
+ * bin o of an axis of n cells = [floor(o n / side), ceil((o + 1) n / side)), neighbouring bins overlap).  x: [B,H,N,D]
+ * view in the EA dtype; mean: fp32 [B,H,side*side,D].  The backward ACCUMULATES into dx (I/O dtype, fp32 math). */
+int ea_adaptive_pool2d_fwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int32_t gw, int32_t side, int32_t D,
+                           const ea_t4* x, float* mean, void* stream);
+int ea_adaptive_pool2d_bwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int32_t gw, int32_t side, int32_t D,
+                           const float* dmean, const ea_t4* dx, void* stream);
 
 /* The projections themselves as streaming kernels (ea_linear.hip): `qkv = self.qkv(x)`, `x = self.proj(x)`
  * (abstract_attention.py:72-78,86-87) and, with the transposed weight, their input gradients.

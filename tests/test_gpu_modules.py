@@ -16,3 +16,21 @@ def test_module_matches_reference(name, mode, dtype):
     import torch
     errs = check_module_case(name, mode, dtype=torch.bfloat16 if dtype == "bf16" else torch.float16)
     print(name, mode, dtype, {k: "%.2e/%.2e" % v for k, v in errs.items()})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", cases.MODES)
+@pytest.mark.parametrize("name", ["lara_2d_dense_antithetic", "lara_2d_vmixed_bh", "lara_2d_poolmixed_tiny",
+                                  "lara_2d_noparam_multisample"])
+def test_lara_landmark_algebra_stays_on_hip(name, mode, monkeypatch):
+    """The [L x L] / [C x L] landmark algebra of these variants (softmax mixing of k_bar, '-vmixed' column bias,
+    proposal densities) runs in the HIP landmark kernels: no torch einsum / softmax / logsumexp may be reached."""
+    import torch
+    import torch.nn.functional as F
+
+    def banned(*a, **k):
+        raise AssertionError("torch einsum/softmax/logsumexp reached in the LARA landmark path")
+    for mod, fn in ((torch, "einsum"), (torch, "softmax"), (torch, "logsumexp"), (F, "softmax"), (torch.Tensor, "softmax")):
+        monkeypatch.setattr(mod, fn, banned)
+    errs = check_module_case(name, mode)
+    print(name, mode, {k: "%.2e/%.2e" % v for k, v in errs.items()})
