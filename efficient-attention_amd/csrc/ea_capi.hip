@@ -863,6 +863,38 @@ int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out
 
 }  // extern "C"
 
+// ---- LARA sampling + proposal densities beyond the fused landmark kernels (ea_lara_segment.hip) ----
+extern "C" {
+
+int ea_lara_sample_fwd(int32_t BH, int32_t L, int32_t C, int32_t D, int32_t mis, int32_t mode, float scale,
+                       const float* qbar, const float* mu, const float* noise, float* omega, float* qbar_rows, float* bhv,
+                       float* lp, void* stream) {
+  if (!qbar || !mu || !omega || !lp || (mode != 0 && !noise) || mis < 0 || mis > 2) return EA_E_BADARG;
+  if (mis == EA_MIS_OPT && (!qbar_rows || !bhv)) return EA_E_BADARG;
+  if (mis == EA_MIS_BIASED && !qbar_rows) return EA_E_BADARG;
+  if ((mode == 0) != (C == L) || (mode != 0 && C != 2 * L)) return EA_E_BADARG;
+  ea::SampP p = {};
+  p.qbar = qbar; p.mu = mu; p.noise = noise; p.omega = omega; p.qrows = mis == EA_MIS_BH ? nullptr : qbar_rows;
+  p.bhv = mis == EA_MIS_OPT ? bhv : nullptr; p.lp = lp;
+  p.BH = BH; p.L = L; p.C = C; p.D = D; p.mis = mis; p.mode = mode; p.scale = scale;
+  return ea::lara_sample_dispatch(false, p, (hipStream_t)stream);
+}
+
+int ea_lara_sample_bwd(int32_t BH, int32_t L, int32_t C, int32_t D, int32_t mis, int32_t mode, float scale,
+                       const float* qbar, const float* mu, const float* noise, const float* d_omega, const float* d_qbar_rows,
+                       const float* d_bhv, const float* d_lp, float* d_qbar, float* d_mu, void* stream) {
+  if (!qbar || !mu || !d_omega || !d_qbar || !d_mu || (mode != 0 && !noise) || mis < 0 || mis > 2) return EA_E_BADARG;
+  if ((mode == 0) != (C == L) || (mode != 0 && C != 2 * L)) return EA_E_BADARG;
+  ea::SampP p = {};
+  p.qbar = qbar; p.mu = mu; p.noise = noise;
+  p.d_omega = d_omega; p.d_qrows = mis == EA_MIS_BH ? nullptr : d_qbar_rows; p.d_bhv = mis == EA_MIS_OPT ? d_bhv : nullptr;
+  p.d_lp = d_lp; p.d_qbar = d_qbar; p.d_mu = d_mu;
+  p.BH = BH; p.L = L; p.C = C; p.D = D; p.mis = mis; p.mode = mode; p.scale = scale;
+  return ea::lara_sample_dispatch(true, p, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
 // ---- adaptive 2-D pooling of a token grid that does not divide evenly (ea_lara_segment.hip) ----
 extern "C" {
 

@@ -21,4 +21,15 @@ struct SegP {
 
 int lara_segment_dispatch(bool bwd, const SegP& p, int dtype, int D, hipStream_t st);
 
+// sampling + proposal densities beyond the fused landmark kernels (lara_sample_kernel)
+struct SampP {
+  const float *qbar, *mu, *noise;                 // [BH,L,D], [BH,L,D], [BH,L or C,D] or null
+  float *omega, *qrows, *bhv, *lp;                // forward outputs ([BH,C,D] x2, [BH,C] x2; qrows / bhv may be null)
+  const float *d_omega, *d_qrows, *d_bhv, *d_lp;  // backward inputs (d_qrows / d_bhv may be null)
+  float *d_qbar, *d_mu;                           // backward outputs [BH,L,D]
+  int BH, L, C, D, mis, mode;
+  float scale;
+};
+int lara_sample_dispatch(bool bwd, const SampP& p, hipStream_t st);
+
 }  // namespace ea

@@ -241,4 +241,144 @@ int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long s
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Sampling + the [C x L] proposal-density algebra on the landmarks when the sample count exceeds what the fused
+// landmark kernels hold (C > 64: antithetic / multi-sample draws at L = 49; lara.py:187-238):
+//     omega_c = mu_{c mod L} +- noise,   prm[c][n] = s <omega_c, mu_n> - s |mu_n|^2 / 2     (n < L)
+//     mis-opt   : lp_c = prm[c][c mod L],  bhv_c = exp(lp_c - logsumexp_n prm[c][n]) / nrep,  qbar_rows = rep(q_bar)
+//     mis-biased: lp_c = logsumexp_n prm[c][n],                                               qbar_rows = rep(mu)
+//     mis-bh    : lp_c = logsumexp_n prm[c][n]
+// (the reference takes the log-sum-exp of mis-opt over the C replicated rows of mu: nrep copies of the same L values).
+// fp32 throughout, one workgroup per (b,h), mu / omega rows in LDS: tiny next to the estimator passes.
+// ------------------------------------------------------------------------------------------
+
+EA_DEV float samp_omega(const SampP& p, const float* mu_s, size_t bh, int c, int d) {
+  const int l = c % p.L;
+  float v = mu_s[l * (p.D + 1) + d];
+  if (p.noise) {
+    if (p.mode == 1) v += (c < p.L ? 1.f : -1.f) * p.noise[(bh * p.L + l) * p.D + d];
+    else v += p.noise[(bh * p.C + c) * p.D + d];
+  }
+  return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void lara_sample_kernel(const SampP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = p.L, C = p.C, D = p.D, LD = D + 1, nrep = C / L;
+  float* mu_s = reinterpret_cast<float*>(smem);          // [L][D+1]
+  float* om_s = mu_s + L * LD;                           // [C][D+1]
+  float* m2_s = om_s + C * LD;                           // [L]  s |mu_n|^2 / 2
+  float* pr_s = m2_s + ((L + 3) & ~3);                   // backward: [C][L+1] prm -> d prm
+  const size_t bh = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float s = p.scale;
+  for (int i = tid; i < L * D; i += 256) mu_s[(i / D) * LD + i % D] = p.mu[bh * L * D + i];
+  __syncthreads();
+  for (int i = tid; i < C * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    const float v = samp_omega(p, mu_s, bh, c, d);
+    om_s[c * LD + d] = v;
+    if (!BWD) {
+      p.omega[(bh * C + c) * D + d] = v;
+      if (p.qrows) p.qrows[(bh * C + c) * D + d] = p.mis == EA_MIS_OPT ? p.qbar[(bh * L + c % L) * D + d] : mu_s[(c % L) * LD + d];
+    }
+  }
+  for (int n = tid; n < L; n += 256) {
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) a += mu_s[n * LD + d] * mu_s[n * LD + d];
+    m2_s[n] = 0.5f * s * a;
+  }
+  __syncthreads();
+  // one thread per sample row c: prm[c][:], its log-sum-exp, the diagonal entry
+  float lse = 0.f, diag = 0.f;
+  const int c = tid;
+  if (c < C) {
+    float mx = -INFINITY, den = 0.f;
+    for (int n = 0; n < L; ++n) {
+      float a = 0.f;
+      for (int d = 0; d < D; ++d) a += om_s[c * LD + d] * mu_s[n * LD + d];
+      a = s * a - m2_s[n];
+      if (BWD) pr_s[c * (L + 1) + n] = a;
+      if (n == c % L) diag = a;
+      const float m = fmaxf(mx, a);
+      den = den * __expf(mx - m) + __expf(a - m);
+      mx = m;
+    }
+    lse = mx + __logf(den);
+    if (!BWD) {
+      if (p.mis == EA_MIS_OPT) {
+        p.lp[bh * C + c] = diag;
+        if (p.bhv) p.bhv[bh * C + c] = __expf(diag - lse) / (float)nrep;
+      } else {
+        p.lp[bh * C + c] = lse;
+      }
+    }
+  }
+  if (!BWD) return;
+  // d prm[c][n] in place
+  if (c < C) {
+    const float dlp = p.d_lp ? p.d_lp[bh * C + c] : 0.f;
+    float dl = 0.f, dd = 0.f;                              // coefficient of P[c][:] and of the diagonal entry
+    if (p.mis == EA_MIS_OPT) {
+      const float gb = p.d_bhv ? p.d_bhv[bh * C + c] * __expf(diag - lse) / (float)nrep : 0.f;
+      dd = dlp + gb; dl = -gb;
+    } else {
+      dl = dlp;
+    }
+    for (int n = 0; n < L; ++n) {
+      const float pcn = __expf(pr_s[c * (L + 1) + n] - lse);
+      pr_s[c * (L + 1) + n] = dl * pcn + (n == c % L ? dd : 0.f);
+    }
+  }
+  __syncthreads();
+  // one thread per (n, d): d mu_n[d] = s sum_c dprm[c][n] (omega_c - mu_n)[d] + sum over the replicas c = n + k L of
+  // d omega_c[d] (= s sum_n' dprm[c][n'] mu_n'[d] + incoming d_omega) [+ d_qrows of mis-biased]; d q_bar from d_qrows
+  for (int i = tid; i < L * D; i += 256) {
+    const int n = i / D, d = i - n * D;
+    float a = 0.f;
+    for (int cc = 0; cc < C; ++cc) a += pr_s[cc * (L + 1) + n] * (om_s[cc * LD + d] - mu_s[n * LD + d]);
+    a *= s;
+    float dq = 0.f;
+    for (int k = 0; k < nrep; ++k) {
+      const int cc = n + k * L;
+      float t = 0.f;
+      for (int n2 = 0; n2 < L; ++n2) t += pr_s[cc * (L + 1) + n2] * mu_s[n2 * LD + d];
+      a += s * t + p.d_omega[(bh * C + cc) * D + d];
+      if (p.d_qrows) {
+        const float g = p.d_qrows[(bh * C + cc) * D + d];
+        if (p.mis == EA_MIS_OPT) dq += g; else a += g;
+      }
+    }
+    p.d_mu[bh * L * D + i] = a;
+    p.d_qbar[bh * L * D + i] = dq;
+  }
+}
+
+size_t lara_sample_lds(int L, int C, int D, bool bwd) {
+  return ((size_t)(L + C) * (D + 1) + ((L + 3) & ~3) + (bwd ? (size_t)C * (L + 1) : 0)) * 4;
+}
+
+int lara_sample_dispatch(bool bwd, const SampP& p, hipStream_t st) {
+  if (p.BH <= 0 || p.L <= 0 || p.C <= 0 || p.C > 256 || p.C % p.L || p.D <= 0) return EA_E_UNSUPPORTED;
+  const size_t lds = lara_sample_lds(p.L, p.C, p.D, bwd);
+  if (lds > 150 * 1024) return EA_E_UNSUPPORTED;
+  if (bwd) {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lara_sample_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(lara_sample_kernel<true>, dim3((unsigned)p.BH), dim3(256), lds, st, p);
+  } else {
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lara_sample_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(lara_sample_kernel<false>, dim3((unsigned)p.BH), dim3(256), lds, st, p);
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace ea

@@ -104,6 +104,8 @@ SIGNATURES = {
     "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
+    "ea_lara_sample_fwd": [_I, _I, _I, _I, _I, _I, _F] + [_P] * 8,
+    "ea_lara_sample_bwd": [_I, _I, _I, _I, _I, _I, _F] + [_P] * 10,
     "ea_adaptive_pool2d_fwd": [_I, _I, _I, _I, _I, _I, _I, _T, _P, _P],
     "ea_adaptive_pool2d_bwd": [_I, _I, _I, _I, _I, _I, _I, _P, _T, _P],
     "ea_linear_supported": [_I, _I],

@@ -999,13 +999,60 @@ def _prm(data, proj, scale):
     return scale * torch.einsum("bhcd,bhnd->bhcn", proj, data) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)
 
 
+class LaraSampleFn(torch.autograd.Function):
+    """omega, qbar_rows, bhv, lp from q_bar, mu = q_bar + k_bar and the noise draw (ea_lara_sample_fwd/bwd): the sampling and
+    the [C x L] proposal-density algebra for sample counts the fused landmark kernels do not hold (C > 64)."""
+
+    @staticmethod
+    def forward(ctx, q_bar, mu, noise, mis, mode, scale):
+        nv.require_cuda(mu, "landmarks")
+        B, h, L, d = mu.shape
+        mode = int(mode) if noise is not None else 0
+        C = L * (2 if mode else 1)
+        dev = mu.device
+        q_bar, mu = q_bar.float().contiguous(), mu.float().contiguous()
+        noise_c = None if noise is None else noise.float().contiguous()
+        omega = torch.empty((B, h, C, d), dtype=torch.float32, device=dev)
+        qrows = torch.empty_like(omega) if mis != 2 else None
+        bhv = torch.empty((B, h, C), dtype=torch.float32, device=dev) if mis == 0 else None
+        lp = torch.empty((B, h, C), dtype=torch.float32, device=dev)
+        nv.call("ea_lara_sample_fwd", B * h, L, C, d, mis, mode, float(scale), nv.ptr(q_bar), nv.ptr(mu), nv.ptr(noise_c),
+                nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.stream())
+        ctx.save_for_backward(q_bar, mu, noise_c)
+        ctx.cfg = (mis, mode, float(scale), C)
+        return omega, qrows, bhv, lp
+
+    @staticmethod
+    def backward(ctx, d_omega, d_qrows, d_bhv, d_lp):
+        q_bar, mu, noise_c = ctx.saved_tensors
+        mis, mode, scale, C = ctx.cfg
+        B, h, L, d = mu.shape
+
+        def f(t):
+            return None if t is None else t.float().contiguous()
+        d_omega = torch.zeros((B, h, C, d), dtype=torch.float32, device=mu.device) if d_omega is None else f(d_omega)
+        d_qbar, d_mu = torch.empty_like(q_bar), torch.empty_like(mu)
+        nv.call("ea_lara_sample_bwd", B * h, L, C, d, mis, mode, scale, nv.ptr(q_bar), nv.ptr(mu), nv.ptr(noise_c),
+                nv.ptr(d_omega), nv.ptr(f(d_qrows)), nv.ptr(f(d_bhv)), nv.ptr(f(d_lp)), nv.ptr(d_qbar), nv.ptr(d_mu), nv.stream())
+        return d_qbar, d_mu, None, None, None, None
+
+
+def _sample_fits(L, C, d):
+    """LDS budget of ea_lara_sample_bwd (lara_sample_lds, ea_lara_segment.hip)."""
+    return C <= 256 and ((L + C) * (d + 1) + ((L + 3) & ~3) + C * (L + 1)) * 4 <= 150 * 1024
+
+
 def lara_attention(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scale, slot=None):
-    """Sampling + the [C x L] proposal-density algebra on the landmarks (tiny torch ops with
-    autograd, lara.py:187-238), then the HIP estimator.  mode: 0 single, 1 antithetic,
-    2 multi-sample noise."""
+    """Sampling + the [C x L] proposal-density algebra on the landmarks (lara.py:187-238), then the HIP estimator.
+    mode: 0 single, 1 antithetic, 2 multi-sample noise.  The algebra is ea_lara_sample_* (fp32 HIP); landmark sets too
+    large for its LDS image fall back to tiny torch ops with autograd."""
     mis = MIS[mis_type]
     q_bar, mu = q_bar.float(), mu.float()
     dup = noise is not None and mode in (1, 2)
+    L, d = mu.shape[-2], mu.shape[-1]
+    if mu.is_cuda and _sample_fits(L, L * (2 if dup else 1), d):
+        omega, qbar_rows, bhv, lp = LaraSampleFn.apply(q_bar, mu, noise, mis, mode, float(scale))
+        return LaraAttnFn.apply(qkv5, mask_u8, omega, qbar_rows, bhv, lp, mis, float(alpha_coeff), slot)
     if noise is None:
         omega = mu
     elif mode == 2:

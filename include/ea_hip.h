@@ -430,6 +430,21 @@ int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_featu
              float* dw_part, float* db_part, int64_t part_ld, void* stream);
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream);
 
+/* LARA sampling + proposal densities for sample counts beyond the fused landmark kernels (C > 64: antithetic /
+ * multi-sample draws at 49 landmarks; lara.py:187-238).  qbar, mu = q_bar + k_bar: fp32 [BH,L,D]; noise: [BH,L,D] (mode 1,
+ * antithetic: omega = [mu + eps; mu - eps]) or [BH,C,D] (mode 2, multi-sample: omega = [mu; mu] + eps), NULL for mode 0
+ * (C = L).  With prm[c][n] = s <omega_c, mu_n> - s |mu_n|^2 / 2 over the L landmarks:
+ *   EA_MIS_OPT   : lp_c = prm[c][c mod L], bhv_c = exp(lp_c - logsumexp_n prm[c][n]) L / C, qbar_rows = q_bar repeated;
+ *   EA_MIS_BIASED: lp_c = logsumexp_n prm[c][n], qbar_rows = mu repeated;      EA_MIS_BH: lp_c likewise, no qbar_rows.
+ * The backward takes the gradients of omega / qbar_rows / bhv / lp (NULL = zero, d_omega required) and returns d_qbar and
+ * d_mu [BH,L,D].  fp32, one workgroup per (b,h); EA_E_UNSUPPORTED when the rows do not fit 150 KB of LDS. */
+int ea_lara_sample_fwd(int32_t BH, int32_t L, int32_t C, int32_t D, int32_t mis, int32_t mode, float scale,
+                       const float* qbar, const float* mu, const float* noise, float* omega, float* qbar_rows, float* bhv,
+                       float* lp, void* stream);
+int ea_lara_sample_bwd(int32_t BH, int32_t L, int32_t C, int32_t D, int32_t mis, int32_t mode, float scale,
+                       const float* qbar, const float* mu, const float* noise, const float* d_omega, const float* d_qbar_rows,
+                       const float* d_bhv, const float* d_lp, float* d_qbar, float* d_mu, void* stream);
+
 /* nn.AdaptiveAvgPool2d of one of q / k / v over a gh x gw token grid that `side` does not divide (lara.py:43,48,145-151:
  * bin o of an axis of n cells = [floor(o n / side), ceil((o + 1) n / side)), neighbouring bins overlap).  x: [B,H,N,D]
  * view in the EA dtype; mean: fp32 [B,H,side*side,D].  The backward ACCUMULATES into dx (I/O dtype, fp32 math). */

@@ -205,3 +205,58 @@ def test_linear_unsupported_geometry_falls_to_library():
         y = _ops.linear(x, lin)
     y.float().sum().backward()
     assert x.grad is not None and lin.weight.grad is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mis_type", ["mis-opt", "mis-biased", "mis-bh"])
+@pytest.mark.parametrize("mode,L,d", [(1, 49, 64), (2, 49, 64), (0, 100, 64), (1, 16, 32), (2, 64, 128)])
+def test_lara_sample_matches_torch(mode, L, d, mis_type):
+    """ea_lara_sample_fwd/bwd (sampling + [C x L] proposal densities for C > 64) against the same algebra written with
+    torch ops in fp64, values and gradients."""
+    import torch
+    from efficient_attention import _ops
+    g = torch.Generator(device="cuda").manual_seed(17 * L + d + mode)
+    B, h = 2, 3
+    C = L * (2 if mode else 1)
+    q_bar = torch.randn(B, h, L, d, device="cuda", generator=g).requires_grad_(True)
+    mu = (torch.randn(B, h, L, d, device="cuda", generator=g) * 0.7).requires_grad_(True)
+    noise = None if mode == 0 else torch.randn(B, h, L if mode == 1 else C, d, device="cuda", generator=g)
+    scale = d ** -0.5
+    mis = _ops.MIS[mis_type]
+    assert _ops._sample_fits(L, C, d)
+    outs = _ops.LaraSampleFn.apply(q_bar, mu, noise, mis, mode, scale)
+    gs = [torch.randn(o.shape, device="cuda", generator=g) if o is not None else None for o in outs]
+    loss = sum((o * w).sum() for o, w in zip(outs, gs) if o is not None)
+    dq, dm = torch.autograd.grad(loss, [q_bar, mu], allow_unused=True)
+
+    q64, m64 = q_bar.detach().double().requires_grad_(True), mu.detach().double().requires_grad_(True)
+    n64 = None if noise is None else noise.double()
+    if mode == 0:
+        om = m64
+    elif mode == 2:
+        om = m64.repeat(1, 1, 2, 1) + n64
+    else:
+        om = torch.cat([m64 + n64, m64 - n64], dim=-2)
+    rep = (lambda t: t.repeat(1, 1, 2, 1)) if mode else (lambda t: t)
+
+    def prm(data, proj):
+        return scale * torch.einsum("bhcd,bhnd->bhcn", proj, data) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)
+    qr = bh = None
+    if mis == 0:
+        lpmu = prm(rep(m64), om)
+        lp = torch.diagonal(lpmu, dim1=-1, dim2=-2)
+        bh = torch.exp(lp - torch.logsumexp(lpmu, dim=-1))
+        qr = rep(q64)
+    else:
+        lp = torch.logsumexp(prm(m64, om), dim=-1)
+        qr = rep(m64) if mis == 1 else None
+    refs = (om, qr, bh, lp)
+    for o, r in zip(outs, refs):
+        assert (o is None) == (r is None)
+        if o is not None:
+            assert torch.allclose(o.double(), r, rtol=2e-4, atol=2e-5), float((o.double() - r).abs().max())
+    loss64 = sum((r * w.double()).sum() for r, w in zip(refs, gs) if r is not None)
+    rq, rm = torch.autograd.grad(loss64, [q64, m64], allow_unused=True)
+    rq = torch.zeros_like(q64) if rq is None else rq
+    assert torch.allclose(dm.double(), rm, rtol=1e-3, atol=1e-3 * float(rm.abs().max())), float((dm.double() - rm).abs().max())
+    assert torch.allclose(dq.double(), rq, rtol=1e-3, atol=1e-4 + 1e-3 * float(rq.abs().max()))
