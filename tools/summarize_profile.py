@@ -15,7 +15,9 @@ KERNEL_TO_ENTRY = [
     ("lara_fq_kernel<", "ea_lara_bwd_q_fused"), ("lara_fk_kernel<", "ea_lara_bwd_k_fused"),
     ("lara_fin_kernel<", "ea_lara_bwd_finish"),
     ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
-    ("wgrad_kernel<", "ea_wgrad"),
+    ("wgrad_kernel<", "ea_wgrad"), ("part_sum_kernel", "ea_part_sum"),
+    ("lin_kernel<ea::BF16, 6, 2, true", "ea_linear (fp32 in)"), ("lin_kernel<", "ea_linear"),
+    ("lara_sample_kernel<", "ea_lara_sample"), ("pool2d_", "ea_adaptive_pool2d"),
     ("sb_fwd_kernel<", "ea_scatter_fwd"), ("sb_bwd_kernel<ea::BF16, false>", "ea_scatter_bwd_window"),
     ("sb_bwd_kernel<ea::BF16, true>", "ea_scatter_bwd_global"),
     ("lara_y_kernel<ea::BF16, 64, 3>", "ea_scatter_kmax / ea_performer_kmax"),
