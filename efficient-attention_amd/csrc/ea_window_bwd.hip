@@ -146,30 +146,34 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     constexpr int NB = 2;
     struct KVb { u32x4 kr[NB], vr[NB]; int rowv[NB]; float mulv[NB], addv[NB]; };
     struct Qb { u32x4 qr[NB], dr[NB], orr[NB]; float lsv[NB], dls[NB]; int rowv[NB]; QLim lim[NB]; };
+    // Every load of a batch is issued unconditionally from a clamped address and zeroed by a select afterwards: a
+    // predicated load is an exec-mask branch of its own and the loads behind it wait for it (round 1's lesson)
     auto issueKV = [&](KVb& x, int base) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        x.kr[i] = x.vr[i] = u32x4{0u, 0u, 0u, 0u};
-        x.rowv[i] = -1; x.mulv[i] = 0.f; x.addv[i] = -INFINITY;
-        if (idx < t.rowsLocal * CPR) {
-          const int row = idx / CPR, c = idx - row * CPR;
-          const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
-          const int slot = row - wi * rowsPerWin;
-          const int win = it * t.wpi + wi;
-          x.rowv[i] = row;
-          if (win < t.nwin && slot < t.Wk) {
-            int oy, ox;
-            win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
-            const int tok = slot_token(p.G, kd[slot], oy, ox);
-            x.addv[i] = MASK_FILL * LOG2E;
-            if (tok >= 0) {
-              x.kr[i] = ldg16(kb + (tok * ksn + c * 8) * 2);
-              x.vr[i] = ldg16(vb + (tok * vsn + c * 8) * 2);
-              if (!(mrow && mrow[tok])) { x.mulv[i] = 1.f; x.addv[i] = 0.f; }
-            }
-          }
-        }
+        const bool in = idx < t.rowsLocal * CPR;
+        const int idc = in ? idx : 0;
+        const int row = idc / CPR, c = idc - row * CPR;
+        const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+        const int slot = row - wi * rowsPerWin;
+        const int win = it * t.wpi + wi;
+        const bool live = in && win < t.nwin && slot < t.Wk;
+        int oy, ox;
+        win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
+        const int tok = slot_token(p.G, kd[slot], oy, ox);
+        const bool has = live && tok >= 0;
+        const int tc = has ? tok : 0;
+        const u32x4 kr = ldg16(kb + (tc * ksn + c * 8) * 2);
+        const u32x4 vr = ldg16(vb + (tc * vsn + c * 8) * 2);
+        bool keep = has;
+        if (mrow) keep = keep && !mrow[tc];
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        x.kr[i] = has ? kr : z;
+        x.vr[i] = has ? vr : z;
+        x.rowv[i] = in ? row : -1;
+        x.mulv[i] = keep ? 1.f : 0.f;
+        x.addv[i] = keep ? 0.f : (live ? MASK_FILL * LOG2E : -INFINITY);
       }
     };
     auto commitKV = [&](const KVb& x, int base) {
@@ -187,31 +191,33 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        x.qr[i] = x.dr[i] = x.orr[i] = u32x4{0u, 0u, 0u, 0u};
-        x.rowv[i] = -1; x.lsv[i] = INFINITY; x.dls[i] = 0.f;
-        if (idx < rowsQ * CPR) {
-          const int row = idx / CPR, c = idx - row * CPR;
-          const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
-          const int slot = row - wi * (nQTe * 16);
-          const int win = it * t.wpi + wi;
-          int tok = -1;
-          if (win < t.nwin && slot < t.Wq) {
-            int oy, ox;
-            win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
-            tok = slot_token(p.G, qd[slot], oy, ox);
-          }
-          x.rowv[i] = row;
-          if (CA && c == 0) x.lim[i] = query_limits(p.causal, t.qoff + slot, tok, p.e, p.chunk, mrow);
-          if (tok >= 0) {
-            x.qr[i] = ldg16(qb + (tok * qsn + c * 8) * 2);
-            x.dr[i] = ldg16(dob + (tok * dosn + c * 8) * 2);
-            x.orr[i] = ldg16(ob + (tok * osn + c * 8) * 2);
-            if (c == 0) {
-              x.lsv[i] = lse_g[tok] * LOG2E;
-              if (p.dlse) x.dls[i] = p.dlse[(size_t)bh * p.G.N + tok];
-            }
-          }
-        }
+        const bool in = idx < rowsQ * CPR;
+        const int idc = in ? idx : 0;
+        const int row = idc / CPR, c = idc - row * CPR;
+        const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
+        const int slot = row - wi * (nQTe * 16);
+        const int win = it * t.wpi + wi;
+        const bool live = in && win < t.nwin && slot < t.Wq;
+        int oy, ox;
+        win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
+        const int tokr = slot_token(p.G, qd[slot], oy, ox);
+        const int tok = live ? tokr : -1;
+        const bool has = tok >= 0;
+        const int tc = has ? tok : 0;
+        x.rowv[i] = in ? row : -1;
+        if (CA && c == 0) x.lim[i] = query_limits(p.causal, t.qoff + slot, tok, p.e, p.chunk, mrow);
+        const u32x4 qr = ldg16(qb + (tc * qsn + c * 8) * 2);
+        const u32x4 dr = ldg16(dob + (tc * dosn + c * 8) * 2);
+        const u32x4 orr = ldg16(ob + (tc * osn + c * 8) * 2);
+        const float ls = lse_g[tc];
+        float dl = 0.f;
+        if (p.dlse) dl = p.dlse[(size_t)bh * p.G.N + tc];
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        x.qr[i] = has ? qr : z;
+        x.dr[i] = has ? dr : z;
+        x.orr[i] = has ? orr : z;
+        x.lsv[i] = has ? ls * LOG2E : INFINITY;
+        x.dls[i] = has ? dl : 0.f;
       }
     };
     auto commitQ = [&](const Qb& x, int base) {
