@@ -95,11 +95,13 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
           qtok0 = slot_token(p.G, qd[qslot], oy, ox);
         }
       }
+      // unconditional loads from a clamped address, zeroed by a select (a predicated load is an exec-mask branch of its
+      // own and the loads behind it wait for it)
+      const int qtc = qtok0 >= 0 ? qtok0 : 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        u32x4 w4 = {0u, 0u, 0u, 0u};
-        if (qtok0 >= 0) w4 = ldg16(qb + (qtok0 * p.q.sn + (g * KS + ks) * 8) * 2);
-        qf[ks] = as_x8<E>(w4);
+        const u32x4 w4 = ldg16(qb + (qtc * p.q.sn + (g * KS + ks) * 8) * 2);
+        qf[ks] = as_x8<E>(qtok0 >= 0 ? w4 : u32x4{0u, 0u, 0u, 0u});
       }
     }
     // ---- gather the local K/V rows of this iteration's windows (batched loads) ----
@@ -110,26 +112,28 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        kr[i] = vr[i] = u32x4{0u, 0u, 0u, 0u};
-        rowv[i] = -1; mulv[i] = 0.f; addv[i] = -INFINITY;      // slot does not exist
-        if (idx < t.rowsLocal * CPR) {
-          const int row = idx / CPR, c = idx - row * CPR;
-          const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
-          const int slot = row - wi * rowsPerWin;
-          const int win = it * t.wpi + wi;
-          rowv[i] = row;
-          if (win < t.nwin && slot < t.Wk) {
-            int oy, ox;
-            win_origin(p.G, win, p.w, oy, ox);
-            const int tok = slot_token(p.G, kd[slot], oy, ox);
-            addv[i] = MASK_FILL * LOG2E;                         // outside / padded: zero k,v, -5e4
-            if (tok >= 0) {
-              kr[i] = ldg16(kb + (tok * p.k.sn + c * 8) * 2);
-              vr[i] = ldg16(vb + (tok * p.v.sn + c * 8) * 2);
-              if (!(mrow && mrow[tok])) { mulv[i] = 1.f; addv[i] = 0.f; }
-            }
-          }
-        }
+        const bool in = idx < t.rowsLocal * CPR;
+        const int idc = in ? idx : 0;
+        const int row = idc / CPR, c = idc - row * CPR;
+        const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+        const int slot = row - wi * rowsPerWin;
+        const int win = it * t.wpi + wi;
+        const bool live = in && win < t.nwin && slot < t.Wk;    // otherwise the slot does not exist
+        int oy, ox;
+        win_origin(p.G, min(win, t.nwin - 1), p.w, oy, ox);
+        const int tok = slot_token(p.G, kd[slot], oy, ox);
+        const bool has = live && tok >= 0;                       // outside / padded: zero k,v, -5e4
+        const int tc = has ? tok : 0;
+        const u32x4 k4 = ldg16(kb + (tc * p.k.sn + c * 8) * 2);
+        const u32x4 v4 = ldg16(vb + (tc * p.v.sn + c * 8) * 2);
+        bool keep = has;
+        if (mrow) keep = keep && !mrow[tc];
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        kr[i] = has ? k4 : z;
+        vr[i] = has ? v4 : z;
+        rowv[i] = in ? row : -1;
+        mulv[i] = keep ? 1.f : 0.f;
+        addv[i] = keep ? 0.f : (live ? MASK_FILL * LOG2E : -INFINITY);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
