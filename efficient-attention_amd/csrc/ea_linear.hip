@@ -32,7 +32,8 @@ struct LinP {
 };
 
 template <typename E, int KT, int RT, bool AF32, int NPR, bool YF32>
-__global__ __launch_bounds__(256, 2) void lin_kernel(const LinP p) {
+__global__ __launch_bounds__((NPR > 8 ? 512 : 256), (NPR > 8 ? 1 : 2)) void lin_kernel(const LinP p) {
+  constexpr int NT = NPR > 8 ? 512 : 256, NW = NT / 64;   // more than 256 weight rows: one 8-wave workgroup per CU
   constexpr int K = KT * 32, ROWB = K * 2, CPR = K / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(const LinP p) {
   const int part = j % p.nsplit, wg = (j / p.nsplit) * 8 + xcd;      // workgroup `wg` of column part `part`
   constexpr int nop = NPR * 32;                                      // this part's output columns
   const int n0 = part * nop;
-  const int nwaves = p.wg_per_part * 4, wid = wg * 4 + wave;
+  const int nwaves = p.wg_per_part * NW, wid = wg * NW + wave;
   const int nsteps = (p.rows + 16 * RT - 1) / (16 * RT);
   const bool cast_out = AF32 && p.a_cast != nullptr && part == 0;
   // chunk swizzle of weight row r (bit 2 of r is not used: the two tiles of a pair, rows r and r + 4, share it).
@@ -69,16 +70,16 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(const LinP p) {
     // weight part -> LDS, eight 16-B loads per thread in flight at a time (a load-store loop would pay one L2 round
     // trip per iteration)
     float* sb = reinterpret_cast<float*>(smem + nop * ROWB);         // this part's bias, rounded to the element type
-    for (int i = tid; i < nop; i += 256) sb[i] = p.bias ? E::to_f(E::from_f(p.bias[n0 + i])) : 0.f;
+    for (int i = tid; i < nop; i += NT) sb[i] = p.bias ? E::to_f(E::from_f(p.bias[n0 + i])) : 0.f;
     const int total = nop * CPR;
     const char* wsrc = p.w + (size_t)n0 * K * 2;
-    for (int base = 0; base < total; base += 8 * 256) {
+    for (int base = 0; base < total; base += 8 * NT) {
       u32x4 wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = ldg16(wsrc + (size_t)min(base + u * 256 + tid, total - 1) * 16);
+      for (int u = 0; u < 8; ++u) wv[u] = ldg16(wsrc + (size_t)min(base + u * NT + tid, total - 1) * 16);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * 256 + tid;
+        const int idx = base + u * NT + tid;
         const int row = idx / CPR, c = idx - row * CPR;
         if (idx < total) sts16(smem + row * ROWB + ((c ^ wswz(row)) << 4), wv[u]);
       }
@@ -168,7 +169,13 @@ static int lin_cus() {
   return n;
 }
 
-constexpr int LIN_LDS_MAX = 72 * 1024;        // weight rows of a part; its bias (<= 1.5 KB) rides on top
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+// weight rows of a part (its bias, <= 1.5 KB, rides on top): two workgroups per CU / one 8-wave workgroup
+constexpr int LIN_LDS_MAX = 72 * 1024, LIN_LDS_MAX1 = 112 * 1024;
 
 template <typename E, int KT, int RT, bool AF32, int NPR, bool YF32>
 static int launch_lin1(const LinP& p, hipStream_t st) {
@@ -176,22 +183,22 @@ static int launch_lin1(const LinP& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<E, KT, RT, AF32, NPR, YF32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LIN_LDS_MAX + 2048);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (NPR > 8 ? LIN_LDS_MAX1 : LIN_LDS_MAX) + 2048);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const dim3 grid((unsigned)(p.wg_per_part * p.nsplit)), block(256);
+  const dim3 grid((unsigned)(p.wg_per_part * p.nsplit)), block(NPR > 8 ? 512 : 256);
   hipLaunchKernelGGL((lin_kernel<E, KT, RT, AF32, NPR, YF32>), grid, block, lds, st, p);
   return (int)hipGetLastError();
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return s ? atoi(s) : dflt;
-}
 
-// column parts: the fewest with 64 / 128 / 192 / 256 weight rows each that fit the LDS budget
+// column parts: the fewest with 64 / 128 / 192 / 256 weight rows each that fit the LDS budget of two workgroups per CU;
+// 576 columns of 192 channels (the qkv projection of a 192-wide model) go as two parts of 288 on one 8-wave workgroup
+// per CU instead: the activations pass the load pipes twice, not three times
 static int lin_nsplit(int K, int NO) {
+  static const int wide = env_int("EA_LIN_WIDE", 1);
+  if (wide && NO == 576 && K == 192) return 2;
   for (int ns = 1; ns <= 4; ++ns) {
     if (NO % ns) continue;
     const int nop = NO / ns;
@@ -217,6 +224,9 @@ static int lin_by_n(const LinP& p, hipStream_t st) {
     case 128: return launch_lin<E, KT, RT, AF32, 4>(p, st);
     case 192: return launch_lin<E, KT, RT, AF32, 6>(p, st);
     case 256: return launch_lin<E, KT, RT, AF32, 8>(p, st);
+    case 288:
+      if constexpr (KT == 6) return launch_lin<E, KT, RT, AF32, 9>(p, st);
+      return EA_E_UNSUPPORTED;
     default: return EA_E_UNSUPPORTED;
   }
 }
@@ -242,11 +252,13 @@ int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const fl
   p.rows = rows; p.NO = NO; p.y_f32 = y_f32; p.lda = lda; p.ldy = ldy;
   p.nsplit = lin_nsplit(K, NO);
   // two resident workgroups per CU in total, a multiple of 8 per part (one XCD each), no more than there are tiles
-  static const int per_cu = env_int("EA_LIN_PER_CU", 2);
+  static const int per_cu_env = env_int("EA_LIN_PER_CU", 0);
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (NO / p.nsplit > 256 ? 1 : 2);
   const int rt = K <= 192 ? 2 : 1;
   const int nsteps = (rows + 16 * rt - 1) / (16 * rt);
   int wgp = per_cu * lin_cus() / p.nsplit / 8 * 8;
-  const int need = ((nsteps + 3) / 4 + 7) / 8 * 8;
+  const int nw = NO / p.nsplit > 256 ? 8 : 4;
+  const int need = ((nsteps + nw - 1) / nw + 7) / 8 * 8;
   if (wgp > need) wgp = need;
   if (wgp < 8) wgp = 8;
   p.wg_per_part = wgp;
