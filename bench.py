@@ -479,6 +479,8 @@ def main():
             else:
                 units = _ops.KERNEL_ALGO_UNITS.get(name, 0)      # [B,H,N,D] tensors read+written per launch
                 algo_bytes = units * B * H * N * d * 2
+                if name in _ops.LABEL_ALGO_BYTES:                # projection kernels: priced on their own shapes
+                    algo_bytes = _ops.LABEL_ALGO_BYTES[name]
                 ach = algo_bytes / (st["avg_ms"] * 1e-3) / 1e9
                 roof = dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(ach / HBM_PEAK_GBS, 4), algo_bytes_per_launch=algo_bytes)

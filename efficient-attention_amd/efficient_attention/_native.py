@@ -247,6 +247,19 @@ KERNEL_TIMER = KernelTimer()
 _FN = {}
 
 
+def call_as(label, name, *args):
+    """call(name, ...) timed under `label` (one C-ABI entry, several shapes: the label tells them apart)."""
+    if not KERNEL_TIMER.enabled:
+        return call(name, *args)
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = getattr(lib(), name)(*args)
+    b.record()
+    KERNEL_TIMER.records.append((label, a, b))
+    _check(rc, name)
+
+
 def call(name, *args):
     fn = _FN.get(name)
     if fn is None:

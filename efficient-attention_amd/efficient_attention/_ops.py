@@ -1413,6 +1413,7 @@ def slice_sum(part):
 
 
 USE_EA_LINEAR = os.environ.get("EA_LINEAR", "1") == "1"
+LABEL_ALGO_BYTES = {}     # timer label -> algorithmic bytes of its last launch (projection kernels: shapes vary per call)
 _ELEM = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -1450,8 +1451,12 @@ def ea_linear(a2, w, bias32, out_dtype, want_cast=False):
     y = torch.empty((rows, NO), dtype=out_dtype, device=a2.device)
     a_f32 = a2.dtype == torch.float32
     a_cast = torch.empty((rows, K), dtype=w.dtype, device=a2.device) if (a_f32 and want_cast) else None
-    nv.call("ea_linear", _ELEM[w.dtype], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w), nv.ptr(bias32),
-            nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
+    label = "ea_linear (fp32 in)" if a_f32 else "ea_linear"
+    if nv.KERNEL_TIMER.enabled:
+        # what the launch has to move: activations in, result out, the rounded copy when asked for (the weight is noise)
+        LABEL_ALGO_BYTES[label] = rows * (K * a2.element_size() + NO * y.element_size() + (K * 2 if a_cast is not None else 0))
+    nv.call_as(label, "ea_linear", _ELEM[w.dtype], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w), nv.ptr(bias32),
+               nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
     return y, a_cast
 
 
@@ -1481,6 +1486,8 @@ def wgrad(dy2, x2, with_bias=True):
     n = M * K + (M if with_bias else 0)
     part = torch.empty((S, n), dtype=torch.float32, device=dy2.device)      # slice s: dW partial, then db partial
     db_ptr = ctypes.c_void_p(part.data_ptr() + M * K * 4) if with_bias else None
+    if nv.KERNEL_TIMER.enabled:
+        LABEL_ALGO_BYTES["ea_wgrad"] = max(LABEL_ALGO_BYTES.get("ea_wgrad", 0), rows * (M + K) * 2 + n * 4)
     nv.call("ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), db_ptr, n, nv.stream())
     out = torch.empty(n, dtype=torch.float32, device=dy2.device)
     nv.call("ea_part_sum", S, n, n, nv.ptr(part), nv.ptr(out), nv.stream())
