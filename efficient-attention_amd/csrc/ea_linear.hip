@@ -6,7 +6,8 @@
 // GEMM to be tiled for operand re-use.
 //
 // The output columns are cut into `nsplit` parts of <= 72 KB of weight rows; a workgroup stages ITS part
-// into LDS once and stays resident (two workgroups per CU).  From there on there is no barrier: every wave
+// into LDS once and stays resident (two 4-wave workgroups per CU; the 576 columns of a 192-wide qkv
+// projection go as two parts of 288 = 111 KB on one 8-wave workgroup per CU).  From there on there is no barrier: every wave
 // walks its own 16 * RT-row token tiles (tile = wave id, + number of waves, ...), keeping the tile's rows, all
 // K channels, in registers as MFMA operands -- loaded straight from global memory in the operand layout
 // (lane = token li, channels 8g .. 8g+7 of a 32-channel step), the next tile's loads in flight under the
