@@ -166,6 +166,13 @@ EA_DEV float wave_sum(float v) {
   return v;
 }
 
+// Destination of stores that must not land anywhere (rows past the end of a slice): a store issued unconditionally to
+// `valid ? dst : ea_trash_line()` keeps the number of memory operations in a loop static, so the compiler can wait for
+// the prefetched loads alone (`s_waitcnt vmcnt(n_stores)`) instead of for everything (`vmcnt(0)`, which also waits for the
+// stores of the previous tile).  64 bytes per thread; nobody reads it.
+static __device__ char ea_trash[512 * 64];
+EA_DEV char* ea_trash_line() { return ea_trash + threadIdx.x * 64; }
+
 EA_DEV u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 EA_DEV void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 EA_DEV u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }

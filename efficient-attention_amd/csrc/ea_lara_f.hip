@@ -304,13 +304,14 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         }
       }
     }
-    if (valid) {
+    {
+      // unconditional stores (rows past the slice go to the trash line): static store count, see ea_trash_line()
       float f[DQ];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
-      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
+      char* dst = valid ? p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2 : ea_trash_line();
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
     }
@@ -543,18 +544,19 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
         acc2[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * ROWB)), as_x8<E>(p2), acc2[dt]);
       }
     }
-    if (valid) {
+    {
+      // unconditional stores (rows past the slice go to the trash line): static store count, see ea_trash_line()
       float f[DQ];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
-      char* dstv = p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2;
+      char* dstv = valid ? p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2 : ea_trash_line();
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
       // dk: the lane's B-fragment chunks of k hold channels 8 (g KS + ks) ..; its D rows hold DQ g + ..
       // -> the k factor is applied in the D layout through the packed store below
-      char* dstk = p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + DQ * g) * 2;
+      char* dstk = valid ? p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + DQ * g) * 2 : ea_trash_line() + 32;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float kf[8], o8[8];

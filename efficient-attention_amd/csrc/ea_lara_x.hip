@@ -498,18 +498,22 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       }
     }
     if (prof_it < 8) EA_STAMP(p, 6 + prof_it * 5);
-    if (!valid) continue;
     // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` ----
     float f[DQ];
     if (MODE == LX_FWD || MODE == LX_POUT) {
+      // issued unconditionally (rows past the end go to the trash line): a static store count lets the wait for the next
+      // tile's prefetched rows leave this tile's stores in flight
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * pden;
-      char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2;
+      char* dst = valid ? p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2 : ea_trash_line();
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
-    } else if (MODE == LX_BWDQ) {
+      continue;
+    }
+    if (!valid) continue;
+    if (MODE == LX_BWDQ) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
