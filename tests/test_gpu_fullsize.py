@@ -33,6 +33,14 @@ FULL = {
     "cfg3_local": ("local", (128, 28, 28, 192), dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True), None),
     "cfg3_performer": ("performer", (128, 28, 28, 192), dict(dim=192, num_heads=3, approx_attn_dim=64,
                                                               proj_method="favorp"), None),
+    # cfg3 with antithetic sampling: 98 samples -> ea_lara_sample_* + the token-row / token-column passes for C > 64
+    "cfg3_lara_antithetic": ("lara", (32, 28, 28, 192), dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                                                              mis_type="mis-opt", alpha_coeff=2.0, use_antithetics=True), None),
+    # 36 landmarks on a 28 x 28 grid: overlapping adaptive-pool bins (ea_adaptive_pool2d_*), '-vmixed' column bias
+    "cfg3_lara_vmixed_uneven": ("lara", (32, 28, 28, 192), dict(dim=192, num_heads=3, num_landmarks=36,
+                                                                 proposal_gen="pool-vmixed", mis_type="mis-bh"), None),
+    "cfg3_scatterbrain": ("scatterbrain", (32, 28, 28, 192), dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True,
+                                                                   approx_attn_dim=64), None),
     # cfg2 (N = 196) at the DeiT batch
     "cfg2_lara": ("lara", (128, 14, 14, 192), dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
                                                     mis_type="mis-opt", alpha_coeff=2.0), None),
@@ -94,7 +102,7 @@ def _mask(shape, pads, device):
 def _run_case(name, dtype):
     import efficient_attention as ea
     import oracle
-    from gpu_checks import MODULE_TOL, LARA_TOL, FP16_TOL
+    from gpu_checks import MODULE_TOL, LARA_TOL, FP16_TOL, SCATTER_TOL
     from util import scaled_err
     attn, shape, args, pads = FULL[name]
     torch.manual_seed(21)
@@ -132,7 +140,7 @@ def _run_case(name, dtype):
     if dtype == torch.float16:
         tol = FP16_TOL
     else:
-        tol = LARA_TOL if attn == "lara" else MODULE_TOL
+        tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(attn, MODULE_TOL)
     pairs = [("y", y.detach().float().cpu().numpy(), ref.detach().numpy()),
              ("dx", x.grad.float().cpu().numpy(), xr.grad.numpy())]
     for k, p in m.named_parameters():
