@@ -731,6 +731,7 @@ namespace ea {
 int colsum_parts(int rows, int cols);
 int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows, int cols, hipStream_t st);
 int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, hipStream_t st);
+int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st);
 int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
 }  // namespace ea
 
@@ -747,6 +748,12 @@ int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* 
   if (!x || !out) return EA_E_BADARG;
   return ea::colsum_f32_dispatch(x, out, rows, cols, (hipStream_t)stream);
 }
+
+int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream) {
+  if (!g || !inv || !out) return EA_E_BADARG;
+  return ea::gather_sum_dispatch(g, inv, out, rows, K, cols, (hipStream_t)stream);
+}
+
 
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream) {

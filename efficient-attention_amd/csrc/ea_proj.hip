@@ -154,4 +154,29 @@ int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S
   return (int)hipGetLastError();
 }
 
+// Gradient of a table gather (relative-position bias table -> dense per-head bias, local_attention.py:70-79):
+//     out[row][c] = sum_k g[inv[row][k]][c]     (inv: the positions that read table row `row`, -1 = none)
+// fixed order.
+__global__ __launch_bounds__(64) void gather_sum_kernel(const float* __restrict__ g, const int* __restrict__ inv,
+                                                         float* __restrict__ out, int rows, int K, int cols) {
+  // one wave per table row: lane k holds position k (k + 64, ...) of the row's list, all loads in flight at once; the
+  // lanes are added by a fixed butterfly
+  const int row = blockIdx.x, lane = threadIdx.x;
+  for (int c = 0; c < cols; ++c) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const int j = inv[(size_t)row * K + k];
+      s += j >= 0 ? g[(size_t)j * cols + c] : 0.f;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)row * cols + c] = s;
+  }
+}
+
+int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st) {
+  if (rows <= 0 || K <= 0 || cols <= 0) return EA_E_BADARG;
+  hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)rows), dim3(64), 0, st, g, inv, out, rows, K, cols);
+  return (int)hipGetLastError();
+}
+
 }  // namespace ea

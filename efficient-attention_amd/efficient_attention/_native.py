@@ -108,6 +108,7 @@ SIGNATURES = {
     "ea_lara_sample_bwd": [_I, _I, _I, _I, _I, _I, _F] + [_P] * 10,
     "ea_adaptive_pool2d_fwd": [_I, _I, _I, _I, _I, _I, _I, _T, _P, _P],
     "ea_adaptive_pool2d_bwd": [_I, _I, _I, _I, _I, _I, _I, _P, _T, _P],
+    "ea_gather_sum": [_I, _I, _I, _P, _P, _P, _P],
     "ea_linear_supported": [_I, _I],
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],

@@ -17,19 +17,40 @@ from .abstract_attention import MultiheadAttention
 
 
 class _TableGather(torch.autograd.Function):
-    """table[idx] (reference local_attention.py:70-79 `relative_position_bias_table[index]`) whose
-    backward is one dense [rows, len(idx)] x [len(idx), h] product with a one-hot matrix instead of
-    autograd's sort-based index_put (six kernels for a 169 x 3 table): deterministic, one tiny GEMM."""
+    """table[idx] (reference local_attention.py:70-79 `relative_position_bias_table[index]`) whose backward adds, for every
+    table row, the gradients of the positions that read it in a fixed order (ea_gather_sum; `inv` [rows, K] lists those
+    positions) instead of autograd's sort-based index_put (six kernels for a 169 x 3 table): deterministic, one launch."""
 
     @staticmethod
-    def forward(ctx, table, idx, onehot):
-        ctx.save_for_backward(onehot)
+    def forward(ctx, table, idx, inv):
+        ctx.save_for_backward(inv)
         return table.index_select(0, idx)
 
     @staticmethod
     def backward(ctx, g):
-        (onehot,) = ctx.saved_tensors
-        return (onehot @ g.float()).to(g.dtype), None, None
+        (inv,) = ctx.saved_tensors
+        if not g.is_cuda:                                     # (CPU construction-time checks only: no kernel there)
+            out = torch.zeros((inv.shape[0],) + tuple(g.shape[1:]), dtype=torch.float32)
+            gz = torch.cat([g.float(), torch.zeros((1,) + tuple(g.shape[1:]))])
+            return gz[torch.where(inv < 0, torch.full_like(inv, g.shape[0]), inv).long()].sum(1).to(g.dtype), None, None
+        g32 = g.float().contiguous()
+        cols = g32[0].numel()
+        out = torch.empty((inv.shape[0], cols), dtype=torch.float32, device=g.device)
+        _ops.nv.call("ea_gather_sum", inv.shape[0], inv.shape[1], cols, _ops.nv.ptr(g32), _ops.nv.ptr(inv), _ops.nv.ptr(out),
+                     _ops.nv.stream())
+        return out.view((inv.shape[0],) + tuple(g.shape[1:])).to(g.dtype), None, None
+
+
+def _inverse_index(flat, rows):
+    """[rows, K] int32: the positions of `flat` that hold each value in [0, rows), padded with -1."""
+    order = torch.argsort(flat, stable=True)
+    counts = torch.bincount(flat, minlength=rows)
+    K = int(counts.max())
+    inv = torch.full((rows, K), -1, dtype=torch.int32)
+    start = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(flat.numel()) - start[flat[order]]
+    inv[flat[order], pos] = order.to(torch.int32)
+    return inv
 
 
 def relative_position_index_2d(window_size, ext_size):
@@ -59,9 +80,7 @@ class LocalAttention(MultiheadAttention):
                 self.local_relative_position_bias_table = nn.Parameter(torch.zeros(rows, self.num_heads))
                 self.register_buffer("relative_position_index", relative_position_index_2d(w, e))
                 flat = self.relative_position_index.reshape(-1)
-                onehot = torch.zeros(rows, flat.numel())
-                onehot[flat, torch.arange(flat.numel())] = 1.0
-                self.register_buffer("_rpe_onehot", onehot, persistent=False)   # not part of state_dict
+                self.register_buffer("_rpe_inv", _inverse_index(flat, rows), persistent=False)   # not part of state_dict
             else:
                 self.local_relative_position_bias_table = nn.Parameter(
                     torch.zeros(self.num_heads, w, w + 2 * e))
@@ -76,7 +95,7 @@ class LocalAttention(MultiheadAttention):
         if not self.attn_2d:
             return tab
         idx = self.relative_position_index
-        return _TableGather.apply(tab, idx.reshape(-1), self._rpe_onehot).reshape(
+        return _TableGather.apply(tab, idx.reshape(-1), self._rpe_inv).reshape(
             idx.shape[0], idx.shape[1], -1).permute(2, 0, 1)
 
     def add_rel_pos_bias(self, local_dots):

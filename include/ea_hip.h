@@ -367,6 +367,10 @@ int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, floa
  * ea_slice_sum: out[bh][j] = scale * (a[bh][j] + sum_s parts[bh][s][j]), j < n (n % 4 == 0), a may
  *   be NULL.  Used for d(omega) = s (d_omega_q + sum over sequence slices of ea_lara_bwd_kstats). */
 int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* stream);
+/* Gradient of a table gather (the relative-position bias table read through `relative_position_index`,
+ * local_attention.py:70-79): out[row][c] = sum_k g[inv[row][k]][c], inv [rows, K] int32 = the gather positions that read
+ * table row `row` (-1 = unused slot), g [n, cols] fp32.  Fixed order (deterministic). */
+int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream);
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream);
 
