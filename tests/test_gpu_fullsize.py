@@ -45,6 +45,11 @@ FULL = {
     "cfg2_lara": ("lara", (128, 14, 14, 192), dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
                                                     mis_type="mis-opt", alpha_coeff=2.0), None),
     "cfg2_eva": ("eva", (128, 14, 14, 192), dict(dim=192, num_heads=3, window_size=7, num_landmarks=49, **EVA2D), None),
+    # cfg4: PvT-b2 stages at 384^2 (window 8, 36 landmarks) at the PvT batch, and its softmax last stage
+    "cfg4_eva_s1": ("eva", (32, 96, 96, 64), dict(dim=64, num_heads=1, window_size=8, num_landmarks=36, **EVA2D), None),
+    "cfg4_eva_s2": ("eva", (32, 48, 48, 128), dict(dim=128, num_heads=2, window_size=8, num_landmarks=36, **EVA2D), None),
+    "cfg4_eva_s3": ("eva", (32, 24, 24, 320), dict(dim=320, num_heads=5, window_size=8, num_landmarks=36, **EVA2D), None),
+    "cfg4_softmax_s4": ("softmax", (32, 12, 12, 512), dict(dim=512, num_heads=8), None),
     # cfg5: 1-D N = 4096, h = 8, pad mask
     "cfg5_lara": ("lara", (4, 4096, 512), dict(dim=512, num_heads=8, num_landmarks=49, proposal_gen="adaptive-1d",
                                                 mis_type="mis-opt"), [0, 410, 0, 17]),
