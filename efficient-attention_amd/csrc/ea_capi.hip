@@ -25,7 +25,7 @@ int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
 int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long sn, float* mean, int B, int H, int gh, int gw,
                     int side, int D, hipStream_t st);
 int linear_supported(int K, int NO);
-int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const float* bias, void* y, int y_f32,
+int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
 int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
@@ -57,7 +57,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 3; }
+int32_t ea_abi_version(void) { return 4; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -281,15 +281,16 @@ int ea_lara_stats_fwd(const ea_lara_geom* g, const ea_t4* q, const ea_t4* k, con
 
 int ea_lara_out_fwd(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar,
                     const float* kv, const float* lse_t, const float* bhv, const float* cst,
-                    const ea_t4* out, void* stream) {
+                    const ea_t4* out, float* lseZ, float* tmean, void* stream) {
   LaraP p = {};
   int rc = fill_lara(g, p, false);
   if (rc != EA_OK) return rc;
   if (!t4_ok(q, g->D) || !t4_ok(out, g->D) || !omega || !kv || !cst) return EA_E_BADARG;
   if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv)) return EA_E_BADARG;
   if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  if ((lseZ == nullptr) != (tmean == nullptr)) return EA_E_BADARG;
   p.q = mkl(q); p.o = mkl(out); p.omega = omega; p.qbar = qbar; p.kv = kv; p.lse_t = lse_t;
-  p.bhv = bhv; p.cst = cst;
+  p.bhv = bhv; p.cst = cst; p.lseZ = lseZ; p.tmean = tmean;
   return lara_x_dispatch(LX_FWD, p, g->dtype, (hipStream_t)stream);
 }
 
@@ -366,18 +367,19 @@ int32_t ea_lara_fused_parts(const ea_lara_geom* g) {
 
 int ea_lara_bwd_q_fused(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
                         const float* qbar, const float* kv, const float* lse_t, const float* bhv,
-                        const float* cst, const ea_t4* dq, float* p_ml, float* p_dkv, float* p_dom,
-                        float* p_m1, float* p_m2, void* stream) {
+                        const float* cst, const float* lseZ, const float* tmean, const ea_t4* dq, float* p_ml,
+                        float* p_dkv, float* p_dom, float* p_m1, float* p_m2, void* stream) {
   LaraP p = {};
   int rc = fill_lara(g, p, false);
   if (rc != EA_OK) return rc;
   if (p.NCT > 4) return EA_E_UNSUPPORTED;
   if (!t4_ok(q, g->D) || !t4_ok(dout, g->D) || !t4_ok(dq, g->D) || !omega || !kv || !cst || !p_ml ||
-      !p_dkv || !p_dom) return EA_E_BADARG;
+      !p_dkv || !p_dom || !lseZ || !tmean) return EA_E_BADARG;
   if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv || !p_m1 || !p_m2)) return EA_E_BADARG;
   if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
   p.q = mkl(q); p.dout = mkl(dout); p.dq = mkl(dq); p.omega = omega; p.qbar = qbar; p.kv = kv;
   p.lse_t = lse_t; p.bhv = bhv; p.cst = cst;
+  p.lseZ = const_cast<float*>(lseZ); p.tmean = const_cast<float*>(tmean);
   p.p_ml = p_ml; p.p_acc0 = p_dkv; p.p_acc1 = p_dom; p.p_acc2 = p_m1; p.p_acc3 = p_m2;
   return lara_f_dispatch(0, p, g->dtype, (hipStream_t)stream);
 }
@@ -730,7 +732,7 @@ int ea_lara_merge_bwd(int32_t BH, int32_t S, int32_t C, int32_t D, int32_t has_t
 namespace ea {
 int colsum_parts(int rows, int cols);
 int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows, int cols, hipStream_t st);
-int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, hipStream_t st);
+int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, const float* x2, float* out2, int cols2, hipStream_t st);
 int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st);
 int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
 }  // namespace ea
@@ -746,7 +748,13 @@ int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, floa
 
 int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* stream) {
   if (!x || !out) return EA_E_BADARG;
-  return ea::colsum_f32_dispatch(x, out, rows, cols, (hipStream_t)stream);
+  return ea::colsum_f32_dispatch(x, out, rows, cols, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, int32_t cols2, const float* x2, float* out2,
+                   void* stream) {
+  if (!x1 || !out1 || !x2 || !out2 || cols2 <= 0) return EA_E_BADARG;
+  return ea::colsum_f32_dispatch(x1, out1, rows, cols1, x2, out2, cols2, (hipStream_t)stream);
 }
 
 int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream) {
@@ -933,8 +941,19 @@ int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_feat
       ((uintptr_t)a_cast & 15))
     return EA_E_BADARG;
   if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
-  return linear_dispatch(dtype, a, a_f32, w, bias, y, y_f32, a_cast, rows, in_features, out_features, (long)lda,
+  return linear_dispatch(dtype, a, a_f32, w, 0, bias, y, y_f32, a_cast, rows, in_features, out_features, (long)lda,
                          (long)ldy, (hipStream_t)stream);
+}
+
+int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
+                  int64_t lda, const float* w, int32_t w_transposed, const float* bias, void* y, int32_t y_f32, int64_t ldy,
+                  void* a_cast, void* stream) {
+  if (!a || !w || !y || ((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)a_cast & 15))
+    return EA_E_BADARG;
+  if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
+  return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
+                         (long)lda, (long)ldy, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -67,6 +67,38 @@ struct ProfReport {
 
 namespace ea {
 
+// ---- per-device launch state.  hipFuncSetAttribute acts on the CURRENT device's copy of a kernel and the CU
+// count is a device property: a process that drives several GPUs must keep both per device.
+constexpr int EA_MAX_DEV = 64;
+inline int ea_cur_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EA_MAX_DEV) dev = 0;
+  return dev;
+}
+inline int ea_device_cus() {
+  static int n[EA_MAX_DEV] = {};
+  const int dev = ea_cur_device();
+  if (!n[dev]) {
+    hipDeviceProp_t prop;
+    int v = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) v = prop.multiProcessorCount;
+    n[dev] = v > 0 ? v : 256;
+  }
+  return n[dev];
+}
+// once per (call site, device): raise the dynamic-LDS limit of kernel `fn`
+#define EA_SET_LDS_ONCE(fn, bytes)                                                                              \
+  do {                                                                                                         \
+    static bool ea_done_[ea::EA_MAX_DEV] = {};                                                                 \
+    const int ea_dev_ = ea::ea_cur_device();                                                                   \
+    if (!ea_done_[ea_dev_]) {                                                                                  \
+      hipError_t ea_e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),                                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));       \
+      if (ea_e_ != hipSuccess) return (int)ea_e_;                                                              \
+      ea_done_[ea_dev_] = true;                                                                                \
+    }                                                                                                          \
+  } while (0)
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;   // arithmetic on it maps to v_pk_*_f32
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -228,5 +260,78 @@ template <int D> struct LaneOff {
     }
   }
 };
+
+// ------------------------------------------------------------------------------------------
+// Round 3: bank-conflict-free tile layout (D = 64: 128-byte rows).  Measured with tools/probe/lds_probe.hip:
+//   * ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS):
+//     with the (row & 7) chunk swizzle of lds_off<> two of the four groups are 2-way conflicted (6.1 instead of 4.0
+//     cycles per wave-instruction);
+//   * the ds_read_b64_tr_b16 pattern of LaneOff<>::tr -- a row's four lanes reading 8-byte pieces 32 bytes apart -- puts
+//     the 32 lanes of a group on 8 of the 32 8-byte slots of the bank space whatever the 16-byte swizzle: 4-way
+//     conflicts, 7.0 instead of 2.0 cycles.  (SQ_LDS_BANK_CONFLICT was 35-55 % of SQ_LDS_IDX_ACTIVE in every kernel.)
+// Fix: (a) chunk swizzle phi2(row) = ((row >> 1) & 3) << 1 | ((row ^ (row >> 3)) & 1), conflict-free for the b128
+// row-operand reads, for 16-byte row stores and for (b) the transpose reads re-shaped so that the four lanes of a row
+// read 32 CONTIGUOUS bytes (channels 16 dt + 4 (li & 3) ..).  With (b) the MFMA that consumes the fragment produces
+// D rows <-> channels 16 dt + 4 g + r: a lane owns four 4-channel pieces 16 channels apart instead of 16 contiguous
+// channels; quad_transpose() below moves the pieces between the four lanes of a token (8 v_permlane swaps on packed
+// data) so that stores stay 32 contiguous bytes per lane.
+EA_DEV int phi2(int row) { return (((row >> 1) & 3) << 1) | ((row ^ (row >> 3)) & 1); }
+template <int D> EA_DEV int lds_off2(int row, int chunk16) {
+  static_assert(D == 64, "lds_off2: 128-byte rows only");
+  return row * (D * 2) + ((chunk16 ^ phi2(row)) << 4);
+}
+template <int D> struct LaneOff2 {
+  static constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16;
+  int plain[KS];   // A/B operand chunk (row = lane & 15, k-step ks) of a 16-row tile
+  int tr[DT];      // ds_read_b64_tr_b16 source: row 4g + (li >> 2), channels 16 dt + 4 (li & 3) ..
+  EA_DEV void init(int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) plain[ks] = lds_off2<D>(li, g * KS + ks);
+    const int r = 4 * g + (li >> 2);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) tr[dt] = lds_off2<D>(r, 2 * dt + ((li & 3) >> 1)) + 8 * (li & 1);
+  }
+};
+// x[s][w]: W registers per piece, piece s of lane-row g = channels 16 s + 4 g + r  ->  piece s = channels 16 g + 4 s + r
+// (4 x 4 transpose of the pieces across the four lanes li, li + 16, li + 32, li + 48 of a token)
+template <int W> EA_DEV void quad_transpose(uint32_t (&x)[4][W]) {
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3"
+                 : "+v"(x[0][w]), "+v"(x[1][w]), "+v"(x[2][w]), "+v"(x[3][w]));
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                 : "+v"(x[0][w]), "+v"(x[1][w]), "+v"(x[2][w]), "+v"(x[3][w]));
+}
+// fp32 accumulators acc[dt][r] (new ownership) -> f[16] in the contiguous ownership (channel 16 g + j)
+EA_DEV void quad_transpose_f32(const f32x4* acc, float* f) {
+  uint32_t x[4][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = acc[s][r];          // (a bit_cast applied directly to the vector element reads element 0: hipcc 7.2)
+      x[s][r] = __builtin_bit_cast(uint32_t, t);
+    }
+  quad_transpose<4>(x);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[4 * s + r] = __builtin_bit_cast(float, x[s][r]);
+}
+// ... rounded to the element type first (values scaled by `mul`): two u32x4 = the lane's 32 contiguous bytes
+template <typename E> EA_DEV void quad_transpose_pack(const f32x4* acc, float mul, u32x4& o0, u32x4& o1) {
+  uint32_t x[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    x[s][0] = pack2<E>(acc[s][0] * mul, acc[s][1] * mul);
+    x[s][1] = pack2<E>(acc[s][2] * mul, acc[s][3] * mul);
+  }
+  quad_transpose<2>(x);
+  o0 = u32x4{x[0][0], x[0][1], x[1][0], x[1][1]};
+  o1 = u32x4{x[2][0], x[2][1], x[3][0], x[3][1]};
+}
 
 }  // namespace ea

@@ -30,6 +30,20 @@ namespace ea {
 // XOR-swizzled by the row (same scheme as the token tiles, lds_off<>)
 template <int W> EA_DEV int wt_off(int row, int c) { return lds_off<W>(row, c >> 3) + ((c & 7) << 1); }
 
+// token / landmark tiles [rows][D]: the conflict-free round-3 layout for 128-byte rows (ea_common.h), the round-1 one for D = 32.
+// NEWTR: the transpose reads hand a lane the channels 16 dt + 4 g + r (pieces), not D/4 contiguous ones.
+template <int D> struct TileL {
+  static constexpr bool NEWTR = (D == 64);
+  static EA_DEV int off(int row, int chunk16) {
+    if constexpr (NEWTR) return lds_off2<D>(row, chunk16);
+    else return lds_off<D>(row, chunk16);
+  }
+};
+template <int D> struct LaneOffSel { typedef LaneOff<D> type; };
+template <> struct LaneOffSel<64> { typedef LaneOff2<64> type; };
+// channel offset (within a [*, D] fp32 row) of accumulator tile dt of lane-row g
+template <int D> EA_DEV int acc_chan(int dt, int g) { return TileL<D>::NEWTR ? 16 * dt + 4 * g : (D / 4) * g + 4 * dt; }
+
 // all global loads of up to three [C][D] fp32 landmark matrices in flight, then convert + store as
 // swizzled element-type rows (zero rows beyond C)
 template <typename E, int D, int Cp>
@@ -60,7 +74,7 @@ EA_DEV void stage_rows3(char* const dst[3], const float* const src[3], int C, in
       if (!src[j] || idx >= Cp * CPRs) continue;
       const float4 lo = rb[j][sl][0], hi = rb[j][sl][1];
       const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      sts16(dst[j] + lds_off<D>(row, c), pack8<E>(f));
+      sts16(dst[j] + TileL<D>::off(row, c), pack8<E>(f));
     }
   }
 }
@@ -73,7 +87,12 @@ template <typename E> EA_DEV typename E::x8 ones_x8() {
 // ------------------------------------------------------------------------------------------
 // query side
 // ------------------------------------------------------------------------------------------
-template <typename E, int D, int NCT>
+// LH: r-pairs of the LAST landmark tile that can hold a real sample (C = 49: tile 3 has the single row 48, so only the
+// first (r = 0, 1) pair of a lane is ever non-zero -> the elementwise stage skips the other: 7 of 8 pairs per lane).
+// The per-token statistics of the estimator's softmax over the samples -- lse_Z (log2 units) and mean_c t -- come from
+// the forward (ea_lara_out_fwd writes them: 8 bytes per token-head), so W = alpha 2^(z - lse_Z) directly: no max, no
+// sum, no reciprocal, and two cross-lane reductions per tile instead of five.
+template <typename E, int D, int NCT, int LH>
 __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int Cp = NCT * 16, ROWW = Cp * 2, NSUB = 4 / NCT;
@@ -107,6 +126,9 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   EA_BLK(p, 0);
   EA_STAMP(p, 0);
   u32x4 nx1[KS], nx2[KS];
+  float nlz, ntm;
+  const float* lzb = p.lseZ + (size_t)bh * p.N;
+  const float* tmb = p.tmean + (size_t)bh * p.N;
   auto issue = [&](int cb_) {
     const int tok_ = min(cb_ + wave * 16 + li, last_tok);
 #pragma unroll
@@ -115,6 +137,8 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       nx1[ks] = ldg16(qb + (tok_ * p.q.sn + eo) * 2);
       nx2[ks] = ldg16(dob + (tok_ * p.dout.sn + eo) * 2);
     }
+    nlz = lzb[tok_];
+    ntm = tmb[tok_];
   };
   issue(n0);
   float sc_v0 = -INFINITY, sc_v1 = INFINITY, sc_v2 = 1.f;
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
     stage_rows3<E, D, Cp>(dst, src, p.C, tid);
   }
   if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
-  LaneOff<D> lo;
+  typename LaneOffSel<D>::type lo;
   lo.init(lane);
   // tr-read offset into a weight slab: rows 4g + (li >> 2), column segment 4 (li & 3) of a landmark tile
   const int wr = 4 * g + (li >> 2);
@@ -163,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       f1[ks] = as_x8<E>(nx1[ks]);
       f2[ks] = as_x8<E>(nx2[ks]);
     }
+    // tokens beyond the slice contribute nothing to the per-landmark sums: lse_Z = +inf -> W = dZ = d alpha = 0
+    const float lz = valid ? nlz : INFINITY;
+    const float tmean = ntm;
     issue(cb + 64);
     // ---- score tiles: A = s omega.q, T = s qbar.q, dW = kv.dout  (D[c = 4g+r][n = li]) ----
     f32x4 a[NCT], tt[NCT], dw[NCT];
@@ -172,80 +199,52 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       const int row = ct * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
-        if (use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt[ct]);
-        dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+        a[ct] = E::mma(as_x8<E>(lds16(R1 + TileL<D>::off(row, g * KS + ks))), f1[ks], a[ct]);
+        if (use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + TileL<D>::off(row, g * KS + ks))), f1[ks], tt[ct]);
+        dw[ct] = E::mma(as_x8<E>(lds16(R3 + TileL<D>::off(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
     if (prof_it < 8) EA_STAMP(p, 3 + prof_it * 7);
-    // ---- elementwise stage (same algebra as LX_BWDQ, ea_lara_x.hip) ----
+    // ---- elementwise stage (lara.py:221-243 differentiated; alpha as a factor, d alpha = 2^z (dW - rd) without a
+    // division, lse_Z / mean t from the forward) ----
     const float s2 = p.scale_log2;
     const f32x2 s22 = {s2, s2};
+    const f32x2 kap = {p.kappa, p.kappa};
+    const f32x2 lz2 = {lz, lz};
+    const float kt = -p.kappa * tmean;
+    // pair (ct, hh) is live unless it lies in the never-populated part of the last tile
+#define EA_LIVE(ct, hh) ((ct) < NCT - 1 || (hh) < LH)
     f32x2 tv[NCT][2], ez[NCT][2], wv[NCT][2];
-    f32x2 tl2 = {0.f, 0.f};
-    if (opt) {
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const float4 ls = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
-        const f32x2 x0 = f32x2{tt[ct][0], tt[ct][1]} * s22 - f32x2{ls.x, ls.y};
-        const f32x2 x1 = f32x2{tt[ct][2], tt[ct][3]} * s22 - f32x2{ls.z, ls.w};
-        tv[ct][0] = f32x2{fast_exp2(x0[0]), fast_exp2(x0[1])};
-        tv[ct][1] = f32x2{fast_exp2(x1[0]), fast_exp2(x1[1])};
-        tl2 += tv[ct][0] + tv[ct][1];
-      }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) tv[ct][0] = tv[ct][1] = f32x2{0.f, 0.f};
-    }
-    const float tmean = quad_sum(tl2[0] + tl2[1]) * invC;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const float4 cs = *reinterpret_cast<const float4*>(SC0 + ct * 16 + 4 * g);
-      f32x2 z0 = f32x2{a[ct][0], a[ct][1]} * s22 + f32x2{cs.x, cs.y};
-      f32x2 z1 = f32x2{a[ct][2], a[ct][3]} * s22 + f32x2{cs.z, cs.w};
-      if (p.mis == MIS_BIASED) {
-        z0 += f32x2{tt[ct][0], tt[ct][1]} * s22;
-        z1 += f32x2{tt[ct][2], tt[ct][3]} * s22;
-      }
-      ez[ct][0] = z0; ez[ct][1] = z1;
-      mx = fmaxf(fmaxf(mx, fmaxf(z0[0], z0[1])), fmaxf(z1[0], z1[1]));
-    }
-    mx = quad_max(mx);
-    const f32x2 mx2 = {mx, mx};
-    f32x2 ss2 = {0.f, 0.f};
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const f32x2 x = ez[ct][hh] - mx2;
-        ez[ct][hh] = f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
-      }
-      if (opt) {
-        const float4 bv = *reinterpret_cast<const float4*>(SC2 + ct * 16 + 4 * g);
-        const float kt = -p.kappa * tmean;
-        const f32x2 kap = {p.kappa, p.kappa};
-        const f32x2 a0 = kap * tv[ct][0] + f32x2{bv.x + kt, bv.y + kt};
-        const f32x2 a1 = kap * tv[ct][1] + f32x2{bv.z + kt, bv.w + kt};
-        wv[ct][0] = ez[ct][0] * f32x2{fmaxf(a0[0], 1e-8f), fmaxf(a0[1], 1e-8f)};
-        wv[ct][1] = ez[ct][1] * f32x2{fmaxf(a1[0], 1e-8f), fmaxf(a1[1], 1e-8f)};
-        ez[ct][0] = f32x2{a0[0] > 1e-8f ? ez[ct][0][0] : 0.f, a0[1] > 1e-8f ? ez[ct][0][1] : 0.f};
-        ez[ct][1] = f32x2{a1[0] > 1e-8f ? ez[ct][1][0] : 0.f, a1[1] > 1e-8f ? ez[ct][1][1] : 0.f};
-      } else {
-        wv[ct][0] = ez[ct][0];
-        wv[ct][1] = ez[ct][1];
-      }
-      ss2 += wv[ct][0] + wv[ct][1];
-    }
-    const float ssum = quad_sum(ss2[0] + ss2[1]);
-    // tokens beyond the block contribute nothing to the per-landmark sums: W = dZ = d alpha = 0
-    const float inv = valid ? fast_rcp(ssum) : 0.f;
-    const f32x2 inv2 = {inv, inv};
     f32x2 rd2 = {0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      wv[ct][0] *= inv2; wv[ct][1] *= inv2;                               // W
-      rd2 += wv[ct][0] * f32x2{dw[ct][0], dw[ct][1]} + wv[ct][1] * f32x2{dw[ct][2], dw[ct][3]};
+      const float4 cs = *reinterpret_cast<const float4*>(SC0 + ct * 16 + 4 * g);
+      const float4 ls = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
+      const float4 bv = *reinterpret_cast<const float4*>(SC2 + ct * 16 + 4 * g);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (!EA_LIVE(ct, hh)) { tv[ct][hh] = ez[ct][hh] = wv[ct][hh] = f32x2{0.f, 0.f}; continue; }
+        const f32x2 av = {a[ct][2 * hh], a[ct][2 * hh + 1]}, tq = {tt[ct][2 * hh], tt[ct][2 * hh + 1]};
+        const f32x2 csv = hh ? f32x2{cs.z, cs.w} : f32x2{cs.x, cs.y};
+        f32x2 z = av * s22 + (csv - lz2);
+        if (p.mis == MIS_BIASED) z += tq * s22;
+        const f32x2 wz = {fast_exp2(z[0]), fast_exp2(z[1])};                  // 2^(z - lse_Z)
+        if (opt) {
+          const f32x2 lsv = hh ? f32x2{ls.z, ls.w} : f32x2{ls.x, ls.y};
+          const f32x2 bvv = hh ? f32x2{bv.z, bv.w} : f32x2{bv.x, bv.y};
+          const f32x2 x = tq * s22 - lsv;
+          const f32x2 t = {fast_exp2(x[0]), fast_exp2(x[1])};
+          const f32x2 al = kap * t + (bvv + f32x2{kt, kt});
+          tv[ct][hh] = t;
+          wv[ct][hh] = wz * f32x2{fmaxf(al[0], 1e-8f), fmaxf(al[1], 1e-8f)};   // W
+          ez[ct][hh] = f32x2{al[0] > 1e-8f ? wz[0] : 0.f, al[1] > 1e-8f ? wz[1] : 0.f};   // W / alpha where the clamp is off
+        } else {
+          tv[ct][hh] = f32x2{0.f, 0.f};
+          wv[ct][hh] = wz;
+          ez[ct][hh] = wz;
+        }
+        rd2 += wv[ct][hh] * f32x2{dw[ct][2 * hh], dw[ct][2 * hh + 1]};
+      }
     }
     const float rd = quad_sum(rd2[0] + rd2[1]);                            // = dout_n . out_n
     const f32x2 rdv = {rd, rd};
@@ -259,32 +258,39 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       f32x2 dz[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
+        if (!EA_LIVE(ct, hh)) { dz[hh] = da[ct][hh] = f32x2{0.f, 0.f}; continue; }
         const f32x2 dd = f32x2{dw[ct][2 * hh], dw[ct][2 * hh + 1]} - rdv;  // dW - rd
         dz[hh] = wv[ct][hh] * dd;
         if (opt) {
-          da[ct][hh] = ez[ct][hh] * inv2 * dd;                             // dZ / alpha
+          da[ct][hh] = ez[ct][hh] * dd;                                    // dZ / alpha
           sda2 += da[ct][hh];
           sdbh[ct][hh] += da[ct][hh];
         }
       }
-      Wp[ct] = u32x2{pack2<E>(wv[ct][0][0], wv[ct][0][1]), pack2<E>(wv[ct][1][0], wv[ct][1][1])};
-      dZp[ct] = u32x2{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[1][0], dz[1][1])};
+      Wp[ct] = u32x2{pack2<E>(wv[ct][0][0], wv[ct][0][1]), EA_LIVE(ct, 1) ? pack2<E>(wv[ct][1][0], wv[ct][1][1]) : 0u};
+      dZp[ct] = u32x2{pack2<E>(dz[0][0], dz[0][1]), EA_LIVE(ct, 1) ? pack2<E>(dz[1][0], dz[1][1]) : 0u};
     }
     const float sda = quad_sum(sda2[0] + sda2[1]);
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       if (opt) {
         const float m = sda * invC;
-        const f32x2 kap = {p.kappa, p.kappa};
         const f32x2 t0 = tv[ct][0] * kap * (da[ct][0] - f32x2{m, m});      // t * dt
-        const f32x2 t1 = tv[ct][1] * kap * (da[ct][1] - f32x2{m, m});
-        tdp[ct] = u32x2{pack2<E>(t0[0], t0[1]), pack2<E>(t1[0], t1[1])};
-        tp[ct] = u32x2{pack2<E>(tv[ct][0][0], tv[ct][0][1]), pack2<E>(tv[ct][1][0], tv[ct][1][1])};
+        tdp[ct][0] = pack2<E>(t0[0], t0[1]);
+        tp[ct][0] = pack2<E>(tv[ct][0][0], tv[ct][0][1]);
+        if (EA_LIVE(ct, 1)) {
+          const f32x2 t1 = tv[ct][1] * kap * (da[ct][1] - f32x2{m, m});
+          tdp[ct][1] = pack2<E>(t1[0], t1[1]);
+          tp[ct][1] = pack2<E>(tv[ct][1][0], tv[ct][1][1]);
+        } else {
+          tdp[ct][1] = 0u; tp[ct][1] = 0u;
+        }
       } else {
         tdp[ct] = dZp[ct];                                                 // mis-biased: dT = dZ
         tp[ct] = u32x2{0u, 0u};
       }
     }
+#undef EA_LIVE
     if (prof_it < 8) EA_STAMP(p, 4 + prof_it * 7);
     // ---- contraction over c: dq^T[d][n] = omega^T . dZ (+ qbar^T . t dt) ----
     f32x4 acc[DT];
@@ -306,14 +312,21 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
     }
     {
       // unconditional stores (rows past the slice go to the trash line): static store count, see ea_trash_line()
-      float f[DQ];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
       char* dst = valid ? p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2 : ea_trash_line();
+      if constexpr (TileL<D>::NEWTR) {
+        u32x4 o0, o1;
+        quad_transpose_pack<E>(acc, p.scale, o0, o1);      // pieces -> the lane's 32 contiguous bytes
+        stg16(dst, o0);
+        stg16(dst + 16, o1);
+      } else {
+        float f[DQ];
 #pragma unroll
-      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+      }
     }
     if (prof_it < 8) EA_STAMP(p, 5 + prof_it * 7);
     // ---- hand the slab to the token-row phase ----
@@ -324,8 +337,8 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
       const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        sts16(TQ + lds_off<D>(row, g * KS + ks), valid ? raw1[ks] : z);
-        sts16(TD + lds_off<D>(row, g * KS + ks), valid ? raw2[ks] : z);
+        sts16(TQ + TileL<D>::off(row, g * KS + ks), valid ? raw1[ks] : z);
+        sts16(TD + TileL<D>::off(row, g * KS + ks), valid ? raw2[ks] : z);
       }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -400,9 +413,9 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
     ml[0] = accR[0]; ml[1] = dbh; ml[2] = accU[0]; ml[3] = 0.f;
   }
   auto put = [&](float* base, const f32x4* av) {
-    float* d = base + slot * D + DQ * g;
+    float* d = base + slot * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g)) = make_float4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
   };
   put(p.p_acc0, acc0);
   put(p.p_acc1, acc1);
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
     stage_rows3<E, D, Cp>(dst, src, p.C, tid);
   }
   if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
-  LaneOff<D> lo;
+  typename LaneOffSel<D>::type lo;
   lo.init(lane);
   const int wr = 4 * g + (li >> 2);
   const int yct = wave % NCT, ysub = wave / NCT;
@@ -492,8 +505,8 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
       const int row = ct * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
-        dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+        a[ct] = E::mma(as_x8<E>(lds16(R1 + TileL<D>::off(row, g * KS + ks))), f1[ks], a[ct]);
+        dw[ct] = E::mma(as_x8<E>(lds16(R3 + TileL<D>::off(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
     float nrm = 0.f;
@@ -546,26 +559,32 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
     }
     {
       // unconditional stores (rows past the slice go to the trash line): static store count, see ea_trash_line()
-      float f[DQ];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
       char* dstv = valid ? p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2 : ea_trash_line();
-#pragma unroll
-      for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
-      // dk: the lane's B-fragment chunks of k hold channels 8 (g KS + ks) ..; its D rows hold DQ g + ..
-      // -> the k factor is applied in the D layout through the packed store below
+      // dk: the lane's B-fragment chunks of k hold channels 8 (g KS + ks) .. = DQ g .., the contiguous ownership: the
+      // k factor is applied there, after the accumulator pieces have been moved to it
       char* dstk = valid ? p.dk.p + (b * p.dk.sb + h * p.dk.sh + tok * p.dk.sn + DQ * g) * 2 : ea_trash_line() + 32;
+      float f2[DQ];
+      if constexpr (TileL<D>::NEWTR) {
+        u32x4 o0, o1;
+        quad_transpose_pack<E>(acc, 1.f, o0, o1);
+        stg16(dstv, o0);
+        stg16(dstv + 16, o1);
+        quad_transpose_f32(acc2, f2);
+      } else {
+        float f[DQ];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { f[4 * dt + r] = acc[dt][r]; f2[4 * dt + r] = acc2[dt][r]; }
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float kf[8], o8[8];
         unpack8<E>(raw1[ks], kf);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int j = 8 * ks + i;
-          o8[i] = p.scale * acc2[j >> 2][j & 3] - p.knorm_coef * kf[i] * sdb;
-        }
+        for (int i = 0; i < 8; ++i) o8[i] = p.scale * f2[8 * ks + i] - p.knorm_coef * kf[i] * sdb;
         stg16(dstk + ks * 16, pack8<E>(o8));
       }
     }
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
       const int row = wave * 16 + li;
       const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) sts16(TK + lds_off<D>(row, g * KS + ks), valid ? raw1[ks] : z);
+      for (int ks = 0; ks < KS; ++ks) sts16(TK + TileL<D>::off(row, g * KS + ks), valid ? raw1[ks] : z);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
         *reinterpret_cast<u32x2*>(WT + wt_off<Cp>(row, 16 * ct + 4 * g)) =
@@ -599,9 +618,9 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
   if (!ywave || c >= p.C) { EA_BLK(p, 1); return; }
   const int S = p.nsplit * NSUB;
   const size_t slot = ((size_t)bh * S + blk * NSUB + ysub) * p.C + c;
-  float* d = p.p_acc0 + slot * D + DQ * g;
+  float* d = p.p_acc0 + slot * D;
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(acc0[dt][0], acc0[dt][1], acc0[dt][2], acc0[dt][3]);
+  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g)) = make_float4(acc0[dt][0], acc0[dt][1], acc0[dt][2], acc0[dt][3]);
   EA_BLK(p, 1);
 }
 
@@ -659,7 +678,7 @@ __global__ __launch_bounds__(256, 3) void lara_fin_kernel(const LaraP p) {
     stage_rows3<E, D, Cp>(dst, src, p.C, tid);
   }
   if (tid < Cp) SC1[tid] = sc_v1;
-  LaneOff<D> lo;
+  typename LaneOffSel<D>::type lo;
   lo.init(lane);
   __syncthreads();
 
@@ -683,7 +702,7 @@ __global__ __launch_bounds__(256, 3) void lara_fin_kernel(const LaraP p) {
         f32x4 tt = {0.f, 0.f, 0.f, 0.f};
         const int row = ct * 16 + li;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) tt = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt);
+        for (int ks = 0; ks < KS; ++ks) tt = E::mma(as_x8<E>(lds16(R2 + TileL<D>::off(row, g * KS + ks))), f1[ks], tt);
         const float4 ls = *reinterpret_cast<const float4*>(SC1 + ct * 16 + 4 * g);
         w1[ct][0] = fast_exp2(tt[0] * p.scale_log2 - ls.x); w1[ct][1] = fast_exp2(tt[1] * p.scale_log2 - ls.y);
         w1[ct][2] = fast_exp2(tt[2] * p.scale_log2 - ls.z); w1[ct][3] = fast_exp2(tt[3] * p.scale_log2 - ls.w);
@@ -700,6 +719,16 @@ __global__ __launch_bounds__(256, 3) void lara_fin_kernel(const LaraP p) {
         }
       }
     }
+    // correction rows in the contiguous ownership (channel DQ g + j) of the dq / dk rows this lane updates
+    float cr[DQ];
+    if constexpr (TileL<D>::NEWTR) {
+      quad_transpose_f32(acc, cr);
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cr[4 * dt + r] = acc[dt][r];
+    }
     if (!valid) continue;
     int chunk = 0;
     if (pool) {
@@ -713,10 +742,7 @@ __global__ __launch_bounds__(256, 3) void lara_fin_kernel(const LaraP p) {
       float old[8];
       unpack8<E>(oq[c], old);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int j = 8 * c + i;
-        old[i] -= acc[j >> 2][j & 3] * p.scale;
-      }
+      for (int i = 0; i < 8; ++i) old[i] -= cr[8 * c + i] * p.scale;
       if (pool) {
         const float4 a0 = *reinterpret_cast<const float4*>(pq + 8 * c), a1 = *reinterpret_cast<const float4*>(pq + 8 * c + 4);
         old[0] += a0.x * p.pool_inv; old[1] += a0.y * p.pool_inv; old[2] += a0.z * p.pool_inv; old[3] += a0.w * p.pool_inv;
@@ -781,21 +807,24 @@ template <typename E, int D, int NCT>
 static int launch_f(int which, LaraP& p, hipStream_t st) {
   const size_t lds = lara_f_lds(which, D, NCT * 16);
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
-  static int occ[3] = {0, 0, 0};            // resident workgroups per CU of the three instantiations
-#define EA_LF(K)                                                                                      \
+  static int occ[4] = {0, 0, 0, 0};         // resident workgroups per CU of the instantiations
+#define EA_LF(K, slot, ...)                                                                           \
   do {                                                                                                \
     if (lds > 64 * 1024) {                                                                            \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K<E, D, NCT>),                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K<__VA_ARGS__>),              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
       if (e != hipSuccess) return (int)e;                                                             \
     }                                                                                                 \
-    if (!occ[which]) occ[which] = f_occupancy(&K<E, D, NCT>, lds);                                    \
-    lara_f_plan(p, occ[which] * f_device_cus());                                                      \
-    hipLaunchKernelGGL((K<E, D, NCT>), grid, block, lds, st, p);                                      \
+    if (!occ[slot]) occ[slot] = f_occupancy(&K<__VA_ARGS__>, lds);                                    \
+    lara_f_plan(p, occ[slot] * f_device_cus());                                                       \
+    hipLaunchKernelGGL((K<__VA_ARGS__>), grid, block, lds, st, p);                                    \
   } while (0)
-  if (which == 0) EA_LF(lara_fq_kernel);
-  else if (which == 1) EA_LF(lara_fk_kernel);
-  else EA_LF(lara_fin_kernel);
+  if (which == 0) {
+    // r-pairs of the last landmark tile that can be populated (see lara_fq_kernel)
+    if (p.C - 16 * (NCT - 1) <= 2) EA_LF(lara_fq_kernel, 0, E, D, NCT, 1);
+    else EA_LF(lara_fq_kernel, 3, E, D, NCT, 2);
+  } else if (which == 1) EA_LF(lara_fk_kernel, 1, E, D, NCT);
+  else EA_LF(lara_fin_kernel, 2, E, D, NCT);
 #undef EA_LF
   return (int)hipGetLastError();
 }

@@ -299,6 +299,11 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       const float inv = fast_rcp(ssum);
       if (MODE == LX_FWD) {
         pden = inv;                                       // normalisation folded into the output scale
+        if (p.lseZ && valid && g == 0) {                  // kept for the fused backward (ea_lara_bwd_q_fused)
+          const size_t o = (size_t)bh * p.N + tok;
+          p.lseZ[o] = mx + fast_log2(ssum);
+          p.tmean[o] = tmean;
+        }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           w1[ct][0] = wv[ct][0][0]; w1[ct][1] = wv[ct][0][1];

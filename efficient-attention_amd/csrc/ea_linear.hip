@@ -29,6 +29,7 @@ struct LinP {
   char* y;              // [rows, NO] element type or fp32, row stride ldy elements
   char* a_cast;         // [rows, K] element type copy of a (fp32 input only) or null
   int rows, NO, nsplit, wg_per_part, y_f32;
+  int w_mode;           // 0: w is [NO, K] in the element type; 1: fp32 [NO, K]; 2: fp32 [K, NO] (the transposed product)
   long lda, ldy;
 };
 
@@ -73,16 +74,57 @@ __global__ __launch_bounds__((NPR > 8 ? 512 : 256), (NPR > 8 ? 1 : 2)) void lin_
     float* sb = reinterpret_cast<float*>(smem + nop * ROWB);         // this part's bias, rounded to the element type
     for (int i = tid; i < nop; i += NT) sb[i] = p.bias ? E::to_f(E::from_f(p.bias[n0 + i])) : 0.f;
     const int total = nop * CPR;
-    const char* wsrc = p.w + (size_t)n0 * K * 2;
-    for (int base = 0; base < total; base += 8 * NT) {
-      u32x4 wv[8];
+    if (p.w_mode == 0) {
+      const char* wsrc = p.w + (size_t)n0 * K * 2;
+      for (int base = 0; base < total; base += 8 * NT) {
+        u32x4 wv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = ldg16(wsrc + (size_t)min(base + u * NT + tid, total - 1) * 16);
+        for (int u = 0; u < 8; ++u) wv[u] = ldg16(wsrc + (size_t)min(base + u * NT + tid, total - 1) * 16);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * NT + tid;
-        const int row = idx / CPR, c = idx - row * CPR;
-        if (idx < total) sts16(smem + row * ROWB + ((c ^ wswz(row)) << 4), wv[u]);
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * NT + tid;
+          const int row = idx / CPR, c = idx - row * CPR;
+          if (idx < total) sts16(smem + row * ROWB + ((c ^ wswz(row)) << 4), wv[u]);
+        }
+      }
+    } else if (p.w_mode == 1) {
+      // fp32 master weight, rounded on the way in (the autocast cast of the weight folded into the staging)
+      const float* wsrc = reinterpret_cast<const float*>(p.w) + (size_t)n0 * K;
+      for (int base = 0; base < total; base += 4 * NT) {
+        f32x4 wv[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* s8 = wsrc + (size_t)min(base + u * NT + tid, total - 1) * 8;
+          wv[u][0] = *reinterpret_cast<const f32x4*>(s8);
+          wv[u][1] = *reinterpret_cast<const f32x4*>(s8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * NT + tid;
+          const int row = idx / CPR, c = idx - row * CPR;
+          const float f[8] = {wv[u][0][0], wv[u][0][1], wv[u][0][2], wv[u][0][3], wv[u][1][0], wv[u][1][1], wv[u][1][2], wv[u][1][3]};
+          if (idx < total) sts16(smem + row * ROWB + ((c ^ wswz(row)) << 4), pack8<E>(f));
+        }
+      }
+    } else {
+      // fp32 source [K, NO]: row o of the staged part is COLUMN n0 + o of the source (dX = dY W without a transposed
+      // copy of W).  Adjacent lanes take adjacent columns, so the eight 4-byte loads of a chunk are coalesced.
+      const float* wsrc = reinterpret_cast<const float*>(p.w) + n0;
+      for (int base = 0; base < total; base += 4 * NT) {
+        float wv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = min(base + u * NT + tid, total - 1);
+          const int c = idx / nop, row = idx - c * nop;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wv[u][i] = wsrc[(size_t)(8 * c + i) * p.NO + row];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * NT + tid;
+          const int c = idx / nop, row = idx - c * nop;
+          if (idx < total) sts16(smem + row * ROWB + ((c ^ wswz(row)) << 4), pack8<E>(wv[u]));
+        }
       }
     }
   }
@@ -159,16 +201,7 @@ __global__ __launch_bounds__((NPR > 8 ? 512 : 256), (NPR > 8 ? 1 : 2)) void lin_
   }
 }
 
-static int lin_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+static int lin_cus() { return ea_device_cus(); }
 
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
@@ -181,13 +214,7 @@ constexpr int LIN_LDS_MAX = 72 * 1024, LIN_LDS_MAX1 = 112 * 1024;
 template <typename E, int KT, int RT, bool AF32, int NPR, bool YF32>
 static int launch_lin1(const LinP& p, hipStream_t st) {
   const size_t lds = (size_t)(NPR * 32) * (KT * 64 + 4);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<E, KT, RT, AF32, NPR, YF32>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (NPR > 8 ? LIN_LDS_MAX1 : LIN_LDS_MAX) + 2048);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  EA_SET_LDS_ONCE((&lin_kernel<E, KT, RT, AF32, NPR, YF32>), (NPR > 8 ? LIN_LDS_MAX1 : LIN_LDS_MAX) + 2048);
   const dim3 grid((unsigned)(p.wg_per_part * p.nsplit)), block(NPR > 8 ? 512 : 256);
   hipLaunchKernelGGL((lin_kernel<E, KT, RT, AF32, NPR, YF32>), grid, block, lds, st, p);
   return (int)hipGetLastError();
@@ -243,14 +270,14 @@ static int lin_by_k(const LinP& p, int K, hipStream_t st) {
   }
 }
 
-int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, const float* bias, void* y, int y_f32,
+int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st) {
   if (!linear_supported(K, NO)) return EA_E_UNSUPPORTED;
   if (rows <= 0) return EA_OK;
   LinP p;
   p.a = (const char*)a; p.w = (const char*)w; p.bias = bias; p.y = (char*)y;
   p.a_cast = a_f32 ? (char*)a_cast : nullptr;
-  p.rows = rows; p.NO = NO; p.y_f32 = y_f32; p.lda = lda; p.ldy = ldy;
+  p.rows = rows; p.NO = NO; p.y_f32 = y_f32; p.w_mode = w_mode; p.lda = lda; p.ldy = ldy;
   p.nsplit = lin_nsplit(K, NO);
   // two resident workgroups per CU in total, a multiple of 8 per part (one XCD each), no more than there are tiles
   static const int per_cu_env = env_int("EA_LIN_PER_CU", 0);

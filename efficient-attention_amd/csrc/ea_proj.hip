@@ -66,11 +66,15 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const uint16_t* __rest
 // stage 2 / generic fp32 column sum: out[c] = sum_r x[r][c] (fixed order).  A block owns 16 columns
 // (64-B row segments), 64 row-lanes per column; the partials are L2-resident, so what matters is
 // having every load of a thread in flight at once.
+// (blocks >= nb1 work on the second matrix x2 / out2 / cols2: two column sums over the same rows in ONE launch)
 __global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                           int rows, int cols) {
+                                                           int rows, int cols, int nb1, const float* __restrict__ x2,
+                                                           float* __restrict__ out2, int cols2) {
   __shared__ float red[64][17];
   const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  int blk = blockIdx.x;
+  if (blk >= nb1) { blk -= nb1; x = x2; out = out2; cols = cols2; }       // (uniform per block)
+  const int c = blk * 16 + cl;
   float s = 0.f;
   if (c < cols) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -86,11 +90,11 @@ __global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restric
   }
   red[rl][cl] = s;
   __syncthreads();
-  if (tid < 16 && blockIdx.x * 16 + tid < cols) {
+  if (tid < 16 && blk * 16 + tid < cols) {
     float t = 0.f;
 #pragma unroll
     for (int j = 0; j < 64; ++j) t += red[j][tid];
-    out[blockIdx.x * 16 + tid] = t;
+    out[blk * 16 + tid] = t;
   }
 }
 
@@ -137,13 +141,15 @@ int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows,
     else
       return EA_E_BADARG;
   }
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, part, out, nblk, cols);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, part, out, nblk, cols, (cols + 15) / 16,
+                     (const float*)nullptr, (float*)nullptr, 0);
   return (int)hipGetLastError();
 }
 
-int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, hipStream_t st) {
-  if (rows <= 0 || cols <= 0) return EA_E_BADARG;
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(1024), 0, st, x, out, rows, cols);
+int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, const float* x2, float* out2, int cols2, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || cols2 < 0) return EA_E_BADARG;
+  const int nb1 = (cols + 15) / 16, nb2 = x2 ? (cols2 + 15) / 16 : 0;
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(nb1 + nb2), dim3(1024), 0, st, x, out, rows, cols, nb1, x2, out2, cols2);
   return (int)hipGetLastError();
 }
 

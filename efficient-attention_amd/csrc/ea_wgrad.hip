@@ -221,16 +221,7 @@ int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipS
   return (int)hipGetLastError();
 }
 
-static int wg_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+static int wg_cus() { return ea_device_cus(); }
 
 static int wg_bt(int M) { return M % 192 == 0 ? 192 : (M % 128 == 0 ? 128 : 64); }
 
@@ -248,13 +239,7 @@ int wgrad_slices(int rows, int M, int K) {
 template <typename E, int BM, int BN>
 static int launch_wg(const WgP& p, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM / 64 + BN / 64) * 64 * 128;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<E, BM, BN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (lds > 64 * 1024) EA_SET_LDS_ONCE((&wgrad_kernel<E, BM, BN>), lds);
   const int T = p.tiles_m * p.tiles_n;
   const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * T)), block(512);
   hipLaunchKernelGGL((wgrad_kernel<E, BM, BN>), grid, block, lds, st, p);

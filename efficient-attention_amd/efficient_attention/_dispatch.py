@@ -12,7 +12,8 @@ implementation (no fallback).  The autograd Functions of _ops.py are thin shells
     ea::eva_fwd / eva_bwd                eva.py:145-227 (and causal_eva.py:666-788)
     ea::lara_fwd / lara_bwd              lara.py:129-175,187-246 (2-D pooled proposals)
     ea::performer_fwd / performer_bwd    kernelized_attention.py:20-56,116-121
-    ea::linear                           abstract_attention.py:72-78,86-87 (qkv / output projection, streaming kernel)
+    ea::linear / linear_w32              abstract_attention.py:72-78,86-87 (qkv / output projection, streaming kernel;
+                                         _w32: straight from the fp32 master weight)
 """
 import torch
 
@@ -37,6 +38,7 @@ _SCHEMAS = {
     "eva_bwd": "(Tensor dout, Tensor qkv, Tensor? mask, Tensor? keep, Tensor? noise, Tensor out, Tensor[] saved, int[] icfg, float[] fcfg, "
                "str adaptive_proj, int bias_cols, Tensor[] params) -> Tensor[]",
     "linear": "(Tensor a, Tensor w, Tensor? bias, bool y_f32, bool want_cast) -> Tensor[]",
+    "linear_w32": "(Tensor a, Tensor w32, Tensor? bias, int elem, bool transposed, bool y_f32, bool want_cast) -> Tensor[]",
 }
 _IMPLS = {
     "softmax_fwd": _ops.softmax_fwd_impl, "softmax_bwd": _ops.softmax_bwd_impl,
@@ -44,7 +46,7 @@ _IMPLS = {
     "performer_fwd": _ops.performer_fwd_impl, "performer_bwd": _ops.performer_bwd_impl,
     "lara_fwd": _ops.lara_fwd_impl, "lara_bwd": _ops.lara_bwd_impl,
     "eva_fwd": _ops.eva_fwd_impl, "eva_bwd": _ops.eva_bwd_impl,
-    "linear": _ops.linear_impl,
+    "linear": _ops.linear_impl, "linear_w32": _ops.linear_w32_impl,
 }
 def _no_cpu(*args, **kwargs):
     _ops.nv.require_cuda(None, "every tensor of torch.ops.ea.*")       # raises: the cores have no CPU fallback
@@ -68,6 +70,14 @@ def _none(like):
 def _(a, w, bias, y_f32, want_cast):
     y = a.new_empty((a.shape[0], w.shape[0]), dtype=torch.float32 if y_f32 else w.dtype)
     ac = a.new_empty(a.shape if (want_cast and a.dtype == torch.float32) else (0,), dtype=w.dtype)
+    return [y, ac]
+
+
+@torch.library.register_fake("ea::linear_w32")
+def _(a, w32, bias, elem, transposed, y_f32, want_cast):
+    dt = _ops._ELEM_DT[int(elem)]
+    y = a.new_empty((a.shape[0], w32.shape[1] if transposed else w32.shape[0]), dtype=torch.float32 if y_f32 else dt)
+    ac = a.new_empty(a.shape if (want_cast and a.dtype == torch.float32) else (0,), dtype=dt)
     return [y, ac]
 
 
@@ -117,7 +127,8 @@ def _(qkv, mask, noise, icfg, fcfg, params):
     return [qkv.new_empty((B, N, h, d)), _f32(qkv, BH, C, d), _f32(qkv, BH, C, d) if mis != 2 else _none(qkv),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, C), _f32(qkv, BH, C, d), _f32(qkv, BH, C),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, L, d), _f32(qkv, BH, L, d),
-            _f32(qkv, BH * (3 * L * d + L * 64 + 128)) if (len(icfg) < 8 or icfg[7]) else _none(qkv)]
+            _f32(qkv, BH * (3 * L * d + L * 64 + 128)) if (len(icfg) < 8 or icfg[7]) else _none(qkv),
+            _f32(qkv, 2, BH, N) if ((len(icfg) < 8 or icfg[7]) and C <= 64) else _none(qkv)]
 
 
 @torch.library.register_fake("ea::lara_bwd")

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 3          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 4          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -89,19 +89,20 @@ SIGNATURES = {
     "ea_bias_grad_parts": [_I, _I],
     "ea_bias_grad": [_I, _I, _I, _P, _P, _P, _P],
     "ea_colsum_f32": [_I, _I, _P, _P, _P],
+    "ea_colsum2_f32": [_I, _I, _P, _P, _I, _P, _P, _P],
     "ea_slice_sum": [_I, _I, _I, _F, _P, _P, _P, _P],
     "ea_lara_segment_fwd": [_G, _T, _T] + [_P] * 12,
     "ea_lara_segment_bwd": [_G, _T, _T] + [_P] * 11 + [_T, _T, _P, _P],
     "ea_lara_parts": [_LG],
     "ea_lara_stats_fwd": [_LG, _T, _T, _T, _P, _P, _P, _P, _P, _P],
-    "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P],
+    "ea_lara_out_fwd": [_LG, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P],
     "ea_lara_bwd_q": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P],
     "ea_lara_bwd_qstats": [_LG, _T, _T] + [_P] * 16,
     "ea_lara_bwd_k": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_lara_bwd_kstats": [_LG, _T, _T] + [_P] * 8,
     "ea_lara_bwd_qcorr": [_LG, _T, _P, _P, _P, _T, _P],
     "ea_lara_fused_parts": [_LG],
-    "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
+    "ea_lara_bwd_q_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_lara_bwd_k_fused": [_LG, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P],
     "ea_lara_bwd_finish": [_LG, _T, _P, _P, _P, _P, _P, _I, _I, _I, _T, _T, _P],
     "ea_lara_sample_fwd": [_I, _I, _I, _I, _I, _I, _F] + [_P] * 8,
@@ -111,6 +112,7 @@ SIGNATURES = {
     "ea_gather_sum": [_I, _I, _I, _P, _P, _P, _P],
     "ea_linear_supported": [_I, _I],
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
+    "ea_linear_w32": [_I, _I, _I, _I, _P, _I, _L, _P, _I, _P, _P, _I, _L, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_part_sum": [_I, _I, _L, _P, _P, _P],

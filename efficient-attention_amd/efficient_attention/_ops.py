@@ -102,21 +102,52 @@ def _mask_u8(mask, B, N, device):
 _LOG2E = 1.4426950408889634
 
 class DerivedCache:
-    """Derived weights (concatenations / products of parameters) re-used while nothing can have changed:
-    only when autograd is off (a cached tensor carries no graph) and no hipGraph is being captured (a
-    capture must record the producing kernels, or its replays would see stale values after an in-graph
-    optimizer step).  Keyed on the identity and `_version` of every source tensor."""
+    """Derived weights (concatenations / products of parameters) re-used across calls of an EVALUATION-mode
+    module: never while the owner is training, autograd is on (a cached tensor carries no graph) or a
+    hipGraph is being captured (a capture must record the producing kernels, or its replays would see
+    stale values after an in-graph optimizer step).  `_version` is not a change detector -- optimizers
+    that update through `.data` (fairseq's Adam / FP16 optimizers, `p.data.copy_()`) never bump it -- so
+    the owner drops the cache on every `train()` call and on `load_state_dict` (`DerivedCacheOwner`);
+    the key (identity, storage pointer, `_version`, device, dtype of every source) only catches
+    re-assigned parameters on top of that."""
 
     def __init__(self):
         self.key, self.value = None, None
 
-    def get(self, sources, build):
-        if torch.is_grad_enabled() or (sources[0].is_cuda and torch.cuda.is_current_stream_capturing()):
+    def invalidate(self):
+        self.key, self.value = None, None
+
+    def get(self, owner, sources, build):
+        if (owner.training or torch.is_grad_enabled()
+                or (sources[0].is_cuda and torch.cuda.is_current_stream_capturing())):
+            self.invalidate()
             return build()
-        key = tuple((id(t), t._version, t.device, t.dtype) for t in sources if t is not None)
+        key = tuple((id(t), t.data_ptr(), t._version, t.device, t.dtype) for t in sources if t is not None)
         if key != self.key:
             self.key, self.value = key, build()
         return self.value
+
+
+class DerivedCacheOwner:
+    """Mixin for modules holding DerivedCache attributes: every mode switch and every state-dict load
+    drops them (an optimizer step between two validation passes always sits between two `train()` calls)."""
+
+    def _drop_derived(self):
+        for v in list(vars(self).values()):
+            if isinstance(v, DerivedCache):
+                v.invalidate()
+
+    def train(self, mode=True):
+        self._drop_derived()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._drop_derived()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def invalidate_derived_weights(self):
+        """Call after writing parameters in place (through `.data`) while the module stays in eval mode."""
+        self._drop_derived()
 
 
 _FP32_WARNED = [False]
@@ -411,8 +442,8 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
                 None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
         nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
                 nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
-        dWs = colsum_f32(dW.view(lg.BH, -1)).view(2, d, d)
-        dvs = colsum_f32(dvec.view(lg.BH, -1)).view(2, 3, d)
+        dWs, dvs = colsum2_f32(dW.view(lg.BH, -1), dvec.view(lg.BH, -1))
+        dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
         raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
         return [dqkv5, _e(dbias, lse)] + raw
     # mu networks backward (ea_rows_mlp_bwd): dz, dx = d(chunk means), per-workgroup dW partials
@@ -636,7 +667,7 @@ class AdaptivePoolFn(torch.autograd.Function):
         return (buf if own else None), None, None, None, None, None
 
 
-def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c):
+def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c, want_tokst=True):
     """Estimator forward (ea_lara_stats_fwd -> ea_lara_merge_fwd -> ea_lara_out_fwd) on contiguous fp32
     landmark tensors [BH,C,d] / [BH,C].  Returns out [B,N,h,d] and (cst, kv, lse_k, lse_t)."""
     B, N, _, h, d = qkv5.shape
@@ -658,12 +689,15 @@ def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c):
             nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
     out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
     to = nv.t4(out.permute(0, 2, 1, 3))
+    # per-token softmax statistics (lse_Z in log2 units, mean_c t) for the fused backward: 8 bytes per token-head
+    tokst = torch.empty((2, BH, N), dtype=torch.float32, device=dev) if (want_tokst and C <= 64) else None
     nv.call("ea_lara_out_fwd", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c),
-            nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to), nv.stream())
-    return out, (cst, kv, lse_k, lse_t)
+            nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to),
+            nv.ptr(tokst), None if tokst is None else nv.ptr(tokst[1]), nv.stream())
+    return out, (cst, kv, lse_k, lse_t, tokst)
 
 
-def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, lse_k, lse_t):
+def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, lse_k, lse_t, tokst):
     """Estimator backward up to (not including) the softmax-over-sequence correction of dq.
     Writes dq (uncorrected), dk, dv into dqkv5; returns d_omega [BH,C,d], d_qbar, d_bhv, d_lp and uq
     (the u_c q_bar_c rows of the correction, mis-opt only).
@@ -686,8 +720,11 @@ def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, 
     p_ml = torch.empty((BH, S, C, 4), dtype=torch.float32, device=dev)
     p_acc = torch.empty((4, BH, S, C, d), dtype=torch.float32, device=dev)
     if fused:
+        if tokst is None:
+            raise RuntimeError("ea_lara_bwd_q_fused needs the forward's per-token statistics (lse_Z, mean t)")
         nv.call("ea_lara_bwd_q_fused", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(omega),
-                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), ctypes.byref(tdq),
+                nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv), nv.ptr(cst), nv.ptr(tokst[0]), nv.ptr(tokst[1]),
+                ctypes.byref(tdq),
                 nv.ptr(p_ml), nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.stream())
     else:
         tok = torch.empty((4, BH, N), dtype=torch.float32, device=dev)
@@ -769,22 +806,22 @@ class LaraAttnFn(torch.autograd.Function):
         qbar_c = None if qbar is None else qbar.float().reshape(BH, C, d).contiguous()
         lp_c = lp.reshape(BH, C).float().contiguous()
         bhv_c = None if bhv is None else bhv.reshape(BH, C).float().contiguous()
-        out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c)
-        ctx.save_for_backward(qkv5, mask_u8, omega, qbar_c, bhv_c, cst, kv, lse_k, lse_t)
+        out, (cst, kv, lse_k, lse_t, tokst) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c)
+        ctx.save_for_backward(qkv5, mask_u8, omega, qbar_c, bhv_c, cst, kv, lse_k, lse_t, tokst)
         ctx.geom = geom
         ctx.has = (qbar is not None, bhv is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv5, mask_u8, omega, qbar, bhv, cst, kv, lse_k, lse_t = ctx.saved_tensors
+        qkv5, mask_u8, omega, qbar, bhv, cst, kv, lse_k, lse_t, tokst = ctx.saved_tensors
         geom = ctx.geom
         B, N, _, h, d = qkv5.shape
         C = geom.C
         dout = dout.contiguous()
         dqkv5 = torch.empty_like(qkv5)
         d_omega, d_qbar, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv,
-                                                          cst, kv, lse_k, lse_t)
+                                                          cst, kv, lse_k, lse_t, tokst)
         _lara_finish(geom, qkv5, dqkv5, qbar, uq, lse_t)
         has_qbar, has_bhv = ctx.has
         if ctx.slot is not None:
@@ -812,7 +849,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
     """torch.ops.ea.lara_fwd: uniform r x r pooling of q, k -> fused landmark pipeline -> estimator.
     icfg = [H, W, r, has_mlp, mixed, mis, dup(, keep_for_backward = 1)], fcfg = [kappa, scale], params = (Wq,
     bq, gq, cq, Wk, bk, gk, ck) when has_mlp.  -> [out, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise, lmk_saved]
-    (absent tensors are empty)."""
+    (absent tensors are empty; the list ends with tokst [2,BH,N], the per-token statistics of the fused backward)."""
     nv.require_cuda(qkv5, "qkv")
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
     need_grad = len(icfg) < 8 or bool(icfg[7])
@@ -836,15 +873,15 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
     saved = _lmk_saved(lg, dev) if need_grad else None
     nv.call("ea_lara_landmarks_fwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
             nv.ptr(omega), nv.ptr(qrows), nv.ptr(bhv), nv.ptr(lp), nv.ptr(saved), nv.stream())
-    out, (cst, kv, lse_k, lse_t) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp)
+    out, (cst, kv, lse_k, lse_t, tokst) = _lara_fwd_core(geom, qkv5, mask_u8, omega, qrows, bhv, lp, need_grad)
     e = lp
-    return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(saved, e)]
+    return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(saved, e), _e(tokst, e)]
 
 
 def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
     """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)]."""
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
-    omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, saved = [_opt(t) for t in saved_list]
+    omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, saved, tokst = [_opt(t) for t in saved_list]
     noise_c = None if noise is None else noise.float().contiguous()
     B, N, _, h, d = qkv5.shape
     BH, dev = B * h, qkv5.device
@@ -852,7 +889,7 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
     dout = dout.contiguous()
     dqkv5 = torch.empty_like(qkv5)
     d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
-                                                       cst, kv, lse_k, lse_t)
+                                                       cst, kv, lse_k, lse_t, tokst)
     dpq = torch.empty_like(pq)
     dpk = torch.empty_like(pk)
     dW = dvec = None
@@ -866,7 +903,8 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
     _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
     grads = [dqkv5]
     if has_mlp:
-        dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
+        dWs, dvs = colsum2_f32(dW.view(BH, -1), dvec.view(BH, -1))
+        dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
         grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
     return grads
 
@@ -980,7 +1018,8 @@ class LaraLandmarkFn(torch.autograd.Function):
                     nv.ptr(dW), nv.ptr(dvec), nv.ptr(d_cb), nv.ptr(ctx.lmk_saved), nv.stream())
         pgrads = []
         if geom.has_mlp:
-            dWs, dvs = colsum_f32(dW.view(BH, -1)).view(2, d, d), colsum_f32(dvec.view(BH, -1)).view(2, 3, d)
+            dWs, dvs = colsum2_f32(dW.view(BH, -1), dvec.view(BH, -1))
+            dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
             raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
             pgrads = [g.to(dt) for g, dt in zip(raw, ctx.pdtypes)]
         return (dpq, dpk, None, d_cb, None) + tuple(pgrads)
@@ -1375,6 +1414,16 @@ def colsum_f32(x2):
     return out
 
 
+def colsum2_f32(x1, x2):
+    """(x1.sum(0), x2.sum(0)) of two contiguous fp32 [rows, *] tensors with the same rows, ONE launch."""
+    rows, c1 = x1.shape
+    c2 = x2.shape[1]
+    out = torch.empty(c1 + c2, dtype=torch.float32, device=x1.device)
+    nv.call_as("ea_colsum_f32", "ea_colsum2_f32", rows, c1, nv.ptr(x1), nv.ptr(out), c2, nv.ptr(x2),
+               ctypes.c_void_p(out.data_ptr() + 4 * c1), nv.stream())
+    return out[:c1], out[c1:]
+
+
 def bias_grad(dy2):
     """db = dY.sum(0) in fp32 through ea_bias_grad (dY: contiguous [rows, cols] bf16/fp16)."""
     rows, cols = dy2.shape
@@ -1428,11 +1477,16 @@ def _lin_geometry(K, NO):
     return False
 
 
-def ea_linear_supported(a2, w):
-    """ea_linear: a [rows, in] (row-contiguous, bf16 / fp16 / fp32), w [out, in] contiguous in the 16-bit dtype."""
+def _lin_rows_ok(a2, wdtype):
+    """Activation-side requirements of ea_linear: row-contiguous [rows, in], 16-byte aligned rows, bf16 / fp16 / fp32."""
     return (USE_EA_LINEAR and a2.is_cuda and a2.dim() == 2 and a2.stride(1) == 1 and a2.stride(0) % 8 == 0
             and a2.shape[0] > 0 and (a2.storage_offset() * a2.element_size()) % 16 == 0
-            and w.dtype in _ELEM and w.is_contiguous() and a2.dtype in (w.dtype, torch.float32)
+            and a2.dtype in (wdtype, torch.float32))
+
+
+def ea_linear_supported(a2, w):
+    """ea_linear: a [rows, in] (row-contiguous, bf16 / fp16 / fp32), w [out, in] contiguous in the 16-bit dtype."""
+    return (w.dtype in _ELEM and w.is_contiguous() and _lin_rows_ok(a2, w.dtype)
             and _lin_geometry(w.shape[1], w.shape[0]))
 
 
@@ -1443,20 +1497,46 @@ def linear_impl(a2, w, bias32, y_f32, want_cast):
     return [y, ac if ac is not None else a2.new_empty(0, dtype=w.dtype)]
 
 
-def ea_linear(a2, w, bias32, out_dtype, want_cast=False):
-    """y = a2 @ w.T (+ bias) by the streaming projection kernel (ea_linear.hip); fp32 `a2` is rounded to w.dtype on
-    the way in and, with want_cast, that rounded copy is returned as well."""
+_ELEM_DT = [torch.bfloat16, torch.float16]
+
+
+def linear_w32_impl(a2, w32, bias32, elem, transposed, y_f32, want_cast):
+    """torch.ops.ea.linear_w32: the same product from the fp32 master weight (rounded while it is staged, no cast
+    kernel); transposed: w32 is [in, out] and y = a2 @ w32 (the input gradient of the layer w32 belongs to)."""
+    nv.require_cuda(a2, "a")
+    dt = _ELEM_DT[int(elem)]
+    y, ac = ea_linear(a2, w32, bias32, torch.float32 if y_f32 else dt, want_cast, elem_dtype=dt, transposed=bool(transposed))
+    return [y, ac if ac is not None else a2.new_empty(0, dtype=dt)]
+
+
+def ea_linear_w32_supported(a2, w32, dtype, transposed=False):
+    """ea_linear_w32: fp32 contiguous weight, the 16-bit compute dtype `dtype`, activations as for ea_linear."""
+    K, NO = (w32.shape[0], w32.shape[1]) if transposed else (w32.shape[1], w32.shape[0])
+    return (dtype in _ELEM and w32.dtype == torch.float32 and w32.is_contiguous() and w32.dim() == 2
+            and (w32.storage_offset() * 4) % 16 == 0 and _lin_rows_ok(a2, dtype) and a2.shape[1] == K and _lin_geometry(K, NO))
+
+
+def ea_linear(a2, w, bias32, out_dtype, want_cast=False, elem_dtype=None, transposed=False):
+    """y = a2 @ w.T (+ bias) by the streaming projection kernel (ea_linear.hip); fp32 `a2` is rounded to the compute
+    dtype on the way in and, with want_cast, that rounded copy is returned as well.  With elem_dtype given, `w` is the
+    fp32 master weight ([out, in], or [in, out] with transposed) and is rounded while it is staged (ea_linear_w32)."""
     rows, K = a2.shape
-    NO = w.shape[0]
+    w32 = elem_dtype is not None
+    cdt = elem_dtype if w32 else w.dtype
+    NO = w.shape[1] if (w32 and transposed) else w.shape[0]
     y = torch.empty((rows, NO), dtype=out_dtype, device=a2.device)
     a_f32 = a2.dtype == torch.float32
-    a_cast = torch.empty((rows, K), dtype=w.dtype, device=a2.device) if (a_f32 and want_cast) else None
+    a_cast = torch.empty((rows, K), dtype=cdt, device=a2.device) if (a_f32 and want_cast) else None
     label = "ea_linear (fp32 in)" if a_f32 else "ea_linear"
     if nv.KERNEL_TIMER.enabled:
         # what the launch has to move: activations in, result out, the rounded copy when asked for (the weight is noise)
         LABEL_ALGO_BYTES[label] = rows * (K * a2.element_size() + NO * y.element_size() + (K * 2 if a_cast is not None else 0))
-    nv.call_as(label, "ea_linear", _ELEM[w.dtype], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w), nv.ptr(bias32),
-               nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
+    if w32:
+        nv.call_as(label, "ea_linear_w32", _ELEM[cdt], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w),
+                   int(transposed), nv.ptr(bias32), nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
+    else:
+        nv.call_as(label, "ea_linear", _ELEM[cdt], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w), nv.ptr(bias32),
+                   nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
     return y, a_cast
 
 
@@ -1505,37 +1585,55 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, dtype):
         x2 = x.reshape(-1, x.shape[-1])
-        wl = weight if weight.dtype == dtype else weight.to(dtype)
-        if ea_linear_supported(x2, wl):
-            # streaming projection kernel: an fp32 x is rounded on the way in (no cast pass), its rounded copy comes
-            # back only when the weight gradient will need it
-            b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
-            want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
-            y, xc = torch.ops.ea.linear(x2, wl, b32, False, want)
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+        if weight.dtype == torch.float32 and dtype != torch.float32 and ea_linear_w32_supported(x2, weight, dtype):
+            # streaming projection kernel fed by the fp32 MASTER weight: both autocast casts (of x and of the weight) are
+            # folded into the kernel's loads -- no cast kernels in a training step
+            y, xc = torch.ops.ea.linear_w32(x2, weight, b32, _ELEM[dtype], False, False, want)
             xl = x2 if x2.dtype == dtype else (xc if want else None)
+            wl = weight
         else:
-            xl = x2 if x2.dtype == dtype else x2.to(dtype)
-            bl = None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype))
-            y = F.linear(xl, wl, bl)
+            wl = weight if weight.dtype == dtype else weight.to(dtype)
+            if ea_linear_supported(x2, wl):
+                # an fp32 x is rounded on the way in (no cast pass), its rounded copy comes back only when the weight
+                # gradient will need it
+                y, xc = torch.ops.ea.linear(x2, wl, b32, False, want)
+                xl = x2 if x2.dtype == dtype else (xc if want else None)
+            else:
+                xl = x2 if x2.dtype == dtype else x2.to(dtype)
+                bl = None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype))
+                y = F.linear(xl, wl, bl)
         ctx.save_for_backward(xl, wl)
-        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, dtype)
         return y.view(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
         xl, wl = ctx.saved_tensors
-        xshape, xdtype, wdtype, bdtype = ctx.meta
+        xshape, xdtype, wdtype, bdtype, cdtype = ctx.meta
         dy2 = dy.reshape(-1, dy.shape[-1])
-        if dy2.dtype != xl.dtype:
-            dy2 = dy2.to(xl.dtype)
+        if dy2.dtype != cdtype:
+            dy2 = dy2.to(cdtype)           # (xl is None when the weight is frozen and x arrived in fp32)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if wl.shape[0] <= 256 and xdtype in (torch.float32, wl.dtype) and ea_linear_supported(dy2, wl):
-                # dX = dY W as the same streaming kernel on the transposed weight (a [in, out] copy of <= 128 KB)
-                dx = torch.ops.ea.linear(dy2, wl.t().contiguous(), None, xdtype == torch.float32, False)[0].view(xshape)
+            y_f32 = xdtype == torch.float32
+            if (wl.dtype == torch.float32 and cdtype != torch.float32 and xdtype in (torch.float32, cdtype)
+                    and ea_linear_w32_supported(dy2, wl, cdtype, transposed=True)):
+                # dX = dY W straight from the master weight [out, in] read as the transposed operand: no W^T copy, no cast
+                dx = torch.ops.ea.linear_w32(dy2, wl, None, _ELEM[cdtype], True, y_f32, False)[0].view(xshape)
             else:
-                dx = _mm_out(dy2, wl, xdtype).view(xshape)
+                wc = wl if wl.dtype == cdtype else wl.to(cdtype)
+                # the launch is y = dY (W^T)^T: the geometry to validate is K = out, NO = in of the forward weight
+                if (xdtype in (torch.float32, wc.dtype) and wc.dtype in _ELEM and _lin_geometry(wc.shape[0], wc.shape[1])
+                        and _lin_rows_ok(dy2, wc.dtype)):
+                    # dX = dY W as the same streaming kernel on the transposed weight (a [in, out] copy of <= 128 KB)
+                    dx = torch.ops.ea.linear(dy2, wc.t().contiguous(), None, y_f32, False)[0].view(xshape)
+                else:
+                    dx = _mm_out(dy2, wc, xdtype).view(xshape)
         need_w, need_b = ctx.needs_input_grad[1], (bdtype is not None and ctx.needs_input_grad[2])
+        if need_w and xl is None:
+            raise RuntimeError("LinearFn: the weight gradient was requested but the forward did not keep its input")
         if need_w and USE_WGRAD and wgrad_supported(dy2, xl):
             # one pass over dY and X: weight gradient (+ bias gradient riding along) -- ea_wgrad
             dw, db32 = wgrad(dy2, xl, need_b)

@@ -30,7 +30,7 @@ def _mu_net(d, with_ln):
     return nn.Sequential(*([nn.Linear(d, d)] + ([nn.LayerNorm(d)] if with_ln else [])))
 
 
-class CausalEVAttention(nn.Module):
+class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
     def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True,
                  self_attention=False, q_noise=0.0, qn_block_size=8, attn_args=None):
         super().__init__()
@@ -123,7 +123,7 @@ class CausalEVAttention(nn.Module):
             if not hasattr(self, "_stacked_cache"):
                 self._stacked_cache = _ops.DerivedCache()
             weight, bias = self._stacked_cache.get(
-                [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight] + biases, build)
+                self, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight] + biases, build)
             qkv = _ops.linear_wb(query, weight, bias)
         else:
             assert key is not None and value is not None

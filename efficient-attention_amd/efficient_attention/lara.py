@@ -19,7 +19,7 @@ from .abstract_attention import MultiheadAttention
 from .attn_utils import FlattenTranspose
 
 
-class LinearRA(MultiheadAttention):
+class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
     def __init__(self, num_landmarks=49, kernel_size=None, proposal_gen='pool',
                  use_antithetics=False, use_multisample=False, pool_module_type='light',
                  mis_type='mis-opt', alpha_coeff=1.0, *args, **kwargs):
@@ -133,7 +133,7 @@ class LinearRA(MultiheadAttention):
         if not hasattr(self, "_folded_cache"):
             self._folded_cache = _ops.DerivedCache()
         w_ext, b_ext = self._folded_cache.get(
-            [self.qkv.weight, self.qkv.bias, self.q_bar_gen[0].weight, self.k_bar_gen[0].weight], build)
+            self, [self.qkv.weight, self.qkv.bias, self.q_bar_gen[0].weight, self.k_bar_gen[0].weight], build)
         qkv = _ops.linear_wb(x, w_ext, b_ext)
         qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 5, h, d)

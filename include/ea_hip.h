@@ -184,9 +184,11 @@ int32_t ea_lara_parts(const ea_lara_geom* g);
 int ea_lara_stats_fwd(const ea_lara_geom* g, const ea_t4* q, const ea_t4* k, const ea_t4* v,
                       const uint8_t* mask, const float* omega, const float* qbar,
                       float* p_ml, float* p_kv, void* stream);
+/* lseZ / tmean (both or neither; fp32 [B*H, N]): the per-token statistics of the estimator's softmax over the samples,
+ * log2(sum_c alpha 2^z) and mean_c t, kept for ea_lara_bwd_q_fused (8 bytes per token-head). */
 int ea_lara_out_fwd(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar,
                     const float* kv, const float* lse_t, const float* bhv, const float* cst,
-                    const ea_t4* out, void* stream);
+                    const ea_t4* out, float* lseZ, float* tmean, void* stream);
 int ea_lara_bwd_q(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
                   const float* qbar, const float* kv, const float* lse_t, const float* bhv,
                   const float* cst, const ea_t4* dq, float* lseZ, float* tmean, float* rowdot,
@@ -208,7 +210,8 @@ int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, 
 /* Fused backward (round 2): the elementwise stage of the estimator is evaluated once per side and its
  * [C x N] weight matrices are transposed through LDS, so q/dout and k/v are each read ONCE
  * (ea_lara_bwd_q + ea_lara_bwd_qstats, ea_lara_bwd_k + ea_lara_bwd_kstats of round 1 read them
- * twice).  C <= 64.  Partial outputs [BH, ea_lara_fused_parts(g), C, *] feed ea_lara_merge_bwd /
+ * twice), and (round 3) the softmax statistics lseZ / tmean of ea_lara_out_fwd are re-used instead of re-derived.
+ * C <= 64.  Partial outputs [BH, ea_lara_fused_parts(g), C, *] feed ea_lara_merge_bwd /
  * ea_slice_sum unchanged.  Replaces the autograd of lara.py:201-246.
  * ea_lara_bwd_finish: dq -= s sum_c t[c,n] (u q_bar)_c (softmax-over-sequence correction, uq may be
  * NULL) and, with pool_r > 0, the backward of the uniform pool_r x pool_r average pooling of q and k
@@ -216,8 +219,8 @@ int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, 
 int32_t ea_lara_fused_parts(const ea_lara_geom* g);
 int ea_lara_bwd_q_fused(const ea_lara_geom* g, const ea_t4* q, const ea_t4* dout, const float* omega,
                         const float* qbar, const float* kv, const float* lse_t, const float* bhv,
-                        const float* cst, const ea_t4* dq, float* p_ml, float* p_dkv, float* p_dom,
-                        float* p_m1, float* p_m2, void* stream);
+                        const float* cst, const float* lseZ, const float* tmean, const ea_t4* dq, float* p_ml,
+                        float* p_dkv, float* p_dom, float* p_m1, float* p_m2, void* stream);
 int ea_lara_bwd_k_fused(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                         const float* omega, const float* dkv, const float* lse_k, const float* dkk,
                         const float* rsum, const ea_t4* dk, const ea_t4* dv, float* p_dom, void* stream);
@@ -367,6 +370,9 @@ int ea_bias_grad(int32_t dtype, int32_t rows, int32_t cols, const void* dy, floa
  * ea_slice_sum: out[bh][j] = scale * (a[bh][j] + sum_s parts[bh][s][j]), j < n (n % 4 == 0), a may
  *   be NULL.  Used for d(omega) = s (d_omega_q + sum over sequence slices of ea_lara_bwd_kstats). */
 int ea_colsum_f32(int32_t rows, int32_t cols, const float* x, float* out, void* stream);
+/* Two column sums over the same rows in one launch (dW_part and dvec_part of the landmark backward). */
+int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, int32_t cols2, const float* x2, float* out2,
+                   void* stream);
 /* Gradient of a table gather (the relative-position bias table read through `relative_position_index`,
  * local_attention.py:70-79): out[row][c] = sum_k g[inv[row][k]][c], inv [rows, K] int32 = the gather positions that read
  * table row `row` (-1 = unused slot), g [n, cols] fp32.  Fixed order (deterministic). */
@@ -469,6 +475,14 @@ int32_t ea_linear_supported(int32_t in_features, int32_t out_features);
 int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
               int64_t lda, const void* w, const float* bias, void* y, int32_t y_f32, int64_t ldy, void* a_cast,
               void* stream);
+/* The same product straight from the fp32 MASTER weight (nn.Linear keeps fp32 parameters under autocast,
+ * abstract_attention.py:34-36): the weight is rounded to the EA dtype while it is staged, so a training step needs no
+ * per-step cast kernels.  w_transposed == 0: w is [out, in]; != 0: w is [in, out] and the product is a w (the input
+ * gradient dX = dY W of a layer whose weight is W [out_layer, in_layer]: in = out_layer, out = in_layer), without a
+ * transposed copy. */
+int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
+                  int64_t lda, const float* w, int32_t w_transposed, const float* bias, void* y, int32_t y_f32, int64_t ldy,
+                  void* a_cast, void* stream);
 
 /* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
  * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);

@@ -189,6 +189,80 @@ def test_linear_matches_fp64(rows, K, NO, a_f32, y_f32, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,K,NO,a_f32,y_f32,transposed", [
+    (100352, 192, 576, 1, 0, 0), (100352, 192, 192, 0, 0, 0), (100352, 192, 192, 0, 1, 1), (1001, 64, 128, 1, 1, 0),
+    (50017, 128, 384, 0, 0, 1), (30001, 256, 256, 1, 1, 1), (77, 192, 576, 1, 0, 0), (4097, 256, 512, 0, 0, 1)])
+def test_linear_w32_equals_cast_weight(rows, K, NO, a_f32, y_f32, transposed, dtype):
+    """ea_linear_w32 (the product straight from the fp32 master weight, optionally read as the transposed operand) is
+    BIT-identical to ea_linear on `weight.to(dtype)` / `weight.t().contiguous().to(dtype)`: the rounding of the weight
+    happens while it is staged and is the same round-to-nearest-even."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(rows + K + NO + transposed)
+    a = torch.randn(rows, K, device="cuda", generator=g)
+    a = a if a_f32 else a.to(td)
+    w32 = torch.randn((K, NO) if transposed else (NO, K), device="cuda", generator=g) * K ** -0.5
+    b = None if transposed else torch.randn(NO, device="cuda", generator=g)
+    assert _ops.ea_linear_w32_supported(a, w32, td, transposed=bool(transposed))
+    od = torch.float32 if y_f32 else td
+    y, ac = _ops.ea_linear(a, w32, b, od, want_cast=bool(a_f32), elem_dtype=td, transposed=bool(transposed))
+    w16 = (w32.t().contiguous() if transposed else w32).to(td)
+    y0, ac0 = _ops.ea_linear(a, w16, b, od, want_cast=bool(a_f32))
+    assert torch.equal(y, y0)
+    if a_f32:
+        assert torch.equal(ac, ac0)
+
+
+@pytest.mark.gpu
+def test_linear_fn_master_weight_path_and_frozen_weight():
+    """LinearFn under autocast with fp32 parameters: forward and the output projection's input gradient run from the
+    master weight (no cast / transpose kernels), results bit-identical to the cast-weight path; a frozen weight with a
+    trainable bias and an fp32 input (`xl is None`) differentiates."""
+    import torch
+    from efficient_attention import _ops
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(192, 192).cuda()
+    x = torch.randn(4, 50, 192, device="cuda", requires_grad=True)
+    gy = torch.randn(4, 50, 192, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = _ops.linear(x, lin)
+    y.backward(gy.to(y.dtype))
+    dx, dw, db = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    # reference: the same kernels on explicitly cast operands
+    w16 = lin.weight.detach().to(torch.bfloat16)
+    y0, xc = _ops.ea_linear(x.detach().reshape(-1, 192), w16, lin.bias.detach().float(), torch.bfloat16, want_cast=True)
+    assert torch.equal(y.reshape(-1, 192), y0)
+    dx0, _ = _ops.ea_linear(gy.to(torch.bfloat16).reshape(-1, 192), w16.t().contiguous(), None, torch.float32)
+    assert torch.equal(dx.reshape(-1, 192), dx0)
+    dw0, db0 = _ops.wgrad(gy.to(torch.bfloat16).reshape(-1, 192), xc, True)
+    assert torch.equal(dw, dw0) and torch.equal(db, db0)
+    # frozen weight, trainable bias, fp32 input
+    lin.weight.requires_grad_(False)
+    lin.bias.grad = None
+    lin.weight.grad = None
+    x2 = torch.randn(4, 50, 192, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = _ops.linear(x2, lin)
+    y2.backward(gy.to(y2.dtype))
+    assert x2.grad is not None and lin.bias.grad is not None and lin.weight.grad is None
+    assert torch.allclose(lin.bias.grad, gy.to(torch.bfloat16).float().sum((0, 1)), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_colsum2_matches_two_colsums():
+    import torch
+    from efficient_attention import _ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(384, 8192, device="cuda", generator=g)
+    b = torch.randn(384, 384, device="cuda", generator=g)
+    sa, sb = _ops.colsum2_f32(a, b)
+    assert torch.equal(sa, _ops.colsum_f32(a)) and torch.equal(sb, _ops.colsum_f32(b))
+    assert torch.allclose(sa.double(), a.double().sum(0), atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_linear_unsupported_geometry_falls_to_library():
     """Geometries the streaming kernel is not built for are refused by the C ABI (EA_E_UNSUPPORTED), and the autograd
     Function routes them to the library GEMM."""
