@@ -295,15 +295,33 @@ template <int D> struct LaneOff2 {
 };
 // x[s][w]: W registers per piece, piece s of lane-row g = channels 16 s + 4 g + r  ->  piece s = channels 16 g + 4 s + r
 // (4 x 4 transpose of the pieces across the four lanes li, li + 16, li + 32, li + 48 of a token)
-template <int W> EA_DEV void quad_transpose(uint32_t (&x)[4][W]) {
-#pragma unroll
-  for (int w = 0; w < W; ++w)
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3"
-                 : "+v"(x[0][w]), "+v"(x[1][w]), "+v"(x[2][w]), "+v"(x[3][w]));
-#pragma unroll
-  for (int w = 0; w < W; ++w)
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                 : "+v"(x[0][w]), "+v"(x[1][w]), "+v"(x[2][w]), "+v"(x[3][w]));
+// One asm statement per stage, opening with s_nop 15: hipcc pads nothing inside inline asm (cdna_hip_programming.md 5.7), and
+// the operands are often MFMA results -- an XDL write needs up to 11 wait states before a VALU read of an 8-pass result
+// (measured: without the pad, accumulators handed straight to the swaps came back as NaN in two channels).
+template <int W> EA_DEV void quad_transpose(uint32_t (&x)[4][W]);
+template <> EA_DEV void quad_transpose<2>(uint32_t (&x)[4][2]) {
+  asm volatile("s_nop 15\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %2, %6\n\t"
+               "v_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %3, %7"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %4, %6\n\t"
+               "v_permlane16_swap_b32 %1, %3\n\tv_permlane16_swap_b32 %5, %7"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1]));
+}
+template <> EA_DEV void quad_transpose<4>(uint32_t (&x)[4][4]) {
+  asm volatile("s_nop 15\n\t"
+               "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %4, %12\n\t"
+               "v_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %5, %13\n\t"
+               "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %6, %14\n\t"
+               "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %7, %15"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]),
+                 "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[2][2]), "+v"(x[2][3]), "+v"(x[3][0]), "+v"(x[3][1]), "+v"(x[3][2]), "+v"(x[3][3]));
+  asm volatile("s_nop 1\n\t"
+               "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %8, %12\n\t"
+               "v_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %9, %13\n\t"
+               "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %10, %14\n\t"
+               "v_permlane16_swap_b32 %3, %7\n\tv_permlane16_swap_b32 %11, %15"
+               : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]),
+                 "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[2][2]), "+v"(x[2][3]), "+v"(x[3][0]), "+v"(x[3][1]), "+v"(x[3][2]), "+v"(x[3][3]));
 }
 // fp32 accumulators acc[dt][r] (new ownership) -> f[16] in the contiguous ownership (channel 16 g + j)
 EA_DEV void quad_transpose_f32(const f32x4* acc, float* f) {
@@ -333,5 +351,19 @@ template <typename E> EA_DEV void quad_transpose_pack(const f32x4* acc, float mu
   o0 = u32x4{x[0][0], x[0][1], x[1][0], x[1][1]};
   o1 = u32x4{x[2][0], x[2][1], x[3][0], x[3][1]};
 }
+
+// token / landmark tiles [rows][D]: the conflict-free round-3 layout for 128-byte rows (ea_common.h), the round-1 one for D = 32.
+// NEWTR: the transpose reads hand a lane the channels 16 dt + 4 g + r (pieces), not D/4 contiguous ones.
+template <int D> struct TileL {
+  static constexpr bool NEWTR = (D == 64);
+  static EA_DEV int off(int row, int chunk16) {
+    if constexpr (NEWTR) return lds_off2<D>(row, chunk16);
+    else return lds_off<D>(row, chunk16);
+  }
+};
+template <int D> struct LaneOffSel { typedef LaneOff<D> type; };
+template <> struct LaneOffSel<64> { typedef LaneOff2<64> type; };
+// channel offset (within a [*, D] fp32 row) of accumulator tile dt of lane-row g
+template <int D> EA_DEV int acc_chan(int dt, int g) { return TileL<D>::NEWTR ? 16 * dt + 4 * g : (D / 4) * g + 4 * dt; }
 
 }  // namespace ea

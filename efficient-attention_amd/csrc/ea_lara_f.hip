@@ -22,6 +22,7 @@
 // The transposed landmark matrices of the contraction over c are ds_read_b64_tr_b16 reads of the
 // row-major staging (no second, transposed copy in LDS): 73 KB per workgroup at C <= 64, d = 64,
 // two workgroups per CU.
+#include <stdlib.h>
 #include "ea_lara.h"
 
 namespace ea {
@@ -29,20 +30,6 @@ namespace ea {
 // byte offset of element (row, c) of a bf16/fp16 LDS tile [rows][W] whose 16-byte chunks are
 // XOR-swizzled by the row (same scheme as the token tiles, lds_off<>)
 template <int W> EA_DEV int wt_off(int row, int c) { return lds_off<W>(row, c >> 3) + ((c & 7) << 1); }
-
-// token / landmark tiles [rows][D]: the conflict-free round-3 layout for 128-byte rows (ea_common.h), the round-1 one for D = 32.
-// NEWTR: the transpose reads hand a lane the channels 16 dt + 4 g + r (pieces), not D/4 contiguous ones.
-template <int D> struct TileL {
-  static constexpr bool NEWTR = (D == 64);
-  static EA_DEV int off(int row, int chunk16) {
-    if constexpr (NEWTR) return lds_off2<D>(row, chunk16);
-    else return lds_off<D>(row, chunk16);
-  }
-};
-template <int D> struct LaneOffSel { typedef LaneOff<D> type; };
-template <> struct LaneOffSel<64> { typedef LaneOff2<64> type; };
-// channel offset (within a [*, D] fp32 row) of accumulator tile dt of lane-row g
-template <int D> EA_DEV int acc_chan(int dt, int g) { return TileL<D>::NEWTR ? 16 * dt + 4 * g : (D / 4) * g + 4 * dt; }
 
 // all global loads of up to three [C][D] fp32 landmark matrices in flight, then convert + store as
 // swizzled element-type rows (zero rows beyond C)
@@ -92,7 +79,9 @@ template <typename E> EA_DEV typename E::x8 ones_x8() {
 // The per-token statistics of the estimator's softmax over the samples -- lse_Z (log2 units) and mean_c t -- come from
 // the forward (ea_lara_out_fwd writes them: 8 bytes per token-head), so W = alpha 2^(z - lse_Z) directly: no max, no
 // sum, no reciprocal, and two cross-lane reductions per tile instead of five.
-template <typename E, int D, int NCT, int LH>
+// MIS: the estimator variant is a template parameter -- as a runtime value every `if (opt)` of the unrolled stage became
+// a branch, and the chunk loop fell apart into ~50 basic blocks of 10-25 instructions (no scheduling across them).
+template <typename E, int D, int NCT, int LH, int MIS>
 __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int Cp = NCT * 16, ROWW = Cp * 2, NSUB = 4 / NCT;
@@ -114,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   const int blk = blockIdx.x / nbh, bh = blockIdx.x - blk * nbh;      // slice-major (see lara_f_plan)
   const int b = bh / p.H, h = bh - b * p.H;
   const size_t lm = (size_t)bh * p.C;
-  const bool opt = p.mis == MIS_OPT;
-  const bool use_t = p.mis != MIS_BH;
+  constexpr bool opt = MIS == MIS_OPT;
+  constexpr bool use_t = MIS != MIS_BH;
   const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
   const char* dob = p.dout.p + (b * p.dout.sb + h * p.dout.sh) * 2;
   const float invC = 1.f / (float)p.C;
@@ -227,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         const f32x2 av = {a[ct][2 * hh], a[ct][2 * hh + 1]}, tq = {tt[ct][2 * hh], tt[ct][2 * hh + 1]};
         const f32x2 csv = hh ? f32x2{cs.z, cs.w} : f32x2{cs.x, cs.y};
         f32x2 z = av * s22 + (csv - lz2);
-        if (p.mis == MIS_BIASED) z += tq * s22;
+        if (MIS == MIS_BIASED) z += tq * s22;
         const f32x2 wz = {fast_exp2(z[0]), fast_exp2(z[1])};                  // 2^(z - lse_Z)
         if (opt) {
           const f32x2 lsv = hh ? f32x2{ls.z, ls.w} : f32x2{ls.x, ls.y};
@@ -773,13 +762,17 @@ size_t lara_f_lds(int which, int D, int Cp) {
 // dispatch the BH first slices start next to slots - BH second slices and the remaining second slices
 // follow in rb = ceil(BH / (slots - BH)) rounds, so first : second = rb : 1 keeps every slot busy to
 // the end (B*h = 384 on 256 CUs x 2 workgroups: 592 + 192 tokens instead of 448 + 336).
-static void lara_f_plan(LaraP& p, int slots) {
+static int f_env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+static void lara_f_plan(LaraP& p, int slots, int F) {
   if (p.nsplit != 2) return;
   const int BH = p.B * p.H, gran = 64;
   p.tok_begin[0] = 0; p.tok_begin[1] = p.tok_per_block < p.N ? p.tok_per_block : p.N; p.tok_begin[2] = p.N;
   if (BH < slots && slots < 2 * BH) {
     const int rb = (BH + (slots - BH) - 1) / (slots - BH);
-    const int F = 96;                       // fixed prologue / epilogue of a workgroup, in token-times
+    // F: fixed prologue / epilogue of a workgroup, in token-times (query side, round 3: ~8 us against 0.05 us per token)
     int b = ((p.N - (rb - 1) * F) / (1 + rb) + gran / 2) / gran * gran;
     if (b >= gran && b < p.N) p.tok_begin[1] = p.N - b;
   }
@@ -807,7 +800,8 @@ template <typename E, int D, int NCT>
 static int launch_f(int which, LaraP& p, hipStream_t st) {
   const size_t lds = lara_f_lds(which, D, NCT * 16);
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
-  static int occ[4] = {0, 0, 0, 0};         // resident workgroups per CU of the instantiations
+  static int occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of the instantiations
+  static const int fq_fixed = f_env_int("EA_LARA_FQ_F", 160);
 #define EA_LF(K, slot, ...)                                                                           \
   do {                                                                                                \
     if (lds > 64 * 1024) {                                                                            \
@@ -816,13 +810,15 @@ static int launch_f(int which, LaraP& p, hipStream_t st) {
       if (e != hipSuccess) return (int)e;                                                             \
     }                                                                                                 \
     if (!occ[slot]) occ[slot] = f_occupancy(&K<__VA_ARGS__>, lds);                                    \
-    lara_f_plan(p, occ[slot] * f_device_cus());                                                       \
+    lara_f_plan(p, occ[slot] * f_device_cus(), which == 0 ? fq_fixed : 96);                           \
     hipLaunchKernelGGL((K<__VA_ARGS__>), grid, block, lds, st, p);                                    \
   } while (0)
   if (which == 0) {
-    // r-pairs of the last landmark tile that can be populated (see lara_fq_kernel)
-    if (p.C - 16 * (NCT - 1) <= 2) EA_LF(lara_fq_kernel, 0, E, D, NCT, 1);
-    else EA_LF(lara_fq_kernel, 3, E, D, NCT, 2);
+    // r-pairs of the last landmark tile that can be populated (see lara_fq_kernel); the estimator variant
+    const bool lh1 = NCT == 4 && p.C - 16 * (NCT - 1) <= 2;
+    if (p.mis == MIS_OPT) { if (lh1) EA_LF(lara_fq_kernel, 0, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_OPT); else EA_LF(lara_fq_kernel, 3, E, D, NCT, 2, MIS_OPT); }
+    else if (p.mis == MIS_BIASED) { if (lh1) EA_LF(lara_fq_kernel, 4, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_BIASED); else EA_LF(lara_fq_kernel, 5, E, D, NCT, 2, MIS_BIASED); }
+    else { if (lh1) EA_LF(lara_fq_kernel, 6, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_BH); else EA_LF(lara_fq_kernel, 7, E, D, NCT, 2, MIS_BH); }
   } else if (which == 1) EA_LF(lara_fk_kernel, 1, E, D, NCT);
   else EA_LF(lara_fin_kernel, 2, E, D, NCT);
 #undef EA_LF

@@ -18,54 +18,22 @@ template <int D> struct LxCfg {
   static constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
 };
 
-// stage fp32 [C][D] -> LDS [Cp][D] element-type rows (swizzled), zero rows beyond C
-template <typename E, int D>
-EA_DEV void stage_rows(char* dst, const float* src, int C, int Cp, int tid) {
-  constexpr int CPR = D / 8;
-  for (int idx = tid; idx < Cp * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    u32x4 w = {0u, 0u, 0u, 0u};
-    if (row < C) {
-      float f[8];
-      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
-      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
-      w = pack8<E>(f);
-    }
-    sts16(dst + lds_off<D>(row, c), w);
-  }
-}
-// stage fp32 [C][D] -> LDS transposed [D][Cp + 4] element type, zero columns beyond C
-template <typename E, int D>
-EA_DEV void stage_cols(char* dst, const float* src, int C, int Cp, int tid) {
-  constexpr int CPR = D / 8;
-  const int ld = Cp + 4;
-  for (int idx = tid; idx < Cp * CPR; idx += 256) {
-    const int row = idx / CPR, c = idx - row * CPR;
-    float f[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = 0.f;
-    if (row < C) {
-      *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
-      *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
-    }
-    uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d16[(c * 8 + i) * ld + row] = E::from_f(f[i]);
-  }
-}
-
-template <typename E, int D, int NCT, int MODE>
+// MIS >= 0: estimator variant at compile time (the forward combine; with mis as a runtime value its tile loop was cut into
+// 17 basic blocks); MIS = -1: read mis (the rare two-pass backward modes and the Performer modes).
+template <typename E, int D, int NCT, int MODE, int MIS>
 __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const LaraP p) {
+  const int mis = MIS >= 0 ? MIS : p.mis;
   using Cfg = LxCfg<D>;
   constexpr int ROWB = Cfg::ROWB, KS = Cfg::KS, DT = Cfg::DT, DQ = Cfg::DQ;
   constexpr int Cp = NCT * 16;
-  constexpr int MT_LDB = (Cp + 4) * 2;             // bytes per row of a transposed matrix
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* R1 = smem;                                  // omega rows
   char* R2 = R1 + Cp * ROWB;                        // qbar rows
-  char* R3 = R2 + Cp * ROWB;                        // kv / dkv rows
-  char* M1 = R3 + Cp * ROWB;
-  char* M2 = M1 + D * MT_LDB;
+  char* R3 = R2 + Cp * ROWB;                        // kv / dkv / uq rows
+  // Round 3: the transposed operands of the contraction over c are ds_read_b64_tr_b16 reads of these row-major tiles
+  // (round 1 kept second, transposed copies M1 / M2 staged with 2-byte LDS stores and read with 2-way bank conflicts).
+  char* const MA = (MODE == LX_BWDQ || MODE == LX_PBWDQ) ? R1 : R3;     // first operand: kv | omega | dkv | uq
+  char* const MB = (MODE == LX_BWDQ || MODE == LX_PBWDQ) ? R2 : R1;     // second: qbar (query side) | omega (key side)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int bh = blockIdx.x / p.nsplit, blk = blockIdx.x - bh * p.nsplit;
@@ -73,7 +41,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   const size_t lm = (size_t)bh * p.C;               // landmark row offset
   const size_t lmw = (size_t)(p.w_per_head ? h : bh) * p.C;   // ... of omega / W
   constexpr bool PERF = MODE >= LX_POUT;
-  const bool use_t = p.mis != MIS_BH && !PERF;
+  const bool use_t = mis != MIS_BH && !PERF;
 
   EA_STAMP(p, 0);
   EA_BLK(p, 0);
@@ -119,9 +87,9 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     if (ok) {
       if (MODE == LX_FWD || MODE == LX_BWDQ) {
         sc_v0 = p.cst[lm + c] * LOG2E;
-        if (p.mis == MIS_OPT) sc_v2 = p.bhv[lm + c];
+        if (mis == MIS_OPT) sc_v2 = p.bhv[lm + c];
       }
-      if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && p.mis == MIS_OPT) sc_v1 = p.lse_t[lm + c] * LOG2E;
+      if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && mis == MIS_OPT) sc_v1 = p.lse_t[lm + c] * LOG2E;
       if (MODE == LX_BWDK) { sc_v0 = p.lse_k[lm + c] * LOG2E; sc_v1 = p.dkk[lm + c]; sc_v2 = p.rsum[lm + c]; }
       if (MODE == LX_POUT || MODE == LX_PBWDQ) sc_v0 = p.cst[lm + c];       // sum_n phi(k_n)[j]
       if (MODE == LX_PBWDK) sc_v2 = p.rsum[lm + c];                         // d ksum[j]
@@ -133,21 +101,16 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     constexpr int CPRs = D / 8;
     constexpr int SL = (Cp * CPRs + 255) / 256;        // (row, 8-channel chunk) slots per thread
     const float* rsrc[3] = {nullptr, nullptr, nullptr};
-    const float* csrc[2] = {nullptr, nullptr};
     if (MODE != LX_QCORR) rsrc[0] = p.omega + lmw * D;
     if (MODE != LX_BWDK && MODE != LX_PBWDK && use_t) rsrc[1] = p.qbar + lm * D;
-    if (MODE == LX_BWDQ || MODE == LX_PBWDQ) rsrc[2] = p.kv + lm * D;
+    if (MODE == LX_BWDQ || MODE == LX_PBWDQ || MODE == LX_FWD || MODE == LX_POUT) rsrc[2] = p.kv + lm * D;
     if (MODE == LX_BWDK || MODE == LX_PBWDK) rsrc[2] = p.dkv + lm * D;
-    if (MODE == LX_FWD || MODE == LX_POUT) csrc[0] = p.kv + lm * D;
-    if (MODE == LX_BWDQ || MODE == LX_PBWDQ) { csrc[0] = p.omega + lmw * D; if (use_t) csrc[1] = p.qbar + lm * D; }
-    if (MODE == LX_BWDK || MODE == LX_PBWDK) { csrc[0] = p.dkv + lm * D; csrc[1] = p.omega + lmw * D; }
-    if (MODE == LX_QCORR) csrc[0] = p.uq + lm * D;
+    if (MODE == LX_QCORR) rsrc[2] = p.uq + lm * D;
     char* rdst[3] = {R1, R2, R3};
-    char* cdst[2] = {M1, M2};
-    float4 rb[3][SL][2], cb[2][SL][2];
+    float4 rb[3][SL][2];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const float* src = j < 3 ? rsrc[j] : csrc[j - 3];
+    for (int j = 0; j < 3; ++j) {
+      const float* src = rsrc[j];
 #pragma unroll
       for (int sl = 0; sl < SL; ++sl) {
         const int idx = tid + sl * 256;
@@ -157,27 +120,20 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
           lo = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8);
           hi = *reinterpret_cast<const float4*>(src + (size_t)row * D + c * 8 + 4);
         }
-        if (j < 3) { rb[j][sl][0] = lo; rb[j][sl][1] = hi; } else { cb[j - 3][sl][0] = lo; cb[j - 3][sl][1] = hi; }
+        rb[j][sl][0] = lo; rb[j][sl][1] = hi;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const bool on = (j < 3 ? rsrc[j] : csrc[j - 3]) != nullptr;
+    for (int j = 0; j < 3; ++j) {
+      const bool on = rsrc[j] != nullptr;
 #pragma unroll
       for (int sl = 0; sl < SL; ++sl) {
         const int idx = tid + sl * 256;
         const int row = idx / CPRs, c = idx - row * CPRs;
         if (!on || idx >= Cp * CPRs) continue;
-        const float4 lo = j < 3 ? rb[j][sl][0] : cb[j - 3][sl][0];
-        const float4 hi = j < 3 ? rb[j][sl][1] : cb[j - 3][sl][1];
+        const float4 lo = rb[j][sl][0], hi = rb[j][sl][1];
         const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (j < 3) {
-          sts16(rdst[j] + lds_off<D>(row, c), pack8<E>(f));
-        } else {
-          uint16_t* d16 = reinterpret_cast<uint16_t*>(cdst[j - 3]);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) d16[(c * 8 + i) * (Cp + 4) + row] = E::from_f(f[i]);
-        }
+        sts16(rdst[j] + TileL<D>::off(row, c), pack8<E>(f));
       }
     }
   }
@@ -185,7 +141,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   EA_STAMP(p, 1);
   // per-landmark scalars live in LDS (three [Cp] fp32 vectors); lanes read the entries of their
   // rows c = 16 ct + 4 g + r at the point of use instead of pinning 6 x NCT x 4 registers
-  float* SC0 = reinterpret_cast<float*>(M2 + D * MT_LDB);
+  float* SC0 = reinterpret_cast<float*>(R3 + Cp * ROWB);
   float* SC1 = SC0 + Cp;
   float* SC2 = SC1 + Cp;
   if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
@@ -196,6 +152,8 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   };
   const LdsVec cst2{SC0, g}, lset2{SC1, g}, bhv{SC2, g}, lsek2{SC0, g}, dkk{SC1, g}, rs{SC2, g};
   const float stabk2 = (MODE == LX_PBWDK) ? p.stab[bh] * LOG2E : 0.f;
+  typename LaneOffSel<D>::type lo;
+  lo.init(lane);
   __syncthreads();
   EA_STAMP(p, 2);
   int prof_it = 0;
@@ -223,9 +181,9 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       const int row = ct * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (MODE != LX_QCORR) a[ct] = E::mma(as_x8<E>(lds16(R1 + lds_off<D>(row, g * KS + ks))), f1[ks], a[ct]);
-        if (MODE != LX_BWDK && use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + lds_off<D>(row, g * KS + ks))), f1[ks], tt[ct]);
-        if (TWO_TOK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + lds_off<D>(row, g * KS + ks))), f2[ks], dw[ct]);
+        if (MODE != LX_QCORR) a[ct] = E::mma(as_x8<E>(lds16(R1 + TileL<D>::off(row, g * KS + ks))), f1[ks], a[ct]);
+        if (MODE != LX_BWDK && use_t) tt[ct] = E::mma(as_x8<E>(lds16(R2 + TileL<D>::off(row, g * KS + ks))), f1[ks], tt[ct]);
+        if (TWO_TOK) dw[ct] = E::mma(as_x8<E>(lds16(R3 + TileL<D>::off(row, g * KS + ks))), f2[ks], dw[ct]);
       }
     }
     if (prof_it < 8) EA_STAMP(p, 4 + prof_it * 5);
@@ -241,7 +199,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       const f32x2 s22 = {s2, s2};
       f32x2 tv[NCT][2], ez[NCT][2];     // ez: 2^(z - mx), zeroed in backward where alpha is clamped
       f32x2 tl2 = {0.f, 0.f};
-      if (p.mis == MIS_OPT) {
+      if (mis == MIS_OPT) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const float4 ls = lset2.v4(ct);
@@ -259,7 +217,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
         const float4 cs = cst2.v4(ct);
         f32x2 z0 = f32x2{a[ct][0], a[ct][1]} * s22 + f32x2{cs.x, cs.y};
         f32x2 z1 = f32x2{a[ct][2], a[ct][3]} * s22 + f32x2{cs.z, cs.w};
-        if (p.mis == MIS_BIASED) {
+        if (mis == MIS_BIASED) {
           z0 += f32x2{tt[ct][0], tt[ct][1]} * s22;
           z1 += f32x2{tt[ct][2], tt[ct][3]} * s22;
         }
@@ -277,7 +235,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
           const f32x2 x = ez[ct][hh] - mx2;
           ez[ct][hh] = f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
         }
-        if (p.mis == MIS_OPT) {
+        if (mis == MIS_OPT) {
           const float4 bv = bhv.v4(ct);
           const float kt = -p.kappa * tmean;
           const f32x2 kap = {p.kappa, p.kappa};
@@ -328,7 +286,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
             const f32x2 dd = f32x2{dw[ct][2 * hh], dw[ct][2 * hh + 1]} - rdv;  // dW - rd
             const f32x2 dz = wv[ct][hh] * dd;
             w1[ct][2 * hh] = dz[0]; w1[ct][2 * hh + 1] = dz[1];
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               da[ct][hh] = ez[ct][hh] * inv2 * dd;                             // dZ / alpha
               sda2 += da[ct][hh];
             }
@@ -339,12 +297,12 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               const float m = sda * invC;
               const f32x2 kap = {p.kappa, p.kappa};
               const f32x2 t2 = tv[ct][hh] * kap * (da[ct][hh] - f32x2{m, m});  // t * dt
               w2[ct][2 * hh] = t2[0]; w2[ct][2 * hh + 1] = t2[1];
-            } else if (p.mis == MIS_BIASED) {
+            } else if (mis == MIS_BIASED) {
               w2[ct][2 * hh] = w1[ct][2 * hh]; w2[ct][2 * hh + 1] = w1[ct][2 * hh + 1];   // dT = dZ
             }
           }
@@ -487,42 +445,52 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int drow = DQ * (li >> 2) + 4 * dt + (li & 3);
-        const int c0 = (32 * kk + 4 * g) * 2;
-        const char* r1 = M1 + drow * MT_LDB;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(r1 + c0);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(r1 + c0 + 32);
-        acc[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(p1), acc[dt]);
+        const char* r1 = MA + (32 * kk) * ROWB + lo.tr[dt];
+        acc[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * ROWB)), as_x8<E>(p1), acc[dt]);
         if (two) {
-          const char* r2 = M2 + drow * MT_LDB;
-          const u32x2 lo2 = *reinterpret_cast<const u32x2*>(r2 + c0);
-          const u32x2 hi2 = *reinterpret_cast<const u32x2*>(r2 + c0 + 32);
-          if (KEYS) acc2[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc2[dt]);
-          else acc[dt] = E::mma(as_x8<E>(lo2, hi2), as_x8<E>(p2), acc[dt]);
+          const char* r2 = MB + (32 * kk) * ROWB + lo.tr[dt];
+          if (KEYS) acc2[dt] = E::mma(as_x8<E>(E::tr4(r2), E::tr4(r2 + 16 * ROWB)), as_x8<E>(p2), acc2[dt]);
+          else acc[dt] = E::mma(as_x8<E>(E::tr4(r2), E::tr4(r2 + 16 * ROWB)), as_x8<E>(p2), acc[dt]);
         }
       }
     }
     if (prof_it < 8) EA_STAMP(p, 6 + prof_it * 5);
-    // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` ----
+    // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` (the accumulator pieces of the transpose-read
+    // layout are first moved between the four lanes of the token: quad_transpose, ea_common.h) ----
     float f[DQ];
     if (MODE == LX_FWD || MODE == LX_POUT) {
       // issued unconditionally (rows past the end go to the trash line): a static store count lets the wait for the next
       // tile's prefetched rows leave this tile's stores in flight
+      char* dst = valid ? p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2 : ea_trash_line();
+      if constexpr (TileL<D>::NEWTR) {
+        u32x4 o0, o1;
+        quad_transpose_pack<E>(acc, pden, o0, o1);
+        stg16(dst, o0);
+        stg16(dst + 16, o1);
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * pden;
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+      }
+      continue;
+    }
+    float fk2[DQ];
+    if constexpr (TileL<D>::NEWTR) {
+      quad_transpose_f32(acc, f);
+      if (KEYS) quad_transpose_f32(acc2, fk2);
+    } else {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * pden;
-      char* dst = valid ? p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2 : ea_trash_line();
-#pragma unroll
-      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
-      continue;
+        for (int r = 0; r < 4; ++r) { f[4 * dt + r] = acc[dt][r]; fk2[4 * dt + r] = acc2[dt][r]; }
     }
     if (!valid) continue;
     if (MODE == LX_BWDQ) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r] * p.scale;
+      for (int j = 0; j < DQ; ++j) f[j] *= p.scale;
       char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + tok * p.dq.sn + DQ * g) * 2;
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
@@ -535,7 +503,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int j = 8 * ks + i;
-          o8[i] = p.scale * acc[j >> 2][j & 3] - p.knorm_coef * qf8[i] * sdb;
+          o8[i] = p.scale * f[j] - p.knorm_coef * qf8[i] * sdb;
         }
         stg16(dst + ks * 16, pack8<E>(o8));
       }
@@ -548,15 +516,11 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int j = 8 * c + i;
-          old[i] -= acc[j >> 2][j & 3] * p.scale;
+          old[i] -= f[j] * p.scale;
         }
         stg16(dst + c * 16, pack8<E>(old));
       }
     } else {   // LX_BWDK: dv = acc, dk = s (acc2 - k * sdb)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f[4 * dt + r] = acc[dt][r];
       char* dstv = p.dv.p + (b * p.dv.sb + h * p.dv.sh + tok * p.dv.sn + DQ * g) * 2;
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) stg16(dstv + c * 16, pack8<E>(f + 8 * c));
@@ -568,7 +532,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int j = 8 * ks + i;
-          o8[i] = p.scale * acc2[j >> 2][j & 3] - p.knorm_coef * kf[i] * sdb;
+          o8[i] = p.scale * fk2[j] - p.knorm_coef * kf[i] * sdb;
         }
         stg16(dstk + ks * 16, pack8<E>(o8));
       }
@@ -582,24 +546,29 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
 
 size_t lara_x_lds(int D, int NCT) {
   const int Cp = NCT * 16;
-  return (size_t)3 * Cp * D * 2 + (size_t)2 * D * (Cp + 4) * 2 + (size_t)3 * Cp * sizeof(float);
+  return (size_t)3 * Cp * D * 2 + (size_t)3 * Cp * sizeof(float);
 }
 
 template <typename E, int D, int NCT>
 static int launch_x(int mode, const LaraP& p, hipStream_t st) {
   const size_t lds = lara_x_lds(D, NCT);
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
-#define EA_LX(M)                                                                                  \
+#define EA_LXM(M, S)                                                                              \
   do {                                                                                            \
     if (lds > 64 * 1024) {                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lara_x_kernel<E, D, NCT, M>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lara_x_kernel<E, D, NCT, M, S>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
       if (e != hipSuccess) return (int)e;                                                         \
     }                                                                                             \
-    hipLaunchKernelGGL((lara_x_kernel<E, D, NCT, M>), grid, block, lds, st, p);                   \
+    hipLaunchKernelGGL((lara_x_kernel<E, D, NCT, M, S>), grid, block, lds, st, p);                \
   } while (0)
+#define EA_LX(M) EA_LXM(M, -1)
   switch (mode) {
-    case LX_FWD: EA_LX(LX_FWD); break;
+    case LX_FWD:
+      if (p.mis == MIS_OPT) EA_LXM(LX_FWD, MIS_OPT);
+      else if (p.mis == MIS_BIASED) EA_LXM(LX_FWD, MIS_BIASED);
+      else EA_LXM(LX_FWD, MIS_BH);
+      break;
     case LX_BWDQ: EA_LX(LX_BWDQ); break;
     case LX_BWDK: EA_LX(LX_BWDK); break;
     case LX_QCORR: EA_LX(LX_QCORR); break;
@@ -609,6 +578,7 @@ static int launch_x(int mode, const LaraP& p, hipStream_t st) {
     default: return EA_E_BADARG;
   }
 #undef EA_LX
+#undef EA_LXM
   return (int)hipGetLastError();
 }
 

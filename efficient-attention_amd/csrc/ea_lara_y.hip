@@ -11,6 +11,7 @@
 // of two 16-token tiles are the B operand of the contraction over n, whose A operand is a
 // ds_read_b64_tr_b16 of the token rows.  Every (split, sub-chunk) writes its own partial result;
 // the caller merges partials (tiny tensors).
+#include <type_traits>
 #include "ea_lara.h"
 
 namespace ea {
@@ -39,8 +40,27 @@ EA_DEV void conv_lm_frag(typename E::x8* dst, const LmRaw<D>& raw) {
   }
 }
 
-template <typename E, int D, int MODE>
+// MIS >= 0: the estimator variant at compile time (the forward statistics pass; round 3 -- with mis and the phase flag
+// `keys` as runtime values the chunk loop was 88 basic blocks); MIS = -1: read mis (the rare two-pass backward modes).
+// token tiles [rows][D]: round-3 conflict-free layout for 128-byte rows (ea_common.h: phi2 swizzle, contiguous transpose
+// reads -> accumulator tile dt of lane-row g holds channels 16 dt + 4 g ..), round-1 layout for D = 32
+template <int D> struct YTile {
+  static constexpr bool NEWTR = (D == 64);
+  static EA_DEV int off(int row, int chunk16) {
+    if constexpr (NEWTR) return lds_off2<D>(row, chunk16);
+    else return lds_off<D>(row, chunk16);
+  }
+  // byte offset of the ds_read_b64_tr_b16 source of lane (li) in row `r`, channel tile dt
+  static EA_DEV int tr(int r, int li, int dt) {
+    const int colb = NEWTR ? (16 * dt + 4 * (li & 3)) * 2 : ((D / 4) * (li & 3) + 4 * dt) * 2;
+    return off(r, colb >> 4) + (colb & 15);
+  }
+  static EA_DEV int chan(int dt, int g) { return NEWTR ? 16 * dt + 4 * g : (D / 4) * g + 4 * dt; }
+};
+
+template <typename E, int D, int MODE, int MIS>
 __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
+  const int mis = MIS >= 0 ? MIS : p.mis;
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   typename E::x8 r1f[KS], r2f[KS], r3f[KS];
   LmRaw<D> raw1, raw2, raw3;
   load_lm_raw<D>(raw1, p.omega + (lmw + (c_ok ? c : 0)) * D, c_ok, g);
-  const bool use_t = p.mis != MIS_BH && MODE != LY_BWDK && !PERF;
+  const bool use_t = mis != MIS_BH && MODE != LY_BWDK && !PERF;
   load_lm_raw<D>(raw2, use_t ? p.qbar + (lm + (c_ok ? c : 0)) * D : p.omega, c_ok && use_t, g);
   const float* r3src = MODE == LY_BWDQ ? p.kv : p.dkv;
   constexpr bool HAS_R3 = MODE == LY_BWDQ || MODE == LY_BWDK;
@@ -82,14 +102,14 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   if (c_ok) {
     if (MODE == LY_BWDQ) {
       cst2 = p.cst[lm + c] * LOG2E;
-      if (p.mis == MIS_OPT) { bhc = p.bhv[lm + c]; lset2 = p.lse_t[lm + c] * LOG2E; }
+      if (mis == MIS_OPT) { bhc = p.bhv[lm + c]; lset2 = p.lse_t[lm + c] * LOG2E; }
     }
     if (MODE == LY_BWDK) { lsek2 = p.lse_k[lm + c] * LOG2E; dkkc = p.dkk[lm + c]; rsc = p.rsum[lm + c]; }
   }
 
   const int n0 = p.tok_begin[split];
   const int n1 = p.tok_begin[split + 1];
-  const int nphase = (MODE == LY_FWD && p.mis == MIS_OPT) ? 2 : 1;
+  const int nphase = (MODE == LY_FWD && mis == MIS_OPT) ? 2 : 1;
 
   f32x4 acc0[DT], acc1[DT], acc2[DT], acc3[DT];
 #pragma unroll
@@ -97,11 +117,11 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
   float m_k = -INFINITY, l_k = 0.f, m_t = -INFINITY, l_t = 0.f;
   float s_r = 0.f, s_dbh = 0.f, s_u = 0.f;
 
-  for (int phase = 0; phase < nphase; ++phase) {
-    const bool keys = (MODE == LY_FWD && phase == 0) || MODE == LY_BWDK || MODE == LY_PMAX || MODE == LY_PKV;
+  auto run_phase = [&](auto keys_tag, int phase) {
+    constexpr bool keys = decltype(keys_tag)::value;
     const T4l& a1 = keys ? p.k : p.q;
     const T4l& a2 = keys ? p.v : p.dout;
-    const bool need2 = !(MODE == LY_FWD && phase == 1) && MODE != LY_PMAX;
+    constexpr bool need2 = MODE == LY_FWD ? keys : MODE != LY_PMAX;
     const char* a1b = a1.p + (b * a1.sb + h * a1.sh) * 2;
     const char* a2b = need2 ? a2.p + (b * a2.sb + h * a2.sh) * 2 : nullptr;
     // Software pipeline: the rows of chunk i+1 (and their per-token scalars) are loaded into
@@ -113,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
       for (int i = 0; i < NSL; ++i) {
         const int idx = tid + i * 256;
         const int row = idx / CPR, cc = idx - row * CPR;
-        const int tok = cb_ + row;
-        const bool valid = tok < n1;
-        pw1[i] = pw2[i] = u32x4{0u, 0u, 0u, 0u};
+        const bool valid = cb_ + row < n1;
+        const int tok = valid ? cb_ + row : n1 - 1;       // clamped, not predicated: rows past the slice are zeroed by commit()
+        pw2[i] = u32x4{0u, 0u, 0u, 0u};
         ps0[i] = ps1[i] = ps2[i] = ps3[i] = 0.f;
+        pw1[i] = ldg16(a1b + (tok * a1.sn + cc * 8) * 2);
+        if (need2) pw2[i] = ldg16(a2b + (tok * a2.sn + cc * 8) * 2);
         if (valid) {
-          pw1[i] = ldg16(a1b + (tok * a1.sn + cc * 8) * 2);
-          if (need2) pw2[i] = ldg16(a2b + (tok * a2.sn + cc * 8) * 2);
           if (cc == 0 && (MODE == LY_BWDQ || MODE == LY_PBWDQ)) {
             const size_t o = (size_t)bh * p.N + tok;
             ps0[i] = p.lseZ[o]; ps1[i] = p.tmean[o]; ps2[i] = p.rowdot[o];
@@ -135,8 +155,10 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
         const int idx = tid + i * 256;
         const int row = idx / CPR, cc = idx - row * CPR;
         const bool valid = cb_ + row < n1;
-        sts16(T1 + lds_off<D>(row, cc), pw1[i]);
-        if (need2) sts16(T2 + lds_off<D>(row, cc), pw2[i]);
+        const u32x4 zz = {0u, 0u, 0u, 0u};
+        if (!valid) pw1[i] = zz;
+        sts16(T1 + YTile<D>::off(row, cc), pw1[i]);
+        if (need2) sts16(T2 + YTile<D>::off(row, cc), valid ? pw2[i] : zz);
         if (keys || MODE == LY_PBWDQ) {
           float f[8], part = 0.f;
           unpack8<E>(pw1[i], f);
@@ -197,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const typename E::x8 ta = as_x8<E>(lds16(T1 + lds_off<D>(row, g * KS + ks)));
+          const typename E::x8 ta = as_x8<E>(lds16(T1 + YTile<D>::off(row, g * KS + ks)));
           if (keys || MODE == LY_BWDQ || MODE == LY_PBWDQ) s1 = E::mma(ta, r1f[ks], s1);
           if (!keys && use_t) s2 = E::mma(ta, r2f[ks], s2);
-          if (HAS_R3) s3 = E::mma(as_x8<E>(lds16(T2 + lds_off<D>(row, g * KS + ks))), r3f[ks], s3);
+          if (HAS_R3) s3 = E::mma(as_x8<E>(lds16(T2 + YTile<D>::off(row, g * KS + ks))), r3f[ks], s3);
         }
         const int r0 = rb + 16 * mt + 4 * g;
         if (MODE == LY_BWDQ) {
@@ -221,20 +243,20 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
             const f32x2 T2 = f32x2{s2[2 * hh], s2[2 * hh + 1]} * s22;
             f32x2 x = S1 * s22 + (f32x2{cst2, cst2} - lzv[hh]);
             f32x2 t = {0.f, 0.f}, al = {1.f, 1.f};
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               const f32x2 tx = T2 - f32x2{lset2, lset2};
               t = f32x2{fast_exp2(tx[0]), fast_exp2(tx[1])};
               al = kap * t + (f32x2{bhc, bhc} - kap * tmv[hh]);
-            } else if (p.mis == MIS_BIASED) {
+            } else if (mis == MIS_BIASED) {
               x += T2;
             }
             const f32x2 wz = {fast_exp2(x[0]), fast_exp2(x[1])};
             f32x2 w = wz;
-            if (p.mis == MIS_OPT) w = wz * f32x2{fmaxf(al[0], 1e-8f), fmaxf(al[1], 1e-8f)};
+            if (mis == MIS_OPT) w = wz * f32x2{fmaxf(al[0], 1e-8f), fmaxf(al[1], 1e-8f)};
             const f32x2 dd = f32x2{s3[2 * hh], s3[2 * hh + 1]} - rdv[hh];
             const f32x2 dz = w * dd;
             f32x2 da = {0.f, 0.f}, tdt = {0.f, 0.f};
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               const f32x2 d0 = wz * dd;
               da = f32x2{al[0] > 1e-8f ? d0[0] : 0.f, al[1] > 1e-8f ? d0[1] : 0.f};
               tdt = t * kap * (da - sdv[hh]);
@@ -270,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
             s_r += phi * sc[2 * chunk + r0 + r];
           } else {   // LY_BWDQ
             const float lz2 = sc[r0 + r], tm = sc[chunk + r0 + r], rd = sc[2 * chunk + r0 + r], sd = sc[3 * chunk + r0 + r];
-            const LaraElem e = lara_alpha(p.mis, s2[r] * p.scale_log2, lset2, bhc, p.kappa, tm);
+            const LaraElem e = lara_alpha(mis, s2[r] * p.scale_log2, lset2, bhc, p.kappa, tm);
             const float z2 = s1[r] * p.scale_log2 + e.la2 + cst2;
             const float w = fast_exp2(z2 - lz2);
             const float dz = w * (s3[r] - rd);
             float da = 0.f, tdt = 0.f;
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               da = e.alpha > 1e-8f ? dz * fast_rcp(e.alpha) : 0.f;
               tdt = e.t * p.kappa * (da - sd);
             }
@@ -308,10 +330,8 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
           pf[2] = pack2<E>(w0[1][0], w0[1][1]); pf[3] = pack2<E>(w0[1][2], w0[1][3]);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-            const int c16 = colb >> 4, within = colb & 15;
-            const u32x2 lo = E::tr4(T2 + ra * ROWB + ((c16 ^ (ra & SW)) << 4) + within);
-            const u32x2 hi = E::tr4(T2 + rb2 * ROWB + ((c16 ^ (rb2 & SW)) << 4) + within);
+            const u32x2 lo = E::tr4(T2 + YTile<D>::tr(ra, li, dt));
+            const u32x2 hi = E::tr4(T2 + YTile<D>::tr(rb2, li, dt));
             acc0[dt] = acc0[dt] * alpha;
             acc0[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf), acc0[dt]);
           }
@@ -328,10 +348,8 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
 #undef EA_PK
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-          const int c16 = colb >> 4, within = colb & 15;
-          const int oa = ra * ROWB + ((c16 ^ (ra & SW)) << 4) + within;
-          const int ob = rb2 * ROWB + ((c16 ^ (rb2 & SW)) << 4) + within;
+          const int oa = YTile<D>::tr(ra, li, dt);
+          const int ob = YTile<D>::tr(rb2, li, dt);
           if (MODE == LY_BWDK) {
             acc0[dt] = E::mma(as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob)), as_x8<E>(f0), acc0[dt]);
           } else if (MODE == LY_PKV || MODE == LY_PBWDQ) {
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
             const typename E::x8 qt = as_x8<E>(E::tr4(T1 + oa), E::tr4(T1 + ob));
             acc0[dt] = E::mma(dot, as_x8<E>(f0), acc0[dt]);      // d kv_stats
             acc1[dt] = E::mma(qt, as_x8<E>(f1), acc1[dt]);       // sum dZ q
-            if (p.mis == MIS_OPT) {
+            if (mis == MIS_OPT) {
               acc2[dt] = E::mma(qt, as_x8<E>(f2), acc2[dt]);     // sum t dt q
               acc3[dt] = E::mma(qt, as_x8<E>(f3), acc3[dt]);     // sum t q
             }
@@ -353,6 +371,14 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
       if (prof_ci < 5) EA_STAMP(p, 7 + prof_ci * 8);
       ++prof_ci;
     }
+  };
+  if constexpr (MODE == LY_FWD) {
+    run_phase(std::true_type{}, 0);
+    if (nphase == 2) run_phase(std::false_type{}, 1);
+  } else if constexpr (MODE == LY_BWDK || MODE == LY_PMAX || MODE == LY_PKV) {
+    run_phase(std::true_type{}, 0);
+  } else {
+    run_phase(std::false_type{}, 0);
   }
   EA_STAMP(p, 60);
   if (!c_ok) { EA_BLK(p, 1); return; }
@@ -376,14 +402,14 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
     if (g == 0) { ml[0] = s_r; ml[1] = 0.f; ml[2] = 0.f; ml[3] = 0.f; }
   }
   auto put = [&](float* base, const f32x4* a) {
-    float* d = base + slot * D + DQ * g;
+    float* d = base + slot * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + 4 * dt) = make_float4(a[dt][0], a[dt][1], a[dt][2], a[dt][3]);
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + YTile<D>::chan(dt, g)) = make_float4(a[dt][0], a[dt][1], a[dt][2], a[dt][3]);
   };
   put(p.p_acc0, acc0);
   if (MODE == LY_BWDQ) {
     put(p.p_acc1, acc1);
-    if (p.mis == MIS_OPT) { put(p.p_acc2, acc2); put(p.p_acc3, acc3); }
+    if (mis == MIS_OPT) { put(p.p_acc2, acc2); put(p.p_acc3, acc3); }
   }
   EA_STAMP(p, 61);
   EA_BLK(p, 1);
@@ -421,25 +447,28 @@ static int device_cus() {
   return n;
 }
 
-template <typename E, int D, int MODE>
+template <typename E, int D, int MODE, int MIS = -1>
 static int launch_y_mode(LaraP& p, hipStream_t st) {
   const size_t lds = (size_t)2 * 128 * D * 2 + (size_t)4 * 128 * sizeof(float);
   static int occ = 0;                       // resident workgroups per CU of this instantiation
   if (!occ) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&lara_y_kernel<E, D, MODE>), 256, lds) != hipSuccess || n <= 0) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&lara_y_kernel<E, D, MODE, MIS>), 256, lds) != hipSuccess || n <= 0) n = 2;
     occ = n;
   }
   lara_y_plan(p, occ * device_cus());
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit), (unsigned)((p.NCT + 3) / 4)), block(256);
-  hipLaunchKernelGGL((lara_y_kernel<E, D, MODE>), grid, block, lds, st, p);
+  hipLaunchKernelGGL((lara_y_kernel<E, D, MODE, MIS>), grid, block, lds, st, p);
   return (int)hipGetLastError();
 }
 
 template <typename E, int D>
 static int launch_y(int mode, LaraP& p, hipStream_t st) {
   switch (mode) {
-    case LY_FWD: return launch_y_mode<E, D, LY_FWD>(p, st);
+    case LY_FWD:
+      if (p.mis == MIS_OPT) return launch_y_mode<E, D, LY_FWD, MIS_OPT>(p, st);
+      if (p.mis == MIS_BIASED) return launch_y_mode<E, D, LY_FWD, MIS_BIASED>(p, st);
+      return launch_y_mode<E, D, LY_FWD, MIS_BH>(p, st);
     case LY_BWDQ: return launch_y_mode<E, D, LY_BWDQ>(p, st);
     case LY_BWDK: return launch_y_mode<E, D, LY_BWDK>(p, st);
     case LY_PMAX: return launch_y_mode<E, D, LY_PMAX>(p, st);
