@@ -25,9 +25,11 @@
 #define EA_STAMP(p, i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (p).prof) (p).prof[i] = (long long)__builtin_readcyclecounter(); } while (0)
 // per-workgroup begin / end on the chip-wide 100 MHz clock
 #define EA_BLK(p, e) do { if (threadIdx.x == 0 && (p).prof && blockIdx.x < 8192) (p).prof[128 + 2 * blockIdx.x + (e)] = (long long)wall_clock64(); } while (0)
+// two more per-workgroup stamps (after the prologue, after the main loop)
+#define EA_BLKX(p, e) do { if (threadIdx.x == 0 && (p).prof && blockIdx.x < 8192) (p).prof[128 + 2 * 8192 + 2 * blockIdx.x + (e)] = (long long)wall_clock64(); } while (0)
 namespace ea {
 struct ProfReport {
-  static constexpr int NW = 128 + 2 * 8192;
+  static constexpr int NW = 128 + 4 * 8192;
   long long* d = nullptr; hipStream_t st; const char* name; int mode;
   long long* arm(hipStream_t s, const char* nm, int md) {
     static long long* buf = nullptr;
@@ -55,6 +57,25 @@ struct ProfReport {
       const size_t n = bs.size();
       fprintf(stderr, "  %zu blocks (10 ns ticks): start p50 %lld p90 %lld max %lld | dur min %lld p50 %lld p90 %lld max %lld | end p50 %lld max %lld\n",
               n, bs[n / 2], bs[n * 9 / 10], bs[n - 1], ds[0], ds[n / 2], ds[n * 9 / 10], ds[n - 1], es[n / 2], es[n - 1]);
+      {
+        std::vector<long long> pro, epi;
+        for (int i = 0; i < 8192; ++i) {
+          const long long b0 = h[128 + 2 * i], e0 = h[129 + 2 * i], x0 = h[128 + 2 * 8192 + 2 * i], x1 = h[129 + 2 * 8192 + 2 * i];
+          if (b0 && e0 && x0 && x1) { pro.push_back(x0 - b0); epi.push_back(e0 - x1); }
+        }
+        if (!pro.empty()) {
+          std::sort(pro.begin(), pro.end()); std::sort(epi.begin(), epi.end());
+          const size_t m = pro.size();
+          fprintf(stderr, "  prologue p10 %lld p50 %lld p90 %lld | epilogue p10 %lld p50 %lld p90 %lld\n", pro[m / 10], pro[m / 2], pro[m * 9 / 10], epi[m / 10], epi[m / 2], epi[m * 9 / 10]);
+        }
+      }
+      fprintf(stderr, "  start deciles:");
+      for (int q = 1; q <= 10; ++q) fprintf(stderr, " %lld", bs[(n * q) / 10 - 1]);
+      fprintf(stderr, " | dur deciles:");
+      for (int q = 1; q <= 10; ++q) fprintf(stderr, " %lld", ds[(n * q) / 10 - 1]);
+      fprintf(stderr, " | end deciles:");
+      for (int q = 1; q <= 10; ++q) fprintf(stderr, " %lld", es[(n * q) / 10 - 1]);
+      fprintf(stderr, "\n");
     }
   }
 };
@@ -62,6 +83,7 @@ struct ProfReport {
 #else
 #define EA_STAMP(p, i) do { } while (0)
 #define EA_BLK(p, e) do { } while (0)
+#define EA_BLKX(p, e) do { } while (0)
 #endif
 
 

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   const typename E::x8 ones = ones_x8<E>();
   __syncthreads();
   EA_STAMP(p, 1);
+  EA_BLKX(p, 0);
   int prof_it = 0;
   (void)prof_it;
 
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
     ++prof_it;
   }
   EA_STAMP(p, 60);
+  EA_BLKX(p, 1);
   // ---- per-landmark sums of d alpha: over the 16 token lanes, then over the four waves ----
   if (opt) {
 #pragma unroll
@@ -774,7 +776,9 @@ static void lara_f_plan(LaraP& p, int slots, int F) {
     const int rb = (BH + (slots - BH) - 1) / (slots - BH);
     // F: fixed prologue / epilogue of a workgroup, in token-times (query side, round 3: ~8 us against 0.05 us per token)
     int b = ((p.N - (rb - 1) * F) / (1 + rb) + gran / 2) / gran * gran;
-    if (b >= gran && b < p.N) p.tok_begin[1] = p.N - b;
+    static const int b_env = f_env_int("EA_LARA_FQ_B", 0);      // dev knob: tokens of the second slice (query side)
+    if (b_env > 0 && F != 96) b = b_env;
+    if (b >= 16 && b < p.N) p.tok_begin[1] = p.N - b;
   }
 }
 
