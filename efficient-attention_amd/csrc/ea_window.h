@@ -218,6 +218,10 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   return EA_OK;
 }
 
+// static geometry of the window kernels: tile counts as template constants (0 = read the tiling at run time)
+struct SGdyn { static constexpr int NQT = 0, NLT = 0, NCT = 0, WPI = 0; };
+template <int a, int b, int c, int d> struct SGs { static constexpr int NQT = a, NLT = b, NCT = c, WPI = d; };
+
 struct T4 {
   char* p;
   int64_t sb, sh, sn;

@@ -25,7 +25,13 @@ namespace ea {
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits, staged per
 // query row in LDS for phase B.
 // DR (with CA): attention dropout from an explicit keep mask (dP and the P of dV carry the mask).
-template <typename E, int D, bool GB, bool CA, bool DR>
+// SG: static geometry (round 3).  With the tile counts as runtime fields of the tiling every loop of the two phases kept its
+// bound and its local-vs-landmark selects at run time: the window loop compiled to 219 basic blocks (4.7 k instructions,
+// nothing scheduled across them).  For the geometries the models use -- 7 x 7 windows with 49 landmarks (DeiT), local
+// attention, 8 x 8 windows with 36 landmarks (PvT) -- the counts are template constants and the loops unroll into
+// straight-line code; SGdyn keeps the general kernel.
+
+template <typename E, int D, bool GB, bool CA, bool DR, typename SG>
 __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
   constexpr int CPR = D / 8;
@@ -44,18 +50,25 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   }
   const WinTiling& t = (CA && p.nq > 1) ? p.tv[qi] : p.t;
   const int bid = (CA && p.nq > 1) ? (int)blockIdx.x - p.qstart[qi] : (int)blockIdx.x;
-  const int nQTe = (t.nQT + 1) & ~1;                 // query tiles per window, padded to even
-  const int rowsQ = t.wpi * nQTe * 16;
+  constexpr bool STATIC = SG::NQT > 0;
+  const int nQT = STATIC ? SG::NQT : t.nQT, nLT = STATIC ? SG::NLT : t.nLT, nCT = STATIC ? SG::NCT : t.nCT;
+  const int wpi = STATIC ? SG::WPI : t.wpi;
+  const int nchunks = STATIC ? (SG::NLT + SG::NCT + 3) / 4 : t.nchunks;
+  const int rowsLocal = STATIC ? SG::WPI * SG::NLT * 16 : t.rowsLocal, rowsLm = STATIC ? SG::NCT * 16 : t.rowsLm;
+  const int rowsTotal = rowsLocal + rowsLm + 16;
+  const int biasLd = STATIC ? SG::NLT * 16 : t.biasLd;
+  const int nQTe = (nQT + 1) & ~1;                   // query tiles per window, padded to even
+  const int rowsQ = wpi * nQTe * 16;
   char* Ks = smem;
-  char* Vs = Ks + t.rowsTotal * ROWB;
-  char* Qs = Vs + t.rowsTotal * ROWB;
+  char* Vs = Ks + rowsTotal * ROWB;
+  char* Qs = Vs + rowsTotal * ROWB;
   char* dOs = Qs + rowsQ * ROWB;
   float* lse_s = reinterpret_cast<float*>(dOs + rowsQ * ROWB);
   float* delta_s = lse_s + rowsQ;
   // bias-gradient accumulator [Wq][BLD] and (bias_lds) the head's log2-domain bias [Wq][BLD]; the
   // odd row stride keeps both the row-wise (phase A) and the column-wise (phase B) accesses of
   // the 64 lanes on distinct banks
-  const int BLD = t.biasLd + 1;
+  const int BLD = biasLd + 1;
   float* dbias_s = delta_s + rowsQ;
   const int nbias = p.bias ? t.Wq * BLD : 0;
   float* bias_s = dbias_s + nbias;
@@ -64,16 +77,16 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   float* kmul = trash64 + 64;
   const float* bread = p.bias_lds ? bias_s : zero64;
   const int brs = p.bias_lds ? BLD : 0, btm = p.bias_lds ? 16 : 0;
-  float* kadd = kmul + t.rowsTotal;
-  int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
-  int* qd = kd + t.nLT * 16;
+  float* kadd = kmul + rowsTotal;
+  int* kd = reinterpret_cast<int*>(kadd + rowsTotal);
+  int* qd = kd + nLT * 16;
   int* qlim_s = qd + nQTe * 16;                      // CA only: last visible local slot / landmark per query row
   int* clim_s = qlim_s + rowsQ;
-  const int rowsPerWin = t.nLT * 16;
+  const int rowsPerWin = nLT * 16;
 
   constexpr bool PHASE_A_GLOBAL_BIAS = GB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  LaneOff<D> lo;
+  typename LaneOffSel<D>::type lo;       // round-3 conflict-free tile layout for D = 64 (ea_common.h)
   lo.init(lane);
   const int bh = bid / t.nblk, blk = bid - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   EA_STAMP(p, 0);
   EA_BLK(p, 0);
   // ---- once per workgroup: landmark rows, zero tile, bias-gradient accumulator ----
-  for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
+  for (int idx = tid; idx < (rowsLm + 16) * CPR; idx += 256) {
     const int row = idx / CPR, c = idx - row * CPR;
     u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
     if (row < p.L) {
@@ -108,20 +121,20 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
       vw = pack8<E>(f);
     }
-    sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
-    sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
+    sts16(Ks + TileL<D>::off(rowsLocal + row, c), kw);
+    sts16(Vs + TileL<D>::off(rowsLocal + row, c), vw);
     if (c == 0) {
-      kmul[t.rowsLocal + row] = row < p.L ? 1.f : 0.f;
-      kadd[t.rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
+      kmul[rowsLocal + row] = row < p.L ? 1.f : 0.f;
+      kadd[rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
     }
   }
   for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
   if (tid < 128) zero64[tid] = 0.f;
   if (p.bias_lds) {
-    const float* bsrc = p.bias + ((size_t)h * t.WqFull + t.qoff) * t.biasLd;
-    for (int idx = tid * 4; idx < t.Wq * t.biasLd; idx += 1024) {
+    const float* bsrc = p.bias + ((size_t)h * t.WqFull + t.qoff) * biasLd;
+    for (int idx = tid * 4; idx < t.Wq * biasLd; idx += 1024) {
       const float4 v = *reinterpret_cast<const float4*>(bsrc + idx);
-      float* d = bias_s + (idx / t.biasLd) * BLD + (idx % t.biasLd);
+      float* d = bias_s + (idx / biasLd) * BLD + (idx % biasLd);
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
@@ -152,12 +165,12 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        const bool in = idx < t.rowsLocal * CPR;
+        const bool in = idx < rowsLocal * CPR;
         const int idc = in ? idx : 0;
         const int row = idc / CPR, c = idc - row * CPR;
-        const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+        const int wi = wpi == 1 ? 0 : row / rowsPerWin;
         const int slot = row - wi * rowsPerWin;
-        const int win = it * t.wpi + wi;
+        const int win = it * wpi + wi;
         const bool live = in && win < t.nwin && slot < t.Wk;
         int oy, ox;
         win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
@@ -181,8 +194,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       for (int i = 0; i < NB; ++i) {
         if (x.rowv[i] >= 0) {
           const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
-          sts16(Ks + lds_off<D>(x.rowv[i], c), x.kr[i]);
-          sts16(Vs + lds_off<D>(x.rowv[i], c), x.vr[i]);
+          sts16(Ks + TileL<D>::off(x.rowv[i], c), x.kr[i]);
+          sts16(Vs + TileL<D>::off(x.rowv[i], c), x.vr[i]);
           if (c == 0) { kmul[x.rowv[i]] = x.mulv[i]; kadd[x.rowv[i]] = x.addv[i]; }
         }
       }
@@ -194,9 +207,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         const bool in = idx < rowsQ * CPR;
         const int idc = in ? idx : 0;
         const int row = idc / CPR, c = idc - row * CPR;
-        const int wi = t.wpi == 1 ? 0 : row / (nQTe * 16);
+        const int wi = wpi == 1 ? 0 : row / (nQTe * 16);
         const int slot = row - wi * (nQTe * 16);
-        const int win = it * t.wpi + wi;
+        const int win = it * wpi + wi;
         const bool live = in && win < t.nwin && slot < t.Wq;
         int oy, ox;
         win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
@@ -233,8 +246,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
         if (x.rowv[i] >= 0) {
           const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
-          sts16(Qs + lds_off<D>(x.rowv[i], c), x.qr[i]);
-          sts16(dOs + lds_off<D>(x.rowv[i], c), x.dr[i]);
+          sts16(Qs + TileL<D>::off(x.rowv[i], c), x.qr[i]);
+          sts16(dOs + TileL<D>::off(x.rowv[i], c), x.dr[i]);
           if (c == 0) {
             // a loss that also reads lse adds P o dlse to dS: dS = P o (dP - (delta - dlse))
             delta_s[x.rowv[i]] = part - x.dls[i]; lse_s[x.rowv[i]] = x.lsv[i];
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       commitKV(kv0, 0);
       commitQ(q0, 0);
     }
-    for (int base = 256 * NB; base < t.rowsLocal * CPR; base += 256 * NB) {
+    for (int base = 256 * NB; base < rowsLocal * CPR; base += 256 * NB) {
       KVb x;
       issueKV(x, base);
       commitKV(x, base);
@@ -268,9 +281,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     if (prof_it < 4) EA_STAMP(p, 5 + prof_it * 6);
 
     // =============================== phase A: dQ ===============================
-    for (int qi = wave; qi < t.wpi * t.nQT; qi += 4) {
-      const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
-      const int win = it * t.wpi + wi;
+    for (int qi = wave; qi < wpi * nQT; qi += 4) {
+      const int wi = qi / nQT, qt = qi - wi * nQT;
+      const int win = it * wpi + wi;
       if (win >= t.nwin) continue;
       const int qslot = qt * 16 + li;
       const int qrow = (wi * nQTe + qt) * 16 + li;
@@ -291,23 +304,23 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       ql.local = ql.lm = 0x7fffffff;
       if (CA) { ql.local = qlim_s[qrow]; ql.lm = clim_s[qrow]; }
       const float* brow = (GB && p.bias)
-          ? p.bias + ((size_t)h * t.WqFull + t.qoff + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+          ? p.bias + ((size_t)h * t.WqFull + t.qoff + (qslot < t.Wq ? qslot : 0)) * biasLd + 4 * g : nullptr;
       const float* brow_s = bread + (qslot < t.Wq ? qslot : 0) * brs + 4 * g;
       f32x4 dq[DT];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
       if (prof_it == 0) EA_STAMP(p, 20);
-      for (int ch = 0; ch < t.nchunks; ++ch) {
+      for (int ch = 0; ch < nchunks; ++ch) {
         int rowbase[4];
         uint32_t dsw[4][2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const int tile = ch * 4 + tt;
-          const bool local = tile < t.nLT;
-          rowbase[tt] = local ? (wi * t.nLT + tile) * 16
-                              : (tile < t.nLT + t.nCT ? t.rowsLocal + (tile - t.nLT) * 16
-                                                      : t.rowsLocal + t.rowsLm);
+          const bool local = tile < nLT;
+          rowbase[tt] = local ? (wi * nLT + tile) * 16
+                              : (tile < nLT + nCT ? rowsLocal + (tile - nLT) * 16
+                                                      : rowsLocal + rowsLm);
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
           const int row = rowbase[tt] + li;
 #pragma unroll
@@ -327,12 +340,12 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             b4 = make_float4(bs[0] * lf, bs[1] * lf, bs[2] * lf, bs[3] * lf);
           }
           const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-          const int kidx0 = (local ? tile : tile - t.nLT) * 16 + 4 * g;
+          const int kidx0 = (local ? tile : tile - nLT) * 16 + 4 * g;
           const int lim = local ? ql.local : ql.lm;
           uint32_t keep4 = 0x01010101u;
           if (DR) {
-            const bool real = tile < t.nLT + t.nCT;
-            const int col = local ? tile * 16 : t.biasLd + (tile - t.nLT) * 16;
+            const bool real = tile < nLT + nCT;
+            const int col = local ? tile * 16 : biasLd + (tile - nLT) * 16;
             keep4 = real ? *reinterpret_cast<const uint32_t*>(
                                p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + col + 4 * g) : 0u;
           }
@@ -371,7 +384,16 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         }
         if (prof_it == 0 && ch < 3) EA_STAMP(p, 22 + 2 * ch);
       }
-      if (qtok >= 0) {
+      if constexpr (TileL<D>::NEWTR) {
+        // accumulator pieces (channels 16 dt + 4 g ..) -> the lane's 32 contiguous bytes (all lanes take part)
+        u32x4 o0, o1;
+        quad_transpose_pack<E>(dq, p.scale, o0, o1);
+        if (qtok >= 0) {
+          char* dst = dqb + (qtok * dqsn + DQ * g) * 2;
+          stg16(dst, o0);
+          stg16(dst + 16, o1);
+        }
+      } else if (qtok >= 0) {
         float f[DQ];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -386,20 +408,21 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     if (prof_it < 4) EA_STAMP(p, 6 + prof_it * 6);
     // =============================== phase B: dK, dV ===============================
     // work items: (window wi, local tile lt) for all staged windows, then landmark tile = wave
-    const int nLocalItems = t.wpi * t.nLT;
-    for (int item = wave; item < nLocalItems + 4; item += 4) {
-      const bool is_lm = item >= nLocalItems;
+    const int nLocalItems = wpi * nLT;
+    // (is_lm as a compile-time tag: the local and the landmark items are two straight-line instances of the body)
+    auto process_item = [&](auto lm_tag, int item) {
+      constexpr bool is_lm = decltype(lm_tag)::value;
       int tile, wi_lo, wi_hi;
       if (is_lm) {
         tile = wave;                                   // landmark tile owned by this wave
-        if (tile >= t.nCT) continue;
-        wi_lo = 0; wi_hi = t.wpi;
+        if (tile >= nCT) return;
+        wi_lo = 0; wi_hi = wpi;
       } else {
-        wi_lo = item / t.nLT; wi_hi = wi_lo + 1;
-        tile = item - wi_lo * t.nLT;
-        if (it * t.wpi + wi_lo >= t.nwin) continue;
+        wi_lo = item / nLT; wi_hi = wi_lo + 1;
+        tile = item - wi_lo * nLT;
+        if (it * wpi + wi_lo >= t.nwin) return;
       }
-      const int krow = (is_lm ? t.rowsLocal + tile * 16 : (wi_lo * t.nLT + tile) * 16) + li;
+      const int krow = (is_lm ? rowsLocal + tile * 16 : (wi_lo * nLT + tile) * 16) + li;
       typename E::x8 kf[KS], vf[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       auto sweep = [&](auto bm_tag) {
         constexpr int BM = decltype(bm_tag)::value;
         for (int wi = wi_lo; wi < wi_hi; ++wi) {
-          if (it * t.wpi + wi >= t.nwin) break;
+          if (it * wpi + wi >= t.nwin) break;
           for (int qq = 0; qq < nQTe / 2; ++qq) {
             uint32_t pw[2][2], dsw[2][2];
             int rq[2];
@@ -450,7 +473,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                   // from the transposed copy in global memory: one 16-B load
                   if (kslot < t.Wk) {
                     const float4 bt4 = *reinterpret_cast<const float4*>(
-                        biasT + ((size_t)h * t.biasLd + kslot) * (ceil_div(t.WqFull, 16) * 16) + t.qoff + q0);
+                        biasT + ((size_t)h * biasLd + kslot) * (ceil_div(t.WqFull, 16) * 16) + t.qoff + q0);
                     bt[0] = bt4.x; bt[1] = bt4.y; bt[2] = bt4.z; bt[3] = bt4.w;
                   }
                 } else {
@@ -477,8 +500,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                 float km = 1.f;
                 if (DR) {
                   // 1-D windows: token of query slot qs of window wi; this lane's softmax column
-                  const int qtk = colour_win(t, p.G, p.w, it * t.wpi + wi) * p.w + t.qoff + min(qs, t.Wq - 1);
-                  const int kcol = is_lm ? t.biasLd + kslot : kslot;
+                  const int qtk = colour_win(t, p.G, p.w, it * wpi + wi) * p.w + t.qoff + min(qs, t.Wq - 1);
+                  const int kcol = is_lm ? biasLd + kslot : kslot;
                   km = p.keep[((size_t)bh * p.G.N + qtk) * p.keep_ld + kcol] ? p.keep_scale : 0.f;
                   dpr *= km;
                 }
@@ -509,26 +532,33 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         }
       };
       if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
-      else if (t.wpi == 1) sweep(std::integral_constant<int, 1>{});
+      else if (wpi == 1) sweep(std::integral_constant<int, 1>{});
       else sweep(std::integral_constant<int, 2>{});
       if (prof_it == 0) EA_STAMP(p, pb + 9);
       if (is_lm) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dlk[dt] += dk[dt]; dlv[dt] += dv[dt]; }
       } else {
-        const int win = it * t.wpi + wi_lo;
+        const int win = it * wpi + wi_lo;
         int tok = -1;
         if (kslot < t.Wk) {
           int oy, ox;
           win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
           tok = slot_token(p.G, kd[kslot], oy, ox);
         }
-        if (tok >= 0) {
-          float fk[DQ], fv[DQ];
+        float fk[DQ], fv[DQ];
+        if constexpr (TileL<D>::NEWTR) {
+          quad_transpose_f32(dk, fk);                 // (all lanes take part, before the per-token predicate)
+          quad_transpose_f32(dv, fv);
+#pragma unroll
+          for (int j = 0; j < DQ; ++j) fk[j] *= p.scale;
+        } else {
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+        }
+        if (tok >= 0) {
           if (p.acc_mode == 0) {
             char* d1 = dkb + (tok * dksn + DQ * g) * 2;
             char* d2 = dvb + (tok * dvsn + DQ * g) * 2;
@@ -562,7 +592,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           }
         }
       }
-    }
+    };
+    for (int item = wave; item < nLocalItems; item += 4) process_item(std::false_type{}, item);
+    process_item(std::true_type{}, nLocalItems + wave);
     if (prof_it == 0) EA_STAMP(p, 55);
     if (prof_it < 4) EA_STAMP(p, 7 + prof_it * 6);
     ++prof_it;
@@ -570,23 +602,23 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   EA_STAMP(p, 60);
 
   // ---- per-workgroup partial sums of the landmark and bias gradients ----
-  if (p.L > 0 && wave < t.nCT) {
+  if (p.L > 0 && wave < nCT) {
     const int lm = wave * 16 + li;
     if (lm < p.L) {
-      float* d1 = p.dlk_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
-      float* d2 = p.dlv_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D + DQ * g;
+      float* d1 = p.dlk_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D;
+      float* d2 = p.dlv_part + (((size_t)(t.blk0 + blk) * p.B * p.H + bh) * p.L + lm) * D;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        *reinterpret_cast<float4*>(d1 + 4 * dt) =
+        *reinterpret_cast<float4*>(d1 + acc_chan<D>(dt, g)) =
             make_float4(dlk[dt][0] * p.scale, dlk[dt][1] * p.scale, dlk[dt][2] * p.scale, dlk[dt][3] * p.scale);
-        *reinterpret_cast<float4*>(d2 + 4 * dt) = make_float4(dlv[dt][0], dlv[dt][1], dlv[dt][2], dlv[dt][3]);
+        *reinterpret_cast<float4*>(d2 + acc_chan<D>(dt, g)) = make_float4(dlv[dt][0], dlv[dt][1], dlv[dt][2], dlv[dt][3]);
       }
     }
   }
   if (p.bias) {
     __syncthreads();
-    float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)t.biasLd;
-    for (int idx = tid; idx < t.Wq * t.biasLd; idx += 256) dst[idx] = dbias_s[(idx / t.biasLd) * BLD + (idx % t.biasLd)];
+    float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)biasLd;
+    for (int idx = tid; idx < t.Wq * biasLd; idx += 256) dst[idx] = dbias_s[(idx / biasLd) * BLD + (idx % biasLd)];
   }
   EA_STAMP(p, 61);
   EA_BLK(p, 1);
@@ -638,9 +670,20 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
   const bool single = win_bwd_single(p0.t), merged = win_bwd_merged(p0.t);
   if (p0.keep && !p0.causal) return EA_E_UNSUPPORTED;
   auto pick = [&](const WinP& p, bool gb) -> KernelT {
-    if (p.keep) return gb ? &win_bwd_kernel<E, D, true, true, true> : &win_bwd_kernel<E, D, false, true, true>;
-    return p.causal ? (gb ? &win_bwd_kernel<E, D, true, true, false> : &win_bwd_kernel<E, D, false, true, false>)
-                    : (gb ? &win_bwd_kernel<E, D, true, false, false> : &win_bwd_kernel<E, D, false, false, false>);
+    if (p.keep) return gb ? &win_bwd_kernel<E, D, true, true, true, SGdyn> : &win_bwd_kernel<E, D, false, true, true, SGdyn>;
+    if (p.causal) return gb ? &win_bwd_kernel<E, D, true, true, false, SGdyn> : &win_bwd_kernel<E, D, false, true, false, SGdyn>;
+    if constexpr (D == 64) {
+      // static-geometry instantiations (single launch, bias table in LDS or none)
+      if (!gb && p.nq <= 1) {
+        const WinTiling& t = p.t;
+        if (t.nQT == 4 && t.nLT == 4 && t.wpi == 1) {
+          if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1>>;
+          if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1>>;
+          if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1>>;
+        }
+      }
+    }
+    return gb ? &win_bwd_kernel<E, D, true, false, false, SGdyn> : &win_bwd_kernel<E, D, false, false, false, SGdyn>;
   };
   auto launch = [&](WinP& p, size_t lds, unsigned blocks) -> int {
     const bool gb = p.bias && !p.bias_lds;

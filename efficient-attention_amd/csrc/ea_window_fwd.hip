@@ -25,7 +25,10 @@ namespace ea {
 // CA: causal_eva.py geometry (ea_geom.causal != 0): per-(query, key) visibility limits on top of the
 // per-key (mul, add) pairs.
 // DR (with CA): attention dropout from an explicit keep mask.
-template <typename E, int D, bool CA, bool DR>
+// SG: static geometry (tile counts as template constants: the query / chunk loops unroll into straight-line code; see
+// ea_window_bwd.hip) or SGdyn.
+
+template <typename E, int D, bool CA, bool DR, typename SG>
 __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const WinP p) {
   constexpr int ROWB = D * 2;      // bytes per LDS row
   constexpr int CPR = D / 8;       // 16-byte chunks per row
@@ -35,15 +38,22 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
   constexpr int NB = 2;            // staging slots per thread per batch
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WinTiling& t = p.t;
+  constexpr bool STATIC = SG::NQT > 0;
+  const int nQT = STATIC ? SG::NQT : t.nQT, nLT = STATIC ? SG::NLT : t.nLT, nCT = STATIC ? SG::NCT : t.nCT;
+  const int wpi = STATIC ? SG::WPI : t.wpi;
+  const int nchunks = STATIC ? (SG::NLT + SG::NCT + 3) / 4 : t.nchunks;
+  const int rowsLocal = STATIC ? SG::WPI * SG::NLT * 16 : t.rowsLocal, rowsLm = STATIC ? SG::NCT * 16 : t.rowsLm;
+  const int rowsTotal = rowsLocal + rowsLm + 16;
+  const int biasLd = STATIC ? SG::NLT * 16 : t.biasLd;
   char* Ks = smem;
-  char* Vs = Ks + t.rowsTotal * ROWB;
-  float* kmul = reinterpret_cast<float*>(Vs + t.rowsTotal * ROWB);
-  float* kadd = kmul + t.rowsTotal;
-  int* kd = reinterpret_cast<int*>(kadd + t.rowsTotal);
-  int* qd = kd + t.nLT * 16;
+  char* Vs = Ks + rowsTotal * ROWB;
+  float* kmul = reinterpret_cast<float*>(Vs + rowsTotal * ROWB);
+  float* kadd = kmul + rowsTotal;
+  int* kd = reinterpret_cast<int*>(kadd + rowsTotal);
+  int* qd = kd + nLT * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  LaneOff<D> lo;
+  typename LaneOffSel<D>::type lo;       // round-3 conflict-free tile layout for D = 64 (ea_common.h)
   lo.init(lane);
   const int bh = blockIdx.x / t.nblk, blk = blockIdx.x - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
@@ -52,11 +62,11 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
   const char* vb = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
   char* ob = p.o.p + (b * p.o.sb + h * p.o.sh) * 2;
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;
-  const int rowsPerWin = t.nLT * 16;
+  const int rowsPerWin = nLT * 16;
 
   // ---- once per workgroup: slot tables, landmark rows, the all-zero dummy tile ----
-  build_slot_tables(kd, qd, t, p.G, p.w, p.e, t.nQT * 16, tid);
-  for (int idx = tid; idx < (t.rowsLm + 16) * CPR; idx += 256) {
+  build_slot_tables(kd, qd, t, p.G, p.w, p.e, nQT * 16, tid);
+  for (int idx = tid; idx < (rowsLm + 16) * CPR; idx += 256) {
     const int row = idx / CPR, c = idx - row * CPR;
     u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
     if (row < p.L) {
@@ -69,11 +79,11 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
       kw = pack8<E>(f);
       vw = pack8<E>(f2);
     }
-    sts16(Ks + lds_off<D>(t.rowsLocal + row, c), kw);
-    sts16(Vs + lds_off<D>(t.rowsLocal + row, c), vw);
+    sts16(Ks + TileL<D>::off(rowsLocal + row, c), kw);
+    sts16(Vs + TileL<D>::off(rowsLocal + row, c), vw);
     if (c == 0) {
-      kmul[t.rowsLocal + row] = row < p.L ? 1.f : 0.f;
-      kadd[t.rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
+      kmul[rowsLocal + row] = row < p.L ? 1.f : 0.f;
+      kadd[rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
     }
   }
 
@@ -85,9 +95,9 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
     int qtok0 = -1;
     {
       const int qi = wave;
-      if (qi < t.wpi * t.nQT) {
-        const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
-        const int win = it * t.wpi + wi;
+      if (qi < wpi * nQT) {
+        const int wi = qi / nQT, qt = qi - wi * nQT;
+        const int win = it * wpi + wi;
         const int qslot = qt * 16 + li;
         if (win < t.nwin && qslot < t.Wq) {
           int oy, ox;
@@ -105,19 +115,19 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
       }
     }
     // ---- gather the local K/V rows of this iteration's windows (batched loads) ----
-    for (int base = 0; base < t.rowsLocal * CPR; base += 256 * NB) {
+    for (int base = 0; base < rowsLocal * CPR; base += 256 * NB) {
       u32x4 kr[NB], vr[NB];
       int rowv[NB];
       float mulv[NB], addv[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int idx = base + tid + i * 256;
-        const bool in = idx < t.rowsLocal * CPR;
+        const bool in = idx < rowsLocal * CPR;
         const int idc = in ? idx : 0;
         const int row = idc / CPR, c = idc - row * CPR;
-        const int wi = t.wpi == 1 ? 0 : row / rowsPerWin;
+        const int wi = wpi == 1 ? 0 : row / rowsPerWin;
         const int slot = row - wi * rowsPerWin;
-        const int win = it * t.wpi + wi;
+        const int win = it * wpi + wi;
         const bool live = in && win < t.nwin && slot < t.Wk;    // otherwise the slot does not exist
         int oy, ox;
         win_origin(p.G, min(win, t.nwin - 1), p.w, oy, ox);
@@ -139,17 +149,17 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
       for (int i = 0; i < NB; ++i) {
         if (rowv[i] >= 0) {
           const int c = (base + tid + i * 256) - rowv[i] * CPR;
-          sts16(Ks + lds_off<D>(rowv[i], c), kr[i]);
-          sts16(Vs + lds_off<D>(rowv[i], c), vr[i]);
+          sts16(Ks + TileL<D>::off(rowv[i], c), kr[i]);
+          sts16(Vs + TileL<D>::off(rowv[i], c), vr[i]);
           if (c == 0) { kmul[rowv[i]] = mulv[i]; kadd[rowv[i]] = addv[i]; }
         }
       }
     }
     __syncthreads();
 
-    for (int qi = wave; qi < t.wpi * t.nQT; qi += 4) {
-      const int wi = qi / t.nQT, qt = qi - wi * t.nQT;
-      const int win = it * t.wpi + wi;
+    for (int qi = wave; qi < wpi * nQT; qi += 4) {
+      const int wi = qi / nQT, qt = qi - wi * nQT;
+      const int win = it * wpi + wi;
       if (win >= t.nwin) continue;                      // wave-uniform
       const int qslot = qt * 16 + li;
       int qtok = qtok0;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
       }
       // bias is pre-multiplied by log2(e) by the caller
       const float* brow = p.bias
-          ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * t.biasLd + 4 * g : nullptr;
+          ? p.bias + ((size_t)h * t.Wq + (qslot < t.Wq ? qslot : 0)) * biasLd + 4 * g : nullptr;
 
       QLim ql;
       ql.local = ql.lm = 0x7fffffff;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-      for (int ch = 0; ch < t.nchunks; ++ch) {
+      for (int ch = 0; ch < nchunks; ++ch) {
         int rowbase[4];
         f32x4 s[4];
         float mloc = -INFINITY;
@@ -189,15 +199,15 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
         for (int tt = 0; tt < 4; ++tt) {                 // bias loads first: they overlap the MFMAs
           const int tile = ch * 4 + tt;
           b4[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (brow && tile < t.nLT) b4[tt] = *reinterpret_cast<const float4*>(brow + tile * 16);
+          if (brow && tile < nLT) b4[tt] = *reinterpret_cast<const float4*>(brow + tile * 16);
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const int tile = ch * 4 + tt;
-          const bool local = tile < t.nLT;
-          rowbase[tt] = local ? (wi * t.nLT + tile) * 16
-                              : (tile < t.nLT + t.nCT ? t.rowsLocal + (tile - t.nLT) * 16
-                                                      : t.rowsLocal + t.rowsLm);
+          const bool local = tile < nLT;
+          rowbase[tt] = local ? (wi * nLT + tile) * 16
+                              : (tile < nLT + nCT ? rowsLocal + (tile - nLT) * 16
+                                                      : rowsLocal + rowsLm);
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const int row = rowbase[tt] + li;
 #pragma unroll
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           const float bb[4] = {b4[tt].x, b4[tt].y, b4[tt].z, b4[tt].w};
-          const int kidx0 = (local ? tile : tile - t.nLT) * 16 + 4 * g;   // key slot / landmark id of r = 0
+          const int kidx0 = (local ? tile : tile - nLT) * 16 + 4 * g;   // key slot / landmark id of r = 0
           const int lim = local ? ql.local : ql.lm;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -242,8 +252,8 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt) {
             const int tile = ch * 4 + tt;
-            const bool real = tile < t.nLT + t.nCT;
-            const int col = tile < t.nLT ? tile * 16 : t.biasLd + (tile - t.nLT) * 16;
+            const bool real = tile < nLT + nCT;
+            const int col = tile < nLT ? tile * 16 : biasLd + (tile - nLT) * 16;
             const uint32_t m4 = real ? *reinterpret_cast<const uint32_t*>(krow + col) : 0u;
             float pv[4];
 #pragma unroll
@@ -272,7 +282,16 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
       // ---- finalize: normalise, store O (lane: query li, channels DQ*g .. DQ*g+DQ-1), lse ----
       const float ltot = quad_sum(lsum);
       const float inv = fast_rcp(ltot);
-      if (qtok >= 0) {
+      if constexpr (TileL<D>::NEWTR) {
+        u32x4 o0, o1;
+        quad_transpose_pack<E>(o, inv, o0, o1);           // pieces -> the lane's 32 contiguous bytes (all lanes take part)
+        if (qtok >= 0) {
+          char* dst = ob + (qtok * p.o.sn + DQ * g) * 2;
+          stg16(dst, o0);
+          stg16(dst + 16, o1);
+          if (g == 0) p.lse[((size_t)bh) * p.G.N + qtok] = (m + fast_log2(ltot)) * LN2;
+        }
+      } else if (qtok >= 0) {
         float f[DQ];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -291,23 +310,32 @@ size_t window_fwd_lds(const WinTiling& t, int D) {
   return (size_t)t.rowsTotal * D * 2 * 2 + (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + t.nQT * 16) * 4;
 }
 
-template <typename E, int D, bool CA, bool DR>
+template <typename E, int D, bool CA, bool DR, typename SG = SGdyn>
 static int launch_fwd_ca(const WinP& p, hipStream_t st) {
   const size_t lds = window_fwd_lds(p.t, D);
   if (lds > 160 * 1024) return EA_E_UNSUPPORTED;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D, CA, DR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fwd_kernel<E, D, CA, DR, SG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)(p.B * p.H * p.t.nblk));
-  hipLaunchKernelGGL((win_fwd_kernel<E, D, CA, DR>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((win_fwd_kernel<E, D, CA, DR, SG>), grid, dim3(256), lds, st, p);
   return (int)hipGetLastError();
 }
 template <typename E, int D>
 static int launch_fwd(const WinP& p, hipStream_t st) {
   if (p.keep) return p.causal ? launch_fwd_ca<E, D, true, true>(p, st) : EA_E_UNSUPPORTED;
-  return p.causal ? launch_fwd_ca<E, D, true, false>(p, st) : launch_fwd_ca<E, D, false, false>(p, st);
+  if (p.causal) return launch_fwd_ca<E, D, true, false>(p, st);
+  if constexpr (D == 64) {
+    const WinTiling& t = p.t;
+    if (t.nQT == 4 && t.nLT == 4 && t.wpi == 1) {
+      if (t.nCT == 4) return launch_fwd_ca<E, D, false, false, SGs<4, 4, 4, 1>>(p, st);
+      if (t.nCT == 3) return launch_fwd_ca<E, D, false, false, SGs<4, 4, 3, 1>>(p, st);
+      if (t.nCT == 0) return launch_fwd_ca<E, D, false, false, SGs<4, 4, 0, 1>>(p, st);
+    }
+  }
+  return launch_fwd_ca<E, D, false, false>(p, st);
 }
 
 int window_fwd_dispatch(const WinP& p, int dtype, int D, hipStream_t st) {
