@@ -383,6 +383,11 @@ template <int D> struct TileL {
     else return lds_off<D>(row, chunk16);
   }
 };
+// byte offset of the ds_read_b64_tr_b16 source of lane li (row-group lanes 4a .. 4a+3 read row r) for channel tile dt
+template <int D> EA_DEV int tile_tr(int r, int li, int dt) {
+  const int colb = TileL<D>::NEWTR ? (16 * dt + 4 * (li & 3)) * 2 : ((D / 4) * (li & 3) + 4 * dt) * 2;
+  return TileL<D>::off(r, colb >> 4) + (colb & 15);
+}
 template <int D> struct LaneOffSel { typedef LaneOff<D> type; };
 template <> struct LaneOffSel<64> { typedef LaneOff2<64> type; };
 // channel offset (within a [*, D] fp32 row) of accumulator tile dt of lane-row g

@@ -60,22 +60,40 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Round 3: the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
+  // clamped rows (no exec-mask branches), rows past the sequence are zeroed when they are committed to LDS.
+  constexpr int NSL = (64 * CPR + 255) / 256;
+  u32x4 nk[NSL], nv[NSL];
+  uint8_t nm[NSL];
+  auto issue = [&](int kc_) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = min(kc_ + row, p.N - 1);
+      nk[i] = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
+      nv[i] = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
+      nm[i] = mrow ? mrow[tok] : (uint8_t)0;
+    }
+  };
+  issue(0);
   for (int kc = 0; kc < p.N; kc += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
       const int row = idx / CPR, c = idx - row * CPR;
-      const int tok = kc + row;
-      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
-      if (tok < p.N) {
-        kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
-        vw = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
-      }
-      sts16(Ks + lds_off<D>(row, c), kw);
-      sts16(Vs + lds_off<D>(row, c), vw);
+      if (64 * CPR % 256 != 0 && idx >= 64 * CPR) continue;
+      const bool in = kc + row < p.N;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4 kw = in ? nk[i] : z, vw = in ? nv[i] : z;
+      sts16(Ks + TileL<D>::off(row, c), kw);
+      sts16(Vs + TileL<D>::off(row, c), vw);
       if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
-      if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
+      if (c == 0) dead[row] = (!in || nm[i]) ? 1 : 0;
     }
     __syncthreads();
+    if (kc + 64 < p.N) issue(kc + 64);
     f32x4 s[4];
     float mloc = -INFINITY;
 #pragma unroll
@@ -84,7 +102,7 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       const int row = tt * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+        acc = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], acc);
       const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
       float4 kb4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KB) kb4 = *reinterpret_cast<const float4*>(kb_s + tt * 16 + 4 * g);
@@ -129,22 +147,26 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-        const int c16 = colb >> 4, within = colb & 15;
-        const u32x2 lo = E::tr4(Vs + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
-        const u32x2 hi = E::tr4(Vs + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+        const u32x2 lo = E::tr4(Vs + tile_tr<D>(r0, li, dt));
+        const u32x2 hi = E::tr4(Vs + tile_tr<D>(r1, li, dt));
         o[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf4), o[dt]);
       }
     }
   }
   const float ltot = quad_sum(lsum);
-  if (qvalid) {
-    const float inv = fast_rcp(ltot);
-    float f[DQ];
+  const float inv = fast_rcp(ltot);
+  float f[DQ];
+  if constexpr (TileL<D>::NEWTR) {
+    quad_transpose_f32(o, f);                   // accumulator pieces -> the lane's contiguous channels (all lanes)
+#pragma unroll
+    for (int j = 0; j < DQ; ++j) f[j] *= inv;
+  } else {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) f[4 * dt + r] = o[dt][r] * inv;
+  }
+  if (qvalid) {
     char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + qtok * p.o.sn + DQ * g) * 2;
 #pragma unroll
     for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
@@ -195,22 +217,40 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Round 3: the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
+  // clamped rows (no exec-mask branches), rows past the sequence are zeroed when they are committed to LDS.
+  constexpr int NSL = (64 * CPR + 255) / 256;
+  u32x4 nk[NSL], nv[NSL];
+  uint8_t nm[NSL];
+  auto issue = [&](int kc_) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = min(kc_ + row, p.N - 1);
+      nk[i] = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
+      nv[i] = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
+      nm[i] = mrow ? mrow[tok] : (uint8_t)0;
+    }
+  };
+  issue(0);
   for (int kc = 0; kc < p.N; kc += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
       const int row = idx / CPR, c = idx - row * CPR;
-      const int tok = kc + row;
-      u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
-      if (tok < p.N) {
-        kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
-        vw = ldg16(vbase + (tok * p.v.sn + c * 8) * 2);
-      }
-      sts16(Ks + lds_off<D>(row, c), kw);
-      sts16(Vs + lds_off<D>(row, c), vw);
+      if (64 * CPR % 256 != 0 && idx >= 64 * CPR) continue;
+      const bool in = kc + row < p.N;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4 kw = in ? nk[i] : z, vw = in ? nv[i] : z;
+      sts16(Ks + TileL<D>::off(row, c), kw);
+      sts16(Vs + TileL<D>::off(row, c), vw);
       if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
-      if (c == 0) dead[row] = (tok >= p.N || (mrow && mrow[tok])) ? 1 : 0;
+      if (c == 0) dead[row] = (!in || nm[i]) ? 1 : 0;
     }
     __syncthreads();
+    if (kc + 64 < p.N) issue(kc + 64);
     uint32_t dsw[4][2];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
@@ -218,8 +258,8 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
       const int row = tt * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], s);
-        dp = E::mma(as_x8<E>(lds16(Vs + lds_off<D>(row, g * KS + ks))), dof[ks], dp);
+        s = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], s);
+        dp = E::mma(as_x8<E>(lds16(Vs + TileL<D>::off(row, g * KS + ks))), dof[ks], dp);
       }
       const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
       uint32_t k4 = 0;
@@ -244,20 +284,24 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
       const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-        const int c16 = colb >> 4, within = colb & 15;
-        const u32x2 lo = E::tr4(Ks + r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within);
-        const u32x2 hi = E::tr4(Ks + r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within);
+        const u32x2 lo = E::tr4(Ks + tile_tr<D>(r0, li, dt));
+        const u32x2 hi = E::tr4(Ks + tile_tr<D>(r1, li, dt));
         dq[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(f4v), dq[dt]);
       }
     }
   }
-  if (qvalid) {
-    float f[DQ];
+  float f[DQ];
+  if constexpr (TileL<D>::NEWTR) {
+    quad_transpose_f32(dq, f);
+#pragma unroll
+    for (int j = 0; j < DQ; ++j) f[j] *= p.scale;
+  } else {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[dt][r] * p.scale;
+  }
+  if (qvalid) {
     char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + qtok * p.dq.sn + DQ * g) * 2;
 #pragma unroll
     for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
@@ -313,24 +357,40 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
     kbias = -0.5f * p.scale_log2 * part;
   }
 
+  constexpr int NSL = (64 * CPR + 255) / 256;
+  u32x4 nq[NSL], nd[NSL];
+  float nl[NSL], ndl[NSL];
+  auto issue = [&](int qc_) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR, c = idx - row * CPR;
+      const int tok = min(qc_ + row, p.N - 1);
+      nq[i] = ldg16(qbase + (tok * p.q.sn + c * 8) * 2);
+      nd[i] = ldg16(dobase + (tok * p.dout.sn + c * 8) * 2);
+      nl[i] = p.lse[(size_t)bh * p.N + tok];
+      ndl[i] = p.delta[(size_t)bh * p.N + tok];
+    }
+  };
+  issue(0);
   for (int qc = 0; qc < p.N; qc += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int idx = tid + i * 256;
       const int row = idx / CPR, c = idx - row * CPR;
-      const int tok = qc + row;
-      u32x4 qw = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u};
-      if (tok < p.N) {
-        qw = ldg16(qbase + (tok * p.q.sn + c * 8) * 2);
-        dw = ldg16(dobase + (tok * p.dout.sn + c * 8) * 2);
-      }
-      sts16(Qs + lds_off<D>(row, c), qw);
-      sts16(dOs + lds_off<D>(row, c), dw);
+      if (64 * CPR % 256 != 0 && idx >= 64 * CPR) continue;
+      const bool in = qc + row < p.N;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      sts16(Qs + TileL<D>::off(row, c), in ? nq[i] : z);
+      sts16(dOs + TileL<D>::off(row, c), in ? nd[i] : z);
       if (c == 0) {
-        lse_s[row] = tok < p.N ? p.lse[(size_t)bh * p.N + tok] * LOG2E : INFINITY;
-        delta_s[row] = tok < p.N ? p.delta[(size_t)bh * p.N + tok] : 0.f;
+        lse_s[row] = in ? nl[i] * LOG2E : INFINITY;
+        delta_s[row] = in ? ndl[i] : 0.f;
       }
     }
     __syncthreads();
+    if (qc + 64 < p.N) issue(qc + 64);
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
       uint32_t pw[2][2], dsw[2][2];
@@ -340,8 +400,8 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          s = E::mma(as_x8<E>(lds16(Qs + lds_off<D>(rq + li, g * KS + ks))), kf[ks], s);
-          dp = E::mma(as_x8<E>(lds16(dOs + lds_off<D>(rq + li, g * KS + ks))), vf[ks], dp);
+          s = E::mma(as_x8<E>(lds16(Qs + TileL<D>::off(rq + li, g * KS + ks))), kf[ks], s);
+          dp = E::mma(as_x8<E>(lds16(dOs + TileL<D>::off(rq + li, g * KS + ks))), vf[ks], dp);
         }
         const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq + 4 * g);
         const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq + 4 * g);
@@ -370,10 +430,8 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
       const int r0 = 32 * qq + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int colb = (DQ * (li & 3) + 4 * dt) * 2;
-        const int c16 = colb >> 4, within = colb & 15;
-        const int o0 = r0 * ROWB + ((c16 ^ (r0 & SW)) << 4) + within;
-        const int o1 = r1 * ROWB + ((c16 ^ (r1 & SW)) << 4) + within;
+        const int o0 = tile_tr<D>(r0, li, dt);
+        const int o1 = tile_tr<D>(r1, li, dt);
         dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), as_x8<E>(a4), dv[dt]);
         dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), as_x8<E>(b4), dk[dt]);
       }
@@ -383,12 +441,19 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
     dscol += __shfl_xor(dscol, 16);
     dscol += __shfl_xor(dscol, 32);
   }
-  if (kvalid) {
-    float fk[DQ], fv[DQ];
+  float fk[DQ], fv[DQ];
+  if constexpr (TileL<D>::NEWTR) {
+    quad_transpose_f32(dk, fk);
+    quad_transpose_f32(dv, fv);
+#pragma unroll
+    for (int j = 0; j < DQ; ++j) fk[j] *= p.scale;
+  } else {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+  }
+  if (kvalid) {
     if (KB) {
       // d/dk_j of -s |k_j|^2 / 2 summed over the queries: -s k_j sum_i dS_ij (this lane's channels)
       const char* krow = p.k.p + (b * p.k.sb + h * p.k.sh + ktok * p.k.sn + DQ * g) * 2;
@@ -448,7 +513,7 @@ __global__ __launch_bounds__(256) void sm_sample_kernel(const SmP p) {
       const int tok = kc + row;
       u32x4 kw = {0u, 0u, 0u, 0u};
       if (tok < p.N) kw = ldg16(kbase + (tok * p.k.sn + c * 8) * 2);
-      sts16(Ks + lds_off<D>(row, c), kw);
+      sts16(Ks + TileL<D>::off(row, c), kw);
     }
     __syncthreads();
 #pragma unroll
@@ -457,7 +522,7 @@ __global__ __launch_bounds__(256) void sm_sample_kernel(const SmP p) {
       const int row = tt * 16 + li;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        acc = E::mma(as_x8<E>(lds16(Ks + lds_off<D>(row, g * KS + ks))), qf[ks], acc);
+        acc = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = kc + tt * 16 + 4 * g + r;
