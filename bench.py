@@ -160,7 +160,73 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
     tok_s, threads, n = max(runs)
     others = "; ".join("%d threads: %.0f tokens/s" % (t, v) for v, t, _ in runs)
     return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": "%d x fwd+bwd of the oracle layer (%s, fp32) at batch %d, N=%d, dim %d [%s]" % (n, attn, B, ntok, dim, others)}
+            "sample": "%d x fwd+bwd of the oracle layer (%s, fp32) at batch %d (the GPU line runs batch 128: a bounded sample of the same "
+                      "per-element work), N=%d, dim %d [%s]" % (n, attn, B, ntok, dim, others)}
+
+
+def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True):
+    """One more workload of BASELINE.json next to the headline one (N = 196 / 4096): the same layer step -- fwd + bwd + SGD
+    under bf16 autocast, captured in a hipGraph -- timed over `steps` replays.  Returns tokens/s and the layer-level
+    fraction of the HBM roofline (1536*h bytes per token at d = 64)."""
+    N = 1
+    for s_ in seq:
+        N *= s_
+    d = C // H
+    layer = build_layer(attn, C, H, seq, dev)
+    layer.train()
+    x = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev, requires_grad=True)
+    g = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev).to(torch.bfloat16)
+    params = list(layer.parameters())
+    big = [prm for prm in params if prm.numel() >= 16384]
+    small = [prm for prm in params if prm.numel() < 16384]
+
+    def step():
+        for prm in params:
+            prm.grad = None
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = layer(x)
+        y.backward(g)
+        for prm in big:
+            if prm.grad is not None:
+                prm.data.add_(prm.grad, alpha=-1e-3)
+        ps = [prm for prm in small if prm.grad is not None]
+        if ps:
+            torch._foreach_add_([prm.data for prm in ps], [prm.grad for prm in ps], alpha=-1e-3)
+    if tune:
+        import torch.cuda.tunable as tunable
+        tunable.tuning_enable(True)
+    for _ in range(max(warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if tune:
+        tunable.tuning_enable(False)
+    graphed = True
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            step()
+        run = gr.replay
+    except Exception:
+        torch.cuda.synchronize()
+        run, graphed = step, False
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tok_s = B * N * steps / el
+    return {"x": [B] + list(seq) + [C], "seq_len": N, "heads": H, "head_dim": d, "ms_per_step": round(el / steps * 1e3, 4),
+            "tokens_per_s": tok_s, "hipgraph": graphed,
+            "layer_hbm_roofline_frac": round(tok_s * BYTES_PER_TOKEN_HEAD * H * d / 64 / (HBM_PEAK_GBS * 1e9), 4)}
 
 
 def main():
@@ -184,6 +250,7 @@ def main():
                          "EVA, wmt_en_de encoder LARA) as a synthetic training step, eager and captured")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the cfg2 / cfg5 lines of `other_workloads`")
     ap.add_argument("--no-gemm-tune", action="store_true",
                     help="skip PyTorch TunableOp selection of the hipBLASLt/rocBLAS projection GEMMs")
     ap.add_argument("--gemm-tune-file", default=None,
@@ -410,6 +477,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # ---- spread of the measurement: five more blocks of `steps` steps each (not part of `value`) ----
+    blocks_ms = []
+    if world == 1:
+        for _ in range(5):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(a.steps):
+                run()
+            torch.cuda.synchronize()
+            blocks_ms.append((time.perf_counter() - tb) / a.steps * 1e3)
+
     # ---- the same step run EAGERLY (the reference's call sites run eagerly, vit/engine.py:47-64) ----
     for _ in range(3):
         step()
@@ -463,7 +541,19 @@ def main():
                 lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
                 sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
                 traffic = rec.get(name) if rec.get("_lib_sha256") == sha else None
-            common = {"kernel": name, "traffic": traffic, "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
+            # MFMA utilisation of that kernel from the committed SQ-counter summary (tools/pmc_sq.sh + summarize_sq.py:
+            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x 4)), same staleness rule
+            mfma_util = None
+            sqf = os.path.join(ROOT, "profiles", "sq_%s.json" % a.attn)
+            if os.path.exists(sqf):
+                import hashlib
+                rec = json.load(open(sqf))
+                lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
+                sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+                if rec.get("_lib_sha256") == sha and isinstance(rec.get(name), dict):
+                    mu = rec[name].get("mfma_util")
+                    mfma_util = None if mu is None else round(mu, 4)
+            common = {"kernel": name, "traffic": traffic, "mfma_util": mfma_util, "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
                       "all_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}}
             if name in ("ea_lara_landmarks_fwd", "ea_lara_landmarks_bwd") and _ops.LAST_LMK_GEOM:
                 # tiny-matrix pipeline in LDS (fp16-operand MFMA, ~1 % of the matrix peak): latency-bound;
@@ -496,6 +586,17 @@ def main():
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(a.attn, C, H, G)
+        # N = 196 and N = 4096 next to the headline N = 784 (north_star): cfg2 at the DeiT batch, cfg5 at the
+        # saturating batch 16 and at the faithful batch 1 (--max-tokens 4096)
+        others = None
+        if world == 1 and a.workload == "cfg3" and a.attn != "causal_eva" and not a.no_other_workloads:
+            others = {}
+            for key, (Bo, Co, Ho, so) in (("cfg2_N196", (128, 192, 3, (14, 14))), ("cfg5_N4096_B16", (16, 512, 8, (4096,))),
+                                           ("cfg5_N4096_B1", (1, 512, 8, (4096,)))):
+                try:
+                    others[key] = measure_workload(a.attn, Bo, Co, Ho, so, dev, tune=tune)
+                except Exception as ex:          # never let an extra line take the headline measurement down
+                    others[key] = {"error": str(ex).split("\n")[0][:200]}
         line = {
             "metric": "attn fwd+bwd tokens/s per GPU at N=784, d=64; 1/2/4/8-GPU DDP scaling",
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -513,6 +614,10 @@ def main():
             "layer_algorithmic_gbs": value / world * BYTES_PER_TOKEN_HEAD * H * d / 64 / 1e9,
             "hbm_measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "roofline": roof, "cpu_baseline": cpu,
+            "ms_per_step_blocks": None if not blocks_ms else {"n": len(blocks_ms), "steps_each": a.steps, "min": round(min(blocks_ms), 4),
+                                                              "median": round(sorted(blocks_ms)[len(blocks_ms) // 2], 4),
+                                                              "max": round(max(blocks_ms), 4)},
+            "other_workloads": others,
         }
     if ddp:
         dist.destroy_process_group()

@@ -17,23 +17,26 @@ KERNEL_TO_ENTRY = [
     ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("wgrad_kernel<", "ea_wgrad"), ("part_sum_kernel", "ea_part_sum"),
     ("lin_kernel<ea::BF16, 6, 2, true", "ea_linear (fp32 in)"), ("lin_kernel<", "ea_linear"),
+    ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("lara_sample_kernel<", "ea_lara_sample"), ("pool2d_", "ea_adaptive_pool2d"),
     ("sb_fwd_kernel<", "ea_scatter_fwd"), ("sb_bwd_kernel<ea::BF16, false>", "ea_scatter_bwd_window"),
     ("sb_bwd_kernel<ea::BF16, true>", "ea_scatter_bwd_global"),
-    ("lara_y_kernel<ea::BF16, 64, 3>", "ea_scatter_kmax / ea_performer_kmax"),
-    ("lara_y_kernel<ea::BF16, 64, 4>", "ea_scatter_kv / ea_performer_kv"),
-    ("lara_x_kernel<ea::BF16, 64, 4, 0>", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1>", "ea_lara_bwd_q"),
-    ("lara_x_kernel<ea::BF16, 64, 4, 2>", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3>", "ea_lara_bwd_qcorr"),
-    ("lara_y_kernel<ea::BF16, 64, 0>", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1>", "ea_lara_bwd_qstats"),
-    ("lara_y_kernel<ea::BF16, 64, 2>", "ea_lara_bwd_kstats"),
+    ("lara_y_kernel<ea::BF16, 64, 3,", "ea_scatter_kmax / ea_performer_kmax"),
+    ("lara_y_kernel<ea::BF16, 64, 4,", "ea_scatter_kv / ea_performer_kv"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 0,", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1,", "ea_lara_bwd_q"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 2,", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3,", "ea_lara_bwd_qcorr"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 4,", "ea_performer_out"), ("lara_x_kernel<ea::BF16, 64, 4, 5,", "ea_performer_bwd_q"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 6,", "ea_performer_bwd_k"),
+    ("lara_y_kernel<ea::BF16, 64, 0,", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1,", "ea_lara_bwd_qstats"),
+    ("lara_y_kernel<ea::BF16, 64, 2,", "ea_lara_bwd_kstats"), ("lara_y_kernel<ea::BF16, 64, 5,", "ea_performer_bwd_qstats"),
     ("lara_lmk_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lara_lmk_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("lara_merge_fwd_kernel", "ea_lara_merge_fwd"), ("lara_merge_bwd_kernel", "ea_lara_merge_bwd"),
     ("win_fwd_kernel<", "ea_window_attn_fwd"), ("win_bwd_finish_kernel<", "ea_window_attn_bwd(finish)"),
     ("win_bwd_kernel<", "ea_window_attn_bwd"),
     ("chunk_mean_fwd_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_kernel<", "ea_eva_beta_bwd"),
-    ("sm_fwd_kernel<ea::BF16, 64>", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dq)"),
-    ("sm_bwd_dkv_kernel<ea::BF16, 64>", "ea_softmax_attn_bwd(dkv)"),
+    ("sm_fwd_kernel<ea::BF16, 64", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64", "ea_softmax_attn_bwd(dq)"),
+    ("sm_bwd_dkv_kernel<ea::BF16, 64", "ea_softmax_attn_bwd(dkv)"),
     ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("slice_sum_kernel", "ea_slice_sum"),
     ("rows_mlp_fwd_kernel", "ea_rows_mlp_fwd"), ("rows_mlp_bwd_kernel", "ea_rows_mlp_bwd"),
