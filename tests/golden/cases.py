@@ -133,6 +133,28 @@ CASES = {
     "performer_2d": dict(
         attn="performer", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    # Performer and the clamp of its normaliser (kernelized_attention.py:55 `clamp(min=1e-2)`).  With the fixture parameters
+    # the two cases above sit ENTIRELY under the clamp (every query's denominator < 1e-2: out = numerator / 1e-2, no gradient
+    # through the denominator).  These two pin the other regimes on reference vectors: x_scale 0.55 ->
+    # about half of the queries clamped (the kink inside the batch), x_scale 0.3 -> none clamped (the full quotient rule).
+    "performer_2d_clamp": dict(
+        attn="performer", x_shape=(1, 14, 14, 128), mask=None, x_scale=0.55,
+        args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    "performer_2d_unclamped": dict(
+        attn="performer", x_shape=(1, 14, 14, 128), mask=None, x_scale=0.3,
+        args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    # ---------------- a FULLY padded batch row (local / EVA fill -5e4 and stay finite; Performer zeroes the
+    # padded features; the reference's softmax and LARA fill -inf and return NaN for such a row -- tests/test_gpu_padding.py)
+    "local_1d_fullpad": dict(
+        attn="local", x_shape=(2, 24, 128), mask=("tail", [0, 24]),
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True)),
+    "eva_1d_fullpad": dict(
+        attn="eva", x_shape=(2, 24, 128), mask=("tail", [5, 24]),
+        args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_rpe=True,
+                  num_landmarks=3, adaptive_proj="default")),
+    "performer_1d_fullpad": dict(
+        attn="performer", x_shape=(2, 24, 128), mask=("tail", [0, 24]),
+        args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
     # ---------------- causal EVA, training/evaluation path (causal_eva.py:666-790) -----
     # x is batch-first here; generator and tests transpose to the module's time-first layout
     "causal_eva_lm_small": dict(  # the wikitext-103 recipe (README.md:184) scaled down

@@ -31,11 +31,43 @@ import torch
 import cases
 from util import Fixture, scaled_err
 
+# Class ceilings (max |err| / max |ref|, rms err / rms ref) -- what DESIGN.md states for bf16 / fp16 operands.  The bound a
+# test actually applies is tol_for(): ~2x the worst error OBSERVED for that (test file, variant, dtype) on MI355X
+# (tests/golden/observed_errors.json, collected with EA_TEST_ERR_LOG by tools/tol_report.py), never
+# above the ceiling -- so a regression of a factor two fails instead of hiding under a generous class bound.
 MODULE_TOL = (4e-2, 2e-2)
 LARA_TOL = (5e-2, 2.5e-2)
 SCATTER_TOL = (8e-2, 4e-2)
 FP16_TOL = (1e-2, 5e-3)
 CORE_TOL = (2e-2, 1e-2)
+# Cases with a stated bound of their own.  performer_2d_clamp: about half of the queries sit under the clamp of the
+# normaliser (kernelized_attention.py:55), where the derivative is DISCONTINUOUS -- a query whose denominator lies within bf16
+# rounding of 1e-2 takes the other branch than the fp32 reference and its whole gradient row differs.  y agrees to 6e-3;
+# the gradients are bounded at 2x their observed error (0.069 / 0.033); the fp16 run of the same case keeps the common bound.
+CASE_TOL = {("performer_2d_clamp", "bf16"): (1.4e-1, 7e-2)}
+_OBSERVED = None
+
+
+def class_tol(attn, dtype):
+    if dtype == "fp16":
+        return FP16_TOL
+    return {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(attn, MODULE_TOL)
+
+
+def tol_for(attn, dtype, where):
+    """(max, rms) bound for variant `attn`, dtype 'bf16' | 'fp16', in test file `where` (its stem)."""
+    global _OBSERVED
+    import json
+    import os
+    if _OBSERVED is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "observed_errors.json")
+        _OBSERVED = json.load(open(path)) if os.path.exists(path) else {}
+    ceil = class_tol(attn, dtype)
+    obs = _OBSERVED.get("%s|%s|%s" % (where, attn, dtype))
+    if obs is None or os.environ.get("EA_TEST_ERR_LOG"):      # (while collecting: the class ceilings)
+        return ceil
+    floor = (4e-3, 3e-3) if dtype == "bf16" else (1e-3, 1e-3)
+    return (min(ceil[0], max(2.0 * obs[0], floor[0])), min(ceil[1], max(2.0 * obs[1], floor[1])))
 
 
 @contextlib.contextmanager
@@ -78,10 +110,8 @@ def build_module(fx, device="cuda"):
 def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None):
     fx = Fixture(name)
     if tol is None:
-        if dtype == torch.float16:
-            tol = FP16_TOL
-        else:
-            tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(fx.case["attn"], MODULE_TOL)
+        dts = "fp16" if dtype == torch.float16 else "bf16"
+        tol = CASE_TOL.get((name, dts)) or tol_for(fx.case["attn"], dts, "test_gpu_modules")
     mod = build_module(fx)
     mod.train(mode == "train")
     keep_fn = fx.keep_fn(device="cuda")

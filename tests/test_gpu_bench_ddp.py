@@ -1,0 +1,23 @@
+"""-m gpu: bench.py's N > 1 code path (process group, flat gradient bucket, RCCL all-reduce, schedule selection, barriers
+and max-over-ranks timing) executed on hardware with a single-rank RCCL group (EA_BENCH_FORCE_DDP=1) -- the driver's
+multi-GPU runs are the only other place that leg executes (VERDICT r02 weak #1e / missing #7)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_collective_leg_runs_on_a_single_rank_rccl_group():
+    env = dict(os.environ, EA_BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-other-workloads"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["ddp_schedule"] in ("pipelined", "three_part")       # the N > 1 path ran and picked a schedule
+    assert "all-reduce" in line["config"]["workload"]

@@ -55,7 +55,8 @@ def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None, keep=None, p_drop
 def test_recipe_geometry_matches_oracle(variant, dtype):
     from gpu_checks import MODULE_TOL, FP16_TOL
     from util import scaled_err
-    base = MODULE_TOL if dtype == "bf16" else FP16_TOL
+    from gpu_checks import tol_for
+    base = tol_for("causal_eva", dtype, "test_gpu_causal_eva")
     dtype = torch.bfloat16 if dtype == "bf16" else torch.float16
     p_drop = 0.1 if variant.endswith("dropout") else 0.0      # transformer_lm_wiki103's attention dropout
     if variant == "recipe_d64":

@@ -127,7 +127,8 @@ def test_one_element_matches_oracle(name):
     mr = None if mask is None else mask[sl].cpu()
     ref = oracle.module_forward(attn, dict(args), params, xr, mr, training=False)
     (ref * gy[sl].cpu()).sum().backward()
-    tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(attn, MODULE_TOL)
+    from gpu_checks import tol_for
+    tol = tol_for(attn, "bf16", "test_gpu_configs")
     for what, got, want in (("y", y.detach().float()[sl].cpu(), ref.detach()), ("dx", x.grad[sl].cpu(), xr.grad)):
         e = scaled_err(got.numpy(), want.numpy())
         assert e[0] <= tol[0] and e[1] <= tol[1], (name, what, e)

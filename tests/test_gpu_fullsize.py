@@ -142,10 +142,8 @@ def _run_case(name, dtype):
     assert [int(np.prod(s)) for s in calls] == [int(np.prod(s)) for s in ocalls], (calls, ocalls)
     (ref * gy.cpu()).sum().backward()
 
-    if dtype == torch.float16:
-        tol = FP16_TOL
-    else:
-        tol = {"lara": LARA_TOL, "scatterbrain": SCATTER_TOL}.get(attn, MODULE_TOL)
+    from gpu_checks import tol_for
+    tol = tol_for(attn, "fp16" if dtype == torch.float16 else "bf16", "test_gpu_fullsize")
     pairs = [("y", y.detach().float().cpu().numpy(), ref.detach().numpy()),
              ("dx", x.grad.float().cpu().numpy(), xr.grad.numpy())]
     for k, p in m.named_parameters():

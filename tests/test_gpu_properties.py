@@ -151,7 +151,8 @@ def test_full_batch_slice_matches_oracle(attn):
     xr = x.detach()[sl].cpu().requires_grad_(True)
     ref = oracle.module_forward(attn, bench.attn_args(attn, C, H, G), params, xr, None, training=False)
     (ref * gy[sl].cpu()).sum().backward()
-    tol = LARA_TOL if attn == "lara" else MODULE_TOL
+    from gpu_checks import tol_for
+    tol = tol_for(attn, "bf16", "test_gpu_properties")
     for name, got, want in (("y", y.detach().float()[sl].cpu(), ref.detach()), ("dx", x.grad[sl].cpu(), xr.grad)):
         e = scaled_err(got.numpy(), want.numpy())
         assert e[0] <= tol[0] and e[1] <= tol[1], (attn, name, e)

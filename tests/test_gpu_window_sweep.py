@@ -72,7 +72,8 @@ def test_geometry_matches_oracle(case, dtype):
     from util import scaled_err
     name, attn, shape, args, pads = case
     args = dict(args)
-    tol = MODULE_TOL if dtype == "bf16" else FP16_TOL
+    from gpu_checks import tol_for
+    tol = tol_for("causal_eva" if attn == "causal_eva" else attn, dtype, "test_gpu_window_sweep")
     td = torch.bfloat16 if dtype == "bf16" else torch.float16
     if attn == "causal_eva":
         args["embed"] = shape[-1]
