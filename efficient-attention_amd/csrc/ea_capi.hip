@@ -46,7 +46,7 @@ static bool t4_ok32(const ea_t4* t, int D, int N) {
 }
 static bool geom_ok(const ea_geom* g) {
   return g && g->B > 0 && g->H > 0 && g->N > 0 && (g->D == 32 || g->D == 64 || g->D == 128) &&
-         (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0 && g->causal >= 0 && g->causal <= 2;
+         (g->dtype == EA_BF16 || g->dtype == EA_F16) && g->ext >= 0 && g->causal >= 0 && g->causal <= 2 && g->lm_base >= 0;
 }
 static Geo mk_geo(const ea_geom* g) {
   Geo G;
@@ -57,7 +57,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 4; }
+int32_t ea_abi_version(void) { return 5; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -104,7 +104,7 @@ static int fill_win(const ea_geom* g, WinP& p, bool backward) {
   if (g->L < 0 || g->L > 64) return EA_E_UNSUPPORTED;      // landmark tiles owned 1:1 by 4 waves
   p.G = mk_geo(g);
   p.B = g->B; p.H = g->H; p.L = g->L; p.w = g->window; p.e = g->ext;
-  p.causal = g->causal; p.chunk = g->chunk;
+  p.causal = g->causal; p.chunk = g->chunk; p.lm_base = g->causal == 2 ? g->lm_base : 0;
   p.scale = g->scale;
   p.scale_log2 = g->scale * LOG2E;
   return EA_OK;

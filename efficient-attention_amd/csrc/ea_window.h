@@ -245,6 +245,7 @@ struct WinP {
   Geo G;
   int B, H, L, w, e;
   int causal, chunk;                         // ea_geom.causal and the landmark chunk length (causal masks)
+  int lm_base;                               // ea_geom.lm_base: landmarks before the call's first token (decoding)
   float scale, scale_log2;
   WinTiling t;
   // attention dropout (causal_eva.py:778): keep mask [B,H,N,keep_ld] u8 over the softmax columns of a
@@ -302,12 +303,12 @@ EA_DEV int colour_win(const WinTiling& t, const Geo& G, int w, int lw) {
 // landmark.  A padded query sees no local key (:742-755); with the causal masks, query slot i sees
 // local slots j <= i + e (:767-773) and the landmarks of the chunks before its own (:716-738).
 struct QLim { int local, lm; };
-EA_DEV QLim query_limits(int causal, int qslot, int qtok, int e, int chunk, const uint8_t* mrow) {
+EA_DEV QLim query_limits(int causal, int qslot, int qtok, int e, int chunk, const uint8_t* mrow, int lm_base = 0) {
   QLim r;
   r.local = 0x7fffffff; r.lm = 0x7fffffff;
   if (causal >= 2) {
     r.local = qslot + e;
-    r.lm = (qtok >= 0 && chunk > 0) ? qtok / chunk - 1 : -1;
+    r.lm = (qtok >= 0 && chunk > 0) ? lm_base + qtok / chunk - 1 : -1;
   }
   if (qtok < 0 || (mrow && mrow[qtok])) r.local = -1;
   return r;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         const bool has = tok >= 0;
         const int tc = has ? tok : 0;
         x.rowv[i] = in ? row : -1;
-        if (CA && c == 0) x.lim[i] = query_limits(p.causal, t.qoff + slot, tok, p.e, p.chunk, mrow);
+        if (CA && c == 0) x.lim[i] = query_limits(p.causal, t.qoff + slot, tok, p.e, p.chunk, mrow, p.lm_base);
         const u32x4 qr = ldg16(qb + (tc * qsn + c * 8) * 2);
         const u32x4 dr = ldg16(dob + (tc * dosn + c * 8) * 2);
         const u32x4 orr = ldg16(ob + (tc * osn + c * 8) * 2);

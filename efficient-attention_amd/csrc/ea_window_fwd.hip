@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
 
       QLim ql;
       ql.local = ql.lm = 0x7fffffff;
-      if (CA) ql = query_limits(p.causal, qslot, qtok, p.e, p.chunk, mrow);
+      if (CA) ql = query_limits(p.causal, qslot, qtok, p.e, p.chunk, mrow, p.lm_base);
 
       float m = -INFINITY, lsum = 0.f;
       f32x4 o[DT];

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 4          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 5          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -30,7 +30,7 @@ class ea_geom(ctypes.Structure):
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("attn_2d", ctypes.c_int32),
                 ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32),
                 ("ext", ctypes.c_int32), ("chunk", ctypes.c_int32), ("L", ctypes.c_int32),
-                ("scale", ctypes.c_float), ("causal", ctypes.c_int32)]
+                ("scale", ctypes.c_float), ("causal", ctypes.c_int32), ("lm_base", ctypes.c_int32)]
 
 
 class ea_perf_geom(ctypes.Structure):
@@ -211,10 +211,10 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0, causal=0):
+def make_geom(B, H, N, D, dtype, attn_2d, seq_shape, window, ext, chunk=0, L=0, causal=0, lm_base=0):
     gh, gw = (seq_shape if attn_2d else (1, N))
     return ea_geom(B, H, N, D, dtype, 1 if attn_2d else 0, gh, gw, window, ext, chunk, L,
-                   float(D) ** -0.5, causal)
+                   float(D) ** -0.5, causal, lm_base)
 
 
 class KernelTimer:

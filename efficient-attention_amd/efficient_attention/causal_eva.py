@@ -139,9 +139,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         """query/key/value: Time x Batch x Channel; key_padding_mask: [B, T], 1 = pad.
         Returns (out [T, B, C], None)."""
         if incremental_state is not None:
-            raise NotImplementedError(
-                "CausalEVAttention: token-by-token decoding with an incremental state "
-                "(causal_eva.py:542-665) is not part of the MI355X build yet")
+            return self._decode(query, key_padding_mask, incremental_state)
         if self.adaptive_proj not in ("qk", "no-ln"):
             raise NotImplementedError("Other adaptive projection methods are not implemented yet.")
         tgt_len, bsz, embed_dim = query.shape
@@ -190,6 +188,112 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             y = y.to(query.dtype)
         if N != tgt_len:
             y = y[:tgt_len]
+        return y.contiguous(), None
+
+    # ---- incremental decoding (reference :537-665) ------------------------------------------
+    def _decode(self, query, key_padding_mask, incremental_state):
+        """Token-by-token decoding with fairseq's incremental state.
+
+        The reference's branch for this (causal_eva.py:537-665) cannot run as shipped -- `N` and `B` are bound only when
+        `incremental_state is None` (:503-509), so any call with a state raises -- and what it sketches (a sliding window of
+        the last `window_size` keys) would not agree with the module's own training path (block windows with a left
+        extension).  This build therefore defines decoding by PREFIX CONSISTENCY with the pinned full-sequence path: the
+        output for token t equals row t of `forward()` on the tokens 0..t (tests/test_gpu_causal_eva.py).  State, all
+        batch-first so that `reorder_incremental_state` can index it:
+            qkv       [B, cap, 3, h, d]   projected rows of every token so far (16-bit; the window needs the last w + e,
+                                          a chunk its own rows)
+            rf_k_bar  [B, h, Lcap, d]     fp32, the landmark keys of the COMPLETED chunks (:588-634)
+            beta      [B, h, Lcap, d]     fp32, their control variates
+            pos       [B]                 tokens decoded so far
+        A step projects the new token, closes a chunk when one completes (chunk means -> mu networks -> beta, the same HIP
+        entry points as the full path on the chunk's rows) and runs the window kernel of the training path on the suffix
+        [previous window, current window] against the landmarks of all completed chunks (`ea_geom.lm_base` re-bases the
+        chunk visibility rule of :716-738); rows after the current token are masked."""
+        if not self.self_attention:
+            raise NotImplementedError("incremental decoding of encoder-decoder attention")
+        if not self.causal:
+            raise NotImplementedError("incremental decoding needs --causal: without the causal masks every query of the "
+                                      "training path sees the landmarks of future chunks (causal_eva.py:716-738)")
+        if self.training:
+            raise NotImplementedError("incremental decoding in training mode")
+        if self.adaptive_proj not in ("qk", "no-ln"):
+            raise NotImplementedError("Other adaptive projection methods are not implemented yet.")
+        _ops.nv.require_cuda(query, "query")                       # (before any state is built: no CPU fallback)
+        if key_padding_mask is not None and bool(key_padding_mask.any()):
+            raise NotImplementedError("padded positions during incremental decoding")
+        T_new, B, C = query.shape
+        w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
+        r = self.chunk_size
+        if r is None:
+            raise NotImplementedError("incremental decoding needs --chunk-size (with --num-chunks the chunk length "
+                                      "depends on the final sequence length)")
+        dev = query.device
+        state = self._get_input_buffer(incremental_state)
+        qkv_new = self._project(query, None, None)                 # [T_new, B, 3, h, d]
+        if "qkv" not in state:
+            cap = max(2 * w, 64)
+            state["qkv"] = torch.zeros((B, cap, 3, h, d), dtype=qkv_new.dtype, device=dev)
+            lcap = max(cap // r, 1)
+            state["rf_k_bar"] = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
+            state["beta"] = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
+            state["pos"] = torch.zeros((B,), dtype=torch.long, device=dev)
+            self.set_incremental_state(incremental_state, "attn_pos", 0)
+        # (the token count also lives on the host, under its own key of the incremental state -- reading `pos` back would
+        #  synchronise every step, and reorder_incremental_state only touches the tensors of the buffer)
+        t0 = int(self.get_incremental_state(incremental_state, "attn_pos") or 0)
+        if state["qkv"].shape[0] != B:
+            raise RuntimeError("incremental state holds batch %d, the step has %d" % (state["qkv"].shape[0], B))
+        need = ((t0 + T_new + w - 1) // w) * w
+        if need > state["qkv"].shape[1]:
+            cap = max(need, 2 * state["qkv"].shape[1])
+            grown = torch.zeros((B, cap, 3, h, d), dtype=state["qkv"].dtype, device=dev)
+            grown[:, :state["qkv"].shape[1]] = state["qkv"]
+            state["qkv"] = grown
+            lcap = cap // r
+            for name in ("rf_k_bar", "beta"):
+                g2 = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
+                g2[:, :, :state[name].shape[2]] = state[name]
+                state[name] = g2
+        cache = state["qkv"]
+        cache[:, t0:t0 + T_new] = qkv_new.transpose(0, 1)
+        bias = None
+        if self.use_t5_rpe:
+            bias = self.rel_pos_bias.dense(w, w + e, dev).expand(h, w, w + e)
+        mlp = self._mu_params()
+        adaptive = "default" if self.adaptive_proj == "qk" else "no-ln"
+        io = _ops.nv.io_dtype(cache)
+        outs = []
+        for i in range(T_new):
+            t = t0 + i
+            # ---- landmarks of the chunks before this token's own (completed at the previous steps) ----
+            nvis = t // r
+            b = t // w
+            b0 = max(b - 1, 0) if e > 0 else b
+            Nc = (b - b0 + 1) * w
+            ctx = cache[:, b0 * w:b0 * w + Nc]                      # [B, Nc, 3, h, d] view
+            mask = torch.zeros((B, Nc), dtype=torch.uint8, device=dev)
+            mask[:, t - b0 * w + 1:] = 1                            # rows after the current token: not decoded yet
+            geom = _ops.nv.make_geom(B, h, Nc, d, io, False, (Nc,), w, e, r, nvis, 2, (b0 * w) // r)
+            lk = state["rf_k_bar"][:, :, :nvis].contiguous() if nvis else None
+            lv = state["beta"][:, :, :nvis].contiguous() if nvis else None
+            bias_p = _ops._bias_padded(bias, geom)
+            out, _ = _ops._window_fwd(geom, ctx, lk, lv, bias_p, mask)
+            outs.append(out[:, t - b0 * w])                         # [B, h, d]
+            # ---- this token closes chunk c: its landmark becomes visible from the next chunk on ----
+            if (t + 1) % r == 0:
+                c = t // r
+                sub = cache[:, c * r:(c + 1) * r]
+                icfg = [0, r, 0, r, 0, r, 1, 1, 0]
+                res = torch.ops.ea.eva_fwd(sub, None, None, None, None, icfg, [1.0, 1.0], adaptive, list(mlp))
+                state["beta"][:, :, c] = res[6][:, :, 0]
+                state["rf_k_bar"][:, :, c] = res[7][:, :, 0]
+        self.set_incremental_state(incremental_state, "attn_pos", t0 + T_new)
+        state["pos"] = state["pos"] + T_new
+        self._set_input_buffer(incremental_state, state)
+        o = torch.stack(outs, 0).reshape(T_new, B, C)               # [T_new, B, h*d]
+        y = _ops.linear(o, self.out_proj)
+        if not torch.is_autocast_enabled() and y.dtype != query.dtype:
+            y = y.to(query.dtype)
         return y.contiguous(), None
 
     def _dropout_keep(self, B, h, N, Wk, L, device):

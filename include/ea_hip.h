@@ -64,6 +64,11 @@ typedef struct {
                               * 2: 1 plus the causal masks -- local key j of query i is masked when
                               *    j > i + e (:767-773) and landmark c unless c < token / chunk (:716-738).
                               * Masked logits are REPLACED by -5e4 (masked_fill), their gradient is zero. */
+  int32_t lm_base;           /* causal == 2 only: landmarks that lie BEFORE the tokens of this call and are visible to
+                              * every query -- landmark c is masked unless c < lm_base + token / chunk.  0 for a whole
+                              * sequence; incremental decoding (causal_eva.py:537-665) runs the suffix [previous window,
+                              * current window] against the landmarks of all completed chunks with lm_base = first chunk
+                              * of that suffix. */
 } ea_geom;
 
 /* ---- library info -------------------------------------------------------------------- */

@@ -121,7 +121,7 @@ def _causal_eva(**over):
 
 def test_causal_eva_flags_and_loud_failures():
     """causal_eva.py:905-916 flag defaults with fairseq's decoder prefix; the paths this build
-    does not carry (incremental decoding, quantization noise) raise instead of
+    does not carry (quantization noise, decoding without the causal masks) raise instead of
     computing something else, and CPU tensors never reach a kernel."""
     parser = argparse.ArgumentParser()
     parser = ea.AttentionFactory.add_attn_specific_args(parser, "causal_eva", struct_name="attn_args_decoder",
@@ -137,8 +137,14 @@ def test_causal_eva_flags_and_loud_failures():
     x = torch.randn(16, 2, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _causal_eva().eval()(x, x, x)
-    with pytest.raises(NotImplementedError, match="incremental"):
+    # incremental decoding is a HIP path too (tests/test_gpu_causal_eva.py): a CPU tensor fails loudly, and the cases the
+    # build cannot pin against the full-sequence path (no --causal, training mode) raise
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         _causal_eva().eval()(x[:1], x[:1], x[:1], incremental_state={})
+    with pytest.raises(NotImplementedError, match="incremental"):
+        _causal_eva(attn_args=dict(causal=False)).eval()(x[:1], x[:1], x[:1], incremental_state={})
+    with pytest.raises(NotImplementedError, match="incremental"):
+        _causal_eva().train()(x[:1], x[:1], x[:1], incremental_state={})
     with pytest.raises(NotImplementedError, match="quantization"):
         _causal_eva(q_noise=0.1)
     with pytest.raises(AssertionError):

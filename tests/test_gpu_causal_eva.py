@@ -206,3 +206,76 @@ def test_separate_key_value_inputs():
     assert (xa.grad - xb.grad).abs().max().item() <= 2e-2 * scale      # three bf16 dgrad GEMMs summed vs one
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert (p1.grad - p2.grad).abs().max().item() <= 2e-2 * max(p1.grad.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_d64", "no_rpe_noln"])
+def test_incremental_decoding_equals_full_forward(variant):
+    """Token-by-token decoding with fairseq's incremental state (reference causal_eva.py:537-665, dead code there: `N`
+    unbound) reproduces the pinned full-sequence causal path row by row -- the definition this build gives it
+    (causal_eva.py::_decode).  Checked on the recipe geometry (w = 128, chunks of 8, T5 bias) at d = 64 and d = 128, with
+    left-extended windows, and without the bias / LayerNorm; chunks of several steps at once; beam reordering."""
+    aa = dict(RECIPE)
+    embed, heads, T, B = 512, 8, 300, 2
+    if variant == "recipe_d128":
+        embed, heads, T = 1024, 8, 200
+    elif variant == "overlap_d64":
+        aa.update(overlap_window=True, window_size=32)
+        T = 150
+    elif variant == "no_rpe_noln":
+        aa.update(use_t5_rpe=False, adaptive_proj="no-ln", window_size=64, chunk_size=16)
+        T = 200
+    m = _build(embed, heads, aa)
+    torch.manual_seed(11)
+    x = torch.randn(T, B, embed, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full, _ = m(x, x, x)
+        state = {}
+        m.init_incremental_state()
+        rows = []
+        t = 0
+        for step in (1, 1, 1, 5, 1, 2, 64, 1, 1, 7):             # single tokens and several at once
+            while t < T and step:
+                n = min(step, T - t)
+                y, _ = m(x[t:t + n], x[t:t + n], x[t:t + n], incremental_state=state)
+                rows.append(y)
+                t += n
+                break
+        while t < T:
+            y, _ = m(x[t:t + 1], x[t:t + 1], x[t:t + 1], incremental_state=state)
+            rows.append(y)
+            t += 1
+    inc = torch.cat(rows, 0)
+    assert inc.shape == full.shape
+    err = (inc.float() - full.float()).abs().max().item()
+    ref = full.float().abs().max().item()
+    assert err <= 2e-2 * ref, (variant, err, ref)               # same kernels on the same rows: bf16 rounding of `out` only
+
+
+@pytest.mark.gpu
+def test_incremental_state_reorders_with_the_beam():
+    aa = dict(RECIPE, window_size=32)
+    m = _build(256, 4, aa)
+    torch.manual_seed(5)
+    x = torch.randn(40, 3, 256, device="cuda")
+    order = torch.tensor([2, 0, 0], device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        st = {}
+        m.init_incremental_state()
+        for t in range(20):
+            m(x[t:t + 1], x[t:t + 1], x[t:t + 1], incremental_state=st)
+        m.reorder_incremental_state(st, order)
+        xr = x[:, order]
+        ys = [m(xr[t:t + 1], xr[t:t + 1], xr[t:t + 1], incremental_state=st)[0] for t in range(20, 40)]
+        full, _ = m(xr, xr, xr)
+    inc = torch.cat(ys, 0)
+    assert (inc.float() - full[20:].float()).abs().max().item() <= 2e-2 * full.float().abs().max().item()
+
+
+@pytest.mark.gpu
+def test_incremental_decoding_refuses_what_it_cannot_pin():
+    aa = dict(RECIPE, causal=False)
+    m = _build(256, 4, aa)
+    x = torch.randn(1, 2, 256, device="cuda")
+    with pytest.raises(NotImplementedError):
+        m(x, x, x, incremental_state={})
