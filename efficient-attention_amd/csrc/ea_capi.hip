@@ -57,7 +57,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 5; }
+int32_t ea_abi_version(void) { return 6; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -1076,6 +1076,156 @@ int ea_scatter_fwd(const ea_sb_geom* g, const ea_t4* q, const ea_t4* k, const ea
   p.q = mks(q); p.k = mks(k); p.v = mks(v); p.oloc = mks(oloc); p.out = mks(out); p.mask = mask; p.Wf = W;
   p.mx = mx; p.zall = zall; p.sall = sall; p.lse_loc = lse_loc; p.r = r;
   return sb_fwd_dispatch(p, g->dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- composite per-module entry points (round 3): one call = the whole LARA core forward, one = the whole backward ----
+// The reference's call sites run eagerly (vit/engine.py:47-64); issued from Python the core was ~15 C-ABI calls and ~30
+// tensor allocations per step.  Here the launch sequence lives in C++ and every intermediate sits in two caller-owned
+// workspaces (`saved`: what the backward needs again; `tmp`: scratch of one direction) whose sizes ea_lara_layer_ws reports.
+namespace {
+struct LaraLayerPlan {
+  ea_geom pg;            // pooling geometry (uniform r x r average pooling of q, k: lara.py:43,48,145-151)
+  ea_lmk_geom lg;        // landmark pipeline
+  ea_lara_geom g;        // estimator
+  int L, C, BH, S_fwd, S_bwd;
+  // offsets (floats) into the saved workspace
+  size_t o_omega, o_qrows, o_bhv, o_cst, o_kv, o_lsek, o_lset, o_pq, o_pk, o_lmk, o_tok, n_saved;
+  // forward scratch: lp, p_ml, p_kv
+  size_t f_lp, f_ml, f_kv, n_ftmp;
+  // backward scratch: p_ml, p_acc[4], big[4], small[4], d_omega, dpq, dpk, dW, dvec
+  size_t b_ml, b_acc, b_big, b_small, b_dom, b_dpq, b_dpk, b_dW, b_dvec, n_btmp;
+};
+size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }       // 16-byte aligned sub-buffers
+int lara_layer_plan(const ea_lara_layer* c, LaraLayerPlan& P) {
+  if (!c || c->B <= 0 || c->H <= 0 || c->gh <= 0 || c->gw <= 0 || c->pool_r <= 0 || c->gh % c->pool_r || c->gw % c->pool_r)
+    return EA_E_BADARG;
+  const int N = c->gh * c->gw;
+  P.L = (c->gh / c->pool_r) * (c->gw / c->pool_r);
+  P.C = P.L * (c->dup ? 2 : 1);
+  P.BH = c->B * c->H;
+  if (P.C > 64 || P.L > 64) return EA_E_UNSUPPORTED;        // larger sample counts: the step-by-step entry points
+  ea_geom pg = {};
+  pg.B = c->B; pg.H = c->H; pg.N = N; pg.D = c->D; pg.dtype = c->dtype; pg.attn_2d = 1; pg.gh = c->gh; pg.gw = c->gw;
+  pg.window = c->pool_r; pg.ext = 0; pg.chunk = c->pool_r; pg.L = P.L; pg.scale = c->scale; pg.causal = 0; pg.lm_base = 0;
+  P.pg = pg;
+  ea_lmk_geom lg = {};
+  lg.BH = P.BH; lg.L = P.L; lg.C = P.C; lg.D = c->D; lg.has_mlp = c->has_mlp; lg.mixed = c->mixed; lg.mis = c->mis;
+  lg.dup = c->dup; lg.scale = c->scale; lg.eva = 0;
+  P.lg = lg;
+  ea_lara_geom g = {};
+  g.B = c->B; g.H = c->H; g.N = N; g.D = c->D; g.dtype = c->dtype; g.C = P.C; g.mis = c->mis; g.kappa = c->kappa; g.scale = c->scale;
+  P.g = g;
+  P.S_fwd = ea_lara_parts(&g);
+  P.S_bwd = ea_lara_fused_parts(&g);
+  if (P.S_fwd <= 0 || P.S_bwd <= 0) return EA_E_UNSUPPORTED;
+  const size_t CD = (size_t)P.BH * P.C * c->D, Cs = (size_t)P.BH * P.C, LD = (size_t)P.BH * P.L * c->D;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += al4(n); return at; };
+  P.o_omega = take(CD); P.o_qrows = take(CD); P.o_bhv = take(Cs); P.o_cst = take(Cs); P.o_kv = take(CD);
+  P.o_lsek = take(Cs); P.o_lset = take(Cs); P.o_pq = take(LD); P.o_pk = take(LD);
+  const int64_t ls = ea_lara_landmarks_saved_floats(&lg);
+  if (ls < 0) return EA_E_UNSUPPORTED;
+  P.o_lmk = take((size_t)ls); P.o_tok = take((size_t)2 * P.BH * N);
+  P.n_saved = o;
+  o = 0;
+  P.f_lp = take(Cs); P.f_ml = take(Cs * P.S_fwd * 4); P.f_kv = take(CD * P.S_fwd);
+  P.n_ftmp = o;
+  o = 0;
+  P.b_ml = take(Cs * P.S_bwd * 4); P.b_acc = take(4 * CD * P.S_bwd); P.b_big = take(4 * CD); P.b_small = take(4 * Cs);
+  P.b_dom = take(CD); P.b_dpq = take(LD); P.b_dpk = take(LD);
+  P.b_dW = take((size_t)P.BH * 2 * c->D * c->D); P.b_dvec = take((size_t)P.BH * 6 * c->D);
+  P.n_btmp = o;
+  return EA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t ea_lara_layer_ws(const ea_lara_layer* c, int32_t which) {
+  LaraLayerPlan P;
+  const int rc = lara_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  return (int64_t)(which == 0 ? P.n_saved : (which == 1 ? P.n_ftmp : P.n_btmp));
+}
+
+int ea_lara_layer_fwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                      const float* noise, const float* const* params, const ea_t4* out, float* saved, float* tmp,
+                      int32_t keep_for_backward, void* stream) {
+  LaraLayerPlan P;
+  int rc = lara_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  if (!saved || !tmp || (c->has_mlp && !params)) return EA_E_BADARG;
+  const float* pr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (c->has_mlp) for (int i = 0; i < 8; ++i) pr[i] = params[i];
+  const bool opt = c->mis == EA_MIS_OPT;
+  float* omega = saved + P.o_omega;
+  float* qrows = c->mis != EA_MIS_BH ? saved + P.o_qrows : nullptr;
+  float* bhv = opt ? saved + P.o_bhv : nullptr;
+  float* lse_t = opt ? saved + P.o_lset : nullptr;
+  float* pq = saved + P.o_pq; float* pk = saved + P.o_pk;
+  rc = ea_eva_chunk_mean_fwd(&P.pg, q, k, nullptr, pq, pk, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_lara_landmarks_fwd(&P.lg, pq, pk, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], noise, omega, qrows, bhv,
+                             tmp + P.f_lp, keep_for_backward ? saved + P.o_lmk : nullptr, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_lara_stats_fwd(&P.g, q, k, v, mask, omega, qrows, tmp + P.f_ml, tmp + P.f_kv, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_lara_merge_fwd(P.BH, P.S_fwd, P.C, c->D, opt ? 1 : 0, tmp + P.f_ml, tmp + P.f_kv, tmp + P.f_lp, saved + P.o_kv,
+                         saved + P.o_lsek, lse_t, saved + P.o_cst, stream);
+  if (rc != EA_OK) return rc;
+  float* tok = keep_for_backward ? saved + P.o_tok : nullptr;
+  return ea_lara_out_fwd(&P.g, q, omega, qrows, saved + P.o_kv, lse_t, bhv, saved + P.o_cst, out, tok,
+                         tok ? tok + (size_t)P.BH * P.g.N : nullptr, stream);
+}
+
+int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                      const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                      const ea_t4* dv, const float* saved, float* tmp, float* dparams, void* stream) {
+  LaraLayerPlan P;
+  int rc = lara_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  if (!saved || !tmp || (c->has_mlp && (!params || !dparams))) return EA_E_BADARG;
+  const float* pr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (c->has_mlp) for (int i = 0; i < 8; ++i) pr[i] = params[i];
+  const bool opt = c->mis == EA_MIS_OPT;
+  const int D = c->D;
+  const size_t CD = (size_t)P.BH * P.C * D, Cs = (size_t)P.BH * P.C;
+  const float* omega = saved + P.o_omega;
+  const float* qrows = c->mis != EA_MIS_BH ? saved + P.o_qrows : nullptr;
+  const float* bhv = opt ? saved + P.o_bhv : nullptr;
+  const float* lse_t = opt ? saved + P.o_lset : nullptr;
+  const float* kv = saved + P.o_kv;
+  const float* tok = saved + P.o_tok;
+  float* p_ml = tmp + P.b_ml;
+  float* acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = tmp + P.b_acc + (size_t)i * CD * P.S_bwd;
+  float *dkv = tmp + P.b_big, *dom_q = dkv + CD, *dqbar_m = dom_q + CD, *uq = dqbar_m + CD;
+  float *r = tmp + P.b_small, *dbh = r + Cs, *dlp_m = dbh + Cs, *dkk = dlp_m + Cs;
+  rc = ea_lara_bwd_q_fused(&P.g, q, dout, omega, qrows, kv, lse_t, bhv, saved + P.o_cst, tok, tok + (size_t)P.BH * P.g.N, dq, p_ml,
+                           acc[0], acc[1], acc[2], acc[3], stream);
+  if (rc != EA_OK) return rc;
+  const bool want_dqbar = c->mis == EA_MIS_OPT || c->mis == EA_MIS_BIASED;
+  rc = ea_lara_merge_bwd(P.BH, P.S_bwd, P.C, D, opt ? 1 : 0, c->scale, p_ml, acc[0], acc[1], acc[2], acc[3], kv, qrows, r, dbh,
+                         dlp_m, dkk, dkv, dom_q, want_dqbar ? dqbar_m : nullptr, opt ? uq : nullptr, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_lara_bwd_k_fused(&P.g, k, v, mask, omega, dkv, saved + P.o_lsek, dkk, r, dk, dv, acc[1], stream);
+  if (rc != EA_OK) return rc;
+  float* d_omega = tmp + P.b_dom;
+  rc = ea_slice_sum(P.BH, P.S_bwd, P.C * D, c->scale, dom_q, acc[1], d_omega, stream);
+  if (rc != EA_OK) return rc;
+  float *dpq = tmp + P.b_dpq, *dpk = tmp + P.b_dpk;
+  float* dW = c->has_mlp ? tmp + P.b_dW : nullptr;
+  float* dvec = c->has_mlp ? tmp + P.b_dvec : nullptr;
+  rc = ea_lara_landmarks_bwd(&P.lg, saved + P.o_pq, saved + P.o_pk, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], noise,
+                             d_omega, want_dqbar ? dqbar_m : nullptr, opt ? dbh : nullptr, dlp_m, dpq, dpk, dW, dvec,
+                             saved + P.o_lmk, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
+  if (rc != EA_OK) return rc;
+  if (c->has_mlp) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
+  return rc;
 }
 
 }  // extern "C"

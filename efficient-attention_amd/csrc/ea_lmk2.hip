@@ -673,22 +673,20 @@ static int launch_lmk2(bool bwd, const LmkP& p, hipStream_t st) {
 }
 
 // the second-generation kernels need the forward's saved intermediates in the backward
-bool lmk2_supported(bool bwd, const LmkP& p) {
-  if (p.L > 64 || p.C > 64 || (p.D != 64 && p.D != 32)) return false;
-  if (bwd && !p.saved && (p.has_mlp || p.mixed)) return false;
-  return true;
-}
-
-int lmk2_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
+// The landmark pipeline has ONE implementation (the round-1 kernels of ea_lara_landmark.hip -- fp32 matrices in LDS, one
+// 16-wave workgroup per CU -- were retired in round 3).  A backward of a parametrised / mixed pipeline needs the workspace the
+// forward filled (`saved`): recomputing the forward inside the backward was the only thing the old kernels still offered.
+int lara_lmk_dispatch(bool bwd, const LmkP& p0, hipStream_t st) {
   LmkP p = p0;
   p.prof = nullptr;
+  if (p.L > 64 || p.C > 64 || (p.D != 64 && p.D != 32)) return EA_E_UNSUPPORTED;
+  if (bwd && !p.saved && (p.has_mlp || p.mixed)) return EA_E_BADARG;
 #ifdef EA_PROFILE
   ProfReport rep;
   p.prof = rep.arm(st, "lmk2", bwd ? 1 : 0);
 #endif
   if (p.D == 64) return launch_lmk2<64>(bwd, p, st);
-  if (p.D == 32) return launch_lmk2<32>(bwd, p, st);
-  return EA_E_UNSUPPORTED;
+  return launch_lmk2<32>(bwd, p, st);
 }
 
 }  // namespace ea

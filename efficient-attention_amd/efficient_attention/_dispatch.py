@@ -124,6 +124,9 @@ def _(qkv, mask, noise, icfg, fcfg, params):
     L = (H // r) * (W // r)
     C = L * (2 if dup else 1)
     BH = B * h
+    lcfg, sizes = _ops._lara_layer_cfg(qkv, icfg, fcfg)          # (host-side size query: works on fake tensors)
+    if lcfg is not None:
+        return [qkv.new_empty((B, N, h, d)), _f32(qkv, sizes[0])]
     return [qkv.new_empty((B, N, h, d)), _f32(qkv, BH, C, d), _f32(qkv, BH, C, d) if mis != 2 else _none(qkv),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, C), _f32(qkv, BH, C, d), _f32(qkv, BH, C),
             _f32(qkv, BH, C) if mis == 0 else _none(qkv), _f32(qkv, BH, L, d), _f32(qkv, BH, L, d),

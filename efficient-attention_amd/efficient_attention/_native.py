@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 5          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 6          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -50,6 +50,13 @@ class ea_lmk_geom(ctypes.Structure):
                 ("dup", ctypes.c_int32), ("scale", ctypes.c_float), ("eva", ctypes.c_int32)]
 
 
+class ea_lara_layer(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("D", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("pool_r", ctypes.c_int32),
+                ("has_mlp", ctypes.c_int32), ("mixed", ctypes.c_int32), ("mis", ctypes.c_int32), ("dup", ctypes.c_int32),
+                ("kappa", ctypes.c_float), ("scale", ctypes.c_float)]
+
+
 class ea_lara_geom(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("C", ctypes.c_int32),
@@ -66,6 +73,7 @@ _PG = ctypes.POINTER(ea_perf_geom)
 _MG = ctypes.POINTER(ea_lmk_geom)
 _T = ctypes.POINTER(ea_t4)
 _SG = ctypes.POINTER(ea_sb_geom)
+_LL = ctypes.POINTER(ea_lara_layer)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
 SIGNATURES = {
@@ -116,6 +124,9 @@ SIGNATURES = {
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_part_sum": [_I, _I, _L, _P, _P, _P],
+    "ea_lara_layer_ws": [_LL, _I],
+    "ea_lara_layer_fwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _P, _P, _I, _P],
+    "ea_lara_layer_bwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _P, _P, _P, _P],
     "ea_scatter_parts": [_SG],
     "ea_scatter_kmax": [_SG, _T, _P, _P, _P, _P],
     "ea_scatter_kv": [_SG, _T, _T, _P, _P, _P, _P, _P, _P],
@@ -159,6 +170,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         cdll.ea_lara_landmarks_saved_floats.restype = ctypes.c_int64
+        cdll.ea_lara_layer_ws.restype = ctypes.c_int64
         cdll.ea_version.restype = ctypes.c_char_p
         cdll.ea_abi_version.restype = ctypes.c_int32
         if cdll.ea_abi_version() != ABI_VERSION:

@@ -845,14 +845,54 @@ def _lara_cfg(qkv5, icfg, fcfg):
     return (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom
 
 
+def _lara_layer_cfg(qkv5, icfg, fcfg):
+    """ea_lara_layer of the composite entry points, or None when the geometry needs the step-by-step path (C > 64)."""
+    H, W, r, has_mlp, mixed, mis, dup = [int(v) for v in icfg[:7]]
+    kappa, scale = [float(v) for v in fcfg]
+    B, N, _, h, d = qkv5.shape
+    cfg = nv.ea_lara_layer(B, h, d, nv.io_dtype(qkv5), H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
+    sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2)]
+    # (per-kernel timing -- bench.py's instrumented pass -- needs the individual entry points)
+    if min(sizes) < 0 or os.environ.get("EA_LARA_COMPOSITE", "1") != "1" or nv.KERNEL_TIMER.enabled:
+        return None, None
+    return cfg, sizes
+
+
+def _param_ptrs(ps):
+    """const float* const params[8] for the composite entry points (kept alive by the caller)."""
+    arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in ps])
+    return arr
+
+
 def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
     """torch.ops.ea.lara_fwd: uniform r x r pooling of q, k -> fused landmark pipeline -> estimator.
     icfg = [H, W, r, has_mlp, mixed, mis, dup(, keep_for_backward = 1)], fcfg = [kappa, scale], params = (Wq,
-    bq, gq, cq, Wk, bk, gk, ck) when has_mlp.  -> [out, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise, lmk_saved]
-    (absent tensors are empty; the list ends with tokst [2,BH,N], the per-token statistics of the fused backward)."""
+    bq, gq, cq, Wk, bk, gk, ck) when has_mlp.
+    C <= 64: ONE composite C-ABI call (ea_lara_layer_fwd) on two workspaces -> [out, saved workspace].
+    Otherwise the step-by-step launch sequence -> [out, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise, lmk_saved, tokst]
+    (absent tensors are empty)."""
+    global LAST_LMK_GEOM
     nv.require_cuda(qkv5, "qkv")
-    (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
+    lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg)
     need_grad = len(icfg) < 8 or bool(icfg[7])
+    if lcfg is not None:
+        B, N, _, h, d = qkv5.shape
+        dev = qkv5.device
+        q, k, v = _qkv_views(qkv5)
+        tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+        ws = torch.empty(sizes[0], dtype=torch.float32, device=dev)
+        tmp = torch.empty(sizes[1], dtype=torch.float32, device=dev)
+        out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+        to = nv.t4(out.permute(0, 2, 1, 3))
+        noise_c = None if noise is None else noise.float().contiguous()
+        ps = [t.detach().float().contiguous() for t in params]
+        pp = _param_ptrs(ps) if ps else None
+        LAST_LMK_GEOM = (B * h, (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r),
+                         (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r) * (2 if lcfg.dup else 1), d, lcfg.has_mlp, lcfg.mixed, 0)
+        nv.call("ea_lara_layer_fwd", ctypes.byref(lcfg), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
+                nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(to), nv.ptr(ws), nv.ptr(tmp), int(need_grad), nv.stream())
+        return [out, ws]
+    (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
     B, N, _, h, d = qkv5.shape
     BH, dev = B * h, qkv5.device
     q, k, _ = _qkv_views(qkv5)
@@ -863,7 +903,6 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
             nv.ptr(pq), nv.ptr(pk), nv.stream())
     noise_c = None if noise is None else noise.float().contiguous()
     ps = [t.detach().float().contiguous() for t in params]
-    global LAST_LMK_GEOM
     LAST_LMK_GEOM = (BH, L, C, d, has_mlp, mixed, 0)
     omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
     qrows = torch.empty_like(omega) if mis != 2 else None
@@ -879,7 +918,31 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
 
 
 def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
-    """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)]."""
+    """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)].  saved_list is what lara_fwd
+    returned after `out`: the composite workspace (one tensor -> ea_lara_layer_bwd) or the step-by-step tensors."""
+    if len(saved_list) == 1:
+        lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg)
+        B, N, _, h, d = qkv5.shape
+        dev = qkv5.device
+        ws = saved_list[0]
+        dout = _rows_contiguous(dout)
+        dqkv5 = torch.empty_like(qkv5)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        ts = [nv.t4(t) for t in (q, k, v, dout.permute(0, 2, 1, 3), dq, dk, dv)]
+        tmp = torch.empty(sizes[2], dtype=torch.float32, device=dev)
+        noise_c = None if noise is None else noise.float().contiguous()
+        ps = [t.detach().float().contiguous() for t in params]
+        pp = _param_ptrs(ps) if ps else None
+        dpar = torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev) if ps else None
+        nv.call("ea_lara_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+                nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
+                ctypes.byref(ts[6]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dpar), nv.stream())
+        grads = [dqkv5]
+        if ps:
+            dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
+            grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+        return grads
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
     omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, saved, tokst = [_opt(t) for t in saved_list]
     noise_c = None if noise is None else noise.float().contiguous()

@@ -302,10 +302,10 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
  * gradients and returns d pq, d pk [BH,L,D] plus per-(b,h) partial parameter gradients
  * dW_part [BH,2,D,D] (q then k; [out][in]) and dvec_part [BH,2,3,D] (Linear bias, LN weight, LN
  * bias) which the caller sums over BH.  L, C <= 64.
- * `saved` (optional, may be NULL in both calls): workspace of ea_lara_landmarks_saved_floats(g)
- * floats in which the forward keeps its intermediates (normalised rows, LayerNorm 1/std, mixing
- * matrix, mu); a backward that is handed the same buffer reloads them instead of recomputing the
- * forward (four of its fourteen matrix products). */
+ * `saved`: workspace of ea_lara_landmarks_saved_floats(g) floats in which the forward keeps its
+ * intermediates (normalised rows, LayerNorm 1/std, mixing matrix, mu) for the backward.  NULL in a
+ * forward that will not be differentiated; the backward of a parametrised (has_mlp) or mixed pipeline
+ * REQUIRES it (EA_E_BADARG otherwise -- round 3 retired the kernels that recomputed the forward). */
 typedef struct {
   int32_t BH, L, C, D;
   int32_t has_mlp, mixed, mis, dup;
@@ -488,6 +488,33 @@ int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_feat
 int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
                   int64_t lda, const float* w, int32_t w_transposed, const float* bias, void* y, int32_t y_f32, int64_t ldy,
                   void* a_cast, void* stream);
+
+/* ---- composite per-module entry points: the whole LARA core in one call each way (round 3) --------------------
+ * lara.py:129-175,187-246 for the 2-D pooled proposals ('pool', 'pool-mixed'): uniform r x r pooling of q, k -> landmark
+ * pipeline -> estimator, i.e. the launch sequences of ea_eva_chunk_mean_fwd / ea_lara_landmarks_* / ea_lara_stats_fwd /
+ * ea_lara_merge_* / ea_lara_out_fwd / ea_lara_bwd_*_fused / ea_slice_sum / ea_lara_bwd_finish / ea_colsum2_f32 issued from
+ * C++ on caller-owned workspaces, so that an eagerly stepping caller (vit/engine.py:47-64) pays two FFI calls per layer
+ * step instead of ~15 (and two allocations instead of ~30).  C = L (x 2 with antithetic / multi-sample noise) <= 64.
+ *   ea_lara_layer_ws(cfg, which): floats of workspace 0 = `saved` (forward -> backward), 1 = forward scratch, 2 = backward
+ *       scratch (negative: EA_E_*).
+ *   params: NULL or 8 pointers (Wq, bq, gamma_q, beta_q, Wk, bk, gamma_k, beta_k: q_bar_gen / k_bar_gen, lara.py:45-54);
+ *   noise: [B*H, C, D] standard normal or NULL (eval); dparams: [2*D*D + 6*D] fp32 = dW_q, dW_k, then (db, dgamma, dbeta)
+ *   of q and of k, summed over the batch and heads. */
+typedef struct {
+  int32_t B, H, D;
+  int32_t dtype;             /* EA_BF16 | EA_F16 */
+  int32_t gh, gw;            /* token grid (N = gh * gw) */
+  int32_t pool_r;            /* pooling side: landmarks L = (gh / r) * (gw / r) */
+  int32_t has_mlp, mixed, mis, dup;   /* as in ea_lmk_geom */
+  float   kappa, scale;      /* alpha_coeff (lara.py:231), D^-0.5 */
+} ea_lara_layer;
+int64_t ea_lara_layer_ws(const ea_lara_layer* cfg, int32_t which);
+int ea_lara_layer_fwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                      const float* noise, const float* const* params, const ea_t4* out, float* saved, float* tmp,
+                      int32_t keep_for_backward, void* stream);
+int ea_lara_layer_bwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                      const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                      const ea_t4* dv, const float* saved, float* tmp, float* dparams, void* stream);
 
 /* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
  * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);

@@ -58,3 +58,22 @@ def test_version_and_argument_validation(lib):
     assert rc == -1
     odd = _native.make_geom(2, 3, 196, 48, 0, True, (14, 14), 7, 0, 2, 49)     # head dim not built
     assert _native.lib().ea_window_bias_ld(ctypes.byref(odd)) < 0
+
+
+def test_composite_layer_entry_points_report_their_workspaces(lib):
+    """ea_lara_layer_ws / _fwd / _bwd (one call per direction for the whole LARA core): sizes on the host, argument
+    validation before any launch.  The numerical check of the composite path is every LARA test of the GPU suite (the
+    module goes through it) plus tests/test_gpu_primitives.py::test_lara_composite_equals_step_by_step."""
+    from efficient_attention import _native
+    cfg = _native.ea_lara_layer(128, 3, 64, 0, 28, 28, 4, 1, 1, 0, 0, 2.0, 0.125)      # cfg3: 49 landmarks, mis-opt, pool-mixed
+    n = [lib.ea_lara_layer_ws(ctypes.byref(cfg), w) for w in (0, 1, 2)]
+    lib.ea_lara_layer_ws.restype = ctypes.c_int64
+    n = [_native.lib().ea_lara_layer_ws(ctypes.byref(cfg), w) for w in (0, 1, 2)]
+    BH, C, L, D, N = 384, 49, 49, 64, 784
+    assert n[0] >= 3 * BH * C * D + 2 * BH * L * D + 2 * BH * N and n[1] >= BH * C * D and n[2] >= 9 * BH * C * D
+    bad = _native.ea_lara_layer(128, 3, 64, 0, 28, 27, 4, 1, 1, 0, 0, 2.0, 0.125)      # grid not divisible by the pooling side
+    assert _native.lib().ea_lara_layer_ws(ctypes.byref(bad), 0) == -1
+    big = _native.ea_lara_layer(2, 3, 64, 0, 28, 28, 2, 0, 0, 0, 0, 2.0, 0.125)        # 196 landmarks: step-by-step path
+    assert _native.lib().ea_lara_layer_ws(ctypes.byref(big), 0) == -2
+    rc = _native.lib().ea_lara_layer_fwd(ctypes.byref(cfg), None, None, None, None, None, None, None, None, None, 1, None)
+    assert rc == -1

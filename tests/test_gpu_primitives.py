@@ -334,3 +334,44 @@ def test_lara_sample_matches_torch(mode, L, d, mis_type):
     rq = torch.zeros_like(q64) if rq is None else rq
     assert torch.allclose(dm.double(), rm, rtol=1e-3, atol=1e-3 * float(rm.abs().max())), float((dm.double() - rm).abs().max())
     assert torch.allclose(dq.double(), rq, rtol=1e-3, atol=1e-4 + 1e-3 * float(rq.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mis,mixed,has_mlp,dup", [(0, 1, 1, 0), (1, 0, 1, 0), (2, 1, 0, 0), (0, 0, 1, 1)])
+def test_lara_composite_equals_step_by_step(mis, mixed, has_mlp, dup):
+    """ea_lara_layer_fwd / _bwd (the whole LARA core as one C-ABI call each way, on caller-owned workspaces) against the
+    step-by-step launch sequence they replace: same kernels, same order -> bit-identical outputs and gradients."""
+    import os
+    import torch
+    from efficient_attention import _ops
+    torch.manual_seed(mis * 7 + mixed)
+    B, H, W, h, d, r = 4, 28, 28, 3, 64, 4
+    L = (H // r) * (W // r)
+    if dup:
+        B, H, W, r = 2, 16, 16, 4                       # 16 landmarks x 2 antithetic samples
+        L = 16
+    C = L * (2 if dup else 1)
+    qkv = (0.5 * torch.randn(B, H * W, 3, h, d, device="cuda")).bfloat16()
+    noise = torch.randn(B, h, C // (2 if dup == 1 else 1) if dup == 1 else C, d, device="cuda")
+    dout = torch.randn(B, H * W, h, d, device="cuda").bfloat16()
+    params = []
+    if has_mlp:
+        for _ in range(2):
+            params += [torch.randn(d, d, device="cuda") * d ** -0.5, torch.randn(d, device="cuda") * 0.1,
+                       1 + 0.1 * torch.randn(d, device="cuda"), 0.1 * torch.randn(d, device="cuda")]
+    icfg = [H, W, r, has_mlp, mixed, mis, dup, 1]
+    fcfg = [2.0, d ** -0.5]
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["EA_LARA_COMPOSITE"] = mode
+        try:
+            outs = torch.ops.ea.lara_fwd(qkv, None, noise, icfg, fcfg, params)
+            grads = torch.ops.ea.lara_bwd(dout, qkv, None, noise, list(outs[1:]), icfg, fcfg, params)
+        finally:
+            os.environ.pop("EA_LARA_COMPOSITE", None)
+        res[mode] = (len(outs), outs[0], grads)
+    assert res["1"][0] == 2 and res["0"][0] > 2          # one workspace vs the individual tensors
+    assert torch.equal(res["1"][1], res["0"][1])
+    assert len(res["1"][2]) == len(res["0"][2])
+    for a, b in zip(res["1"][2], res["0"][2]):
+        assert torch.equal(a, b)

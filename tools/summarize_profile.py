@@ -29,7 +29,6 @@ KERNEL_TO_ENTRY = [
     ("lara_x_kernel<ea::BF16, 64, 4, 6,", "ea_performer_bwd_k"),
     ("lara_y_kernel<ea::BF16, 64, 0,", "ea_lara_stats_fwd"), ("lara_y_kernel<ea::BF16, 64, 1,", "ea_lara_bwd_qstats"),
     ("lara_y_kernel<ea::BF16, 64, 2,", "ea_lara_bwd_kstats"), ("lara_y_kernel<ea::BF16, 64, 5,", "ea_performer_bwd_qstats"),
-    ("lara_lmk_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lara_lmk_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("lara_merge_fwd_kernel", "ea_lara_merge_fwd"), ("lara_merge_bwd_kernel", "ea_lara_merge_bwd"),
     ("win_fwd_kernel<", "ea_window_attn_fwd"), ("win_bwd_finish_kernel<", "ea_window_attn_bwd(finish)"),
     ("win_bwd_kernel<", "ea_window_attn_bwd"),
