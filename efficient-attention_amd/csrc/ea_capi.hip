@@ -1,6 +1,7 @@
 // ea_capi.hip -- extern "C" entry points of libea_hip.so (declared in include/ea_hip.h).
 // Argument validation and launch-parameter construction only; every kernel lives in its own
 // translation unit and is reached through a *_dispatch function.
+#include <stdlib.h>
 #include "ea_window.h"
 
 namespace ea {
@@ -25,6 +26,9 @@ int lara_f_dispatch(int which, const LaraP& p, int dtype, hipStream_t st);
 int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long sn, float* mean, int B, int H, int gh, int gw,
                     int side, int D, hipStream_t st);
 int linear_supported(int K, int NO);
+int proj_rs_supported(int K, int NO);
+int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
+                     long lda, long ldy, hipStream_t st);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
@@ -952,6 +956,10 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
       ((uintptr_t)a_cast & 15))
     return EA_E_BADARG;
   if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
+  // the qkv projection of a 192-wide model: weight resident in registers, activations through LDS once (ea_proj_rs.hip)
+  static const bool rs_on = !(getenv("EA_PROJ_RS") && getenv("EA_PROJ_RS")[0] == '0');
+  if (rs_on && !w_transposed && !y_f32 && proj_rs_supported(in_features, out_features))
+    return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream);
   return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
                          (long)lda, (long)ldy, (hipStream_t)stream);
 }

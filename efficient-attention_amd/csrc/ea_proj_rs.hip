@@ -1,0 +1,156 @@
+// ea_proj_rs.hip -- the qkv projection of a 192-wide model with the WEIGHT RESIDENT IN REGISTERS (round 3).
+//     qkv[t][o] = sum_k x[t][k] W[o][k] + b[o],   K = 192, 576 output columns, t over all B*N tokens
+// (abstract_attention.py:72-78).  ea_linear.hip keeps the weight in LDS, which at 576 x 192 needs two column parts: every
+// activation row passes the CU's load pipe twice (385 MB through the pipes for 231 MB of algorithmic traffic: 66 us).
+// Here a 12-wave workgroup (one per CU) holds the whole weight in its registers -- wave w owns the 48 output columns
+// 48 w .. 48 w + 47 as MFMA A operands, 72 VGPRs per lane, loaded once from the fp32 master weight and rounded on the way
+// -- and the activations stream through LDS exactly once: a 32-token tile is fetched by all 768 threads (one 16-byte
+// bf16 chunk each: two 16-byte fp32 loads, the autocast cast folded in; the rounded copy is written out for the
+// weight-gradient pass), double-buffered, one barrier per tile; every wave then reads the tile's rows as B operands
+// (ds_read_b128, conflict-free phi2 layout per 64-channel slab) and forms its [48 x 32] piece transposed, D[out][token].
+// The weight rows of a tile PAIR are interleaved in fours, so a lane ends up with eight consecutive columns of one token
+// (16-byte stores); the third tile of a wave gives 8-byte stores.
+#include "ea_common.h"
+
+namespace ea {
+
+struct RsP {
+  const char* a;        // [rows, 192] fp32 (AF32) or element type, row stride lda elements
+  const float* w;       // [576, 192] fp32 master weight
+  const float* bias;    // [576] fp32 or null (rounded to the element type before it is added, as F.linear under autocast does)
+  char* y;              // [rows, 576] element type, row stride ldy elements
+  char* a_cast;         // [rows, 192] element-type copy of a (AF32 only) or null
+  int rows, ntiles;
+  long lda, ldy;
+};
+
+constexpr int RS_K = 192, RS_NO = 576, RS_WAVES = 12, RS_TOK = 32, RS_KT = RS_K / 32, RS_SLABS = RS_K / 64;
+
+// LDS tile: [slab][token][64 channels] element type, phi2-swizzled 128-byte rows
+EA_DEV int rs_off(int slab, int tok, int chunk16) { return slab * (RS_TOK * 128) + lds_off2<64>(tok, chunk16); }
+
+template <typename E, bool AF32>
+__global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) {
+  __shared__ __attribute__((aligned(16))) char tile[2][RS_SLABS * RS_TOK * 128];
+  __shared__ __attribute__((aligned(16))) float bias_s[RS_NO];          // rounded to the element type
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- this thread's staging slot: token st_tok of the tile, channels 8 st_c .. 8 st_c + 7 ----
+  const int st_tok = tid / 24, st_c = tid - st_tok * 24;           // 32 tokens x 24 chunks = 768 slots
+  u32x4 nb[AF32 ? 2 : 1];
+  auto issue = [&](int t) {
+    const int tok = min(t * RS_TOK + st_tok, p.rows - 1);
+    const char* ap = p.a + (size_t)tok * p.lda * (AF32 ? 4 : 2) + st_c * (AF32 ? 32 : 16);
+    nb[0] = ldg16(ap);
+    if constexpr (AF32) nb[1] = ldg16(ap + 16);
+  };
+  int t = blockIdx.x;
+  if (t < p.ntiles) issue(t);
+  // ---- the weight slice of this wave -> registers (A operands).  MFMA row li of the tile pair (0, 1) <-> output column
+  // 8 (li >> 2) + (li & 3) [+ 4] of the wave's first 32 columns, of tile 2 <-> column 32 + li ----
+  typename E::x8 wr[3][RS_KT];
+  for (int i = tid; i < RS_NO; i += RS_WAVES * 64) bias_s[i] = p.bias ? E::to_f(E::from_f(p.bias[i])) : 0.f;
+  {
+    const int c0 = 48 * wave;
+    const int col[3] = {c0 + 8 * (li >> 2) + (li & 3), c0 + 8 * (li >> 2) + (li & 3) + 4, c0 + 32 + li};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int ks = 0; ks < RS_KT; ++ks) {
+        const float* s = p.w + (size_t)col[j] * RS_K + ks * 32 + 8 * g;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
+        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        wr[j][ks] = as_x8<E>(pack8<E>(f));
+      }
+  }
+  const int slab_s = st_c >> 3, ch_s = st_c & 7;
+  int buf = 0;
+  for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
+    // ---- commit this tile's slot: round, park in LDS, write the rounded copy ----
+    {
+      u32x4 w8;
+      if constexpr (AF32) {
+        const f32x4 lo = __builtin_bit_cast(f32x4, nb[0]), hi = __builtin_bit_cast(f32x4, nb[1]);
+        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        w8 = pack8<E>(f);
+      } else {
+        w8 = nb[0];
+      }
+      sts16(tile[buf] + rs_off(slab_s, st_tok, ch_s), w8);
+      if (AF32 && p.a_cast) {
+        const int tok = min(t * RS_TOK + st_tok, p.rows - 1);       // (clamped rows rewrite the last row with its own values)
+        stg16(p.a_cast + ((size_t)tok * RS_K + st_c * 8) * 2, w8);
+      }
+    }
+    if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x);
+    __syncthreads();
+    // ---- [48 x 32] piece of this wave ----
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < RS_KT; ++ks) {
+      const int slab = ks >> 1;                                      // 32-channel step ks = chunks 4 (ks & 1) .. + 3 of slab ks >> 1
+      const typename E::x8 b0 = as_x8<E>(lds16(tile[buf] + rs_off(slab, li, 4 * (ks & 1) + g)));
+      const typename E::x8 b1 = as_x8<E>(lds16(tile[buf] + rs_off(slab, 16 + li, 4 * (ks & 1) + g)));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[j][0] = E::mma(wr[j][ks], b0, acc[j][0]);
+        acc[j][1] = E::mma(wr[j][ks], b1, acc[j][1]);
+      }
+    }
+    // ---- store: lane (g, li) holds, for tokens li and 16 + li, columns c0 + 8 g .. + 7 (pair) and c0 + 32 + 4 g .. + 3 ----
+    const int c0 = 48 * wave;
+    // bias of the D rows 4 g + r this lane holds: pair -> columns c0 + 8 g + r (+ 4); tile 2 -> c0 + 32 + 4 g + r
+    const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bias_s + c0 + 8 * g), bv1 = *reinterpret_cast<const f32x4*>(bias_s + c0 + 8 * g + 4);
+    const f32x4 bv2 = *reinterpret_cast<const f32x4*>(bias_s + c0 + 32 + 4 * g);
+    u32x2 third[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int tok = min(t * RS_TOK + 16 * rt + li, p.rows - 1);
+      char* yp = p.y + ((size_t)tok * p.ldy + c0) * 2;
+      const f32x4 v0 = acc[0][rt] + bv0, v1 = acc[1][rt] + bv1, v2 = acc[2][rt] + bv2;
+      u32x4 o;
+      o[0] = pack2<E>(v0[0], v0[1]); o[1] = pack2<E>(v0[2], v0[3]);
+      o[2] = pack2<E>(v1[0], v1[1]); o[3] = pack2<E>(v1[2], v1[3]);
+      stg16(yp + 16 * g, o);
+      third[rt] = u32x2{pack2<E>(v2[0], v2[1]), pack2<E>(v2[2], v2[3])};
+    }
+    // third tile: lane-row g holds columns c0 + 32 + 4 g .. + 3 of tokens li (rt 0) and 16 + li (rt 1).  Lane-rows 2 m and
+    // 2 m + 1 trade pieces (even row's rt-1 piece <-> odd row's rt-0 piece, one v_permlane16_swap per register) so that row
+    // 2 m ends up with columns c0 + 32 + 8 m .. + 7 of token li and row 2 m + 1 with the same columns of token 16 + li:
+    // 16-byte stores here too (8-byte stores cost the same issue slot for half the bytes; the store pipe is the bound).
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                 : "+v"(third[0][0]), "+v"(third[0][1]), "+v"(third[1][0]), "+v"(third[1][1]));
+    {
+      const int tok = min(t * RS_TOK + 16 * (g & 1) + li, p.rows - 1);
+      const u32x4 o = {third[0][0], third[0][1], third[1][0], third[1][1]};
+      stg16(p.y + ((size_t)tok * p.ldy + c0 + 32 + 8 * (g >> 1)) * 2, o);
+    }
+  }
+}
+
+int proj_rs_supported(int K, int NO) { return K == RS_K && NO == RS_NO; }
+
+int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
+                     long lda, long ldy, hipStream_t st) {
+  if (rows <= 0) return EA_OK;
+  RsP p;
+  p.a = (const char*)a; p.w = w; p.bias = bias; p.y = (char*)y; p.a_cast = a_f32 ? (char*)a_cast : nullptr;
+  p.rows = rows; p.ntiles = (rows + RS_TOK - 1) / RS_TOK; p.lda = lda; p.ldy = ldy;
+  int grid = ea_device_cus();
+  if (grid > p.ntiles) grid = p.ntiles;
+  const dim3 g((unsigned)grid), b(RS_WAVES * 64);
+  if (dtype == EA_BF16) {
+    if (a_f32) hipLaunchKernelGGL((proj_rs_kernel<BF16, true>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((proj_rs_kernel<BF16, false>), g, b, 0, st, p);
+  } else if (dtype == EA_F16) {
+    if (a_f32) hipLaunchKernelGGL((proj_rs_kernel<F16, true>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((proj_rs_kernel<F16, false>), g, b, 0, st, p);
+  } else {
+    return EA_E_BADARG;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace ea
