@@ -958,7 +958,9 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
   if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
   // the qkv projection of a 192-wide model: weight resident in registers, activations through LDS once (ea_proj_rs.hip)
   static const bool rs_on = !(getenv("EA_PROJ_RS") && getenv("EA_PROJ_RS")[0] == '0');
-  if (rs_on && !w_transposed && !y_f32 && proj_rs_supported(in_features, out_features))
+  // (a workgroup first loads the whole 576 x 192 weight into its registers: worth it from ~8 token tiles per workgroup on --
+  //  at N = 196 x batch 128 the LDS-resident kernel is faster, 25.7 against 30.1 us)
+  if (rs_on && !w_transposed && !y_f32 && rows >= 65536 && proj_rs_supported(in_features, out_features))
     return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream);
   return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
                          (long)lda, (long)ldy, (hipStream_t)stream);
