@@ -40,8 +40,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   // block -> (slice, tile): every tile of a slice on the same XCD (block id modulo 8)
   const int T = p.tiles_m * p.tiles_n;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int tile = j % T, slice = (j / T) * 8 + xcd;
+  int tile, slice;
+  if ((p.S & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = j % T; slice = (j / T) * 8 + xcd;
+  } else {                                     // slice count chosen to fill the CUs (wgrad_slices): tiles of a slice side by side
+    tile = blockIdx.x % T; slice = blockIdx.x / T;
+  }
   if (slice >= p.S) return;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -66,9 +71,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
       pb[k] = t < r1 ? ldg16(p.x + ((size_t)t * p.K + n0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  float accb[SA][8];
+  // bias partials: a thread's staged chunks all sit in ONE 8-channel group when 512 is a multiple of the chunks per row
+  // (BM = 64, 128, 256), so they share one set of accumulators
+  constexpr int NB = (512 % CPRA == 0) ? 1 : SA;
+  float accb[NB][8];
 #pragma unroll
-  for (int k = 0; k < SA; ++k)
+  for (int k = 0; k < NB; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) accb[k][e] = 0.f;
   auto commit = [&](char* st) {
@@ -76,19 +84,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     for (int k = 0; k < SA; ++k) {
       const int idx = tid + k * 512;
       const int row = idx / CPRA, ch = idx - row * CPRA;
-      sts16(st + (ch >> 3) * (64 * 128) + lds_off<64>(row, ch & 7), pa[k]);
+      sts16(st + (ch >> 3) * (64 * 128) + lds_off2<64>(row, ch & 7), pa[k]);
       if (with_bias) {
         float f[8];
         unpack8<E>(pa[k], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) accb[k][e] += f[e];
+        for (int e = 0; e < 8; ++e) accb[NB == 1 ? 0 : k][e] += f[e];
       }
     }
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
       const int idx = tid + k * 512;
       const int row = idx / CPRB, ch = idx - row * CPRB;
-      sts16(st + (SA + (ch >> 3)) * (64 * 128) + lds_off<64>(row, ch & 7), pb[k]);
+      sts16(st + (SA + (ch >> 3)) * (64 * 128) + lds_off2<64>(row, ch & 7), pb[k]);
     }
   };
 
@@ -97,18 +105,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   const int wr = 4 * g + (li >> 2);
   // per-fragment LDS offsets, computed (not looked up: an array indexed by the runtime wave id lives in scratch,
   // and a scratch access shares -- and drains -- the vmcnt queue of the prefetched global loads)
+  // Both fragments are transposed reads in which the four lanes of a token row take 32 CONTIGUOUS bytes (16 channels) of
+  // the phi2-swizzled row (ea_common.h, round 3): the round-2 dY pattern -- 8-byte pieces 32 bytes apart -- was 4-way
+  // bank-conflicted and made the kernel LDS-bound.
   int aoff[FA], boff[FB];
+  const int q = li & 3;
 #pragma unroll
   for (int f = 0; f < FA; ++f) {
-    const int fa = wa * FA + f, dt = fa & 3;           // 16-channel group fa of the dY stage: sub-tile fa / 4
-    const int colb = (16 * (li & 3) + 4 * dt) * 2;
-    aoff[f] = (fa >> 2) * (64 * 128) + wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
+    const int fa = wa * FA + f;                        // 16-channel group fa of the dY stage: sub-tile fa / 4
+    aoff[f] = (fa >> 2) * (64 * 128) + lds_off2<64>(wr, 2 * (fa & 3) + (q >> 1)) + 8 * (q & 1);
   }
 #pragma unroll
   for (int c = 0; c < FB; ++c) {
     const int fb = wb * FB + c;                        // 16-channel group fb of the X stage
-    const int colb = (16 * (fb & 3) + 4 * (li & 3)) * 2;
-    boff[c] = (SA + (fb >> 2)) * (64 * 128) + wr * 128 + ((((colb >> 4)) ^ (wr & 7)) << 4) + (colb & 15);
+    boff[c] = (SA + (fb >> 2)) * (64 * 128) + lds_off2<64>(wr, 2 * (fb & 3) + (q >> 1)) + 8 * (q & 1);
   }
   f32x4 acc[FA][FB];
 #pragma unroll
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     buf ^= 1;
   }
   // ---- partial tile -> part[slice][m][n], through LDS so that it leaves in 16-byte row segments (D row 4g+r of
-  // fragment fa <-> out channel 64 sa + 16 g + 4 dt + r, D column li of fragment fb <-> in channel 16 fb + li): 72
+  // fragment fa <-> out channel 64 sa + 16 dt + 4 g + r, D column li of fragment fb <-> in channel 16 fb + li): 72
   // dword stores per lane straight from the accumulators would cost more than the whole stream.  The stage buffers
   // are free; one half of the in-channels (the waves of one wb) at a time fits them.
   float* out = p.part + (size_t)slice * p.part_ld;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
 #pragma unroll
         for (int c = 0; c < FB; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ot[(64 * sa + 16 * g + 4 * dt + r) * HN + 16 * c + li] = acc[f][c][r];
+          for (int r = 0; r < 4; ++r) ot[(64 * sa + 16 * dt + 4 * g + r) * HN + 16 * c + li] = acc[f][c][r];
       }
     }
     __syncthreads();
@@ -173,16 +183,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   }
   if (!with_bias) return;
   // ---- bias partial: 64 staged rows per column group, summed through LDS in a fixed order ----
-  float* red = reinterpret_cast<float*>(smem);            // [SA * 512][8] (the stage buffers are free)
+  float* red = reinterpret_cast<float*>(smem);            // [NB * 512][8] (the stage buffers are free)
 #pragma unroll
-  for (int k = 0; k < SA; ++k)
+  for (int k = 0; k < NB; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[(size_t)(tid + k * 512) * 8 + e] = accb[k][e];
   __syncthreads();
   if (tid < BM) {
     const int ch = tid >> 3, e = tid & 7;
     float s = 0.f;
-    for (int row = 0; row < 64; ++row) s += red[(size_t)(row * CPRA + ch) * 8 + e];
+    for (int row = 0; row < NB * 512 / CPRA; ++row) s += red[(size_t)(row * CPRA + ch) * 8 + e];
     p.db_part[(size_t)slice * p.part_ld + m0 + tid] = s;
   }
 }
@@ -223,7 +233,17 @@ int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipS
 
 static int wg_cus() { return ea_device_cus(); }
 
-static int wg_bt(int M) { return M % 192 == 0 ? 192 : (M % 128 == 0 ? 128 : 64); }
+// tile edge along one axis.  The kernel is fed from L2 at ~10 B/clk/CU, so its MFMA rate is set by the FLOPs per staged
+// byte = (BM * BN) / (BM + BN): a [256 x 256] tile (wide models: 512 / 1024 / 1536 / 3072 channels) does twice the work
+// per byte of a [128 x 128] one (measured 378 TFLOP/s with 128 x 128 tiles at 1536 x 512 x 65536).
+static int wg_tile_max() {
+  static const int v = [] { const char* e = getenv("EA_WGRAD_TILE_MAX"); return e ? atoi(e) : 256; }();   // dev knob
+  return v;
+}
+static int wg_bt(int M) {
+  const int mx = wg_tile_max();
+  return (M % 256 == 0 && mx >= 256) ? 256 : ((M % 192 == 0 && mx >= 192) ? 192 : ((M % 128 == 0 && mx >= 128) ? 128 : 64));
+}
 
 // token slices: one workgroup per CU (96 KB of LDS each), the tiles of a slice on one XCD (32 CUs), >= 256 tokens each
 int wgrad_slices(int rows, int M, int K) {
@@ -233,6 +253,14 @@ int wgrad_slices(int rows, int M, int K) {
   int S = per_xcd / T * 8;
   if (S < 8) S = 8;
   while (S > 8 && rows / S < 256) S -= 8;
+  // many tiles (wide models): a multiple of 8 slices can leave a third of the CUs idle (20 tiles x 8 slices = 160
+  // workgroups).  The kernel is bound by what ONE CU can pull out of L2 (~12.5 B/clk measured), so filling the CUs beats
+  // keeping a slice's tiles on one XCD -- the re-reads of a dY / X row by the other XCDs hit the Infinity Cache.
+  if (S * T < wg_cus() * 85 / 100 && T <= wg_cus()) {
+    int Sf = wg_cus() / T;
+    while (Sf > 1 && rows / Sf < 256) --Sf;
+    if (Sf * T > S * T && (Sf & 7) != 0) S = Sf;
+  }
   return S;
 }
 
@@ -241,13 +269,14 @@ static int launch_wg(const WgP& p, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM / 64 + BN / 64) * 64 * 128;
   if (lds > 64 * 1024) EA_SET_LDS_ONCE((&wgrad_kernel<E, BM, BN>), lds);
   const int T = p.tiles_m * p.tiles_n;
-  const dim3 grid((unsigned)(((p.S + 7) / 8) * 8 * T)), block(512);
+  const dim3 grid((unsigned)(((p.S & 7) == 0 ? ((p.S + 7) / 8) * 8 : p.S) * T)), block(512);
   hipLaunchKernelGGL((wgrad_kernel<E, BM, BN>), grid, block, lds, st, p);
   return (int)hipGetLastError();
 }
 
 template <typename E, int BM>
 static int launch_wg_n(const WgP& p, int bn, hipStream_t st) {
+  if (bn == 256) return launch_wg<E, BM, 256>(p, st);
   if (bn == 192) return launch_wg<E, BM, 192>(p, st);
   if (bn == 128) return launch_wg<E, BM, 128>(p, st);
   return launch_wg<E, BM, 64>(p, st);
@@ -266,6 +295,7 @@ int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float*
   p.tiles_m = M / bm; p.tiles_n = K / bn;
 #define EA_WG(E)                                                        \
   do {                                                                  \
+    if (bm == 256) return launch_wg_n<E, 256>(p, bn, st);               \
     if (bm == 192) return launch_wg_n<E, 192>(p, bn, st);               \
     if (bm == 128) return launch_wg_n<E, 128>(p, bn, st);               \
     return launch_wg_n<E, 64>(p, bn, st);                               \

@@ -127,7 +127,8 @@ def test_rows_mlp_matches_fp64(R, D, sides, ln):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("rows,M,K", [(100352, 576, 192), (100352, 192, 192), (25088, 576, 192), (4096, 1536, 512),
-                                      (1000, 64, 64), (777, 128, 320), (294912, 192, 64), (65, 960, 320)])
+                                      (1000, 64, 64), (777, 128, 320), (294912, 192, 64), (65, 960, 320),
+                                      (8192, 2560, 512), (3000, 512, 512), (700, 768, 256), (1025, 256, 192)])
 def test_wgrad_matches_fp64(rows, M, K, dtype):
     """ea_wgrad (weight + bias gradient of a projection in one pass) against fp64 on the same bf16/fp16 data:
     fp32 accumulation of exact products -> error far below one operand ulp of the result; deterministic."""

@@ -11,7 +11,8 @@ for rows, M, K in shapes:
     dy = torch.randn(rows, M, device="cuda").bfloat16()
     x = torch.randn(rows, K, device="cuda").bfloat16()
     for name, fn in (("ea_wgrad", lambda: _ops.wgrad(dy, x, True)),
-                     ("ea_wgrad_nobias", lambda: _ops.wgrad(dy, x, False))):
+                     ("ea_wgrad_nobias", lambda: _ops.wgrad(dy, x, False)),
+                     ("torch dy^T x", lambda: dy.t() @ x)):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
