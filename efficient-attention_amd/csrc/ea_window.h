@@ -219,8 +219,12 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
 }
 
 // static geometry of the window kernels: tile counts as template constants (0 = read the tiling at run time)
-struct SGdyn { static constexpr int NQT = 0, NLT = 0, NCT = 0, WPI = 0; };
-template <int a, int b, int c, int d> struct SGs { static constexpr int NQT = a, NLT = b, NCT = c, WPI = d; };
+// HO (backward): phase A hands P and dS to phase B through LDS instead of phase B recomputing them (ea_window_bwd.hip)
+struct SGdyn { static constexpr int NQT = 0, NLT = 0, NCT = 0, WPI = 0; static constexpr bool HO = false; };
+template <int a, int b, int c, int d, bool ho = false> struct SGs {
+  static constexpr int NQT = a, NLT = b, NCT = c, WPI = d;
+  static constexpr bool HO = ho;
+};
 
 struct T4 {
   char* p;

@@ -13,6 +13,7 @@
 //   workgroup and are written once as per-workgroup partial sums; the bias gradient accumulates in
 //   LDS and is written once per workgroup.
 // There is no barrier between the phases: delta and lse are staged with the Q/dO rows.
+#include <stdlib.h>
 #include "ea_window.h"
 #include <type_traits>
 #include <algorithm>
@@ -59,18 +60,37 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   const int biasLd = STATIC ? SG::NLT * 16 : t.biasLd;
   const int nQTe = (nQT + 1) & ~1;                   // query tiles per window, padded to even
   const int rowsQ = wpi * nQTe * 16;
+  // HAND (round 3, static geometries, one window per iteration): phase A keeps P and dS of its (query tile, key tile)
+  // pairs and hands them to phase B as [query][key] tiles in LDS; phase B reads them back transposed
+  // (ds_read_b64_tr_b16) as the B operands of dV^T = dO^T P and dK^T = Q^T dS -- no second S / dP product, no second
+  // exp.  The tiles of the LOCAL keys overlay the local K / V rows (dead once every wave has left phase A: phase B
+  // needs only Q, dO and the tiles), those of the landmark keys take the room of the bias table and of the bias-gradient
+  // accumulator, which live in registers here (a wave owns one query tile for the whole launch, so the bias rows it
+  // reads and the bias-gradient entries it produces never change lanes).
+  constexpr bool HAND = SG::HO;
+  static_assert(!HAND || (STATIC && SG::WPI == 1 && SG::NQT <= 4 && SG::NLT <= 4 && !GB && !CA && !DR && D == 64),
+                "hand-over variant: static one-window geometries only");
+  constexpr int NKT = SG::NLT + SG::NCT;             // key tiles of a window (HAND)
   char* Ks = smem;
-  char* Vs = Ks + rowsTotal * ROWB;
-  char* Qs = Vs + rowsTotal * ROWB;
+  // HAND: [K local | V local | K landmark (+ zero tile) | V landmark (+ zero tile)], else [K all | V all]
+  char* Vs = Ks + (HAND ? rowsLocal : rowsTotal) * ROWB;
+  char* Klm = HAND ? Vs + rowsLocal * ROWB : Ks + rowsLocal * ROWB;
+  char* Vlm = HAND ? Klm + (rowsLm + 16) * ROWB : Vs + rowsLocal * ROWB;
+  char* Qs = Ks + 2 * rowsTotal * ROWB;
   char* dOs = Qs + rowsQ * ROWB;
   float* lse_s = reinterpret_cast<float*>(dOs + rowsQ * ROWB);
   float* delta_s = lse_s + rowsQ;
+  char* slabL = Ks;                                   // HAND: P / dS tiles of the local key tiles
+  char* slabC = reinterpret_cast<char*>(delta_s + rowsQ);   // HAND: ... of the landmark key tiles
+  auto slab_tile = [&](int qt, int kt) -> char* {     // 1 KB per (query tile, key tile): P then dS, [16 queries][16 keys]
+    return kt < SG::NLT ? slabL + (qt * SG::NLT + kt) * 1024 : slabC + (qt * SG::NCT + (kt - SG::NLT)) * 1024;
+  };
   // bias-gradient accumulator [Wq][BLD] and (bias_lds) the head's log2-domain bias [Wq][BLD]; the
   // odd row stride keeps both the row-wise (phase A) and the column-wise (phase B) accesses of
   // the 64 lanes on distinct banks
   const int BLD = biasLd + 1;
-  float* dbias_s = delta_s + rowsQ;
-  const int nbias = p.bias ? t.Wq * BLD : 0;
+  float* dbias_s = HAND ? reinterpret_cast<float*>(slabC + SG::NQT * SG::NCT * 1024) : delta_s + rowsQ;
+  const int nbias = (p.bias && !HAND) ? t.Wq * BLD : 0;
   float* bias_s = dbias_s + nbias;
   float* zero64 = bias_s + (p.bias_lds ? nbias : 0);   // bias reads without a bias table land here
   float* trash64 = zero64 + 64;                        // bias-gradient writes of padded entries
@@ -121,8 +141,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.lv + off + 4);
       vw = pack8<E>(f);
     }
-    sts16(Ks + TileL<D>::off(rowsLocal + row, c), kw);
-    sts16(Vs + TileL<D>::off(rowsLocal + row, c), vw);
+    sts16(Klm + TileL<D>::off(row, c), kw);
+    sts16(Vlm + TileL<D>::off(row, c), vw);
     if (c == 0) {
       kmul[rowsLocal + row] = row < p.L ? 1.f : 0.f;
       kadd[rowsLocal + row] = row < p.L ? 0.f : -INFINITY;
@@ -130,7 +150,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   }
   for (int idx = tid; idx < nbias; idx += 256) dbias_s[idx] = 0.f;
   if (tid < 128) zero64[tid] = 0.f;
-  if (p.bias_lds) {
+  if (!HAND && p.bias_lds) {
     const float* bsrc = p.bias + ((size_t)h * t.WqFull + t.qoff) * biasLd;
     for (int idx = tid * 4; idx < t.Wq * biasLd; idx += 1024) {
       const float4 v = *reinterpret_cast<const float4*>(bsrc + idx);
@@ -146,6 +166,23 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dlk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dlv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+  // HAND: this wave's query tile (= wave) for the whole launch: its bias rows and its bias-gradient entries
+  // (query 16 wave + li, keys 16 tile + 4 g + r) in registers
+  constexpr int HT = HAND ? (SG::NLT > 0 ? SG::NLT : 1) : 1;
+  f32x4 breg[HT], dbacc[HT];
+  uint32_t hp[HAND ? NKT : 1][2], hd[HAND ? NKT : 1][2];
+  if constexpr (HAND) {
+    const int qs = min(wave * 16 + li, t.Wq - 1);
+#pragma unroll
+    for (int tl = 0; tl < HT; ++tl) {
+      dbacc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+      breg[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const float4 v = *reinterpret_cast<const float4*>(p.bias + ((size_t)h * t.WqFull + t.qoff + qs) * biasLd + tl * 16 + 4 * g);
+        breg[tl] = f32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+  }
   const int it_end = min((blk + 1) * t.ipb, t.niter);
   EA_STAMP(p, 1);
   int prof_it = 0;
@@ -313,6 +350,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       if (prof_it == 0) EA_STAMP(p, 20);
       for (int ch = 0; ch < nchunks; ++ch) {
         int rowbase[4];
+        const char* kt_p[4];
         uint32_t dsw[4][2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -322,17 +360,20 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                               : (tile < nLT + nCT ? rowsLocal + (tile - nLT) * 16
                                                       : rowsLocal + rowsLm);
           f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          const int row = rowbase[tt] + li;
+          kt_p[tt] = local ? Ks + rowbase[tt] * ROWB : Klm + (rowbase[tt] - rowsLocal) * ROWB;
+          const char* vt_p = local ? Vs + rowbase[tt] * ROWB : Vlm + (rowbase[tt] - rowsLocal) * ROWB;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            s = E::mma(as_x8<E>(lds16(Ks + rowbase[tt] * ROWB + lo.plain[ks])), qf[ks], s);
-            dp = E::mma(as_x8<E>(lds16(Vs + rowbase[tt] * ROWB + lo.plain[ks])), dof[ks], dp);
+            s = E::mma(as_x8<E>(lds16(kt_p[tt] + lo.plain[ks])), qf[ks], s);
+            dp = E::mma(as_x8<E>(lds16(vt_p + lo.plain[ks])), dof[ks], dp);
           }
           const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
           const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);                                  // log2-domain bias
-          if (PHASE_A_GLOBAL_BIAS) {
+          if constexpr (HAND) {
+            if (local) b4 = make_float4(breg[tile][0], breg[tile][1], breg[tile][2], breg[tile][3]);
+          } else if (PHASE_A_GLOBAL_BIAS) {
             if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
           } else {
             const float* bs = brow_s + (local ? tile : 0) * btm;
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             keep4 = real ? *reinterpret_cast<const uint32_t*>(
                                p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + col + 4 * g) : 0u;
           }
-          float ds[4];
+          float ds[4], prr[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
@@ -364,9 +405,20 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             if (DR) dpr = ((keep4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
             // masked_fill blocks the gradient of the replaced logits (mul == 0)
             ds[r] = gm * pr * (dpr - delta);
+            prr[r] = pr;
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
+          if constexpr (HAND) {
+            if (tile < NKT) {
+              hp[tile][0] = pack2<E>(prr[0], prr[1]); hp[tile][1] = pack2<E>(prr[2], prr[3]);
+              hd[tile][0] = dsw[tt][0]; hd[tile][1] = dsw[tt][1];
+            }
+            if (tile < SG::NLT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dbacc[tile][r] += ds[r];
+            }
+          }
         }
         if (prof_it == 0 && ch < 3) EA_STAMP(p, 21 + 2 * ch);
 #pragma unroll
@@ -377,8 +429,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           const typename E::x8 dsf = as_x8<E>(f4v);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const u32x2 lo_ = E::tr4(Ks + rowbase[2 * kk] * ROWB + lo.tr[dt]);
-            const u32x2 hi_ = E::tr4(Ks + rowbase[2 * kk + 1] * ROWB + lo.tr[dt]);
+            const u32x2 lo_ = E::tr4(kt_p[2 * kk] + lo.tr[dt]);
+            const u32x2 hi_ = E::tr4(kt_p[2 * kk + 1] + lo.tr[dt]);
             dq[dt] = E::mma(as_x8<E>(lo_, hi_), dsf, dq[dt]);
           }
         }
@@ -405,6 +457,19 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       }
     }
 
+    if constexpr (HAND) {
+      __syncthreads();                                 // every wave is done with the local K / V rows
+      if (wave < SG::NQT) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          // S^T tile in registers: keys 4 g + r of query li  ->  row li (32 bytes), bytes 8 g .. of the [query][key] tile
+          char* dst = slab_tile(wave, kt) + li * 32 + g * 8;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{hp[kt][0], hp[kt][1]};
+          *reinterpret_cast<u32x2*>(dst + 512) = u32x2{hd[kt][0], hd[kt][1]};
+        }
+      }
+      __syncthreads();
+    }
     if (prof_it < 4) EA_STAMP(p, 6 + prof_it * 6);
     // =============================== phase B: dK, dV ===============================
     // work items: (window wi, local tile lt) for all staged windows, then landmark tile = wave
@@ -423,11 +488,15 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         if (it * wpi + wi_lo >= t.nwin) return;
       }
       const int krow = (is_lm ? rowsLocal + tile * 16 : (wi_lo * nLT + tile) * 16) + li;
+      const char* kbp = is_lm ? Klm + tile * 16 * ROWB : Ks + (wi_lo * nLT + tile) * 16 * ROWB;
+      const char* vbp = is_lm ? Vlm + tile * 16 * ROWB : Vs + (wi_lo * nLT + tile) * 16 * ROWB;
       typename E::x8 kf[KS], vf[KS];
+      if constexpr (!HAND) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = as_x8<E>(lds16(Ks + (krow - li) * ROWB + lo.plain[ks]));
-        vf[ks] = as_x8<E>(lds16(Vs + (krow - li) * ROWB + lo.plain[ks]));
+        for (int ks = 0; ks < KS; ++ks) {
+          kf[ks] = as_x8<E>(lds16(kbp + lo.plain[ks]));
+          vf[ks] = as_x8<E>(lds16(vbp + lo.plain[ks]));
+        }
       }
       const float kmu = kmul[krow], kad = kadd[krow];
       const int kslot = tile * 16 + li;                // key slot within the window / landmark id
@@ -531,7 +600,27 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           }
         }
       };
-      if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
+      if constexpr (HAND) {
+        // P and dS of (query tiles 2 qq, 2 qq + 1; this key tile) from the hand-over tiles: lane (g, key li) gets
+        // queries 4 g .. 4 g + 3 of each -- the k-slot order of the transposed dO / Q fragments
+        const int kt = is_lm ? SG::NLT + tile : tile;
+#pragma unroll
+        for (int qq = 0; qq < (SG::NQT + 1) / 2; ++qq) {
+          const char* t0 = slab_tile(2 * qq, kt) + lane * 8;
+          const char* t1 = slab_tile(2 * qq + 1 < SG::NQT ? 2 * qq + 1 : 2 * qq, kt) + lane * 8;
+          u32x2 p1 = E::tr4(t1), d1 = E::tr4(t1 + 512);
+          if (2 * qq + 1 >= SG::NQT) { p1 = u32x2{0u, 0u}; d1 = u32x2{0u, 0u}; }
+          const typename E::x8 pf = as_x8<E>(E::tr4(t0), p1), dsf = as_x8<E>(E::tr4(t0 + 512), d1);
+          const int rq0 = 2 * qq * 16, rq1 = (2 * qq + 1) * 16;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int o0 = rq0 * ROWB + lo.tr[dt];
+            const int o1 = rq1 * ROWB + lo.tr[dt];
+            dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
+            dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
+          }
+        }
+      } else if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
       else if (wpi == 1) sweep(std::integral_constant<int, 1>{});
       else sweep(std::integral_constant<int, 2>{});
       if (prof_it == 0) EA_STAMP(p, pb + 9);
@@ -616,9 +705,19 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     }
   }
   if (p.bias) {
-    __syncthreads();
     float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)biasLd;
-    for (int idx = tid; idx < t.Wq * biasLd; idx += 256) dst[idx] = dbias_s[(idx / biasLd) * BLD + (idx % biasLd)];
+    if constexpr (HAND) {
+      const int qs = wave * 16 + li;
+      if (wave < SG::NQT && qs < t.Wq) {
+#pragma unroll
+        for (int tl = 0; tl < HT; ++tl)
+          *reinterpret_cast<float4*>(dst + (size_t)qs * biasLd + tl * 16 + 4 * g) =
+              make_float4(dbacc[tl][0], dbacc[tl][1], dbacc[tl][2], dbacc[tl][3]);
+      }
+    } else {
+      __syncthreads();
+      for (int idx = tid; idx < t.Wq * biasLd; idx += 256) dst[idx] = dbias_s[(idx / biasLd) * BLD + (idx % biasLd)];
+    }
   }
   EA_STAMP(p, 61);
   EA_BLK(p, 1);
@@ -664,6 +763,12 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
   }
 }
 
+// dev switch: EA_WIN_HANDOVER=0 keeps the recomputing phase B for the static geometries
+static bool hand_over() {
+  static const bool v = [] { const char* e = getenv("EA_WIN_HANDOVER"); return !e || atoi(e) != 0; }();
+  return v;
+}
+
 template <typename E, int D>
 static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
@@ -677,6 +782,11 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
       if (!gb && p.nq <= 1) {
         const WinTiling& t = p.t;
         if (t.nQT == 4 && t.nLT == 4 && t.wpi == 1) {
+          if (hand_over()) {
+            if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true>>;
+            if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true>>;
+            if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true>>;
+          }
           if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1>>;
           if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1>>;
           if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1>>;
@@ -688,6 +798,10 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
   auto launch = [&](WinP& p, size_t lds, unsigned blocks) -> int {
     const bool gb = p.bias && !p.bias_lds;
     const KernelT kern = pick(p, gb);
+    if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && hand_over() && p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 &&
+        (p.t.nCT == 4 || p.t.nCT == 3 || p.t.nCT == 0))
+      // hand-over variant: no bias table / bias-gradient image in LDS, P / dS tiles of the landmark keys instead
+      lds = window_bwd_lds(p.t, D, false, false) + (size_t)p.t.nQT * p.t.nCT * 1024;
     if (lds > WIN_LDS_MAX) return EA_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
