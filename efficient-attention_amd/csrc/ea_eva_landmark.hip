@@ -12,6 +12,7 @@
 // The chunk partition (rearrange / pad + as_strided copies in the reference) is address
 // arithmetic (part_token); slots outside the sequence and padded tokens count as zeros in the
 // means and get the finite -5e4 logit, exactly like the reference's masked_fill sequence.
+#include <stdlib.h>
 #include "ea_landmark_params.h"
 
 namespace ea {
@@ -414,6 +415,284 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
   }
 }
 
+// ==========================================================================================
+// Register-resident variants (round 3) for short chunks (2-D pooling: one wave per chunk, J <= 8 row steps).
+// The loops above fetch a row step, wait, use it, fetch the next: 8 (forward) to 24 (beta backward) dependent memory
+// round trips per wave, and hipcc turns the `live ? load : 0` selects back into predicated loads.  Here EVERY row of the
+// chunk is requested up front from clamped addresses (k, v -- and dk, dv for the read-modify-writes -- stay packed in
+// registers), the wave waits once, and the backward reads k a single time instead of twice.
+template <int N> EA_DEV void pin_regs(u32x4 (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i]));
+}
+template <int D, int NI> struct ChunkRows {
+  static constexpr int CPR = D / 8, RPW = 64 / CPR;
+  int tok[NI];
+  uint32_t flags[NI];          // bit 0: slot exists (j < J), bit 1: inside the sequence, bits 8..: mask byte
+  EA_DEV void init(const LmP& p, int cidx, int rg, const uint8_t* mrow) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = rg + i * RPW;
+      const bool ex = j < p.J;
+      const int t = ex ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+      tok[i] = t >= 0 ? t : 0;
+      flags[i] = (ex ? 1u : 0u) | (t >= 0 ? 2u : 0u);
+      if (mrow) flags[i] |= (uint32_t)mrow[tok[i]] << 8;
+    }
+  }
+  EA_DEV void pin() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(flags[i]));
+  }
+  EA_DEV bool exists(int i) const { return flags[i] & 1u; }
+  EA_DEV bool live(int i) const { return (flags[i] & 2u) && !(flags[i] >> 8); }
+};
+#define EA_CHUNK_PROLOGUE                                                                       \
+  constexpr int CPR = D / 8, RPW = 64 / CPR;                                                    \
+  const int lane = threadIdx.x & 63, c = lane % CPR, rg = lane / CPR, wave = threadIdx.x >> 6;  \
+  const long chunk_id = (long)blockIdx.x * 4 + wave;                                            \
+  if (chunk_id >= (long)p.B * p.H * p.L) return;                                                \
+  const int cidx = (int)(chunk_id % p.L);                                                       \
+  const int bh = (int)(chunk_id / p.L), b = bh / p.H, h = bh - b * p.H;                         \
+  const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.G.N : nullptr;                          \
+  (void)RPW; (void)rg; (void)h
+
+EA_DEV void ld8(const float* s, float* f) {
+  const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+EA_DEV void st8(float* d, const float* f) {
+  *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+template <typename E, int D, int NI>
+__global__ __launch_bounds__(256) void chunk_mean_fwd_r_kernel(const LmP p) {
+  EA_CHUNK_PROLOGUE;
+  const char* qb = p.q + (b * p.q_sb + h * p.q_sh) * 2;
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  ChunkRows<D, NI> R;
+  R.init(p, cidx, rg, mrow);
+  u32x4 qr[NI], kr[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    qr[i] = ldg16(qb + (R.tok[i] * p.q_sn + c * 8) * 2);
+    kr[i] = ldg16(kb + (R.tok[i] * p.k_sn + c * 8) * 2);
+  }
+  pin_regs(qr); pin_regs(kr); R.pin();
+  float aq[8], ak[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) aq[i] = ak[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float w = R.live(i) ? 1.f : 0.f;
+    float f[8];
+    unpack8<E>(qr[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aq[e] = fmaf(w, f[e], aq[e]);
+    unpack8<E>(kr[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ak[e] = fmaf(w, f[e], ak[e]);
+  }
+  const float inv = 1.f / (float)p.J;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { aq[i] = rows_sum<CPR>(aq[i]) * inv; ak[i] = rows_sum<CPR>(ak[i]) * inv; }
+  if (rg == 0) {
+    st8(p.qmean + (size_t)chunk_id * D + c * 8, aq);
+    st8(p.kmean + (size_t)chunk_id * D + c * 8, ak);
+  }
+}
+
+template <typename E, int D, int NI>
+__global__ __launch_bounds__(256) void chunk_mean_bwd_r_kernel(const LmP p) {
+  EA_CHUNK_PROLOGUE;
+  char* dqb = p.dq + (b * p.dq_sb + h * p.dq_sh) * 2;
+  char* dkb = p.dk + (b * p.dk_sb + h * p.dk_sh) * 2;
+  ChunkRows<D, NI> R;
+  R.init(p, cidx, rg, mrow);
+  u32x4 qr[NI], kr[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    qr[i] = ldg16(dqb + (R.tok[i] * p.dq_sn + c * 8) * 2);
+    kr[i] = ldg16(dkb + (R.tok[i] * p.dk_sn + c * 8) * 2);
+  }
+  float gq[8], gk[8];
+  ld8(p.dqmean + (size_t)chunk_id * D + c * 8, gq);
+  ld8(p.dkmean + (size_t)chunk_id * D + c * 8, gk);
+  pin_regs(qr); pin_regs(kr); R.pin();
+  const float inv = 1.f / (float)p.J;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gq[i] *= inv; gk[i] *= inv; }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (!R.live(i)) continue;
+    float f[8];
+    unpack8<E>(qr[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += gq[e];
+    stg16(dqb + (R.tok[i] * p.dq_sn + c * 8) * 2, pack8<E>(f));
+    unpack8<E>(kr[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += gk[e];
+    stg16(dkb + (R.tok[i] * p.dk_sn + c * 8) * 2, pack8<E>(f));
+  }
+}
+
+// logits of the chunk's rows from the packed k rows: x[i] (live), MASK_FILL (padded / outside), -inf (no such slot)
+template <typename E, int D, int NI>
+EA_DEV void chunk_logits(const ChunkRows<D, NI>& R, const u32x4* kr, const float* om, float scale, float* x) {
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float kf[8];
+    unpack8<E>(kr[i], kf);
+    float dot = 0.f, nrm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dot += om[e] * kf[e]; nrm += kf[e] * kf[e]; }
+    dot = chan_sum<CPR>(dot);
+    nrm = chan_sum<CPR>(nrm);
+    const float v = scale * (dot - 0.5f * nrm);
+    x[i] = R.live(i) ? v : (R.exists(i) ? MASK_FILL : -INFINITY);
+  }
+}
+// max and sum of exp over ALL rows of the chunk (the row steps of this lane, then the row groups of the wave)
+template <int CPR, int NI> EA_DEV void chunk_lse(const float* x, float& m, float& l) {
+  m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) m = fmaxf(m, x[i]);
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  l = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) l += __expf(x[i] - m);
+  l = rows_sum<CPR>(l);
+}
+
+template <typename E, int D, int NI>
+__global__ __launch_bounds__(256) void beta_fwd_r_kernel(const LmP p) {
+  EA_CHUNK_PROLOGUE;
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  const char* vb = p.v + (b * p.v_sb + h * p.v_sh) * 2;
+  ChunkRows<D, NI> R;
+  R.init(p, cidx, rg, mrow);
+  u32x4 kr[NI], vr[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    kr[i] = ldg16(kb + (R.tok[i] * p.k_sn + c * 8) * 2);
+    vr[i] = ldg16(vb + (R.tok[i] * p.v_sn + c * 8) * 2);
+  }
+  float om[8];
+  ld8(p.omega + (size_t)chunk_id * D + c * 8, om);
+  pin_regs(kr); pin_regs(vr); R.pin();
+  float x[NI], m, l;
+  chunk_logits<E, D, NI>(R, kr, om, p.scale, x);
+  chunk_lse<CPR, NI>(x, m, l);                             // (slot 0 always exists: m is finite)
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float pj = R.live(i) ? __expf(x[i] - m) : 0.f;   // padded slots weigh in l only (their v counts as zero)
+    float vf[8];
+    unpack8<E>(vr[i], vf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = rows_sum<CPR>(acc[e]) * inv;
+  if (rg == 0) st8(p.beta_out + (size_t)chunk_id * D + c * 8, acc);
+}
+
+template <typename E, int D, int NI>
+__global__ __launch_bounds__(256) void beta_bwd_r_kernel(const LmP p, int colour, int nc) {
+  EA_CHUNK_PROLOGUE;
+  if (nc > 1) {
+    int col;
+    if (p.G.attn2d) { const int per_row = p.G.gw / p.r; col = ((cidx / per_row) % nc) * nc + ((cidx % per_row) % nc); }
+    else col = cidx % nc;
+    if (col != colour) return;
+  }
+  const char* kb = p.k + (b * p.k_sb + h * p.k_sh) * 2;
+  const char* vb = p.v + (b * p.v_sb + h * p.v_sh) * 2;
+  char* dkb = p.dk + (b * p.dk_sb + h * p.dk_sh) * 2;
+  char* dvb = p.dv + (b * p.dv_sb + h * p.dv_sh) * 2;
+  ChunkRows<D, NI> R;
+  R.init(p, cidx, rg, mrow);
+  u32x4 kr[NI], vr[NI], dkr[NI], dvr[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    kr[i] = ldg16(kb + (R.tok[i] * p.k_sn + c * 8) * 2);
+    vr[i] = ldg16(vb + (R.tok[i] * p.v_sn + c * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    dkr[i] = ldg16(dkb + (R.tok[i] * p.dk_sn + c * 8) * 2);
+    dvr[i] = ldg16(dvb + (R.tok[i] * p.dv_sn + c * 8) * 2);
+  }
+  float om[8], db[8], bt[8];
+  {
+    const size_t off = (size_t)chunk_id * D + c * 8;
+    ld8(p.omega + off, om); ld8(p.dbeta + off, db); ld8(p.beta + off, bt);
+  }
+  pin_regs(kr); pin_regs(vr); pin_regs(dkr); pin_regs(dvr); R.pin();
+  float bd = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bd += bt[e] * db[e];
+  bd = chan_sum<CPR>(bd);                                   // beta . dbeta
+  float x[NI], m, l;
+  chunk_logits<E, D, NI>(R, kr, om, p.scale, x);
+  chunk_lse<CPR, NI>(x, m, l);
+  const float lse = m + __logf(l);
+  float dom[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dom[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float kf[8], vf[8];
+    unpack8<E>(kr[i], kf);
+    unpack8<E>(vr[i], vf);
+    float vd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vd += vf[e] * db[e];
+    vd = chan_sum<CPR>(vd);
+    if (R.live(i)) {
+      const float pj = __expf(x[i] - lse);
+      const float dx = pj * (vd - bd) * p.scale;
+      float f[8];
+      unpack8<E>(dvr[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += pj * db[e];
+      stg16(dvb + (R.tok[i] * p.dv_sn + c * 8) * 2, pack8<E>(f));
+      unpack8<E>(dkr[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { f[e] += dx * (om[e] - kf[e]); dom[e] += dx * kf[e]; }
+      stg16(dkb + (R.tok[i] * p.dk_sn + c * 8) * 2, pack8<E>(f));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dom[e] = rows_sum<CPR>(dom[e]);
+  if (rg == 0) st8(p.domega + (size_t)chunk_id * D + c * 8, dom);
+}
+#undef EA_CHUNK_PROLOGUE
+
+// dev switch: EA_LM_REG=0 keeps the looping kernels for short chunks
+static bool lm_reg_on() {
+  static const bool v = [] { const char* e = getenv("EA_LM_REG"); return !e || atoi(e) != 0; }();
+  return v;
+}
+template <typename E, int D, int NI>
+static void launch_lm_r(int which, const LmP& p, dim3 grid, int ncolour, int nc, hipStream_t st) {
+  const dim3 block(256);
+  switch (which) {
+    case 0: hipLaunchKernelGGL((chunk_mean_fwd_r_kernel<E, D, NI>), grid, block, 0, st, p); break;
+    case 1: hipLaunchKernelGGL((chunk_mean_bwd_r_kernel<E, D, NI>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((beta_fwd_r_kernel<E, D, NI>), grid, block, 0, st, p); break;
+    default:
+      for (int col = 0; col < ncolour; ++col) hipLaunchKernelGGL((beta_bwd_r_kernel<E, D, NI>), grid, block, 0, st, p, col, nc);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 template <typename E, int D>
 static int launch_lm(int which, const LmP& p, hipStream_t st) {
@@ -426,6 +705,18 @@ static int launch_lm(int which, const LmP& p, hipStream_t st) {
   // read-modify-writes of one launch never touch the same token.
   const int nc = p.e > 0 ? 1 + (2 * p.e + p.r - 1) / p.r : 1;
   const int ncolour = p.G.attn2d ? nc * nc : nc;
+  if constexpr (D <= 64) {
+    // short chunks, one wave each: the register-resident variants (the chunk-mean backward of overlapping chunks keeps its
+    // token-centric gather kernel)
+    const int steps = (p.J + 64 / (D / 8) - 1) / (64 / (D / 8));
+    if (!coop && steps <= 8 && lm_reg_on() && !(which == 1 && ncolour > 1)) {
+      if (steps <= 1) launch_lm_r<E, D, 1>(which, p, grid, ncolour, nc, st);
+      else if (steps <= 2) launch_lm_r<E, D, 2>(which, p, grid, ncolour, nc, st);
+      else if (steps <= 4) launch_lm_r<E, D, 4>(which, p, grid, ncolour, nc, st);
+      else launch_lm_r<E, D, 8>(which, p, grid, ncolour, nc, st);
+      return (int)hipGetLastError();
+    }
+  }
   switch (which) {
     case 0:
       if (coop) hipLaunchKernelGGL((chunk_mean_fwd_kernel<E, D, 4>), grid, block, 0, st, p);
