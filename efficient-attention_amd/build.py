@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the architectural VGPRs.  Left to its heuristics hipcc 7.2 parks them
+# in AGPRs whenever a loop also touches them with VALU code (online-softmax rescale, P / dS products) and pays a
+# v_accvgpr_read/write pair per register per iteration: 17 k such moves in ea_softmax.hip, 14 k in ea_window_bwd.hip.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I" + INCLUDE, "-I" + CSRC]
 
 LIB_SOURCES = ["ea_capi.hip", "ea_window_fwd.hip", "ea_window_bwd.hip", "ea_eva_landmark.hip",
                "ea_lara_x.hip", "ea_lara_y.hip", "ea_lara_f.hip", "ea_softmax.hip",

@@ -164,8 +164,14 @@ struct F16 {
   static EA_DEV uint16_t from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 };
 
+// two floats -> one packed 16-bit pair, round-to-nearest-even, as ONE v_cvt_pk_{bf16,f16}_f32: the vector conversion is
+// what selects the packed instruction -- two scalar conversions plus shift-and-or compile to four instructions per pair
+// (found in round 3 in the softmax forward, whose VALU work bounds it: 16 conversions + 8 shifts + 8 ors per 64-key chunk).
 template <typename E> EA_DEV uint32_t pack2(float lo, float hi) {
-  return (uint32_t)E::from_f(lo) | ((uint32_t)E::from_f(hi) << 16);
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef typename E::T ex2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ex2_));
 }
 template <typename E> EA_DEV void unpack2(uint32_t w, float& lo, float& hi) {
   lo = E::to_f((uint16_t)(w & 0xffffu));

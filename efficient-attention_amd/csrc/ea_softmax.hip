@@ -11,6 +11,7 @@
 //             chunks, S = Q K^T, dP = dO V^T tiles [query][key] -> dV^T = dO^T P, dK^T = Q^T dS
 // Two recomputing passes instead of fp32 atomics on dQ: deterministic, and no read-modify-write
 // traffic on the gradient.
+#include <stdlib.h>
 #include "ea_softmax.h"
 
 namespace ea {
@@ -30,37 +31,50 @@ template <typename E, int CPR> EA_DEV float key_norm_term(u32x4 kw, float scale_
 }
 
 // KB: per-key bias -s |k|^2 / 2 in the logits (p.key_norm_bias)
-template <typename E, int D, bool DR, bool KB>
+// QT: 16-query tiles per wave (round 3).  The K / V fragments a wave reads from LDS feed QT MFMAs instead of one, and a
+// chunk's two barriers and its staging are amortised over QT times the work.  Padded / out-of-range keys enter the logits
+// as an additive -inf from LDS (kadd_s, together with the KB term) -- one fma per score instead of a byte unpack, a
+// compare and a select: the forward is bound by its VALU work (v_exp_f32 alone takes as long as the two MFMAs a score
+// costs), not by the matrix cores.
+template <typename E, int D, bool DR, bool KB, int QT>
 __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
-  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
-  __shared__ __attribute__((aligned(16))) uint8_t dead[64];
-  __shared__ __attribute__((aligned(16))) float kb_s[64];
+  __shared__ __attribute__((aligned(16))) float kadd_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int nqb = (p.N + 63) / 64;
+  constexpr int QPB = 64 * QT;                       // queries per workgroup
+  const int nqb = (p.N + QPB - 1) / QPB;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* qbase = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
   const char* kbase = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
   const char* vbase = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.N : nullptr;
-  const int qtok = qb * 64 + wave * 16 + li;
-  const bool qvalid = qtok < p.N;
-  typename E::x8 qf[KS];
+  int qtok[QT];
+  bool qvalid[QT];
+  typename E::x8 qf[QT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    u32x4 w = {0u, 0u, 0u, 0u};
-    if (qvalid) w = ldg16(qbase + (qtok * p.q.sn + (g * KS + ks) * 8) * 2);
-    qf[ks] = as_x8<E>(w);
+  for (int u = 0; u < QT; ++u) {
+    qtok[u] = qb * QPB + (wave * QT + u) * 16 + li;
+    qvalid[u] = qtok[u] < p.N;
+    const int tq = min(qtok[u], p.N - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 w = ldg16(qbase + (tq * p.q.sn + (g * KS + ks) * 8) * 2);
+      qf[u][ks] = as_x8<E>(qvalid[u] ? w : u32x4{0u, 0u, 0u, 0u});
+    }
   }
-  float m = -INFINITY, lsum = 0.f;
-  f32x4 o[DT];
+  float m[QT], lsum[QT];
+  f32x4 o[QT][DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < QT; ++u) {
+    m[u] = -INFINITY; lsum[u] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  // Round 3: the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
+  // the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
   // clamped rows (no exec-mask branches), rows past the sequence are zeroed when they are committed to LDS.
   constexpr int NSL = (64 * CPR + 255) / 256;
   u32x4 nk[NSL], nv[NSL];
@@ -89,88 +103,133 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       const u32x4 kw = in ? nk[i] : z, vw = in ? nv[i] : z;
       sts16(Ks + TileL<D>::off(row, c), kw);
       sts16(Vs + TileL<D>::off(row, c), vw);
-      if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
-      if (c == 0) dead[row] = (!in || nm[i]) ? 1 : 0;
+      float kn = 0.f;
+      if (KB) kn = key_norm_term<E, CPR>(kw, p.scale_log2);
+      if (c == 0) kadd_s[row] = (!in || nm[i]) ? -INFINITY : kn;
     }
     __syncthreads();
     if (kc + 64 < p.N) issue(kc + 64);
-    f32x4 s[4];
-    float mloc = -INFINITY;
+    // A chunk without padded / masked keys and without the KB term (the common case: no mask, N a multiple of 64) needs
+    // no additive term: the row maximum is taken over the raw scores and the scale is applied together with the shift,
+    // exp2(s * scale - m), one fma per score instead of an fma and a subtraction.  (uniform condition)
+    const bool plain = !KB && !mrow && kc + 64 <= p.N;
+    f32x4 s[QT][4];
+    float mloc[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) mloc[u] = -INFINITY;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int row = tt * 16 + li;
+      f32x4 acc[QT];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        acc = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], acc);
-      const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
-      float4 kb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KB) kb4 = *reinterpret_cast<const float4*>(kb_s + tt * 16 + 4 * g);
-      const float kbv[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
+      for (int u = 0; u < QT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x = ((f4 >> (8 * r)) & 0xffu) ? -INFINITY : fmaf(acc[r], p.scale_log2, kbv[r]);
-        acc[r] = x;
-        mloc = fmaxf(mloc, x);
+      for (int ks = 0; ks < KS; ++ks) {
+        const typename E::x8 kfr = as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks)));
+#pragma unroll
+        for (int u = 0; u < QT; ++u) acc[u] = E::mma(kfr, qf[u][ks], acc[u]);
       }
-      s[tt] = acc;
-    }
-    mloc = quad_max(mloc);
-    const float mnew = fmaxf(m, mloc);
-    const float msafe = mnew == -INFINITY ? 0.f : mnew;
-    const float alpha = fast_exp2(m - msafe);
-    m = mnew;
-    float psum = 0.f;
-    uint32_t pw[4][2];
-    const uint8_t* krow = DR ? p.keep + ((size_t)bh * p.N + (qvalid ? qtok : 0)) * p.keep_ld + kc + 4 * g : nullptr;
+      if (plain) {
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      float pv[4];
-      uint32_t k4 = 0;
-      if (DR) k4 = *reinterpret_cast<const uint32_t*>(krow + tt * 16);
+        for (int u = 0; u < QT; ++u) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pv[r] = fast_exp2(s[tt][r] - msafe);
-        psum += pv[r];
-        if (DR) pv[r] = ((k4 >> (8 * r)) & 0xffu) ? pv[r] * p.keep_scale : 0.f;
+          for (int r = 0; r < 4; ++r) mloc[u] = fmaxf(mloc[u], acc[u][r]);
+          s[u][tt] = acc[u];
+        }
+      } else {
+        const float4 ka4 = *reinterpret_cast<const float4*>(kadd_s + tt * 16 + 4 * g);
+        const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w};
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = fmaf(acc[u][r], p.scale_log2, kav[r]);
+            acc[u][r] = x;
+            mloc[u] = fmaxf(mloc[u], x);
+          }
+          s[u][tt] = acc[u];
+        }
       }
-      pw[tt][0] = pack2<E>(pv[0], pv[1]);
-      pw[tt][1] = pack2<E>(pv[2], pv[3]);
     }
-    lsum = lsum * alpha + psum;
+    uint32_t pw[QT][4][2];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+    for (int u = 0; u < QT; ++u) {
+      float ml = quad_max(mloc[u]);
+      if (plain) ml *= p.scale_log2;                     // (scale > 0: the maximum commutes with it)
+      const float mnew = fmaxf(m[u], ml);
+      const float msafe = mnew == -INFINITY ? 0.f : mnew;
+      // the running maximum moves in the first few chunks of a row and then hardly ever: the rescale of the 16
+      // accumulators (which costs 32 moves between the MFMA accumulation registers and the VALU's on top of the
+      // multiplications) is skipped when no lane of the wave needs it -- alpha is exactly 1 there
+      const bool moved = mnew != m[u];
+      const float alpha = fast_exp2(m[u] - msafe);
+      m[u] = mnew;
+      float psum = 0.f;
+      const uint8_t* krow = DR ? p.keep + ((size_t)bh * p.N + (qvalid[u] ? qtok[u] : 0)) * p.keep_ld + kc + 4 * g : nullptr;
+      const float sc = plain ? p.scale_log2 : 1.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        float pv[4];
+        uint32_t k4 = 0;
+        if (DR) k4 = *reinterpret_cast<const uint32_t*>(krow + tt * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv[r] = fast_exp2(fmaf(s[u][tt][r], sc, -msafe));
+          psum += pv[r];
+          if (DR) pv[r] = ((k4 >> (8 * r)) & 0xffu) ? pv[r] * p.keep_scale : 0.f;
+        }
+        pw[u][tt][0] = pack2<E>(pv[0], pv[1]);
+        pw[u][tt][1] = pack2<E>(pv[2], pv[3]);
+      }
+      if (__any(moved)) {
+        lsum[u] = lsum[u] * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[u][dt] *= alpha;
+      } else {
+        lsum[u] += psum;
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      u32x4 pf4;
-      pf4[0] = pw[2 * kk][0]; pf4[1] = pw[2 * kk][1]; pf4[2] = pw[2 * kk + 1][0]; pf4[3] = pw[2 * kk + 1][1];
+      typename E::x8 pf[QT];
+#pragma unroll
+      for (int u = 0; u < QT; ++u) {
+        u32x4 pf4;
+        pf4[0] = pw[u][2 * kk][0]; pf4[1] = pw[u][2 * kk][1]; pf4[2] = pw[u][2 * kk + 1][0]; pf4[3] = pw[u][2 * kk + 1][1];
+        pf[u] = as_x8<E>(pf4);
+      }
       const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const u32x2 lo = E::tr4(Vs + tile_tr<D>(r0, li, dt));
         const u32x2 hi = E::tr4(Vs + tile_tr<D>(r1, li, dt));
-        o[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(pf4), o[dt]);
+        const typename E::x8 vfr = as_x8<E>(lo, hi);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][dt] = E::mma(vfr, pf[u], o[u][dt]);
       }
     }
   }
-  const float ltot = quad_sum(lsum);
-  const float inv = fast_rcp(ltot);
-  float f[DQ];
-  if constexpr (TileL<D>::NEWTR) {
-    quad_transpose_f32(o, f);                   // accumulator pieces -> the lane's contiguous channels (all lanes)
 #pragma unroll
-    for (int j = 0; j < DQ; ++j) f[j] *= inv;
-  } else {
+  for (int u = 0; u < QT; ++u) {
+    const float ltot = quad_sum(lsum[u]);
+    const float inv = fast_rcp(ltot);
+    float f[DQ];
+    if constexpr (TileL<D>::NEWTR) {
+      quad_transpose_f32(o[u], f);                // accumulator pieces -> the lane's contiguous channels (all lanes)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int j = 0; j < DQ; ++j) f[j] *= inv;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) f[4 * dt + r] = o[dt][r] * inv;
-  }
-  if (qvalid) {
-    char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + qtok * p.o.sn + DQ * g) * 2;
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
-    if (g == 0) p.lse[(size_t)bh * p.N + qtok] = (m + fast_log2(ltot)) * LN2;
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = o[u][dt][r] * inv;
+    }
+    if (qvalid[u]) {
+      char* dst = p.o.p + (b * p.o.sb + h * p.o.sh + qtok[u] * p.o.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+      if (g == 0) p.lse[(size_t)bh * p.N + qtok[u]] = (m[u] + fast_log2(ltot)) * LN2;
+    }
   }
 }
 
@@ -553,8 +612,20 @@ static int launch_sample(const SmP& p, hipStream_t st) {
 template <typename E, int D, bool DR, bool KB>
 static int launch_sm_dr(int which, const SmP& p, hipStream_t st) {
   const dim3 grid((unsigned)((long)p.B * p.H * ((p.N + 63) / 64))), block(256);
-  if (which == 0) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB>), grid, block, 0, st, p);
-  else {
+  if (which == 0) {
+    // two (D <= 64: four) query tiles per wave whenever that still leaves every CU a few workgroups
+    const long bh = (long)p.B * p.H;
+    static const int qt_env = [] { const char* e = getenv("EA_SM_QT"); return e ? atoi(e) : 0; }();   // dev knob
+    int qt = 1;
+    if (bh * ((p.N + 127) / 128) >= 2 * ea_device_cus()) qt = 2;
+    if (D <= 64 && bh * ((p.N + 255) / 256) >= 2 * ea_device_cus()) qt = 4;
+    if (qt_env > 0) qt = qt_env;
+    if (D > 64 && qt > 2) qt = 2;
+    const dim3 gq((unsigned)(bh * ((p.N + 64 * qt - 1) / (64 * qt))));
+    if (qt == 4) { if constexpr (D <= 64) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 4>), gq, block, 0, st, p); }
+    else if (qt == 2) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 2>), gq, block, 0, st, p);
+    else hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 1>), gq, block, 0, st, p);
+  } else {
     hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR, KB>), grid, block, 0, st, p);
     hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR, KB>), grid, block, 0, st, p);
   }

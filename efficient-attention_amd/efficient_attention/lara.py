@@ -64,7 +64,9 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             if self.pool_module_type == 'dense':
                 def dense(p, net):
                     z = p.permute(0, 2, 1, 3).reshape(B, side * side, h * d)
-                    z = net[3](net[2](z))
+                    # model-wide Linear through the projection kernels (ea_linear / ea_wgrad); its LayerNorm over
+                    # B * L rows of `dim` channels is the one op of this generator left to the framework
+                    z = net[3](_ops.linear(z.contiguous(), net[2]))
                     return z.reshape(B, side * side, h, d).permute(0, 2, 1, 3)
                 q_bar, k_bar = dense(pq, self.q_bar_gen), dense(pk, self.k_bar_gen)
             else:

@@ -8,7 +8,7 @@ OBJS=""
 for f in $R/efficient-attention_amd/csrc/ea_*.hip; do
   o=$R/tools/bin/prof/$(basename ${f%.hip}).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find $R/efficient-attention_amd/csrc -name '*.h' -newer $o)" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DEA_PROFILE -I$R/include -I$R/efficient-attention_amd/csrc -c $f -o $o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -DEA_PROFILE -I$R/include -I$R/efficient-attention_amd/csrc -c $f -o $o &
   fi
   OBJS="$OBJS $o"
 done
