@@ -12,6 +12,7 @@
 // Two recomputing passes instead of fp32 atomics on dQ: deterministic, and no read-modify-write
 // traffic on the gradient.
 #include <stdlib.h>
+#include <type_traits>
 #include "ea_softmax.h"
 
 namespace ea {
@@ -239,8 +240,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
-  __shared__ __attribute__((aligned(16))) uint8_t dead[64];
-  __shared__ __attribute__((aligned(16))) float kb_s[64];
+  __shared__ __attribute__((aligned(16))) float kadd_s[64];     // -inf on padded / out-of-range keys, else the KB term
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int nqb = (p.N + 63) / 64;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
@@ -305,12 +305,18 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
       const u32x4 kw = in ? nk[i] : z, vw = in ? nv[i] : z;
       sts16(Ks + TileL<D>::off(row, c), kw);
       sts16(Vs + TileL<D>::off(row, c), vw);
-      if (KB) { const float kn = key_norm_term<E, CPR>(kw, p.scale_log2); if (c == 0) kb_s[row] = kn; }
-      if (c == 0) dead[row] = (!in || nm[i]) ? 1 : 0;
+      float kn = 0.f;
+      if (KB) kn = key_norm_term<E, CPR>(kw, p.scale_log2);
+      if (c == 0) kadd_s[row] = (!in || nm[i]) ? -INFINITY : kn;
     }
     __syncthreads();
     if (kc + 64 < p.N) issue(kc + 64);
+    const bool plain = !KB && !mrow && kc + 64 <= p.N;      // (uniform) no additive term in this chunk
     uint32_t dsw[4][2];
+    // (two straight-line instances of the chunk body: written as one body with `plain ? a : b` hipcc evaluates both
+    //  arguments of every score and selects)
+    auto score_tiles = [&](auto plain_tag) {
+    constexpr bool PL = decltype(plain_tag)::value;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -320,15 +326,19 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
         s = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], s);
         dp = E::mma(as_x8<E>(lds16(Vs + TileL<D>::off(row, g * KS + ks))), dof[ks], dp);
       }
-      const uint32_t f4 = *reinterpret_cast<const uint32_t*>(dead + tt * 16 + 4 * g);
+      float kav[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!PL) {
+        const float4 ka4 = *reinterpret_cast<const float4*>(kadd_s + tt * 16 + 4 * g);
+        kav[0] = ka4.x; kav[1] = ka4.y; kav[2] = ka4.z; kav[3] = ka4.w;
+      }
       uint32_t k4 = 0;
       if (DR) k4 = *reinterpret_cast<const uint32_t*>(
                   p.keep + ((size_t)bh * p.N + (qvalid ? qtok : 0)) * p.keep_ld + kc + tt * 16 + 4 * g);
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool dd = (f4 >> (8 * r)) & 0xffu;
-        const float pr = dd ? 0.f : fast_exp2(fmaf(s[r], p.scale_log2, KB ? kb_s[tt * 16 + 4 * g + r] : 0.f) - lse2);
+        // (lse2 = +inf on rows past the sequence, kav = -inf on dead keys: either way exp2(-inf) = 0)
+        const float pr = PL ? fast_exp2(fmaf(s[r], p.scale_log2, -lse2)) : fast_exp2(fmaf(s[r], p.scale_log2, kav[r]) - lse2);
         float dpr = dp[r];
         if (DR) dpr = ((k4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
         ds[r] = pr * (dpr - delta);
@@ -336,6 +346,8 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
       dsw[tt][0] = pack2<E>(ds[0], ds[1]);
       dsw[tt][1] = pack2<E>(ds[2], ds[3]);
     }
+    };
+    if (plain) score_tiles(std::true_type{}); else score_tiles(std::false_type{});
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       u32x4 f4v;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
       sts16(Qs + TileL<D>::off(row, c), in ? nq[i] : z);
       sts16(dOs + TileL<D>::off(row, c), in ? nd[i] : z);
       if (c == 0) {
-        lse_s[row] = in ? nl[i] * LOG2E : INFINITY;
+        lse_s[row] = in ? -nl[i] * LOG2E : -INFINITY;       // MINUS the log2-domain lse: added inside the score fma
         delta_s[row] = in ? ndl[i] : 0.f;
       }
     }
@@ -468,7 +480,8 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
         float pr[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = kdead ? 0.f : fast_exp2(fmaf(s[r], p.scale_log2, kbias) - ll[r]);
+          // a dead key's column is computed like any other and zeroed in the epilogue (columns are independent)
+          pr[r] = KB ? fast_exp2(fmaf(s[r], p.scale_log2, kbias) + ll[r]) : fast_exp2(fmaf(s[r], p.scale_log2, ll[r]));
           float dpr = dp[r];
           float km = 1.f;
           if (DR) {
@@ -511,6 +524,11 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
+  }
+  if (kdead) {
+#pragma unroll
+    for (int j = 0; j < DQ; ++j) fk[j] = fv[j] = 0.f;
+    dscol = 0.f;
   }
   if (kvalid) {
     if (KB) {
