@@ -234,49 +234,56 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
   }
 }
 
-template <typename E, int D, bool DR, bool KB>
+// QT: 16-query tiles per wave (see sm_fwd_kernel)
+template <typename E, int D, bool DR, bool KB, int QT>
 __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
-  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
   __shared__ __attribute__((aligned(16))) float kadd_s[64];     // -inf on padded / out-of-range keys, else the KB term
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int nqb = (p.N + 63) / 64;
+  constexpr int QPB = 64 * QT;
+  const int nqb = (p.N + QPB - 1) / QPB;
   const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* kbase = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
   const char* vbase = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
   const uint8_t* mrow = p.mask ? p.mask + (size_t)b * p.N : nullptr;
-  const int qtok = qb * 64 + wave * 16 + li;
-  const bool qvalid = qtok < p.N;
-  typename E::x8 qf[KS], dof[KS];
-  float delta = 0.f;
+  int qtok[QT];
+  bool qvalid[QT];
+  typename E::x8 qf[QT][KS], dof[QT][KS];
+  float delta[QT], lse2[QT];
+  f32x4 dq[QT][DT];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    u32x4 w = {0u, 0u, 0u, 0u}, dw = {0u, 0u, 0u, 0u}, ow = {0u, 0u, 0u, 0u};
-    if (qvalid) {
+  for (int u = 0; u < QT; ++u) {
+    qtok[u] = qb * QPB + (wave * QT + u) * 16 + li;
+    qvalid[u] = qtok[u] < p.N;
+    const int tq = min(qtok[u], p.N - 1);
+    delta[u] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
       const int eo = (g * KS + ks) * 8;
-      w = ldg16(p.q.p + (b * p.q.sb + h * p.q.sh + qtok * p.q.sn + eo) * 2);
-      dw = ldg16(p.dout.p + (b * p.dout.sb + h * p.dout.sh + qtok * p.dout.sn + eo) * 2);
-      ow = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + qtok * p.o.sn + eo) * 2);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      u32x4 w = ldg16(p.q.p + (b * p.q.sb + h * p.q.sh + tq * p.q.sn + eo) * 2);
+      u32x4 dw = ldg16(p.dout.p + (b * p.dout.sb + h * p.dout.sh + tq * p.dout.sn + eo) * 2);
+      u32x4 ow = ldg16(p.o.p + (b * p.o.sb + h * p.o.sh + tq * p.o.sn + eo) * 2);
+      w = qvalid[u] ? w : z; dw = qvalid[u] ? dw : z; ow = qvalid[u] ? ow : z;
+      qf[u][ks] = as_x8<E>(w);
+      dof[u][ks] = as_x8<E>(dw);
+      float a8[8], c8[8];
+      unpack8<E>(dw, a8);
+      unpack8<E>(ow, c8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) delta[u] += a8[i] * c8[i];
     }
-    qf[ks] = as_x8<E>(w);
-    dof[ks] = as_x8<E>(dw);
-    float a[8], c8[8];
-    unpack8<E>(dw, a);
-    unpack8<E>(ow, c8);
+    delta[u] = quad_sum(delta[u]);
+    lse2[u] = qvalid[u] ? p.lse[(size_t)bh * p.N + qtok[u]] * LOG2E : INFINITY;
+    if (qvalid[u] && g == 0) p.delta[(size_t)bh * p.N + qtok[u]] = delta[u];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) delta += a[i] * c8[i];
+    for (int dt = 0; dt < DT; ++dt) dq[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  delta = quad_sum(delta);
-  const float lse2 = qvalid ? p.lse[(size_t)bh * p.N + qtok] * LOG2E : INFINITY;
-  if (qvalid && g == 0) p.delta[(size_t)bh * p.N + qtok] = delta;
-  f32x4 dq[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Round 3: the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
+  // the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
   // clamped rows (no exec-mask branches), rows past the sequence are zeroed when they are committed to LDS.
   constexpr int NSL = (64 * CPR + 255) / 256;
   u32x4 nk[NSL], nv[NSL];
@@ -312,120 +319,147 @@ __global__ __launch_bounds__(256) void sm_bwd_dq_kernel(const SmP p) {
     __syncthreads();
     if (kc + 64 < p.N) issue(kc + 64);
     const bool plain = !KB && !mrow && kc + 64 <= p.N;      // (uniform) no additive term in this chunk
-    uint32_t dsw[4][2];
+    uint32_t dsw[QT][4][2];
     // (two straight-line instances of the chunk body: written as one body with `plain ? a : b` hipcc evaluates both
     //  arguments of every score and selects)
     auto score_tiles = [&](auto plain_tag) {
-    constexpr bool PL = decltype(plain_tag)::value;
+      constexpr bool PL = decltype(plain_tag)::value;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      const int row = tt * 16 + li;
+      for (int tt = 0; tt < 4; ++tt) {
+        f32x4 s[QT], dp[QT];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = E::mma(as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks))), qf[ks], s);
-        dp = E::mma(as_x8<E>(lds16(Vs + TileL<D>::off(row, g * KS + ks))), dof[ks], dp);
-      }
-      float kav[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!PL) {
-        const float4 ka4 = *reinterpret_cast<const float4*>(kadd_s + tt * 16 + 4 * g);
-        kav[0] = ka4.x; kav[1] = ka4.y; kav[2] = ka4.z; kav[3] = ka4.w;
-      }
-      uint32_t k4 = 0;
-      if (DR) k4 = *reinterpret_cast<const uint32_t*>(
-                  p.keep + ((size_t)bh * p.N + (qvalid ? qtok : 0)) * p.keep_ld + kc + tt * 16 + 4 * g);
-      float ds[4];
+        for (int u = 0; u < QT; ++u) { s[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int row = tt * 16 + li;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (lse2 = +inf on rows past the sequence, kav = -inf on dead keys: either way exp2(-inf) = 0)
-        const float pr = PL ? fast_exp2(fmaf(s[r], p.scale_log2, -lse2)) : fast_exp2(fmaf(s[r], p.scale_log2, kav[r]) - lse2);
-        float dpr = dp[r];
-        if (DR) dpr = ((k4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
-        ds[r] = pr * (dpr - delta);
+        for (int ks = 0; ks < KS; ++ks) {
+          const typename E::x8 kfr = as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks)));
+          const typename E::x8 vfr = as_x8<E>(lds16(Vs + TileL<D>::off(row, g * KS + ks)));
+#pragma unroll
+          for (int u = 0; u < QT; ++u) {
+            s[u] = E::mma(kfr, qf[u][ks], s[u]);
+            dp[u] = E::mma(vfr, dof[u][ks], dp[u]);
+          }
+        }
+        float kav[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!PL) {
+          const float4 ka4 = *reinterpret_cast<const float4*>(kadd_s + tt * 16 + 4 * g);
+          kav[0] = ka4.x; kav[1] = ka4.y; kav[2] = ka4.z; kav[3] = ka4.w;
+        }
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+          uint32_t k4 = 0;
+          if (DR) k4 = *reinterpret_cast<const uint32_t*>(
+                      p.keep + ((size_t)bh * p.N + (qvalid[u] ? qtok[u] : 0)) * p.keep_ld + kc + tt * 16 + 4 * g);
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // (lse2 = +inf on rows past the sequence, kav = -inf on dead keys: either way exp2(-inf) = 0)
+            const float pr = PL ? fast_exp2(fmaf(s[u][r], p.scale_log2, -lse2[u]))
+                                : fast_exp2(fmaf(s[u][r], p.scale_log2, kav[r]) - lse2[u]);
+            float dpr = dp[u][r];
+            if (DR) dpr = ((k4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
+            ds[r] = pr * (dpr - delta[u]);
+          }
+          dsw[u][tt][0] = pack2<E>(ds[0], ds[1]);
+          dsw[u][tt][1] = pack2<E>(ds[2], ds[3]);
+        }
       }
-      dsw[tt][0] = pack2<E>(ds[0], ds[1]);
-      dsw[tt][1] = pack2<E>(ds[2], ds[3]);
-    }
     };
     if (plain) score_tiles(std::true_type{}); else score_tiles(std::false_type{});
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      u32x4 f4v;
-      f4v[0] = dsw[2 * kk][0]; f4v[1] = dsw[2 * kk][1]; f4v[2] = dsw[2 * kk + 1][0]; f4v[3] = dsw[2 * kk + 1][1];
+      typename E::x8 dsf[QT];
+#pragma unroll
+      for (int u = 0; u < QT; ++u) {
+        u32x4 f4v;
+        f4v[0] = dsw[u][2 * kk][0]; f4v[1] = dsw[u][2 * kk][1]; f4v[2] = dsw[u][2 * kk + 1][0]; f4v[3] = dsw[u][2 * kk + 1][1];
+        dsf[u] = as_x8<E>(f4v);
+      }
       const int r0 = 32 * kk + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const u32x2 lo = E::tr4(Ks + tile_tr<D>(r0, li, dt));
         const u32x2 hi = E::tr4(Ks + tile_tr<D>(r1, li, dt));
-        dq[dt] = E::mma(as_x8<E>(lo, hi), as_x8<E>(f4v), dq[dt]);
+        const typename E::x8 kt = as_x8<E>(lo, hi);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) dq[u][dt] = E::mma(kt, dsf[u], dq[u][dt]);
       }
     }
   }
-  float f[DQ];
-  if constexpr (TileL<D>::NEWTR) {
-    quad_transpose_f32(dq, f);
 #pragma unroll
-    for (int j = 0; j < DQ; ++j) f[j] *= p.scale;
-  } else {
+  for (int u = 0; u < QT; ++u) {
+    float f[DQ];
+    if constexpr (TileL<D>::NEWTR) {
+      quad_transpose_f32(dq[u], f);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int j = 0; j < DQ; ++j) f[j] *= p.scale;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[dt][r] * p.scale;
-  }
-  if (qvalid) {
-    char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + qtok * p.dq.sn + DQ * g) * 2;
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+        for (int r = 0; r < 4; ++r) f[4 * dt + r] = dq[u][dt][r] * p.scale;
+    }
+    if (qvalid[u]) {
+      char* dst = p.dq.p + (b * p.dq.sb + h * p.dq.sh + qtok[u] * p.dq.sn + DQ * g) * 2;
+#pragma unroll
+      for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
+    }
   }
 }
 
-template <typename E, int D, bool DR, bool KB>
+// KT: 16-key tiles per wave: the Q / dO fragments a wave reads from LDS (plain and transposed) feed KT MFMAs each
+template <typename E, int D, bool DR, bool KB, int KT>
 __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
-  constexpr int SW = CPR >= 8 ? 7 : CPR - 1;
   __shared__ __attribute__((aligned(16))) char Qs[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char dOs[64 * ROWB];
   __shared__ __attribute__((aligned(16))) float lse_s[64];
   __shared__ __attribute__((aligned(16))) float delta_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int nkb = (p.N + 63) / 64;
+  constexpr int KPB = 64 * KT;                       // keys per workgroup
+  const int nkb = (p.N + KPB - 1) / KPB;
   const int bh = blockIdx.x / nkb, kb = blockIdx.x - bh * nkb;
   const int b = bh / p.H, h = bh - b * p.H;
   const char* qbase = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
   const char* dobase = p.dout.p + (b * p.dout.sb + h * p.dout.sh) * 2;
-  const int ktok = kb * 64 + wave * 16 + li;
-  const bool kvalid = ktok < p.N;
-  const bool kdead = !kvalid || (p.mask && p.mask[(size_t)b * p.N + ktok]);
-  typename E::x8 kf[KS], vf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
-    if (kvalid) {
-      const int eo = (g * KS + ks) * 8;
-      kw = ldg16(p.k.p + (b * p.k.sb + h * p.k.sh + ktok * p.k.sn + eo) * 2);
-      vw = ldg16(p.v.p + (b * p.v.sb + h * p.v.sh + ktok * p.v.sn + eo) * 2);
-    }
-    kf[ks] = as_x8<E>(kw);
-    vf[ks] = as_x8<E>(vw);
-  }
-  f32x4 dk[DT], dv[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  int ktok[KT];
+  bool kvalid[KT], kdead[KT];
+  typename E::x8 kf[KT][KS], vf[KT][KS];
+  f32x4 dk[KT][DT], dv[KT][DT];
   // KB: this lane's key bias (its key row is spread over the four lane groups) and the running
   // column sum of dS, which is the gradient of that bias
-  float kbias = 0.f, dscol = 0.f;
-  if (KB) {
-    float part = 0.f;
+  float kbias[KT], dscol[KT];
+#pragma unroll
+  for (int u = 0; u < KT; ++u) {
+    ktok[u] = kb * KPB + (wave * KT + u) * 16 + li;
+    kvalid[u] = ktok[u] < p.N;
+    const int tk = min(ktok[u], p.N - 1);
+    kdead[u] = !kvalid[u] || (p.mask && p.mask[(size_t)b * p.N + tk]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      float f[8];
-      unpack8<E>(__builtin_bit_cast(u32x4, kf[ks]), f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part += f[j] * f[j];
+      const int eo = (g * KS + ks) * 8;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4 kw = ldg16(p.k.p + (b * p.k.sb + h * p.k.sh + tk * p.k.sn + eo) * 2);
+      const u32x4 vw = ldg16(p.v.p + (b * p.v.sb + h * p.v.sh + tk * p.v.sn + eo) * 2);
+      kf[u][ks] = as_x8<E>(kvalid[u] ? kw : z);
+      vf[u][ks] = as_x8<E>(kvalid[u] ? vw : z);
     }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    kbias = -0.5f * p.scale_log2 * part;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dk[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    kbias[u] = 0.f; dscol[u] = 0.f;
+    if (KB) {
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float f[8];
+        unpack8<E>(__builtin_bit_cast(u32x4, kf[u][ks]), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += f[j] * f[j];
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      kbias[u] = -0.5f * p.scale_log2 * part;
+    }
   }
 
   constexpr int NSL = (64 * CPR + 255) / 256;
@@ -464,90 +498,113 @@ __global__ __launch_bounds__(256) void sm_bwd_dkv_kernel(const SmP p) {
     if (qc + 64 < p.N) issue(qc + 64);
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
-      uint32_t pw[2][2], dsw[2][2];
+      uint32_t pw[KT][2][2], dsw[KT][2][2];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rq = (2 * qq + u) * 16;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      for (int uq = 0; uq < 2; ++uq) {
+        const int rq = (2 * qq + uq) * 16;
+        f32x4 s[KT], dp[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) { s[u] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          s = E::mma(as_x8<E>(lds16(Qs + TileL<D>::off(rq + li, g * KS + ks))), kf[ks], s);
-          dp = E::mma(as_x8<E>(lds16(dOs + TileL<D>::off(rq + li, g * KS + ks))), vf[ks], dp);
+          const typename E::x8 qfr = as_x8<E>(lds16(Qs + TileL<D>::off(rq + li, g * KS + ks)));
+          const typename E::x8 dfr = as_x8<E>(lds16(dOs + TileL<D>::off(rq + li, g * KS + ks)));
+#pragma unroll
+          for (int u = 0; u < KT; ++u) {
+            s[u] = E::mma(qfr, kf[u][ks], s[u]);
+            dp[u] = E::mma(dfr, vf[u][ks], dp[u]);
+          }
         }
         const float4 l4 = *reinterpret_cast<const float4*>(lse_s + rq + 4 * g);
         const float4 d4 = *reinterpret_cast<const float4*>(delta_s + rq + 4 * g);
         const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-        float pr[4], ds[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // a dead key's column is computed like any other and zeroed in the epilogue (columns are independent)
-          pr[r] = KB ? fast_exp2(fmaf(s[r], p.scale_log2, kbias) + ll[r]) : fast_exp2(fmaf(s[r], p.scale_log2, ll[r]));
-          float dpr = dp[r];
-          float km = 1.f;
-          if (DR) {
-            const int qt = min(qc + rq + 4 * g + r, p.N - 1);
-            km = p.keep[((size_t)bh * p.N + qt) * p.keep_ld + (kvalid ? ktok : 0)] ? p.keep_scale : 0.f;
-            dpr *= km;
+        for (int u = 0; u < KT; ++u) {
+          float pr[4], ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // a dead key's column is computed like any other and zeroed in the epilogue (columns are independent)
+            pr[r] = KB ? fast_exp2(fmaf(s[u][r], p.scale_log2, kbias[u]) + ll[r]) : fast_exp2(fmaf(s[u][r], p.scale_log2, ll[r]));
+            float dpr = dp[u][r];
+            float km = 1.f;
+            if (DR) {
+              const int qt = min(qc + rq + 4 * g + r, p.N - 1);
+              km = p.keep[((size_t)bh * p.N + qt) * p.keep_ld + (kvalid[u] ? ktok[u] : 0)] ? p.keep_scale : 0.f;
+              dpr *= km;
+            }
+            ds[r] = pr[r] * (dpr - dd[r]);
+            if (KB) dscol[u] += ds[r];
+            if (DR) pr[r] *= km;
           }
-          ds[r] = pr[r] * (dpr - dd[r]);
-          if (KB) dscol += ds[r];
-          if (DR) pr[r] *= km;
+          pw[u][uq][0] = pack2<E>(pr[0], pr[1]); pw[u][uq][1] = pack2<E>(pr[2], pr[3]);
+          dsw[u][uq][0] = pack2<E>(ds[0], ds[1]); dsw[u][uq][1] = pack2<E>(ds[2], ds[3]);
         }
-        pw[u][0] = pack2<E>(pr[0], pr[1]); pw[u][1] = pack2<E>(pr[2], pr[3]);
-        dsw[u][0] = pack2<E>(ds[0], ds[1]); dsw[u][1] = pack2<E>(ds[2], ds[3]);
       }
-      u32x4 a4, b4;
-      a4[0] = pw[0][0]; a4[1] = pw[0][1]; a4[2] = pw[1][0]; a4[3] = pw[1][1];
-      b4[0] = dsw[0][0]; b4[1] = dsw[0][1]; b4[2] = dsw[1][0]; b4[3] = dsw[1][1];
+      typename E::x8 pf[KT], dsf[KT];
+#pragma unroll
+      for (int u = 0; u < KT; ++u) {
+        u32x4 a4, b4;
+        a4[0] = pw[u][0][0]; a4[1] = pw[u][0][1]; a4[2] = pw[u][1][0]; a4[3] = pw[u][1][1];
+        b4[0] = dsw[u][0][0]; b4[1] = dsw[u][0][1]; b4[2] = dsw[u][1][0]; b4[3] = dsw[u][1][1];
+        pf[u] = as_x8<E>(a4); dsf[u] = as_x8<E>(b4);
+      }
       const int r0 = 32 * qq + 4 * g + (li >> 2), r1 = r0 + 16;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int o0 = tile_tr<D>(r0, li, dt);
         const int o1 = tile_tr<D>(r1, li, dt);
-        dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), as_x8<E>(a4), dv[dt]);
-        dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), as_x8<E>(b4), dk[dt]);
+        const typename E::x8 dot = as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1));
+        const typename E::x8 qt_ = as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1));
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+          dv[u][dt] = E::mma(dot, pf[u], dv[u][dt]);
+          dk[u][dt] = E::mma(qt_, dsf[u], dk[u][dt]);
+        }
       }
     }
   }
-  if (KB) {
-    dscol += __shfl_xor(dscol, 16);
-    dscol += __shfl_xor(dscol, 32);
-  }
-  float fk[DQ], fv[DQ];
-  if constexpr (TileL<D>::NEWTR) {
-    quad_transpose_f32(dk, fk);
-    quad_transpose_f32(dv, fv);
 #pragma unroll
-    for (int j = 0; j < DQ; ++j) fk[j] *= p.scale;
-  } else {
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[dt][r] * p.scale; fv[4 * dt + r] = dv[dt][r]; }
-  }
-  if (kdead) {
-#pragma unroll
-    for (int j = 0; j < DQ; ++j) fk[j] = fv[j] = 0.f;
-    dscol = 0.f;
-  }
-  if (kvalid) {
+  for (int u = 0; u < KT; ++u) {
     if (KB) {
-      // d/dk_j of -s |k_j|^2 / 2 summed over the queries: -s k_j sum_i dS_ij (this lane's channels)
-      const char* krow = p.k.p + (b * p.k.sb + h * p.k.sh + ktok * p.k.sn + DQ * g) * 2;
+      dscol[u] += __shfl_xor(dscol[u], 16);
+      dscol[u] += __shfl_xor(dscol[u], 32);
+    }
+    float fk[DQ], fv[DQ];
+    if constexpr (TileL<D>::NEWTR) {
+      quad_transpose_f32(dk[u], fk);
+      quad_transpose_f32(dv[u], fv);
+#pragma unroll
+      for (int j = 0; j < DQ; ++j) fk[j] *= p.scale;
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { fk[4 * dt + r] = dk[u][dt][r] * p.scale; fv[4 * dt + r] = dv[u][dt][r]; }
+    }
+    if (kdead[u]) {
+#pragma unroll
+      for (int j = 0; j < DQ; ++j) fk[j] = fv[j] = 0.f;
+      dscol[u] = 0.f;
+    }
+    if (kvalid[u]) {
+      if (KB) {
+        // d/dk_j of -s |k_j|^2 / 2 summed over the queries: -s k_j sum_i dS_ij (this lane's channels)
+        const char* krow = p.k.p + (b * p.k.sb + h * p.k.sh + ktok[u] * p.k.sn + DQ * g) * 2;
+#pragma unroll
+        for (int c = 0; c < DQ / 8; ++c) {
+          float kv8[8];
+          unpack8<E>(ldg16(krow + c * 16), kv8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fk[8 * c + j] -= p.scale * dscol[u] * kv8[j];
+        }
+      }
+      char* d1 = p.dk.p + (b * p.dk.sb + h * p.dk.sh + ktok[u] * p.dk.sn + DQ * g) * 2;
+      char* d2 = p.dv.p + (b * p.dv.sb + h * p.dv.sh + ktok[u] * p.dv.sn + DQ * g) * 2;
 #pragma unroll
       for (int c = 0; c < DQ / 8; ++c) {
-        float kv8[8];
-        unpack8<E>(ldg16(krow + c * 16), kv8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) fk[8 * c + j] -= p.scale * dscol * kv8[j];
+        stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
+        stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
       }
-    }
-    char* d1 = p.dk.p + (b * p.dk.sb + h * p.dk.sh + ktok * p.dk.sn + DQ * g) * 2;
-    char* d2 = p.dv.p + (b * p.dv.sb + h * p.dv.sh + ktok * p.dv.sn + DQ * g) * 2;
-#pragma unroll
-    for (int c = 0; c < DQ / 8; ++c) {
-      stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
-      stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
     }
   }
 }
@@ -644,8 +701,16 @@ static int launch_sm_dr(int which, const SmP& p, hipStream_t st) {
     else if (qt == 2) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 2>), gq, block, 0, st, p);
     else hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 1>), gq, block, 0, st, p);
   } else {
-    hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR, KB>), grid, block, 0, st, p);
-    hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR, KB>), grid, block, 0, st, p);
+    const long bh = (long)p.B * p.H;
+    static const int qt_env = [] { const char* e = getenv("EA_SM_BQT"); return e ? atoi(e) : 0; }();   // dev knob
+    int qt = (D <= 64 && bh * ((p.N + 127) / 128) >= 2 * ea_device_cus()) ? 2 : 1;
+    if (qt_env > 0) qt = qt_env;
+    if (D > 64) qt = 1;
+    const dim3 gq((unsigned)(bh * ((p.N + 64 * qt - 1) / (64 * qt))));
+    if (qt == 2) { if constexpr (D <= 64) hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR, KB, 2>), gq, block, 0, st, p); }
+    else hipLaunchKernelGGL((sm_bwd_dq_kernel<E, D, DR, KB, 1>), gq, block, 0, st, p);
+    if (qt == 2) { if constexpr (D <= 64) hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR, KB, 2>), gq, block, 0, st, p); }
+    else hipLaunchKernelGGL((sm_bwd_dkv_kernel<E, D, DR, KB, 1>), gq, block, 0, st, p);
   }
   return (int)hipGetLastError();
 }
