@@ -124,7 +124,11 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
             mx = lk.amax(dim=-2, keepdim=True).detach()
             if self.ext_size > 0:
                 # overlapping windows: sums over the extended patch, gathered; a slot outside the sequence is a key
-                # with log-feature 0 and v = 0 (the reference's zero padding), which also enters the stabiliser
+                # with log-feature 0 and v = 0 (the reference's zero padding), which also enters the stabiliser.
+                # Memory: the gathers below are fp32 [B,h,G,Wk,m] / [B,h,G,Wk,d] and stay alive for autograd -- with
+                # e = w/2 on a 2-D grid that is ~4x the token count times (m + d) floats per layer (the reference
+                # materialises the same padded tensors).  This variant is kept for parity with the reference's
+                # behaviour (NaN beyond small keys), not as a production path.
                 mx = mx.clamp(min=0.0)
                 pk = torch.exp(lk - mx)
                 slots = self._key_slots(seq_shape, q.device)                            # [G, Wk], N = outside
