@@ -220,10 +220,11 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
 
 // static geometry of the window kernels: tile counts as template constants (0 = read the tiling at run time)
 // HO (backward): phase A hands P and dS to phase B through LDS instead of phase B recomputing them (ea_window_bwd.hip)
-struct SGdyn { static constexpr int NQT = 0, NLT = 0, NCT = 0, WPI = 0; static constexpr bool HO = false; };
-template <int a, int b, int c, int d, bool ho = false> struct SGs {
+// PW (with HO): launches without a padding mask whose windows are all complete -- key validity is static
+struct SGdyn { static constexpr int NQT = 0, NLT = 0, NCT = 0, WPI = 0; static constexpr bool HO = false, PW = false; };
+template <int a, int b, int c, int d, bool ho = false, bool pw = false> struct SGs {
   static constexpr int NQT = a, NLT = b, NCT = c, WPI = d;
-  static constexpr bool HO = ho;
+  static constexpr bool HO = ho, PW = pw;
 };
 
 struct T4 {
@@ -259,6 +260,7 @@ struct WinP {
   int keep_ld;
   float keep_scale;
   int bias_lds;                              // bwd: the bias table of the head is staged in LDS
+  int plain;                                 // no padding mask and every window complete: key validity is static (round 3)
   // bwd, how local dk/dv leave the kernel: 0 = stored to dk/dv; 1 = fp32 read-modify-write into dk32/dv32
   // (launches ordered by the stream); 2 / 3 = plain fp32 stores into slice t.slice of dk32/dv32 (2: one
   // slice per query block, 3: one per colour class -- they differ in the finish pass)

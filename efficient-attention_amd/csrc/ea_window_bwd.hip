@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         const float4 v = *reinterpret_cast<const float4*>(p.bias + ((size_t)h * t.WqFull + t.qoff + qs) * biasLd + tl * 16 + 4 * g);
         breg[tl] = f32x4{v.x, v.y, v.z, v.w};
       }
+      if (SG::PW) {
+        // static key validity (slots beyond the window's keys) rides in the bias registers as an additive -inf
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (tl * 16 + 4 * g + r >= t.Wk) breg[tl][r] = -INFINITY;
+      }
     }
   }
   const int it_end = min((blk + 1) * t.ipb, t.niter);
@@ -348,6 +354,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
       if (prof_it == 0) EA_STAMP(p, 20);
+      // PW (HAND launches without a padding mask whose windows are all complete): key validity is static, so the
+      // logit is ONE fma -- s * scale + (bias | -inf) -- and dS needs no gradient mask; otherwise the masked_fill form
+      constexpr bool PW = HAND && SG::PW;
       for (int ch = 0; ch < nchunks; ++ch) {
         int rowbase[4];
         const char* kt_p[4];
@@ -367,8 +376,9 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             s = E::mma(as_x8<E>(lds16(kt_p[tt] + lo.plain[ks])), qf[ks], s);
             dp = E::mma(as_x8<E>(lds16(vt_p + lo.plain[ks])), dof[ks], dp);
           }
-          const float4 m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
-          const float4 a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
+          float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!PW) m4 = *reinterpret_cast<const float4*>(kmul + rowbase[tt] + 4 * g);
+          if (!PW || !local) a4 = *reinterpret_cast<const float4*>(kadd + rowbase[tt] + 4 * g);
           const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w};
           float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);                                  // log2-domain bias
           if constexpr (HAND) {
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           float ds[4], prr[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float x = fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
+            float x = PW ? fmaf(s[r], p.scale_log2, local ? bb[r] : aa[r]) : fmaf(mm[r], fmaf(s[r], p.scale_log2, bb[r]), aa[r]);
             float gm = mm[r];
             if (CA) {
               const bool blocked = kidx0 + r > lim;
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
             float dpr = dp[r];
             if (DR) dpr = ((keep4 >> (8 * r)) & 0xffu) ? dpr * p.keep_scale : 0.f;
             // masked_fill blocks the gradient of the replaced logits (mul == 0)
-            ds[r] = gm * pr * (dpr - delta);
+            ds[r] = PW ? pr * (dpr - delta) : gm * pr * (dpr - delta);
             prr[r] = pr;
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
@@ -782,6 +792,11 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
       if (!gb && p.nq <= 1) {
         const WinTiling& t = p.t;
         if (t.nQT == 4 && t.nLT == 4 && t.wpi == 1) {
+          if (hand_over() && p.plain) {
+            if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true, true>>;
+            if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true, true>>;
+            if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true, true>>;
+          }
           if (hand_over()) {
             if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true>>;
             if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true>>;
@@ -797,6 +812,9 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
   };
   auto launch = [&](WinP& p, size_t lds, unsigned blocks) -> int {
     const bool gb = p.bias && !p.bias_lds;
+    static const bool plain_on = [] { const char* e = getenv("EA_WIN_PLAIN"); return !e || atoi(e) != 0; }();   // dev switch
+    p.plain = (plain_on && !p.mask && p.e == 0 &&
+               (p.G.attn2d ? (p.G.gh % p.w == 0 && p.G.gw % p.w == 0) : p.G.N % p.w == 0)) ? 1 : 0;
     const KernelT kern = pick(p, gb);
     if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && hand_over() && p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 &&
         (p.t.nCT == 4 || p.t.nCT == 3 || p.t.nCT == 0))
