@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Worst observed parity errors per (test file, variant, dtype) from an EA_TEST_ERR_LOG file."""
+"""Worst observed parity errors per (test file, variant, dtype) from an EA_TEST_ERR_LOG file.
+  usage: tol_report.py <log> [out.json]   (out.json: the table tests/gpu_checks.py::tol_for reads,
+  tests/golden/observed_errors.json -- {"<test file>|<variant>|<dtype>": [max, rms]})"""
 import collections, re, sys
 worst = collections.defaultdict(lambda: [0.0, 0.0, ""])
 for line in open(sys.argv[1]):
@@ -16,3 +18,6 @@ for line in open(sys.argv[1]):
     if rms > worst[k][1]: worst[k][1] = rms
 for k in sorted(worst):
     print("%-28s %-13s %-5s max %.4f rms %.4f   (%s)" % (k + (worst[k][0], worst[k][1], worst[k][2])))
+if len(sys.argv) > 2:
+    import json
+    json.dump({"%s|%s|%s" % k: [round(v[0], 5), round(v[1], 5)] for k, v in sorted(worst.items())}, open(sys.argv[2], "w"), indent=1)
