@@ -591,10 +591,18 @@ def main():
         others = None
         if world == 1 and a.workload == "cfg3" and a.attn != "causal_eva" and not a.no_other_workloads:
             others = {}
-            for key, (Bo, Co, Ho, so) in (("cfg2_N196", (128, 192, 3, (14, 14))), ("cfg5_N4096_B16", (16, 512, 8, (4096,))),
-                                           ("cfg5_N4096_B1", (1, 512, 8, (4096,)))):
+            runs = [("cfg2_N196", a.attn, (128, 192, 3, (14, 14))), ("cfg5_N4096_B16", a.attn, (16, 512, 8, (4096,))),
+                    ("cfg5_N4096_B1", a.attn, (1, 512, 8, (4096,)))]
+            # the other variants north_star names, at the headline geometry and at N = 4096, so that a driver-run line exists
+            # for them too: EVA (named first) and the softmax baseline both are measured against
+            for other in ("eva", "softmax"):
+                if other != a.attn:
+                    runs.append(("cfg3_N784_%s" % other, other, (B, C, H, seq)))
+                    runs.append(("cfg5_N4096_B16_%s" % other, other, (16, 512, 8, (4096,))))
+            for key, attn_o, (Bo, Co, Ho, so) in runs:
                 try:
-                    others[key] = measure_workload(a.attn, Bo, Co, Ho, so, dev, tune=tune)
+                    others[key] = measure_workload(attn_o, Bo, Co, Ho, so, dev, tune=tune)
+                    others[key]["attn"] = attn_o
                 except Exception as ex:          # never let an extra line take the headline measurement down
                     others[key] = {"error": str(ex).split("\n")[0][:200]}
         line = {
