@@ -773,12 +773,6 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
   }
 }
 
-// dev switch: EA_WIN_HANDOVER=0 keeps the recomputing phase B for the static geometries
-static bool hand_over() {
-  static const bool v = [] { const char* e = getenv("EA_WIN_HANDOVER"); return !e || atoi(e) != 0; }();
-  return v;
-}
-
 template <typename E, int D>
 static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
@@ -792,19 +786,15 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
       if (!gb && p.nq <= 1) {
         const WinTiling& t = p.t;
         if (t.nQT == 4 && t.nLT == 4 && t.wpi == 1) {
-          if (hand_over() && p.plain) {
+          // (the static geometries always take the hand-over kernels; the recomputing phase B lives on in SGdyn only)
+          if (p.plain) {
             if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true, true>>;
             if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true, true>>;
             if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true, true>>;
           }
-          if (hand_over()) {
-            if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true>>;
-            if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true>>;
-            if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true>>;
-          }
-          if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1>>;
-          if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1>>;
-          if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1>>;
+          if (t.nCT == 4) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 4, 1, true>>;
+          if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true>>;
+          if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true>>;
         }
       }
     }
@@ -816,7 +806,7 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
     p.plain = (plain_on && !p.mask && p.e == 0 &&
                (p.G.attn2d ? (p.G.gh % p.w == 0 && p.G.gw % p.w == 0) : p.G.N % p.w == 0)) ? 1 : 0;
     const KernelT kern = pick(p, gb);
-    if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && hand_over() && p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 &&
+    if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 &&
         (p.t.nCT == 4 || p.t.nCT == 3 || p.t.nCT == 0))
       // hand-over variant: no bias table / bias-gradient image in LDS, P / dS tiles of the landmark keys instead
       lds = window_bwd_lds(p.t, D, false, false) + (size_t)p.t.nQT * p.t.nCT * 1024;

@@ -18,6 +18,19 @@ from . import _native as nv
 
 KERNEL_TIMER = nv.KERNEL_TIMER
 # algorithmic HBM traffic of one launch, in units of one [B,H,N,D] I/O-dtype tensor
+# Eager calls of the cores skip the dispatcher: torch.ops.ea.<name> costs ~15-20 us of host time per call (Python -> C++
+# dispatcher -> Python implementation), six of them per layer step.  While a graph is being traced (torch.compile) the
+# dispatcher op stays, so the core is one opaque node there (its fake implementation lives in _dispatch.py).
+_DIRECT = os.environ.get("EA_DIRECT_IMPL", "1") == "1"
+
+
+def _ea_op(name, impl, *args):
+    # (any active dispatch mode -- fake tensors, make_fx proxies, functionalisation -- means somebody is tracing)
+    if _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0:
+        return impl(*args)
+    return getattr(torch.ops.ea, name)(*args)
+
+
 def landmark_flops(BH, L, C, D, has_mlp, mixed, eva, bwd):
     """FLOPs executed by one ea_lara_landmarks_fwd/bwd launch (real sizes, 2 per multiply-add): the
     matrix products of ea_lara_landmark.hip.  The backward reloads the forward's saved intermediates
@@ -304,7 +317,7 @@ class LocalAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
         geo = _geo(attn_2d, seq_shape, window, ext)
-        out, lse, bias_p = torch.ops.ea.local_fwd(qkv5, bias, mask_u8, geo)
+        out, lse, bias_p = _ea_op("local_fwd", local_fwd_impl, qkv5, bias, mask_u8, geo)
         ctx.save_for_backward(qkv5, _opt(bias_p), mask_u8, lse, out)
         ctx.geo = geo
         ctx.bias_cols = 0 if bias is None else bias.shape[-1]
@@ -313,7 +326,7 @@ class LocalAttnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
-        dqkv5, dbias = torch.ops.ea.local_bwd(dout, None, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
+        dqkv5, dbias = _ea_op("local_bwd", local_bwd_impl, dout, None, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
         return dqkv5, _opt(dbias), None, None, None, None, None
 
 
@@ -324,7 +337,7 @@ class LocalAttnLseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv5, bias, mask_u8, attn_2d, seq_shape, window, ext):
         geo = _geo(attn_2d, seq_shape, window, ext)
-        out, lse, bias_p = torch.ops.ea.local_fwd(qkv5, bias, mask_u8, geo)
+        out, lse, bias_p = _ea_op("local_fwd", local_fwd_impl, qkv5, bias, mask_u8, geo)
         ctx.save_for_backward(qkv5, _opt(bias_p), mask_u8, lse, out)
         ctx.geo = geo
         ctx.bias_cols = 0 if bias is None else bias.shape[-1]
@@ -333,7 +346,7 @@ class LocalAttnLseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dlse):
         qkv5, bias_p, mask_u8, lse, out = ctx.saved_tensors
-        dqkv5, dbias = torch.ops.ea.local_bwd(dout, dlse, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
+        dqkv5, dbias = _ea_op("local_bwd", local_bwd_impl, dout, dlse, qkv5, bias_p, mask_u8, out, lse, ctx.geo, ctx.bias_cols)
         return dqkv5, _opt(dbias), None, None, None, None, None
 
 
@@ -498,7 +511,7 @@ class EvaAttnFn(torch.autograd.Function):
         keep, keep_scale = cfg[9:11] if len(cfg) > 9 else (None, 1.0)
         icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), int(causal), int(any(ctx.needs_input_grad))]
         fcfg = [float(mu_scale), float(keep_scale)]
-        outs = torch.ops.ea.eva_fwd(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
+        outs = _ea_op("eva_fwd", eva_fwd_impl, qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
         ctx.save_for_backward(qkv5, mask_u8, keep, noise, *outs, *mlp_params)
         ctx.nsaved = len(outs) - 1
         ctx.cfg = (icfg, fcfg, adaptive_proj, 0 if bias is None else bias.shape[-1])
@@ -510,7 +523,7 @@ class EvaAttnFn(torch.autograd.Function):
         qkv5, mask_u8, keep, noise, out, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         icfg, fcfg, adaptive_proj, bias_cols = ctx.cfg
-        g = torch.ops.ea.eva_bwd(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
+        g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
                                  bias_cols, list(params))
         pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
         return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
@@ -987,7 +1000,7 @@ class LaraPooledFn(torch.autograd.Function):
         icfg = [int(H), int(W), int(r), int(bool(has_mlp)), int(bool(mixed)), int(mis), int(dup),
                 int(any(ctx.needs_input_grad))]
         fcfg = [float(kappa), float(scale)]
-        outs = torch.ops.ea.lara_fwd(qkv5, mask_u8, noise, icfg, fcfg, list(params))
+        outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
         ctx.save_for_backward(qkv5, mask_u8, noise, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
         ctx.pdtypes = [t.dtype for t in params]
@@ -997,7 +1010,7 @@ class LaraPooledFn(torch.autograd.Function):
     def backward(ctx, dout):
         qkv5, mask_u8, noise, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
-        grads = torch.ops.ea.lara_bwd(dout, qkv5, mask_u8, noise, list(saved), ctx.icfg, ctx.fcfg, list(params))
+        grads = _ea_op("lara_bwd", lara_bwd_impl, dout, qkv5, mask_u8, noise, list(saved), ctx.icfg, ctx.fcfg, list(params))
         pgrads = [g.to(dt) for g, dt in zip(grads[1:], ctx.pdtypes)]
         return (grads[0], None, None, None) + tuple(pgrads)
 
@@ -1218,7 +1231,7 @@ class SoftmaxAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv5, mask_u8, keep=None, keep_scale=1.0):
-        out, lse = torch.ops.ea.softmax_fwd(qkv5, mask_u8, keep, float(keep_scale))
+        out, lse = _ea_op("softmax_fwd", softmax_fwd_impl, qkv5, mask_u8, keep, float(keep_scale))
         ctx.save_for_backward(qkv5, mask_u8, out, lse, keep)
         ctx.keep_scale = float(keep_scale)
         return out
@@ -1226,7 +1239,7 @@ class SoftmaxAttnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         qkv5, mask_u8, out, lse, keep = ctx.saved_tensors
-        return torch.ops.ea.softmax_bwd(dout, qkv5, mask_u8, out, lse, keep, ctx.keep_scale), None, None, None
+        return _ea_op("softmax_bwd", softmax_bwd_impl, dout, qkv5, mask_u8, out, lse, keep, ctx.keep_scale), None, None, None
 
 
 class SoftmaxQKVFn(torch.autograd.Function):
@@ -1346,14 +1359,14 @@ class PerformerAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv5, mask_u8, W):
-        out, stab, kv, ksum = torch.ops.ea.performer_fwd(qkv5, mask_u8, W)
+        out, stab, kv, ksum = _ea_op("performer_fwd", performer_fwd_impl, qkv5, mask_u8, W)
         ctx.save_for_backward(qkv5, mask_u8, W, stab, kv, ksum, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv5, mask_u8, W, stab, kv, ksum, out = ctx.saved_tensors
-        return torch.ops.ea.performer_bwd(dout, qkv5, mask_u8, W, stab, kv, ksum, out), None, None
+        return _ea_op("performer_bwd", performer_bwd_impl, dout, qkv5, mask_u8, W, stab, kv, ksum, out), None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -1653,7 +1666,7 @@ class LinearFn(torch.autograd.Function):
         if weight.dtype == torch.float32 and dtype != torch.float32 and ea_linear_w32_supported(x2, weight, dtype):
             # streaming projection kernel fed by the fp32 MASTER weight: both autocast casts (of x and of the weight) are
             # folded into the kernel's loads -- no cast kernels in a training step
-            y, xc = torch.ops.ea.linear_w32(x2, weight, b32, _ELEM[dtype], False, False, want)
+            y, xc = _ea_op("linear_w32", linear_w32_impl, x2, weight, b32, _ELEM[dtype], False, False, want)
             xl = x2 if x2.dtype == dtype else (xc if want else None)
             wl = weight
         else:
@@ -1661,7 +1674,7 @@ class LinearFn(torch.autograd.Function):
             if ea_linear_supported(x2, wl):
                 # an fp32 x is rounded on the way in (no cast pass), its rounded copy comes back only when the weight
                 # gradient will need it
-                y, xc = torch.ops.ea.linear(x2, wl, b32, False, want)
+                y, xc = _ea_op("linear", linear_impl, x2, wl, b32, False, want)
                 xl = x2 if x2.dtype == dtype else (xc if want else None)
             else:
                 xl = x2 if x2.dtype == dtype else x2.to(dtype)
@@ -1684,14 +1697,14 @@ class LinearFn(torch.autograd.Function):
             if (wl.dtype == torch.float32 and cdtype != torch.float32 and xdtype in (torch.float32, cdtype)
                     and ea_linear_w32_supported(dy2, wl, cdtype, transposed=True)):
                 # dX = dY W straight from the master weight [out, in] read as the transposed operand: no W^T copy, no cast
-                dx = torch.ops.ea.linear_w32(dy2, wl, None, _ELEM[cdtype], True, y_f32, False)[0].view(xshape)
+                dx = _ea_op("linear_w32", linear_w32_impl, dy2, wl, None, _ELEM[cdtype], True, y_f32, False)[0].view(xshape)
             else:
                 wc = wl if wl.dtype == cdtype else wl.to(cdtype)
                 # the launch is y = dY (W^T)^T: the geometry to validate is K = out, NO = in of the forward weight
                 if (xdtype in (torch.float32, wc.dtype) and wc.dtype in _ELEM and _lin_geometry(wc.shape[0], wc.shape[1])
                         and _lin_rows_ok(dy2, wc.dtype)):
                     # dX = dY W as the same streaming kernel on the transposed weight (a [in, out] copy of <= 128 KB)
-                    dx = torch.ops.ea.linear(dy2, wc.t().contiguous(), None, y_f32, False)[0].view(xshape)
+                    dx = _ea_op("linear", linear_impl, dy2, wc.t().contiguous(), None, y_f32, False)[0].view(xshape)
                 else:
                     dx = _mm_out(dy2, wc, xdtype).view(xshape)
         need_w, need_b = ctx.needs_input_grad[1], (bdtype is not None and ctx.needs_input_grad[2])
