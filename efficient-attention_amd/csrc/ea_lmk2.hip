@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       ri[r] = p.dup == 1 ? c % L : c;
       sg[r] = (p.dup == 1 && c >= L) ? -1.f : 1.f;
     }
-    gather_strip<NT>(n, p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC, D, ri, ok, D, l);
+    gather_strip<NT>(n, p.dup == 1 ? p.noise + (size_t)bh * L * D : p.noise + oC, D, p.dup == 1 ? L : nrows, ri, ok, D, l);
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
           k0[ct][r] = pv[2 * D + o] * xk[ct][r] + pv[3 * D + o];
         }
       if (sv) {
-        save_strip<NT>(sv_xq, xq, D, L, D, l);
-        save_strip<NT>(sv_xk, xk, D, L, D, l);
+        gsave_strip<NT>(sv_xq, xq, D, L, D, l);
+        gsave_strip<NT>(sv_xk, xk, D, L, D, l);
         if (l.li == 0)
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (r0 + r < 64) { sv_rstd[r0 + r] = rsq[r]; sv_rstd[64 + r0 + r] = rsk[r]; }
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           om[ct][r] = 0.5f * (qb[ct][r] + k0[ct][r]) + nz[ct][r];
-      save_strip<NT>(p.qbar_rows + oC, k0, D, L, D, l);
-      save_strip<NT>(p.omega + oC, om, D, L, D, l);
+      gsave_strip<NT>(p.qbar_rows + oC, k0, D, L, D, l);
+      gsave_strip<NT>(p.omega + oC, om, D, L, D, l);
       return;
     }
     __syncthreads();                                 // every wave is done with PQ / PK / WQ / WK
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[ct][r] *= den[r];
-      if (sv) save_strip<4>(sv_a, a, 64, L, L, l);
+      if (sv) gsave_strip<4>(sv_a, a, 64, L, L, l);
       store_t<H, 4>(T1, a, 1.f, L, L, l);               // AST [l'][l]: read back by this wave only (its own columns)
       zero<NT>(kb);
       mm<H, 64, true, 64, true, NT>(kb, T1, T0, 2, l);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int r = 0; r < 4; ++r) { mu[ct][r] = (r0 + r < L) ? qb[ct][r] + kb[ct][r] : 0.f; m2[r] += mu[ct][r] * mu[ct][r]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m2[r] = row16_sum(m2[r]); if (l.li == 0 && r0 + r < 64) musq[r0 + r] = m2[r]; }
-    if (sv) save_strip<NT>(sv_mu, mu, D, L, D, l);
+    if (sv) gsave_strip<NT>(sv_mu, mu, D, L, D, l);
     float* XMU = reinterpret_cast<float*>(T5);        // [64][D] fp32
     float* XQB = XMU + 64 * D;
     save_strip<NT>(XMU, mu, D, 64, D, l);
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
         om[ct][r] = c < C ? m + nz[ct][r] : 0.f;
         qr[ct][r] = p.mis == 0 ? q : m;
       }
-    save_strip<NT>(p.omega + oC, om, D, C, D, l);
-    if (p.mis != 2) save_strip<NT>(p.qbar_rows + oC, qr, D, C, D, l);
+    gsave_strip<NT>(p.omega + oC, om, D, C, D, l);
+    if (p.mis != 2) gsave_strip<NT>(p.qbar_rows + oC, qr, D, C, D, l);
     store_t<H, NT>(T3, om, 1.f, C, D, l);               // OMT [o][c]
     __syncthreads();
     // F5: M = s omega mu^T - s |mu_l|^2 / 2 ; proposal densities per sample row
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
         f32x4 t[NT];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ok[r] = r0 + r < L; ri[r] = min(r0 + r, L - 1) + k * L; }
-        gather_strip<NT>(t, p.d_qbar_rows + oC, D, ri, ok, D, l);
+        gather_strip<NT>(t, p.d_qbar_rows + oC, D, C, ri, ok, D, l);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) dqs[ct] = dqs[ct] + t[ct];
       }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     }
     if (have_mu) {
       load_strip<NT>(mu, sv_mu, D, L, D, l);
-      gather_strip<NT>(muc, sv_mu, D, rl, rok, D, l);
+      gather_strip<NT>(muc, sv_mu, D, L, rl, rok, D, l);
     } else {
       // no saved mu: mu = q_bar + k_bar with both given
       f32x4 a[NT], b[NT];
@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       load_strip<NT>(b, p.pk + oL, D, L, D, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) mu[ct] = a[ct] + b[ct];
-      gather_strip<NT>(a, p.pq + oL, D, rl, rok, D, l);
-      gather_strip<NT>(b, p.pk + oL, D, rl, rok, D, l);
+      gather_strip<NT>(a, p.pq + oL, D, L, rl, rok, D, l);
+      gather_strip<NT>(b, p.pk + oL, D, L, rl, rok, D, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) muc[ct] = a[ct] + b[ct];
     }
@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
   EA_STAMP(p, 6);
   // ---- tail: LayerNorm + Linear backward of both sides (dY = dqb / dk0 in registers) ----
   if (!p.has_mlp) {
-    save_strip<NT>(p.dpq + oL, dqb, D, L, D, l);
-    save_strip<NT>(p.dpk + oL, dk0, D, L, D, l);
+    gsave_strip<NT>(p.dpq + oL, dqb, D, L, D, l);
+    gsave_strip<NT>(p.dpk + oL, dk0, D, L, D, l);
     return;
   }
   __syncthreads();                                    // cpart / tiles of the mixing backward / the exchange buffer are free
@@ -626,24 +626,24 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     mm<H, 64, true, D, false, NT>(dp, T0, WQt, KD, l);   // A-op = dH rows l (DHT = [k][m]); B[k=o][n=i] = W row-major
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) dp[ct] = dp[ct] * (1.f / shq);
-    save_strip<NT>(p.dpq + oL, dp, D, L, D, l);
+    gsave_strip<NT>(p.dpq + oL, dp, D, L, D, l);
     zero<NT>(dp);
     mm<H, 64, true, D, false, NT>(dp, T3, WKt, KD, l);
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) dp[ct] = dp[ct] * (1.f / shk);
-    save_strip<NT>(p.dpk + oL, dp, D, L, D, l);
+    gsave_strip<NT>(p.dpk + oL, dp, D, L, D, l);
     if (16 * l.w < D) {                               // rows o of dW: D / 16 strips
       f32x4 dw[NT];
       zero<NT>(dw);
       mm<H, 64, false, D, false, NT>(dw, T0, PQt, 2, l); // A-op = dH^T rows o (DHT row-major); B[k=l][n=i] = P row-major
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) dw[ct] = dw[ct] * (1.f / shq);
-      save_strip<NT>(p.dW_part + ((size_t)bh * 2 + 0) * D * D, dw, D, D, D, l);
+      gsave_strip<NT>(p.dW_part + ((size_t)bh * 2 + 0) * D * D, dw, D, D, D, l);
       zero<NT>(dw);
       mm<H, 64, false, D, false, NT>(dw, T3, PKt, 2, l);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) dw[ct] = dw[ct] * (1.f / shk);
-      save_strip<NT>(p.dW_part + ((size_t)bh * 2 + 1) * D * D, dw, D, D, D, l);
+      gsave_strip<NT>(p.dW_part + ((size_t)bh * 2 + 1) * D * D, dw, D, D, D, l);
     }
   }
   EA_STAMP(p, 9);

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, GLOBAL ? 3 : 1) void sb_bwd_kernel(const SbP p
     }
   }
   if (!GLOBAL) {
-    save_strip<4>(p.p_dsall + ((size_t)bh * npb + np) * M * 64, gs, 64, M, 64, l);
+    gsave_strip<4>(p.p_dsall + ((size_t)bh * npb + np) * M * 64, gs, 64, M, 64, l);
     if (l.li == 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r)

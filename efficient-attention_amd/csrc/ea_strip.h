@@ -64,34 +64,60 @@ template <typename H, int NT> EA_DEV void store_t(char* tile, const f32x4* s, fl
   }
 }
 
-// fp32 [rows][ld] matrix <-> strip
-// (loads are unconditional -- clamped indices, zero selected afterwards: a predicated load costs an
-//  exec-mask branch and a full memory round trip EACH, which made the first version latency-bound)
+// fp32 [rows][ld] matrix in GLOBAL memory <-> strip, through raw buffer instructions (round 3).
+// A strip element (row r0 + r, column 16 ct + li) sits at byte offset ((r0 + r) ld + li) 4 + 64 ct: ONE offset register per
+// r plus an immediate, no 64-bit address arithmetic; the buffer's size is rows * ld * 4, so rows beyond `rows` read as
+// zero and their stores are dropped BY THE HARDWARE bounds check -- no clamp, no select, no exec-mask branch per element.
+// (The dword-per-element form with flat addresses was ~40 % of the landmark kernels' instructions: 16 address computations
+// per strip, a predicated region per stored element, and `cond ? load : 0` selects that hipcc turned back into branches
+// with a full wait behind each.)
+EA_DEV __amdgpu_buffer_rsrc_t strip_rsrc(const float* base, int rows, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, rows * ld * 4, 0x00020000);
+}
+constexpr int STRIP_OOB = 0x40000000;               // an offset no buffer here reaches: reads 0, stores nothing
+EA_DEV float strip_ld(__amdgpu_buffer_rsrc_t rs, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
 template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
   if (!src) { zero<NT>(s); return; }                 // (uniform)
-  const int r0 = 16 * l.w + 4 * l.g;
+  const __amdgpu_buffer_rsrc_t rs = strip_rsrc(src, rows, ld);
+  const int base = ((16 * l.w + 4 * l.g) * ld + l.li) * 4;
+  const bool cm = cols < 16 * NT;                    // (uniform) narrower than the strip: mask the columns too
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
+    const bool cok = !cm || 16 * ct + l.li < cols;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = src[(size_t)min(r0 + r, rows - 1) * ld + cc];
-      s[ct][r] = (r0 + r < rows && col < cols) ? v : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) s[ct][r] = strip_ld(rs, cok ? base + r * ld * 4 + 64 * ct : STRIP_OOB);
   }
 }
-// rows given explicitly (ri[r] valid indices), zero where !ok[r]
-template <int NT> EA_DEV void gather_strip(f32x4* s, const float* src, int ld, const int* ri, const bool* ok, int cols, const Lane& l) {
+// rows given explicitly (ri[r] < nrows), zero where !ok[r]
+template <int NT>
+EA_DEV void gather_strip(f32x4* s, const float* src, int ld, int nrows, const int* ri, const bool* ok, int cols, const Lane& l) {
+  const __amdgpu_buffer_rsrc_t rs = strip_rsrc(src, nrows, ld);
+  const bool cm = cols < 16 * NT;
+  int ro[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ro[r] = ok[r] ? (ri[r] * ld + l.li) * 4 : STRIP_OOB;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
-    const int col = 16 * ct + l.li, cc = min(col, cols - 1);
+    const bool cok = !cm || 16 * ct + l.li < cols;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = src[(size_t)ri[r] * ld + cc];
-      s[ct][r] = (ok[r] && col < cols) ? v : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) s[ct][r] = strip_ld(rs, cok ? ro[r] + 64 * ct : STRIP_OOB);
   }
 }
+template <int NT> EA_DEV void gsave_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
+  const __amdgpu_buffer_rsrc_t rs = strip_rsrc(dst, rows, ld);
+  const int base = ((16 * l.w + 4 * l.g) * ld + l.li) * 4;
+  const bool cm = cols < 16 * NT;
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+    const bool cok = !cm || 16 * ct + l.li < cols;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (float)s[ct][r]), rs, cok ? base + r * ld * 4 + 64 * ct : STRIP_OOB, 0, 0);
+  }
+}
+// strip -> fp32 [rows][ld] matrix behind a plain pointer (LDS exchange buffers)
 template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
   const int r0 = 16 * l.w + 4 * l.g;
 #pragma unroll
