@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[ct][r] *= den[r];
-      if (sv) gsave_strip<4>(sv_a, a, 64, L, L, l);
+      if (sv) gsave_strip<4, true>(sv_a, a, 64, L, L, l);
       store_t<H, 4>(T1, a, 1.f, L, L, l);               // AST [l'][l]: read back by this wave only (its own columns)
       zero<NT>(kb);
       mm<H, 64, true, 64, true, NT>(kb, T1, T0, 2, l);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) muc[ct] = a[ct] + b[ct];
     }
-    if (p.mixed) load_strip<4>(asm_, sv_a, 64, L, L, l);
+    if (p.mixed) load_strip<4, true>(asm_, sv_a, 64, L, L, l);
     if (p.has_mlp) {
       commit_rows<D>(WQt, sb0, D, tid); commit_rows<D>(WKt, sb1, D, tid);
       commit_rows<D>(PQt, sb2, L, tid); commit_rows<D>(PKt, sb3, L, tid);

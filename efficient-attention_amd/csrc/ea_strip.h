@@ -78,11 +78,13 @@ constexpr int STRIP_OOB = 0x40000000;               // an offset no buffer here 
 EA_DEV float strip_ld(__amdgpu_buffer_rsrc_t rs, int off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
 }
-template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
+// CM: the matrix is narrower than the strip (cols < 16 NT): mask the columns too (otherwise `cols` is not looked at and
+// the column part of every offset is an immediate)
+template <int NT, bool CM = false> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int rows, int cols, const Lane& l) {
   if (!src) { zero<NT>(s); return; }                 // (uniform)
   const __amdgpu_buffer_rsrc_t rs = strip_rsrc(src, rows, ld);
   const int base = ((16 * l.w + 4 * l.g) * ld + l.li) * 4;
-  const bool cm = cols < 16 * NT;                    // (uniform) narrower than the strip: mask the columns too
+  constexpr bool cm = CM;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     const bool cok = !cm || 16 * ct + l.li < cols;
@@ -91,10 +93,10 @@ template <int NT> EA_DEV void load_strip(f32x4* s, const float* src, int ld, int
   }
 }
 // rows given explicitly (ri[r] < nrows), zero where !ok[r]
-template <int NT>
+template <int NT, bool CM = false>
 EA_DEV void gather_strip(f32x4* s, const float* src, int ld, int nrows, const int* ri, const bool* ok, int cols, const Lane& l) {
   const __amdgpu_buffer_rsrc_t rs = strip_rsrc(src, nrows, ld);
-  const bool cm = cols < 16 * NT;
+  constexpr bool cm = CM;
   int ro[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) ro[r] = ok[r] ? (ri[r] * ld + l.li) * 4 : STRIP_OOB;
@@ -105,10 +107,10 @@ EA_DEV void gather_strip(f32x4* s, const float* src, int ld, int nrows, const in
     for (int r = 0; r < 4; ++r) s[ct][r] = strip_ld(rs, cok ? ro[r] + 64 * ct : STRIP_OOB);
   }
 }
-template <int NT> EA_DEV void gsave_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
+template <int NT, bool CM = false> EA_DEV void gsave_strip(float* dst, const f32x4* s, int ld, int rows, int cols, const Lane& l) {
   const __amdgpu_buffer_rsrc_t rs = strip_rsrc(dst, rows, ld);
   const int base = ((16 * l.w + 4 * l.g) * ld + l.li) * 4;
-  const bool cm = cols < 16 * NT;
+  constexpr bool cm = CM;
 #pragma unroll
   for (int ct = 0; ct < NT; ++ct) {
     const bool cok = !cm || 16 * ct + l.li < cols;
@@ -129,14 +131,24 @@ template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int
   }
 }
 
+// reductions over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15): four rotations within the row, each fused into
+// its add / max as a DPP operand.  (__shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip per step; the landmark
+// backward issued 174 of them in dependent chains.)  Every lane ends up with the full result.
+template <int CTRL> EA_DEV float dpp_rot(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 EA_DEV float row16_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_rot<0x128>(v);   // row_ror:8
+  v += dpp_rot<0x124>(v);   // row_ror:4
+  v += dpp_rot<0x122>(v);   // row_ror:2
+  v += dpp_rot<0x121>(v);   // row_ror:1
   return v;
 }
 EA_DEV float row16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  v = fmaxf(v, dpp_rot<0x128>(v));
+  v = fmaxf(v, dpp_rot<0x124>(v));
+  v = fmaxf(v, dpp_rot<0x122>(v));
+  v = fmaxf(v, dpp_rot<0x121>(v));
   return v;
 }
 EA_DEV float wave_maxf(float v) {
