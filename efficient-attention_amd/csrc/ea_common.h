@@ -219,6 +219,36 @@ EA_DEV float quad_sum(float v) {
   lane_swap32(a, b);
   return a + b;
 }
+
+// ---- lane reductions without the LDS pipe (round 3) ----
+// __shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip per step, in kernels whose LDS pipe is already the busy one.
+// Within a DPP row (16 lanes) the same sums are row rotations / quad permutes / a half-row mirror fused into the add as
+// DPP operands; across the four rows they are the two v_permlane swaps of quad_sum / quad_max above.
+template <int CTRL> EA_DEV float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// over the G consecutive lanes of an aligned group (G = 4, 8, 16); every lane gets the result
+template <int G> EA_DEV float group_sum(float v) {
+  static_assert(G == 4 || G == 8 || G == 16, "group_sum: 4, 8 or 16 lanes");
+  v += dpp_mov<0xB1>(v);                              // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);                              // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_mov<0x141>(v);                 // row_half_mirror: the other quad of the 8
+  if (G >= 16) v += dpp_mov<0x128>(v);                // row_ror:8: the other half of the row
+  return v;
+}
+// over the lanes with equal (lane % S) of the whole wave (S = 4, 8, 16): strides S .. 8 inside the rows, then the rows
+template <int S> EA_DEV float stride_sum(float v) {
+  static_assert(S == 4 || S == 8 || S == 16, "stride_sum: stride 4, 8 or 16");
+  if (S <= 8) v += dpp_mov<0x128>(v);                 // row_ror:8
+  if (S <= 4) v += dpp_mov<0x124>(v);                 // row_ror:4
+  return quad_sum(v);
+}
+template <int S> EA_DEV float stride_max(float v) {
+  static_assert(S == 4 || S == 8 || S == 16, "stride_max: stride 4, 8 or 16");
+  if (S <= 8) v = fmaxf(v, dpp_mov<0x128>(v));
+  if (S <= 4) v = fmaxf(v, dpp_mov<0x124>(v));
+  return quad_max(v);
+}
 EA_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 EA_DEV float wave_sum(float v) {
 #pragma unroll

@@ -19,17 +19,9 @@ namespace ea {
 
 
 // reduce across the lanes that hold the same channel chunk (stride CPR in lane id)
-template <int CPR> EA_DEV float rows_sum(float v) {
-#pragma unroll
-  for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o);
-  return v;
-}
+template <int CPR> EA_DEV float rows_sum(float v) { return stride_sum<CPR>(v); }
 // reduce across the CPR lanes of one row
-template <int CPR> EA_DEV float chan_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < CPR; o <<= 1) v += __shfl_xor(v, o);
-  return v;
-}
+template <int CPR> EA_DEV float chan_sum(float v) { return group_sum<CPR>(v); }
 
 // ------------------------------------------------------------------------------------------
 template <typename E, int D, int WPC>
@@ -560,8 +552,7 @@ template <int CPR, int NI> EA_DEV void chunk_lse(const float* x, float& m, float
   m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NI; ++i) m = fmaxf(m, x[i]);
-#pragma unroll
-  for (int o = CPR; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+  m = stride_max<CPR>(m);
   l = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) l += __expf(x[i] - m);

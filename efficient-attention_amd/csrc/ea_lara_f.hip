@@ -387,8 +387,7 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           float v = sdbh[ct][hh][e];
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          v = group_sum<16>(v);
           if (li == 0) DB[wave * Cp + 16 * ct + 4 * g + 2 * hh + e] = v;
         }
   }

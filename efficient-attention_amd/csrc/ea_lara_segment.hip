@@ -11,16 +11,8 @@
 
 namespace ea {
 
-template <int CPR> EA_DEV float row_sum(float v) {          // over the CPR lanes that share a row
-#pragma unroll
-  for (int o = 1; o < CPR; o <<= 1) v += __shfl_xor(v, o);
-  return v;
-}
-template <int CPR> EA_DEV float col_sum(float v) {          // over the 64/CPR row groups (same channels)
-#pragma unroll
-  for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o);
-  return v;
-}
+template <int CPR> EA_DEV float row_sum(float v) { return group_sum<CPR>(v); }           // over the CPR lanes that share a row
+template <int CPR> EA_DEV float col_sum(float v) { return stride_sum<CPR>(v); }          // over the 64/CPR row groups (same channels)
 
 template <typename E, int D, bool BWD>
 __global__ __launch_bounds__(256) void lara_segment_kernel(const SegP p) {

@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256, 2) void lara_y_kernel(const LaraP p) {
           unpack8<E>(pw1[i], f);
 #pragma unroll
           for (int k = 0; k < 8; ++k) part += f[k] * f[k];
-#pragma unroll
-          for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+          part = group_sum<CPR>(part);
           if (cc == 0) {
             if (MODE == LY_PMAX && p.stab_per_feature) {
               sc[row] = (!valid || ps0[i] != 0.f) ? -INFINITY : -p.norm_coef2 * part;   // max of the whole log-feature

@@ -26,8 +26,7 @@ template <typename E, int CPR> EA_DEV float key_norm_term(u32x4 kw, float scale_
   unpack8<E>(kw, f);
 #pragma unroll
   for (int j = 0; j < 8; ++j) part += f[j] * f[j];
-#pragma unroll
-  for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+  part = group_sum<CPR>(part);
   return -0.5f * scale_log2 * part;
 }
 

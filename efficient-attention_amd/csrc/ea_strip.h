@@ -134,21 +134,18 @@ template <int NT> EA_DEV void save_strip(float* dst, const f32x4* s, int ld, int
 // reductions over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15): four rotations within the row, each fused into
 // its add / max as a DPP operand.  (__shfl_xor compiles to ds_bpermute_b32 -- an LDS round trip per step; the landmark
 // backward issued 174 of them in dependent chains.)  Every lane ends up with the full result.
-template <int CTRL> EA_DEV float dpp_rot(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
 EA_DEV float row16_sum(float v) {
-  v += dpp_rot<0x128>(v);   // row_ror:8
-  v += dpp_rot<0x124>(v);   // row_ror:4
-  v += dpp_rot<0x122>(v);   // row_ror:2
-  v += dpp_rot<0x121>(v);   // row_ror:1
+  v += dpp_mov<0x128>(v);   // row_ror:8
+  v += dpp_mov<0x124>(v);   // row_ror:4
+  v += dpp_mov<0x122>(v);   // row_ror:2
+  v += dpp_mov<0x121>(v);   // row_ror:1
   return v;
 }
 EA_DEV float row16_max(float v) {
-  v = fmaxf(v, dpp_rot<0x128>(v));
-  v = fmaxf(v, dpp_rot<0x124>(v));
-  v = fmaxf(v, dpp_rot<0x122>(v));
-  v = fmaxf(v, dpp_rot<0x121>(v));
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x122>(v));
+  v = fmaxf(v, dpp_mov<0x121>(v));
   return v;
 }
 EA_DEV float wave_maxf(float v) {

@@ -285,8 +285,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         unpack8<E>(x.orr[i], o8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part += a8[j] * o8[j];
-#pragma unroll
-        for (int o = 1; o < CPR; o <<= 1) part += __shfl_xor(part, o);
+        part = group_sum<CPR>(part);
         if (x.rowv[i] >= 0) {
           const int c = (base + tid + i * 256) - x.rowv[i] * CPR;
           sts16(Qs + TileL<D>::off(x.rowv[i], c), x.qr[i]);
