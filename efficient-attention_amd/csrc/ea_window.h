@@ -1,6 +1,7 @@
 // ea_window.h -- host-side derived geometry + kernel parameter block of the window-attention
 // kernels (ea_window_fwd.hip / ea_window_bwd.hip).
 #pragma once
+#include <stdlib.h>
 #include "ea_common.h"
 
 namespace ea {
@@ -34,6 +35,10 @@ struct WinTiling {
   int slice;                  // merged query-block launch: this block's slice of the dk/dv scratch
   int bblk0;                  // offset of this launch's workgroups in dbias_part (query blocks write
                               // disjoint rows, so merged blocks share the slabs: bblk0 = 0)
+  int cdirect;                // 1-D windows extended by HALF a window on both sides (2 e = w, two colour classes): the
+                              // even windows' key ranges tile the sequence (but its last e tokens) and so do the odd
+                              // ones' (but the first e): class 0 STORES dk / dv in the I/O dtype, class 1 adds to them
+                              // -- no fp32 scratch slices, no finish pass (round 3)
 };
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -160,10 +165,10 @@ inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t);
 // Each class stores into its own scratch slice (plain stores: a read-modify-write is a dependent
 // global round trip per key tile, 20 % of the kernel at N = 4096) and the finish pass sums the
 // slices of the windows that cover a token.
-inline bool win_bwd_colour_slices(const WinTiling& t) { return t.qsplit == 1 && t.ncy == 1 && t.ncx > 1; }
+inline bool win_bwd_colour_slices(const WinTiling& t) { return t.qsplit == 1 && t.ncy == 1 && t.ncx > 1 && !t.cdirect; }
 // fp32 [B,H,N,D] scratch slices the backward needs for dk and for dv
 inline int win_bwd_acc_slices(const WinTiling& t) {
-  if (win_bwd_single(t)) return 0;
+  if (win_bwd_single(t) || t.cdirect) return 0;
   if (win_bwd_merged(t)) return t.qsplit;
   return win_bwd_colour_slices(t) ? t.ncx : 1;
 }
@@ -175,6 +180,11 @@ inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t) {
   return m;
 }
 
+// dev switch: EA_WIN_CDIRECT=0 keeps the scratch slices + finish pass for half-window overlap
+inline bool win_cdirect_on() {
+  static const bool v = [] { const char* e = getenv("EA_WIN_CDIRECT"); return !e || atoi(e) != 0; }();
+  return v;
+}
 inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   if (g.window <= 0 || g.D <= 0 || g.B <= 0 || g.H <= 0 || g.N <= 0) return EA_E_BADARG;
   if (g.causal < 0 || g.causal > 2 || (g.causal && (g.attn_2d || g.N % g.window))) return EA_E_BADARG;
@@ -194,7 +204,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   }
   t.WqFull = t.Wq;
   t.biasLd = ceil_div(t.Wk, 16) * 16;
-  t.qsplit = 1; t.qoff = 0; t.slice = 0; t.bblk0 = 0;
+  t.qsplit = 1; t.qoff = 0; t.slice = 0; t.bblk0 = 0; t.cdirect = 0;
   t.ncx = t.ncy = 1;
   t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
   win_derive(g, t, backward);
@@ -213,6 +223,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
       t.ncx = 1 + ceil_div(kext, w);
       t.ncy = g.attn_2d ? t.ncx : 1;
     }
+    t.cdirect = (!g.attn_2d && !g.causal && t.qsplit == 1 && t.ncx == 2 && 2 * e == w && g.N % w == 0 && win_cdirect_on()) ? 1 : 0;
     t.parts_total = win_bwd_launches(g, t, [](const WinTiling&) {});
   }
   return EA_OK;

@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   // accumulator, which live in registers here (a wave owns one query tile for the whole launch, so the bias rows it
   // reads and the bias-gradient entries it produces never change lanes).
   constexpr bool HAND = SG::HO;
-  static_assert(!HAND || (STATIC && SG::WPI == 1 && SG::NQT <= 4 && SG::NLT <= 4 && !GB && !CA && !DR && D == 64),
-                "hand-over variant: static one-window geometries only");
+  // NQW: (window, query tile) pairs of an iteration -- one per wave, the same pair index every iteration
+  constexpr int NQW = STATIC ? SG::WPI * SG::NQT : 0;
+  static_assert(!HAND || (STATIC && NQW <= 4 && SG::NLT <= 4 && !GB && !CA && !DR && D == 64),
+                "hand-over variant: static geometries with at most four query tiles per iteration");
   constexpr int NKT = SG::NLT + SG::NCT;             // key tiles of a window (HAND)
   char* Ks = smem;
   // HAND: [K local | V local | K landmark (+ zero tile) | V landmark (+ zero tile)], else [K all | V all]
@@ -83,13 +85,13 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   char* slabL = Ks;                                   // HAND: P / dS tiles of the local key tiles
   char* slabC = reinterpret_cast<char*>(delta_s + rowsQ);   // HAND: ... of the landmark key tiles
   auto slab_tile = [&](int qt, int kt) -> char* {     // 1 KB per (query tile, key tile): P then dS, [16 queries][16 keys]
-    return kt < SG::NLT ? slabL + (qt * SG::NLT + kt) * 1024 : slabC + (qt * SG::NCT + (kt - SG::NLT)) * 1024;
+    return kt < SG::NLT ? slabL + (qt * SG::NLT + kt) * 1024 : slabC + (qt * SG::NCT + (kt - SG::NLT)) * 1024;   // qt: pair index
   };
   // bias-gradient accumulator [Wq][BLD] and (bias_lds) the head's log2-domain bias [Wq][BLD]; the
   // odd row stride keeps both the row-wise (phase A) and the column-wise (phase B) accesses of
   // the 64 lanes on distinct banks
   const int BLD = biasLd + 1;
-  float* dbias_s = HAND ? reinterpret_cast<float*>(slabC + SG::NQT * SG::NCT * 1024) : delta_s + rowsQ;
+  float* dbias_s = HAND ? reinterpret_cast<float*>(slabC + NQW * SG::NCT * 1024) : delta_s + rowsQ;
   const int nbias = (p.bias && !HAND) ? t.Wq * BLD : 0;
   float* bias_s = dbias_s + nbias;
   float* zero64 = bias_s + (p.bias_lds ? nbias : 0);   // bias reads without a bias table land here
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   f32x4 breg[HT], dbacc[HT];
   uint32_t hp[HAND ? NKT : 1][2], hd[HAND ? NKT : 1][2];
   if constexpr (HAND) {
-    const int qs = min(wave * 16 + li, t.Wq - 1);
+    const int qs = min((STATIC ? wave % (SG::NQT > 0 ? SG::NQT : 1) : 0) * 16 + li, t.Wq - 1);
 #pragma unroll
     for (int tl = 0; tl < HT; ++tl) {
       dbacc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -323,10 +325,12 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     if (prof_it < 4) EA_STAMP(p, 5 + prof_it * 6);
 
     // =============================== phase A: dQ ===============================
+    bool qact = false;                                 // HAND: this wave produced hand-over tiles in this iteration
     for (int qi = wave; qi < wpi * nQT; qi += 4) {
       const int wi = qi / nQT, qt = qi - wi * nQT;
       const int win = it * wpi + wi;
       if (win >= t.nwin) continue;
+      qact = true;
       const int qslot = qt * 16 + li;
       const int qrow = (wi * nQTe + qt) * 16 + li;
       int qtok = -1;
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
 
     if constexpr (HAND) {
       __syncthreads();                                 // every wave is done with the local K / V rows
-      if (wave < SG::NQT) {
+      if (wave < NQW && qact) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           // S^T tile in registers: keys 4 g + r of query li  ->  row li (32 bytes), bytes 8 g .. of the [query][key] tile
@@ -488,9 +492,18 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       constexpr bool is_lm = decltype(lm_tag)::value;
       int tile, wi_lo, wi_hi;
       if (is_lm) {
-        tile = wave;                                   // landmark tile owned by this wave
-        if (tile >= nCT) return;
-        wi_lo = 0; wi_hi = wpi;
+        if constexpr (HAND && SG::WPI > 1) {
+          // several windows per iteration, ONE landmark tile: every wave takes the landmark columns of its own window
+          // (summed over the waves after the last iteration) instead of wave 0 taking all of them
+          static_assert(SG::NCT <= 1, "hand-over with several windows per iteration: at most one landmark tile");
+          tile = 0;
+          if (SG::NCT == 0 || wave >= SG::WPI) return;
+          wi_lo = wave; wi_hi = wave + 1;
+        } else {
+          tile = wave;                                 // landmark tile owned by this wave
+          if (tile >= nCT) return;
+          wi_lo = 0; wi_hi = wpi;
+        }
       } else {
         wi_lo = item / nLT; wi_hi = wi_lo + 1;
         tile = item - wi_lo * nLT;
@@ -613,20 +626,24 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         // P and dS of (query tiles 2 qq, 2 qq + 1; this key tile) from the hand-over tiles: lane (g, key li) gets
         // queries 4 g .. 4 g + 3 of each -- the k-slot order of the transposed dO / Q fragments
         const int kt = is_lm ? SG::NLT + tile : tile;
+        for (int wi = wi_lo; wi < wi_hi; ++wi) {
+          if (it * wpi + wi >= t.nwin) break;
 #pragma unroll
-        for (int qq = 0; qq < (SG::NQT + 1) / 2; ++qq) {
-          const char* t0 = slab_tile(2 * qq, kt) + lane * 8;
-          const char* t1 = slab_tile(2 * qq + 1 < SG::NQT ? 2 * qq + 1 : 2 * qq, kt) + lane * 8;
-          u32x2 p1 = E::tr4(t1), d1 = E::tr4(t1 + 512);
-          if (2 * qq + 1 >= SG::NQT) { p1 = u32x2{0u, 0u}; d1 = u32x2{0u, 0u}; }
-          const typename E::x8 pf = as_x8<E>(E::tr4(t0), p1), dsf = as_x8<E>(E::tr4(t0 + 512), d1);
-          const int rq0 = 2 * qq * 16, rq1 = (2 * qq + 1) * 16;
+          for (int qq = 0; qq < (SG::NQT + 1) / 2; ++qq) {
+            const int q0 = wi * SG::NQT + 2 * qq;          // pair index of the first query tile
+            const char* t0 = slab_tile(q0, kt) + lane * 8;
+            const char* t1 = slab_tile(2 * qq + 1 < SG::NQT ? q0 + 1 : q0, kt) + lane * 8;
+            u32x2 p1 = E::tr4(t1), d1 = E::tr4(t1 + 512);
+            if (2 * qq + 1 >= SG::NQT) { p1 = u32x2{0u, 0u}; d1 = u32x2{0u, 0u}; }
+            const typename E::x8 pf = as_x8<E>(E::tr4(t0), p1), dsf = as_x8<E>(E::tr4(t0 + 512), d1);
+            const int rq0 = (wi * nQTe + 2 * qq) * 16, rq1 = rq0 + 16;
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int o0 = rq0 * ROWB + lo.tr[dt];
-            const int o1 = rq1 * ROWB + lo.tr[dt];
-            dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
-            dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
+            for (int dt = 0; dt < DT; ++dt) {
+              const int o0 = rq0 * ROWB + lo.tr[dt];
+              const int o1 = rq1 * ROWB + lo.tr[dt];
+              dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
+              dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
+            }
           }
         }
       } else if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
@@ -665,6 +682,24 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
               stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
               stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
             }
+          } else if (p.acc_mode == 4) {
+            // half-window overlap, colour classes run back to back: class 0 stores, class 1 adds to what class 0 stored
+            // (a token of the last e is not covered by class 0: plain store)
+            char* d1 = dkb + (tok * dksn + DQ * g) * 2;
+            char* d2 = dvb + (tok * dvsn + DQ * g) * 2;
+            const bool add = t.col_x != 0 && 2 * ((tok + p.e) / (2 * p.w)) < p.G.N / p.w;
+#pragma unroll
+            for (int c = 0; c < DQ / 8; ++c) {
+              if (add) {
+                float o1[8], o2[8];
+                unpack8<E>(ldg16(d1 + c * 16), o1);
+                unpack8<E>(ldg16(d2 + c * 16), o2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { fk[8 * c + j] += o1[j]; fv[8 * c + j] += o2[j]; }
+              }
+              stg16(d1 + c * 16, pack8<E>(fk + 8 * c));
+              stg16(d2 + c * 16, pack8<E>(fv + 8 * c));
+            }
           } else if (p.acc_mode >= 2) {
             // merged query blocks: this block's own slice, every (token, channel) written once
             const size_t row = ((size_t)t.slice * p.B * p.H + bh) * p.G.N + tok;
@@ -700,6 +735,26 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   EA_STAMP(p, 60);
 
   // ---- per-workgroup partial sums of the landmark and bias gradients ----
+  if constexpr (HAND && SG::WPI > 1 && SG::NCT == 1) {
+    // the waves' landmark partials (one window each per iteration) -> wave 0, in wave order
+    __syncthreads();
+    float* r2 = reinterpret_cast<float*>(smem);        // [wave][dlk | dlv][dt][lane] x 4 floats
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      *reinterpret_cast<f32x4*>(r2 + (((wave * 2 + 0) * DT + dt) * 64 + lane) * 4) = dlk[dt];
+      *reinterpret_cast<f32x4*>(r2 + (((wave * 2 + 1) * DT + dt) * 64 + lane) * 4) = dlv[dt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 1; w < SG::WPI; ++w)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          dlk[dt] += *reinterpret_cast<const f32x4*>(r2 + (((w * 2 + 0) * DT + dt) * 64 + lane) * 4);
+          dlv[dt] += *reinterpret_cast<const f32x4*>(r2 + (((w * 2 + 1) * DT + dt) * 64 + lane) * 4);
+        }
+    }
+  }
   if (p.L > 0 && wave < nCT) {
     const int lm = wave * 16 + li;
     if (lm < p.L) {
@@ -715,13 +770,33 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   }
   if (p.bias) {
     float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)biasLd;
-    if constexpr (HAND) {
+    if constexpr (HAND && SG::WPI == 1) {
       const int qs = wave * 16 + li;
       if (wave < SG::NQT && qs < t.Wq) {
 #pragma unroll
         for (int tl = 0; tl < HT; ++tl)
           *reinterpret_cast<float4*>(dst + (size_t)qs * biasLd + tl * 16 + 4 * g) =
               make_float4(dbacc[tl][0], dbacc[tl][1], dbacc[tl][2], dbacc[tl][3]);
+      }
+    } else if constexpr (HAND) {
+      // several windows per iteration: the waves that own the same query tile of different windows add up (fixed order)
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);     // [NQW][16 queries][NLT * 16 keys]
+      constexpr int RW = SG::NLT * 16;
+      if (wave < NQW) {
+#pragma unroll
+        for (int tl = 0; tl < HT; ++tl)
+          *reinterpret_cast<float4*>(red + (wave * 16 + li) * RW + tl * 16 + 4 * g) =
+              make_float4(dbacc[tl][0], dbacc[tl][1], dbacc[tl][2], dbacc[tl][3]);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < t.Wq * biasLd; idx += 256) {
+        const int qs = idx / biasLd, k = idx - qs * biasLd;
+        const int qt = qs >> 4;
+        float sum = 0.f;
+#pragma unroll
+        for (int wi = 0; wi < SG::WPI; ++wi) sum += red[((wi * SG::NQT + qt) * 16 + (qs & 15)) * RW + k];
+        dst[idx] = sum;
       }
     } else {
       __syncthreads();
@@ -772,6 +847,12 @@ __global__ __launch_bounds__(256) void win_bwd_finish_kernel(const WinP p) {
   }
 }
 
+// dev switch: EA_WIN_HAND_SMALL=0 keeps the general kernel for the 16-token 1-D windows
+static bool win_hand_small_on() {
+  static const bool v = [] { const char* e = getenv("EA_WIN_HAND_SMALL"); return !e || atoi(e) != 0; }();
+  return v;
+}
+
 template <typename E, int D>
 static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const float* biasT, hipStream_t st) {
   using KernelT = void (*)(const WinP, const T4, const float*);
@@ -795,6 +876,12 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
           if (t.nCT == 3) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 3, 1, true>>;
           if (t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<4, 4, 0, 1, true>>;
         }
+        // 16-token 1-D windows (the LRA / cfg5 geometries), four windows per iteration: with an 8-token extension and up to
+        // 16 landmarks (EVA), plain (local attention)
+        if (t.nQT == 1 && t.wpi == 4 && win_hand_small_on()) {
+          if (t.nLT == 2 && t.nCT == 1) return &win_bwd_kernel<E, D, false, false, false, SGs<1, 2, 1, 4, true>>;
+          if (t.nLT == 1 && t.nCT == 0) return &win_bwd_kernel<E, D, false, false, false, SGs<1, 1, 0, 4, true>>;
+        }
       }
     }
     return gb ? &win_bwd_kernel<E, D, true, false, false, SGdyn> : &win_bwd_kernel<E, D, false, false, false, SGdyn>;
@@ -805,10 +892,12 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
     p.plain = (plain_on && !p.mask && p.e == 0 &&
                (p.G.attn2d ? (p.G.gh % p.w == 0 && p.G.gw % p.w == 0) : p.G.N % p.w == 0)) ? 1 : 0;
     const KernelT kern = pick(p, gb);
-    if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 &&
-        (p.t.nCT == 4 || p.t.nCT == 3 || p.t.nCT == 0))
+    const bool hand_big = p.t.nQT == 4 && p.t.nLT == 4 && p.t.wpi == 1 && (p.t.nCT == 4 || p.t.nCT == 3 || p.t.nCT == 0);
+    const bool hand_small = p.t.nQT == 1 && p.t.wpi == 4 && win_hand_small_on() &&
+                            ((p.t.nLT == 2 && p.t.nCT == 1) || (p.t.nLT == 1 && p.t.nCT == 0));
+    if (D == 64 && !p.keep && !p.causal && !gb && p.nq <= 1 && (hand_big || hand_small))
       // hand-over variant: no bias table / bias-gradient image in LDS, P / dS tiles of the landmark keys instead
-      lds = window_bwd_lds(p.t, D, false, false) + (size_t)p.t.nQT * p.t.nCT * 1024;
+      lds = window_bwd_lds(p.t, D, false, false) + (size_t)p.t.wpi * p.t.nQT * p.t.nCT * 1024;
     if (lds > WIN_LDS_MAX) return EA_E_UNSUPPORTED;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -842,8 +931,8 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
     p.qstart[n] = start;
     rc = launch(p, lds, (unsigned)start);
   } else {
-    const bool cslices = win_bwd_colour_slices(p0.t);
-    if (!single && !cslices) {
+    const bool cslices = win_bwd_colour_slices(p0.t), cdirect = p0.t.cdirect != 0;
+    if (!single && !cslices && !cdirect) {
       const size_t bytes = (size_t)p0.B * p0.H * p0.G.N * D * sizeof(float);
       hipError_t e = hipMemsetAsync(p0.dk32, 0, bytes, st);
       if (e == hipSuccess) e = hipMemsetAsync(p0.dv32, 0, bytes, st);
@@ -855,7 +944,7 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
       WinP p = p0;
       p.t = t;
       p.t.slice = t.col_x;
-      p.acc_mode = single ? 0 : (cslices ? 3 : 1);
+      p.acc_mode = single ? 0 : (cdirect ? 4 : (cslices ? 3 : 1));
       p.nq = 0;
       // the head's bias table lives in LDS whenever it fits (it is read once per (query, key) pair of
       // every window; from global memory those loads sit exposed in the inner loops)
@@ -864,7 +953,7 @@ static int launch_bwd(const WinP& p0, const ea_geom& geom, const T4& outp, const
     });
   }
   if (rc != EA_OK) return rc;
-  if (!single) {
+  if (!single && !p0.t.cdirect) {
     WinP pf = p0;
     pf.acc_mode = merged ? 2 : (win_bwd_colour_slices(p0.t) ? 3 : 1);
     hipLaunchKernelGGL((win_bwd_finish_kernel<E, D>), dim3(2048), dim3(256), 0, st, pf);
