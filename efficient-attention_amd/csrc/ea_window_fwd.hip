@@ -334,6 +334,11 @@ static int launch_fwd(const WinP& p, hipStream_t st) {
       if (t.nCT == 3) return launch_fwd_ca<E, D, false, false, SGs<4, 4, 3, 1>>(p, st);
       if (t.nCT == 0) return launch_fwd_ca<E, D, false, false, SGs<4, 4, 0, 1>>(p, st);
     }
+    // 16-token 1-D windows, four per iteration (cfg5: EVA with an 8-token extension and 8 landmarks; local attention)
+    if (t.nQT == 1 && t.wpi == 4) {
+      if (t.nLT == 2 && t.nCT == 1) return launch_fwd_ca<E, D, false, false, SGs<1, 2, 1, 4>>(p, st);
+      if (t.nLT == 1 && t.nCT == 0) return launch_fwd_ca<E, D, false, false, SGs<1, 1, 0, 4>>(p, st);
+    }
   }
   return launch_fwd_ca<E, D, false, false>(p, st);
 }
