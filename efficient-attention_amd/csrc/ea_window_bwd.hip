@@ -198,6 +198,23 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   for (int it = blk * t.ipb; it < it_end; ++it) {
     __syncthreads();
     if (prof_it < 4) EA_STAMP(p, 2 + prof_it * 6);
+    // window origins of this iteration, once (static geometries): every staging slot, query tile and key tile used to redo
+    // the two integer divisions behind win_origin -- ~23 scalar divisions per iteration in a kernel that already spills SGPRs
+    int woy[STATIC ? SG::WPI : 1], wox[STATIC ? SG::WPI : 1];
+    if constexpr (STATIC) {
+#pragma unroll
+      for (int wi = 0; wi < SG::WPI; ++wi)
+        win_origin(p.G, colour_win(t, p.G, p.w, min(it * wpi + wi, t.nwin - 1)), p.w, woy[wi], wox[wi]);
+    }
+    auto origin_of = [&](int wi, int win, int& oy, int& ox) {
+      if constexpr (STATIC) {
+        oy = woy[0]; ox = wox[0];
+#pragma unroll
+        for (int k = 1; k < SG::WPI; ++k) { oy = wi == k ? woy[k] : oy; ox = wi == k ? wox[k] : ox; }
+      } else {
+        win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
+      }
+    };
     // ---- stage local K/V rows and Q/dO rows (+ lse, delta = dO.O).  Batches of NB slots per thread:
     // every global load of a batch is in flight before the first conversion / LDS store, so the
     // staging costs ~one memory round trip per iteration instead of one per 256-slot sweep. ----
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         const int win = it * wpi + wi;
         const bool live = in && win < t.nwin && slot < t.Wk;
         int oy, ox;
-        win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
+        origin_of(wi, min(win, t.nwin - 1), oy, ox);
         const int tok = slot_token(p.G, kd[slot], oy, ox);
         const bool has = live && tok >= 0;
         const int tc = has ? tok : 0;
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         const int win = it * wpi + wi;
         const bool live = in && win < t.nwin && slot < t.Wq;
         int oy, ox;
-        win_origin(p.G, colour_win(t, p.G, p.w, min(win, t.nwin - 1)), p.w, oy, ox);
+        origin_of(wi, min(win, t.nwin - 1), oy, ox);
         const int tokr = slot_token(p.G, qd[slot], oy, ox);
         const int tok = live ? tokr : -1;
         const bool has = tok >= 0;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       int qtok = -1;
       if (qslot < t.Wq) {
         int oy, ox;
-        win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
+        origin_of(wi, win, oy, ox);
         qtok = slot_token(p.G, qd[qslot], oy, ox);
       }
       typename E::x8 qf[KS], dof[KS];
@@ -658,7 +675,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         int tok = -1;
         if (kslot < t.Wk) {
           int oy, ox;
-          win_origin(p.G, colour_win(t, p.G, p.w, win), p.w, oy, ox);
+          origin_of(wi_lo, win, oy, ox);
           tok = slot_token(p.G, kd[kslot], oy, ox);
         }
         float fk[DQ], fv[DQ];
