@@ -1015,6 +1015,90 @@ class LaraPooledFn(torch.autograd.Function):
         return (grads[0], None, None, None) + tuple(pgrads)
 
 
+class LaraModuleFn(torch.autograd.Function):
+    """qkv projection -> 2-D pooled LARA core -> output projection as ONE autograd node (round 3): the same launches as
+    LinearFn + LaraPooledFn + LinearFn, without two of the three nodes' host cost (ctx objects, saved-tensor packing, engine
+    hand-overs: ~0.1 ms of the eager step, which is host-bound).  Only for the common training case -- autocast in a 16-bit
+    dtype, fp32 master weights the projection kernels cover -- every other case keeps the three nodes (lara.py).
+    args: x [B, H, W, C], qkv weight / bias, proj weight / bias, mask_u8, noise, cfg (LaraPooledFn's), compute dtype, heads,
+    then the generator parameters."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wp, bp, mask_u8, noise, cfg, cdtype, heads, *params):
+        H, W, r, has_mlp, mixed, mis, dup, kappa, scale = cfg
+        C = x.shape[-1]
+        B = x.shape[0]
+        N = x.numel() // (B * C)
+        x2 = x.reshape(-1, C)
+        elem = _ELEM[cdtype]
+        bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
+        bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
+        want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+        y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
+        xl = x2 if x2.dtype == cdtype else (xc if want else None)
+        qkv5 = y.view(B, N, 3, heads, C // heads)
+        icfg = [int(H), int(W), int(r), int(bool(has_mlp)), int(bool(mixed)), int(mis), int(dup),
+                int(any(ctx.needs_input_grad))]
+        fcfg = [float(kappa), float(scale)]
+        outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
+        o2 = outs[0].reshape(-1, C)
+        y2 = _ea_op("linear_w32", linear_w32_impl, o2, wp, bp32, elem, False, False, False)[0]
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)
+        ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
+        ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
+                    [t.dtype for t in params], heads)
+        return y2.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xl, qkv5, mask_u8, noise, o2, wq, wp, *rest = ctx.saved_tensors
+        saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
+        xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads = ctx.meta
+        C = xshape[-1]
+        elem = _ELEM[cdtype]
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype != cdtype:
+            dy2 = dy2.to(cdtype)
+        # output projection: input gradient from the master weight read transposed, weight + bias gradient in one pass
+        d_o2 = _ea_op("linear_w32", linear_w32_impl, dy2, wp, None, elem, True, False, False)[0]
+        dwp = dbp = None
+        if need[3] or (bpd is not None and need[4]):
+            dwp, dbp32 = wgrad(dy2, o2, bpd is not None and need[4])
+            dwp = dwp.to(wpd) if need[3] else None
+            dbp = dbp32.to(bpd) if (bpd is not None and need[4]) else None
+        B, N = qkv5.shape[:2]
+        grads = _ea_op("lara_bwd", lara_bwd_impl, d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved),
+                       ctx.icfg, ctx.fcfg, list(params))
+        dqkv2 = grads[0].view(-1, 3 * C)
+        dwq = dbq = dx = None
+        if need[1] or (bqd is not None and need[2]):
+            if xl is None:
+                raise RuntimeError("LaraModuleFn: the weight gradient was requested but the forward did not keep its input")
+            dwq, dbq32 = wgrad(dqkv2, xl, bqd is not None and need[2])
+            dwq = dwq.to(wqd) if need[1] else None
+            dbq = dbq32.to(bqd) if (bqd is not None and need[2]) else None
+        if need[0]:
+            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+        pgrads = [g.to(dt) for g, dt in zip(grads[1:], pdtypes)]
+        return (dx, dwq, dbq, dwp, dbp, None, None, None, None, None) + tuple(pgrads)
+
+
+def lara_module_fn_supported(x, qkv, proj, cdtype):
+    """The single-node path of LinearRA (LaraModuleFn): 16-bit autocast dtype, fp32 master weights both projection kernels
+    cover (forward of both layers, the output projection's transposed input gradient), the one-pass weight gradient."""
+    if not (USE_LARA_MODULE_FN and x.is_cuda and cdtype in _ELEM and x.dtype in (torch.float32, cdtype)):
+        return False
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+
+    def w_ok(w, out):
+        return (w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() and tuple(w.shape) == (out, C)
+                and (w.storage_offset() * 4) % 16 == 0)
+    return (w_ok(qkv.weight, 3 * C) and w_ok(proj.weight, C) and _lin_rows_ok(x2, cdtype) and _lin_geometry(C, 3 * C)
+            and _lin_geometry(C, C) and USE_WGRAD and C % 64 == 0 and x2.shape[0] >= 64)
+
+
 def _lmk_saved(geom, device):
     """Workspace in which ea_lara_landmarks_fwd keeps its intermediates for the backward."""
     n = nv.lib().ea_lara_landmarks_saved_floats(ctypes.byref(geom))
@@ -1627,6 +1711,8 @@ def wgrad_supported(dy2, x2):
 # 51 us / 31 us for the two cfg3 projections against 94 / 48 us for the library split-K GEMM + its reduction + the
 # bias-gradient pass.  EA_WGRAD=0 switches back to the library path.
 USE_WGRAD = os.environ.get("EA_WGRAD", "1") == "1"
+# LinearRA as one autograd node (LaraModuleFn); EA_LARA_MODULE_FN=0 keeps the three nodes
+USE_LARA_MODULE_FN = os.environ.get("EA_LARA_MODULE_FN", "1") == "1"
 
 
 def wgrad(dy2, x2, with_bias=True):

@@ -178,7 +178,13 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         gen = self.proposal_gen
         # 'adaptive-1d' on the GPU: the per-token Linear of q_bar_gen / k_bar_gen rides along in the qkv GEMM
         fold_1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and d in (32, 64) and x.is_cuda)
-        qkv5 = self._project_qkv_folded(x.reshape(B, N, C)) if fold_1d else self.project_qkv(x.reshape(B, N, C))
+        # the common 2-D training case as ONE autograd node (projections + core): decided before anything is launched
+        module_fn = (len(seq_shape) == 2 and not fold_1d and torch.is_autocast_enabled()
+                     and (self.proj_drop.p == 0.0 or not self.training)
+                     and _ops.lara_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda")))
+        qkv5 = None
+        if not module_fn:
+            qkv5 = self._project_qkv_folded(x.reshape(B, N, C)) if fold_1d else self.project_qkv(x.reshape(B, N, C))
         dup = self.training and (self.use_multisample or self.use_antithetics)
         mode = 0
         if self.training:
@@ -208,8 +214,14 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             noise = draw_noise(n_lm)
             cfg = (seq_shape[0], seq_shape[1], seq_shape[0] // side, bool(params), gen.endswith('mixed'),
                    _ops.MIS[self.mis_type], mode if noise is not None else 0, float(self.alpha_coeff), float(self.scale))
+            if module_fn:
+                y = _ops.LaraModuleFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, mask, noise, cfg,
+                                            torch.get_autocast_dtype("cuda"), h, *params)
+                return self.proj_drop(y)
             out = _ops.LaraPooledFn.apply(qkv5, mask, noise, cfg, *params)
             return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+        if module_fn:                                    # (decided for a geometry the fused pipeline does not cover after all)
+            qkv5 = self.project_qkv(x.reshape(B, N, C))
 
         mixed_k = colbias = None
         if len(seq_shape) == 2:
