@@ -376,3 +376,45 @@ def test_lara_composite_equals_step_by_step(mis, mixed, has_mlp, dup):
     assert len(res["1"][2]) == len(res["0"][2])
     for a, b in zip(res["1"][2], res["0"][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gen,train", [("pool-mixed", True), ("pool", True), ("pool-mixed", False)])
+def test_lara_module_single_node_equals_three_nodes(gen, train):
+    """LinearRA's common 2-D training case runs as ONE autograd node (_ops.LaraModuleFn: qkv projection + core + output
+    projection); it issues the same kernels in the same order as the three nodes it replaces -> bit-identical output,
+    input gradient and parameter gradients."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(11)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen=gen,
+                                                             mis_type="mis-opt", alpha_coeff=2.0)).cuda()
+    m.train(train)
+    x0 = torch.randn(4, 28, 28, 192, device="cuda")
+    g = torch.randn(4, 28, 28, 192, device="cuda").bfloat16()
+    res = {}
+    for single in (True, False):
+        old = _ops.USE_LARA_MODULE_FN
+        _ops.USE_LARA_MODULE_FN = single
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)                          # the same landmark noise in both runs
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            node = type(y.grad_fn).__name__
+            y.backward(g)
+            res[single] = (node, y.detach(), x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _ops.USE_LARA_MODULE_FN = old
+    assert res[True][0].startswith("LaraModuleFn") and not res[False][0].startswith("LaraModuleFn")
+    assert torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][2], res[False][2])
+    assert res[True][3].keys() == res[False][3].keys() and len(res[True][3]) >= 4
+    for n in res[True][3]:
+        assert torch.equal(res[True][3][n], res[False][3][n]), n
