@@ -34,6 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 DEFAULT_ATTN = "lara"
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16 matrix peak (MI355X_MICROARCH.md; the headline figure with sparsity is 2x)
 BYTES_PER_TOKEN_HEAD = 1536    # fwd (q,k,v,out) + bwd (q,k,v,out,dout,dq,dk,dv) at d=64, bf16
 
 
@@ -512,82 +513,99 @@ def main():
     ktimes = _ops.KERNEL_TIMER.summary()
     _ops.KERNEL_TIMER.disable()
 
-    # achievable HBM bandwidth of this GPU, babel-stream style: a device-to-device copy of 512 MB
-    # (read + write counted), the yardstick SURVEY 8d asks for next to the nominal 8 TB/s
-    copy_gbs = None
+    # achievable HBM bandwidth of this GPU, babel-stream style: the library's own 16-byte-per-lane copy kernel
+    # over 512 MB (read + write counted), next to the nominal 8 TB/s; torch's copy_ alongside for reference
+    copy_gbs = copy_torch_gbs = None
     if rank == 0:
+        from efficient_attention import _native as nv
         src = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+        def _time_copy(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return 10 * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        copy_gbs = _time_copy(lambda: nv.call("ea_stream_copy", nv.ptr(src), nv.ptr(dst), src.numel(), nv.stream()))
+        copy_torch_gbs = _time_copy(lambda: dst.copy_(src))
         del src, dst
 
+    roof = None
+    step_bytes = None
     if rank == 0:
         tokens = B * N * world * a.steps
         value = tokens / el
-        dom = max(ktimes.items(), key=lambda kv: kv[1]["total_ms"]) if ktimes else (None, None)
-        roof = None
-        if dom[0] is not None:
-            name, st = dom
-            traffic = None
-            # HBM bytes per launch from the committed rocprofv3 PMC summary -- only while it describes THIS build
-            # of the library (tools/summarize_profile.py stamps the .so's sha256 into the file)
-            pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % a.attn)
-            if os.path.exists(pmc):
-                import hashlib
-                rec = json.load(open(pmc))
-                lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
-                sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
-                traffic = rec.get(name) if rec.get("_lib_sha256") == sha else None
-            # MFMA utilisation of that kernel from the committed SQ-counter summary (tools/pmc_sq.sh + summarize_sq.py:
-            # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x 4)), same staleness rule
-            mfma_util = None
-            sqf = os.path.join(ROOT, "profiles", "sq_%s.json" % a.attn)
-            if os.path.exists(sqf):
-                import hashlib
-                rec = json.load(open(sqf))
-                lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
-                sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
-                if rec.get("_lib_sha256") == sha and isinstance(rec.get(name), dict):
-                    mu = rec[name].get("mfma_util")
-                    mfma_util = None if mu is None else round(mu, 4)
-            common = {"kernel": name, "traffic": traffic, "mfma_util": mfma_util, "avg_us": round(st["avg_ms"] * 1e3, 2), "launches": st["n"],
-                      "all_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}}
-            if name in ("ea_lara_landmarks_fwd", "ea_lara_landmarks_bwd") and _ops.LAST_LMK_GEOM:
-                # tiny-matrix pipeline in LDS (fp16-operand MFMA, ~1 % of the matrix peak): latency-bound;
-                # priced on the tensors it has to move, with its executed FLOPs alongside
-                bwd = name.endswith("bwd")
-                algo_bytes = _ops.landmark_bytes(*_ops.LAST_LMK_GEOM, bwd=bwd)
-                flops = _ops.landmark_flops(*_ops.LAST_LMK_GEOM, bwd=bwd)
-                ach = algo_bytes / (st["avg_ms"] * 1e-3) / 1e9
-                roof = dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), algo_bytes_per_launch=algo_bytes,
-                            algo_flops_per_launch=flops,
-                            mfma_tflops=round(flops / (st["avg_ms"] * 1e-3) / 1e12, 2))
-            else:
-                units = _ops.KERNEL_ALGO_UNITS.get(name, 0)      # [B,H,N,D] tensors read+written per launch
-                algo_bytes = units * B * H * N * d * 2
-                if name in _ops.LABEL_ALGO_BYTES:                # projection kernels: priced on their own shapes
-                    algo_bytes = _ops.LABEL_ALGO_BYTES[name]
-                ach = algo_bytes / (st["avg_ms"] * 1e-3) / 1e9
-                roof = dict(common, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), algo_bytes_per_launch=algo_bytes)
-            # the streaming kernel with the largest total time, for reference next to an mfma-bound dominant
-            hb = [(k, v) for k, v in ktimes.items() if k in _ops.KERNEL_ALGO_UNITS]
-            if hb and name not in _ops.KERNEL_ALGO_UNITS:
-                k2, v2 = max(hb, key=lambda kv: kv[1]["total_ms"])
-                b2 = _ops.KERNEL_ALGO_UNITS[k2] * B * H * N * d * 2
-                a2 = b2 / (v2["avg_ms"] * 1e-3) / 1e9
-                roof["top_streaming_kernel"] = {"kernel": k2, "bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS,
-                                                "unit": "GB/s", "frac": round(a2 / HBM_PEAK_GBS, 4),
-                                                "avg_us": round(v2["avg_ms"] * 1e3, 2), "algo_bytes_per_launch": b2}
+        unit_bytes = B * H * N * d * 2                   # one [B,H,N,D] tensor in the I/O dtype
+        # committed counter summaries, used only while they describe THIS build of the library
+        # (tools/summarize_profile.py / summarize_sq.py stamp the .so's sha256 into them)
+        import hashlib
+        lib_path = os.path.join(ROOT, "efficient-attention_amd", "lib", "libea_hip.so")
+        sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+
+        def _stamped(fname):
+            path = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(path):
+                return {}
+            rec = json.load(open(path))
+            return rec if rec.get("_lib_sha256") == sha else {}
+        pmc, sq = _stamped("pmc_%s.json" % a.attn), _stamped("sq_%s.json" % a.attn)
+
+        def _entry(name, st, algo_bytes):
+            # achieved = SUMMED algorithmic bytes / SUMMED time of every launch under the label (== bytes / avg duration
+            # when all launches of the label have one shape, which the per-shape labels guarantee)
+            ach = algo_bytes * st["n"] / (st["total_ms"] * 1e-3) / 1e9
+            mu = sq.get(name, {}).get("mfma_util") if isinstance(sq.get(name), dict) else None
+            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc.get(name), "avg_us": round(st["avg_ms"] * 1e3, 2),
+                    "launches": st["n"], "algo_bytes_per_launch": algo_bytes,
+                    "mfma_util": None if mu is None else round(mu, 4)}
+        # `roofline`: the kernel with the largest total time AMONG THOSE SURVEY 8(d) PRICES -- the attention kernels that
+        # stream q, k, v, out and their gradients (KERNEL_ALGO_UNITS: [B,H,N,D] tensors read + written per launch).  The
+        # projection kernels (the module edges) have no 8(d) bytes: they are reported under
+        # `projection_kernels`, each label one shape, priced on the activations that launch has to move.
+        priced = [(k, v) for k, v in ktimes.items() if _ops.KERNEL_ALGO_UNITS.get(k)]
+        if priced:
+            name, st = max(priced, key=lambda kv: kv[1]["total_ms"])
+            roof = _entry(name, st, _ops.KERNEL_ALGO_UNITS[name] * unit_bytes)
+            roof["attention_kernels"] = {k: _entry(k, v, _ops.KERNEL_ALGO_UNITS[k] * unit_bytes) for k, v in priced}
+            for v in roof["attention_kernels"].values():
+                del v["kernel"], v["bound"], v["peak"], v["unit"]
+            roof["projection_kernels"] = {}
+            for k, v in ktimes.items():
+                rec = _ops.LABEL_ALGO_BYTES.get(k)
+                if rec and rec[1]:
+                    e = _entry(k, v, rec[0] // rec[1])
+                    del e["kernel"], e["bound"], e["peak"], e["unit"], e["traffic"], e["mfma_util"]
+                    roof["projection_kernels"][k] = e
+            roof["all_kernels_avg_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}
+            if name.startswith("ea_softmax_attn") and N >= 600:
+                # the softmax baseline is MFMA-bound for N >~ 600.  ALGORITHMIC FLOPs: forward 4 N^2 d per
+                # (b,h) (QK^T, PV), backward 10 N^2 d (dV, dP, dQ, dK + the S recompute a flash-style backward cannot
+                # avoid) = 3.5 x forward for the pair; executed-but-redundant products are not counted
+                fl = (4 if name.endswith("fwd") else 10) * N * N * d * B * H
+                tf = fl * st["n"] / (st["total_ms"] * 1e-3) / 1e12
+                roof.update(bound="mfma", achieved=round(tf, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(tf / MFMA_PEAK_TFLOPS, 4), algo_flops_per_launch=fl,
+                            hbm_achieved_gbs=roof["achieved"], hbm_frac=roof["frac"])
+        # bytes of one step: measured (counter summaries x launches per step) against algorithmic
+        Cq = 3 * C
+        rows = B * N
+        step_bytes = {
+            # q, k, v -> out forward (4 units) + backward (8 units)
+            "algo_op_level": 12 * unit_bytes,
+            # the module: x (fp32) -> qkv (+ the rounded copy of x the weight gradient reads), core, out -> y; backward:
+            # dy -> d out, both weight gradients, d qkv -> dx (fp32)
+            "algo_module_level": (rows * (C * 4 + Cq * 2 + C * 2) + 12 * unit_bytes + rows * (C * 2 + C * 2)
+                                  + rows * (C * 2 + C * 2) + rows * (C * 2 + C * 2)
+                                  + rows * (Cq * 2 + C * 4) + rows * (Cq * 2 + C * 2)),
+            "measured_traffic": pmc.get("_step_traffic_bytes"),
+            "measured_traffic_attention_kernels": pmc.get("_step_traffic_bytes_attention"),
+        }
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(a.attn, C, H, G)
@@ -628,6 +646,8 @@ def main():
             # whole layer priced on the op-level q,k,v -> out traffic (1536*h bytes per token at d = 64)
             "layer_algorithmic_gbs": value / world * BYTES_PER_TOKEN_HEAD * H * d / 64 / 1e9,
             "hbm_measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
+            "hbm_measured_torch_copy_gbs": None if copy_torch_gbs is None else round(copy_torch_gbs, 1),
+            "step_bytes": step_bytes,
             "roofline": roof, "cpu_baseline": cpu,
             "ms_per_step_blocks": None if not blocks_ms else {"n": len(blocks_ms), "steps_each": a.steps, "min": round(min(blocks_ms), 4),
                                                               "median": round(sorted(blocks_ms)[len(blocks_ms) // 2], 4),

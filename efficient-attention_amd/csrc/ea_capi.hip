@@ -61,7 +61,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 6; }
+int32_t ea_abi_version(void) { return 7; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -739,6 +739,7 @@ int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows,
 int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, const float* x2, float* out2, int cols2, hipStream_t st);
 int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st);
 int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
+int stream_copy_dispatch(const void* src, void* dst, size_t bytes, hipStream_t st);
 }  // namespace ea
 
 extern "C" {
@@ -766,6 +767,11 @@ int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const i
   return ea::gather_sum_dispatch(g, inv, out, rows, K, cols, (hipStream_t)stream);
 }
 
+
+int ea_stream_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes <= 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return EA_E_BADARG;
+  return ea::stream_copy_dispatch(src, dst, (size_t)bytes, (hipStream_t)stream);
+}
 
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream) {

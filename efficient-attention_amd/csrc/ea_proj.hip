@@ -185,4 +185,22 @@ int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, in
   return (int)hipGetLastError();
 }
 
+// Bandwidth yardstick (bench.py `hbm_measured_copy_gbs`, SURVEY 8d "babel-stream-style copy kernel on the same GPU"):
+// dst[i] = src[i] in 16-byte pieces, four independent loads in flight per lane, two resident rounds of workgroups.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+int stream_copy_dispatch(const void* src, void* dst, size_t bytes, hipStream_t st) {
+  if (bytes == 0 || (bytes & 15)) return EA_E_BADARG;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, st, (const float4*)src, (float4*)dst, bytes / 16);
+  return (int)hipGetLastError();
+}
+
 }  // namespace ea

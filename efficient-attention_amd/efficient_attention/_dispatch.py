@@ -124,7 +124,9 @@ def _(qkv, mask, noise, icfg, fcfg, params):
     L = (H // r) * (W // r)
     C = L * (2 if dup else 1)
     BH = B * h
-    lcfg, sizes = _ops._lara_layer_cfg(qkv, icfg, fcfg)          # (host-side size query: works on fake tensors)
+    # (host-side size query: works on fake tensors; the composite decision is taken like the real forward takes it -- the
+    # traced output count must be what the implementation will return when the graph runs)
+    lcfg, sizes = _ops._lara_layer_cfg(qkv, icfg, fcfg) if _ops._lara_use_composite() else (None, None)
     if lcfg is not None:
         return [qkv.new_empty((B, N, h, d)), _f32(qkv, sizes[0])]
     return [qkv.new_empty((B, N, h, d)), _f32(qkv, BH, C, d), _f32(qkv, BH, C, d) if mis != 2 else _none(qkv),

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 6          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 7          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "ea_colsum_f32": [_I, _I, _P, _P, _P],
     "ea_colsum2_f32": [_I, _I, _P, _P, _I, _P, _P, _P],
     "ea_slice_sum": [_I, _I, _I, _F, _P, _P, _P, _P],
+    "ea_stream_copy": [_P, _P, _L, _P],
     "ea_lara_segment_fwd": [_G, _T, _T] + [_P] * 12,
     "ea_lara_segment_bwd": [_G, _T, _T] + [_P] * 11 + [_T, _T, _P, _P],
     "ea_lara_parts": [_LG],

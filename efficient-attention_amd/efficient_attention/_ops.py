@@ -865,10 +865,16 @@ def _lara_layer_cfg(qkv5, icfg, fcfg):
     B, N, _, h, d = qkv5.shape
     cfg = nv.ea_lara_layer(B, h, d, nv.io_dtype(qkv5), H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
     sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2)]
-    # (per-kernel timing -- bench.py's instrumented pass -- needs the individual entry points)
-    if min(sizes) < 0 or os.environ.get("EA_LARA_COMPOSITE", "1") != "1" or nv.KERNEL_TIMER.enabled:
+    if min(sizes) < 0:
         return None, None
     return cfg, sizes
+
+
+def _lara_use_composite():
+    """The FORWARD's decision between the composite entry and the step-by-step launches (per-kernel timing -- bench.py's
+    instrumented pass -- needs the individual entry points).  The backward never re-takes it: it follows what the forward
+    saved (one workspace tensor = composite), so flipping the switch or the timer between the two cannot desynchronise them."""
+    return os.environ.get("EA_LARA_COMPOSITE", "1") == "1" and not nv.KERNEL_TIMER.enabled
 
 
 def _param_ptrs(ps):
@@ -886,7 +892,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
     (absent tensors are empty)."""
     global LAST_LMK_GEOM
     nv.require_cuda(qkv5, "qkv")
-    lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg)
+    lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg) if _lara_use_composite() else (None, None)
     need_grad = len(icfg) < 8 or bool(icfg[7])
     if lcfg is not None:
         B, N, _, h, d = qkv5.shape
@@ -934,7 +940,9 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
     """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)].  saved_list is what lara_fwd
     returned after `out`: the composite workspace (one tensor -> ea_lara_layer_bwd) or the step-by-step tensors."""
     if len(saved_list) == 1:
-        lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg)
+        lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg)          # pure geometry / size query: valid whenever the forward's was
+        if lcfg is None:
+            raise RuntimeError("lara_bwd: a composite workspace was saved for a geometry ea_lara_layer_ws rejects")
         B, N, _, h, d = qkv5.shape
         dev = qkv5.device
         ws = saved_list[0]
@@ -1063,21 +1071,28 @@ class LaraModuleFn(torch.autograd.Function):
         # output projection: input gradient from the master weight read transposed, weight + bias gradient in one pass
         d_o2 = _ea_op("linear_w32", linear_w32_impl, dy2, wp, None, elem, True, False, False)[0]
         dwp = dbp = None
-        if need[3] or (bpd is not None and need[4]):
-            dwp, dbp32 = wgrad(dy2, o2, bpd is not None and need[4])
-            dwp = dwp.to(wpd) if need[3] else None
-            dbp = dbp32.to(bpd) if (bpd is not None and need[4]) else None
+        need_bp = bpd is not None and need[4]
+        if need[3]:
+            dwp, dbp32 = wgrad(dy2, o2, need_bp)
+            dwp = dwp.to(wpd)
+            dbp = dbp32.to(bpd) if need_bp else None
+        elif need_bp:
+            dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
         grads = _ea_op("lara_bwd", lara_bwd_impl, d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved),
                        ctx.icfg, ctx.fcfg, list(params))
         dqkv2 = grads[0].view(-1, 3 * C)
         dwq = dbq = dx = None
-        if need[1] or (bqd is not None and need[2]):
+        need_bq = bqd is not None and need[2]
+        if need[1]:
             if xl is None:
                 raise RuntimeError("LaraModuleFn: the weight gradient was requested but the forward did not keep its input")
-            dwq, dbq32 = wgrad(dqkv2, xl, bqd is not None and need[2])
-            dwq = dwq.to(wqd) if need[1] else None
-            dbq = dbq32.to(bqd) if (bqd is not None and need[2]) else None
+            dwq, dbq32 = wgrad(dqkv2, xl, need_bq)
+            dwq = dwq.to(wqd)
+            dbq = dbq32.to(bqd) if need_bq else None
+        elif need_bq:
+            # frozen qkv weight, trainable bias (bias-only fine-tuning): a column sum of d qkv, no input rows needed
+            dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
             dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
         pgrads = [g.to(dt) for g, dt in zip(grads[1:], pdtypes)]
@@ -1622,7 +1637,15 @@ def slice_sum(part):
 
 
 USE_EA_LINEAR = os.environ.get("EA_LINEAR", "1") == "1"
-LABEL_ALGO_BYTES = {}     # timer label -> algorithmic bytes of its last launch (projection kernels: shapes vary per call)
+LABEL_ALGO_BYTES = {}     # timer label -> [summed algorithmic bytes, launches] of the projection kernels (one label per shape)
+
+
+def _note_bytes(label, nbytes):
+    """bench.py's instrumented pass: algorithmic bytes of every launch timed under `label`, SUMMED -- the achieved rate of a
+    label is summed bytes / summed time, never a maximum over one and a mean over the other."""
+    rec = LABEL_ALGO_BYTES.setdefault(label, [0, 0])
+    rec[0] += nbytes
+    rec[1] += 1
 _ELEM = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -1687,10 +1710,12 @@ def ea_linear(a2, w, bias32, out_dtype, want_cast=False, elem_dtype=None, transp
     y = torch.empty((rows, NO), dtype=out_dtype, device=a2.device)
     a_f32 = a2.dtype == torch.float32
     a_cast = torch.empty((rows, K), dtype=cdt, device=a2.device) if (a_f32 and want_cast) else None
-    label = "ea_linear (fp32 in)" if a_f32 else "ea_linear"
+    label = "ea_linear"
     if nv.KERNEL_TIMER.enabled:
-        # what the launch has to move: activations in, result out, the rounded copy when asked for (the weight is noise)
-        LABEL_ALGO_BYTES[label] = rows * (K * a2.element_size() + NO * y.element_size() + (K * 2 if a_cast is not None else 0))
+        # one label per shape; what the launch has to move: activations in, result out, the rounded copy when asked for
+        # (the weight is noise)
+        label = "ea_linear[%d->%d,%s->%s]" % (K, NO, "f32" if a_f32 else "16", "f32" if out_dtype == torch.float32 else "16")
+        _note_bytes(label, rows * (K * a2.element_size() + NO * y.element_size() + (K * 2 if a_cast is not None else 0)))
     if w32:
         nv.call_as(label, "ea_linear_w32", _ELEM[cdt], rows, K, NO, nv.ptr(a2), int(a_f32), a2.stride(0), nv.ptr(w),
                    int(transposed), nv.ptr(bias32), nv.ptr(y), int(out_dtype == torch.float32), NO, nv.ptr(a_cast), nv.stream())
@@ -1728,9 +1753,11 @@ def wgrad(dy2, x2, with_bias=True):
     n = M * K + (M if with_bias else 0)
     part = torch.empty((S, n), dtype=torch.float32, device=dy2.device)      # slice s: dW partial, then db partial
     db_ptr = ctypes.c_void_p(part.data_ptr() + M * K * 4) if with_bias else None
+    label = "ea_wgrad"
     if nv.KERNEL_TIMER.enabled:
-        LABEL_ALGO_BYTES["ea_wgrad"] = max(LABEL_ALGO_BYTES.get("ea_wgrad", 0), rows * (M + K) * 2 + n * 4)
-    nv.call("ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), db_ptr, n, nv.stream())
+        label = "ea_wgrad[%dx%d]" % (M, K)
+        _note_bytes(label, rows * (M + K) * 2 + n * 4)
+    nv.call_as(label, "ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), db_ptr, n, nv.stream())
     out = torch.empty(n, dtype=torch.float32, device=dy2.device)
     nv.call("ea_part_sum", S, n, n, nv.ptr(part), nv.ptr(out), nv.stream())
     dw = out[:M * K].view(M, K)

@@ -384,6 +384,10 @@ int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, in
 int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream);
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream);
+/* Measurement aid, not on the path: dst[0 .. bytes) = src[0 .. bytes) by a plain 16-byte-per-lane device copy kernel
+ * (src, dst 16-byte aligned, bytes a multiple of 16).  bench.py times it as the achievable-HBM-bandwidth yardstick next
+ * to the nominal 8 TB/s ("babel-stream-style copy kernel on the same GPU"). */
+int ea_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
 
 /* ---- LARA 1-D landmark proposals (LinearRA._proposal_gen_1d, lara.py:84-127) ----
  * Segment means over the sequence, q_bar_l = mean_{n in segment l} row_n, with the reference's

@@ -418,3 +418,50 @@ def test_lara_module_single_node_equals_three_nodes(gen, train):
     assert res[True][3].keys() == res[False][3].keys() and len(res[True][3]) >= 4
     for n in res[True][3]:
         assert torch.equal(res[True][3][n], res[False][3][n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frozen", ["qkv.weight", "proj.weight", "both"])
+def test_lara_module_single_node_bias_only_finetuning(frozen):
+    """frozen projection weight + trainable bias + fp32 x under autocast (bias-only fine-tuning).  The single
+    node must not ask for the rounded input it did not keep: the bias gradient is a column sum of d qkv (ea_bias_grad).
+    Same gradients as the three-node path, bit for bit."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(12)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                                                             mis_type="mis-opt", alpha_coeff=2.0, qkv_bias=True)).cuda()
+    m.train()
+    for n, p in m.named_parameters():
+        if n == frozen or (frozen == "both" and n in ("qkv.weight", "proj.weight")):
+            p.requires_grad_(False)
+    assert m.qkv.bias is not None and m.qkv.bias.requires_grad
+    x0 = torch.randn(2, 28, 28, 192, device="cuda")
+    g = torch.randn(2, 28, 28, 192, device="cuda").bfloat16()
+    res = {}
+    for single in (True, False):
+        old = _ops.USE_LARA_MODULE_FN
+        _ops.USE_LARA_MODULE_FN = single
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            node = type(y.grad_fn).__name__
+            y.backward(g)
+            res[single] = (node, x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _ops.USE_LARA_MODULE_FN = old
+    assert res[True][0].startswith("LaraModuleFn")
+    assert torch.equal(res[True][1], res[False][1])
+    assert res[True][2].keys() == res[False][2].keys() and "qkv.bias" in res[True][2] and "proj.bias" in res[True][2]
+    for n in res[True][2]:
+        a, b = res[True][2][n], res[False][2][n]
+        # the one-pass weight gradient carries the bias sum along; alone it is ea_bias_grad: same sum, other order
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max())), n

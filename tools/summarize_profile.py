@@ -16,7 +16,7 @@ KERNEL_TO_ENTRY = [
     ("lara_fin_kernel<", "ea_lara_bwd_finish"),
     ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
     ("wgrad_kernel<", "ea_wgrad"), ("part_sum_kernel", "ea_part_sum"),
-    ("lin_kernel<ea::BF16, 6, 2, true", "ea_linear (fp32 in)"), ("lin_kernel<", "ea_linear"),
+    ("lin_kernel<ea::BF16, 6, 2, true", "ea_linear[fp32 in]"), ("lin_kernel<", "ea_linear"),
     ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("lara_sample_kernel<", "ea_lara_sample"), ("pool2d_", "ea_adaptive_pool2d"),
     ("sb_fwd_kernel<", "ea_scatter_fwd"), ("sb_bwd_kernel<ea::BF16, false>", "ea_scatter_bwd_window"),
@@ -34,7 +34,7 @@ KERNEL_TO_ENTRY = [
     ("win_bwd_kernel<", "ea_window_attn_bwd"),
     ("chunk_mean_fwd_r_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_r_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_r_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_r_kernel<", "ea_eva_beta_bwd"),
-    ("proj_rs_kernel<", "ea_linear (fp32 in)"),
+    ("proj_rs_kernel<", "ea_linear[fp32 in]"),
     ("chunk_mean_fwd_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_kernel<", "ea_eva_beta_bwd"),
     ("sm_fwd_kernel<ea::BF16, 64", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64", "ea_softmax_attn_bwd(dq)"),
@@ -85,6 +85,20 @@ def main(src, tag, attn, outdir, workload="default workload"):
         total = (2 * f + wv) * 1024
         out[e] = total
         lines.append("| %s | %.1f | %.0f | %.0f | %.1f |" % (e, avg_ns.get(e, 0) / 1e3, f, wv, total / 1e6))
+    # bytes of one step: every dispatch of every ea:: kernel, summed, / the number of steps the counter pass ran (= the
+    # dispatch count of a kernel launched once per step); `attention` = everything but the projection / reduction kernels
+    nrows = {e: max(len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"])) for e, d in pmc.items()}
+    steps = collections.Counter(nrows.values()).most_common(1)[0][0] if nrows else 0   # most kernels launch once per step
+    if steps:
+        proj = ("ea_linear", "ea_wgrad", "ea_part_sum", "ea_bias_grad")
+        tot = {e: (2 * sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1) + sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1))
+               * 1024 * nrows[e] / steps for e, d in pmc.items()}
+        out["_launches_per_step"] = {e: round(nrows[e] / steps, 2) for e in pmc}
+        out["_step_traffic_bytes"] = sum(tot.values())
+        out["_step_traffic_bytes_attention"] = sum(v for e, v in tot.items() if not e.startswith(proj))
+        lines.append("")
+        lines.append("Per step (all ea:: kernels x launches per step): %.1f MB; attention kernels only: %.1f MB."
+                     % (out["_step_traffic_bytes"] / 1e6, out["_step_traffic_bytes_attention"] / 1e6))
     out["_lib_sha256"] = lib_sha()            # bench.py ignores the file once the library has changed
     json.dump(out, open(os.path.join(outdir, "pmc_%s.json" % attn), "w"), indent=1)
     open(os.path.join(outdir, "%s_%s_hbm.md" % (tag, attn)), "w").write(
