@@ -27,8 +27,9 @@ int pool2d_dispatch(bool bwd, int dtype, const void* x, long sb, long sh, long s
                     int side, int D, hipStream_t st);
 int linear_supported(int K, int NO);
 int proj_rs_supported(int K, int NO);
+int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r);
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st);
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
@@ -967,9 +968,27 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
   // (a workgroup first loads the whole 576 x 192 weight into its registers: worth it from ~8 token tiles per workgroup on --
   //  at N = 196 x batch 128 the LDS-resident kernel is faster, 25.7 against 30.1 us)
   if (rs_on && !w_transposed && !y_f32 && rows >= 65536 && proj_rs_supported(in_features, out_features))
-    return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream);
+    return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream, 0, 0, 0, 0,
+                            nullptr, nullptr);
   return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
                          (long)lda, (long)ldy, (hipStream_t)stream);
+}
+
+// qkv projection + pooled q / k rows in one pass (ea_proj_rs.hip, POOL variants)
+int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int32_t B, int32_t gh, int32_t gw, int32_t r) {
+  return proj_rs_pool_supported(in_features, out_features, B, gh, gw, r);
+}
+
+int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t r, int32_t in_features, int32_t out_features,
+                       const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
+                       void* a_cast, float* pooled_q, float* pooled_k, void* stream) {
+  if (!a || !w || !y || !pooled_q || !pooled_k || ((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) ||
+      ((uintptr_t)bias & 15) || ((uintptr_t)a_cast & 15) || ((uintptr_t)pooled_q & 15) || ((uintptr_t)pooled_k & 15))
+    return EA_E_BADARG;
+  if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
+  if (!proj_rs_pool_supported(in_features, out_features, B, gh, gw, r)) return EA_E_UNSUPPORTED;
+  return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, B * gh * gw, (long)lda, (long)ldy, (hipStream_t)stream, B, gh, gw,
+                          r, pooled_q, pooled_k);
 }
 
 }  // extern "C"
@@ -1163,7 +1182,14 @@ int64_t ea_lara_layer_ws(const ea_lara_layer* c, int32_t which) {
   LaraLayerPlan P;
   const int rc = lara_layer_plan(c, P);
   if (rc != EA_OK) return rc;
-  return (int64_t)(which == 0 ? P.n_saved : (which == 1 ? P.n_ftmp : P.n_btmp));
+  switch (which) {
+    case 0: return (int64_t)P.n_saved;
+    case 1: return (int64_t)P.n_ftmp;
+    case 2: return (int64_t)P.n_btmp;
+    case 3: return (int64_t)P.o_pq;
+    case 4: return (int64_t)P.o_pk;
+    default: return EA_E_BADARG;
+  }
 }
 
 int ea_lara_layer_fwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
@@ -1181,8 +1207,11 @@ int ea_lara_layer_fwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
   float* bhv = opt ? saved + P.o_bhv : nullptr;
   float* lse_t = opt ? saved + P.o_lset : nullptr;
   float* pq = saved + P.o_pq; float* pk = saved + P.o_pk;
-  rc = ea_eva_chunk_mean_fwd(&P.pg, q, k, nullptr, pq, pk, stream);
-  if (rc != EA_OK) return rc;
+  if (!(keep_for_backward & EA_LARA_POOLED_READY)) {
+    rc = ea_eva_chunk_mean_fwd(&P.pg, q, k, nullptr, pq, pk, stream);
+    if (rc != EA_OK) return rc;
+  }
+  keep_for_backward &= 1;
   rc = ea_lara_landmarks_fwd(&P.lg, pq, pk, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], noise, omega, qrows, bhv,
                              tmp + P.f_lp, keep_for_backward ? saved + P.o_lmk : nullptr, stream);
   if (rc != EA_OK) return rc;

@@ -263,8 +263,16 @@ EA_DEV float wave_sum(float v) {
 static __device__ char ea_trash[512 * 64];
 EA_DEV char* ea_trash_line() { return ea_trash + threadIdx.x * 64; }
 
+#ifdef EA_NT_LOADS
+EA_DEV u32x4 ldg16(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
+#else
 EA_DEV u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+#endif
+#ifdef EA_NT_STORES
+EA_DEV void stg16(void* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); }
+#else
 EA_DEV void stg16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+#endif
 EA_DEV u32x4 lds16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 EA_DEV void sts16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 

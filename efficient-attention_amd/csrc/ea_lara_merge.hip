@@ -20,16 +20,27 @@ __global__ __launch_bounds__(256) void lara_merge_fwd_kernel(const MergeP p) {
   if (blockIdx.y == 0) {
     for (int c = tid; c < C; c += 256) {
       float mk = -INFINITY, mt = -INFINITY;
-      for (int s = 0; s < S; ++s) {
-        const float* ml = p.p_ml + (((size_t)bh * S + s) * C + c) * 4;
-        mk = fmaxf(mk, ml[0]);
-        mt = fmaxf(mt, ml[2]);
+      for (int s0 = 0; s0 < S; s0 += 8) {
+        float4 m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          m8[u] = *reinterpret_cast<const float4*>(p.p_ml + (((size_t)bh * S + min(s0 + u, S - 1)) * C + c) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { mk = fmaxf(mk, m8[u].x); mt = fmaxf(mt, m8[u].z); }
       }
       float lk = 0.f, lt = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float* ml = p.p_ml + (((size_t)bh * S + s) * C + c) * 4;
-        lk += ml[1] * __expf(ml[0] - mk);
-        if (p.has_t) lt += ml[3] * __expf(ml[2] - mt);
+      for (int s0 = 0; s0 < S; s0 += 8) {
+        float4 m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          m8[u] = *reinterpret_cast<const float4*>(p.p_ml + (((size_t)bh * S + min(s0 + u, S - 1)) * C + c) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < S) {
+            lk += m8[u].y * __expf(m8[u].x - mk);
+            if (p.has_t) lt += m8[u].w * __expf(m8[u].z - mt);
+          }
+        }
       }
       const float lsek = mk + __logf(lk);
       const size_t o = (size_t)bh * C + c;
@@ -40,16 +51,36 @@ __global__ __launch_bounds__(256) void lara_merge_fwd_kernel(const MergeP p) {
   }
   if (i4 * 4 >= C * D) return;
   const int e = i4 * 4, c = e / D, j = e - c * D;
+  // slices in batches of 8 with every load of a batch in flight (a runtime-S loop issued one dependent round trip per
+  // slice: 16 us at B*h = 8, S = 64)
   float mk = -INFINITY;
-  for (int s = 0; s < S; ++s) mk = fmaxf(mk, p.p_ml[(((size_t)bh * S + s) * C + c) * 4]);
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    float m8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m8[u] = p.p_ml[(((size_t)bh * S + min(s0 + u, S - 1)) * C + c) * 4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mk = fmaxf(mk, m8[u]);
+  }
   float lk = 0.f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < S; ++s) {
-    const size_t slot = ((size_t)bh * S + s) * C + c;
-    const float w = __expf(p.p_ml[slot * 4] - mk);
-    lk += p.p_ml[slot * 4 + 1] * w;
-    const float4 v = *reinterpret_cast<const float4*>(p.p_kv + slot * D + j);
-    acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+  for (int s0 = 0; s0 < S; s0 += 8) {
+    float m8[8], l8[8];
+    float4 v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const size_t slot = ((size_t)bh * S + min(s0 + u, S - 1)) * C + c;
+      m8[u] = p.p_ml[slot * 4];
+      l8[u] = p.p_ml[slot * 4 + 1];
+      v8[u] = *reinterpret_cast<const float4*>(p.p_kv + slot * D + j);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < S) {
+        const float w = __expf(m8[u] - mk);
+        lk += l8[u] * w;
+        acc.x += v8[u].x * w; acc.y += v8[u].y * w; acc.z += v8[u].z * w; acc.w += v8[u].w * w;
+      }
+    }
   }
   const float iv = 1.f / lk;
   *reinterpret_cast<float4*>(p.kv + (size_t)bh * C * D + e) = make_float4(acc.x * iv, acc.y * iv, acc.z * iv, acc.w * iv);
@@ -65,9 +96,15 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
   if (blockIdx.y == 0) {
     for (int c = tid; c < C; c += 256) {
       float r = 0.f, dbh = 0.f;
-      for (int s = 0; s < S; ++s) {
-        const float* ml = p.p_ml + (((size_t)bh * S + s) * C + c) * 4;
-        r += ml[0]; dbh += ml[1];
+      for (int s0 = 0; s0 < S; s0 += 8) {
+        float4 m8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          m8[u] = *reinterpret_cast<const float4*>(p.p_ml + (((size_t)bh * S + min(s0 + u, S - 1)) * C + c) * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + u < S) { r += m8[u].x; dbh += m8[u].y; }
+        }
       }
       const size_t o = (size_t)bh * C + c;
       p.r[o] = r;
@@ -85,19 +122,33 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
   const int c = e / D, j = e - c * D;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
   float u = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const size_t slot = ((size_t)bh * S + s) * C + c;
-    const size_t o4 = slot * D + j;
-    const float4 v0 = *reinterpret_cast<const float4*>(p.acc0 + o4);
-    const float4 v1 = *reinterpret_cast<const float4*>(p.acc1 + o4);
-    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-    if (p.has_t) {
-      u += p.p_ml[slot * 4 + 2];
-      const float4 v2 = *reinterpret_cast<const float4*>(p.acc2 + o4);
-      const float4 v3 = *reinterpret_cast<const float4*>(p.acc3 + o4);
-      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  // slices in batches of 4, all (up to 17) loads of a batch in flight; same summation order as a plain loop
+  for (int s0 = 0; s0 < S; s0 += 4) {
+    float4 v0[4], v1[4], v2[4], v3[4];
+    float uu[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const size_t slot = ((size_t)bh * S + min(s0 + b, S - 1)) * C + c;
+      const size_t o4 = slot * D + j;
+      v0[b] = *reinterpret_cast<const float4*>(p.acc0 + o4);
+      v1[b] = *reinterpret_cast<const float4*>(p.acc1 + o4);
+      if (p.has_t) {
+        uu[b] = p.p_ml[slot * 4 + 2];
+        v2[b] = *reinterpret_cast<const float4*>(p.acc2 + o4);
+        v3[b] = *reinterpret_cast<const float4*>(p.acc3 + o4);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (s0 + b < S) {
+        a0.x += v0[b].x; a0.y += v0[b].y; a0.z += v0[b].z; a0.w += v0[b].w;
+        a1.x += v1[b].x; a1.y += v1[b].y; a1.z += v1[b].z; a1.w += v1[b].w;
+        if (p.has_t) {
+          u += uu[b];
+          a2.x += v2[b].x; a2.y += v2[b].y; a2.z += v2[b].z; a2.w += v2[b].w;
+          a3.x += v3[b].x; a3.y += v3[b].y; a3.z += v3[b].z; a3.w += v3[b].w;
+        }
+      }
     }
   }
   const size_t o = (size_t)bh * C * D + e;

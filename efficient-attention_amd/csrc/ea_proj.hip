@@ -105,9 +105,14 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float* __restrict_
   if (i >= total4) return;
   const size_t bh = i / n4, j = i - bh * n4;
   float4 acc = a ? reinterpret_cast<const float4*>(a)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < S; ++s) {
-    const float4 v = reinterpret_cast<const float4*>(p)[(bh * S + s) * n4 + j];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  for (int s0 = 0; s0 < S; s0 += 8) {              // eight slices in flight; summation order unchanged
+    float4 v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = reinterpret_cast<const float4*>(p)[(bh * S + min(s0 + u, S - 1)) * n4 + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < S) { acc.x += v8[u].x; acc.y += v8[u].y; acc.z += v8[u].z; acc.w += v8[u].w; }
+    }
   }
   reinterpret_cast<float4*>(out)[i] = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
 }
@@ -186,20 +191,30 @@ int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, in
 }
 
 // Bandwidth yardstick (bench.py `hbm_measured_copy_gbs`, SURVEY 8d "babel-stream-style copy kernel on the same GPU"):
-// dst[i] = src[i] in 16-byte pieces, four independent loads in flight per lane, two resident rounds of workgroups.
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+// dst[i] = src[i] in 16-byte pieces.  Measured on MI355X over 512 MB (tools/probe/copy_probe.hip): a workgroup walking
+// CONTIGUOUS 16 KB pieces (four 4 KB rows of its 256 lanes in flight) with non-temporal loads / stores reaches 6.25 TB/s
+// (plain: 5.7); the classic grid-stride loop whose four loads lie a whole grid (8 MB) apart 4.4 TB/s -- DRAM page locality
+// of what is in flight at one time matters more than anything else in a streaming kernel; hipMemcpyDtoD 4.7 TB/s.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+  const size_t step = (size_t)gridDim.x * 1024;
+  size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 768 < n16; i += step) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v[u], dst + i + u * 256);
   }
-  for (; i < n16; i += stride) dst[i] = src[i];
+  for (int u = 0; u < 4; ++u)
+    if (i + u * 256 < n16 && i + 768 >= n16) dst[i + u * 256] = src[i + u * 256];
 }
 
 int stream_copy_dispatch(const void* src, void* dst, size_t bytes, hipStream_t st) {
   if (bytes == 0 || (bytes & 15)) return EA_E_BADARG;
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, st, (const float4*)src, (float4*)dst, bytes / 16);
+  const size_t n16 = bytes / 16;
+  size_t grid = (n16 + 1023) / 1024;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, n16);
   return (int)hipGetLastError();
 }
 

@@ -22,6 +22,12 @@ struct RsP {
   char* a_cast;         // [rows, 192] element-type copy of a (AF32 only) or null
   int rows, ntiles;
   long lda, ldy;
+  // pooling epilogue (POOL > 0): the means of the ROUNDED q / k rows over the r x r token cells of a gw-wide grid -- what
+  // ea_eva_chunk_mean_fwd recomputes from the stored rows (lara.py:43,48,145-151; eva.py:178-181 for 2-D chunks) -- leave
+  // with the projection, fp32 [B*3, Lc, 64] per side.  A tile is then 32 / (r r) WHOLE cells (token slots gathered).
+  float *pq, *pk;
+  int gw, cw, Lc, ntok, ncell;        // cw = gw / r cells per grid row, Lc cells per image, ntok = gh gw, ncell = B Lc
+  unsigned m_Lc, m_cw;                // floor(2^32 / d) + 1: n / d == umulhi(n, m) for n d < 2^32
 };
 
 constexpr int RS_K = 192, RS_NO = 576, RS_WAVES = 12, RS_TOK = 32, RS_KT = RS_K / 32, RS_SLABS = RS_K / 64;
@@ -29,7 +35,8 @@ constexpr int RS_K = 192, RS_NO = 576, RS_WAVES = 12, RS_TOK = 32, RS_KT = RS_K 
 // LDS tile: [slab][token][64 channels] element type, phi2-swizzled 128-byte rows
 EA_DEV int rs_off(int slab, int tok, int chunk16) { return slab * (RS_TOK * 128) + lds_off2<64>(tok, chunk16); }
 
-template <typename E, bool AF32>
+// POOL: tokens per pooling cell (0: none; 16: 4 x 4 cells, two per tile; 4: 2 x 2 cells, eight per tile)
+template <typename E, bool AF32, int POOL>
 __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) {
   __shared__ __attribute__((aligned(16))) char tile[2][RS_SLABS * RS_TOK * 128];
   __shared__ __attribute__((aligned(16))) float bias_s[RS_NO];          // rounded to the element type
@@ -37,9 +44,29 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- this thread's staging slot: token st_tok of the tile, channels 8 st_c .. 8 st_c + 7 ----
   const int st_tok = tid / 24, st_c = tid - st_tok * 24;           // 32 tokens x 24 chunks = 768 slots
+  // token behind slot s of tile t.  Plain: consecutive rows.  POOL: the tile's cells' tokens (cell-major, then row-major
+  // inside the r x r cell) -- every row is still read and written whole, only the order inside a tile changes -- clamped to
+  // the last cell (duplicates rewrite their own values, like the clamped rows of the plain order).
+  constexpr int PR = POOL == 16 ? 4 : 2;
+  auto cell_of = [&](int t, int s, int& img, int& cl) {
+    const int cell = min(t * (RS_TOK / (POOL ? POOL : 1)) + s / (POOL ? POOL : 1), p.ncell - 1);
+    img = (int)__umulhi((unsigned)cell, p.m_Lc);
+    cl = cell - img * p.Lc;
+  };
+  auto tok_of = [&](int t, int s) {
+    if constexpr (POOL == 0) {
+      return min(t * RS_TOK + s, p.rows - 1);
+    } else {
+      int img, cl;
+      cell_of(t, s, img, cl);
+      const int cy = (int)__umulhi((unsigned)cl, p.m_cw), cx = cl - cy * p.cw;
+      const int w = s % POOL, dy = w / PR, dx = w % PR;
+      return img * p.ntok + (cy * PR + dy) * p.gw + cx * PR + dx;
+    }
+  };
   u32x4 nb[AF32 ? 2 : 1];
   auto issue = [&](int t) {
-    const int tok = min(t * RS_TOK + st_tok, p.rows - 1);
+    const int tok = tok_of(t, st_tok);
     const char* ap = p.a + (size_t)tok * p.lda * (AF32 ? 4 : 2) + st_c * (AF32 ? 32 : 16);
     nb[0] = ldg16(ap);
     if constexpr (AF32) nb[1] = ldg16(ap + 16);
@@ -78,7 +105,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       }
       sts16(tile[buf] + rs_off(slab_s, st_tok, ch_s), w8);
       if (AF32 && p.a_cast) {
-        const int tok = min(t * RS_TOK + st_tok, p.rows - 1);       // (clamped rows rewrite the last row with its own values)
+        const int tok = tok_of(t, st_tok);                          // (clamped rows rewrite the last row with its own values)
         stg16(p.a_cast + ((size_t)tok * RS_K + st_c * 8) * 2, w8);
       }
     }
@@ -107,7 +134,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     u32x2 third[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const int tok = min(t * RS_TOK + 16 * rt + li, p.rows - 1);
+      const int tok = tok_of(t, 16 * rt + li);
       char* yp = p.y + ((size_t)tok * p.ldy + c0) * 2;
       const f32x4 v0 = acc[0][rt] + bv0, v1 = acc[1][rt] + bv1, v2 = acc[2][rt] + bv2;
       u32x4 o;
@@ -115,6 +142,28 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       o[2] = pack2<E>(v1[0], v1[1]); o[3] = pack2<E>(v1[2], v1[3]);
       stg16(yp + 16 * g, o);
       third[rt] = u32x2{pack2<E>(v2[0], v2[1]), pack2<E>(v2[2], v2[3])};
+      if constexpr (POOL > 0) {
+        // q / k columns (waves 0 .. 7): cell sums of the values just rounded, over the POOL lanes of the cell (DPP adds)
+        if (wave < 8) {
+          float f[12];
+          unpack2<E>(o[0], f[0], f[1]); unpack2<E>(o[1], f[2], f[3]); unpack2<E>(o[2], f[4], f[5]); unpack2<E>(o[3], f[6], f[7]);
+          unpack2<E>(third[rt][0], f[8], f[9]); unpack2<E>(third[rt][1], f[10], f[11]);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) f[i] = group_sum<POOL>(f[i]) * (1.f / POOL);
+          if ((li & (POOL - 1)) == 0 && t * (RS_TOK / POOL) + (16 * rt + li) / POOL < p.ncell) {
+            int img, cl;
+            cell_of(t, 16 * rt + li, img, cl);
+            // columns c0 + 8 g .. + 7 and c0 + 32 + 4 g .. + 3; a 4-column piece never straddles a head (64 | 192)
+            const int cols[3] = {c0 + 8 * g, c0 + 8 * g + 4, c0 + 32 + 4 * g};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int side = cols[j] >= RS_K, hc = cols[j] - side * RS_K, head = hc >> 6, ch = hc & 63;
+              float* dst = (side ? p.pk : p.pq) + ((size_t)(img * 3 + head) * p.Lc + cl) * 64 + ch;
+              *reinterpret_cast<f32x4*>(dst) = f32x4{f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]};
+            }
+          }
+        }
+      }
     }
     // third tile: lane-row g holds columns c0 + 32 + 4 g .. + 3 of tokens li (rt 0) and 16 + li (rt 1).  Lane-rows 2 m and
     // 2 m + 1 trade pieces (even row's rt-1 piece <-> odd row's rt-0 piece, one v_permlane16_swap per register) so that row
@@ -123,7 +172,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
                  : "+v"(third[0][0]), "+v"(third[0][1]), "+v"(third[1][0]), "+v"(third[1][1]));
     {
-      const int tok = min(t * RS_TOK + 16 * (g & 1) + li, p.rows - 1);
+      const int tok = tok_of(t, 16 * (g & 1) + li);
       const u32x4 o = {third[0][0], third[0][1], third[1][0], third[1][1]};
       stg16(p.y + ((size_t)tok * p.ldy + c0 + 32 + 8 * (g >> 1)) * 2, o);
     }
@@ -132,24 +181,47 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
 
 int proj_rs_supported(int K, int NO) { return K == RS_K && NO == RS_NO; }
 
+static unsigned rs_magic(int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; }
+
+// pooled variant: B images of gh x gw tokens, r x r cells (r = 2 or 4), three heads of 64 channels
+int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r) {
+  if (K != RS_K || NO != RS_NO || (r != 2 && r != 4) || B <= 0 || gh <= 0 || gw <= 0 || gh % r || gw % r) return 0;
+  const long Lc = (long)(gh / r) * (gw / r), ncell = (long)B * Lc;
+  return ncell * Lc < (1l << 32) && (long)B * gh * gw < (1l << 31);
+}
+
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st) {
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk) {
   if (rows <= 0) return EA_OK;
-  RsP p;
+  RsP p = {};
   p.a = (const char*)a; p.w = w; p.bias = bias; p.y = (char*)y; p.a_cast = a_f32 ? (char*)a_cast : nullptr;
   p.rows = rows; p.ntiles = (rows + RS_TOK - 1) / RS_TOK; p.lda = lda; p.ldy = ldy;
+  const int pool = r * r;
+  if (pool) {
+    if (!pq || !pk || rows != B * gh * gw) return EA_E_BADARG;
+    p.pq = pq; p.pk = pk; p.gw = gw; p.cw = gw / r; p.Lc = (gh / r) * p.cw; p.ntok = gh * gw; p.ncell = B * p.Lc;
+    p.m_Lc = rs_magic(p.Lc); p.m_cw = rs_magic(p.cw);
+    p.ntiles = (p.ncell * pool + RS_TOK - 1) / RS_TOK;
+  }
   int grid = ea_device_cus();
   if (grid > p.ntiles) grid = p.ntiles;
   const dim3 g((unsigned)grid), b(RS_WAVES * 64);
+#define EA_RS_LAUNCH(E_, AF_)                                                                                  \
+  do {                                                                                                         \
+    if (pool == 16) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 16>), g, b, 0, st, p);                         \
+    else if (pool == 4) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 4>), g, b, 0, st, p);                      \
+    else hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 0>), g, b, 0, st, p);                                     \
+  } while (0)
   if (dtype == EA_BF16) {
-    if (a_f32) hipLaunchKernelGGL((proj_rs_kernel<BF16, true>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((proj_rs_kernel<BF16, false>), g, b, 0, st, p);
+    if (a_f32) EA_RS_LAUNCH(BF16, true);
+    else EA_RS_LAUNCH(BF16, false);
   } else if (dtype == EA_F16) {
-    if (a_f32) hipLaunchKernelGGL((proj_rs_kernel<F16, true>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((proj_rs_kernel<F16, false>), g, b, 0, st, p);
+    if (a_f32) EA_RS_LAUNCH(F16, true);
+    else EA_RS_LAUNCH(F16, false);
   } else {
     return EA_E_BADARG;
   }
+#undef EA_RS_LAUNCH
   return (int)hipGetLastError();
 }
 

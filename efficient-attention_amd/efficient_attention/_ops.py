@@ -860,10 +860,14 @@ def _lara_cfg(qkv5, icfg, fcfg):
 
 def _lara_layer_cfg(qkv5, icfg, fcfg):
     """ea_lara_layer of the composite entry points, or None when the geometry needs the step-by-step path (C > 64)."""
+    B, N, _, h, d = qkv5.shape
+    return _lara_layer_cfg_dims(B, h, d, nv.io_dtype(qkv5), icfg, fcfg)
+
+
+def _lara_layer_cfg_dims(B, h, d, io, icfg, fcfg):
     H, W, r, has_mlp, mixed, mis, dup = [int(v) for v in icfg[:7]]
     kappa, scale = [float(v) for v in fcfg]
-    B, N, _, h, d = qkv5.shape
-    cfg = nv.ea_lara_layer(B, h, d, nv.io_dtype(qkv5), H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
+    cfg = nv.ea_lara_layer(B, h, d, io, H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
     sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2)]
     if min(sizes) < 0:
         return None, None
@@ -883,23 +887,28 @@ def _param_ptrs(ps):
     return arr
 
 
-def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
+def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params, pooled=None):
     """torch.ops.ea.lara_fwd: uniform r x r pooling of q, k -> fused landmark pipeline -> estimator.
     icfg = [H, W, r, has_mlp, mixed, mis, dup(, keep_for_backward = 1)], fcfg = [kappa, scale], params = (Wq,
     bq, gq, cq, Wk, bk, gk, ck) when has_mlp.
     C <= 64: ONE composite C-ABI call (ea_lara_layer_fwd) on two workspaces -> [out, saved workspace].
     Otherwise the step-by-step launch sequence -> [out, omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, noise, lmk_saved, tokst]
-    (absent tensors are empty)."""
+    (absent tensors are empty).
+    pooled (direct calls only, never through the dispatcher): what project_qkv_pooled returned -- the pooled q / k rows
+    already computed by the projection kernel, either inside the composite workspace (ws, None, None) or as two tensors
+    (None, pq, pk): the pooling pass is skipped."""
     global LAST_LMK_GEOM
     nv.require_cuda(qkv5, "qkv")
     lcfg, sizes = _lara_layer_cfg(qkv5, icfg, fcfg) if _lara_use_composite() else (None, None)
     need_grad = len(icfg) < 8 or bool(icfg[7])
+    if pooled is not None and (pooled[0] is not None) != (lcfg is not None):
+        raise RuntimeError("lara_fwd: pooled rows prepared for the other launch path")
     if lcfg is not None:
         B, N, _, h, d = qkv5.shape
         dev = qkv5.device
         q, k, v = _qkv_views(qkv5)
         tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
-        ws = torch.empty(sizes[0], dtype=torch.float32, device=dev)
+        ws = pooled[0] if pooled is not None else torch.empty(sizes[0], dtype=torch.float32, device=dev)
         tmp = torch.empty(sizes[1], dtype=torch.float32, device=dev)
         out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
         to = nv.t4(out.permute(0, 2, 1, 3))
@@ -909,17 +918,21 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params):
         LAST_LMK_GEOM = (B * h, (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r),
                          (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r) * (2 if lcfg.dup else 1), d, lcfg.has_mlp, lcfg.mixed, 0)
         nv.call("ea_lara_layer_fwd", ctypes.byref(lcfg), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
-                nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(to), nv.ptr(ws), nv.ptr(tmp), int(need_grad), nv.stream())
+                nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(to), nv.ptr(ws), nv.ptr(tmp),
+                int(need_grad) | (2 if pooled is not None else 0), nv.stream())
         return [out, ws]
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
     B, N, _, h, d = qkv5.shape
     BH, dev = B * h, qkv5.device
     q, k, _ = _qkv_views(qkv5)
     tq, tk = nv.t4(q), nv.t4(k)
-    pq = torch.empty((BH, L, d), dtype=torch.float32, device=dev)
-    pk = torch.empty_like(pq)
-    nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
-            nv.ptr(pq), nv.ptr(pk), nv.stream())
+    if pooled is not None:
+        pq, pk = pooled[1].view(BH, L, d), pooled[2].view(BH, L, d)
+    else:
+        pq = torch.empty((BH, L, d), dtype=torch.float32, device=dev)
+        pk = torch.empty_like(pq)
+        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
+                nv.ptr(pq), nv.ptr(pk), nv.stream())
     noise_c = None if noise is None else noise.float().contiguous()
     ps = [t.detach().float().contiguous() for t in params]
     LAST_LMK_GEOM = (BH, L, C, d, has_mlp, mixed, 0)
@@ -1023,6 +1036,33 @@ class LaraPooledFn(torch.autograd.Function):
         return (grads[0], None, None, None) + tuple(pgrads)
 
 
+USE_PROJ_POOL = os.environ.get("EA_PROJ_POOL", "1") == "1"
+
+
+def proj_pool_supported(x2, w32, cdtype, B, H, W, r, heads):
+    """ea_linear_w32_pool: the qkv projection of a 192-wide three-head model that also emits the r x r pooled q / k rows."""
+    C = x2.shape[1]
+    return (USE_PROJ_POOL and heads == 3 and C == 192 and tuple(w32.shape) == (576, 192) and w32.dtype == torch.float32
+            and x2.shape[0] == B * H * W and x2.is_contiguous()
+            and bool(nv.lib().ea_linear_pool_supported(192, 576, B, H, W, r)))
+
+
+def project_qkv_pooled(x2, wq, bq32, cdtype, want_cast, B, H, W, r, pq, pk):
+    """qkv = x2 @ wq.T + bq in `cdtype` with the means of the rounded q / k rows over the r x r cells written to pq / pk
+    (fp32 [B*3, L, 64]) by the same kernel (ea_linear_w32_pool) -> (y [rows, 576], rounded copy of an fp32 x2 or None)."""
+    rows, K = x2.shape
+    a_f32 = x2.dtype == torch.float32
+    y = torch.empty((rows, 576), dtype=cdtype, device=x2.device)
+    a_cast = torch.empty((rows, K), dtype=cdtype, device=x2.device) if (a_f32 and want_cast) else None
+    label = "ea_linear_w32_pool"
+    if nv.KERNEL_TIMER.enabled:
+        label = "ea_linear[192->576,%s->16,+pool]" % ("f32" if a_f32 else "16")
+        _note_bytes(label, rows * (K * x2.element_size() + 576 * 2 + (K * 2 if a_cast is not None else 0)))
+    nv.call_as(label, "ea_linear_w32_pool", _ELEM[cdtype], B, H, W, r, K, 576, nv.ptr(x2), int(a_f32), x2.stride(0), nv.ptr(wq),
+               nv.ptr(bq32), nv.ptr(y), 576, nv.ptr(a_cast), nv.ptr(pq), nv.ptr(pk), nv.stream())
+    return y, a_cast
+
+
 class LaraModuleFn(torch.autograd.Function):
     """qkv projection -> 2-D pooled LARA core -> output projection as ONE autograd node (round 3): the same launches as
     LinearFn + LaraPooledFn + LinearFn, without two of the three nodes' host cost (ctx objects, saved-tensor packing, engine
@@ -1042,13 +1082,34 @@ class LaraModuleFn(torch.autograd.Function):
         bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
         bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
         want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
-        y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
-        xl = x2 if x2.dtype == cdtype else (xc if want else None)
-        qkv5 = y.view(B, N, 3, heads, C // heads)
         icfg = [int(H), int(W), int(r), int(bool(has_mlp)), int(bool(mixed)), int(mis), int(dup),
                 int(any(ctx.needs_input_grad))]
         fcfg = [float(kappa), float(scale)]
-        outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
+        direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+        if direct and proj_pool_supported(x2, wq, cdtype, B, H, W, r, heads):
+            # round 4: the projection kernel walks the tokens cell by cell and emits the pooled q / k rows itself -- the
+            # pooling pass (ea_eva_chunk_mean_fwd: q, k read once more, 87 MB / 17 us at cfg3) is gone
+            d, L = C // heads, (H // r) * (W // r)
+            lcfg, sizes = _lara_layer_cfg_dims(B, heads, d, elem, icfg, fcfg) if _lara_use_composite() else (None, None)
+            if lcfg is not None:
+                ws = torch.empty(sizes[0], dtype=torch.float32, device=x.device)
+                o_pq, o_pk = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(lcfg), w)) for w in (3, 4)]
+                n_p = B * heads * L * d
+                pooled = (ws, None, None)
+                pq, pk = ws[o_pq:o_pq + n_p], ws[o_pk:o_pk + n_p]
+            else:
+                pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
+                pk = torch.empty_like(pq)
+                pooled = (None, pq, pk)
+            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, H, W, r, pq, pk)
+            xl = x2 if x2.dtype == cdtype else (xc if want else None)
+            qkv5 = y.view(B, N, 3, heads, d)
+            outs = lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, list(params), pooled=pooled)
+        else:
+            y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
+            xl = x2 if x2.dtype == cdtype else (xc if want else None)
+            qkv5 = y.view(B, N, 3, heads, C // heads)
+            outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
         o2 = outs[0].reshape(-1, C)
         y2 = _ea_op("linear_w32", linear_w32_impl, o2, wp, bp32, elem, False, False, False)[0]
         ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)

@@ -241,6 +241,11 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         # (the token count also lives on the host, under its own key of the incremental state -- reading `pos` back would
         #  synchronise every step, and reorder_incremental_state only touches the tensors of the buffer)
         t0 = int(self.get_incremental_state(incremental_state, "attn_pos") or 0)
+        if (t0 + T_new - 1) // r > 64:
+            # checked BEFORE the cache is touched: the window kernel takes at most 64 landmark rows (ea_window.h), and every
+            # completed chunk is one.  Per-token cost is O(w (w + e + L)): the training kernel re-runs over the suffix.
+            raise NotImplementedError("incremental decoding beyond 64 completed chunks (%d tokens at chunk size %d): the "
+                                      "window kernel holds at most 64 landmark rows" % (65 * r, r))
         if state["qkv"].shape[0] != B:
             raise RuntimeError("incremental state holds batch %d, the step has %d" % (state["qkv"].shape[0], B))
         need = ((t0 + T_new + w - 1) // w) * w

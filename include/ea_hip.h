@@ -492,6 +492,17 @@ int ea_linear(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_feat
 int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* a, int32_t a_f32,
                   int64_t lda, const float* w, int32_t w_transposed, const float* bias, void* y, int32_t y_f32, int64_t ldy,
                   void* a_cast, void* stream);
+/* `qkv = self.qkv(x)` of a 192-wide, three-head model (abstract_attention.py:72-78) TOGETHER WITH the pooled q / k rows the
+ * 2-D landmark generators start from (LinearRA: adaptive average pooling, lara.py:43,48,145-151; EVA: the chunk means of
+ * eva.py:178-181 with 2-D chunks and no window extension): a [B*gh*gw, 192] tokens of B images, row-major gh x gw grids;
+ * pooled_q / pooled_k: fp32 [B*3, (gh/r)*(gw/r), 64], the means of the ROUNDED q / k rows over the r x r cells -- exactly what
+ * ea_eva_chunk_mean_fwd computes from the stored rows, without re-reading them (the kernel walks the tokens cell by cell and
+ * sums the cell's rows while they are still in registers).  r = 2 or 4, in = 192, out = 576
+ * (ea_linear_pool_supported != 0), EA_E_UNSUPPORTED otherwise; the other arguments as for ea_linear_w32. */
+int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int32_t B, int32_t gh, int32_t gw, int32_t r);
+int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t r, int32_t in_features, int32_t out_features,
+                       const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
+                       void* a_cast, float* pooled_q, float* pooled_k, void* stream);
 
 /* ---- composite per-module entry points: the whole LARA core in one call each way (round 3) --------------------
  * lara.py:129-175,187-246 for the 2-D pooled proposals ('pool', 'pool-mixed'): uniform r x r pooling of q, k -> landmark
@@ -500,7 +511,9 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
  * C++ on caller-owned workspaces, so that an eagerly stepping caller (vit/engine.py:47-64) pays two FFI calls per layer
  * step instead of ~15 (and two allocations instead of ~30).  C = L (x 2 with antithetic / multi-sample noise) <= 64.
  *   ea_lara_layer_ws(cfg, which): floats of workspace 0 = `saved` (forward -> backward), 1 = forward scratch, 2 = backward
- *       scratch (negative: EA_E_*).
+ *       scratch; 3 / 4 = offsets (floats) of the pooled q / k rows [B*H, L, D] inside `saved` (negative: EA_E_*).
+ *   keep_for_backward: bit 0 = keep the intermediates the backward needs; bit 1 (EA_LARA_POOLED_READY) = the pooled q / k
+ *       rows are already in `saved` at those offsets (written by ea_linear_w32_pool): the pooling pass is skipped.
  *   params: NULL or 8 pointers (Wq, bq, gamma_q, beta_q, Wk, bk, gamma_k, beta_k: q_bar_gen / k_bar_gen, lara.py:45-54);
  *   noise: [B*H, C, D] standard normal or NULL (eval); dparams: [2*D*D + 6*D] fp32 = dW_q, dW_k, then (db, dgamma, dbeta)
  *   of q and of k, summed over the batch and heads. */
@@ -512,6 +525,7 @@ typedef struct {
   int32_t has_mlp, mixed, mis, dup;   /* as in ea_lmk_geom */
   float   kappa, scale;      /* alpha_coeff (lara.py:231), D^-0.5 */
 } ea_lara_layer;
+#define EA_LARA_POOLED_READY 2
 int64_t ea_lara_layer_ws(const ea_lara_layer* cfg, int32_t which);
 int ea_lara_layer_fwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                       const float* noise, const float* const* params, const ea_t4* out, float* saved, float* tmp,

@@ -217,6 +217,50 @@ def test_linear_w32_equals_cast_weight(rows, K, NO, a_f32, y_f32, transposed, dt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,r", [(128, 28, 28, 4), (3, 28, 28, 4), (5, 14, 14, 2), (128, 14, 14, 2), (2, 8, 12, 4), (1, 4, 4, 4)])
+@pytest.mark.parametrize("a_f32", [1, 0])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_linear_pool_equals_projection_plus_chunk_mean(B, H, W, r, a_f32, dtype):
+    """ea_linear_w32_pool (round 4): the 192 -> 576 projection that walks the tokens cell by cell and emits the r x r
+    pooled q / k rows from its epilogue.  qkv and the rounded copy of x: BIT-identical to ea_linear_w32; pooled rows: the
+    means ea_eva_chunk_mean_fwd computes from the stored rows (same rounded values, another summation order)."""
+    import ctypes
+    import torch
+    from efficient_attention import _ops
+    from efficient_attention import _native as nv
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + r + a_f32)
+    rows, h, d = B * H * W, 3, 64
+    x = torch.randn(rows, 192, device="cuda", generator=g)
+    x = x if a_f32 else x.to(td)
+    w32 = torch.randn(576, 192, device="cuda", generator=g) * 192 ** -0.5
+    b = torch.randn(576, device="cuda", generator=g)
+    assert _ops.proj_pool_supported(x, w32, td, B, H, W, r, 3)
+    L = (H // r) * (W // r)
+    pq = torch.full((B * h, L, d), float("nan"), device="cuda")
+    pk = torch.full((B * h, L, d), float("nan"), device="cuda")
+    y, xc = _ops.project_qkv_pooled(x, w32, b, td, bool(a_f32), B, H, W, r, pq, pk)
+    y0, xc0 = _ops.ea_linear(x, w32, b, td, want_cast=bool(a_f32), elem_dtype=td)
+    assert torch.equal(y, y0)
+    if a_f32:
+        assert torch.equal(xc, xc0)
+    qkv5 = y0.view(B, H * W, 3, h, d)
+    q, k, _ = _ops._qkv_views(qkv5)
+    pgeom = nv.make_geom(B, h, H * W, d, nv.io_dtype(qkv5), True, (H, W), r, 0, r, L)
+    pq0 = torch.empty_like(pq)
+    pk0 = torch.empty_like(pk)
+    tq, tk = nv.t4(q), nv.t4(k)
+    nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None, nv.ptr(pq0), nv.ptr(pk0),
+            nv.stream())
+    assert torch.isfinite(pq).all() and torch.isfinite(pk).all()
+    # and against plain torch on the rounded rows
+    ref = y0.float().view(B, H // r, r, W // r, r, 3, h, d).mean((2, 4)).permute(3, 0, 4, 1, 2, 5).reshape(3, B * h, L, d)
+    for got, other, t in ((pq, pq0, ref[0]), (pk, pk0, ref[1])):
+        assert (got - other).abs().max() <= 1e-5 * max(1.0, float(other.abs().max()))
+        assert (got - t).abs().max() <= 1e-5 * max(1.0, float(t.abs().max()))
+
+
+@pytest.mark.gpu
 def test_linear_fn_master_weight_path_and_frozen_weight():
     """LinearFn under autocast with fp32 parameters: forward and the output projection's input gradient run from the
     master weight (no cast / transpose kernels), results bit-identical to the cast-weight path; a frozen weight with a
