@@ -91,8 +91,73 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       }
   }
   const int slab_s = st_c >> 3, ch_s = st_c & 7;
-  int buf = 0;
-  for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
+  // ---- pooling epilogue (POOL > 0), all of it on the matrix pipe -- a first version that summed the rounded outputs
+  // across the lanes of a cell (12 values x 4 DPP adds x 2 tiles per wave and tile) cost 9 us of VALU time at cfg3:
+  //   (1) xbar[cell][ch] = mean over the cell's tokens of the staged (rounded) x rows: ONE MFMA per wave and tile --
+  //       A = the tile's rows read transposed (channel tile 16 (wave & 3) of slab wave >> 2), B = a 0 / 1 pattern that
+  //       assigns token slots to cells -- split into a high and a low 16-bit part (exact to 2^-17) and parked in LDS;
+  //   (2) one tile later (after that tile's barrier) the q / k waves form  W xbar + b  for the parked cells with their
+  //       resident weight rows: pooled rows = the cell means of the UNROUNDED product (the stored q / k rows differ from it
+  //       by their final rounding, which averages out over the cell).
+  constexpr int NC = POOL ? RS_TOK / POOL : 1;                          // cells per tile
+  constexpr int XB = 8 * RS_K * 2;                                      // one [8 cells][192] 16-bit image
+  __shared__ __attribute__((aligned(16))) char xbar[POOL ? 2 : 1][POOL ? 2 * XB : 16];
+  const int pc0 = 48 * wave;
+  auto pool_x = [&](int b_) {
+    const int slab = wave >> 2, dt = wave & 3;
+    const char* tb = tile[b_] + slab * (RS_TOK * 128);
+    const int r_ = 4 * g + (li >> 2);
+    const int off = lds_off2<64>(r_, 2 * dt + ((li & 3) >> 1)) + 8 * (li & 1);
+    const typename E::x8 a = as_x8<E>(E::tr4(tb + off), E::tr4(tb + 16 * 128 + off));
+    // (the pattern is rebuilt per tile -- two compares -- instead of living in four registers: the kernel sits at its
+    //  register limit, 168 of 170 at three waves per SIMD)
+    const uint32_t one = (uint32_t)E::from_f(1.f) * 0x00010001u;
+    const uint32_t lo_on = (POOL == 16 ? li == 0 : li == g) ? one : 0u, hi_on = (POOL == 16 ? li == 1 : li == 4 + g) ? one : 0u;
+    const typename E::x8 pat = as_x8<E>(u32x4{lo_on, lo_on, hi_on, hi_on});
+    const f32x4 d = E::mma(a, pat, f32x4{0.f, 0.f, 0.f, 0.f});
+    // lane (g, li = cell): channels 64 slab + 16 dt + 4 g + r of that cell
+    float hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = d[r] * (1.f / (POOL ? POOL : 1));
+      hi[r] = E::to_f(E::from_f(v));
+      lo[r] = v - hi[r];
+    }
+    if (li < NC) {
+      char* dst = xbar[b_] + li * (RS_K * 2) + (64 * slab + 16 * dt + 4 * g) * 2;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<E>(hi[0], hi[1]), pack2<E>(hi[2], hi[3])};
+      *reinterpret_cast<u32x2*>(dst + XB) = u32x2{pack2<E>(lo[0], lo[1]), pack2<E>(lo[2], lo[3])};
+    }
+  };
+  auto pool_out = [&](int tp, int b_) {
+    if (wave >= 8) return;                                              // v columns: nothing to pool
+    f32x4 pa[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const char* xb = xbar[b_] + min(li, NC - 1) * (RS_K * 2);
+#pragma unroll
+    for (int ks = 0; ks < RS_KT; ++ks) {
+      const typename E::x8 bh = as_x8<E>(lds16(xb + (4 * ks + g) * 16));
+      const typename E::x8 bl = as_x8<E>(lds16(xb + XB + (4 * ks + g) * 16));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        pa[j] = E::mma(wr[j][ks], bh, pa[j]);
+        pa[j] = E::mma(wr[j][ks], bl, pa[j]);
+      }
+    }
+    const int cell = tp * NC + li;
+    if (li < NC && cell < p.ncell) {
+      const int img = (int)__umulhi((unsigned)cell, p.m_Lc), cl = cell - img * p.Lc;
+      // columns pc0 + 8 g .. + 7 and pc0 + 32 + 4 g .. + 3; a 4-column piece never straddles a head (64 | 192)
+      const int cols[3] = {pc0 + 8 * g, pc0 + 8 * g + 4, pc0 + 32 + 4 * g};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int side = cols[j] >= RS_K, hc = cols[j] - side * RS_K, head = hc >> 6, ch = hc & 63;
+        float* dst = (side ? p.pk : p.pq) + ((size_t)(img * 3 + head) * p.Lc + cl) * 64 + ch;
+        *reinterpret_cast<f32x4*>(dst) = pa[j] + *reinterpret_cast<const f32x4*>(bias_s + cols[j]);
+      }
+    }
+  };
+  int buf = 0, tprev = -1;
+  for (; t < p.ntiles; tprev = t, t += gridDim.x, buf ^= 1) {
     // ---- commit this tile's slot: round, park in LDS, write the rounded copy ----
     {
       u32x4 w8;
@@ -111,6 +176,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     }
     if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x);
     __syncthreads();
+#ifndef EA_RS_NOPOOLMATH
+    if constexpr (POOL > 0) pool_x(buf);
+#endif
     // ---- [48 x 32] piece of this wave ----
     f32x4 acc[3][2];
 #pragma unroll
@@ -142,28 +210,6 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       o[2] = pack2<E>(v1[0], v1[1]); o[3] = pack2<E>(v1[2], v1[3]);
       stg16(yp + 16 * g, o);
       third[rt] = u32x2{pack2<E>(v2[0], v2[1]), pack2<E>(v2[2], v2[3])};
-      if constexpr (POOL > 0) {
-        // q / k columns (waves 0 .. 7): cell sums of the values just rounded, over the POOL lanes of the cell (DPP adds)
-        if (wave < 8) {
-          float f[12];
-          unpack2<E>(o[0], f[0], f[1]); unpack2<E>(o[1], f[2], f[3]); unpack2<E>(o[2], f[4], f[5]); unpack2<E>(o[3], f[6], f[7]);
-          unpack2<E>(third[rt][0], f[8], f[9]); unpack2<E>(third[rt][1], f[10], f[11]);
-#pragma unroll
-          for (int i = 0; i < 12; ++i) f[i] = group_sum<POOL>(f[i]) * (1.f / POOL);
-          if ((li & (POOL - 1)) == 0 && t * (RS_TOK / POOL) + (16 * rt + li) / POOL < p.ncell) {
-            int img, cl;
-            cell_of(t, 16 * rt + li, img, cl);
-            // columns c0 + 8 g .. + 7 and c0 + 32 + 4 g .. + 3; a 4-column piece never straddles a head (64 | 192)
-            const int cols[3] = {c0 + 8 * g, c0 + 8 * g + 4, c0 + 32 + 4 * g};
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const int side = cols[j] >= RS_K, hc = cols[j] - side * RS_K, head = hc >> 6, ch = hc & 63;
-              float* dst = (side ? p.pk : p.pq) + ((size_t)(img * 3 + head) * p.Lc + cl) * 64 + ch;
-              *reinterpret_cast<f32x4*>(dst) = f32x4{f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]};
-            }
-          }
-        }
-      }
     }
     // third tile: lane-row g holds columns c0 + 32 + 4 g .. + 3 of tokens li (rt 0) and 16 + li (rt 1).  Lane-rows 2 m and
     // 2 m + 1 trade pieces (even row's rt-1 piece <-> odd row's rt-0 piece, one v_permlane16_swap per register) so that row
@@ -175,6 +221,19 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       const int tok = tok_of(t, 16 * (g & 1) + li);
       const u32x4 o = {third[0][0], third[0][1], third[1][0], third[1][1]};
       stg16(p.y + ((size_t)tok * p.ldy + c0 + 32 + 8 * (g >> 1)) * 2, o);
+    }
+    // pooled rows of the PREVIOUS tile (parked one barrier ago; its image is overwritten after the next barrier), once the
+    // accumulators of this tile are dead
+#ifndef EA_RS_NOPOOLMATH
+    if constexpr (POOL > 0) {
+      if (tprev >= 0) pool_out(tprev, buf ^ 1);
+    }
+#endif
+  }
+  if constexpr (POOL > 0) {
+    if (tprev >= 0) {                                                  // the last tile's cells
+      __syncthreads();
+      pool_out(tprev, buf ^ 1);
     }
   }
 }

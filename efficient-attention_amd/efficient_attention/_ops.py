@@ -363,7 +363,7 @@ def _eva_cfg(qkv5, icfg, fcfg, adaptive_proj):
     return geom, L, mu_scale, keep_scale, fused_mu
 
 
-def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, mlp_params):
+def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, mlp_params, pooled=None):
     """torch.ops.ea.eva_fwd: chunk means -> mu MLP -> omega -> beta -> window attention with control-variate
     columns (eva.py:145-227).  icfg = [attn_2d, s0, s1, window, ext, chunk, L, causal(, keep_for_backward = 1)],
     fcfg = [mu_scale, keep_scale].  -> [out, bias_padded, lse, qmean, kmean, omega, beta, rf_k_bar, noise, lmk_saved, zhat, rstd]
@@ -375,10 +375,14 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
     dev = qkv5.device
     q, k, v = _qkv_views(qkv5)
     tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
-    qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
-    kmean = torch.empty_like(qmean)
-    nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
-            nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
+    if pooled is not None:
+        # (direct calls only) the chunk means came out of the projection kernel (ea_linear_w32_pool, LinearPoolFn)
+        qmean, kmean = pooled[0].view(B, h, L, d), pooled[1].view(B, h, L, d)
+    else:
+        qmean = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
+        kmean = torch.empty_like(qmean)
+        nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
+                nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
     ps = [p.detach().float().contiguous() for p in mlp_params]
     noise_c = saved = zhat = rstd = None
     if fused_mu:
@@ -511,7 +515,11 @@ class EvaAttnFn(torch.autograd.Function):
         keep, keep_scale = cfg[9:11] if len(cfg) > 9 else (None, 1.0)
         icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), int(causal), int(any(ctx.needs_input_grad))]
         fcfg = [float(mu_scale), float(keep_scale)]
-        outs = _ea_op("eva_fwd", eva_fwd_impl, qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
+        pooled = cfg[-1][1:] if (isinstance(cfg[-1], tuple) and cfg[-1][:1] == ("pooled",)) else None
+        if pooled is not None:
+            outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params), pooled=pooled)
+        else:
+            outs = _ea_op("eva_fwd", eva_fwd_impl, qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
         ctx.save_for_backward(qkv5, mask_u8, keep, noise, *outs, *mlp_params)
         ctx.nsaved = len(outs) - 1
         ctx.cfg = (icfg, fcfg, adaptive_proj, 0 if bias is None else bias.shape[-1])
@@ -1911,6 +1919,47 @@ def linear(x, layer):
     if not x.is_cuda:
         return layer(x)
     return linear_wb(x, layer.weight, layer.bias)
+
+
+class LinearPoolFn(torch.autograd.Function):
+    """LinearFn for the qkv projection of a 192-wide three-head model on a 2-D token grid that ALSO returns the r x r pooled
+    q / k rows (ea_linear_w32_pool; round 4): -> (qkv [B, N, 576], pooled_q, pooled_k [B*3, L, 64] fp32).  The pooled rows are
+    non-differentiable hints for the attention core that consumes qkv: the core computes them itself otherwise
+    (ea_eva_chunk_mean_fwd) and differentiates through the pooling in its own backward, so the gradient of this node is
+    LinearFn's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype, grid):
+        B, H, W, r = grid
+        x2 = x.reshape(-1, x.shape[-1])
+        b32 = None if bias is None else (bias if bias.dtype == torch.float32 else bias.float())
+        want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+        L = (H // r) * (W // r)
+        pq = torch.empty((B * 3, L, 64), dtype=torch.float32, device=x.device)
+        pk = torch.empty_like(pq)
+        y, xc = project_qkv_pooled(x2, weight, b32, dtype, want, B, H, W, r, pq, pk)
+        xl = x2 if x2.dtype == dtype else (xc if want else None)
+        ctx.save_for_backward(xl, weight)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, dtype)
+        ctx.mark_non_differentiable(pq, pk)
+        return y.view(x.shape[:-1] + (weight.shape[0],)), pq, pk
+
+    @staticmethod
+    def backward(ctx, dy, _dpq, _dpk):
+        return LinearFn.backward(ctx, dy) + (None,)
+
+
+def linear_pool_usable(x, layer, grid, heads):
+    """LinearPoolFn applies: autocast in a 16-bit dtype, fp32 master weight, the geometry ea_linear_w32_pool covers, and
+    nobody tracing (the pooled rows travel outside the dispatcher ops)."""
+    if not (x.is_cuda and torch.is_autocast_enabled() and _DIRECT and not torch.compiler.is_compiling()
+            and torch._C._len_torch_dispatch_stack() == 0):
+        return False
+    dtype = torch.get_autocast_dtype("cuda")
+    B, H, W, r = grid
+    x2 = x.reshape(-1, x.shape[-1])
+    return (dtype in _ELEM and x2.dtype in (torch.float32, dtype) and layer.weight.is_contiguous()
+            and _lin_rows_ok(x2, dtype) and proj_pool_supported(x2, layer.weight, dtype, B, H, W, r, heads))
 
 
 def linear_wb(x, weight, bias):

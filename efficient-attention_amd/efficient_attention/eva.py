@@ -150,20 +150,30 @@ class EVA(LocalAttention):
         x, key_padding_mask, seq_shape = self._process_input(x, key_padding_mask)
         N = int(math.prod(seq_shape))
         w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
-        qkv5 = self.project_qkv(x.reshape(B, N, C))
-
+        pooled = None
         if self.attn_2d:
             r = int(math.sqrt(N // self.num_landmarks))
             L = (seq_shape[0] // r) * (seq_shape[1] // r)
             if e == 0:
                 assert seq_shape[0] % r == 0 and seq_shape[1] % r == 0
             Wq, Wk = w * w, (w + 2 * e) ** 2
+            grid = (B, seq_shape[0], seq_shape[1], r)
+            if e == 0 and key_padding_mask is None and _ops.linear_pool_usable(x, self.qkv, grid, h):
+                # the chunk means of q, k (eva.py:178-181 on 2-D chunks without extension) leave the projection kernel
+                # with qkv: no second pass over q, k (round 4)
+                y, pq, pk = _ops.LinearPoolFn.apply(x.reshape(B, N, C), self.qkv.weight, self.qkv.bias,
+                                                    torch.get_autocast_dtype("cuda"), grid)
+                qkv5 = y.reshape(B, N, 3, h, d)
+                pooled = ("pooled", pq, pk)
         else:
             r = int(N // self.num_landmarks)
             L = N // r
             if e == 0:
                 assert N % r == 0
             Wq, Wk = w, w + 2 * e
+
+        if pooled is None:
+            qkv5 = self.project_qkv(x.reshape(B, N, C))
 
         if self.use_t5_rpe:
             bias = self.rel_pos_bias.dense(Wq, Wk, x.device)
@@ -174,6 +184,8 @@ class EVA(LocalAttention):
             noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
         mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
         cfg = (self.attn_2d, tuple(seq_shape), w, e, r, L, self.adaptive_proj)
+        if pooled is not None:
+            cfg = cfg + (0, 0.5, None, 1.0, pooled)
         out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask, cfg, *self._mu_params())
         y = self.merge_and_project(out, B, seq_shape, C, x.dtype)
         if not self.attn_2d:
