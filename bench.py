@@ -641,6 +641,9 @@ def main():
                                                         ", data-parallel flat-bucket all-reduce" if ddp else ""),
                        "attn": a.attn, "global_batch": B * world, "seq_len": N, "heads": H, "head_dim": d,
                        "parallelism": "dp%d" % world, "hipgraph": graphed, "ddp_schedule": ddp_scheme,
+                       # one flat fp32 bucket of every parameter gradient per step (efficient_attention.data_parallel); a
+                       # ring all-reduce moves 2 (N - 1) / N of it over each GPU's links
+                       "allreduce_bytes_per_step": (sum(prm.numel() for prm in params) * 4) if ddp else None,
                        "gemm_tunableop": tune},
             "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H * d / 64),
             # whole layer priced on the op-level q,k,v -> out traffic (1536*h bytes per token at d = 64)
@@ -672,8 +675,16 @@ def main_model(a):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group(os.environ.get("EA_BENCH_BACKEND", "nccl"))
+    # EA_BENCH_FORCE_DDP=1 (dev / tests): the N > 1 leg -- RCCL process group, DistributedDataParallel with 25 MB buckets,
+    # all-reduce overlapped with backward -- on a single rank, so that it executes on a 1-GPU box
+    ddp = world > 1 or bool(os.environ.get("EA_BENCH_FORCE_DDP"))
+    if ddp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            dist.init_process_group(os.environ.get("EA_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
+        else:
+            dist.init_process_group(os.environ.get("EA_BENCH_BACKEND", "nccl"))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         wl = trainer.build_workload(a.workload, dev, batch=None if a.batch == 128 else a.batch, seed=1234 + rank)
@@ -682,8 +693,17 @@ def main_model(a):
         tunable.enable(True)
         tunable.set_filename(a.gemm_tune_file or os.path.join(tempfile.gettempdir(), "ea_bench_tunableop_%d.csv" % os.getpid()))
         tunable.tuning_enable(not (a.gemm_tune_file and os.path.exists(a.gemm_tune_file)))
-    ddp_model = trainer.wrap_ddp(wl.model, dev) if world > 1 else None
+    ddp_model = trainer.wrap_ddp(wl.model, dev) if ddp else None
     step = trainer.make_step(wl, ddp_model=ddp_model)
+    # what one step puts on the links: every parameter gradient once, fp32, in buckets of <= 25 MB issued as the backward
+    # reaches them (ring all-reduce moves 2 (N - 1) / N of that per GPU)
+    grad_bytes = sum(p.numel() * 4 for p in wl.model.parameters() if p.requires_grad)
+    ddp_info = None
+    if ddp:
+        ddp_info = {"schedule": "DistributedDataParallel: bucketed all-reduce overlapped with backward, gradients as bucket views",
+                    "bucket_cap_mb": 25, "allreduce_bytes_per_step": grad_bytes,
+                    "buckets_per_step": max(1, -(-grad_bytes // (25 << 20))),
+                    "ring_bytes_on_links_per_gpu": int(2 * (world - 1) / world * grad_bytes), "backend": dist.get_backend()}
     for _ in range(max(a.warmup, 2)):
         step()
     torch.cuda.synchronize()
@@ -711,7 +731,7 @@ def main_model(a):
         step()
     eager_el = timed(step, a.steps)
     graph_ms = None
-    if not a.no_graph and world == 1:
+    if not a.no_graph and not ddp:
         try:
             replay = trainer.capture_step(step)
             for _ in range(3):
@@ -736,14 +756,15 @@ def main_model(a):
             "graph_ms_per_step": graph_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s: %s; whole-model training step (fwd + loss + bwd + SGD momentum), eager, bf16 "
-                                   "autocast%s" % (a.workload, wl.desc, ", DistributedDataParallel" if world > 1 else ""),
+                                   "autocast%s" % (a.workload, wl.desc, ", DistributedDataParallel" if ddp else ""),
                        "tokens_per_step_per_gpu": wl.tokens, "parallelism": "dp%d" % world, "hipgraph": False,
+                       "ddp_schedule": ddp_info,
                        "params_M": round(sum(p.numel() for p in wl.model.parameters()) / 1e6, 2)},
             "attention_core_ms_per_step": round(hip_ms, 4),
             "attention_kernels_avg_us": {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()},
             "roofline": None, "cpu_baseline": None,
         }
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
     if rank == 0:
         _emit(line)

@@ -21,3 +21,21 @@ def test_bench_collective_leg_runs_on_a_single_rank_rccl_group():
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["config"]["ddp_schedule"] in ("pipelined", "three_part")       # the N > 1 path ran and picked a schedule
     assert "all-reduce" in line["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_whole_model_ddp_leg_runs_on_a_single_rank_rccl_group():
+    """the 25 MB-bucket DistributedDataParallel path of ea_harness.trainer.wrap_ddp (whole-model
+    workloads, BASELINE.json configs 3-5 are "DDP 8 x MI355X") over RCCL -- a single-rank group is what a 1-GPU box can
+    run; the line carries the schedule and the all-reduce bytes of a step."""
+    env = dict(os.environ, EA_BENCH_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "model_cfg3", "--batch", "8", "--steps", "3",
+                        "--warmup", "2", "--no-gemm-tune"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    info = line["config"]["ddp_schedule"]
+    assert info["backend"] == "nccl" and info["bucket_cap_mb"] == 25
+    assert info["allreduce_bytes_per_step"] == int(line["config"]["params_M"] * 1e6 * 4) or \
+        abs(info["allreduce_bytes_per_step"] - line["config"]["params_M"] * 4e6) < 4e4
+    assert "DistributedDataParallel" in line["config"]["workload"]
