@@ -36,6 +36,8 @@ int wgrad_slices(int rows, int M, int K);
 int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
                    int K, hipStream_t st);
 int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipStream_t st);
+int multi_sum_dispatch(int K, const float* const* part, const int* S, const int* n, const long long* ld, float* const* out,
+                       hipStream_t st);
 }
 
 using namespace ea;
@@ -887,6 +889,12 @@ int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out
   return part_sum_dispatch(parts, out, S, n, (long)ld, (hipStream_t)stream);
 }
 
+int ea_multi_sum(int32_t K, const float* const* parts, const int32_t* S, const int32_t* n, const int64_t* ld, float* const* out,
+                 void* stream) {
+  if (!parts || !S || !n || !ld || !out) return EA_E_BADARG;
+  return multi_sum_dispatch(K, parts, S, n, (const long long*)ld, out, (hipStream_t)stream);
+}
+
 }  // extern "C"
 
 // ---- LARA sampling + proposal densities beyond the fused landmark kernels (ea_lara_segment.hip) ----
@@ -1188,6 +1196,8 @@ int64_t ea_lara_layer_ws(const ea_lara_layer* c, int32_t which) {
     case 2: return (int64_t)P.n_btmp;
     case 3: return (int64_t)P.o_pq;
     case 4: return (int64_t)P.o_pk;
+    case 5: return (int64_t)P.b_dW;
+    case 6: return (int64_t)P.b_dvec;
     default: return EA_E_BADARG;
   }
 }
@@ -1231,7 +1241,7 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
   LaraLayerPlan P;
   int rc = lara_layer_plan(c, P);
   if (rc != EA_OK) return rc;
-  if (!saved || !tmp || (c->has_mlp && (!params || !dparams))) return EA_E_BADARG;
+  if (!saved || !tmp || (c->has_mlp && !params)) return EA_E_BADARG;
   const float* pr[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (c->has_mlp) for (int i = 0; i < 8; ++i) pr[i] = params[i];
   const bool opt = c->mis == EA_MIS_OPT;
@@ -1269,7 +1279,9 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
   if (rc != EA_OK) return rc;
   rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
   if (rc != EA_OK) return rc;
-  if (c->has_mlp) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
+  // dparams == NULL: the caller adds the per-(b,h) partials up itself (tmp + ea_lara_layer_ws(cfg, 5 / 6): [B*H, 2 D D] and
+  // [B*H, 6 D]), e.g. together with other terminal sums of its backward in one ea_multi_sum launch
+  if (c->has_mlp && dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
   return rc;
 }
 

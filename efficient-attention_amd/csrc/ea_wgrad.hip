@@ -224,6 +224,63 @@ __global__ __launch_bounds__(256) void part_sum_kernel(const float* __restrict__
   }
 }
 
+// Several such reductions in ONE launch (round 4): the terminal sums of a layer's backward -- the slice partials of both
+// projections' weight gradients and the per-(b,h) partials of the landmark parameters -- each cost a 6-10 us launch of their
+// own.  Segment k: out_k[j] = sum_s part_k[s * ld_k + j]; blocks [blk0_k, blk0_{k+1}) work on it, same order of additions
+// as part_sum_kernel.
+struct MultiSumP {
+  const float* part[4];
+  float* out[4];
+  int S[4], n4[4], blk0[5];
+  long ld4[4];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void multi_sum_kernel(const MultiSumP p) {
+  __shared__ f32x4 red[8][32];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) k += (i < p.nseg && (int)blockIdx.x >= p.blk0[i]) ? 1 : 0;
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int j = ((int)blockIdx.x - p.blk0[k]) * 32 + c;
+  const int S = p.S[k], n4 = p.n4[k];
+  const long ld4 = p.ld4[k];
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.part[k]) + min(j, n4 - 1);
+  f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = sl;
+  for (; s + 24 < S; s += 32) {
+    const f32x4 v0 = src[(size_t)s * ld4], v1 = src[(size_t)(s + 8) * ld4];
+    const f32x4 v2 = src[(size_t)(s + 16) * ld4], v3 = src[(size_t)(s + 24) * ld4];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; s < S; s += 8) a0 += src[(size_t)s * ld4];
+  red[sl][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && j < n4) {
+    f32x4 t = red[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][c];
+    reinterpret_cast<f32x4*>(p.out[k])[j] = t;
+  }
+}
+
+int multi_sum_dispatch(int K, const float* const* part, const int* S, const int* n, const long long* ld, float* const* out,
+                       hipStream_t st) {
+  if (K <= 0 || K > 4) return EA_E_BADARG;
+  MultiSumP p = {};
+  int blk = 0;
+  for (int k = 0; k < K; ++k) {
+    if (!part[k] || !out[k] || S[k] <= 0 || n[k] <= 0 || (n[k] & 3) || (ld[k] & 3) || ld[k] < n[k] ||
+        ((uintptr_t)part[k] & 15) || ((uintptr_t)out[k] & 15)) return EA_E_BADARG;
+    p.part[k] = part[k]; p.out[k] = out[k]; p.S[k] = S[k]; p.n4[k] = n[k] / 4; p.ld4[k] = (long)(ld[k] / 4);
+    p.blk0[k] = blk;
+    blk += (p.n4[k] + 31) / 32;
+  }
+  p.blk0[K] = blk;
+  p.nseg = K;
+  hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)blk), dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+
 int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipStream_t st) {
   if (S <= 0 || n <= 0 || (n & 3) || (ld & 3) || ld < n) return EA_E_BADARG;
   const int n4 = n / 4;

@@ -127,6 +127,7 @@ SIGNATURES = {
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_part_sum": [_I, _I, _L, _P, _P, _P],
+    "ea_multi_sum": [_I, _P, _P, _P, _P, _P, _P],
     "ea_lara_layer_ws": [_LL, _I],
     "ea_lara_layer_fwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _P, _P, _I, _P],
     "ea_lara_layer_bwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _P, _P, _P, _P],

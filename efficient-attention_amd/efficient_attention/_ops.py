@@ -233,8 +233,9 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
     dev = qkv5.device
     dlk_p = dlv_p = dbias_p = None
     if L > 0:
-        dlk_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
-        dlv_p = torch.empty((parts, B * h, L, d), dtype=torch.float32, device=dev)
+        # both landmark-gradient partial sets in one buffer [2, parts, B*h*L*d]: ONE slice reduction below
+        dl_p = torch.empty((2, parts, B * h, L, d), dtype=torch.float32, device=dev)
+        dlk_p, dlv_p = dl_p[0], dl_p[1]
     if bias_p is not None:
         # several query blocks per window: each launch writes only its block's rows
         alloc = torch.zeros if nv.query("ea_window_bwd_query_blocks", geom) > 1 else torch.empty
@@ -259,11 +260,10 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
     dlk = dlv = dbias = None
     if L > 0:
         # per-workgroup partials [parts, B*h*L*d] -> one pass each (fixed summation order)
-        dlk = torch.empty((B, h, L, d), dtype=torch.float32, device=dev)
-        dlv = torch.empty_like(dlk)
+        dl = torch.empty((2, B, h, L, d), dtype=torch.float32, device=dev)
         n = B * h * L * d
-        nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlk_p), nv.ptr(dlk), nv.stream())
-        nv.call("ea_slice_sum", 1, parts, n, 1.0, None, nv.ptr(dlv_p), nv.ptr(dlv), nv.stream())
+        nv.call("ea_slice_sum", 2, parts, n, 1.0, None, nv.ptr(dl_p), nv.ptr(dl), nv.stream())
+        dlk, dlv = dl[0], dl[1]
     if bias_p is not None:
         dbias = colsum_f32(dbias_p.view(dbias_p.shape[0] * B, -1)).view(bias_p.shape)
     return dlk, dlv, dbias
@@ -957,7 +957,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params, pooled=None):
     return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(saved, e), _e(tokst, e)]
 
 
-def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
+def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, defer_param_sums=False):
     """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)].  saved_list is what lara_fwd
     returned after `out`: the composite workspace (one tensor -> ea_lara_layer_bwd) or the step-by-step tensors."""
     if len(saved_list) == 1:
@@ -976,11 +976,18 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
         noise_c = None if noise is None else noise.float().contiguous()
         ps = [t.detach().float().contiguous() for t in params]
         pp = _param_ptrs(ps) if ps else None
-        dpar = torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev) if ps else None
+        defer = bool(defer_param_sums and ps)
+        dpar = torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev) if (ps and not defer) else None
         nv.call("ea_lara_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
                 nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
                 ctypes.byref(ts[6]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dpar), nv.stream())
         grads = [dqkv5]
+        if defer:
+            # (direct calls only) the per-(b,h) partials, still to be added up: [B*h, 2 d d], [B*h, 6 d]
+            o_dW, o_dvec = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(lcfg), w)) for w in (5, 6)]
+            BH = B * h
+            return grads + [("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
+                             tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))]
         if ps:
             dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
             grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
@@ -1007,6 +1014,8 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params):
             nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
     _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
     grads = [dqkv5]
+    if has_mlp and defer_param_sums:
+        return grads + [("partials", dW.view(BH, -1), dvec.view(BH, -1))]
     if has_mlp:
         dWs, dvs = colsum2_f32(dW.view(BH, -1), dvec.view(BH, -1))
         dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
@@ -1045,6 +1054,7 @@ class LaraPooledFn(torch.autograd.Function):
 
 
 USE_PROJ_POOL = os.environ.get("EA_PROJ_POOL", "1") == "1"
+USE_MULTI_SUM = os.environ.get("EA_MULTI_SUM", "1") == "1"
 
 
 def proj_pool_supported(x2, w32, cdtype, B, H, W, r, heads):
@@ -1139,31 +1149,67 @@ class LaraModuleFn(torch.autograd.Function):
             dy2 = dy2.to(cdtype)
         # output projection: input gradient from the master weight read transposed, weight + bias gradient in one pass
         d_o2 = _ea_op("linear_w32", linear_w32_impl, dy2, wp, None, elem, True, False, False)[0]
+        direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+        # round 4: the terminal sums of this backward -- slice partials of both weight gradients, per-(b,h) partials of the
+        # landmark parameters -- are added up by ONE launch at the end (ea_multi_sum) instead of three
+        defer = direct and USE_MULTI_SUM
+        pend = []                                                  # (what, partial tensor, meta)
         dwp = dbp = None
         need_bp = bpd is not None and need[4]
         if need[3]:
-            dwp, dbp32 = wgrad(dy2, o2, need_bp)
-            dwp = dwp.to(wpd)
-            dbp = dbp32.to(bpd) if need_bp else None
+            r_ = wgrad(dy2, o2, need_bp, defer=defer)
+            if defer:
+                pend.append(("proj", r_[0], r_[1]))
+            else:
+                dwp, dbp32 = r_
+                dwp = dwp.to(wpd)
+                dbp = dbp32.to(bpd) if need_bp else None
         elif need_bp:
             dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
-        grads = _ea_op("lara_bwd", lara_bwd_impl, d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved),
-                       ctx.icfg, ctx.fcfg, list(params))
+        if defer:
+            grads = lara_bwd_impl(d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved), ctx.icfg, ctx.fcfg,
+                                  list(params), defer_param_sums=True)
+            if grads[1:] and isinstance(grads[1], tuple):
+                pend.append(("lmk_W", grads[1][1], None))
+                pend.append(("lmk_v", grads[1][2], None))
+                grads = grads[:1]
+        else:
+            grads = _ea_op("lara_bwd", lara_bwd_impl, d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved),
+                           ctx.icfg, ctx.fcfg, list(params))
         dqkv2 = grads[0].view(-1, 3 * C)
         dwq = dbq = dx = None
         need_bq = bqd is not None and need[2]
         if need[1]:
             if xl is None:
                 raise RuntimeError("LaraModuleFn: the weight gradient was requested but the forward did not keep its input")
-            dwq, dbq32 = wgrad(dqkv2, xl, need_bq)
-            dwq = dwq.to(wqd)
-            dbq = dbq32.to(bqd) if need_bq else None
+            r_ = wgrad(dqkv2, xl, need_bq, defer=defer)
+            if defer:
+                pend.append(("qkv", r_[0], r_[1]))
+            else:
+                dwq, dbq32 = r_
+                dwq = dwq.to(wqd)
+                dbq = dbq32.to(bqd) if need_bq else None
         elif need_bq:
             # frozen qkv weight, trainable bias (bias-only fine-tuning): a column sum of d qkv, no input rows needed
             dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
             dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+        if pend:
+            sums = multi_sum([t for _, t, _ in pend])
+            res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}
+            if "proj" in res:
+                dwp, dbp32 = _wgrad_split(*res["proj"])
+                dwp = dwp.to(wpd)
+                dbp = dbp32.to(bpd) if need_bp else None
+            if "qkv" in res:
+                dwq, dbq32 = _wgrad_split(*res["qkv"])
+                dwq = dwq.to(wqd)
+                dbq = dbq32.to(bqd) if need_bq else None
+            if "lmk_W" in res:
+                d = C // heads
+                dWs, dvs = res["lmk_W"][0].view(2, d, d), res["lmk_v"][0].view(2, 3, d)
+                grads = grads + [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
         pgrads = [g.to(dt) for g, dt in zip(grads[1:], pdtypes)]
         return (dx, dwq, dbq, dwp, dbp, None, None, None, None, None) + tuple(pgrads)
 
@@ -1809,7 +1855,7 @@ USE_WGRAD = os.environ.get("EA_WGRAD", "1") == "1"
 USE_LARA_MODULE_FN = os.environ.get("EA_LARA_MODULE_FN", "1") == "1"
 
 
-def wgrad(dy2, x2, with_bias=True):
+def wgrad(dy2, x2, with_bias=True, defer=False):
     """dW [out, in] = dY^T X and db [out] = dY.sum(0), both fp32, from one pass over dY and X (ea_wgrad:
     token slices x output tiles, slice partials summed in a fixed order)."""
     dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
@@ -1827,11 +1873,29 @@ def wgrad(dy2, x2, with_bias=True):
         label = "ea_wgrad[%dx%d]" % (M, K)
         _note_bytes(label, rows * (M + K) * 2 + n * 4)
     nv.call_as(label, "ea_wgrad", nv.io_dtype(dy2), rows, M, K, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part), db_ptr, n, nv.stream())
+    if defer:
+        return part, (M, K, with_bias)            # the caller adds the slices up (multi_sum: several reductions, one launch)
     out = torch.empty(n, dtype=torch.float32, device=dy2.device)
     nv.call("ea_part_sum", S, n, n, nv.ptr(part), nv.ptr(out), nv.stream())
-    dw = out[:M * K].view(M, K)
-    db = out[M * K:] if with_bias else None
-    return dw, db
+    return _wgrad_split(out, (M, K, with_bias))
+
+
+def _wgrad_split(out, meta):
+    M, K, with_bias = meta
+    return out[:M * K].view(M, K), (out[M * K:] if with_bias else None)
+
+
+def multi_sum(parts):
+    """parts: up to four contiguous fp32 [S_k, n_k] tensors (n_k % 4 == 0) -> [sum over S_k] in ONE launch (ea_multi_sum)."""
+    K = len(parts)
+    outs = [torch.empty(p.shape[1], dtype=torch.float32, device=p.device) for p in parts]
+    P = (ctypes.c_void_p * K)(*[p.data_ptr() for p in parts])
+    O = (ctypes.c_void_p * K)(*[o.data_ptr() for o in outs])
+    S = (ctypes.c_int32 * K)(*[p.shape[0] for p in parts])
+    n = (ctypes.c_int32 * K)(*[p.shape[1] for p in parts])
+    ld = (ctypes.c_int64 * K)(*[p.stride(0) for p in parts])
+    nv.call("ea_multi_sum", K, P, S, n, ld, O, nv.stream())
+    return outs
 
 
 class LinearFn(torch.autograd.Function):

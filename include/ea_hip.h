@@ -448,6 +448,11 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
              float* dw_part, float* db_part, int64_t part_ld, void* stream);
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream);
+/* K <= 4 such reductions in one launch: out[k][j] = sum_s parts[k][s * ld[k] + j], j < n[k] (same order of additions as
+ * ea_part_sum).  The terminal sums of a layer's backward -- both projections' slice partials and the per-(b,h) partials of
+ * the landmark parameters (ea_lara_layer_bwd with dparams == NULL) -- share one launch this way. */
+int ea_multi_sum(int32_t K, const float* const* parts, const int32_t* S, const int32_t* n, const int64_t* ld, float* const* out,
+                 void* stream);
 
 /* LARA sampling + proposal densities for sample counts beyond the fused landmark kernels (C > 64: antithetic /
  * multi-sample draws at 49 landmarks; lara.py:187-238).  qbar, mu = q_bar + k_bar: fp32 [BH,L,D]; noise: [BH,L,D] (mode 1,
@@ -511,7 +516,9 @@ int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t
  * C++ on caller-owned workspaces, so that an eagerly stepping caller (vit/engine.py:47-64) pays two FFI calls per layer
  * step instead of ~15 (and two allocations instead of ~30).  C = L (x 2 with antithetic / multi-sample noise) <= 64.
  *   ea_lara_layer_ws(cfg, which): floats of workspace 0 = `saved` (forward -> backward), 1 = forward scratch, 2 = backward
- *       scratch; 3 / 4 = offsets (floats) of the pooled q / k rows [B*H, L, D] inside `saved` (negative: EA_E_*).
+ *       scratch; 3 / 4 = offsets (floats) of the pooled q / k rows [B*H, L, D] inside `saved`; 5 / 6 = offsets inside the
+ *       backward scratch of the per-(b,h) parameter-gradient partials [B*H, 2 D D] (dW_q, dW_k) and [B*H, 6 D]
+ *       (negative: EA_E_*).  ea_lara_layer_bwd with dparams == NULL leaves those partials to the caller (ea_multi_sum).
  *   keep_for_backward: bit 0 = keep the intermediates the backward needs; bit 1 (EA_LARA_POOLED_READY) = the pooled q / k
  *       rows are already in `saved` at those offsets (written by ea_linear_w32_pool): the pooling pass is skipped.
  *   params: NULL or 8 pointers (Wq, bq, gamma_q, beta_q, Wk, bk, gamma_k, beta_k: q_bar_gen / k_bar_gen, lara.py:45-54);

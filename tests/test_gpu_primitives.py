@@ -453,8 +453,9 @@ def test_lara_module_single_node_equals_three_nodes(gen, train):
     # (the single node's projection also emits the pooled q / k rows -- round 4, ea_linear_w32_pool: cell means of the
     #  UNROUNDED product instead of the stored rows; switched off here for the bit-for-bit comparison and compared on its
     #  own in test_lara_module_pooled_projection_close_to_separate_pooling)
-    old_pool = _ops.USE_PROJ_POOL
+    old_pool, old_ms = _ops.USE_PROJ_POOL, _ops.USE_MULTI_SUM
     _ops.USE_PROJ_POOL = False
+    _ops.USE_MULTI_SUM = False        # (one launch for all terminal sums: another order of additions for the landmark parameters)
     for single in (True, False):
         old = _ops.USE_LARA_MODULE_FN
         _ops.USE_LARA_MODULE_FN = single
@@ -470,13 +471,77 @@ def test_lara_module_single_node_equals_three_nodes(gen, train):
             res[single] = (node, y.detach(), x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
         finally:
             _ops.USE_LARA_MODULE_FN = old
-    _ops.USE_PROJ_POOL = old_pool
+    _ops.USE_PROJ_POOL, _ops.USE_MULTI_SUM = old_pool, old_ms
     assert res[True][0].startswith("LaraModuleFn") and not res[False][0].startswith("LaraModuleFn")
     assert torch.equal(res[True][1], res[False][1])
     assert torch.equal(res[True][2], res[False][2])
     assert res[True][3].keys() == res[False][3].keys() and len(res[True][3]) >= 4
     for n in res[True][3]:
         assert torch.equal(res[True][3][n], res[False][3][n]), n
+
+
+@pytest.mark.gpu
+def test_multi_sum_equals_fp64_sums_and_single_reductions():
+    """ea_multi_sum: up to four slice reductions in one launch -- bit-identical to ea_part_sum on each segment, and equal to
+    fp64 sums to fp32 accuracy; reproducible."""
+    import torch
+    from efficient_attention import _ops
+    from efficient_attention import _native as nv
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(12, 37056), (12, 111168), (384, 8192), (384, 384)]
+    parts = [torch.randn(S, n, device="cuda", generator=g) for S, n in shapes]
+    outs = _ops.multi_sum(parts)
+    outs2 = _ops.multi_sum(parts)
+    for p, o, o2 in zip(parts, outs, outs2):
+        assert torch.equal(o, o2)
+        ref = p.double().sum(0)
+        assert float((o.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, p.shape[0] ** 0.5 / 4)
+        single = torch.empty_like(o)
+        nv.call("ea_part_sum", p.shape[0], p.shape[1], p.shape[1], nv.ptr(p), nv.ptr(single), nv.stream())
+        assert torch.equal(o, single)
+    one = _ops.multi_sum(parts[:1])
+    assert torch.equal(one[0], outs[0])
+
+
+@pytest.mark.gpu
+def test_lara_module_deferred_sums_equal_separate_reductions():
+    """LaraModuleFn's backward with the terminal sums in one launch (EA_MULTI_SUM) against the separate reductions: the
+    projection gradients bit for bit (same order of additions), the landmark parameters to fp32 accuracy."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(15)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                                                             mis_type="mis-opt", alpha_coeff=2.0)).cuda()
+    m.train()
+    x0 = torch.randn(4, 28, 28, 192, device="cuda")
+    g = torch.randn(4, 28, 28, 192, device="cuda").bfloat16()
+    res = {}
+    for ms in (True, False):
+        old = _ops.USE_MULTI_SUM
+        _ops.USE_MULTI_SUM = ms
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+            y.backward(g)
+            res[ms] = (x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _ops.USE_MULTI_SUM = old
+    assert torch.equal(res[True][0], res[False][0])
+    assert res[True][1].keys() == res[False][1].keys()
+    for n in res[True][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        if n.startswith(("qkv.", "proj.")):
+            assert torch.equal(a, b), n
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, n
 
 
 @pytest.mark.gpu
