@@ -590,6 +590,7 @@ def test_lara_module_pooled_projection_close_to_separate_pooling(dtype, composit
     close(res[True][0], res[False][0], "y")
     close(res[True][1], res[False][1], "dx")
     assert res[True][2].keys() == res[False][2].keys()
+    tol *= 4                      # parameter gradients: sums over all tokens with cancellation (LayerNorm gains most of all)
     for n in res[True][2]:
         close(res[True][2][n], res[False][2][n], n)
 
@@ -642,6 +643,7 @@ def test_eva_pooled_projection_close_to_separate_chunk_means(dtype, grid, window
     close(res[True][0], res[False][0], "y")
     close(res[True][1], res[False][1], "dx")
     assert res[True][2].keys() == res[False][2].keys()
+    tol *= 4                      # parameter gradients: sums over all tokens with cancellation (LayerNorm gains most of all)
     for n in res[True][2]:
         close(res[True][2][n], res[False][2][n], n)
 
