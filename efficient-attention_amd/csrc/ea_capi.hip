@@ -17,6 +17,7 @@ int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, cons
 #include "ea_lara_segment.h"
 #include "ea_scatter.h"
 #include "ea_rows_mlp.h"
+#include "ea_performer_f32.h"
 namespace ea {
 int rows_mlp_dispatch(const RowsP& p, int D, int sides, int layer_norm, bool bwd, hipStream_t st);
 int rows_mlp_blocks(int R, int D);
@@ -944,6 +945,87 @@ int ea_adaptive_pool2d_bwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int3
   if (!dx || !dx->ptr || !dmean) return EA_E_BADARG;
   return pool2d_dispatch(true, dtype, dx->ptr, (long)dx->sb, (long)dx->sh, (long)dx->sn, const_cast<float*>(dmean), B, H, gh,
                          gw, side, D, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- Performer in exact fp32 arithmetic (ea_performer_f32.hip) ----
+static bool pf_t4_ok(const ea_t4* t, int dtype) {
+  const int a = dtype == EA_F32 ? 4 : 8;                  // 16-byte vector access
+  return t && t->ptr && ((uintptr_t)t->ptr % 16 == 0) && t->sb % a == 0 && t->sh % a == 0 && t->sn % a == 0 && t->sn >= 64;
+}
+static Pf32T pf_mk(const ea_t4* t) {
+  Pf32T r;
+  r.p = t ? (char*)t->ptr : nullptr;
+  r.sb = t ? t->sb : 0; r.sh = t ? t->sh : 0; r.sn = t ? t->sn : 0;
+  return r;
+}
+static int pf_fill(const ea_perf_geom* g, Pf32P& p) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->N <= 0 || g->dtype < 0 || g->dtype > EA_F32) return EA_E_BADARG;
+  if (g->D != 64 || g->M <= 0 || g->M > 96 || (g->M & 15)) return EA_E_UNSUPPORTED;
+  p.B = g->B; p.H = g->H; p.N = g->N; p.M = g->M; p.dtype = g->dtype;
+  return EA_OK;
+}
+
+extern "C" {
+
+int32_t ea_performer_f32_parts(const ea_perf_geom* g) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  return rc != EA_OK ? rc : pf32_slices(g->B * g->H, g->N);
+}
+
+int ea_performer_f32_kmax(const ea_perf_geom* g, const ea_t4* k, const float* W, float* p_max, void* stream) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pf_t4_ok(k, g->dtype) || !W || !p_max) return EA_E_BADARG;
+  p.k = pf_mk(k); p.W = W; p.p_max = p_max;
+  return pf32_dispatch(0, p, (hipStream_t)stream);
+}
+
+int ea_performer_f32_kv(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                        const float* p_max, float* p_kv, float* p_ksum, void* stream) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pf_t4_ok(k, g->dtype) || !pf_t4_ok(v, g->dtype) || !W || !p_max || !p_kv || !p_ksum) return EA_E_BADARG;
+  p.k = pf_mk(k); p.v = pf_mk(v); p.mask = mask; p.W = W; p.p_max = const_cast<float*>(p_max); p.p_kv = p_kv; p.p_ks = p_ksum;
+  return pf32_dispatch(1, p, (hipStream_t)stream);
+}
+
+int ea_performer_f32_out(const ea_perf_geom* g, const ea_t4* q, const float* W, const float* kv, const float* ksum,
+                         const ea_t4* out, void* stream) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pf_t4_ok(q, g->dtype) || !pf_t4_ok(out, g->dtype) || !W || !kv || !ksum) return EA_E_BADARG;
+  p.q = pf_mk(q); p.o = pf_mk(out); p.W = W; p.kv = kv; p.ksum = ksum;
+  return pf32_dispatch(2, p, (hipStream_t)stream);
+}
+
+int ea_performer_f32_bwd_q(const ea_perf_geom* g, const ea_t4* q, const ea_t4* dout, const float* W, const float* kv,
+                           const float* ksum, const ea_t4* dq, float* p_dkv, float* p_dksum, void* stream) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pf_t4_ok(q, g->dtype) || !pf_t4_ok(dout, g->dtype) || !pf_t4_ok(dq, g->dtype) || !W || !kv || !ksum || !p_dkv || !p_dksum)
+    return EA_E_BADARG;
+  p.q = pf_mk(q); p.dout = pf_mk(dout); p.dq = pf_mk(dq); p.W = W; p.kv = kv; p.ksum = ksum; p.p_kv = p_dkv; p.p_ks = p_dksum;
+  return pf32_dispatch(3, p, (hipStream_t)stream);
+}
+
+int ea_performer_f32_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                           const float* p_max, const float* dkv, const float* dksum, const ea_t4* dk, const ea_t4* dv,
+                           void* stream) {
+  Pf32P p = {};
+  const int rc = pf_fill(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pf_t4_ok(k, g->dtype) || !pf_t4_ok(v, g->dtype) || !pf_t4_ok(dk, g->dtype) || !pf_t4_ok(dv, g->dtype) || !W || !p_max ||
+      !dkv || !dksum) return EA_E_BADARG;
+  p.k = pf_mk(k); p.v = pf_mk(v); p.mask = mask; p.W = W; p.p_max = const_cast<float*>(p_max); p.dkv = dkv; p.dksum = dksum;
+  p.dk = pf_mk(dk); p.dv = pf_mk(dv);
+  return pf32_dispatch(4, p, (hipStream_t)stream);
 }
 
 }  // extern "C"

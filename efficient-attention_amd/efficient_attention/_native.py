@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get(
     "EA_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libea_hip.so"))
 
-EA_BF16, EA_F16 = 0, 1
+EA_BF16, EA_F16, EA_F32 = 0, 1, 2
 _DTYPES = {torch.bfloat16: EA_BF16, torch.float16: EA_F16}
 
 
@@ -145,6 +145,12 @@ SIGNATURES = {
     "ea_performer_bwd_q": [_PG, _T, _T, _T, _P, _P, _P, _T, _P, _P, _P, _P],
     "ea_performer_bwd_qstats": [_PG, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_performer_bwd_k": [_PG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
+    "ea_performer_f32_parts": [_PG],
+    "ea_performer_f32_kmax": [_PG, _T, _P, _P, _P],
+    "ea_performer_f32_kv": [_PG, _T, _T, _P, _P, _P, _P, _P, _P],
+    "ea_performer_f32_out": [_PG, _T, _P, _P, _P, _T, _P],
+    "ea_performer_f32_bwd_q": [_PG, _T, _T, _P, _P, _P, _T, _P, _P, _P],
+    "ea_performer_f32_bwd_k": [_PG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
     "ea_softmax_attn_fwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _P, _P, _F, _I, _P],
     "ea_softmax_sample": [_I, _I, _I, _I, _I, _F, _T, _T, _P, _P, _P],
     "ea_softmax_attn_bwd": [_I, _I, _I, _I, _I, _F, _T, _T, _T, _P, _T, _T, _P, _P, _T, _T, _T, _P, _F, _I, _P],

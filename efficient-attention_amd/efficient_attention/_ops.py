@@ -1679,7 +1679,97 @@ class ScatterFeatureFn(torch.autograd.Function):
         return dqkv5, d_oloc, dlse, None, None, None, None, None
 
 
+# ---- Performer in exact fp32 arithmetic (ea_performer_f32_*; round 4) --------------------------------------
+# The reference's linear attention is full precision whatever the AMP state (kernelized_attention.py:116-121,343-345);
+# this is the default Performer core.  EA_PERFORMER_16BIT=1 selects the faster 16-bit-operand kernels above (phi rounded
+# to bf16 / fp16 for the MFMA -- narrower than the reference).
+PERFORMER_16BIT = os.environ.get("EA_PERFORMER_16BIT", "0") == "1"
+_IO32 = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def performer_f32_supported(qkv5, W):
+    return qkv5.is_cuda and qkv5.dtype in _IO32 and qkv5.shape[-1] == 64 and W.shape[1] <= 96 and W.shape[1] % 16 == 0
+
+
+def performer_f32_fwd(qkv5, mask_u8, W):
+    """-> out [B,N,h,d] (dtype of qkv5), p_max [BH,S], kv [BH,m,d], ksum [BH,m]."""
+    nv.require_cuda(qkv5, "qkv")
+    B, N, _, h, d = qkv5.shape
+    m = W.shape[1]
+    BH, dev = B * h, qkv5.device
+    W = W.float().contiguous()
+    geom = nv.ea_perf_geom(B, h, N, d, _IO32[qkv5.dtype], m)
+    q, k, v = _qkv_views(qkv5)
+    tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+    S = nv.lib().ea_performer_f32_parts(ctypes.byref(geom))
+    if S <= 0:
+        raise RuntimeError("ea_performer_f32_parts: %d" % S)
+    p_max = torch.empty((BH, S), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_f32_kmax", ctypes.byref(geom), ctypes.byref(tk), nv.ptr(W), nv.ptr(p_max), nv.stream())
+    p_kv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+    p_ks = torch.empty((BH, S, m), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_f32_kv", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(W),
+            nv.ptr(p_max), nv.ptr(p_kv), nv.ptr(p_ks), nv.stream())
+    kv = torch.empty((BH, m, d), dtype=torch.float32, device=dev)
+    ksum = torch.empty((BH, m), dtype=torch.float32, device=dev)
+    nv.call("ea_slice_sum", BH, S, m * d, 1.0, None, nv.ptr(p_kv), nv.ptr(kv), nv.stream())
+    nv.call("ea_slice_sum", BH, S, m, 1.0, None, nv.ptr(p_ks), nv.ptr(ksum), nv.stream())
+    out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+    to = nv.t4(out.permute(0, 2, 1, 3))
+    nv.call("ea_performer_f32_out", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(W), nv.ptr(kv), nv.ptr(ksum),
+            ctypes.byref(to), nv.stream())
+    return out, p_max, kv, ksum
+
+
+def performer_f32_bwd(dout, qkv5, mask_u8, W, p_max, kv, ksum):
+    B, N, _, h, d = qkv5.shape
+    m = W.shape[1]
+    BH, dev = B * h, qkv5.device
+    W = W.float().contiguous()
+    geom = nv.ea_perf_geom(B, h, N, d, _IO32[qkv5.dtype], m)
+    S = p_max.shape[1]
+    dout = dout.to(qkv5.dtype).contiguous()
+    dqkv5 = torch.empty_like(qkv5)
+    q, k, v = _qkv_views(qkv5)
+    dq, dk, dv = _qkv_views(dqkv5)
+    tq, tk, tv, tdo = nv.t4(q), nv.t4(k), nv.t4(v), nv.t4(dout.permute(0, 2, 1, 3))
+    tdq, tdk, tdv = nv.t4(dq), nv.t4(dk), nv.t4(dv)
+    p_dkv = torch.empty((BH, S, m, d), dtype=torch.float32, device=dev)
+    p_dks = torch.empty((BH, S, m), dtype=torch.float32, device=dev)
+    nv.call("ea_performer_f32_bwd_q", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tdo), nv.ptr(W), nv.ptr(kv),
+            nv.ptr(ksum), ctypes.byref(tdq), nv.ptr(p_dkv), nv.ptr(p_dks), nv.stream())
+    dkv = torch.empty((BH, m, d), dtype=torch.float32, device=dev)
+    dksum = torch.empty((BH, m), dtype=torch.float32, device=dev)
+    nv.call("ea_slice_sum", BH, S, m * d, 1.0, None, nv.ptr(p_dkv), nv.ptr(dkv), nv.stream())
+    nv.call("ea_slice_sum", BH, S, m, 1.0, None, nv.ptr(p_dks), nv.ptr(dksum), nv.stream())
+    nv.call("ea_performer_f32_bwd_k", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(W),
+            nv.ptr(p_max), nv.ptr(dkv), nv.ptr(dksum), ctypes.byref(tdk), ctypes.byref(tdv), nv.stream())
+    return dqkv5
+
+
+class PerformerF32Fn(torch.autograd.Function):
+    """The Performer core in exact fp32 arithmetic on qkv of any I/O type (bf16 / fp16 under autocast, fp32 outside):
+    out = phi(q) (phi(k)^T v) / clamp(phi(q) . sum phi(k), 1e-2); no gradient to the random features."""
+
+    @staticmethod
+    def forward(ctx, qkv5, mask_u8, W):
+        out, p_max, kv, ksum = performer_f32_fwd(qkv5, mask_u8, W)
+        ctx.save_for_backward(qkv5, mask_u8, W, p_max, kv, ksum)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv5, mask_u8, W, p_max, kv, ksum = ctx.saved_tensors
+        return performer_f32_bwd(dout, qkv5, mask_u8, W, p_max, kv, ksum), None, None
+
+
 def performer_attention(qkv5, mask_u8, proj):
+    tracing = torch.compiler.is_compiling() or torch._C._len_torch_dispatch_stack() != 0
+    # (while a graph is being traced the dispatcher ops torch.ops.ea.performer_fwd / _bwd -- the 16-bit kernels -- stay)
+    if not PERFORMER_16BIT and (not tracing or qkv5.dtype == torch.float32) and performer_f32_supported(qkv5, proj):
+        return PerformerF32Fn.apply(qkv5, mask_u8, proj)
+    if qkv5.dtype == torch.float32:
+        qkv5 = to_io_dtype(qkv5)
     return PerformerAttnFn.apply(qkv5, mask_u8, proj)
 
 

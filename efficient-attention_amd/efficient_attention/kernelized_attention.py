@@ -74,6 +74,15 @@ class KernelizedAttention(MultiheadAttention):
             return self.eval_proj
         return self.random_proj
 
+    def project_qkv(self, x):
+        """fp32 activations outside autocast stay fp32: the Performer core computes in exact fp32 arithmetic
+        (_ops.PerformerF32Fn), as the reference does there (abstract_attention.py:120-133)."""
+        if (x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_cuda and not _ops.PERFORMER_16BIT
+                and self.head_dim == 64 and self.approx_attn_dim <= 96 and self.approx_attn_dim % 16 == 0):
+            B, N, C = x.shape
+            return _ops.linear(x, self.qkv).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        return super().project_qkv(x)
+
     def _attend(self, qkv5, key_padding_mask, seq_shape):
         B, N = qkv5.shape[:2]
         proj = self.get_proj_matrix(device=qkv5.device, dtype=torch.float32)

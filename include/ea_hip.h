@@ -35,6 +35,7 @@ extern "C" {
 
 #define EA_BF16 0
 #define EA_F16  1
+#define EA_F32  2          /* accepted by the ea_performer_f32_* entry points only */
 
 #define EA_OK            0
 #define EA_E_BADARG     -1   /* null pointer / inconsistent sizes */
@@ -286,6 +287,32 @@ int ea_performer_bwd_qstats(const ea_perf_geom* g, const ea_t4* q, const ea_t4* 
 int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                        const float* W, const float* stab, const float* dkv, const float* dksum,
                        const ea_t4* dk, const ea_t4* dv, void* stream);
+
+/* ---- Performer in EXACT fp32 arithmetic (ea_performer_f32.hip; round 4) --------------------
+ * The reference computes its linear attention in full precision whatever the AMP state (kernelized_attention.py:116-121
+ * `autocast(enabled=False)`, :343-345 `.float()`), and a module called outside autocast computes everything in fp32
+ * (abstract_attention.py:120-133).  These entry points are that arithmetic: q, k, v, dout of type g->dtype = EA_BF16 /
+ * EA_F16 / EA_F32 (16-bit values are exact in fp32), every product on v_mfma_f32_16x16x4_f32 with fp32 operands, fp32
+ * features phi, outputs in g->dtype.  D = 64, M <= 96 (multiple of 16); W [H, M, 64] fp32.
+ *   S = ea_performer_f32_parts(g) sequence slices per (b,h);
+ *   kmax : p_max [BH,S]  = slice maxima of d^-1/4 W_j.k_n (the key stabiliser is their maximum; padded keys included,
+ *          as in the reference, which masks the features afterwards);
+ *   kv   : p_kv [BH,S,M,64], p_ksum [BH,S,M] = partial sum_n phi(k_n)^T v_n, sum_n phi(k_n) (padded keys: phi = 0);
+ *          the caller adds the slices (ea_slice_sum) -> kv [BH,M,64], ksum [BH,M];
+ *   out  : out_n = phi(q_n) kv / max(phi(q_n).ksum, 1e-2);
+ *   bwd_q: dq, and the slice partials of d kv, d ksum (same shapes as kv's);  bwd_k: dk, dv from the summed d kv, d ksum.
+ * Replaces favorp_projection + linear_attention and their autograd (kernelized_attention.py:20-56,116-121). */
+int32_t ea_performer_f32_parts(const ea_perf_geom* g);
+int ea_performer_f32_kmax(const ea_perf_geom* g, const ea_t4* k, const float* W, float* p_max, void* stream);
+int ea_performer_f32_kv(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                        const float* p_max, float* p_kv, float* p_ksum, void* stream);
+int ea_performer_f32_out(const ea_perf_geom* g, const ea_t4* q, const float* W, const float* kv, const float* ksum,
+                         const ea_t4* out, void* stream);
+int ea_performer_f32_bwd_q(const ea_perf_geom* g, const ea_t4* q, const ea_t4* dout, const float* W, const float* kv,
+                           const float* ksum, const ea_t4* dq, float* p_dkv, float* p_dksum, void* stream);
+int ea_performer_f32_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* W,
+                           const float* p_max, const float* dkv, const float* dksum, const ea_t4* dk, const ea_t4* dv,
+                           void* stream);
 
 /* ---- LARA landmark pipeline, fused (lara.py:145-198,214-238) -----------------------------------
  * One workgroup per (b,h), all matrices in LDS, exact fp32:

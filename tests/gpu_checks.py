@@ -122,7 +122,8 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
     x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)
     mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np).cuda()
     with injected_noise(fx, mode, "cuda") as calls:
-        with torch.autocast("cuda", dtype=dtype):
+        # dtype = torch.float32: NO autocast -- the module called the way the reference computes in fp32
+        with (torch.autocast("cuda", dtype=dtype) if dtype != torch.float32 else contextlib.nullcontext()):
             y = cases.call_module(fx.case, mod, x, mask)
     assert calls == fx.expected_noise_shapes(mode), (calls, fx.expected_noise_shapes(mode))
     assert [int(np.prod(s)) for s in keep_fn.calls] == fx.expected_drop_elems(mode)

@@ -15,7 +15,8 @@ KERNEL_TO_ENTRY = [
     ("lara_fq_kernel<", "ea_lara_bwd_q_fused"), ("lara_fk_kernel<", "ea_lara_bwd_k_fused"),
     ("lara_fin_kernel<", "ea_lara_bwd_finish"),
     ("lmk2_kernel<64, false>", "ea_lara_landmarks_fwd"), ("lmk2_kernel<64, true>", "ea_lara_landmarks_bwd"),
-    ("wgrad_kernel<", "ea_wgrad"), ("part_sum_kernel", "ea_part_sum"),
+    ("wgrad_kernel<", "ea_wgrad"), ("part_sum_kernel", "ea_part_sum"), ("multi_sum_kernel", "ea_multi_sum"),
+    ("stream_copy_kernel", "ea_stream_copy"),
     ("lin_kernel<ea::BF16, 6, 2, true", "ea_linear[fp32 in]"), ("lin_kernel<", "ea_linear"),
     ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("lara_sample_kernel<", "ea_lara_sample"), ("pool2d_", "ea_adaptive_pool2d"),
@@ -90,7 +91,7 @@ def main(src, tag, attn, outdir, workload="default workload"):
     nrows = {e: max(len(d["FETCH_SIZE"]), len(d["WRITE_SIZE"])) for e, d in pmc.items()}
     steps = collections.Counter(nrows.values()).most_common(1)[0][0] if nrows else 0   # most kernels launch once per step
     if steps:
-        proj = ("ea_linear", "ea_wgrad", "ea_part_sum", "ea_bias_grad")
+        proj = ("ea_linear", "ea_wgrad", "ea_part_sum", "ea_bias_grad", "ea_multi_sum", "ea_stream_copy")
         tot = {e: (2 * sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1) + sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1))
                * 1024 * nrows[e] / steps for e, d in pmc.items()}
         out["_launches_per_step"] = {e: round(nrows[e] / steps, 2) for e in pmc}
