@@ -76,6 +76,8 @@ def main(src, tag, attn, outdir, workload="default workload"):
             continue
         for r in csv.DictReader(open(path)):
             e = entry_of(r["Kernel_Name"])
+            if e == "ea_stream_copy":               # bench.py's bandwidth yardstick, not part of a step
+                continue
             if e and r["Counter_Name"] == cname:
                 pmc[e][cname].append(float(r["Counter_Value"]))
     avg_ns = {entry_of(r["Name"]): float(r["AverageNs"]) for r in stats if entry_of(r["Name"])}
