@@ -29,12 +29,18 @@ constexpr int PD = 64;            // head dim
 constexpr int LDD = PD + 1;       // row stride of the [*][64] images
 
 // acc += A(m0.., k) B(k, n0..) over K (multiple of 16); TA / TB_: operand stored transposed (ea_rows_mlp.hip)
-template <bool TA, bool TB_>
+// KC > 0: K is that compile-time constant -- the loop unrolls completely and every operand load of a tile is in flight
+// before the first MFMA (with a run-time K each of the K / 16 trips waited for its own eight loads: a workgroup here is
+// one wave per SIMD, nothing else hides that latency)
+template <bool TA, bool TB_, int KC = 0>
 EA_DEV void tile_mm(f32x4& acc, const float* A, int lda, const float* B, int ldb, int m0, int n0, int K, int lane) {
   const int g = lane >> 4, li = lane & 15;
-  const int steps = K >> 2, kb = g * steps;
+  const int steps = (KC > 0 ? KC : K) >> 2, kb = g * steps;
   const int am = m0 + li, bn = n0 + li;
-  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  // four independent accumulation chains: a workgroup of these kernels is one wave per SIMD (its LDS images fill most of
+  // the CU), so back-to-back dependent MFMAs would leave the matrix pipe idle three quarters of the time
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1, acc3 = acc1;
+#pragma unroll
   for (int k0 = 0; k0 < steps; k0 += 4) {
     float a[4], b[4];
 #pragma unroll
@@ -44,11 +50,11 @@ EA_DEV void tile_mm(f32x4& acc, const float* A, int lda, const float* B, int ldb
       b[i] = TB_ ? B[bn * ldb + k] : B[k * ldb + bn];
     }
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc3, 0, 0, 0);
   }
-  acc += acc2;
+  acc += (acc1 + acc2) + acc3;
 }
 
 // rows n0 .. n0 + 63 of a [B,H,N,64] view -> dst[row][65] fp32 (rows >= N: zeros); thread = (row, 16 channels)
@@ -106,7 +112,8 @@ EA_DEV void load_mat(float* dst, const float* src, int rows, int tid) {
   }
 }
 
-// sum over the 4 lanes that share a row (row = tid >> 2)
+// sum over the 4 lanes that share a row (row = tid >> 2); lane q4 of a row walks the CONTIGUOUS quarter q4 of it, which with
+// the odd row stride keeps the 64 lanes of a wave on distinct LDS banks
 EA_DEV float row4_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
 EA_DEV float row4_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return v; }
 
@@ -128,13 +135,13 @@ EA_DEV void logits(float* Ps, int ldp, const float* Xs, const float* Ws, float* 
   for (int t = wave; t < (TB / 16) * ntn; t += 4) {
     const int m0 = (t / ntn) * 16, n0 = (t % ntn) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    tile_mm<false, true>(acc, Xs, LDD, Ws, LDD, m0, n0, PD, lane);
+    tile_mm<false, true, PD>(acc, Xs, LDD, Ws, LDD, m0, n0, PD, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ps[(m0 + 4 * g + r) * ldp + n0 + li] = acc[r] * c;
   }
   const int row = tid >> 2, q4 = tid & 3;
   float s = 0.f;
-  for (int e = q4; e < PD; e += 4) { const float x = Xs[row * LDD + e]; s += x * x; }
+  for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) { const float x = Xs[row * LDD + e]; s += x * x; }
   s = row4_sum(s);
   if (q4 == 0) diag[row] = s * c2;
 }
@@ -171,18 +178,17 @@ __global__ __launch_bounds__(256) void pf32_kmax_kernel(const Pf32P p) {
     __syncthreads();
     logits(Ps, ldp, Xs, Ws, diag, M, k.c, k.c2, tid);
     __syncthreads();
-    for (int idx = tid; idx < TB * M; idx += 256) {
-      const int n = idx / M, j = idx - n * M;
-      if (t0 + n < n1) mx = fmaxf(mx, Ps[n * ldp + j]);
+    {
+      const int row = tid >> 2, q4 = tid & 3;                         // (no index divisions: four lanes per token row)
+      if (t0 + row < n1)
+        for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
     }
   }
-  red[tid] = mx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  if (tid == 0) {
-    float m2 = -INFINITY;
-    for (int i = 0; i < 256; ++i) m2 = fmaxf(m2, red[i]);
-    p.p_max[(size_t)bh * p.S + s] = m2;
-  }
+  if (tid == 0) p.p_max[(size_t)bh * p.S + s] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // the key stabiliser of a (b,h): maximum of the slice maxima
@@ -196,12 +202,10 @@ EA_DEV float key_stab(const Pf32P& p, int bh) {
 EA_DEV void key_features(float* Ps, int ldp, const float* diag, const Pf32P& p, int b, int t0, int n1, float stab, float ratio,
                          int tid) {
   const int M = p.M;
-  for (int idx = tid; idx < TB * M; idx += 256) {
-    const int n = idx / M, j = idx - n * M;
-    const int tok = t0 + n;
-    const bool live = tok < n1 && !(p.mask && p.mask[(size_t)b * p.N + tok]);
-    Ps[n * ldp + j] = live ? ratio * __expf(Ps[n * ldp + j] - diag[n] - stab) + 1e-4f : 0.f;
-  }
+  const int n = tid >> 2, q4 = tid & 3, tok = t0 + n;
+  const bool live = tok < n1 && !(p.mask && p.mask[(size_t)b * p.N + tok]);
+  const float sh = diag[n] + stab;
+  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) Ps[n * ldp + j] = live ? ratio * __expf(Ps[n * ldp + j] - sh) + 1e-4f : 0.f;
 }
 
 // keys, pass 2: partial KV [M][64] and ksum [M] of the slice
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int t = wave + 4 * i;
-      if (t < nt * 4) tile_mm<true, false>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
+      if (t < nt * 4) tile_mm<true, false, TB>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
     }
     if (tid < M) {
       float a = 0.f;
@@ -262,11 +266,11 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
 EA_DEV void query_features(float* Ps, int ldp, const float* diag, float* den, const float* ksum_s, int M, float ratio, int tid) {
   const int row = tid >> 2, q4 = tid & 3;
   float mx = -INFINITY;
-  for (int j = q4; j < M; j += 4) mx = fmaxf(mx, Ps[row * ldp + j]);
+  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
   mx = row4_max(mx);
   const float sh = diag[row] + mx;
   float dn = 0.f;
-  for (int j = q4; j < M; j += 4) {
+  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) {
     const float f = ratio * __expf(Ps[row * ldp + j] - sh) + 1e-4f;
     Ps[row * ldp + j] = f;
     dn += f * ksum_s[j];
@@ -282,7 +286,8 @@ EA_DEV void feat_times(float* Os, const float* Ps, int ldp, const float* KVs, in
   for (int t = wave; t < 16; t += 4) {
     const int m0 = (t >> 2) * 16, n0 = (t & 3) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    tile_mm<false, false>(acc, Ps, ldp, KVs, LDD, m0, n0, M, lane);
+    if (M == 64) tile_mm<false, false, 64>(acc, Ps, ldp, KVs, LDD, m0, n0, 64, lane);
+    else tile_mm<false, false>(acc, Ps, ldp, KVs, LDD, m0, n0, M, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Os[(m0 + 4 * g + r) * LDD + n0 + li] = acc[r] * rowscale(m0 + 4 * g + r);
   }
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(256) void pf32_out_kernel(const Pf32P p) {
   float* Ws = sm;
   float* KVs = Ws + M * LDD;
   float* Xs = KVs + M * LDD;
-  float* Os = Xs + TB * LDD;
-  float* Ps = Os + TB * LDD;
+  float* Os = Xs;                                // the q tile is dead once its logits and |q|^2 are formed
+  float* Ps = Xs + TB * LDD;
   float* diag = Ps + TB * ldp;
   float* den = diag + TB;
   float* ksum_s = den + TB;
@@ -329,7 +334,8 @@ EA_DEV void logit_grad(float* Os, const float* Gs, int ldp, const float* Ws, con
   for (int t = wave; t < 16; t += 4) {
     const int m0 = (t >> 2) * 16, n0 = (t & 3) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    tile_mm<false, false>(acc, Gs, ldp, Ws, LDD, m0, n0, M, lane);
+    if (M == 64) tile_mm<false, false, 64>(acc, Gs, ldp, Ws, LDD, m0, n0, 64, lane);
+    else tile_mm<false, false>(acc, Gs, ldp, Ws, LDD, m0, n0, M, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = m0 + 4 * g + r, e = n0 + li;
@@ -383,9 +389,9 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
       // d num = dout / max(den, 1e-2);  d den = -(dout . out) / max(den, 1e-2) where the clamp is inactive
       const float inv = 1.f / fmaxf(den[row], 1e-2f);
       float rd = 0.f;
-      for (int e = q4; e < PD; e += 4) rd += Ys[row * LDD + e] * Os[row * LDD + e];
+      for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) rd += Ys[row * LDD + e] * Os[row * LDD + e];
       rd = row4_sum(rd);
-      for (int e = q4; e < PD; e += 4) Ys[row * LDD + e] *= inv;
+      for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) Ys[row * LDD + e] *= inv;
       if (q4 == 0) dden[row] = den[row] > 1e-2f ? -rd * inv : 0.f;
     }
     __syncthreads();
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
     for (int t = wave; t < (TB / 16) * nt; t += 4) {
       const int m0 = (t / nt) * 16, j0 = (t % nt) * 16;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      tile_mm<false, true>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
+      tile_mm<false, true, PD>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = m0 + 4 * g + r, j = j0 + li;
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
     __syncthreads();
     {
       float sacc = 0.f;
-      for (int j = q4; j < M; j += 4) sacc += Gs[row * ldp + j];
+      for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) sacc += Gs[row * ldp + j];
       sacc = row4_sum(sacc);
       if (q4 == 0) sdl[row] = sacc;
     }
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int t = wave + 4 * i;
-      if (t < nt * 4) tile_mm<true, false>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
+      if (t < nt * 4) tile_mm<true, false, TB>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
     }
     if (tid < M) {
       float a = 0.f;
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
     for (int t = wave; t < (TB / 16) * nt; t += 4) {
       const int m0 = (t / nt) * 16, j0 = (t % nt) * 16;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      tile_mm<false, true>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
+      tile_mm<false, true, PD>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = m0 + 4 * g + r, j = j0 + li;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
     __syncthreads();
     {
       float sacc = 0.f;
-      for (int j = q4; j < M; j += 4) sacc += Gs[row * ldp + j];
+      for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) sacc += Gs[row * ldp + j];
       sacc = row4_sum(sacc);
       if (q4 == 0) sdl[row] = sacc;
     }
@@ -514,7 +520,7 @@ static size_t pf32_lds(int which, int M) {
   switch (which) {
     case 0: return (M * LDD + TB * LDD + TB * ldp + TB + 256) * sizeof(float);
     case 1: return (M * LDD + 2 * TB * LDD + TB * ldp + TB) * sizeof(float);
-    case 2: return (2 * M * LDD + 2 * TB * LDD + TB * ldp + 2 * TB + M) * sizeof(float);
+    case 2: return (2 * M * LDD + TB * LDD + TB * ldp + 2 * TB + M) * sizeof(float);
     case 3: return (2 * M * LDD + 2 * TB * LDD + TB * ldp + TB * big + 4 * TB + M) * sizeof(float);
     default: return (2 * M * LDD + 2 * TB * LDD + 2 * TB * ldp + 2 * TB + M) * sizeof(float);
   }

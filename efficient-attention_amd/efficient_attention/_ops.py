@@ -86,6 +86,11 @@ KERNEL_ALGO_UNITS = {
     "ea_performer_bwd_q": 4,      # read q,out,dout; write dq
     "ea_performer_bwd_qstats": 2, # read q,dout
     "ea_performer_bwd_k": 4,      # read k,v; write dk,dv
+    "ea_performer_f32_kmax": 1,   # read k
+    "ea_performer_f32_kv": 2,     # read k,v
+    "ea_performer_f32_out": 2,    # read q; write out
+    "ea_performer_f32_bwd_q": 3,  # read q,dout; write dq
+    "ea_performer_f32_bwd_k": 4,  # read k,v; write dk,dv
     "ea_lara_stats_fwd": 3,       # read q,k,v
     "ea_lara_out_fwd": 2,         # read q; write out
     "ea_lara_bwd_q": 3,           # read q,dout; write dq
