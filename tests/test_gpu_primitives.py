@@ -650,7 +650,7 @@ def test_eva_pooled_projection_close_to_separate_chunk_means(dtype, grid, window
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("frozen", ["qkv.weight", "proj.weight", "both"])
-def test_lara_module_single_node_bias_only_finetuning(frozen):
+def test_lara_module_single_node_bias_only_finetuning(frozen, monkeypatch):
     """frozen projection weight + trainable bias + fp32 x under autocast (bias-only fine-tuning).  The single
     node must not ask for the rounded input it did not keep: the bias gradient is a column sum of d qkv (ea_bias_grad).
     Same gradients as the three-node path, bit for bit."""
@@ -671,6 +671,7 @@ def test_lara_module_single_node_bias_only_finetuning(frozen):
     x0 = torch.randn(2, 28, 28, 192, device="cuda")
     g = torch.randn(2, 28, 28, 192, device="cuda").bfloat16()
     res = {}
+    monkeypatch.setattr(_ops, "USE_PROJ_POOL", False)      # (pooled rows from the projection: not bit-equal to the three nodes)
     for single in (True, False):
         old = _ops.USE_LARA_MODULE_FN
         _ops.USE_LARA_MODULE_FN = single
