@@ -949,6 +949,46 @@ int ea_adaptive_pool2d_bwd(int32_t dtype, int32_t B, int32_t H, int32_t gh, int3
 
 }  // extern "C"
 
+// ---- LARA 'adaptive-1d': the generators' Linear folded into the qkv projection (ea_fold.hip) ----
+namespace ea {
+struct FoldP {
+  const float *W, *b, *Gq, *Gk, *gqb, *gkb;
+  char* w_ext;
+  char* b_ext;
+  float *bias_q, *bias_k;
+  const float *dW_ext, *db_ext, *dbias_q, *dbias_k;
+  float *dW, *db, *dGq, *dGk, *dgqb, *dgkb;
+  long ldw;
+  int C, h, d;
+};
+int fold_dispatch(bool bwd, int dtype, const FoldP& p, hipStream_t st);
+}  // namespace ea
+
+extern "C" {
+
+int ea_lara_fold_fwd(int32_t dtype, int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* gq_b,
+                     const float* Gk, const float* gk_b, void* w_ext, void* b_ext, float* bias_q, float* bias_k, void* stream) {
+  if (!W || !Gq || !Gk || !gq_b || !gk_b || !w_ext || !bias_q || !bias_k || heads <= 0 || C % heads) return EA_E_BADARG;
+  ea::FoldP p = {};
+  p.W = W; p.b = b; p.Gq = Gq; p.Gk = Gk; p.gqb = gq_b; p.gkb = gk_b; p.w_ext = (char*)w_ext; p.b_ext = (char*)b_ext;
+  p.bias_q = bias_q; p.bias_k = bias_k; p.C = C; p.h = heads; p.d = C / heads;
+  return ea::fold_dispatch(false, dtype, p, (hipStream_t)stream);
+}
+
+int ea_lara_fold_bwd(int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* Gk,
+                     const float* dW_ext, int64_t ldw, const float* db_ext, const float* dbias_q, const float* dbias_k,
+                     float* dW, float* db, float* dGq, float* dgq_b, float* dGk, float* dgk_b, void* stream) {
+  if (!W || !Gq || !Gk || !dW_ext || !dbias_q || !dbias_k || !dW || !dGq || !dGk || !dgq_b || !dgk_b || heads <= 0 || C % heads ||
+      ldw < C) return EA_E_BADARG;
+  ea::FoldP p = {};
+  p.W = W; p.b = b; p.Gq = Gq; p.Gk = Gk; p.dW_ext = dW_ext; p.ldw = (long)ldw; p.db_ext = db_ext; p.dbias_q = dbias_q;
+  p.dbias_k = dbias_k; p.dW = dW; p.db = db; p.dGq = dGq; p.dGk = dGk; p.dgqb = dgq_b; p.dgkb = dgk_b;
+  p.C = C; p.h = heads; p.d = C / heads;
+  return ea::fold_dispatch(true, 0, p, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
 // ---- Performer in exact fp32 arithmetic (ea_performer_f32.hip) ----
 static bool pf_t4_ok(const ea_t4* t, int dtype) {
   const int a = dtype == EA_F32 ? 4 : 8;                  // 16-byte vector access

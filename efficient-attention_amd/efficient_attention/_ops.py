@@ -641,6 +641,72 @@ class SegmentLnMeanFn(torch.autograd.Function):
         return ((buf if own else None), None, None, None) + grads
 
 
+USE_FOLD_KERNELS = os.environ.get("EA_FOLD_KERNELS", "1") == "1"
+
+
+class FoldedQkvFn(torch.autograd.Function):
+    """LARA 'adaptive-1d' (lara.py:56-63,100-103): qkv projection with the generators' per-token Linear folded in --
+    x [B,N,C] -> (qkvE [B,N,5C] in `dtype`: q, k, v, G_q q, G_k k without the folded rows' biases; bias_q, bias_k [h,d] fp32:
+    those biases).  The extended weight is built and its gradient taken apart by ea_lara_fold_fwd / _bwd (one launch each
+    way instead of ~30 framework kernels: cat / permute copies / small GEMMs / casts / adds); the GEMMs are the library's
+    (512-wide models), the weight gradient ea_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, Gq, gqb, Gk, gkb, dtype, heads):
+        C = x.shape[-1]
+        d = C // heads
+        dev = x.device
+        x2 = x.reshape(-1, C)
+        xl = x2 if x2.dtype == dtype else x2.to(dtype)
+        ps = [None if t is None else t.detach().float().contiguous() for t in (W, b, Gq, gqb, Gk, gkb)]
+        w_ext = torch.empty((5 * C, C), dtype=dtype, device=dev)
+        b_ext = torch.empty((5 * C,), dtype=dtype, device=dev)
+        bias_q = torch.empty((heads, d), dtype=torch.float32, device=dev)
+        bias_k = torch.empty_like(bias_q)
+        nv.call("ea_lara_fold_fwd", _ELEM[dtype], C, heads, nv.ptr(ps[0]), nv.ptr(ps[1]), nv.ptr(ps[2]), nv.ptr(ps[3]),
+                nv.ptr(ps[4]), nv.ptr(ps[5]), nv.ptr(w_ext), nv.ptr(b_ext), nv.ptr(bias_q), nv.ptr(bias_k), nv.stream())
+        y = F.linear(xl, w_ext, b_ext)
+        ctx.save_for_backward(xl, w_ext, *[t for t in ps if t is not None])
+        ctx.has_b = b is not None
+        ctx.meta = (x.shape, x.dtype, heads, [None if t is None else t.dtype for t in (W, b, Gq, gqb, Gk, gkb)])
+        return y.view(x.shape[:-1] + (5 * C,)), bias_q, bias_k
+
+    @staticmethod
+    def backward(ctx, dy, dbias_q, dbias_k):
+        xl, w_ext, *ps = ctx.saved_tensors
+        xshape, xdtype, heads, pd = ctx.meta
+        if ctx.has_b:
+            W, b, Gq, gqb, Gk, gkb = ps
+        else:
+            (W, Gq, gqb, Gk, gkb), b = ps, None
+        C = xshape[-1]
+        d = C // heads
+        dev = dy.device
+        dy2 = dy.reshape(-1, 5 * C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = _mm_out(dy2, w_ext, xdtype).view(xshape) if ctx.needs_input_grad[0] else None
+        if wgrad_supported(dy2, xl):
+            dW_ext, db_ext = wgrad(dy2, xl, b is not None)
+        else:
+            dW_ext = torch.mm(dy2.t(), xl).float()
+            db_ext = dy2.sum(0, dtype=torch.float32) if b is not None else None
+        zq = torch.zeros((heads, d), dtype=torch.float32, device=dev)
+        dbq = zq if dbias_q is None else dbias_q.float().contiguous()
+        dbk = zq if dbias_k is None else dbias_k.float().contiguous()
+        dW = torch.empty((3 * C, C), dtype=torch.float32, device=dev)
+        db = torch.empty((3 * C,), dtype=torch.float32, device=dev) if b is not None else None
+        dGq = torch.empty((d, d), dtype=torch.float32, device=dev)
+        dGk = torch.empty_like(dGq)
+        dgqb = torch.empty((d,), dtype=torch.float32, device=dev)
+        dgkb = torch.empty_like(dgqb)
+        nv.call("ea_lara_fold_bwd", C, heads, nv.ptr(W), nv.ptr(b), nv.ptr(Gq), nv.ptr(Gk), nv.ptr(dW_ext), dW_ext.stride(0),
+                nv.ptr(db_ext), nv.ptr(dbq), nv.ptr(dbk), nv.ptr(dW), nv.ptr(db), nv.ptr(dGq), nv.ptr(dgqb), nv.ptr(dGk),
+                nv.ptr(dgkb), nv.stream())
+        outs = [dW, db, dGq, dgqb, dGk, dgkb]
+        outs = [None if (o is None or t is None) else o.to(t) for o, t in zip(outs, pd)]
+        return (dx,) + tuple(outs) + (None, None)
+
+
 def pool2d_qkv(qkv5, H, W, side, slot=None, need_v=False):
     """Adaptive 2-D average pool of q, k (and v when asked) over the token grid -> fp32
     [B, h, side*side, d] each (nn.AdaptiveAvgPool2d on each head's [d, H, W] map,

@@ -120,6 +120,16 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         group of output columns of the same GEMM instead of a K = d GEMM over B*h*N strided rows)."""
         B, N, C = x.shape
         h, d = self.num_heads, self.head_dim
+        if (_ops.USE_FOLD_KERNELS and x.is_cuda and torch.is_autocast_enabled() and d <= 64
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+                and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0):
+            # extended weight built (and differentiated) by one HIP launch each way: ea_lara_fold_fwd / _bwd
+            lq, lk = self.q_bar_gen[0], self.k_bar_gen[0]
+            qkv, bias_q, bias_k = _ops.FoldedQkvFn.apply(x, self.qkv.weight, self.qkv.bias, lq.weight, lq.bias, lk.weight, lk.bias,
+                                                         torch.get_autocast_dtype("cuda"), h)
+            self._fold_bias = (bias_q, bias_k)
+            return qkv.reshape(B, N, 5, h, d)
+        self._fold_bias = None
 
         def build():
             with torch.autocast(device_type="cuda", enabled=False):
@@ -153,6 +163,12 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             keep = (~key_padding_mask.to(torch.bool)).to(qkvE.dtype).view(B, N, 1, 1, 1)
             qkvE = qkvE * keep
         lq, nq, lk, nk = self.q_bar_gen[0], self.q_bar_gen[1], self.k_bar_gen[0], self.k_bar_gen[1]
+        fold_bias, self._fold_bias = getattr(self, "_fold_bias", None), None
+        if fold_bias is not None:
+            bias_q, bias_k = fold_bias
+            pq, pk = _ops.SegmentLnMeanFn.apply(qkvE, mask_u8, self.num_landmarks, slot, bias_q, bias_k,
+                                                lq.bias, lk.bias, nq.weight, nq.bias, nk.weight, nk.bias)
+            return pq, pk, qkvE
         with torch.autocast(device_type="cuda", enabled=False):
             C = h * d
             if self.qkv.bias is not None:

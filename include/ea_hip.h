@@ -288,6 +288,21 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
                        const float* W, const float* stab, const float* dkv, const float* dksum,
                        const ea_t4* dk, const ea_t4* dv, void* stream);
 
+/* ---- LARA 'adaptive-1d' proposals: the generators' per-token Linear folded into the qkv projection (ea_fold.hip) ----
+ * q_bar_gen / k_bar_gen start with Linear(d, d) on every token's q / k row (lara.py:56-63,100-103).  The module computes
+ * Linear_gen(q) as two more groups of output columns of the qkv GEMM (W' = G W_head per head); these two entry points
+ * build the extended weight and take its gradient apart in one launch each way (round 4; ~30 framework kernels before).
+ *   fwd: w_ext [5C, C] (EA dtype) = [ W ; Gq W_q,head ; Gk W_k,head ], b_ext [5C] (EA dtype, may be NULL) = [ b ; 0 ],
+ *        bias_q / bias_k [heads, d] fp32 = G b_head + g_b: the bias of a folded row (consumed by ea_lara_segment_*).
+ *        W [3C, C], b [3C] (may be NULL), Gq / Gk [d, d], gq_b / gk_b [d]: fp32 parameters.
+ *   bwd: from dW_ext [5C, ldw] / db_ext [5C] (the weight / bias gradient of the extended projection, e.g. ea_wgrad's sums)
+ *        and dbias_q / dbias_k [heads, d]: dW [3C, C], db [3C] (NULL when b is), dGq, dGk [d, d], dgq_b, dgk_b [d]. */
+int ea_lara_fold_fwd(int32_t dtype, int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* gq_b,
+                     const float* Gk, const float* gk_b, void* w_ext, void* b_ext, float* bias_q, float* bias_k, void* stream);
+int ea_lara_fold_bwd(int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* Gk,
+                     const float* dW_ext, int64_t ldw, const float* db_ext, const float* dbias_q, const float* dbias_k,
+                     float* dW, float* db, float* dGq, float* dgq_b, float* dGk, float* dgk_b, void* stream);
+
 /* ---- Performer in EXACT fp32 arithmetic (ea_performer_f32.hip; round 4) --------------------
  * The reference computes its linear attention in full precision whatever the AMP state (kernelized_attention.py:116-121
  * `autocast(enabled=False)`, :343-345 `.float()`), and a module called outside autocast computes everything in fp32

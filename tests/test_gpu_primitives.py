@@ -694,3 +694,56 @@ def test_lara_module_single_node_bias_only_finetuning(frozen, monkeypatch):
         a, b = res[True][2][n], res[False][2][n]
         # the one-pass weight gradient carries the bias sum along; alone it is ea_bias_grad: same sum, other order
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max())), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("masked,bias", [(False, True), (True, True), (False, False)])
+def test_lara_adaptive_1d_fold_kernels_match_framework_fold(dtype, masked, bias):
+    """LARA 'adaptive-1d' with the generators' Linear folded into the qkv projection: extended weight built and
+    differentiated by ea_lara_fold_fwd / _bwd (round 4) against the framework-op construction it replaces -- y, dx and every
+    parameter gradient (the fp32 fold differs in summation order only; its 16-bit rounding can flip single weights by one
+    ulp)."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(21)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=512, num_heads=8, num_landmarks=16, proposal_gen="adaptive-1d",
+                                                             mis_type="mis-opt", qkv_bias=bias)).cuda()
+    m.train()
+    B, N = 2, 1000
+    x0 = torch.randn(B, N, 512, device="cuda")
+    g = torch.randn(B, N, 512, device="cuda").to(td)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, N, dtype=torch.bool, device="cuda")
+        mask[0, 900:] = True
+    res = {}
+    for fold in (True, False):
+        old = _ops.USE_FOLD_KERNELS
+        _ops.USE_FOLD_KERNELS = fold
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=td):
+                y = m(x, mask)
+            y.backward(g)
+            res[fold] = (y.detach().float(), x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _ops.USE_FOLD_KERNELS = old
+    tol = 1.6e-2 if dtype == "bf16" else 2e-3
+
+    def close(a, b, what, t):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= t * sc, (what, float((a - b).abs().max()) / sc)
+    close(res[True][0], res[False][0], "y", tol)
+    close(res[True][1], res[False][1], "dx", tol)
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 8
+    for n in res[True][2]:
+        close(res[True][2][n], res[False][2][n], n, 4 * tol)

@@ -9,7 +9,15 @@ run() {  # name attn flags...
   rm -rf /tmp/prof_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o t -- python $R/bench.py --no-other-workloads --no-graph --no-cpu-baseline --no-gemm-tune --steps 10 --warmup 3 "$@" > $OUT/$name.log 2>&1
   f=$(find /tmp/prof_$name -name 't_kernel_stats.csv' | head -1)
-  [ -n "$f" ] && head -45 $f | cut -c1-200 > $OUT/$name.csv
+  [ -n "$f" ] && python - "$f" "$OUT/$name.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+with open(sys.argv[2], "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    for r in rows[:70]:
+        w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+PY
 }
 for w in "$@"; do
   case $w in
