@@ -958,10 +958,12 @@ struct FoldP {
   float *bias_q, *bias_k;
   const float *dW_ext, *db_ext, *dbias_q, *dbias_k;
   float *dW, *db, *dGq, *dGk, *dgqb, *dgkb;
+  float *dG_part, *dG_base;
   long ldw;
   int C, h, d;
 };
 int fold_dispatch(bool bwd, int dtype, const FoldP& p, hipStream_t st);
+int fold_bwd_parts(int heads);
 }  // namespace ea
 
 extern "C" {
@@ -975,16 +977,24 @@ int ea_lara_fold_fwd(int32_t dtype, int32_t C, int32_t heads, const float* W, co
   return ea::fold_dispatch(false, dtype, p, (hipStream_t)stream);
 }
 
+int32_t ea_lara_fold_parts(int32_t heads) { return ea::fold_bwd_parts(heads); }
+
 int ea_lara_fold_bwd(int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* Gk,
                      const float* dW_ext, int64_t ldw, const float* db_ext, const float* dbias_q, const float* dbias_k,
-                     float* dW, float* db, float* dGq, float* dgq_b, float* dGk, float* dgk_b, void* stream) {
-  if (!W || !Gq || !Gk || !dW_ext || !dbias_q || !dbias_k || !dW || !dGq || !dGk || !dgq_b || !dgk_b || heads <= 0 || C % heads ||
-      ldw < C) return EA_E_BADARG;
+                     float* dW, float* db, float* dG, float* dG_part, float* dgq_b, float* dgk_b, void* stream) {
+  if (!W || !Gq || !Gk || !dW_ext || !dbias_q || !dbias_k || !dW || !dG || !dG_part || !dgq_b || !dgk_b || heads <= 0 ||
+      C % heads || ldw < C) return EA_E_BADARG;
   ea::FoldP p = {};
   p.W = W; p.b = b; p.Gq = Gq; p.Gk = Gk; p.dW_ext = dW_ext; p.ldw = (long)ldw; p.db_ext = db_ext; p.dbias_q = dbias_q;
-  p.dbias_k = dbias_k; p.dW = dW; p.db = db; p.dGq = dGq; p.dGk = dGk; p.dgqb = dgq_b; p.dgkb = dgk_b;
+  p.dbias_k = dbias_k; p.dW = dW; p.db = db; p.dgqb = dgq_b; p.dgkb = dgk_b;
   p.C = C; p.h = heads; p.d = C / heads;
-  return ea::fold_dispatch(true, 0, p, (hipStream_t)stream);
+  // the bias part of dG goes to a scratch behind the partials; one slice sum adds everything up into dG [2, d, d]
+  const int S = ea::fold_bwd_parts(heads);
+  const size_t dd = (size_t)p.d * p.d;
+  p.dG_part = dG_part; p.dG_base = dG_part + (size_t)2 * S * dd;
+  int rc = ea::fold_dispatch(true, 0, p, (hipStream_t)stream);
+  if (rc != EA_OK) return rc;
+  return ea_slice_sum(2, S, (int32_t)dd, 1.0f, p.dG_base, dG_part, dG, stream);
 }
 
 }  // extern "C"

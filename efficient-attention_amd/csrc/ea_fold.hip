@@ -9,6 +9,7 @@
 //             dGq [d, d] = sum_head dW_ext,q'[head] W_q[head]^T + sum_head dbias_q[head] b_q[head]^T;   d gq_b = sum_head dbias_q
 //             db [3C] = db_ext[:3C] + Gq^T dbias_q (q part) + Gk^T dbias_k (k part)
 #include "ea_common.h"
+#include "ea_f32_mm.h"
 
 namespace ea {
 
@@ -20,27 +21,54 @@ struct FoldP {
   // backward
   const float *dW_ext, *db_ext, *dbias_q, *dbias_k;   // [5C, ldw], [5C] | null, [h, d] x 2
   float *dW, *db, *dGq, *dGk, *dgqb, *dgkb;            // [3C, C], [3C] | null, [d, d] x 2, [d] x 2
+  float *dG_part, *dG_base;                            // [2][h FB_SPLIT][64 x 64] partials, [2][64 x 64] bias part
   long ldw;
   int C, h, d;
 };
 
+// 64 x 64 fp32 tile of a row-major matrix (row stride ld) -> LDS image [64][65]
+EA_DEV void fold_load(float* dst, const float* src, long ld, int tid) {
+  float4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 4;
+    v[u] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 4;
+    float* d = dst + r * 65 + c;
+    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+  }
+}
+
+// Forward.  blocks [0, 3C): cast rows of W;  then 2 h (C / 64) tile blocks: w_ext[3C + side C + head 64 + i][c] =
+// sum_j G_side[i][j] W[side C + head 64 + j][c] as one [64 x 64] x [64 x 64] product out of LDS (d = 64);  last block: b_ext
+// and the biases of the folded rows.  (A first version without tiles re-read the head's 64 weight rows for every output
+// row: 134 MB through the CUs' L2 ports, 40 us; the backward's dG part re-read a whole side per output row: 97 us.)
 template <typename E>
 __global__ __launch_bounds__(256) void fold_fwd_kernel(const FoldP p) {
-  const int C = p.C, d = p.d, tid = threadIdx.x;
-  const int r = blockIdx.x;
-  if (r < 5 * C) {
-    uint16_t* out = reinterpret_cast<uint16_t*>(p.w_ext) + (size_t)r * C;
-    if (r < 3 * C) {
-      for (int c = tid; c < C; c += 256) out[c] = E::from_f(p.W[(size_t)r * C + c]);
-    } else {
-      const int side = (r - 3 * C) / C, hr = (r - 3 * C) - side * C, head = hr / d, i = hr - head * d;
-      const float* G = (side ? p.Gk : p.Gq) + (size_t)i * d;
-      const float* Wh = p.W + ((size_t)side * C + (size_t)head * d) * C;
-      for (int c = tid; c < C; c += 256) {
-        float a = 0.f;
-        for (int j = 0; j < d; ++j) a = fmaf(G[j], Wh[(size_t)j * C + c], a);
-        out[c] = E::from_f(a);
-      }
+  __shared__ float Gs[64 * 65], Ws[64 * 65];
+  const int C = p.C, d = p.d, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nct = C / 64, ntile = 2 * p.h * nct;
+  const int blk = blockIdx.x;
+  if (blk < 3 * C) {
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.w_ext) + (size_t)blk * C;
+    for (int c = tid; c < C; c += 256) out[c] = E::from_f(p.W[(size_t)blk * C + c]);
+    return;
+  }
+  if (blk < 3 * C + ntile) {
+    const int t = blk - 3 * C, side = t / (p.h * nct), hr = t - side * p.h * nct, head = hr / nct, c0 = (hr - head * nct) * 64;
+    fold_load(Gs, side ? p.Gk : p.Gq, d, tid);
+    fold_load(Ws, p.W + ((size_t)side * C + (size_t)head * 64) * C + c0, C, tid);
+    __syncthreads();
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.w_ext) + ((size_t)3 * C + (size_t)side * C + (size_t)head * 64) * C + c0;
+    for (int tt = wave; tt < 16; tt += 4) {
+      const int m0 = (tt >> 2) * 16, n0 = (tt & 3) * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      tile_mm<false, false, 64>(acc, Gs, 65, Ws, 65, m0, n0, 64, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(m0 + 4 * g + r) * C + n0 + li] = E::from_f(acc[r]);
     }
     return;
   }
@@ -53,59 +81,79 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const FoldP p) {
     const int side = idx / (p.h * d), hr = idx - side * p.h * d, head = hr / d, i = hr - head * d;
     const float* G = (side ? p.Gk : p.Gq) + (size_t)i * d;
     float a = (side ? p.gkb : p.gqb)[i];
-    if (p.b)
-      for (int j = 0; j < d; ++j) a = fmaf(G[j], p.b[side * C + head * d + j], a);
+    if (p.b) {
+      const float* bh = p.b + side * C + head * 64;
+#pragma unroll                                              // (d = 64: every load of the dot product in flight at once)
+      for (int j = 0; j < 64; ++j) a = fmaf(G[j], bh[j], a);
+    }
     (side ? p.bias_k : p.bias_q)[head * d + i] = a;
   }
 }
 
-// blocks [0, 3C): rows of dW;  [3C, 3C + 2d): rows of dGq / dGk;  last: db, d gq_b, d gk_b
+// Backward.  blocks [0, C): copy the v rows of dW;  then 2 h FB_SPLIT tile blocks (side, head, group of column tiles): per
+// 64-column tile  dW[side C + head 64 + j][c] = dW_ext[same][c] + sum_i G[i][j] dW2[i][c]  and, accumulated over the
+// group's tiles, the partial  dG[i][j] += sum_c dW2[i][c] W[head 64 + j][c]  -> dG_part [2][h FB_SPLIT][64 x 64] (added by
+// ea_slice_sum together with the bias term the next 32 blocks leave in dG_base);  last block: d g_b, db.  (All scalar loops
+// have compile-time trip counts: a run-time loop of dependent-latency loads in ONE block was 30-50 us of each launch.)
+constexpr int FB_SPLIT = 8;          // (2: 35 us -- four dependent tile trips per block; 8: one trip, 64 partials per side)
 __global__ __launch_bounds__(256) void fold_bwd_kernel(const FoldP p) {
-  __shared__ float red[4][64];
-  const int C = p.C, d = p.d, h = p.h, tid = threadIdx.x;
+  __shared__ float Gs[64 * 65], Ws[64 * 65], Ds[64 * 65];
+  const int C = p.C, d = p.d, h = p.h, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int nct = C / 64, ntile = 2 * h * FB_SPLIT;
   const int blk = blockIdx.x;
-  if (blk < 3 * C) {
-    const int r = blk;
-    float* out = p.dW + (size_t)r * C;
-    const float* src = p.dW_ext + (size_t)r * p.ldw;
-    if (r >= 2 * C) {
-      for (int c = tid; c < C; c += 256) out[c] = src[c];
-      return;
-    }
-    const int side = r / C, hr = r - side * C, head = hr / d, j = hr - head * d;
-    const float* G = side ? p.Gk : p.Gq;                                 // column j of G
-    const float* dWf = p.dW_ext + ((size_t)3 * C + (size_t)side * C + (size_t)head * d) * p.ldw;
-    for (int c = tid; c < C; c += 256) {
-      float a = src[c];
-      for (int i = 0; i < d; ++i) a = fmaf(G[(size_t)i * d + j], dWf[(size_t)i * p.ldw + c], a);
-      out[c] = a;
-    }
+  if (blk < C) {
+    const int r = 2 * C + blk;
+    for (int c = tid; c < C; c += 256) p.dW[(size_t)r * C + c] = p.dW_ext[(size_t)r * p.ldw + c];
     return;
   }
-  if (blk < 3 * C + 2 * d) {
-    // dG_side[i][j] = sum_head sum_c dW_ext[3C + side C + head d + i][c] W[side C + head d + j][c] + sum_head dbias[head][i] b[..j]
-    const int side = (blk - 3 * C) / d, i = (blk - 3 * C) - side * d;
-    // a wave per (head, j) pair: both rows read along c by the 64 lanes (coalesced), fixed-order wave sum
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j = tid; j < 4 * 64; j += 256) red[j >> 6][j & 63] = 0.f;
-    __syncthreads();
-    for (int pair = wave; pair < h * d; pair += 4) {
-      const int head = pair / d, j = pair - head * d;
-      const float* dr = p.dW_ext + ((size_t)3 * C + (size_t)side * C + (size_t)head * d + i) * p.ldw;
-      const float* wr = p.W + ((size_t)side * C + (size_t)head * d + j) * C;
-      float a = 0.f;
-      for (int c = lane; c < C; c += 64) a = fmaf(dr[c], wr[c], a);
-      a = wave_sum(a);
-      if (lane == 0) {
-        if (p.b) a = fmaf((side ? p.dbias_k : p.dbias_q)[head * d + i], p.b[side * C + head * d + j], a);
-        red[wave][j] += a;                                   // (this wave only: heads of a j in increasing order)
+  if (blk < C + ntile) {
+    const int t = blk - C, side = t / (h * FB_SPLIT), hr = t - side * h * FB_SPLIT, head = hr / FB_SPLIT, part = hr - head * FB_SPLIT;
+    fold_load(Gs, side ? p.Gk : p.Gq, d, tid);
+    f32x4 dg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t row0 = (size_t)side * C + (size_t)head * 64;
+    for (int ct = part; ct < nct; ct += FB_SPLIT) {
+      const int c0 = ct * 64;
+      __syncthreads();
+      fold_load(Ds, p.dW_ext + ((size_t)3 * C + row0) * p.ldw + c0, p.ldw, tid);        // dW2[i][c]
+      fold_load(Ws, p.W + row0 * C + c0, C, tid);                                        // W[j][c]
+      __syncthreads();
+      for (int tt = wave, k = 0; tt < 16; tt += 4, ++k) {
+        const int m0 = (tt >> 2) * 16, n0 = (tt & 3) * 16;
+        // dG[i = m][j = n] += sum_c Ds[i][c] Ws[j][c]
+        tile_mm<false, true, 64>(dg[k], Ds, 65, Ws, 65, m0, n0, 64, lane);
+        // dW[j = m][c = n] = dW_ext[j][c] + sum_i Gs[i][j] Ds[i][c]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        tile_mm<true, false, 64>(acc, Gs, 65, Ds, 65, m0, n0, 64, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t row = row0 + m0 + 4 * g + r;
+          p.dW[row * C + c0 + n0 + li] = acc[r] + p.dW_ext[row * p.ldw + c0 + n0 + li];
+        }
       }
     }
-    __syncthreads();
-    if (tid < d) (side ? p.dGk : p.dGq)[(size_t)i * d + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    float* part_out = p.dG_part + ((size_t)side * h * FB_SPLIT + hr) * 64 * 64;
+    for (int tt = wave, k = 0; tt < 16; tt += 4, ++k) {
+      const int m0 = (tt >> 2) * 16, n0 = (tt & 3) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part_out[(m0 + 4 * g + r) * 64 + n0 + li] = dg[k][r];
+    }
     return;
   }
-  // d gq_b / d gk_b and the bias gradient of the qkv Linear
+  // the 32 blocks after the tiles: the bias part of dG (one output per thread)
+  if (blk < C + ntile + 32) {
+    const int idx = (blk - C - ntile) * 256 + tid;
+    const int side = idx / (d * d), ij = idx - side * d * d, i = ij / d, j = ij - i * d;
+    float a = 0.f;
+    if (p.b) {
+#pragma unroll 8
+      for (int head = 0; head < h; ++head) a = fmaf((side ? p.dbias_k : p.dbias_q)[head * d + i], p.b[side * C + head * d + j], a);
+    }
+    p.dG_base[idx] = a;
+    return;
+  }
+  // last block: d gq_b / d gk_b and the bias gradient of the qkv Linear
   for (int idx = tid; idx < 2 * d; idx += 256) {
     const int side = idx / d, i = idx - side * d;
     float a = 0.f;
@@ -119,22 +167,27 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(const FoldP p) {
         const int side = c / C, hr = c - side * C, head = hr / d, j = hr - head * d;
         const float* G = side ? p.Gk : p.Gq;
         const float* dbf = (side ? p.dbias_k : p.dbias_q) + head * d;
-        for (int i = 0; i < d; ++i) a = fmaf(G[(size_t)i * d + j], dbf[i], a);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) a = fmaf(G[(size_t)i * 64 + j], dbf[i], a);
       }
       p.db[c] = a;
     }
   }
 }
 
+int fold_bwd_parts(int heads) { return heads * FB_SPLIT; }
+
 int fold_dispatch(bool bwd, int dtype, const FoldP& p, hipStream_t st) {
-  if (p.C <= 0 || p.h <= 0 || p.d <= 0 || p.d > 64 || p.h * p.d != p.C || (p.C & 3)) return EA_E_UNSUPPORTED;
+  if (p.C <= 0 || p.h <= 0 || p.d != 64 || p.h * p.d != p.C) return EA_E_UNSUPPORTED;     // d = 64 tiles
+  const int nct = p.C / 64;
   if (!bwd) {
-    const dim3 grid((unsigned)(5 * p.C + 1)), block(256);
+    const dim3 grid((unsigned)(3 * p.C + 2 * p.h * nct + 1)), block(256);
     if (dtype == EA_BF16) hipLaunchKernelGGL(fold_fwd_kernel<BF16>, grid, block, 0, st, p);
     else if (dtype == EA_F16) hipLaunchKernelGGL(fold_fwd_kernel<F16>, grid, block, 0, st, p);
     else return EA_E_BADARG;
   } else {
-    hipLaunchKernelGGL(fold_bwd_kernel, dim3((unsigned)(3 * p.C + 2 * p.d + 1)), dim3(256), 0, st, p);
+    if ((p.ldw & 3) || ((uintptr_t)p.dW_ext & 15)) return EA_E_BADARG;
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3((unsigned)(p.C + 2 * p.h * FB_SPLIT + 32 + 1)), dim3(256), 0, st, p);
   }
   return (int)hipGetLastError();
 }

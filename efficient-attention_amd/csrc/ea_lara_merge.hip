@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void lara_merge_fwd_kernel(const MergeP p) {
 //   p_ml [BH,S,C,4] = (r, dbh, u, -), acc0..3 [BH,S,C,D] = (dkv, sum dZ q, sum t dt q, sum t q)
 //   -> r, dbh, u, dkk = dkv.kv [BH,C];  dkv, domq, dqbar = s (M1 - u M2), uq = u qbar [BH,C,D]
 // Same grid as the forward merge; D/4 consecutive lanes hold one landmark row.
+template <int SL>
 __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
   const int bh = blockIdx.x, tid = threadIdx.x;
   const int C = p.C, D = p.D, S = p.S;
@@ -112,23 +113,28 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
       if (p.dlp) p.dlp[o] = -r;
     }
   }
-  // four channels per thread (16-B loads); the D/4 lanes of a row sit in one wave, so
-  // dkk[c] = dkv[c] . kv[c] is a fixed-order shuffle reduction (no LDS atomics)
+  // four channels per thread (16-B loads), FOUR slice lanes per column (round 4: with B*h = 8 and S = 64 slices a thread
+  // that walked all slices alone made this a 26-70 us launch); lane sl adds slices sl, sl + 4, .. (four in flight), wave 0
+  // then adds the four lane sums in order -- for S <= 4 that is the plain slice order.  The D/4 lanes of a landmark row sit
+  // in wave 0, so dkk[c] = dkv[c] . kv[c] is a fixed-order shuffle reduction (no LDS atomics).
+  constexpr int NC = 256 / SL;                             // columns per block (SL = 1: few slices, no lane split)
+  __shared__ float4 red[4][SL][NC];
+  __shared__ float redu[SL][NC];
   const int lpr = D >> 2;                                  // lanes per landmark row: 16 (D = 64) or 8
   const int n4 = (C * D) >> 2;
-  const int i4 = blockIdx.y * 256 + tid;
+  const int col = tid % NC, sl = tid / NC;
+  const int i4 = blockIdx.y * NC + col;
   const bool ok = i4 < n4;
   const int e = (ok ? i4 : 0) * 4;
   const int c = e / D, j = e - c * D;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
   float u = 0.f;
-  // slices in batches of 4, all (up to 17) loads of a batch in flight; same summation order as a plain loop
-  for (int s0 = 0; s0 < S; s0 += 4) {
+  for (int s0 = sl; s0 < S; s0 += 4 * SL) {
     float4 v0[4], v1[4], v2[4], v3[4];
     float uu[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const size_t slot = ((size_t)bh * S + min(s0 + b, S - 1)) * C + c;
+      const size_t slot = ((size_t)bh * S + min(s0 + SL * b, S - 1)) * C + c;
       const size_t o4 = slot * D + j;
       v0[b] = *reinterpret_cast<const float4*>(p.acc0 + o4);
       v1[b] = *reinterpret_cast<const float4*>(p.acc1 + o4);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (s0 + b < S) {
+      if (s0 + SL * b < S) {
         a0.x += v0[b].x; a0.y += v0[b].y; a0.z += v0[b].z; a0.w += v0[b].w;
         a1.x += v1[b].x; a1.y += v1[b].y; a1.z += v1[b].z; a1.w += v1[b].w;
         if (p.has_t) {
@@ -150,6 +156,21 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
         }
       }
     }
+  }
+  if (SL > 1) {
+    red[0][sl][col] = a0; red[1][sl][col] = a1; red[2][sl][col] = a2; red[3][sl][col] = a3;
+    redu[sl][col] = u;
+    __syncthreads();
+    if (sl != 0) return;
+  }
+#pragma unroll
+  for (int l = 1; l < SL; ++l) {
+    const float4 b0 = red[0][l][col], b1 = red[1][l][col], b2 = red[2][l][col], b3 = red[3][l][col];
+    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+    a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+    u += redu[l][col];
   }
   const size_t o = (size_t)bh * C * D + e;
   const float4 kv4 = *reinterpret_cast<const float4*>(p.kv + o);
@@ -174,7 +195,9 @@ __global__ __launch_bounds__(256) void lara_merge_bwd_kernel(const MergeP p) {
 int lara_merge_dispatch(bool bwd, const MergeP& p, hipStream_t st) {
   if (p.C > 128) return EA_E_UNSUPPORTED;
   const dim3 grid((unsigned)p.BH, (unsigned)((p.C * p.D / 4 + 255) / 256));
-  if (bwd) hipLaunchKernelGGL(lara_merge_bwd_kernel, grid, dim3(256), 0, st, p);
+  const dim3 grid_b((unsigned)p.BH, (unsigned)((p.C * p.D / 4 + 63) / 64));       // 64 columns x 4 slice lanes per block
+  if (bwd && p.S > 4) hipLaunchKernelGGL(lara_merge_bwd_kernel<4>, grid_b, dim3(256), 0, st, p);
+  else if (bwd) hipLaunchKernelGGL(lara_merge_bwd_kernel<1>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(lara_merge_fwd_kernel, grid, dim3(256), 0, st, p);
   return (int)hipGetLastError();
 }

@@ -695,14 +695,15 @@ class FoldedQkvFn(torch.autograd.Function):
         dbk = zq if dbias_k is None else dbias_k.float().contiguous()
         dW = torch.empty((3 * C, C), dtype=torch.float32, device=dev)
         db = torch.empty((3 * C,), dtype=torch.float32, device=dev) if b is not None else None
-        dGq = torch.empty((d, d), dtype=torch.float32, device=dev)
-        dGk = torch.empty_like(dGq)
+        dG = torch.empty((2, d, d), dtype=torch.float32, device=dev)
+        S = nv.lib().ea_lara_fold_parts(heads)
+        scratch = torch.empty(((2 * S + 2) * d * d,), dtype=torch.float32, device=dev)
         dgqb = torch.empty((d,), dtype=torch.float32, device=dev)
         dgkb = torch.empty_like(dgqb)
         nv.call("ea_lara_fold_bwd", C, heads, nv.ptr(W), nv.ptr(b), nv.ptr(Gq), nv.ptr(Gk), nv.ptr(dW_ext), dW_ext.stride(0),
-                nv.ptr(db_ext), nv.ptr(dbq), nv.ptr(dbk), nv.ptr(dW), nv.ptr(db), nv.ptr(dGq), nv.ptr(dgqb), nv.ptr(dGk),
+                nv.ptr(db_ext), nv.ptr(dbq), nv.ptr(dbk), nv.ptr(dW), nv.ptr(db), nv.ptr(dG), nv.ptr(scratch), nv.ptr(dgqb),
                 nv.ptr(dgkb), nv.stream())
-        outs = [dW, db, dGq, dgqb, dGk, dgkb]
+        outs = [dW, db, dG[0], dgqb, dG[1], dgkb]
         outs = [None if (o is None or t is None) else o.to(t) for o, t in zip(outs, pd)]
         return (dx,) + tuple(outs) + (None, None)
 

@@ -120,7 +120,7 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         group of output columns of the same GEMM instead of a K = d GEMM over B*h*N strided rows)."""
         B, N, C = x.shape
         h, d = self.num_heads, self.head_dim
-        if (_ops.USE_FOLD_KERNELS and x.is_cuda and torch.is_autocast_enabled() and d <= 64
+        if (_ops.USE_FOLD_KERNELS and x.is_cuda and torch.is_autocast_enabled() and d == 64
                 and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
                 and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0):
             # extended weight built (and differentiated) by one HIP launch each way: ea_lara_fold_fwd / _bwd

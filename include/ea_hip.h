@@ -296,12 +296,15 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
  *        bias_q / bias_k [heads, d] fp32 = G b_head + g_b: the bias of a folded row (consumed by ea_lara_segment_*).
  *        W [3C, C], b [3C] (may be NULL), Gq / Gk [d, d], gq_b / gk_b [d]: fp32 parameters.
  *   bwd: from dW_ext [5C, ldw] / db_ext [5C] (the weight / bias gradient of the extended projection, e.g. ea_wgrad's sums)
- *        and dbias_q / dbias_k [heads, d]: dW [3C, C], db [3C] (NULL when b is), dGq, dGk [d, d], dgq_b, dgk_b [d]. */
+ *        and dbias_q / dbias_k [heads, d]: dW [3C, C], db [3C] (NULL when b is), dG [2, d, d] = (dGq, dGk), dgq_b, dgk_b [d].
+ *        dG_part: scratch of (2 * ea_lara_fold_parts(heads) + 2) * d * d floats (per-head partials of dG; the entry point
+ *        adds them up with ea_slice_sum).  d = 64 (EA_E_UNSUPPORTED otherwise). */
 int ea_lara_fold_fwd(int32_t dtype, int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* gq_b,
                      const float* Gk, const float* gk_b, void* w_ext, void* b_ext, float* bias_q, float* bias_k, void* stream);
+int32_t ea_lara_fold_parts(int32_t heads);
 int ea_lara_fold_bwd(int32_t C, int32_t heads, const float* W, const float* b, const float* Gq, const float* Gk,
                      const float* dW_ext, int64_t ldw, const float* db_ext, const float* dbias_q, const float* dbias_k,
-                     float* dW, float* db, float* dGq, float* dgq_b, float* dGk, float* dgk_b, void* stream);
+                     float* dW, float* db, float* dG, float* dG_part, float* dgq_b, float* dgk_b, void* stream);
 
 /* ---- Performer in EXACT fp32 arithmetic (ea_performer_f32.hip; round 4) --------------------
  * The reference computes its linear attention in full precision whatever the AMP state (kernelized_attention.py:116-121
