@@ -828,6 +828,77 @@ int ea_lara_segment_bwd(const ea_geom* g, const ea_t4* q2, const ea_t4* k2, cons
 
 }  // extern "C"
 
+// ---- LARA 'adaptive-1d' with the generator Linear inside the segment kernels (ea_lara_seglin.hip) ----
+namespace ea {
+struct SegLinP {
+  char *q, *k;
+  int64_t q_sb, q_sh, q_sn, k_sb, k_sh, k_sn;
+  char *dq, *dk;
+  int64_t dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn;
+  const float *Gq, *Gk, *gqb, *gkb;
+  const float *lnq_w, *lnq_b, *lnk_w, *lnk_b;
+  float *qbar, *kbar;
+  const float *d_qbar, *d_kbar;
+  float* part;
+  void* stats;
+  float* dG_part;
+  int B, H, N, L, segs, nshort, groups, seg_per_group, cgroups, cseg_per_group;
+};
+int seglin_groups(int BH, int L);
+int seglin_dispatch(int which, const SegLinP& p, int dtype, hipStream_t st);
+}  // namespace ea
+
+static int fill_seglin(const ea_geom* g, ea::SegLinP& p) {
+  SegP sp = {};
+  const int rc = fill_seg(g, sp);
+  if (rc != EA_OK) return rc;
+  if (g->D != 64) return EA_E_UNSUPPORTED;
+  p.B = sp.B; p.H = sp.H; p.N = sp.N; p.L = sp.L; p.segs = sp.segs; p.nshort = sp.nshort;
+  return EA_OK;
+}
+
+extern "C" {
+
+int32_t ea_lara_seglin_groups(const ea_geom* g) {
+  ea::SegLinP p = {};
+  const int rc = fill_seglin(g, p);
+  return rc != EA_OK ? rc : ea::seglin_groups(p.B * p.H, p.L);
+}
+
+int ea_lara_seglin_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                       float* qbar, float* kbar, void* stream) {
+  ea::SegLinP p = {};
+  const int rc = fill_seglin(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok32(q, 64, g->N) || !t4_ok32(k, 64, g->N) || !Gq || !gq_b || !Gk || !gk_b || !lnq_w || !lnq_b || !lnk_w || !lnk_b ||
+      !qbar || !kbar) return EA_E_BADARG;
+  SET3(q, q); SET3(k, k);
+  p.Gq = Gq; p.gqb = gq_b; p.Gk = Gk; p.gkb = gk_b; p.lnq_w = lnq_w; p.lnq_b = lnq_b; p.lnk_w = lnk_w; p.lnk_b = lnk_b;
+  p.qbar = qbar; p.kbar = kbar;
+  return ea::seglin_dispatch(0, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_seglin_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                       const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
+                       float* stats, void* stream) {
+  ea::SegLinP p = {};
+  int rc = fill_seglin(g, p);
+  if (rc != EA_OK) return rc;
+  if (!t4_ok32(q, 64, g->N) || !t4_ok32(k, 64, g->N) || !t4_ok32(dq, 64, g->N) || !t4_ok32(dk, 64, g->N) || !Gq || !gq_b || !Gk ||
+      !gk_b || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !d_qbar || !d_kbar || !part || !dG_part || !stats || ((uintptr_t)stats & 15))
+    return EA_E_BADARG;
+  SET3(q, q); SET3(k, k); SET3(dq, dq); SET3(dk, dk);
+  p.Gq = Gq; p.gqb = gq_b; p.Gk = Gk; p.gkb = gk_b; p.lnq_w = lnq_w; p.lnq_b = lnq_b; p.lnk_w = lnk_w; p.lnk_b = lnk_b;
+  p.d_qbar = d_qbar; p.d_kbar = d_kbar; p.part = part; p.dG_part = dG_part; p.stats = stats;
+  rc = ea::seglin_dispatch(1, p, g->dtype, (hipStream_t)stream);
+  if (rc != EA_OK) return rc;
+  return ea::seglin_dispatch(2, p, g->dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
 // ---- mu networks: per-row Linear (+ LayerNorm) on the chunk means ----
 extern "C" {
 

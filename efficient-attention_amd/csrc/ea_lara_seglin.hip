@@ -1,0 +1,434 @@
+// ea_lara_seglin.hip -- LARA 'adaptive-1d' proposals (lara.py:56-63,84-127) WITHOUT the folded projection (round 4):
+//     q_bar_l = mean_{n in segment l} LayerNorm(G_q q_n + g_q),     k_bar_l likewise,
+// generator Linear, LayerNorm and segment mean in one pass over the stored q / k rows; nothing token-sized is written in the
+// forward, and the backward writes dq / dk (accumulated into the attention core's gradient) and the generator gradients only.
+//
+// Rounds 1-3 folded the generator Linear into the qkv projection (W' = G W_head: two more groups of output columns).  That
+// made every one of the three 512-wide library GEMMs of the layer (forward, input gradient, weight gradient) 5C instead of 3C
+// columns wide: +67 % of their FLOPs, ~250 us of the 1.27 ms cfg5 step -- for a product that costs 16 k FLOPs per token-head.
+// Here the [64 x 64] product runs on the MFMA inside the segment kernels; the projection stays 3C wide.
+//
+// Layouts (v_mfma_f32_16x16x32, D[m = 4g + r][n = li]):
+//   * forward and the dq / dk pass: z^T[out][token] = G X^T -- A = rows of G (resident, 32 VGPRs), B = the token rows as
+//     they are loaded (lane (g, li): token li, channels 32 ks + 8 g ..).  A lane owns 16 channels of ONE token: LayerNorm
+//     statistics are in-lane sums + two v_permlane swaps.  d x^T = G^T d z^T chains register-for-register: a lane's D values
+//     of two adjacent out-tiles are exactly its eight k-slots of the next MFMA (the P -> PV trick of the window kernels).
+//   * the dG pass: z[token][out] (operands swapped) -- a lane owns one out-channel of FOUR tokens, LayerNorm statistics are
+//     16-lane DPP sums, and dz as well as X (brought into the same layout by four exact MFMAs with a 0 / 1 pattern) are the
+//     k-slots of dG[out][in] = sum_tokens dz[token][out] x[token][in] without any LDS transpose.
+// One wave per (b, h, side, segment) -- the dG pass: per group of segments, its [64 x 64] partial in registers.
+#include "ea_lara_segment.h"
+
+namespace ea {
+
+struct SegLinP {
+  char *q, *k;                       // stored q / k rows (element type), [B,H,N,64] views
+  int64_t q_sb, q_sh, q_sn, k_sb, k_sh, k_sn;
+  char *dq, *dk;                     // backward: accumulated into
+  int64_t dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn;
+  const float *Gq, *Gk, *gqb, *gkb;  // generator Linear [64, 64] (out, in), bias [64]
+  const float *lnq_w, *lnq_b, *lnk_w, *lnk_b;   // LayerNorm weight / bias [64]
+  float *qbar, *kbar;                // forward outputs [B*H, L, 64]
+  const float *d_qbar, *d_kbar;      // backward inputs
+  float* part;                       // backward: [B*H*groups, 2, 4, 64] partial sums (d ln_w, d ln_b, d g_b, unused)
+  f32x4* stats;                      // backward scratch [B*H, 2, N]: (mean, rstd, mean(a xhat), -) of every token's LayerNorm
+  float* dG_part;                    // backward: [nG, 2, 64, 64] partial sums of dG (nG = B*H*groups)
+  int B, H, N, L, segs, nshort, groups, seg_per_group, cgroups, cseg_per_group;
+};
+
+namespace {
+
+template <typename E> struct GenA {      // G as the A operand of z^T = G X^T: lane (g, li): G[16 mt + li][32 ks + 8 g ..]
+  typename E::x8 a[4][2];
+  EA_DEV void load(const float* G, int g, int li) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* s = G + (16 * mt + li) * 64 + 32 * ks + 8 * g;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
+        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[mt][ks] = as_x8<E>(pack8<E>(f));
+      }
+  }
+};
+
+EA_DEV int seg_start(const SegLinP& p, int l) { return l < p.nshort ? l * p.segs : p.nshort * p.segs + (l - p.nshort) * (p.segs + 1); }
+EA_DEV int seg_len(const SegLinP& p, int l) { return l < p.nshort ? p.segs : p.segs + 1; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// token-column passes: forward (BWD = false) and the dq / dk pass (BWD = true)
+template <typename E, bool BWD>
+__global__ __launch_bounds__(256) void seglin_col_kernel(const SegLinP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  // a wave = (b, h, side, group of consecutive segments): the generator operands (64 + 64 registers' worth of loads, the
+  // transposed one a 64-way gather) are fetched once per wave, not once per 84-token segment
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= p.B * p.H * p.cgroups * 2) return;
+  const int side = unit & 1, rest = unit >> 1;
+  const int grp = rest % p.cgroups, bh = rest / p.cgroups, b = bh / p.H, h = bh - b * p.H;
+  const char* src = side ? p.k + (b * p.k_sb + h * p.k_sh) * 2 : p.q + (b * p.q_sb + h * p.q_sh) * 2;
+  const int sn = (int)(side ? p.k_sn : p.q_sn);
+  const float* G = side ? p.Gk : p.Gq;
+  GenA<E> ga;
+  ga.load(G, g, li);
+  // per-lane channel constants: channel 16 mt + 4 g + r
+  float gb[4][4], lw[4][4], lb[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int ch = 16 * mt + 4 * g;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>((side ? p.gkb : p.gqb) + ch);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>((side ? p.lnk_w : p.lnq_w) + ch);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>((side ? p.lnk_b : p.lnq_b) + ch);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gb[mt][r] = v0[r]; lw[mt][r] = v1[r]; lb[mt][r] = v2[r]; }
+  }
+  // backward state
+  typename E::x8 gt[4][2];             // G^T as the A operand of dx^T = G^T dz^T: lane (g, li): in 16 mi + li, k-slots (out)
+  float a_[4][4], dy[4][4], s1 = 0.f;
+  char* dst = nullptr;
+  int dsn = 0;
+  if constexpr (BWD) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int out = 16 * (2 * kk + (j >> 2)) + 4 * g + (j & 3);      // k-slot j <-> D value r = j & 3 of out-tile 2 kk + (j >> 2)
+          f[j] = G[out * 64 + 16 * mi + li];
+        }
+        gt[mi][kk] = as_x8<E>(pack8<E>(f));
+      }
+    dst = side ? p.dk + (b * p.dk_sb + h * p.dk_sh) * 2 : p.dq + (b * p.dq_sb + h * p.dq_sh) * 2;
+    dsn = (int)(side ? p.dk_sn : p.dq_sn);
+  }
+  const int l0 = grp * p.cseg_per_group, l1 = min(p.L, l0 + p.cseg_per_group);
+  for (int l = l0; l < l1; ++l) {
+  const int s0 = seg_start(p, l), len = seg_len(p, l);
+  const float inv_len = 1.f / (float)len;
+  if constexpr (BWD) {
+    const float* dbar = (side ? p.d_kbar : p.d_qbar) + ((size_t)bh * p.L + l) * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dbar + 16 * mt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dy[mt][r] = v[r] * inv_len;
+        a_[mt][r] = dy[mt][r] * lw[mt][r];
+        s += a_[mt][r];
+      }
+    }
+    s1 = quad_sum(s) * (1.f / 64);
+  }
+  float accy[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) accy[mt][r] = 0.f;
+
+  const int steps = (len + 15) >> 4;
+  // rows of the NEXT TWO steps in flight (a wave is one of 8 per CU: with one step ahead the passes ran at 2-3 TB/s), and in
+  // the backward the gradient row piece (channels 16 g .. + 15) the next step adds to
+  u32x4 nxa[2], nxb[2], nog[2];
+  auto issue = [&](int it, u32x4* dstv) {
+    const int tok_ = s0 + min(it * 16 + li, len - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) dstv[ks] = ldg16(src + (tok_ * sn + 32 * ks + 8 * g) * 2);
+  };
+  auto issue_g = [&](int it) {
+    if constexpr (BWD) {
+      const int tok_ = s0 + min(it * 16 + li, len - 1);
+      nog[0] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g) * 2);
+      nog[1] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g + 8) * 2);
+    }
+  };
+  issue(0, nxa);
+  issue_g(0);
+  issue(1, nxb);                                   // (clamped to the segment: a harmless re-read when steps == 1)
+  for (int it = 0; it < steps; ++it) {
+    const typename E::x8 bx0 = as_x8<E>(nxa[0]), bx1 = as_x8<E>(nxa[1]);
+    const u32x4 oldg[2] = {nog[0], nog[1]};
+    const int off = it * 16 + li;
+    const bool valid = off < len;
+    const int tok = s0 + min(off, len - 1);
+    nxa[0] = nxb[0]; nxa[1] = nxb[1];
+    issue(it + 2, nxb);
+    issue_g(it + 1);
+    f32x4 z[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      z[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      z[mt] = E::mma(ga.a[mt][0], bx0, z[mt]);
+      z[mt] = E::mma(ga.a[mt][1], bx1, z[mt]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { z[mt][r] += gb[mt][r]; s += z[mt][r]; }
+    const float mean = quad_sum(s) * (1.f / 64);
+    float v = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { z[mt][r] -= mean; v += z[mt][r] * z[mt][r]; }
+    const float rstd = rsqrtf(quad_sum(v) * (1.f / 64) + 1e-5f);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[mt][r] *= rstd;                   // z = xhat from here on
+    if constexpr (!BWD) {
+      const float w = valid ? 1.f : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accy[mt][r] += w * (lw[mt][r] * z[mt][r] + lb[mt][r]);
+    } else {
+      float s2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s2 += a_[mt][r] * z[mt][r];
+      s2 = quad_sum(s2) * (1.f / 64);
+      // the token's LayerNorm statistics for the dG pass (which would otherwise redo them with 16-lane reductions)
+      if (g == 0 && valid) p.stats[((size_t)(bh * 2 + side) * p.N + tok)] = f32x4{mean, rstd, s2, 0.f};
+      const float w = valid ? rstd : 0.f;
+      float dz[4][4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dz[mt][r] = w * (a_[mt][r] - s1 - z[mt][r] * s2);
+        }
+      // dx^T[in][token] = G^T dz^T: the D values of out-tiles (2 kk, 2 kk + 1) are the k-slots of step kk
+      f32x4 dx[4];
+      const typename E::x8 bz0 = as_x8<E>(u32x4{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[0][2], dz[0][3]),
+                                               pack2<E>(dz[1][0], dz[1][1]), pack2<E>(dz[1][2], dz[1][3])});
+      const typename E::x8 bz1 = as_x8<E>(u32x4{pack2<E>(dz[2][0], dz[2][1]), pack2<E>(dz[2][2], dz[2][3]),
+                                               pack2<E>(dz[3][0], dz[3][1]), pack2<E>(dz[3][2], dz[3][3])});
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        dx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dx[mi] = E::mma(gt[mi][0], bz0, dx[mi]);
+        dx[mi] = E::mma(gt[mi][1], bz1, dx[mi]);
+      }
+      // accumulate into the gradient rows.  The four lanes of a token trade their 4-channel pieces (quad_transpose) so that a
+      // lane owns 16 contiguous channels: two 16-byte accesses, the row's 128-byte line complete per instruction pair (8-byte
+      // pieces of four different lines per instruction ran this pass at 2 TB/s)
+      float f[16];
+      quad_transpose_f32(dx, f);
+      if (valid) {
+        float o[16];
+        unpack8<E>(oldg[0], o); unpack8<E>(oldg[1], o + 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] += f[i];
+        stg16(dst + ((size_t)tok * dsn + 16 * g) * 2, pack8<E>(o));
+        stg16(dst + ((size_t)tok * dsn + 16 * g + 8) * 2, pack8<E>(o + 8));
+      }
+    }
+  }
+  if constexpr (!BWD) {
+    float* out = (side ? p.kbar : p.qbar) + ((size_t)bh * p.L + l) * 64;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = group_sum<16>(accy[mt][r]) * inv_len;
+      if (li == 0) *reinterpret_cast<f32x4*>(out + 16 * mt + 4 * g) = o;
+    }
+  }
+  }  // segments of the group
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// token-row pass: dG partials.  z[token = 4 g + r][out = 16 nt + li]
+template <typename E>
+__global__ __launch_bounds__(256) void seglin_dg_kernel(const SegLinP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  // a unit = (b, h, group of segments, side, half of the out-tiles): two waves share a (group, side) -- 32 accumulator
+  // registers each instead of 64, which pays for the prefetch of the next step's rows
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= p.B * p.H * p.groups * 4) return;
+  const int half = unit & 1, side = (unit >> 1) & 1, rest = unit >> 2;
+  const int grp = rest % p.groups, bh = rest / p.groups, b = bh / p.H, h = bh - b * p.H;
+  const char* src = side ? p.k + (b * p.k_sb + h * p.k_sh) * 2 : p.q + (b * p.q_sb + h * p.q_sh) * 2;
+  const int sn = (int)(side ? p.k_sn : p.q_sn);
+  const float* G = side ? p.Gk : p.Gq;
+  // B operand of z = X G^T: lane (g, li): G[16 nt + li][32 ks + 8 g ..] -- the same registers as GenA
+  GenA<E> gbop;
+  gbop.load(G, g, li);
+  // 0 / 1 pattern that brings X into the D layout: XD[token][in = 16 it + li] = sum_ch X[token][ch] I[ch][16 it + li];
+  // only k-step ks = it >> 1 has a non-zero: slot j of lane (g, li) is channel 32 ks + 8 g + j
+  typename E::x8 iop[4];
+  {
+    const uint32_t one = (uint32_t)E::from_f(1.f);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int j = 16 * (it & 1) + li - 8 * g;                       // the slot that holds channel 16 it + li, if any
+      u32x4 w = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = (j == 2 * q ? one : 0u) | (j == 2 * q + 1 ? one << 16 : 0u);
+      iop[it] = as_x8<E>(w);
+    }
+  }
+  float gb[4], lw[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    gb[nt] = (side ? p.gkb : p.gqb)[16 * nt + li];
+    lw[nt] = (side ? p.lnk_w : p.lnq_w)[16 * nt + li];
+  }
+  __shared__ f32x4 stat_lds[4][32];
+  f32x4* stw = stat_lds[wave];
+  f32x4 dg[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dg[nt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // partial sums of d ln_w, d ln_b, d g_b over the group's tokens: lane (g, li) owns channel 16 nt + li of rows 4 g + r
+  float p_dw[4] = {0.f, 0.f, 0.f, 0.f}, p_db[4] = {0.f, 0.f, 0.f, 0.f}, p_dgb[4] = {0.f, 0.f, 0.f, 0.f};
+  const int l0 = grp * p.seg_per_group, l1 = min(p.L, l0 + p.seg_per_group);
+  for (int l = l0; l < l1; ++l) {
+    const int s0 = seg_start(p, l), len = seg_len(p, l);
+    const float inv_len = 1.f / (float)len;
+    const float* dbar = (side ? p.d_kbar : p.d_qbar) + ((size_t)bh * p.L + l) * 64;
+    float a_[4], dyv[4], s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { dyv[nt] = dbar[16 * nt + li] * inv_len; a_[nt] = dyv[nt] * lw[nt]; s += a_[nt]; p_db[nt] += dyv[nt] * (float)len; }
+    const float s1 = group_sum<16>(s) * (1.f / 64);
+    const int steps = (len + 31) >> 5;
+    u32x4 nx[2][2];
+    f32x4 nst;                                      // statistics of token (step base + (lane & 31)): one coalesced load per step
+    const f32x4* stb = p.stats + (size_t)(bh * 2 + side) * p.N + s0;
+    auto issue = [&](int i2) {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const int tok = s0 + min(i2 * 32 + tl * 16 + li, len - 1);    // A-operand row li of tile tl
+        nx[tl][0] = ldg16(src + (tok * sn + 8 * g) * 2);
+        nx[tl][1] = ldg16(src + (tok * sn + 32 + 8 * g) * 2);
+      }
+      nst = stb[min(i2 * 32 + (lane & 31), len - 1)];
+    };
+    issue(0);
+    for (int it2 = 0; it2 < steps; ++it2) {
+      u32x4 pz[2], px[2][2];                                          // packed pieces of the two 16-token tiles
+      const u32x4 cur[2][2] = {{nx[0][0], nx[0][1]}, {nx[1][0], nx[1][1]}};
+      // the step's 32 statistics go through this wave's LDS slot: a lane needs those of its four rows 4 g + r of either tile
+      // (fetching them from global memory where they are needed was a dependent round trip per tile: 110 -> 161 us)
+      if (lane < 32) stw[lane] = nst;
+      if (it2 + 1 < steps) issue(it2 + 1);
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const int base = it2 * 32 + tl * 16;
+        const typename E::x8 ax0 = as_x8<E>(cur[tl][0]);
+        const typename E::x8 ax1 = as_x8<E>(cur[tl][1]);
+        f32x4 z[4], xd[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          z[nt] = E::mma(ax0, gbop.a[nt][0], z[nt]);
+          z[nt] = E::mma(ax1, gbop.a[nt][1], z[nt]);
+          xd[nt] = E::mma((nt >> 1) ? ax1 : ax0, iop[nt], f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        // rows r = tokens base + 4 g + r; their LayerNorm statistics (mean, rstd, mean(a xhat)) come from the dq / dk pass
+        float dzr[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 st = stw[tl * 16 + 4 * g + r];
+          const bool live = base + 4 * g + r < len;
+          const float w = live ? st[1] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const float xh = (z[nt][r] + gb[nt] - st[0]) * st[1];
+            dzr[nt][r] = w * (a_[nt] - s1 - xh * st[2]);
+            if (live) p_dw[nt] += dyv[nt] * xh;
+            p_dgb[nt] += dzr[nt][r];
+          }
+        }
+        // this tile's four tokens of the lane = four k-slots: out-tile nt of dz, in-tile nt of X
+        // (this wave's half of the out-tiles: 2 half, 2 half + 1)
+        if (half == 0)
+          pz[tl] = u32x4{pack2<E>(dzr[0][0], dzr[0][1]), pack2<E>(dzr[0][2], dzr[0][3]), pack2<E>(dzr[1][0], dzr[1][1]), pack2<E>(dzr[1][2], dzr[1][3])};
+        else
+          pz[tl] = u32x4{pack2<E>(dzr[2][0], dzr[2][1]), pack2<E>(dzr[2][2], dzr[2][3]), pack2<E>(dzr[3][0], dzr[3][1]), pack2<E>(dzr[3][2], dzr[3][3])};
+        px[tl][0] = u32x4{pack2<E>(xd[0][0], xd[0][1]), pack2<E>(xd[0][2], xd[0][3]), pack2<E>(xd[1][0], xd[1][1]), pack2<E>(xd[1][2], xd[1][3])};
+        px[tl][1] = u32x4{pack2<E>(xd[2][0], xd[2][1]), pack2<E>(xd[2][2], xd[2][3]), pack2<E>(xd[3][0], xd[3][1]), pack2<E>(xd[3][2], xd[3][3])};
+      }
+      // dG[out 16 nt + ..][in 16 it + ..] += sum over the 32 tokens: k-slots (tile 0 rows 4 g + r, tile 1 rows 4 g + r)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int qn = nt * 2;
+        const typename E::x8 aop = as_x8<E>(u32x4{pz[0][qn], pz[0][qn + 1], pz[1][qn], pz[1][qn + 1]});
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int hi_ = it >> 1, qi = (it & 1) * 2;
+          const typename E::x8 bop = as_x8<E>(u32x4{px[0][hi_][qi], px[0][hi_][qi + 1], px[1][hi_][qi], px[1][hi_][qi + 1]});
+          dg[nt][it] = E::mma(aop, bop, dg[nt][it]);
+        }
+      }
+    }
+  }
+  if (half == 0) {
+    // [group][side][4][64]: (d ln_w, d ln_b, d g_b, 0); the four lane rows g hold different tokens of the same channel
+    float* pr = p.part + (((size_t)bh * p.groups + grp) * 2 + side) * 4 * 64;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float v0 = quad_sum(p_dw[nt]), v2 = quad_sum(p_dgb[nt]);
+      if (g == 0) {
+        pr[16 * nt + li] = v0;
+        pr[64 + 16 * nt + li] = p_db[nt];
+        pr[128 + 16 * nt + li] = v2;
+        pr[192 + 16 * nt + li] = 0.f;
+      }
+    }
+  }
+  float* out = p.dG_part + (((size_t)bh * p.groups + grp) * 2 + side) * 64 * 64;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(16 * (2 * half + nt) + 4 * g + r) * 64 + 16 * it + li] = dg[nt][it][r];
+}
+
+int seglin_groups(int BH, int L) {
+  // ~2048 waves for the dG pass (two per (group, side)), every wave at least one segment
+  int per = (BH * 4 * L + 2047) / 2048;
+  if (per < 1) per = 1;
+  return (L + per - 1) / per;
+}
+
+int seglin_dispatch(int which, const SegLinP& p0, int dtype, hipStream_t st) {
+  SegLinP p = p0;
+  p.groups = seglin_groups(p.B * p.H, p.L);
+  p.seg_per_group = (p.L + p.groups - 1) / p.groups;
+  {
+    // forward / dq-dk passes: ~4096 waves (two resident rounds of 8 per CU), every wave at least one segment
+    int per = (int)(((long)p.B * p.H * 2 * p.L + 4095) / 4096);
+    if (per < 1) per = 1;
+    p.cgroups = (p.L + per - 1) / per;
+    p.cseg_per_group = (p.L + p.cgroups - 1) / p.cgroups;
+  }
+  const long units = (long)p.B * p.H * p.cgroups * 2;
+  const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+  const long gunits = (long)p.B * p.H * p.groups * 4;
+  const dim3 ggrid((unsigned)((gunits + 3) / 4));
+#define EA_SL(E_)                                                                                                  \
+  do {                                                                                                             \
+    if (which == 0) hipLaunchKernelGGL((seglin_col_kernel<E_, false>), grid, block, 0, st, p);                    \
+    else if (which == 1) hipLaunchKernelGGL((seglin_col_kernel<E_, true>), grid, block, 0, st, p);                \
+    else hipLaunchKernelGGL((seglin_dg_kernel<E_>), ggrid, block, 0, st, p);                                      \
+  } while (0)
+  if (dtype == EA_BF16) EA_SL(BF16);
+  else if (dtype == EA_F16) EA_SL(F16);
+  else return EA_E_UNSUPPORTED;
+#undef EA_SL
+  return (int)hipGetLastError();
+}
+
+}  // namespace ea

@@ -145,6 +145,9 @@ SIGNATURES = {
     "ea_performer_bwd_q": [_PG, _T, _T, _T, _P, _P, _P, _T, _P, _P, _P, _P],
     "ea_performer_bwd_qstats": [_PG, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_performer_bwd_k": [_PG, _T, _T, _P, _P, _P, _P, _P, _T, _T, _P],
+    "ea_lara_seglin_groups": [_G],
+    "ea_lara_seglin_fwd": [_G, _T, _T] + [_P] * 11,
+    "ea_lara_seglin_bwd": [_G, _T, _T] + [_P] * 10 + [_T, _T, _P, _P, _P, _P],
     "ea_lara_fold_fwd": [_I, _I, _I] + [_P] * 11,
     "ea_lara_fold_parts": [_I],
     "ea_lara_fold_bwd": [_I, _I, _P, _P, _P, _P, _P, _L] + [_P] * 10,

@@ -641,6 +641,62 @@ class SegmentLnMeanFn(torch.autograd.Function):
         return ((buf if own else None), None, None, None) + grads
 
 
+USE_SEGLIN = os.environ.get("EA_SEGLIN", "1") == "1"
+
+
+class SegLinLnMeanFn(torch.autograd.Function):
+    """LARA 'adaptive-1d' proposals (lara.py:56-63,84-127) from the stored q / k rows of qkv5 [B,N,3,h,64]: generator Linear,
+    LayerNorm and segment mean in one HIP pass each way (ea_lara_seglin_fwd / _bwd; round 4) -- the qkv projection stays 3C wide.
+    The backward ACCUMULATES its input gradient into the gradient buffer the attention core publishes for qkv5 (slot.buf), like
+    the 2-D pooling does.  -> q_bar, k_bar [B,h,L,64] fp32."""
+
+    @staticmethod
+    def forward(ctx, qkv5, L, slot, Gq, gqb, Gk, gkb, lqw, lqb, lkw, lkb):
+        nv.require_cuda(qkv5, "qkv")
+        B, N, _, h, d = qkv5.shape
+        geom = nv.make_geom(B, h, N, d, nv.io_dtype(qkv5), False, (N,), 0, 0, 0, L)
+        ps = [t.detach().float().contiguous() for t in (Gq, gqb, Gk, gkb, lqw, lqb, lkw, lkb)]
+        q, k, _ = _qkv_views(qkv5)
+        tq, tk = nv.t4(q), nv.t4(k)
+        qbar = torch.empty((B, h, L, d), dtype=torch.float32, device=qkv5.device)
+        kbar = torch.empty_like(qbar)
+        nv.call("ea_lara_seglin_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk), *[nv.ptr(t) for t in ps],
+                nv.ptr(qbar), nv.ptr(kbar), nv.stream())
+        ctx.save_for_backward(qkv5, *ps)
+        ctx.geom, ctx.slot = geom, slot
+        ctx.pdtypes = [t.dtype for t in (Gq, gqb, Gk, gkb, lqw, lqb, lkw, lkb)]
+        return qbar, kbar
+
+    @staticmethod
+    def backward(ctx, dqb, dkb):
+        qkv5, *ps = ctx.saved_tensors
+        geom, slot = ctx.geom, ctx.slot
+        B, N, _, h, d = qkv5.shape
+        L = geom.L
+        dev = qkv5.device
+        own = slot is None or slot.buf is None
+        buf = torch.zeros_like(qkv5) if own else slot.buf
+        q, k, _ = _qkv_views(qkv5)
+        dq, dk, _ = _qkv_views(buf)
+        ts = [nv.t4(t) for t in (q, k, dq, dk)]
+        groups = nv.query("ea_lara_seglin_groups", geom)
+        part = torch.empty((B * h * groups, 2 * 4 * d), dtype=torch.float32, device=dev)
+        dG_part = torch.empty((B * h * groups, 2 * d * d), dtype=torch.float32, device=dev)
+        stats = torch.empty((B * h * 2 * N, 4), dtype=torch.float32, device=dev)
+        nv.call("ea_lara_seglin_bwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), *[nv.ptr(t) for t in ps],
+                nv.ptr(dqb.float().contiguous()), nv.ptr(dkb.float().contiguous()), ctypes.byref(ts[2]), ctypes.byref(ts[3]),
+                nv.ptr(part), nv.ptr(dG_part), nv.ptr(stats), nv.stream())
+        if slot is not None:
+            slot.buf = None
+        # tall, narrow partial matrices: the column-sum kernel (64 row lanes per 16 columns), not the slice reduction
+        sums, dGs = colsum2_f32(part, dG_part)                        # (same number of rows: one launch)
+        sums, dGs = sums.view(2, 4, d), dGs.view(2, d, d)
+        # Gq, gqb, Gk, gkb, lqw, lqb, lkw, lkb
+        grads = [dGs[0], sums[0, 2], dGs[1], sums[1, 2], sums[0, 0], sums[0, 1], sums[1, 0], sums[1, 1]]
+        grads = [g_.to(dt) for g_, dt in zip(grads, ctx.pdtypes)]
+        return ((buf if own else None), None, None) + tuple(grads)
+
+
 USE_FOLD_KERNELS = os.environ.get("EA_FOLD_KERNELS", "1") == "1"
 
 

@@ -192,8 +192,12 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         h, d = self.num_heads, self.head_dim
         L = self.num_landmarks
         gen = self.proposal_gen
-        # 'adaptive-1d' on the GPU: the per-token Linear of q_bar_gen / k_bar_gen rides along in the qkv GEMM
-        fold_1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and d in (32, 64) and x.is_cuda)
+        # 'adaptive-1d' on the GPU.  Round 4: generator Linear + LayerNorm + segment mean in one HIP pass over the stored
+        # q / k rows (_ops.SegLinLnMeanFn; d = 64), the projection stays 3C wide.  Otherwise (rounds 1-3) the per-token Linear
+        # of q_bar_gen / k_bar_gen rides along in the qkv GEMM (two more groups of output columns).
+        ad1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and x.is_cuda)
+        seglin = ad1d and d == 64 and _ops.USE_SEGLIN
+        fold_1d = ad1d and not seglin and d in (32, 64)
         # the common 2-D training case as ONE autograd node (projections + core): decided before anything is launched
         module_fn = (len(seq_shape) == 2 and not fold_1d and torch.is_autocast_enabled()
                      and (self.proj_drop.p == 0.0 or not self.training)
@@ -244,6 +248,13 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             # the softmax mixing of k_bar runs inside the landmark kernel whenever that kernel is used
             pq, pk, colbias = self._proposal_gen_2d(qkv5, seq_shape[0], seq_shape[1], slot, mix=not fused_b)
             mixed_k = fused_b and gen.endswith('mixed')
+        elif seglin:
+            if key_padding_mask is not None:           # padded tokens: q = k = v = 0 for the generator AND the estimator (:93-96)
+                keep = (~key_padding_mask.to(torch.bool)).to(qkv5.dtype).view(B, N, 1, 1, 1)
+                qkv5 = qkv5 * keep
+            lq, nq, lk, nk = self.q_bar_gen[0], self.q_bar_gen[1], self.k_bar_gen[0], self.k_bar_gen[1]
+            pq, pk = _ops.SegLinLnMeanFn.apply(qkv5, L, slot, lq.weight, lq.bias, lk.weight, lk.bias,
+                                               nq.weight, nq.bias, nk.weight, nk.bias)
         elif fold_1d:
             pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
         elif len(seq_shape) == 1:

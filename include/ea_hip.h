@@ -288,6 +288,26 @@ int ea_performer_bwd_k(const ea_perf_geom* g, const ea_t4* k, const ea_t4* v, co
                        const float* W, const float* stab, const float* dkv, const float* dksum,
                        const ea_t4* dk, const ea_t4* dv, void* stream);
 
+/* ---- LARA 'adaptive-1d' proposals with the generator INSIDE the segment kernels (ea_lara_seglin.hip; round 4) ----
+ * q_bar_l = mean over segment l of LayerNorm(G_q q_n + g_q), k_bar_l likewise (lara.py:56-63,84-127), straight from the
+ * stored q / k rows: generator Linear (a [64 x 64] MFMA product per 16 tokens), LayerNorm and segment mean in one pass; the
+ * qkv projection stays 3C wide (the folded form below makes all three GEMMs of the layer 5C wide).  g: B, H, N, D = 64,
+ * dtype, L (segments as in ea_lara_segment_*); G [64, 64] (out, in), g_b, ln_w, ln_b [64]: fp32.
+ *   fwd: qbar, kbar [B*H, L, 64] fp32.
+ *   bwd: ACCUMULATES G^T d z into dq / dk (the attention core's gradient rows, I/O dtype); with S = B*H*
+ *        ea_lara_seglin_groups(g): part [S, 2, 4, 64] = partial sums of (d ln_w, d ln_b, d g_b, 0) per side, dG_part
+ *        [S, 2, 64, 64] = partial sums of dG (side 0: q generator) -- the caller adds them over S; stats: scratch of
+ *        B*H*2*N*4 floats (16-byte aligned) in which the dq / dk pass leaves every token's LayerNorm statistics for the dG
+ *        pass. */
+int32_t ea_lara_seglin_groups(const ea_geom* g);
+int ea_lara_seglin_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                       float* qbar, float* kbar, void* stream);
+int ea_lara_seglin_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                       const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
+                       float* stats, void* stream);
+
 /* ---- LARA 'adaptive-1d' proposals: the generators' per-token Linear folded into the qkv projection (ea_fold.hip) ----
  * q_bar_gen / k_bar_gen start with Linear(d, d) on every token's q / k row (lara.py:56-63,100-103).  The module computes
  * Linear_gen(q) as two more groups of output columns of the qkv GEMM (W' = G W_head per head); these two entry points

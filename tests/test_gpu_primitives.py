@@ -747,3 +747,118 @@ def test_lara_adaptive_1d_fold_kernels_match_framework_fold(dtype, masked, bias)
     assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 8
     for n in res[True][2]:
         close(res[True][2][n], res[False][2][n], n, 4 * tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,h,N,L", [(2, 8, 4096, 49), (1, 2, 1000, 16), (2, 3, 333, 7), (1, 1, 130, 64)])
+def test_lara_seglin_matches_fp64_torch(dtype, B, h, N, L):
+    """ea_lara_seglin_fwd / _bwd (round 4): segment means of LayerNorm(G x + b) straight from the stored q / k rows, the
+    generator Linear on the MFMA inside the kernel -- against fp64 torch on the same 16-bit-rounded rows and generator
+    weights: means, the gradient accumulated into dq / dk (on top of a pre-filled buffer), dG, d g_b, d ln_w, d ln_b."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    gen = torch.Generator(device="cuda").manual_seed(N + L)
+    qkv = (torch.randn(B, N, 3, h, 64, device="cuda", generator=gen)).to(td)
+    ps = [torch.randn(64, 64, device="cuda", generator=gen) * 0.15, torch.randn(64, device="cuda", generator=gen) * 0.1,
+          torch.randn(64, 64, device="cuda", generator=gen) * 0.15, torch.randn(64, device="cuda", generator=gen) * 0.1,
+          1 + 0.2 * torch.randn(64, device="cuda", generator=gen), 0.1 * torch.randn(64, device="cuda", generator=gen),
+          1 + 0.2 * torch.randn(64, device="cuda", generator=gen), 0.1 * torch.randn(64, device="cuda", generator=gen)]
+    ps = [p_.requires_grad_(True) for p_ in ps]
+    slot = _ops._GradSlot()
+    base = (torch.randn(B, N, 3, h, 64, device="cuda", generator=gen) * 0.01).to(td)
+    slot.buf = base.clone()
+    qbar, kbar = _ops.SegLinLnMeanFn.apply(qkv, L, slot, *ps)
+    gq = torch.randn(B, h, L, 64, device="cuda", generator=gen)
+    gk = torch.randn(B, h, L, 64, device="cuda", generator=gen)
+    buf = slot.buf
+    (qbar * gq).sum().backward(retain_graph=True)
+    # (one backward call handles both sides: run it once with both cotangents)
+    for p_ in ps:
+        p_.grad = None
+    slot.buf = base.clone()
+    buf = slot.buf
+    torch.autograd.backward([qbar, kbar], [gq, gk])
+    # fp64 reference on the rounded values
+    x = qkv.double().cpu().requires_grad_(True)
+    rp = [p_.detach().to(td).double().cpu().requires_grad_(True) if i in (0, 2) else p_.detach().double().cpu().requires_grad_(True)
+          for i, p_ in enumerate(ps)]
+    segs = N // L
+    nshort = L if N % L == 0 else (segs + 1) * L - N
+
+    def side(xs, G, gb, lw, lb):
+        z = torch.einsum("bnhd,ed->bnhe", xs, G) + gb
+        y = torch.nn.functional.layer_norm(z, (64,), lw, lb, 1e-5).permute(0, 2, 1, 3)          # [B,h,N,64]
+        head = y[:, :, :nshort * segs].reshape(B, h, nshort, segs, 64).mean(-2)
+        if nshort == L:
+            return head
+        tail = y[:, :, nshort * segs:].reshape(B, h, L - nshort, segs + 1, 64).mean(-2)
+        return torch.cat([head, tail], -2)
+    rq = side(x[:, :, 0], rp[0], rp[1], rp[4], rp[5])
+    rk = side(x[:, :, 1], rp[2], rp[3], rp[6], rp[7])
+    torch.autograd.backward([rq, rk], [gq.double().cpu(), gk.double().cpu()])
+    tol = 1.2e-2 if dtype == "bf16" else 2e-3
+
+    def close(a, b, what, t=tol):
+        sc = float(b.abs().max())
+        assert float((a.double().cpu() - b).abs().max()) <= t * sc, (what, float((a.double().cpu() - b).abs().max()) / sc)
+    close(qbar, rq.detach(), "qbar", tol / 4)
+    close(kbar, rk.detach(), "kbar", tol / 4)
+    dgrad = (buf.double().cpu() - base.double().cpu())
+    close(dgrad[:, :, 0], x.grad[:, :, 0], "dq", 2 * tol)           # (accumulated in the 16-bit buffer: its own rounding)
+    close(dgrad[:, :, 1], x.grad[:, :, 1], "dk", 2 * tol)
+    assert float(dgrad[:, :, 2].abs().max()) == 0.0
+    for i, nm in enumerate(["Gq", "gqb", "Gk", "gkb", "lqw", "lqb", "lkw", "lkb"]):
+        close(ps[i].grad, rp[i].grad, nm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_lara_adaptive_1d_seglin_matches_folded_path(dtype, masked):
+    """The module with the generator inside the segment kernels (round 4 default) against the folded-projection path it
+    replaces (EA_SEGLIN=0): y, dx and every parameter gradient."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(23)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=512, num_heads=8, num_landmarks=16, proposal_gen="adaptive-1d",
+                                                             mis_type="mis-opt")).cuda()
+    m.train()
+    B, N = 2, 1000
+    x0 = torch.randn(B, N, 512, device="cuda")
+    g = torch.randn(B, N, 512, device="cuda").to(td)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, N, dtype=torch.bool, device="cuda")
+        mask[0, 900:] = True
+    res = {}
+    for sl in (True, False):
+        old = _ops.USE_SEGLIN
+        _ops.USE_SEGLIN = sl
+        try:
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=td):
+                y = m(x, mask)
+            y.backward(g)
+            res[sl] = (y.detach().float(), x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            _ops.USE_SEGLIN = old
+    tol = 2.4e-2 if dtype == "bf16" else 3e-3
+
+    def close(a, b, what, t):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= t * sc, (what, float((a - b).abs().max()) / sc)
+    close(res[True][0], res[False][0], "y", tol)
+    close(res[True][1], res[False][1], "dx", tol)
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 8
+    for n in res[True][2]:
+        close(res[True][2][n], res[False][2][n], n, 4 * tol)
