@@ -408,8 +408,10 @@ int seglin_dispatch(int which, const SegLinP& p0, int dtype, hipStream_t st) {
   p.groups = seglin_groups(p.B * p.H, p.L);
   p.seg_per_group = (p.L + p.groups - 1) / p.groups;
   {
-    // forward / dq-dk passes: ~4096 waves (two resident rounds of 8 per CU), every wave at least one segment
-    int per = (int)(((long)p.B * p.H * 2 * p.L + 4095) / 4096);
+    // forward / dq-dk passes: ONE resident round of waves (12 per CU at 166 registers, 8 at 222) -- 3328 waves on 3072 / 2048
+    // slots ran as two rounds, the second nearly empty -- every wave at least one segment
+    const long cap = (long)ea_device_cus() * (which == 0 ? 12 : 8);
+    int per = (int)(((long)p.B * p.H * 2 * p.L + cap - 1) / cap);
     if (per < 1) per = 1;
     p.cgroups = (p.L + per - 1) / per;
     p.cseg_per_group = (p.L + p.cgroups - 1) / p.cgroups;
