@@ -2166,8 +2166,10 @@ class LinearFn(torch.autograd.Function):
                 wc = wl if wl.dtype == cdtype else wl.to(cdtype)
                 # the launch is y = dY (W^T)^T: the geometry to validate is K = out, NO = in of the forward weight
                 if (xdtype in (torch.float32, wc.dtype) and wc.dtype in _ELEM and _lin_geometry(wc.shape[0], wc.shape[1])
-                        and _lin_rows_ok(dy2, wc.dtype)):
-                    # dX = dY W as the same streaming kernel on the transposed weight (a [in, out] copy of <= 128 KB)
+                        and _lin_rows_ok(dy2, wc.dtype) and wc.numel() * 2 <= 128 * 1024):
+                    # dX = dY W as the same streaming kernel on the transposed weight: a [in, out] copy per backward, so only
+                    # for weights of <= 128 KB (a pure 16-bit model has no fp32 master weight to read transposed;
+                    # above the cap the library GEMM takes it without a copy)
                     dx = _ea_op("linear", linear_impl, dy2, wc.t().contiguous(), None, y_f32, False)[0].view(xshape)
                 else:
                     dx = _mm_out(dy2, wc, xdtype).view(xshape)

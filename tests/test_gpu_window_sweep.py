@@ -107,3 +107,51 @@ def test_geometry_matches_oracle(case, dtype):
     for what, got, want in (("y", y.detach().float().cpu(), yr.detach()), ("dx", x.grad.cpu(), xr.grad)):
         e = scaled_err(got.numpy(), want.numpy())
         assert e[0] <= tol[0] and e[1] <= tol[1], (name, what, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nwin,mask_tail", [(5, 0), (1, 0), (8, 5), (3, 20)])
+def test_half_window_overlap_direct_accumulation_matches_scratch_slices(nwin, mask_tail):
+    """1-D windows extended by half a window accumulate dk / dv in the I/O dtype across the two colour-class
+    launches (class 0 stores, class 1 adds: WinTiling::cdirect) instead of fp32 scratch slices + a finish pass.  That rounds
+    twice where the slices rounded once, and relies on class 0 having written every covered token before class 1 runs.
+    Compared here against EA_WIN_CDIRECT=0 (a subprocess: the switch is read once per process) at LARGE magnitudes, odd
+    window counts, a single window and a padding mask: agreement within two 16-bit ulps of the largest gradient."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import efficient_attention as ea
+torch.manual_seed(3)
+nwin, mask_tail, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+w, B, h = 16, 2, 2
+N = nwin * w
+m = ea.AttentionFactory.build_attention("local", dict(dim=128, num_heads=h, window_size=w, overlap_window=True)).cuda()
+x = (4.0 * torch.randn(B, N, 128, device="cuda")).requires_grad_(True)
+mask = None
+if mask_tail:
+    mask = torch.zeros(B, N, dtype=torch.bool, device="cuda"); mask[0, N - mask_tail:] = True
+with torch.autocast("cuda", dtype=torch.bfloat16):
+    y = m(x, mask)
+g = 8.0 * torch.randn_like(y)
+y.backward(g)
+torch.save({"dx": x.grad.cpu(), "dw": m.qkv.weight.grad.cpu()}, out)
+'''
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "efficient-attention_amd")
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            out = os.path.join(td, "r%s.pt" % flag)
+            env = dict(os.environ, EA_WIN_CDIRECT=flag)
+            r = subprocess.run([sys.executable, "-c", code, pkg, str(nwin), str(mask_tail), out], env=env, capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-1500:]
+            import torch
+            res[flag] = torch.load(out)
+    for k in ("dx", "dw"):
+        a, b = res["1"][k].float(), res["0"][k].float()
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2 * 2.0 ** -8 * float(b.abs().max()), k
