@@ -13,7 +13,7 @@
 //   out_n = phi(q_n) KV / max(phi(q_n).ksum, 1e-2),  KV = sum_n phi(k_n)^T v_n,  ksum = sum_n phi(k_n)   (:116-121)
 //   padded keys: phi = 0 (:337-340).
 //
-// One 4-wave workgroup per (b,h, sequence slice); 64-token tiles; every matrix product is tile_mm() over LDS images with an
+// One 8-wave workgroup per (b,h, sequence slice); 64-token tiles; every matrix product is tile_mm() over LDS images with an
 // odd row stride (conflict-free for both operand orientations).  Sequence-wide sums (KV, ksum, their gradients) leave as
 // per-slice partials, added by ea_slice_sum.  Simple on purpose: this is the faithful path, the 16-bit kernels stay the
 // fast one (EA_PERFORMER_16BIT=1).
@@ -28,55 +28,54 @@ namespace {
 constexpr int TB = 64;            // tokens per tile
 constexpr int PD = 64;            // head dim
 constexpr int LDD = PD + 1;       // row stride of the [*][64] images
+constexpr int NTH = 512;          // threads per workgroup: 8 waves, two per SIMD (the LDS images allow one workgroup per CU)
+constexpr int NWV = NTH / 64;     // waves
+constexpr int LPR = NTH / TB;     // lanes per token row in the elementwise stages (8)
 
-// rows n0 .. n0 + 63 of a [B,H,N,64] view -> dst[row][65] fp32 (rows >= N: zeros); thread = (row, 16 channels)
+// rows n0 .. n0 + 63 of a [B,H,N,64] view -> dst[row][65] fp32 (rows >= N: zeros); thread = (row, 8 channels)
 EA_DEV void load_tile(float* dst, const Pf32T& t, int b, int h, int n0, int N, int dtype, int tid) {
-  const int row = tid >> 2, c0 = (tid & 3) * 16;
-  float f[16];
+  const int row = tid / LPR, c0 = (tid % LPR) * 8;
+  float f[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) f[i] = 0.f;
+  for (int i = 0; i < 8; ++i) f[i] = 0.f;
   if (n0 + row < N) {
     const size_t eo = (size_t)b * t.sb + (size_t)h * t.sh + (size_t)(n0 + row) * t.sn + c0;
     if (dtype == 2) {
       const float* s = reinterpret_cast<const float*>(t.p) + eo;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(s + 4 * i);
-        f[4 * i] = v[0]; f[4 * i + 1] = v[1]; f[4 * i + 2] = v[2]; f[4 * i + 3] = v[3];
-      }
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(s), v1 = *reinterpret_cast<const f32x4*>(s + 4);
+      f[0] = v0[0]; f[1] = v0[1]; f[2] = v0[2]; f[3] = v0[3]; f[4] = v1[0]; f[5] = v1[1]; f[6] = v1[2]; f[7] = v1[3];
     } else {
-      const char* s = t.p + eo * 2;
-      const u32x4 w0 = ldg16(s), w1 = ldg16(s + 16);
-      if (dtype == 0) { unpack8<BF16>(w0, f); unpack8<BF16>(w1, f + 8); }
-      else { unpack8<F16>(w0, f); unpack8<F16>(w1, f + 8); }
+      const u32x4 w0 = ldg16(t.p + eo * 2);
+      if (dtype == 0) unpack8<BF16>(w0, f);
+      else unpack8<F16>(w0, f);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) dst[row * LDD + c0 + i] = f[i];
+  for (int i = 0; i < 8; ++i) dst[row * LDD + c0 + i] = f[i];
 }
 
 // src[row][65] fp32 -> rows n0 .. of a [B,H,N,64] view in its I/O type (rows >= N dropped)
 EA_DEV void store_tile(const float* src, const Pf32T& t, int b, int h, int n0, int N, int dtype, int tid) {
-  const int row = tid >> 2, c0 = (tid & 3) * 16;
+  const int row = tid / LPR, c0 = (tid % LPR) * 8;
   if (n0 + row >= N) return;
-  float f[16];
+  float f[8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) f[i] = src[row * LDD + c0 + i];
+  for (int i = 0; i < 8; ++i) f[i] = src[row * LDD + c0 + i];
   const size_t eo = (size_t)b * t.sb + (size_t)h * t.sh + (size_t)(n0 + row) * t.sn + c0;
   if (dtype == 2) {
     float* d = reinterpret_cast<float*>(t.p) + eo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(d + 4 * i) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+    *reinterpret_cast<f32x4*>(d) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(d + 4) = f32x4{f[4], f[5], f[6], f[7]};
   } else {
     char* d = t.p + eo * 2;
-    if (dtype == 0) { stg16(d, pack8<BF16>(f)); stg16(d + 16, pack8<BF16>(f + 8)); }
-    else { stg16(d, pack8<F16>(f)); stg16(d + 16, pack8<F16>(f + 8)); }
+    if (dtype == 0) stg16(d, pack8<BF16>(f));
+    else stg16(d, pack8<F16>(f));
   }
 }
 
 // [rows][64] fp32 global matrix -> dst[rows][65]
 EA_DEV void load_mat(float* dst, const float* src, int rows, int tid) {
-  for (int idx = tid; idx < rows * (PD / 4); idx += 256) {
+  for (int idx = tid; idx < rows * (PD / 4); idx += NTH) {
     const int r = idx / (PD / 4), c = (idx - r * (PD / 4)) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)r * PD + c);
     float* d = dst + r * LDD + c;
@@ -84,10 +83,10 @@ EA_DEV void load_mat(float* dst, const float* src, int rows, int tid) {
   }
 }
 
-// sum over the 4 lanes that share a row (row = tid >> 2); lane q4 of a row walks the CONTIGUOUS quarter q4 of it, which with
+// sum over the LPR lanes that share a row (row = tid / LPR); lane q4 of a row walks the CONTIGUOUS part q4 of it, which with
 // the odd row stride keeps the 64 lanes of a wave on distinct LDS banks
-EA_DEV float row4_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
-EA_DEV float row4_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); return v; }
+EA_DEV float row4_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+EA_DEV float row4_max(float v) { v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); return v; }
 
 struct Consts {
   float c, c2, ratio;
@@ -104,16 +103,16 @@ EA_DEV Consts consts(int M) {
 EA_DEV void logits(float* Ps, int ldp, const float* Xs, const float* Ws, float* diag, int M, float c, float c2, int tid) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int ntn = M / 16;
-  for (int t = wave; t < (TB / 16) * ntn; t += 4) {
+  for (int t = wave; t < (TB / 16) * ntn; t += NWV) {
     const int m0 = (t / ntn) * 16, n0 = (t % ntn) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     tile_mm<false, true, PD>(acc, Xs, LDD, Ws, LDD, m0, n0, PD, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ps[(m0 + 4 * g + r) * ldp + n0 + li] = acc[r] * c;
   }
-  const int row = tid >> 2, q4 = tid & 3;
+  const int row = tid / LPR, q4 = tid % LPR;
   float s = 0.f;
-  for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) { const float x = Xs[row * LDD + e]; s += x * x; }
+  for (int e = q4 * (PD / LPR); e < (q4 + 1) * (PD / LPR); ++e) { const float x = Xs[row * LDD + e]; s += x * x; }
   s = row4_sum(s);
   if (q4 == 0) diag[row] = s * c2;
 }
@@ -129,7 +128,7 @@ EA_DEV void slice_range(const Pf32P& p, int s, int& n0, int& n1) {
 // ------------------------------------------------------------------------------------------------------------
 // keys, pass 1: partial maximum of data_dash over the slice's tokens and all features (padded keys included, as in the
 // reference: the mask is applied to the features afterwards)
-__global__ __launch_bounds__(256) void pf32_kmax_kernel(const Pf32P p) {
+__global__ __launch_bounds__(NTH) void pf32_kmax_kernel(const Pf32P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = p.M, ldp = M + 1;
   float* Ws = sm;
@@ -151,16 +150,20 @@ __global__ __launch_bounds__(256) void pf32_kmax_kernel(const Pf32P p) {
     logits(Ps, ldp, Xs, Ws, diag, M, k.c, k.c2, tid);
     __syncthreads();
     {
-      const int row = tid >> 2, q4 = tid & 3;                         // (no index divisions: four lanes per token row)
+      const int row = tid / LPR, q4 = tid % LPR;                         // (no index divisions: four lanes per token row)
       if (t0 + row < n1)
-        for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
+        for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  if (tid == 0) p.p_max[(size_t)bh * p.S + s] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (tid == 0) {
+    float m2 = red[0];
+    for (int i = 1; i < NWV; ++i) m2 = fmaxf(m2, red[i]);
+    p.p_max[(size_t)bh * p.S + s] = m2;
+  }
 }
 
 // the key stabiliser of a (b,h): maximum of the slice maxima
@@ -174,14 +177,14 @@ EA_DEV float key_stab(const Pf32P& p, int bh) {
 EA_DEV void key_features(float* Ps, int ldp, const float* diag, const Pf32P& p, int b, int t0, int n1, float stab, float ratio,
                          int tid) {
   const int M = p.M;
-  const int n = tid >> 2, q4 = tid & 3, tok = t0 + n;
+  const int n = tid / LPR, q4 = tid % LPR, tok = t0 + n;
   const bool live = tok < n1 && !(p.mask && p.mask[(size_t)b * p.N + tok]);
   const float sh = diag[n] + stab;
-  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) Ps[n * ldp + j] = live ? ratio * __expf(Ps[n * ldp + j] - sh) + 1e-4f : 0.f;
+  for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) Ps[n * ldp + j] = live ? ratio * __expf(Ps[n * ldp + j] - sh) + 1e-4f : 0.f;
 }
 
 // keys, pass 2: partial KV [M][64] and ksum [M] of the slice
-__global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
+__global__ __launch_bounds__(NTH) void pf32_kv_kernel(const Pf32P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = p.M, ldp = M + 1;
   float* Ws = sm;
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
   int n0, n1;
   slice_range(p, s, n0, n1);
   const int nt = M / 16;                        // feature tiles; wave w owns (jt, et) pairs t = w, w + 4, ..: nt of them
-  f32x4 acc[6];
+  f32x4 acc[3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float ks = 0.f;
   for (int t0 = n0; t0 < n1; t0 += TB) {
     __syncthreads();
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
     key_features(Ps, ldp, diag, p, b, t0, n1, stab, k.ratio, tid);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int t = wave + 4 * i;
+    for (int i = 0; i < 3; ++i) {
+      const int t = wave + NWV * i;
       if (t < nt * 4) tile_mm<true, false, TB>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
     }
     if (tid < M) {
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
   }
   float* okv = p.p_kv + ((size_t)bh * p.S + s) * M * PD;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int t = wave + 4 * i;
+  for (int i = 0; i < 3; ++i) {
+    const int t = wave + NWV * i;
     if (t < nt * 4) {
       const int j0 = (t >> 2) * 16, e0 = (t & 3) * 16;
 #pragma unroll
@@ -236,13 +239,13 @@ __global__ __launch_bounds__(256) void pf32_kv_kernel(const Pf32P p) {
 
 // query features of the tile in Xs: Ps <- phi(q), den[n] = phi(q_n) . ksum
 EA_DEV void query_features(float* Ps, int ldp, const float* diag, float* den, const float* ksum_s, int M, float ratio, int tid) {
-  const int row = tid >> 2, q4 = tid & 3;
+  const int row = tid / LPR, q4 = tid % LPR;
   float mx = -INFINITY;
-  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
+  for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) mx = fmaxf(mx, Ps[row * ldp + j]);
   mx = row4_max(mx);
   const float sh = diag[row] + mx;
   float dn = 0.f;
-  for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) {
+  for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) {
     const float f = ratio * __expf(Ps[row * ldp + j] - sh) + 1e-4f;
     Ps[row * ldp + j] = f;
     dn += f * ksum_s[j];
@@ -255,7 +258,7 @@ EA_DEV void query_features(float* Ps, int ldp, const float* diag, float* den, co
 template <typename F>
 EA_DEV void feat_times(float* Os, const float* Ps, int ldp, const float* KVs, int M, int tid, F rowscale) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  for (int t = wave; t < 16; t += 4) {
+  for (int t = wave; t < 16; t += NWV) {
     const int m0 = (t >> 2) * 16, n0 = (t & 3) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (M == 64) tile_mm<false, false, 64>(acc, Ps, ldp, KVs, LDD, m0, n0, 64, lane);
@@ -266,7 +269,7 @@ EA_DEV void feat_times(float* Os, const float* Ps, int ldp, const float* KVs, in
 }
 
 // queries, forward: out
-__global__ __launch_bounds__(256) void pf32_out_kernel(const Pf32P p) {
+__global__ __launch_bounds__(NTH) void pf32_out_kernel(const Pf32P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = p.M, ldp = M + 1;
   float* Ws = sm;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void pf32_out_kernel(const Pf32P p) {
 EA_DEV void logit_grad(float* Os, const float* Gs, int ldp, const float* Ws, const float* Xs, const float* sdl, int M, float c,
                        float c2, int tid) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  for (int t = wave; t < 16; t += 4) {
+  for (int t = wave; t < 16; t += NWV) {
     const int m0 = (t >> 2) * 16, n0 = (t & 3) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (M == 64) tile_mm<false, false, 64>(acc, Gs, ldp, Ws, LDD, m0, n0, 64, lane);
@@ -317,7 +320,7 @@ EA_DEV void logit_grad(float* Os, const float* Gs, int ldp, const float* Ws, con
 }
 
 // queries, backward: dq and the partial d KV [M][64], d ksum [M] of the slice
-__global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
+__global__ __launch_bounds__(NTH) void pf32_bwd_q_kernel(const Pf32P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = p.M, ldp = M + 1;
   float* Ws = sm;
@@ -340,11 +343,11 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
   int n0, n1;
   slice_range(p, s, n0, n1);
   const int nt = M / 16;
-  f32x4 acc[6];
+  f32x4 acc[3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dks = 0.f;
-  const int row = tid >> 2, q4 = tid & 3;
+  const int row = tid / LPR, q4 = tid % LPR;
   for (int t0 = n0; t0 < n1; t0 += TB) {
     __syncthreads();
     load_tile(Xs, p.q, b, h, t0, p.N, p.dtype, tid);
@@ -361,14 +364,14 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
       // d num = dout / max(den, 1e-2);  d den = -(dout . out) / max(den, 1e-2) where the clamp is inactive
       const float inv = 1.f / fmaxf(den[row], 1e-2f);
       float rd = 0.f;
-      for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) rd += Ys[row * LDD + e] * Os[row * LDD + e];
+      for (int e = q4 * (PD / LPR); e < (q4 + 1) * (PD / LPR); ++e) rd += Ys[row * LDD + e] * Os[row * LDD + e];
       rd = row4_sum(rd);
-      for (int e = q4 * (PD / 4); e < (q4 + 1) * (PD / 4); ++e) Ys[row * LDD + e] *= inv;
+      for (int e = q4 * (PD / LPR); e < (q4 + 1) * (PD / LPR); ++e) Ys[row * LDD + e] *= inv;
       if (q4 == 0) dden[row] = den[row] > 1e-2f ? -rd * inv : 0.f;
     }
     __syncthreads();
     // d phi[n][j] = d num[n] . KV[j] + d den[n] ksum[j];  d logit = d phi (phi - eps)
-    for (int t = wave; t < (TB / 16) * nt; t += 4) {
+    for (int t = wave; t < (TB / 16) * nt; t += NWV) {
       const int m0 = (t / nt) * 16, j0 = (t % nt) * 16;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       tile_mm<false, true, PD>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
@@ -381,14 +384,14 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
     __syncthreads();
     {
       float sacc = 0.f;
-      for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) sacc += Gs[row * ldp + j];
+      for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) sacc += Gs[row * ldp + j];
       sacc = row4_sum(sacc);
       if (q4 == 0) sdl[row] = sacc;
     }
     // partial d KV[j][e] += sum_n phi[n][j] d num[n][e];  d ksum[j] += sum_n phi[n][j] d den[n]
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int t = wave + 4 * i;
+    for (int i = 0; i < 3; ++i) {
+      const int t = wave + NWV * i;
       if (t < nt * 4) tile_mm<true, false, TB>(acc[i], Ps, ldp, Ys, LDD, (t >> 2) * 16, (t & 3) * 16, TB, lane);
     }
     if (tid < M) {
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
   }
   float* okv = p.p_kv + ((size_t)bh * p.S + s) * M * PD;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int t = wave + 4 * i;
+  for (int i = 0; i < 3; ++i) {
+    const int t = wave + NWV * i;
     if (t < nt * 4) {
       const int j0 = (t >> 2) * 16, e0 = (t & 3) * 16;
 #pragma unroll
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_q_kernel(const Pf32P p) {
 }
 
 // keys, backward: dk, dv from the summed d KV, d ksum
-__global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
+__global__ __launch_bounds__(NTH) void pf32_bwd_k_kernel(const Pf32P p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = p.M, ldp = M + 1;
   float* Ws = sm;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
   int n0, n1;
   slice_range(p, s, n0, n1);
   const int nt = M / 16;
-  const int row = tid >> 2, q4 = tid & 3;
+  const int row = tid / LPR, q4 = tid % LPR;
   for (int t0 = n0; t0 < n1; t0 += TB) {
     __syncthreads();
     load_tile(Xs, p.k, b, h, t0, p.N, p.dtype, tid);
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
     key_features(Ps, ldp, diag, p, b, t0, n1, stab, k.ratio, tid);
     __syncthreads();
     // d phi[n][j] = v[n] . dKV[j] + d ksum[j];  d logit = d phi (phi - eps), 0 where phi was masked to 0
-    for (int t = wave; t < (TB / 16) * nt; t += 4) {
+    for (int t = wave; t < (TB / 16) * nt; t += NWV) {
       const int m0 = (t / nt) * 16, j0 = (t % nt) * 16;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       tile_mm<false, true, PD>(a, Ys, LDD, KVs, LDD, m0, j0, PD, lane);
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void pf32_bwd_k_kernel(const Pf32P p) {
     __syncthreads();
     {
       float sacc = 0.f;
-      for (int j = q4 * (M >> 2), je = j + (M >> 2); j < je; ++j) sacc += Gs[row * ldp + j];
+      for (int j = q4 * (M / LPR), je = j + (M / LPR); j < je; ++j) sacc += Gs[row * ldp + j];
       sacc = row4_sum(sacc);
       if (q4 == 0) sdl[row] = sacc;
     }
@@ -504,7 +507,7 @@ int pf32_dispatch(int which, const Pf32P& p0, hipStream_t st) {
   p.S = pf32_slices(p.B * p.H, p.N);
   const int tiles = (p.N + TB - 1) / TB;
   p.tps = ((tiles + p.S - 1) / p.S) * TB;
-  const dim3 grid((unsigned)(p.B * p.H), (unsigned)p.S), block(256);
+  const dim3 grid((unsigned)(p.B * p.H), (unsigned)p.S), block(NTH);
   const size_t lds = pf32_lds(which, p.M);
   switch (which) {
     case 0:
