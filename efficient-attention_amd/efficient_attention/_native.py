@@ -312,8 +312,18 @@ def call(name, *args):
     _check(getattr(lib(), name)(*args), name)
 
 
+_QUERY_CACHE = {}
+
+
 def query(name, geom):
-    v = getattr(lib(), name)(ctypes.byref(geom))
-    if v < 0:
-        _check(v, name)
+    """Host-side plan query (a pure function of the geometry struct): memoised -- an eager step asks the same five questions
+    about the same geometry every backward."""
+    key = (name, bytes(geom))
+    v = _QUERY_CACHE.get(key)
+    if v is None:
+        v = getattr(lib(), name)(ctypes.byref(geom))
+        if v < 0:
+            _check(v, name)
+        if len(_QUERY_CACHE) < 4096:
+            _QUERY_CACHE[key] = v
     return v

@@ -44,6 +44,9 @@ CORE_TOL = (2e-2, 1e-2)
 # normaliser (kernelized_attention.py:55), where the derivative is DISCONTINUOUS -- a query whose denominator lies within bf16
 # rounding of 1e-2 takes the other branch than the fp32 reference and its whole gradient row differs.  y agrees to 6e-3;
 # the gradients are bounded at 2x their observed error (0.069 / 0.033); the fp16 run of the same case keeps the common bound.
+# Round 4: the Performer core itself now computes in exact fp32 arithmetic (ea_performer_f32_*) -- the flips that remain under
+# bf16 autocast come from the bf16 rounding of q, k by the qkv projection (the same 0.069 / 0.033 with either core); in fp32
+# outside autocast the case matches the reference at 2e-4 / 1e-4 (tests/test_gpu_performer_f32.py).
 CASE_TOL = {("performer_2d_clamp", "bf16"): (1.4e-1, 7e-2)}
 _OBSERVED = None
 
