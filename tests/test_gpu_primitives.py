@@ -220,7 +220,7 @@ def test_linear_w32_equals_cast_weight(rows, K, NO, a_f32, y_f32, transposed, dt
 @pytest.mark.parametrize("B,H,W,r", [(128, 28, 28, 4), (3, 28, 28, 4), (5, 14, 14, 2), (128, 14, 14, 2), (2, 8, 12, 4), (1, 4, 4, 4)])
 @pytest.mark.parametrize("a_f32", [1, 0])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_linear_pool_equals_projection_plus_chunk_mean(B, H, W, r, a_f32, dtype):
+def test_linear_pool_equals_projection_plus_chunk_mean(B, H, W, r, a_f32, dtype, monkeypatch):
     """ea_linear_w32_pool (round 4): the 192 -> 576 projection that walks the tokens cell by cell and emits the r x r
     pooled q / k rows from its epilogue.  qkv and the rounded copy of x: BIT-identical to ea_linear_w32; pooled rows: the
     means ea_eva_chunk_mean_fwd computes from the stored rows (same rounded values, another summation order)."""
@@ -235,6 +235,7 @@ def test_linear_pool_equals_projection_plus_chunk_mean(B, H, W, r, a_f32, dtype)
     x = x if a_f32 else x.to(td)
     w32 = torch.randn(576, 192, device="cuda", generator=g) * 192 ** -0.5
     b = torch.randn(576, device="cuda", generator=g)
+    monkeypatch.setattr(_ops, "USE_PROJ_POOL", True)          # (the kernel under test, whatever EA_PROJ_POOL says)
     assert _ops.proj_pool_supported(x, w32, td, B, H, W, r, 3)
     L = (H // r) * (W // r)
     pq = torch.full((B * h, L, d), float("nan"), device="cuda")
