@@ -433,7 +433,8 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
     return [out, _e(bias_p, e), lse, qmean, kmean, omega, beta, rf_k_bar, _e(saved, e), _e(zhat, e), _e(rstd, e)]
 
 
-def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params):
+def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params,
+                 defer_param_sums=False):
     """torch.ops.ea.eva_bwd -> [dqkv, dbias | empty, *parameter gradients (fp32, in the order of mlp_params)]."""
     geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
     bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, saved, zhat, rstd = [_opt(t) for t in saved_list]
@@ -464,6 +465,8 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
                 None, None, nv.ptr(dqm), nv.ptr(dkm), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
         nv.call("ea_eva_chunk_mean_bwd", ctypes.byref(geom), nv.ptr(dqm), nv.ptr(dkm),
                 nv.ptr(mask_u8), ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+        if defer_param_sums:                       # (direct calls only) the per-(b,h) partials, still to be added up
+            return [dqkv5, _e(dbias, lse), ("partials", dW.view(lg.BH, -1), dvec.view(lg.BH, -1))]
         dWs, dvs = colsum2_f32(dW.view(lg.BH, -1), dvec.view(lg.BH, -1))
         dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
         raw = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
@@ -540,6 +543,126 @@ class EvaAttnFn(torch.autograd.Function):
                                  bias_cols, list(params))
         pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
         return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
+
+
+USE_EVA_MODULE_FN = os.environ.get("EA_EVA_MODULE_FN", "1") == "1"
+
+
+def eva_module_fn_supported(x, qkv, proj, cdtype, adaptive_proj, L, d):
+    """The single-node path of EVA (EvaModuleFn): what LaraModuleFn needs of the projections, plus the fused landmark
+    kernel for the mu networks (adaptive_proj 'default', L <= 64, d in {32, 64})."""
+    return (USE_EVA_MODULE_FN and adaptive_proj == "default" and L <= 64 and d in (32, 64)
+            and lara_module_fn_supported(x, qkv, proj, cdtype)
+            and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0 and _DIRECT)
+
+
+class EvaModuleFn(torch.autograd.Function):
+    """qkv projection -> EVA core -> output projection as ONE autograd node (round 4, the EVA counterpart of LaraModuleFn): the
+    same launches as LinearFn / LinearPoolFn + EvaAttnFn + LinearFn without two of the three nodes' host cost, the chunk means
+    out of the projection kernel where it can emit them, and the terminal sums of the backward (both weight gradients' slice
+    partials, the mu networks' per-(b,h) partials) in ONE launch (ea_multi_sum).
+    args: x [B, *seq, C], qkv weight / bias, proj weight / bias, dense bias [h, Wq, Wk] | None, mask_u8, noise, cfg (EvaAttnFn's
+    first seven entries), compute dtype, heads, then the mu-network parameters."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wp, bp, bias, mask_u8, noise, cfg, cdtype, heads, *params):
+        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg
+        C = x.shape[-1]
+        B = x.shape[0]
+        N = x.numel() // (B * C)
+        d = C // heads
+        x2 = x.reshape(-1, C)
+        elem = _ELEM[cdtype]
+        bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
+        bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
+        want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+        icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), 0, int(any(ctx.needs_input_grad))]
+        fcfg = [0.5, 1.0]
+        pooled = None
+        if (attn_2d and ext == 0 and mask_u8 is None
+                and proj_pool_supported(x2, wq, cdtype, B, seq_shape[0], seq_shape[1], chunk, heads)):
+            pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
+            pk = torch.empty_like(pq)
+            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk)
+            pooled = (pq, pk)
+        else:
+            y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
+            xc = xc if want else None
+        xl = x2 if x2.dtype == cdtype else (xc if want else None)
+        qkv5 = y.view(B, N, 3, heads, d)
+        outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, None, icfg, fcfg, adaptive_proj, list(params), pooled=pooled)
+        o2 = outs[0].reshape(-1, C)
+        y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)
+        ctx.icfg, ctx.fcfg, ctx.nsaved, ctx.adaptive = icfg, fcfg, len(outs) - 1, adaptive_proj
+        ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
+                    [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], None if bias is None else bias.dtype)
+        return y2.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xl, qkv5, mask_u8, noise, o2, wq, wp, *rest = ctx.saved_tensors
+        saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
+        xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads, bias_cols, bias_dt = ctx.meta
+        C = xshape[-1]
+        d = C // heads
+        elem = _ELEM[cdtype]
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype != cdtype:
+            dy2 = dy2.to(cdtype)
+        d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
+        defer = USE_MULTI_SUM
+        pend = []
+        dwp = dbp = dwq = dbq = dx = None
+        need_bp = bpd is not None and need[4]
+        if need[3]:
+            r_ = wgrad(dy2, o2, need_bp, defer=defer)
+            if defer:
+                pend.append(("proj", r_[0], r_[1]))
+            else:
+                dwp, dbp = r_[0].to(wpd), (r_[1].to(bpd) if need_bp else None)
+        elif need_bp:
+            dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
+        B, N = qkv5.shape[:2]
+        g = eva_bwd_impl(d_o2.view(B, N, heads, d), qkv5, mask_u8, None, noise, o2.view(B, N, heads, d), list(saved), ctx.icfg,
+                         ctx.fcfg, ctx.adaptive, bias_cols, list(params), defer_param_sums=defer)
+        dqkv2 = g[0].view(-1, 3 * C)
+        dbias = _opt(g[1])
+        pgrads = list(g[2:])
+        if pgrads and isinstance(pgrads[0], tuple):
+            pend.append(("mu_W", pgrads[0][1], None))
+            pend.append(("mu_v", pgrads[0][2], None))
+            pgrads = []
+        need_bq = bqd is not None and need[2]
+        if need[1]:
+            if xl is None:
+                raise RuntimeError("EvaModuleFn: the weight gradient was requested but the forward did not keep its input")
+            r_ = wgrad(dqkv2, xl, need_bq, defer=defer)
+            if defer:
+                pend.append(("qkv", r_[0], r_[1]))
+            else:
+                dwq, dbq = r_[0].to(wqd), (r_[1].to(bqd) if need_bq else None)
+        elif need_bq:
+            dbq = bias_grad(dqkv2).to(bqd)
+        if need[0]:
+            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+        if pend:
+            sums = multi_sum([t for _, t, _ in pend])
+            res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}
+            if "proj" in res:
+                dwp, dbp32 = _wgrad_split(*res["proj"])
+                dwp, dbp = dwp.to(wpd), (dbp32.to(bpd) if need_bp else None)
+            if "qkv" in res:
+                dwq, dbq32 = _wgrad_split(*res["qkv"])
+                dwq, dbq = dwq.to(wqd), (dbq32.to(bqd) if need_bq else None)
+            if "mu_W" in res:
+                dWs, dvs = res["mu_W"][0].view(2, d, d), res["mu_v"][0].view(2, 3, d)
+                pgrads = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+        pgrads = [t.to(dt) for t, dt in zip(pgrads, pdtypes)]
+        if dbias is not None and bias_dt is not None:
+            dbias = dbias.to(bias_dt)
+        return (dx, dwq, dbq, dwp, dbp, dbias, None, None, None, None, None) + tuple(pgrads)
 
 
 # ------------------------------------------------------------------------------------------

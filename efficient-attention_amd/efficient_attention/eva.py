@@ -151,6 +151,27 @@ class EVA(LocalAttention):
         N = int(math.prod(seq_shape))
         w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
         pooled = None
+        # the common training case as ONE autograd node (projections + core, round 4): decided before anything is launched
+        if (torch.is_autocast_enabled() and x.is_cuda and (self.proj_drop.p == 0.0 or not self.training)
+                and w > 0 and self.num_landmarks > 0):
+            r0 = int(math.sqrt(N // self.num_landmarks)) if self.attn_2d else int(N // self.num_landmarks)
+            ok_geo = r0 > 0 and (e > 0 or (all(s_ % r0 == 0 for s_ in seq_shape) if self.attn_2d else N % r0 == 0))
+            L0 = ((seq_shape[0] // r0) * (seq_shape[1] // r0) if self.attn_2d else N // r0) if r0 > 0 else 0
+            cdt = torch.get_autocast_dtype("cuda")
+            if ok_geo and _ops.eva_module_fn_supported(x, self.qkv, self.proj, cdt, self.adaptive_proj, L0, d):
+                Wq_, Wk_ = (w * w, (w + 2 * e) ** 2) if self.attn_2d else (w, w + 2 * e)
+                bias = self.rel_pos_bias.dense(Wq_, Wk_, x.device) if self.use_t5_rpe else self._table_bias()
+                noise = None
+                if self.training:
+                    noise = torch.randn_like(torch.empty(B, h, L0, d, device=x.device, dtype=torch.float32))
+                mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+                cfg = (self.attn_2d, tuple(seq_shape), w, e, r0, L0, self.adaptive_proj)
+                y = _ops.EvaModuleFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, bias, mask, noise,
+                                           cfg, cdt, h, *self._mu_params())
+                y = self.proj_drop(y)
+                if not self.attn_2d:
+                    y = y[..., :orig_n, :]
+                return y
         if self.attn_2d:
             r = int(math.sqrt(N // self.num_landmarks))
             L = (seq_shape[0] // r) * (seq_shape[1] // r)
