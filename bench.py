@@ -165,15 +165,22 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
                       "per-element work), N=%d, dim %d [%s]" % (n, attn, B, ntok, dim, others)}
 
 
-def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True):
+def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, overrides=None):
     """One more workload of BASELINE.json next to the headline one (N = 196 / 4096): the same layer step -- fwd + bwd + SGD
     under bf16 autocast, captured in a hipGraph -- timed over `steps` replays.  Returns tokens/s and the layer-level
-    fraction of the HBM roofline (1536*h bytes per token at d = 64)."""
+    fraction of the HBM roofline (1536*h bytes per token at d = 64).  overrides: attention arguments that
+    replace the recipe's for this layer only (the PvT stages: window_size 8, 36 landmarks)."""
     N = 1
     for s_ in seq:
         N *= s_
     d = C // H
-    layer = build_layer(attn, C, H, seq, dev)
+    keep = dict(OVERRIDES)
+    OVERRIDES.update(overrides or {})
+    try:
+        layer = build_layer(attn, C, H, seq, dev)
+    finally:
+        OVERRIDES.clear()
+        OVERRIDES.update(keep)
     layer.train()
     x = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev, requires_grad=True)
     g = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev).to(torch.bfloat16)
@@ -622,9 +629,16 @@ def main():
                 if other != a.attn:
                     runs.append(("cfg3_N784_%s" % other, other, (B, C, H, seq)))
                     runs.append(("cfg5_N4096_B16_%s" % other, other, (16, 512, 8, (4096,))))
-            for key, attn_o, (Bo, Co, Ho, so) in runs:
+            # cfg4 (BASELINE.json config 4): the attention layers of the four PvTv2-b2 stages at 384 x 384, batch 32 per GPU
+            # (pvt_legacy.py:309-319,349-359: dims 64/128/320/512, heads 1/2/5/8; grids 96/48/24/12).  The reference's own
+            # recipe (w = 7, 49 landmarks) asserts on these grids: 8 x 8 windows and 36 landmarks are the
+            # nearest geometry it runs; the last stage is softmax attention.
+            pvt = dict(window_size=8, num_landmarks=36)
+            runs += [("cfg4_stage1_N9216_eva", "eva", (32, 64, 1, (96, 96)), pvt), ("cfg4_stage2_N2304_eva", "eva", (32, 128, 2, (48, 48)), pvt),
+                     ("cfg4_stage3_N576_eva", "eva", (32, 320, 5, (24, 24)), pvt), ("cfg4_stage4_N144_softmax", "softmax", (32, 512, 8, (12, 12)))]
+            for key, attn_o, (Bo, Co, Ho, so), *ov in runs:
                 try:
-                    others[key] = measure_workload(attn_o, Bo, Co, Ho, so, dev, tune=tune)
+                    others[key] = measure_workload(attn_o, Bo, Co, Ho, so, dev, tune=tune, overrides=ov[0] if ov else None)
                     others[key]["attn"] = attn_o
                 except Exception as ex:          # never let an extra line take the headline measurement down
                     others[key] = {"error": str(ex).split("\n")[0][:200]}

@@ -65,7 +65,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 7; }
+int32_t ea_abi_version(void) { return 8; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -1485,6 +1485,142 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
   // dparams == NULL: the caller adds the per-(b,h) partials up itself (tmp + ea_lara_layer_ws(cfg, 5 / 6): [B*H, 2 D D] and
   // [B*H, 6 D]), e.g. together with other terminal sums of its backward in one ea_multi_sum launch
   if (c->has_mlp && dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
+  return rc;
+}
+
+}  // extern "C"
+
+// ---- composite per-module entry points, EVA (round 4): the 2-D core of eva.py:145-227 in one call each way ----
+// chunk means (or the projection kernel's) -> mu networks + omega (fused landmark kernel, eva mode) -> beta -> window
+// attention with the control-variate columns; backward: window backward -> landmark-gradient slice sum (+ bias-gradient
+// column sum) -> beta backward -> mu-network backward -> chunk-mean backward (-> parameter sums).  Same contract as the
+// LARA pair: caller-owned workspaces, sizes from ea_eva_layer_ws.
+namespace {
+struct EvaLayerPlan {
+  ea_geom g;
+  ea_lmk_geom lg;
+  int L, BH, N, Wq, ld, parts, bparts;
+  size_t o_lse, o_qm, o_km, o_omega, o_beta, o_rfk, o_lmk, n_saved;
+  size_t b_dlp, b_dl, b_dbp, b_dom, b_dqm, b_dkm, b_dW, b_dvec, n_btmp;
+};
+int eva_layer_plan(const ea_eva_layer* c, EvaLayerPlan& P) {
+  if (!c || c->B <= 0 || c->H <= 0 || c->gh <= 0 || c->gw <= 0 || c->window <= 0 || c->chunk <= 0 ||
+      c->gh % c->window || c->gw % c->window || c->gh % c->chunk || c->gw % c->chunk) return EA_E_BADARG;
+  if (c->D != 32 && c->D != 64) return EA_E_UNSUPPORTED;
+  P.N = c->gh * c->gw;
+  P.L = (c->gh / c->chunk) * (c->gw / c->chunk);
+  P.BH = c->B * c->H;
+  if (P.L > 64) return EA_E_UNSUPPORTED;                    // the fused mu / omega kernel; larger: the step-by-step entries
+  ea_geom g = {};
+  g.B = c->B; g.H = c->H; g.N = P.N; g.D = c->D; g.dtype = c->dtype; g.attn_2d = 1; g.gh = c->gh; g.gw = c->gw;
+  g.window = c->window; g.ext = 0; g.chunk = c->chunk; g.L = P.L; g.scale = c->scale; g.causal = 0; g.lm_base = 0;
+  P.g = g;
+  ea_lmk_geom lg = {};
+  lg.BH = P.BH; lg.L = P.L; lg.C = P.L; lg.D = c->D; lg.has_mlp = 1; lg.mixed = 0; lg.mis = 0; lg.dup = 0;
+  lg.scale = c->scale; lg.eva = 1;
+  P.lg = lg;
+  P.Wq = c->window * c->window;
+  P.ld = ea_window_bias_ld(&g);
+  P.parts = ea_window_bwd_parts(&g);
+  P.bparts = c->has_bias ? ea_window_bwd_bias_parts(&g) : 0;
+  if (P.ld <= 0 || P.parts <= 0 || (c->has_bias && P.bparts <= 0)) return EA_E_UNSUPPORTED;
+  // geometries whose backward needs scratch slices, several query blocks or the transposed bias copy: step-by-step entries
+  if (ea_window_bwd_acc_slices(&g) != 0 || ea_window_bwd_query_blocks(&g) != 1 ||
+      (c->has_bias && ea_window_bwd_needs_bias_t(&g) != 0)) return EA_E_UNSUPPORTED;
+  const size_t LD = (size_t)P.BH * P.L * c->D;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += al4(n); return at; };
+  P.o_lse = take((size_t)P.BH * P.N);
+  P.o_qm = take(LD); P.o_km = take(LD); P.o_omega = take(LD); P.o_beta = take(LD); P.o_rfk = take(LD);
+  const int64_t ls = ea_lara_landmarks_saved_floats(&lg);
+  if (ls < 0) return EA_E_UNSUPPORTED;
+  P.o_lmk = take((size_t)ls);
+  P.n_saved = o;
+  o = 0;
+  P.b_dlp = take((size_t)2 * P.parts * LD); P.b_dl = take(2 * LD);
+  P.b_dbp = take((size_t)P.bparts * c->B * c->H * P.Wq * P.ld);
+  P.b_dom = take(LD); P.b_dqm = take(LD); P.b_dkm = take(LD);
+  P.b_dW = take((size_t)P.BH * 2 * c->D * c->D); P.b_dvec = take((size_t)P.BH * 6 * c->D);
+  P.n_btmp = o;
+  return EA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t ea_eva_layer_ws(const ea_eva_layer* c, int32_t which) {
+  EvaLayerPlan P;
+  const int rc = eva_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  switch (which) {
+    case 0: return (int64_t)P.n_saved;
+    case 1: return 0;
+    case 2: return (int64_t)P.n_btmp;
+    case 3: return (int64_t)P.o_qm;
+    case 4: return (int64_t)P.o_km;
+    case 5: return (int64_t)P.b_dW;
+    case 6: return (int64_t)P.b_dvec;
+    case 7: return (int64_t)P.ld;
+    case 8: return (int64_t)P.o_lse;
+    default: return EA_E_BADARG;
+  }
+}
+
+int ea_eva_layer_fwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                     const float* noise, const float* const* params, const ea_t4* out, float* saved,
+                     int32_t keep_for_backward, void* stream) {
+  EvaLayerPlan P;
+  int rc = eva_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  if (!saved || !params || (c->has_bias != 0) != (bias != nullptr)) return EA_E_BADARG;
+  float *qm = saved + P.o_qm, *km = saved + P.o_km, *omega = saved + P.o_omega, *beta = saved + P.o_beta, *rfk = saved + P.o_rfk;
+  if (!(keep_for_backward & EA_LARA_POOLED_READY)) {
+    rc = ea_eva_chunk_mean_fwd(&P.g, q, k, nullptr, qm, km, stream);
+    if (rc != EA_OK) return rc;
+  }
+  keep_for_backward &= 1;
+  rc = ea_lara_landmarks_fwd(&P.lg, qm, km, params[0], params[1], params[2], params[3], params[4], params[5], params[6],
+                             params[7], noise, omega, rfk, nullptr, nullptr, keep_for_backward ? saved + P.o_lmk : nullptr, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_eva_beta_fwd(&P.g, k, v, nullptr, omega, beta, stream);
+  if (rc != EA_OK) return rc;
+  return ea_window_attn_fwd(&P.g, q, k, v, rfk, beta, bias, nullptr, out, saved + P.o_lse, nullptr, 1.f, stream);
+}
+
+int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                     const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
+                     const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
+                     void* stream) {
+  EvaLayerPlan P;
+  int rc = eva_layer_plan(c, P);
+  if (rc != EA_OK) return rc;
+  if (!saved || !tmp || !params || (c->has_bias != 0) != (bias != nullptr) || (c->has_bias && !dbias)) return EA_E_BADARG;
+  const int D = c->D;
+  const size_t LD = (size_t)P.BH * P.L * D;
+  const float *qm = saved + P.o_qm, *km = saved + P.o_km, *omega = saved + P.o_omega, *beta = saved + P.o_beta, *rfk = saved + P.o_rfk;
+  float* dl_p = tmp + P.b_dlp;
+  float* dl = tmp + P.b_dl;                 // [2][B*H, L, D]: d rf_k_bar, d beta
+  float* dbp = c->has_bias ? tmp + P.b_dbp : nullptr;
+  rc = ea_window_attn_bwd(&P.g, q, k, v, rfk, beta, bias, nullptr, out, dout, saved + P.o_lse, dq, dk, dv, dl_p,
+                          dl_p + (size_t)P.parts * LD, dbp, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_slice_sum(2, P.parts, (int32_t)LD, 1.f, nullptr, dl_p, dl, stream);
+  if (rc != EA_OK) return rc;
+  if (c->has_bias) {
+    rc = ea_colsum_f32(P.bparts * c->B, c->H * P.Wq * P.ld, dbp, dbias, stream);
+    if (rc != EA_OK) return rc;
+  }
+  float* d_omega = tmp + P.b_dom;
+  rc = ea_eva_beta_bwd(&P.g, k, v, nullptr, omega, beta, dl + LD, dk, dv, d_omega, stream);
+  if (rc != EA_OK) return rc;
+  float *dqm = tmp + P.b_dqm, *dkm = tmp + P.b_dkm, *dW = tmp + P.b_dW, *dvec = tmp + P.b_dvec;
+  rc = ea_lara_landmarks_bwd(&P.lg, qm, km, params[0], params[1], params[2], params[3], params[4], params[5], params[6],
+                             params[7], noise, d_omega, dl, nullptr, nullptr, dqm, dkm, dW, dvec, saved + P.o_lmk, stream);
+  if (rc != EA_OK) return rc;
+  rc = ea_eva_chunk_mean_bwd(&P.g, dqm, dkm, nullptr, dq, dk, stream);
+  if (rc != EA_OK) return rc;
+  // dparams == NULL: the per-(b,h) partials stay in tmp (offsets ea_eva_layer_ws(cfg, 5 / 6)) for the caller's own reduction
+  if (dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
   return rc;
 }
 

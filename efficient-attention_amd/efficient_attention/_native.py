@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 7          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 8          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -57,6 +57,12 @@ class ea_lara_layer(ctypes.Structure):
                 ("kappa", ctypes.c_float), ("scale", ctypes.c_float)]
 
 
+class ea_eva_layer(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("D", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32), ("chunk", ctypes.c_int32),
+                ("has_bias", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
 class ea_lara_geom(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("dtype", ctypes.c_int32), ("C", ctypes.c_int32),
@@ -74,6 +80,7 @@ _MG = ctypes.POINTER(ea_lmk_geom)
 _T = ctypes.POINTER(ea_t4)
 _SG = ctypes.POINTER(ea_sb_geom)
 _LL = ctypes.POINTER(ea_lara_layer)
+_EL = ctypes.POINTER(ea_eva_layer)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
 SIGNATURES = {
@@ -131,6 +138,9 @@ SIGNATURES = {
     "ea_lara_layer_ws": [_LL, _I],
     "ea_lara_layer_fwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _P, _P, _I, _P],
     "ea_lara_layer_bwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _P, _P, _P, _P],
+    "ea_eva_layer_ws": [_EL, _I],
+    "ea_eva_layer_fwd": [_EL, _T, _T, _T, _P, _P, _P, _T, _P, _I, _P],
+    "ea_eva_layer_bwd": [_EL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P],
     "ea_scatter_parts": [_SG],
     "ea_scatter_kmax": [_SG, _T, _P, _P, _P, _P],
     "ea_scatter_kv": [_SG, _T, _T, _P, _P, _P, _P, _P, _P],
@@ -187,6 +197,7 @@ def lib():
             fn.restype = ctypes.c_int
         cdll.ea_lara_landmarks_saved_floats.restype = ctypes.c_int64
         cdll.ea_lara_layer_ws.restype = ctypes.c_int64
+        cdll.ea_eva_layer_ws.restype = ctypes.c_int64
         cdll.ea_version.restype = ctypes.c_char_p
         cdll.ea_abi_version.restype = ctypes.c_int32
         if cdll.ea_abi_version() != ABI_VERSION:

@@ -368,16 +368,68 @@ def _eva_cfg(qkv5, icfg, fcfg, adaptive_proj):
     return geom, L, mu_scale, keep_scale, fused_mu
 
 
-def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, mlp_params, pooled=None):
+def _eva_use_composite():
+    """The FORWARD's decision between ea_eva_layer_fwd and the step-by-step launches (bench.py's per-kernel timing needs the
+    individual entry points); the backward follows what the forward saved (see _lara_use_composite)."""
+    return os.environ.get("EA_EVA_COMPOSITE", "1") == "1" and not nv.KERNEL_TIMER.enabled
+
+
+_EVA_LAYER_CFG = {}
+
+
+def _eva_layer_cfg_dims(B, h, d, io, icfg, fcfg, adaptive_proj, has_bias, masked):
+    """(ea_eva_layer, [saved floats, backward scratch floats, offsets of qmean, kmean, dW partials, dvec partials]) of the
+    composite entry points, or (None, None): 2-D non-overlapping windows, no pad mask / dropout, the fused mu networks."""
+    attn_2d, s0, s1, window, ext, chunk, L, causal = [int(v) for v in icfg[:8]]
+    if (not attn_2d or ext != 0 or causal != 0 or masked or adaptive_proj != "default" or float(fcfg[0]) != 0.5
+            or float(fcfg[1]) != 1.0 or chunk <= 0 or s0 % chunk or s1 % chunk or (s0 // chunk) * (s1 // chunk) != L):
+        return None, None
+    key = (B, h, d, io, s0, s1, window, chunk, int(has_bias))
+    hit = _EVA_LAYER_CFG.get(key)
+    if hit is None:
+        cfg = nv.ea_eva_layer(B, h, d, io, s0, s1, window, chunk, int(has_bias), float(d) ** -0.5)
+        sizes = [int(nv.lib().ea_eva_layer_ws(ctypes.byref(cfg), w)) for w in (0, 2, 3, 4, 5, 6)]
+        hit = (cfg, sizes) if min(sizes) >= 0 else (None, None)
+        if len(_EVA_LAYER_CFG) < 256:
+            _EVA_LAYER_CFG[key] = hit
+    return hit
+
+
+def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, mlp_params, pooled=None, composite=False):
     """torch.ops.ea.eva_fwd: chunk means -> mu MLP -> omega -> beta -> window attention with control-variate
     columns (eva.py:145-227).  icfg = [attn_2d, s0, s1, window, ext, chunk, L, causal(, keep_for_backward = 1)],
     fcfg = [mu_scale, keep_scale].  -> [out, bias_padded, lse, qmean, kmean, omega, beta, rf_k_bar, noise, lmk_saved, zhat, rstd]
-    (absent tensors are empty)."""
+    (absent tensors are empty).
+    composite (direct calls only, never through the dispatcher): ONE C-ABI call (ea_eva_layer_fwd) on a caller-owned
+    workspace where the geometry allows it -> [out, bias_padded, saved workspace]; pooled is then (ws,) -- the chunk means
+    already written into that workspace by the projection kernel -- or None."""
+    global LAST_LMK_GEOM
     nv.require_cuda(qkv5, "qkv")
-    geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
-    need_grad = len(icfg) < 9 or bool(icfg[8])
     B, N, _, h, d = qkv5.shape
     dev = qkv5.device
+    if composite:
+        lcfg, sizes = _eva_layer_cfg_dims(B, h, d, nv.io_dtype(qkv5), icfg, fcfg, adaptive_proj, bias is not None,
+                                          mask_u8 is not None or keep is not None)
+        if pooled is not None and (len(pooled) == 1) != (lcfg is not None):
+            raise RuntimeError("eva_fwd: chunk means prepared for the other launch path")
+        if lcfg is not None:
+            need_grad = len(icfg) < 9 or bool(icfg[8])
+            q, k, v = _qkv_views(qkv5)
+            tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
+            ws = pooled[0] if pooled is not None else torch.empty(sizes[0], dtype=torch.float32, device=dev)
+            out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
+            to = nv.t4(out.permute(0, 2, 1, 3))
+            geom = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)[0]
+            bias_p = _bias_padded(bias, geom)
+            noise_c = None if noise is None else noise.float().contiguous()
+            ps = [p.detach().float().contiguous() for p in mlp_params]
+            LAST_LMK_GEOM = (B * h, int(icfg[6]), int(icfg[6]), d, 1, 0, 1)
+            nv.call("ea_eva_layer_fwd", ctypes.byref(lcfg), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
+                    nv.ptr(bias_p), nv.ptr(noise_c), _param_ptrs(ps), ctypes.byref(to), nv.ptr(ws),
+                    int(need_grad) | (2 if pooled is not None else 0), nv.stream())
+            return [out, _e(bias_p, ws), ws]
+    geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
+    need_grad = len(icfg) < 9 or bool(icfg[8])
     q, k, v = _qkv_views(qkv5)
     tq, tk, tv = nv.t4(q), nv.t4(k), nv.t4(v)
     if pooled is not None:
@@ -393,7 +445,6 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
     if fused_mu:
         # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
         lg = nv.ea_lmk_geom(B * h, L, L, d, 1, 0, 0, 0, float(d) ** -0.5, 1)
-        global LAST_LMK_GEOM
         LAST_LMK_GEOM = (B * h, L, L, d, 1, 0, 1)
         noise_c = None if noise is None else noise.float().contiguous()
         omega = torch.empty_like(qmean)
@@ -436,6 +487,36 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
 def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params,
                  defer_param_sums=False):
     """torch.ops.ea.eva_bwd -> [dqkv, dbias | empty, *parameter gradients (fp32, in the order of mlp_params)]."""
+    if len(saved_list) == 2:
+        # the forward went through ea_eva_layer_fwd: (bias_padded | empty, saved workspace)
+        bias_p, ws = _opt(saved_list[0]), saved_list[1]
+        B, N, _, h, d = qkv5.shape
+        lcfg, sizes = _eva_layer_cfg_dims(B, h, d, nv.io_dtype(qkv5), icfg, fcfg, adaptive_proj, bias_p is not None, False)
+        if lcfg is None:
+            raise RuntimeError("eva_bwd: a composite workspace was saved for a geometry ea_eva_layer_ws rejects")
+        dev = qkv5.device
+        dout = _rows_contiguous(dout)
+        dqkv5 = torch.empty_like(qkv5)
+        q, k, v = _qkv_views(qkv5)
+        dq, dk, dv = _qkv_views(dqkv5)
+        ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
+        tmp = torch.empty(sizes[1], dtype=torch.float32, device=dev)
+        noise_c = None if noise is None else noise.float().contiguous()
+        ps = [p.detach().float().contiguous() for p in mlp_params]
+        dbias = None if bias_p is None else torch.empty_like(bias_p)
+        dpar = None if defer_param_sums else torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev)
+        nv.call("ea_eva_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+                nv.ptr(bias_p), nv.ptr(noise_c), _param_ptrs(ps), ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
+                ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dbias), nv.ptr(dpar), nv.stream())
+        if dbias is not None:
+            dbias = dbias[..., :bias_cols].contiguous()
+        BH = B * h
+        if defer_param_sums:
+            o_dW, o_dvec = sizes[4], sizes[5]
+            return [dqkv5, _e(dbias, ws), ("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
+                                          tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))]
+        dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
+        return [dqkv5, _e(dbias, ws), dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
     geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
     bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, saved, zhat, rstd = [_opt(t) for t in saved_list]
     noise_c = None if noise is None else noise.float().contiguous()
@@ -524,8 +605,13 @@ class EvaAttnFn(torch.autograd.Function):
         icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), int(causal), int(any(ctx.needs_input_grad))]
         fcfg = [float(mu_scale), float(keep_scale)]
         pooled = cfg[-1][1:] if (isinstance(cfg[-1], tuple) and cfg[-1][:1] == ("pooled",)) else None
+        direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
         if pooled is not None:
             outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params), pooled=pooled)
+        elif direct:
+            # round 4: one C-ABI call for the whole core where the geometry allows it (ea_eva_layer_fwd)
+            outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params),
+                                composite=_eva_use_composite())
         else:
             outs = _ea_op("eva_fwd", eva_fwd_impl, qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params))
         ctx.save_for_backward(qkv5, mask_u8, keep, noise, *outs, *mlp_params)
@@ -539,8 +625,11 @@ class EvaAttnFn(torch.autograd.Function):
         qkv5, mask_u8, keep, noise, out, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         icfg, fcfg, adaptive_proj, bias_cols = ctx.cfg
-        g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
-                                 bias_cols, list(params))
+        if len(saved) == 2:             # composite workspace: only a direct forward saves one
+            g = eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols, list(params))
+        else:
+            g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
+                       bias_cols, list(params))
         pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
         return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
 
@@ -579,18 +668,29 @@ class EvaModuleFn(torch.autograd.Function):
         icfg = _geo(attn_2d, seq_shape, window, ext) + [int(chunk), int(L), 0, int(any(ctx.needs_input_grad))]
         fcfg = [0.5, 1.0]
         pooled = None
+        comp = _eva_use_composite()
+        lcfg, sizes = (_eva_layer_cfg_dims(B, heads, d, elem, icfg, fcfg, adaptive_proj, bias is not None, mask_u8 is not None)
+                       if comp else (None, None))
         if (attn_2d and ext == 0 and mask_u8 is None
                 and proj_pool_supported(x2, wq, cdtype, B, seq_shape[0], seq_shape[1], chunk, heads)):
-            pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
-            pk = torch.empty_like(pq)
+            if lcfg is not None:
+                # the projection kernel writes the chunk means straight into the composite entry's workspace
+                ws = torch.empty(sizes[0], dtype=torch.float32, device=x.device)
+                n_p = B * heads * L * d
+                pq, pk = ws[sizes[2]:sizes[2] + n_p], ws[sizes[3]:sizes[3] + n_p]
+                pooled = (ws,)
+            else:
+                pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
+                pk = torch.empty_like(pq)
+                pooled = (pq, pk)
             y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk)
-            pooled = (pq, pk)
         else:
             y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
             xc = xc if want else None
         xl = x2 if x2.dtype == cdtype else (xc if want else None)
         qkv5 = y.view(B, N, 3, heads, d)
-        outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, None, icfg, fcfg, adaptive_proj, list(params), pooled=pooled)
+        outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, None, icfg, fcfg, adaptive_proj, list(params), pooled=pooled,
+                            composite=lcfg is not None)
         o2 = outs[0].reshape(-1, C)
         y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
         ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)

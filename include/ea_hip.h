@@ -606,6 +606,41 @@ int ea_lara_layer_bwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, 
                       const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
                       const ea_t4* dv, const float* saved, float* tmp, float* dparams, void* stream);
 
+/* ---- composite per-module entry points, EVA (round 4) -----------------------------------------------------------
+ * The 2-D EVA core (eva.py:145-227: non-overlapping w x w windows, r x r landmark chunks, adaptive_proj 'default', no pad
+ * mask) in one call each way -- the launch sequences of ea_eva_chunk_mean_fwd / ea_lara_landmarks_* (eva mode) /
+ * ea_eva_beta_* / ea_window_attn_* / ea_slice_sum / ea_colsum_f32 / ea_eva_chunk_mean_bwd / ea_colsum2_f32 on caller-owned
+ * workspaces, for the same reason as the LARA pair above (eagerly stepping call sites, vit/engine.py:47-64).
+ *   ea_eva_layer_ws(cfg, which): 0 = floats of `saved` (forward -> backward), 1 = 0 (no forward scratch), 2 = floats of the
+ *       backward scratch; 3 / 4 = offsets (floats) inside `saved` of the chunk means of q / k [B*H, L, D]; 5 / 6 = offsets
+ *       inside the backward scratch of the per-(b,h) parameter-gradient partials [B*H, 2 D D] and [B*H, 6 D]; 7 = padded
+ *       row length of `bias` (= ea_window_bias_ld); 8 = offset inside `saved` of the joint log-sum-exp [B,H,N]
+ *       (negative: EA_E_*; EA_E_UNSUPPORTED: L > 64 or a window geometry whose backward needs scratch slices -- use the
+ *       step-by-step entry points).
+ *   bias: fp32 [H, w*w, ld] dense per-head bias multiplied by log2(e), rows padded to ld (as for ea_window_attn_fwd), or
+ *       NULL (then cfg->has_bias == 0); dbias: fp32 [H, w*w, ld], gradient with respect to the NATURAL-unit bias.
+ *   params: 8 pointers (W, b, gamma, beta of the q and of the k mu network: eva.py:93-103); noise: [B*H, L, D] or NULL.
+ *   keep_for_backward: bit 0 = keep the intermediates; bit 1 (EA_LARA_POOLED_READY) = the chunk means are already in
+ *       `saved` (ea_linear_w32_pool wrote them).  dparams: [2 D D + 6 D] fp32 as for ea_lara_layer_bwd, or NULL (partials
+ *       left in the scratch for the caller's reduction).  dq, dk, dv are WRITTEN. */
+typedef struct {
+  int32_t B, H, D;
+  int32_t dtype;             /* EA_BF16 | EA_F16 */
+  int32_t gh, gw;            /* token grid (N = gh * gw) */
+  int32_t window;            /* window side w (gh, gw multiples of it; no overlap extension) */
+  int32_t chunk;             /* landmark chunk side r: L = (gh / r) * (gw / r) <= 64 */
+  int32_t has_bias;
+  float   scale;             /* D^-0.5 */
+} ea_eva_layer;
+int64_t ea_eva_layer_ws(const ea_eva_layer* cfg, int32_t which);
+int ea_eva_layer_fwd(const ea_eva_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                     const float* noise, const float* const* params, const ea_t4* out, float* saved,
+                     int32_t keep_for_backward, void* stream);
+int ea_eva_layer_bwd(const ea_eva_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                     const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
+                     const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
+                     void* stream);
+
 /* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
  * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);
  * these entry points evaluate the m random-feature columns of the same softmax and merge the two halves:

@@ -863,3 +863,70 @@ def test_lara_adaptive_1d_seglin_matches_folded_path(dtype, masked):
     assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 8
     for n in res[True][2]:
         close(res[True][2][n], res[False][2][n], n, 4 * tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dim,heads,grid,window,landmarks,module_fn", [
+    (192, 3, (28, 28), 7, 49, True),        # cfg3: single node, chunk means from the projection kernel into the workspace
+    (192, 3, (14, 14), 7, 49, True),        # cfg2
+    (192, 3, (28, 28), 7, 49, False),       # three nodes: LinearPoolFn hint -> step-by-step in both runs (hint is not in a workspace)
+    (128, 2, (48, 48), 8, 36, True),        # PvT stage 2 (cfg4): single node without the pooled projection
+    (128, 2, (16, 16), 8, 16, False),       # three nodes, plain projection: EvaAttnFn takes the composite entry
+    (64, 2, (16, 16), 4, 16, False),        # d = 32
+])
+def test_eva_composite_equals_step_by_step(dtype, dim, heads, grid, window, landmarks, module_fn, monkeypatch):
+    """ea_eva_layer_fwd / _bwd (one C-ABI call per direction for the 2-D EVA core) issue exactly the launches the
+    step-by-step path issues: outputs and every gradient are bit-identical, with and without the relative-position bias."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    monkeypatch.setattr(_ops, "USE_EVA_MODULE_FN", module_fn)
+    for use_rpe in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.manual_seed(15)
+            m = ea.AttentionFactory.build_attention("eva", dict(dim=dim, num_heads=heads, num_landmarks=landmarks, window_size=window,
+                                                                attn_2d=True, use_rpe=use_rpe, adaptive_proj="default")).cuda()
+        m.train()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.02 * torch.randn_like(p))
+        x0 = torch.randn(3, grid[0], grid[1], dim, device="cuda")
+        g = torch.randn(3, grid[0], grid[1], dim, device="cuda").to(td)
+        res, used = {}, {}
+        for comp in (True, False):
+            monkeypatch.setattr(_ops, "_eva_use_composite", lambda comp=comp: comp)
+            calls = []
+            orig = _ops.nv.call
+
+            def spy(name, *a, _calls=calls, _orig=orig):
+                _calls.append(name)
+                return _orig(name, *a)
+            monkeypatch.setattr(_ops.nv, "call", spy)
+            for p in m.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(5)
+            with torch.autocast("cuda", dtype=td):
+                y = m(x)
+            y.backward(g)
+            monkeypatch.setattr(_ops.nv, "call", orig)
+            res[comp] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            used[comp] = ("ea_eva_layer_fwd" in calls, "ea_eva_layer_bwd" in calls)
+        pooled_three_nodes = (not module_fn) and dim == 192
+        assert used[True] == ((False, False) if pooled_three_nodes else (True, True)), used
+        assert used[False] == (False, False)
+        assert torch.equal(res[True][0], res[False][0])
+        assert torch.equal(res[True][1], res[False][1])
+        assert res[True][2].keys() == res[False][2].keys()
+        for n in res[True][2]:
+            a, b = res[True][2][n], res[False][2][n]
+            if n == "local_relative_position_bias_table" and window == 4:
+                # general-geometry window backward with several windows of a workgroup in flight: the bias gradient is
+                # accumulated with fp32 LDS atomics, whose order is not fixed from run to run (ea_window_bwd.hip, bias mode 2)
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), n
+            else:
+                assert torch.equal(a, b), n
