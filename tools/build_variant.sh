@@ -8,7 +8,7 @@ mkdir -p $R/tools/bin/$NAME
 OBJS=""
 for f in $R/efficient-attention_amd/csrc/ea_*.hip; do
   o=$R/tools/bin/$NAME/$(basename ${f%.hip}).o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form "$@" -I$R/include -I$R/efficient-attention_amd/csrc -c $f -o $o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -cuid=$(basename ${f%.hip}) "$@" -I$R/include -I$R/efficient-attention_amd/csrc -c $f -o $o &
   OBJS="$OBJS $o"
 done
 wait
