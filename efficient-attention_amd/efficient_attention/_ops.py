@@ -277,6 +277,15 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
 # ------------------------------------------------------------------------------------------
 # local window attention  (reference local_attention.py:134-182)
 # ------------------------------------------------------------------------------------------
+def _f32c(t):
+    """A parameter as the kernels read it (fp32, contiguous: only its data pointer is taken).  fp32 master parameters -- the
+    normal case -- pass through untouched: detach() + float() + contiguous() were three dispatcher calls per parameter, 48 per
+    eager step of a layer with two landmark networks."""
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t
+    return t.detach().float().contiguous()
+
+
 def _opt(t):
     """Dispatcher ops carry `None` tensors of a Tensor[] as empty tensors."""
     return None if (t is None or t.numel() == 0) else t
@@ -422,7 +431,7 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
             geom = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)[0]
             bias_p = _bias_padded(bias, geom)
             noise_c = None if noise is None else noise.float().contiguous()
-            ps = [p.detach().float().contiguous() for p in mlp_params]
+            ps = [_f32c(p) for p in mlp_params]
             LAST_LMK_GEOM = (B * h, int(icfg[6]), int(icfg[6]), d, 1, 0, 1)
             nv.call("ea_eva_layer_fwd", ctypes.byref(lcfg), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
                     nv.ptr(bias_p), nv.ptr(noise_c), _param_ptrs(ps), ctypes.byref(to), nv.ptr(ws),
@@ -440,7 +449,7 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
         kmean = torch.empty_like(qmean)
         nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
                 nv.ptr(mask_u8), nv.ptr(qmean), nv.ptr(kmean), nv.stream())
-    ps = [p.detach().float().contiguous() for p in mlp_params]
+    ps = [_f32c(p) for p in mlp_params]
     noise_c = saved = zhat = rstd = None
     if fused_mu:
         # Linear + LayerNorm + mu + omega in one HIP kernel (ea_lara_landmarks_fwd, eva mode)
@@ -502,7 +511,7 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
         ts = [nv.t4(t) for t in (q, k, v, out.permute(0, 2, 1, 3), dout.permute(0, 2, 1, 3), dq, dk, dv)]
         tmp = torch.empty(sizes[1], dtype=torch.float32, device=dev)
         noise_c = None if noise is None else noise.float().contiguous()
-        ps = [p.detach().float().contiguous() for p in mlp_params]
+        ps = [_f32c(p) for p in mlp_params]
         dbias = None if bias_p is None else torch.empty_like(bias_p)
         dpar = None if defer_param_sums else torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev)
         nv.call("ea_eva_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
@@ -532,7 +541,7 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
     nv.call("ea_eva_beta_bwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
             nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.ptr(d_beta), ctypes.byref(tdk),
             ctypes.byref(tdv), nv.ptr(d_omega), nv.stream())
-    ps = [p.detach().float().contiguous() for p in mlp_params]
+    ps = [_f32c(p) for p in mlp_params]
     if dbias is not None:
         dbias = dbias[..., :bias_cols].contiguous()
     if fused_mu:
@@ -1223,14 +1232,23 @@ def _lara_layer_cfg(qkv5, icfg, fcfg):
     return _lara_layer_cfg_dims(B, h, d, nv.io_dtype(qkv5), icfg, fcfg)
 
 
+_LARA_LAYER_CFG = {}
+
+
 def _lara_layer_cfg_dims(B, h, d, io, icfg, fcfg):
-    H, W, r, has_mlp, mixed, mis, dup = [int(v) for v in icfg[:7]]
-    kappa, scale = [float(v) for v in fcfg]
-    cfg = nv.ea_lara_layer(B, h, d, io, H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
-    sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2)]
-    if min(sizes) < 0:
-        return None, None
-    return cfg, sizes
+    """(ea_lara_layer, [saved, forward scratch, backward scratch floats; offsets of pq, pk, dW partials, dvec partials]) or
+    (None, None) -- a pure function of the geometry, memoised (seven host calls per query otherwise, twice per eager step)."""
+    key = (B, h, d, io) + tuple(int(v) for v in icfg[:7]) + tuple(float(v) for v in fcfg)
+    hit = _LARA_LAYER_CFG.get(key)
+    if hit is None:
+        H, W, r, has_mlp, mixed, mis, dup = key[4:11]
+        kappa, scale = key[11:13]
+        cfg = nv.ea_lara_layer(B, h, d, io, H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
+        sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2, 3, 4, 5, 6)]
+        hit = (cfg, sizes) if min(sizes) >= 0 else (None, None)
+        if len(_LARA_LAYER_CFG) < 256:
+            _LARA_LAYER_CFG[key] = hit
+    return hit
 
 
 def _lara_use_composite():
@@ -1272,7 +1290,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params, pooled=None):
         out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
         to = nv.t4(out.permute(0, 2, 1, 3))
         noise_c = None if noise is None else noise.float().contiguous()
-        ps = [t.detach().float().contiguous() for t in params]
+        ps = [_f32c(t) for t in params]
         pp = _param_ptrs(ps) if ps else None
         LAST_LMK_GEOM = (B * h, (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r),
                          (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r) * (2 if lcfg.dup else 1), d, lcfg.has_mlp, lcfg.mixed, 0)
@@ -1293,7 +1311,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params, pooled=None):
         nv.call("ea_eva_chunk_mean_fwd", ctypes.byref(pgeom), ctypes.byref(tq), ctypes.byref(tk), None,
                 nv.ptr(pq), nv.ptr(pk), nv.stream())
     noise_c = None if noise is None else noise.float().contiguous()
-    ps = [t.detach().float().contiguous() for t in params]
+    ps = [_f32c(t) for t in params]
     LAST_LMK_GEOM = (BH, L, C, d, has_mlp, mixed, 0)
     omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
     qrows = torch.empty_like(omega) if mis != 2 else None
@@ -1325,7 +1343,7 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
         ts = [nv.t4(t) for t in (q, k, v, dout.permute(0, 2, 1, 3), dq, dk, dv)]
         tmp = torch.empty(sizes[2], dtype=torch.float32, device=dev)
         noise_c = None if noise is None else noise.float().contiguous()
-        ps = [t.detach().float().contiguous() for t in params]
+        ps = [_f32c(t) for t in params]
         pp = _param_ptrs(ps) if ps else None
         defer = bool(defer_param_sums and ps)
         dpar = torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev) if (ps and not defer) else None
@@ -1335,7 +1353,7 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
         grads = [dqkv5]
         if defer:
             # (direct calls only) the per-(b,h) partials, still to be added up: [B*h, 2 d d], [B*h, 6 d]
-            o_dW, o_dvec = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(lcfg), w)) for w in (5, 6)]
+            o_dW, o_dvec = sizes[5], sizes[6]
             BH = B * h
             return grads + [("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
                              tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))]
@@ -1348,7 +1366,7 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
     noise_c = None if noise is None else noise.float().contiguous()
     B, N, _, h, d = qkv5.shape
     BH, dev = B * h, qkv5.device
-    ps = [t.detach().float().contiguous() for t in params]
+    ps = [_f32c(t) for t in params]
     dout = dout.contiguous()
     dqkv5 = torch.empty_like(qkv5)
     d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
@@ -1462,7 +1480,7 @@ class LaraModuleFn(torch.autograd.Function):
             lcfg, sizes = _lara_layer_cfg_dims(B, heads, d, elem, icfg, fcfg) if _lara_use_composite() else (None, None)
             if lcfg is not None:
                 ws = torch.empty(sizes[0], dtype=torch.float32, device=x.device)
-                o_pq, o_pk = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(lcfg), w)) for w in (3, 4)]
+                o_pq, o_pk = sizes[3], sizes[4]
                 n_p = B * heads * L * d
                 pooled = (ws, None, None)
                 pq, pk = ws[o_pq:o_pq + n_p], ws[o_pk:o_pk + n_p]
@@ -2296,6 +2314,9 @@ USE_WGRAD = os.environ.get("EA_WGRAD", "1") == "1"
 USE_LARA_MODULE_FN = os.environ.get("EA_LARA_MODULE_FN", "1") == "1"
 
 
+_WGRAD_PARTS = {}       # (rows, out, in) -> slice count of ea_wgrad (a pure function of the shape)
+
+
 def wgrad(dy2, x2, with_bias=True, defer=False):
     """dW [out, in] = dY^T X and db [out] = dY.sum(0), both fp32, from one pass over dY and X (ea_wgrad:
     token slices x output tiles, slice partials summed in a fixed order)."""
@@ -2303,9 +2324,13 @@ def wgrad(dy2, x2, with_bias=True, defer=False):
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
     rows, M = dy2.shape
     K = x2.shape[1]
-    S = nv.lib().ea_wgrad_parts(rows, M, K)
-    if S <= 0:
-        raise RuntimeError("ea_wgrad_parts: %d" % S)
+    S = _WGRAD_PARTS.get((rows, M, K))
+    if S is None:
+        S = nv.lib().ea_wgrad_parts(rows, M, K)
+        if S <= 0:
+            raise RuntimeError("ea_wgrad_parts: %d" % S)
+        if len(_WGRAD_PARTS) < 1024:
+            _WGRAD_PARTS[(rows, M, K)] = S
     n = M * K + (M if with_bias else 0)
     part = torch.empty((S, n), dtype=torch.float32, device=dy2.device)      # slice s: dW partial, then db partial
     db_ptr = ctypes.c_void_p(part.data_ptr() + M * K * 4) if with_bias else None
