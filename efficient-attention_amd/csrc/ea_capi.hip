@@ -34,6 +34,9 @@ int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const 
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
+int wgrad_pair_slices(int rows, int M1, int K1, int M2, int K2);
+int wgrad_pair_dispatch(int dtype, int rows, const void* dy1, const void* x1, float* part1, float* db1, long ld1, int M1, int K1,
+                        const void* dy2, const void* x2, float* part2, float* db2, long ld2, int M2, int K2, hipStream_t st);
 int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
                    int K, hipStream_t st);
 int part_sum_dispatch(const float* part, float* out, int S, int n, long ld, hipStream_t st);
@@ -65,7 +68,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 8; }
+int32_t ea_abi_version(void) { return 9; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -954,6 +957,21 @@ int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_featu
   if (!dy || !x || !dw_part || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw_part & 15)) return EA_E_BADARG;
   if (part_ld < (int64_t)out_features * in_features || (part_ld & 3)) return EA_E_BADARG;
   return wgrad_dispatch(dtype, dy, x, dw_part, db_part, (long)part_ld, rows, out_features, in_features, (hipStream_t)stream);
+}
+
+int32_t ea_wgrad_pair_parts(int32_t rows, int32_t out1, int32_t in1, int32_t out2, int32_t in2) {
+  return wgrad_pair_slices(rows, out1, in1, out2, in2);
+}
+
+int ea_wgrad_pair(int32_t dtype, int32_t rows, int32_t out1, int32_t in1, const void* dy1, const void* x1, float* dw_part1,
+                  float* db_part1, int64_t part_ld1, int32_t out2, int32_t in2, const void* dy2, const void* x2,
+                  float* dw_part2, float* db_part2, int64_t part_ld2, void* stream) {
+  if ((dtype != EA_BF16 && dtype != EA_F16) || rows <= 0 || !dy1 || !x1 || !dw_part1 || !dy2 || !x2 || !dw_part2) return EA_E_BADARG;
+  if (part_ld1 < (int64_t)out1 * in1 || part_ld2 < (int64_t)out2 * in2 || (part_ld1 & 3) || (part_ld2 & 3)) return EA_E_BADARG;
+  if (((uintptr_t)dy1 | (uintptr_t)x1 | (uintptr_t)dw_part1 | (uintptr_t)dy2 | (uintptr_t)x2 | (uintptr_t)dw_part2) & 15)
+    return EA_E_BADARG;
+  return wgrad_pair_dispatch(dtype, rows, dy1, x1, dw_part1, db_part1, (long)part_ld1, out1, in1, dy2, x2, dw_part2, db_part2,
+                             (long)part_ld2, out2, in2, (hipStream_t)stream);
 }
 
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream) {

@@ -27,6 +27,14 @@ struct WgP {
   long part_ld;
   int rows, M, K;
   int S, rows_per_slice, tiles_m, tiles_n;
+  // a SECOND product over the same token rows in the same launch (ea_wgrad_pair, round 4): its tiles follow the first one's
+  // in the tile index.  T2 = 0: none.
+  const char* dy2;
+  const char* x2;
+  float* part2;
+  float* db_part2;
+  long part_ld2;
+  int M2, K2, tiles_n2, T2;
 };
 
 template <typename E, int BM, int BN>
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   // block -> (slice, tile): every tile of a slice on the same XCD (block id modulo 8)
-  const int T = p.tiles_m * p.tiles_n;
+  const int T1 = p.tiles_m * p.tiles_n, T = T1 + p.T2;
   int tile, slice;
   if ((p.S & 7) == 0) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -48,11 +56,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     tile = blockIdx.x % T; slice = blockIdx.x / T;
   }
   if (slice >= p.S) return;
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  // which product this workgroup belongs to (uniform): everything below reads these copies
+  const bool second = tile >= T1;
+  const char* const dyp = second ? p.dy2 : p.dy;
+  const char* const xp = second ? p.x2 : p.x;
+  float* const partp = second ? p.part2 : p.part;
+  float* const dbp = second ? p.db_part2 : p.db_part;
+  const long part_ld = second ? p.part_ld2 : p.part_ld;
+  const int pM = second ? p.M2 : p.M, pK = second ? p.K2 : p.K, tiles_n = second ? p.tiles_n2 : p.tiles_n;
+  if (second) tile -= T1;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int r0 = slice * p.rows_per_slice;
   const int r1 = min(p.rows, r0 + p.rows_per_slice);
-  const bool with_bias = p.db_part != nullptr && tn == 0;
+  const bool with_bias = dbp != nullptr && tn == 0;
 
   u32x4 pa[SA], pb[SB];
   auto issue = [&](int rb) {
@@ -61,14 +78,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
       const int idx = tid + k * 512;
       const int row = idx / CPRA, ch = idx - row * CPRA;
       const int t = rb + row;
-      pa[k] = t < r1 ? ldg16(p.dy + ((size_t)t * p.M + m0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+      pa[k] = t < r1 ? ldg16(dyp + ((size_t)t * pM + m0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
       const int idx = tid + k * 512;
       const int row = idx / CPRB, ch = idx - row * CPRB;
       const int t = rb + row;
-      pb[k] = t < r1 ? ldg16(p.x + ((size_t)t * p.K + n0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+      pb[k] = t < r1 ? ldg16(xp + ((size_t)t * pK + n0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
     }
   };
   // bias partials: a thread's staged chunks all sit in ONE 8-channel group when 512 is a multiple of the chunks per row
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   // fragment fa <-> out channel 64 sa + 16 dt + 4 g + r, D column li of fragment fb <-> in channel 16 fb + li): 72
   // dword stores per lane straight from the accumulators would cost more than the whole stream.  The stage buffers
   // are free; one half of the in-channels (the waves of one wb) at a time fits them.
-  float* out = p.part + (size_t)slice * p.part_ld;
+  float* out = partp + (size_t)slice * part_ld;
   float* ot = reinterpret_cast<float*>(smem);             // [BM][BN / 2]
   constexpr int HN = BN / 2;
 #pragma unroll
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     __syncthreads();
     for (int idx = tid; idx < BM * (HN / 4); idx += 512) {
       const int m = idx / (HN / 4), c4 = idx - m * (HN / 4);
-      *reinterpret_cast<f32x4*>(out + (size_t)(m0 + m) * p.K + n0 + h * HN + c4 * 4) =
+      *reinterpret_cast<f32x4*>(out + (size_t)(m0 + m) * pK + n0 + h * HN + c4 * 4) =
           *reinterpret_cast<const f32x4*>(ot + m * HN + c4 * 4);
     }
     __syncthreads();
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     const int ch = tid >> 3, e = tid & 7;
     float s = 0.f;
     for (int row = 0; row < NB * 512 / CPRA; ++row) s += red[(size_t)(row * CPRA + ch) * 8 + e];
-    p.db_part[(size_t)slice * p.part_ld + m0 + tid] = s;
+    dbp[(size_t)slice * part_ld + m0 + tid] = s;
   }
 }
 
@@ -325,7 +342,7 @@ template <typename E, int BM, int BN>
 static int launch_wg(const WgP& p, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM / 64 + BN / 64) * 64 * 128;
   if (lds > 64 * 1024) EA_SET_LDS_ONCE((&wgrad_kernel<E, BM, BN>), lds);
-  const int T = p.tiles_m * p.tiles_n;
+  const int T = p.tiles_m * p.tiles_n + p.T2;
   const dim3 grid((unsigned)(((p.S & 7) == 0 ? ((p.S + 7) / 8) * 8 : p.S) * T)), block(512);
   hipLaunchKernelGGL((wgrad_kernel<E, BM, BN>), grid, block, lds, st, p);
   return (int)hipGetLastError();
@@ -339,11 +356,51 @@ static int launch_wg_n(const WgP& p, int bn, hipStream_t st) {
   return launch_wg<E, BM, 64>(p, st);
 }
 
+// Two products over the SAME token rows in one launch (the weight gradients of a layer's qkv and output projections): with the
+// tiles of both in the tile index a slice is four [192 x 192] tiles instead of three and one, i.e. 64 slices of 1568 tokens for
+// the pair instead of 80 + 256 slices -- half the partial-sum traffic (38 MB written and read back instead of 73 MB at cfg3)
+// and one launch's fixed cost less.  Both must take the same tile edges.
+int wgrad_pair_slices(int rows, int M1, int K1, int M2, int K2) {
+  if (rows <= 0 || M1 <= 0 || K1 <= 0 || M2 <= 0 || K2 <= 0 || ((M1 | K1 | M2 | K2) & 63)) return EA_E_UNSUPPORTED;
+  if (wg_bt(M1) != wg_bt(M2) || wg_bt(K1) != wg_bt(K2)) return EA_E_UNSUPPORTED;
+  const int T = (M1 / wg_bt(M1)) * (K1 / wg_bt(K1)) + (M2 / wg_bt(M2)) * (K2 / wg_bt(K2));
+  const int per_xcd = wg_cus() / 8;
+  int S = per_xcd / T * 8;
+  if (S < 8) S = 8;
+  while (S > 8 && rows / S < 256) S -= 8;
+  return S;
+}
+
+int wgrad_pair_dispatch(int dtype, int rows, const void* dy1, const void* x1, float* part1, float* db1, long ld1, int M1, int K1,
+                        const void* dy2, const void* x2, float* part2, float* db2, long ld2, int M2, int K2, hipStream_t st) {
+  const int S = wgrad_pair_slices(rows, M1, K1, M2, K2);
+  if (S < 0) return S;
+  WgP p = {};
+  p.dy = (const char*)dy1; p.x = (const char*)x1; p.part = part1; p.db_part = db1; p.part_ld = ld1;
+  p.rows = rows; p.M = M1; p.K = K1; p.S = S;
+  p.rows_per_slice = (rows + S - 1) / S;
+  const int bm = wg_bt(M1), bn = wg_bt(K1);
+  p.tiles_m = M1 / bm; p.tiles_n = K1 / bn;
+  p.dy2 = (const char*)dy2; p.x2 = (const char*)x2; p.part2 = part2; p.db_part2 = db2; p.part_ld2 = ld2;
+  p.M2 = M2; p.K2 = K2; p.tiles_n2 = K2 / bn; p.T2 = (M2 / bm) * (K2 / bn);
+#define EA_WG(E)                                                        \
+  do {                                                                  \
+    if (bm == 256) return launch_wg_n<E, 256>(p, bn, st);               \
+    if (bm == 192) return launch_wg_n<E, 192>(p, bn, st);               \
+    if (bm == 128) return launch_wg_n<E, 128>(p, bn, st);               \
+    return launch_wg_n<E, 64>(p, bn, st);                               \
+  } while (0)
+  if (dtype == EA_BF16) EA_WG(BF16);
+  if (dtype == EA_F16) EA_WG(F16);
+#undef EA_WG
+  return EA_E_BADARG;
+}
+
 int wgrad_dispatch(int dtype, const void* dy, const void* x, float* part, float* db_part, long part_ld, int rows, int M,
                    int K, hipStream_t st) {
   const int S = wgrad_slices(rows, M, K);
   if (S < 0) return S;
-  WgP p;
+  WgP p = {};
   p.dy = (const char*)dy; p.x = (const char*)x; p.part = part; p.db_part = db_part;
   p.rows = rows; p.M = M; p.K = K; p.S = S;
   p.part_ld = part_ld;

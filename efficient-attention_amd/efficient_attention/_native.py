@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 8          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 9          # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -133,6 +133,8 @@ SIGNATURES = {
     "ea_linear_w32_pool": [_I] * 7 + [_P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
+    "ea_wgrad_pair_parts": [_I, _I, _I, _I, _I],
+    "ea_wgrad_pair": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_part_sum": [_I, _I, _L, _P, _P, _P],
     "ea_multi_sum": [_I, _P, _P, _P, _P, _P, _P],
     "ea_lara_layer_ws": [_LL, _I],

@@ -725,13 +725,14 @@ class EvaModuleFn(torch.autograd.Function):
         pend = []
         dwp = dbp = dwq = dbq = dx = None
         need_bp = bpd is not None and need[4]
-        if need[3]:
+        pair = bool(defer and need[3] and need[1] and wgrad_pair_usable(dy2, o2, qkv5.view(-1, 3 * C), xl))
+        if need[3] and not pair:
             r_ = wgrad(dy2, o2, need_bp, defer=defer)
             if defer:
                 pend.append(("proj", r_[0], r_[1]))
             else:
                 dwp, dbp = r_[0].to(wpd), (r_[1].to(bpd) if need_bp else None)
-        elif need_bp:
+        elif need_bp and not pair:
             dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
         g = eva_bwd_impl(d_o2.view(B, N, heads, d), qkv5, mask_u8, None, noise, o2.view(B, N, heads, d), list(saved), ctx.icfg,
@@ -744,7 +745,11 @@ class EvaModuleFn(torch.autograd.Function):
             pend.append(("mu_v", pgrads[0][2], None))
             pgrads = []
         need_bq = bqd is not None and need[2]
-        if need[1]:
+        if pair:
+            rq, rp = wgrad_pair(dqkv2, xl, need_bq, dy2, o2, need_bp)
+            pend.append(("qkv", rq[0], rq[1]))
+            pend.append(("proj", rp[0], rp[1]))
+        elif need[1]:
             if xl is None:
                 raise RuntimeError("EvaModuleFn: the weight gradient was requested but the forward did not keep its input")
             r_ = wgrad(dqkv2, xl, need_bq, defer=defer)
@@ -1525,7 +1530,9 @@ class LaraModuleFn(torch.autograd.Function):
         pend = []                                                  # (what, partial tensor, meta)
         dwp = dbp = None
         need_bp = bpd is not None and need[4]
-        if need[3]:
+        # both weight gradients in ONE launch at the end of this backward when both are wanted (ea_wgrad_pair)
+        pair = bool(defer and need[3] and need[1] and wgrad_pair_usable(dy2, o2, qkv5.view(-1, 3 * C), xl))
+        if need[3] and not pair:
             r_ = wgrad(dy2, o2, need_bp, defer=defer)
             if defer:
                 pend.append(("proj", r_[0], r_[1]))
@@ -1533,7 +1540,7 @@ class LaraModuleFn(torch.autograd.Function):
                 dwp, dbp32 = r_
                 dwp = dwp.to(wpd)
                 dbp = dbp32.to(bpd) if need_bp else None
-        elif need_bp:
+        elif need_bp and not pair:
             dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
         if defer:
@@ -1549,7 +1556,11 @@ class LaraModuleFn(torch.autograd.Function):
         dqkv2 = grads[0].view(-1, 3 * C)
         dwq = dbq = dx = None
         need_bq = bqd is not None and need[2]
-        if need[1]:
+        if pair:
+            rq, rp = wgrad_pair(dqkv2, xl, need_bq, dy2, o2, need_bp)
+            pend.append(("qkv", rq[0], rq[1]))
+            pend.append(("proj", rp[0], rp[1]))
+        elif need[1]:
             if xl is None:
                 raise RuntimeError("LaraModuleFn: the weight gradient was requested but the forward did not keep its input")
             r_ = wgrad(dqkv2, xl, need_bq, defer=defer)
@@ -2344,6 +2355,58 @@ def wgrad(dy2, x2, with_bias=True, defer=False):
     out = torch.empty(n, dtype=torch.float32, device=dy2.device)
     nv.call("ea_part_sum", S, n, n, nv.ptr(part), nv.ptr(out), nv.stream())
     return _wgrad_split(out, (M, K, with_bias))
+
+
+USE_WGRAD_PAIR = os.environ.get("EA_WGRAD_PAIR", "1") == "1"
+_WGRAD_PAIR_PARTS = {}
+
+
+def wgrad_pair_parts(rows, M1, K1, M2, K2):
+    """Slice count of ea_wgrad_pair for the two products, or 0 when they cannot share a launch."""
+    key = (rows, M1, K1, M2, K2)
+    S = _WGRAD_PAIR_PARTS.get(key)
+    if S is None:
+        S = max(int(nv.lib().ea_wgrad_pair_parts(rows, M1, K1, M2, K2)), 0)
+        if len(_WGRAD_PAIR_PARTS) < 1024:
+            _WGRAD_PAIR_PARTS[key] = S
+    return S
+
+
+def wgrad_pair(dy1, x1, bias1, dy2, x2, bias2):
+    """The weight (+ bias) gradients of two projections over the same token rows in ONE launch (ea_wgrad_pair) ->
+    ((partials [S, n1], meta1), (partials [S, n2], meta2)), each as wgrad(..., defer=True) returns them: the caller adds the
+    slices up (multi_sum).  A layer's qkv and output projections: 64 slices for the pair instead of 80 + 256 at cfg3 -- half
+    the partial-sum traffic, one launch less."""
+    dy1 = dy1 if dy1.is_contiguous() else dy1.contiguous()
+    x1 = x1 if x1.is_contiguous() else x1.contiguous()
+    dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    rows, M1 = dy1.shape
+    K1 = x1.shape[1]
+    M2, K2 = dy2.shape[1], x2.shape[1]
+    S = wgrad_pair_parts(rows, M1, K1, M2, K2)
+    if S <= 0:
+        raise RuntimeError("ea_wgrad_pair_parts: the two products cannot share a launch")
+    n1 = M1 * K1 + (M1 if bias1 else 0)
+    n2 = M2 * K2 + (M2 if bias2 else 0)
+    part1 = torch.empty((S, n1), dtype=torch.float32, device=dy1.device)
+    part2 = torch.empty((S, n2), dtype=torch.float32, device=dy1.device)
+    db1 = ctypes.c_void_p(part1.data_ptr() + M1 * K1 * 4) if bias1 else None
+    db2 = ctypes.c_void_p(part2.data_ptr() + M2 * K2 * 4) if bias2 else None
+    label = "ea_wgrad_pair"
+    if nv.KERNEL_TIMER.enabled:
+        label = "ea_wgrad_pair[%dx%d+%dx%d]" % (M1, K1, M2, K2)
+        _note_bytes(label, rows * (M1 + K1 + M2 + K2) * 2 + (n1 + n2) * 4)
+    nv.call_as(label, "ea_wgrad_pair", nv.io_dtype(dy1), rows, M1, K1, nv.ptr(dy1), nv.ptr(x1), nv.ptr(part1), db1, n1,
+               M2, K2, nv.ptr(dy2), nv.ptr(x2), nv.ptr(part2), db2, n2, nv.stream())
+    return (part1, (M1, K1, bool(bias1))), (part2, (M2, K2, bool(bias2)))
+
+
+def wgrad_pair_usable(dy1, x1, dy2, x2):
+    """Both products go through ea_wgrad and share their rows and tile edges."""
+    return (USE_WGRAD_PAIR and x1 is not None and x2 is not None
+            and wgrad_supported(dy1, x1) and wgrad_supported(dy2, x2) and dy1.shape[0] == dy2.shape[0]
+            and wgrad_pair_parts(dy1.shape[0], dy1.shape[1], x1.shape[1], dy2.shape[1], x2.shape[1]) > 0)
 
 
 def _wgrad_split(out, meta):

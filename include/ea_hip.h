@@ -513,6 +513,15 @@ int32_t ea_wgrad_parts(int32_t rows, int32_t out_features, int32_t in_features);
 int ea_wgrad(int32_t dtype, int32_t rows, int32_t out_features, int32_t in_features, const void* dy, const void* x,
              float* dw_part, float* db_part, int64_t part_ld, void* stream);
 int ea_part_sum(int32_t S, int32_t n, int64_t ld, const float* parts, float* out, void* stream);
+/* The weight (+ bias) gradients of TWO projections over the same token rows in one launch -- a layer's qkv and output
+ * projections (abstract_attention.py:72-78,86-87 differentiated): dW1 = dY1^T X1, dW2 = dY2^T X2, rows shared.  With both
+ * products' tiles in one grid a token slice is longer (S = ea_wgrad_pair_parts(...) slices for BOTH, fewer than either
+ * product alone takes): half the partial-sum bytes and one launch less.  Arguments per product as for ea_wgrad; both need
+ * the same tile edges (EA_E_UNSUPPORTED from ea_wgrad_pair_parts otherwise: use two ea_wgrad calls). */
+int32_t ea_wgrad_pair_parts(int32_t rows, int32_t out1, int32_t in1, int32_t out2, int32_t in2);
+int ea_wgrad_pair(int32_t dtype, int32_t rows, int32_t out1, int32_t in1, const void* dy1, const void* x1, float* dw_part1,
+                  float* db_part1, int64_t part_ld1, int32_t out2, int32_t in2, const void* dy2, const void* x2,
+                  float* dw_part2, float* db_part2, int64_t part_ld2, void* stream);
 /* K <= 4 such reductions in one launch: out[k][j] = sum_s parts[k][s * ld[k] + j], j < n[k] (same order of additions as
  * ea_part_sum).  The terminal sums of a layer's backward -- both projections' slice partials and the per-(b,h) partials of
  * the landmark parameters (ea_lara_layer_bwd with dparams == NULL) -- share one launch this way. */

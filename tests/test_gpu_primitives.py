@@ -505,13 +505,14 @@ def test_multi_sum_equals_fp64_sums_and_single_reductions():
 
 
 @pytest.mark.gpu
-def test_lara_module_deferred_sums_equal_separate_reductions():
+def test_lara_module_deferred_sums_equal_separate_reductions(monkeypatch):
     """LaraModuleFn's backward with the terminal sums in one launch (EA_MULTI_SUM) against the separate reductions: the
     projection gradients bit for bit (same order of additions), the landmark parameters to fp32 accuracy."""
     import warnings
     import torch
     import efficient_attention as ea
     from efficient_attention import _ops
+    monkeypatch.setattr(_ops, "USE_WGRAD_PAIR", False)      # (the paired launch cuts the token axis into other slices)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.manual_seed(15)
@@ -930,3 +931,90 @@ def test_eva_composite_equals_step_by_step(dtype, dim, heads, grid, window, land
                 assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), n
             else:
                 assert torch.equal(a, b), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows", [100352, 25088, 1000])
+def test_wgrad_pair_matches_two_launches(dtype, rows):
+    """ea_wgrad_pair (both projections' weight + bias gradients over the same token rows in one launch) against two ea_wgrad
+    launches and against an fp64 product: same tiles and MFMA order per slice, different slice boundaries -> fp32 summation
+    order differs, nothing else."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy1 = torch.randn(rows, 576, device="cuda", generator=g).to(td)
+    x1 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
+    dy2 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
+    x2 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
+    assert _ops.wgrad_pair_usable(dy1, x1, dy2, x2)
+    (p1, m1), (p2, m2) = _ops.wgrad_pair(dy1, x1, True, dy2, x2, True)
+    assert p1.shape[0] == p2.shape[0] and p1.shape[0] < _ops.nv.lib().ea_wgrad_parts(rows, 576, 192) + (1 if rows < 4096 else 0)
+    s1, s2 = _ops.multi_sum([p1, p2])
+    dw1, db1 = _ops._wgrad_split(s1, m1)
+    dw2, db2 = _ops._wgrad_split(s2, m2)
+    for (dw, db, dy, x) in ((dw1, db1, dy1, x1), (dw2, db2, dy2, x2)):
+        rw, rb = _ops.wgrad(dy, x, True)
+        ref_w = dy.double().t() @ x.double()
+        ref_b = dy.double().sum(0)
+        sc = float(ref_w.abs().max())
+        assert float((dw.double() - ref_w).abs().max()) <= 2e-5 * sc + 1e-3
+        assert float((rw.double() - ref_w).abs().max()) <= 2e-5 * sc + 1e-3
+        assert float((db.double() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-3
+        assert float((dw - rw).abs().max()) <= 2e-5 * sc + 1e-3 and float((db - rb).abs().max()) <= 1e-3 + 2e-5 * float(ref_b.abs().max())
+    # one without bias, different widths that still share the tile edge
+    (q1, n1), (q2, n2) = _ops.wgrad_pair(dy1, x1, False, dy2, x2, True)
+    t1, t2 = _ops.multi_sum([q1, q2])
+    assert _ops._wgrad_split(t1, n1)[1] is None
+    assert torch.equal(_ops._wgrad_split(t1, n1)[0], dw1) and torch.equal(_ops._wgrad_split(t2, n2)[0], dw2)
+    # 512-wide against 192-wide: different tile edges -> not pairable
+    assert _ops.wgrad_pair_parts(rows, 1536, 512, 192, 192) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["lara", "eva"])
+def test_module_backward_with_paired_weight_gradients(attn, monkeypatch):
+    """LaraModuleFn / EvaModuleFn with ea_wgrad_pair against the two-launch path: every gradient within fp32 summation noise."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    args = (dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)
+            if attn == "lara" else dict(dim=192, num_heads=3, num_landmarks=49, window_size=7, attn_2d=True, use_rpe=True,
+                                        adaptive_proj="default"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(16)
+        m = ea.AttentionFactory.build_attention(attn, args).cuda()
+    m.train()
+    x0 = torch.randn(4, 28, 28, 192, device="cuda")
+    g = torch.randn(4, 28, 28, 192, device="cuda").bfloat16()
+    res, used = {}, {}
+    for pair in (True, False):
+        monkeypatch.setattr(_ops, "USE_WGRAD_PAIR", pair)
+        calls = []
+        orig = _ops.nv.call
+
+        def spy(name, *a, _calls=calls, _orig=orig):
+            _calls.append(name)
+            return _orig(name, *a)
+        monkeypatch.setattr(_ops.nv, "call", spy)
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(5)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        y.backward(g)
+        monkeypatch.setattr(_ops.nv, "call", orig)
+        used[pair] = "ea_wgrad_pair" in calls
+        res[pair] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert used == {True: True, False: False}
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n in res[True][2]:
+        a, b = res[True][2][n], res[False][2][n]
+        if n in ("qkv.weight", "qkv.bias", "proj.weight", "proj.bias"):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, n
+        else:
+            assert torch.equal(a, b), n
