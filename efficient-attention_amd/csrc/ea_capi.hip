@@ -30,7 +30,7 @@ int linear_supported(int K, int NO);
 int proj_rs_supported(int K, int NO);
 int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r);
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk);
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
@@ -1198,7 +1198,7 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
   //  at N = 196 x batch 128 the LDS-resident kernel is faster, 25.7 against 30.1 us)
   if (rs_on && !w_transposed && !y_f32 && rows >= 65536 && proj_rs_supported(in_features, out_features))
     return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream, 0, 0, 0, 0,
-                            nullptr, nullptr);
+                            nullptr, nullptr, nullptr);
   return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
                          (long)lda, (long)ldy, (hipStream_t)stream);
 }
@@ -1210,14 +1210,15 @@ int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int3
 
 int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t r, int32_t in_features, int32_t out_features,
                        const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
-                       void* a_cast, float* pooled_q, float* pooled_k, void* stream) {
+                       void* a_cast, float* pooled_q, float* pooled_k, void* w_cast, void* stream) {
   if (!a || !w || !y || !pooled_q || !pooled_k || ((uintptr_t)a & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) ||
-      ((uintptr_t)bias & 15) || ((uintptr_t)a_cast & 15) || ((uintptr_t)pooled_q & 15) || ((uintptr_t)pooled_k & 15))
+      ((uintptr_t)bias & 15) || ((uintptr_t)a_cast & 15) || ((uintptr_t)pooled_q & 15) || ((uintptr_t)pooled_k & 15) ||
+      ((uintptr_t)w_cast & 15))
     return EA_E_BADARG;
   if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
   if (!proj_rs_pool_supported(in_features, out_features, B, gh, gw, r)) return EA_E_UNSUPPORTED;
   return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, B * gh * gw, (long)lda, (long)ldy, (hipStream_t)stream, B, gh, gw,
-                          r, pooled_q, pooled_k);
+                          r, pooled_q, pooled_k, w_cast);
 }
 
 }  // extern "C"

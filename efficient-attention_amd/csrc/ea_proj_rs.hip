@@ -20,6 +20,8 @@ struct RsP {
   const float* bias;    // [576] fp32 or null (rounded to the element type before it is added, as F.linear under autocast does)
   char* y;              // [rows, 576] element type, row stride ldy elements
   char* a_cast;         // [rows, 192] element-type copy of a (AF32 only) or null
+  char* w_cast;         // [576, 192] element-type copy of w or null (workgroup 0 writes it: the input-gradient GEMM of the
+                        // backward takes a 16-bit weight, and a cast launch of its own costs 5 us for 110 k elements)
   int rows, ntiles;
   long lda, ldy;
   // pooling epilogue (POOL > 0): the means of the ROUNDED q / k rows over the r x r token cells of a gw-wide grid -- what
@@ -88,6 +90,8 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
         const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
         const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         wr[j][ks] = as_x8<E>(pack8<E>(f));
+        if (p.w_cast && blockIdx.x == 0)
+          stg16(p.w_cast + ((size_t)col[j] * RS_K + ks * 32 + 8 * g) * 2, __builtin_bit_cast(u32x4, wr[j][ks]));
       }
   }
   const int slab_s = st_c >> 3, ch_s = st_c & 7;
@@ -250,10 +254,11 @@ int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r) {
 }
 
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk) {
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast) {
   if (rows <= 0) return EA_OK;
   RsP p = {};
   p.a = (const char*)a; p.w = w; p.bias = bias; p.y = (char*)y; p.a_cast = a_f32 ? (char*)a_cast : nullptr;
+  p.w_cast = (char*)w_cast;
   p.rows = rows; p.ntiles = (rows + RS_TOK - 1) / RS_TOK; p.lda = lda; p.ldy = ldy;
   const int pool = r * r;
   if (pool) {

@@ -130,7 +130,7 @@ SIGNATURES = {
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_linear_w32": [_I, _I, _I, _I, _P, _I, _L, _P, _I, _P, _P, _I, _L, _P, _P],
     "ea_linear_pool_supported": [_I] * 6,
-    "ea_linear_w32_pool": [_I] * 7 + [_P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P],
+    "ea_linear_w32_pool": [_I] * 7 + [_P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_wgrad_pair_parts": [_I, _I, _I, _I, _I],

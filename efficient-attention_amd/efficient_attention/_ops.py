@@ -692,8 +692,10 @@ class EvaModuleFn(torch.autograd.Function):
                 pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
                 pk = torch.empty_like(pq)
                 pooled = (pq, pk)
-            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk)
+            w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
+            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk, w_cast=w16)
         else:
+            w16 = None
             y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
             xc = xc if want else None
         xl = x2 if x2.dtype == cdtype else (xc if want else None)
@@ -702,7 +704,7 @@ class EvaModuleFn(torch.autograd.Function):
                             composite=lcfg is not None)
         o2 = outs[0].reshape(-1, C)
         y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved, ctx.adaptive = icfg, fcfg, len(outs) - 1, adaptive_proj
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], None if bias is None else bias.dtype)
@@ -710,7 +712,7 @@ class EvaModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, mask_u8, noise, o2, wq, wp, *rest = ctx.saved_tensors
+        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads, bias_cols, bias_dt = ctx.meta
         C = xshape[-1]
@@ -760,7 +762,7 @@ class EvaModuleFn(torch.autograd.Function):
         elif need_bq:
             dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+            dx = _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}
@@ -1439,9 +1441,10 @@ def proj_pool_supported(x2, w32, cdtype, B, H, W, r, heads):
             and bool(nv.lib().ea_linear_pool_supported(192, 576, B, H, W, r)))
 
 
-def project_qkv_pooled(x2, wq, bq32, cdtype, want_cast, B, H, W, r, pq, pk):
+def project_qkv_pooled(x2, wq, bq32, cdtype, want_cast, B, H, W, r, pq, pk, w_cast=None):
     """qkv = x2 @ wq.T + bq in `cdtype` with the means of the rounded q / k rows over the r x r cells written to pq / pk
-    (fp32 [B*3, L, 64]) by the same kernel (ea_linear_w32_pool) -> (y [rows, 576], rounded copy of an fp32 x2 or None)."""
+    (fp32 [B*3, L, 64]) by the same kernel (ea_linear_w32_pool) -> (y [rows, 576], rounded copy of an fp32 x2 or None).
+    w_cast: a [576, 192] `cdtype` tensor that receives the rounded weight (for the backward's input-gradient GEMM), or None."""
     rows, K = x2.shape
     a_f32 = x2.dtype == torch.float32
     y = torch.empty((rows, 576), dtype=cdtype, device=x2.device)
@@ -1451,7 +1454,7 @@ def project_qkv_pooled(x2, wq, bq32, cdtype, want_cast, B, H, W, r, pq, pk):
         label = "ea_linear[192->576,%s->16,+pool]" % ("f32" if a_f32 else "16")
         _note_bytes(label, rows * (K * x2.element_size() + 576 * 2 + (K * 2 if a_cast is not None else 0)))
     nv.call_as(label, "ea_linear_w32_pool", _ELEM[cdtype], B, H, W, r, K, 576, nv.ptr(x2), int(a_f32), x2.stride(0), nv.ptr(wq),
-               nv.ptr(bq32), nv.ptr(y), 576, nv.ptr(a_cast), nv.ptr(pq), nv.ptr(pk), nv.stream())
+               nv.ptr(bq32), nv.ptr(y), 576, nv.ptr(a_cast), nv.ptr(pq), nv.ptr(pk), nv.ptr(w_cast), nv.stream())
     return y, a_cast
 
 
@@ -1493,18 +1496,21 @@ class LaraModuleFn(torch.autograd.Function):
                 pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
                 pk = torch.empty_like(pq)
                 pooled = (None, pq, pk)
-            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, H, W, r, pq, pk)
+            # the rounded weight for the backward's input-gradient GEMM leaves with the same launch (no cast kernel there)
+            w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
+            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, H, W, r, pq, pk, w_cast=w16)
             xl = x2 if x2.dtype == cdtype else (xc if want else None)
             qkv5 = y.view(B, N, 3, heads, d)
             outs = lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, list(params), pooled=pooled)
         else:
+            w16 = None
             y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
             xl = x2 if x2.dtype == cdtype else (xc if want else None)
             qkv5 = y.view(B, N, 3, heads, C // heads)
             outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
         o2 = outs[0].reshape(-1, C)
         y2 = _ea_op("linear_w32", linear_w32_impl, o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, *outs[1:], *params)
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     [t.dtype for t in params], heads)
@@ -1512,7 +1518,7 @@ class LaraModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, mask_u8, noise, o2, wq, wp, *rest = ctx.saved_tensors
+        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads = ctx.meta
         C = xshape[-1]
@@ -1574,7 +1580,7 @@ class LaraModuleFn(torch.autograd.Function):
             # frozen qkv weight, trainable bias (bias-only fine-tuning): a column sum of d qkv, no input rows needed
             dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+            dx = _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}

@@ -577,11 +577,13 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
  * pooled_q / pooled_k: fp32 [B*3, (gh/r)*(gw/r), 64], the means of the ROUNDED q / k rows over the r x r cells -- exactly what
  * ea_eva_chunk_mean_fwd computes from the stored rows, without re-reading them (the kernel walks the tokens cell by cell and
  * sums the cell's rows while they are still in registers).  r = 2 or 4, in = 192, out = 576
- * (ea_linear_pool_supported != 0), EA_E_UNSUPPORTED otherwise; the other arguments as for ea_linear_w32. */
+ * (ea_linear_pool_supported != 0), EA_E_UNSUPPORTED otherwise; the other arguments as for ea_linear_w32.
+ * w_cast (ABI 9): NULL, or [out_features, in_features] in the I/O type: the rounded weight, written by the same launch for
+ * the backward's input-gradient GEMM (a cast launch of its own costs more than the 220 KB it moves). */
 int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int32_t B, int32_t gh, int32_t gw, int32_t r);
 int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t r, int32_t in_features, int32_t out_features,
                        const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
-                       void* a_cast, float* pooled_q, float* pooled_k, void* stream);
+                       void* a_cast, float* pooled_q, float* pooled_k, void* w_cast, void* stream);
 
 /* ---- composite per-module entry points: the whole LARA core in one call each way (round 3) --------------------
  * lara.py:129-175,187-246 for the 2-D pooled proposals ('pool', 'pool-mixed'): uniform r x r pooling of q, k -> landmark

@@ -1018,3 +1018,48 @@ def test_module_backward_with_paired_weight_gradients(attn, monkeypatch):
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, n
         else:
             assert torch.equal(a, b), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["lara", "eva"])
+def test_rounded_weight_from_the_projection_launch(attn, monkeypatch):
+    """ea_linear_w32_pool's w_cast output (the rounded qkv weight for the backward's input-gradient GEMM, written by
+    workgroup 0 of the projection launch) equals weight.to(dtype) bit for bit, and the module's dx with it equals the dx with
+    a cast launch in the backward."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    args = (dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed", mis_type="mis-opt", alpha_coeff=2.0)
+            if attn == "lara" else dict(dim=192, num_heads=3, num_landmarks=49, window_size=7, attn_2d=True, use_rpe=True,
+                                        adaptive_proj="default"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(17)
+        m = ea.AttentionFactory.build_attention(attn, args).cuda()
+    m.train()
+    x0 = torch.randn(2, 28, 28, 192, device="cuda")
+    g = torch.randn(2, 28, 28, 192, device="cuda").to(torch.float16)
+    res, seen = {}, []
+    orig = _ops.project_qkv_pooled
+    for keep in (True, False):
+        def wrapped(*a, w_cast=None, _keep=keep, **k):
+            out = orig(*a, w_cast=w_cast if _keep else None, **k)
+            if _keep and w_cast is not None:
+                seen.append(w_cast)
+            return out
+        monkeypatch.setattr(_ops, "project_qkv_pooled", wrapped)
+        if not keep:
+            # the module allocated w16 but the kernel did not fill it: make the backward fall back to the cast
+            real_mm = _ops._mm_out
+            monkeypatch.setattr(_ops, "_mm_out", lambda a, b, dt: real_mm(a, m.qkv.weight.to(a.dtype) if tuple(b.shape) == (576, 192) else b, dt))
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(5)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = m(x)
+        y.backward(g)
+        res[keep] = x.grad.clone()
+    assert len(seen) == 1 and torch.equal(seen[0], m.qkv.weight.detach().to(torch.float16))
+    assert torch.equal(res[True], res[False])
