@@ -14,6 +14,7 @@ int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, cons
 #include "ea_softmax.h"
 #include "ea_lara_lmk.h"
 #include "ea_lara_merge.h"
+#include "ea_layernorm.h"
 #include "ea_lara_segment.h"
 #include "ea_scatter.h"
 #include "ea_rows_mlp.h"
@@ -1641,6 +1642,29 @@ int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, cons
   // dparams == NULL: the per-(b,h) partials stay in tmp (offsets ea_eva_layer_ws(cfg, 5 / 6)) for the caller's own reduction
   if (dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
   return rc;
+}
+
+}  // extern "C"
+
+// ---- row LayerNorm (ea_layernorm.hip) ----
+extern "C" {
+
+int32_t ea_layernorm_parts(int32_t rows) { return ea::layernorm_parts(rows); }
+
+int ea_layernorm_fwd(int32_t xtype, int32_t rows, int32_t C, const void* x, const float* gamma, const float* beta, float eps,
+                     float* y, float* stats, void* stream) {
+  if (!x || !gamma || !beta || !y) return EA_E_BADARG;
+  ea::LnP p = {};
+  p.x = x; p.gamma = gamma; p.beta = beta; p.y = y; p.stats = stats; p.rows = rows; p.C = C; p.eps = eps;
+  return ea::layernorm_dispatch(false, p, xtype, (hipStream_t)stream);
+}
+
+int ea_layernorm_bwd(int32_t xtype, int32_t rows, int32_t C, const void* x, const float* gamma, const float* stats,
+                     const float* dy, void* dx, float* part, void* stream) {
+  if (!x || !gamma || !stats || !dy || !dx || !part) return EA_E_BADARG;
+  ea::LnP p = {};
+  p.x = x; p.gamma = gamma; p.stats = const_cast<float*>(stats); p.dy = dy; p.dx = dx; p.part = part; p.rows = rows; p.C = C;
+  return ea::layernorm_dispatch(true, p, xtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -134,6 +134,9 @@ SIGNATURES = {
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_wgrad_pair_parts": [_I, _I, _I, _I, _I],
+    "ea_layernorm_parts": [_I],
+    "ea_layernorm_fwd": [_I, _I, _I, _P, _P, _P, _F, _P, _P, _P],
+    "ea_layernorm_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "ea_wgrad_pair": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P],
     "ea_part_sum": [_I, _I, _L, _P, _P, _P],
     "ea_multi_sum": [_I, _P, _P, _P, _P, _P, _P],

@@ -2515,6 +2515,58 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+_XTYPE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+class LayerNormFn(torch.autograd.Function):
+    """F.layer_norm over the last axis of a [rows, C] matrix with fp32 statistics and fp32 output (ea_layernorm_fwd / _bwd):
+    what torch computes for nn.LayerNorm under autocast on a 16-bit input.  The LayerNorm of LinearRA's 'dense' landmark
+    generators (lara.py:34-44,64-71)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, eps):
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows, C = x2.shape
+        y = torch.empty((rows, C), dtype=torch.float32, device=x2.device)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x2.device)
+        w32, b32 = _f32c(weight), _f32c(bias)
+        nv.call("ea_layernorm_fwd", _XTYPE[x2.dtype], rows, C, nv.ptr(x2), nv.ptr(w32), nv.ptr(b32), float(eps), nv.ptr(y),
+                nv.ptr(stats), nv.stream())
+        ctx.save_for_backward(x2, weight, stats)
+        ctx.pd = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, stats = ctx.saved_tensors
+        rows, C = x2.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x2)
+        nb = int(nv.lib().ea_layernorm_parts(rows))
+        part = torch.empty((nb, 2 * C), dtype=torch.float32, device=x2.device)
+        nv.call("ea_layernorm_bwd", _XTYPE[x2.dtype], rows, C, nv.ptr(x2), nv.ptr(_f32c(weight)), nv.ptr(stats), nv.ptr(dy),
+                nv.ptr(dx), nv.ptr(part), nv.stream())
+        sums = colsum_f32(part)
+        return dx, sums[:C].to(ctx.pd[0]), sums[C:].to(ctx.pd[1]), None
+
+
+def layer_norm_supported(x, layer):
+    """ea_layernorm_*: CUDA rows of C <= 1024 channels (C % 64 == 0), affine LayerNorm over the last axis, direct calls."""
+    C = x.shape[-1]
+    return (x.is_cuda and x.dtype in _XTYPE and C % 64 == 0 and C <= 1024 and layer.elementwise_affine and layer.bias is not None
+            and tuple(layer.normalized_shape) == (C,) and x.numel() >= C
+            and _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0)
+
+
+def layer_norm(x, layer):
+    """nn.LayerNorm(x) as torch evaluates it under autocast (fp32 statistics and output), through LayerNormFn where it applies."""
+    # (outside autocast a 16-bit input gets a 16-bit result from torch: left to it)
+    if not layer_norm_supported(x, layer) or (x.dtype != torch.float32 and not torch.is_autocast_enabled()):
+        return layer(x)
+    y = LayerNormFn.apply(x.reshape(-1, x.shape[-1]), layer.weight, layer.bias, layer.eps)
+    return y.view(x.shape)
+
+
 def linear(x, layer):
     """nn.Linear forward through LinearFn, in the autocast dtype when autocast is on."""
     if not x.is_cuda:

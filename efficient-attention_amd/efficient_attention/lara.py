@@ -64,9 +64,9 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             if self.pool_module_type == 'dense':
                 def dense(p, net):
                     z = p.permute(0, 2, 1, 3).reshape(B, side * side, h * d)
-                    # model-wide Linear through the projection kernels (ea_linear / ea_wgrad); its LayerNorm over
-                    # B * L rows of `dim` channels is the one op of this generator left to the framework
-                    z = net[3](_ops.linear(z.contiguous(), net[2]))
+                    # model-wide Linear through the projection kernels (ea_linear / ea_wgrad), its LayerNorm over the
+                    # B * L rows of `dim` channels through ea_layernorm_fwd / _bwd (round 4)
+                    z = _ops.layer_norm(_ops.linear(z.contiguous(), net[2]), net[3])
                     return z.reshape(B, side * side, h, d).permute(0, 2, 1, 3)
                 q_bar, k_bar = dense(pq, self.q_bar_gen), dense(pk, self.k_bar_gen)
             else:

@@ -652,6 +652,20 @@ int ea_eva_layer_bwd(const ea_eva_layer* cfg, const ea_t4* q, const ea_t4* k, co
                      const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
                      void* stream);
 
+/* ---- row LayerNorm (ea_layernorm.hip) -------------------------------------------------------------------------
+ * The LayerNorm of LinearRA's model-wide ('dense') landmark generators (lara.py:34-44,64-71: Linear(dim, dim) + LayerNorm(dim)
+ * on the B * L pooled rows).  x [rows, C] contiguous, xtype EA_BF16 / EA_F16 / EA_F32 (under autocast torch evaluates
+ * layer_norm in fp32 on the 16-bit Linear output); C a multiple of 64, <= 1024 (EA_E_UNSUPPORTED otherwise).
+ *   fwd: y fp32 [rows, C] = (x - mean) rstd gamma + beta, biased variance, two-pass statistics in fp32; stats [rows, 2] =
+ *        (mean, rstd) for the backward (may be NULL).
+ *   bwd: dx [rows, C] in x's type; part [ea_layernorm_parts(rows), 2, C] fp32 = per-workgroup partial sums of d gamma and
+ *        d beta (add them with ea_colsum_f32(parts, 2 * C, ...)). */
+int32_t ea_layernorm_parts(int32_t rows);
+int ea_layernorm_fwd(int32_t xtype, int32_t rows, int32_t C, const void* x, const float* gamma, const float* beta, float eps,
+                     float* y, float* stats, void* stream);
+int ea_layernorm_bwd(int32_t xtype, int32_t rows, int32_t C, const void* x, const float* gamma, const float* stats,
+                     const float* dy, void* dx, float* part, void* stream);
+
 /* ---- ScatterBrain, low-rank half (scatterbrain_attention.py:99-160; ea_scatter.hip) --------------------
  * The window half is ea_window_attn_fwd/bwd (it returns / takes the gradient of its per-query log-sum-exp);
  * these entry points evaluate the m random-feature columns of the same softmax and merge the two halves:

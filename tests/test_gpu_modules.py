@@ -32,5 +32,10 @@ def test_lara_landmark_algebra_stays_on_hip(name, mode, monkeypatch):
         raise AssertionError("torch einsum/softmax/logsumexp reached in the LARA landmark path")
     for mod, fn in ((torch, "einsum"), (torch, "softmax"), (torch, "logsumexp"), (F, "softmax"), (torch.Tensor, "softmax")):
         monkeypatch.setattr(mod, fn, banned)
+    if "dense" in name:
+        # round 4: the model-wide generator's LayerNorm runs on ea_layernorm_fwd / _bwd as well
+        def no_ln(*a, **k):
+            raise AssertionError("F.layer_norm reached in the 'dense' landmark generator")
+        monkeypatch.setattr(F, "layer_norm", no_ln)
     errs = check_module_case(name, mode)
     print(name, mode, {k: "%.2e/%.2e" % v for k, v in errs.items()})

@@ -1063,3 +1063,36 @@ def test_rounded_weight_from_the_projection_launch(attn, monkeypatch):
         res[keep] = x.grad.clone()
     assert len(seen) == 1 and torch.equal(seen[0], m.qkv.weight.detach().to(torch.float16))
     assert torch.equal(res[True], res[False])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xdtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("rows,C", [(6272, 192), (49, 128), (1000, 512), (37, 1024), (5, 64)])
+def test_layernorm_kernels_match_torch(xdtype, rows, C):
+    """ea_layernorm_fwd / _bwd (LinearRA's 'dense' generator LayerNorm) against torch.nn.functional.layer_norm evaluated in
+    fp64 on the same (rounded) input: output, input gradient, d gamma, d beta."""
+    import torch
+    import torch.nn.functional as F
+    from efficient_attention import _ops
+    td = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[xdtype]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.randn(rows, C, device="cuda", generator=g) * 1.7 + 0.3).to(td).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(C, device="cuda", generator=g)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device="cuda", generator=g)).requires_grad_(True)
+    dy = torch.randn(rows, C, device="cuda", generator=g)
+    y = _ops.LayerNormFn.apply(x, w, b, 1e-5)
+    assert y.dtype == torch.float32
+    y.backward(dy)
+    xr = x.detach().double().requires_grad_(True)
+    wr = w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    yr.backward(dy.double())
+
+    def close(a, ref, tol, what):
+        sc = float(ref.abs().max())
+        assert float((a.double() - ref).abs().max()) <= tol * sc + 1e-7, (what, float((a.double() - ref).abs().max()) / sc)
+    close(y, yr, 2e-6, "y")
+    close(x.grad, xr.grad, {"bf16": 8e-3, "fp16": 1e-3, "fp32": 5e-6}[xdtype], "dx")       # dx is rounded to x's type
+    close(w.grad, wr.grad, 1e-5, "dgamma")
+    close(b.grad, br.grad, 1e-5, "dbeta")
