@@ -559,6 +559,7 @@ def test_lara_module_pooled_projection_close_to_separate_pooling(dtype, composit
     import efficient_attention as ea
     from efficient_attention import _ops
     monkeypatch.setenv("EA_LARA_COMPOSITE", composite)
+    monkeypatch.setattr(_ops, "USE_LARA_MODULE_FN", True)
     td = torch.bfloat16 if dtype == "bf16" else torch.float16
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -885,6 +886,7 @@ def test_eva_composite_equals_step_by_step(dtype, dim, heads, grid, window, land
     from efficient_attention import _ops
     td = torch.bfloat16 if dtype == "bf16" else torch.float16
     monkeypatch.setattr(_ops, "USE_EVA_MODULE_FN", module_fn)
+    monkeypatch.setattr(_ops, "USE_LARA_MODULE_FN", True)      # (eva_module_fn_supported builds on lara_module_fn_supported)
     for use_rpe in (True, False):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -917,7 +919,7 @@ def test_eva_composite_equals_step_by_step(dtype, dim, heads, grid, window, land
             monkeypatch.setattr(_ops.nv, "call", orig)
             res[comp] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
             used[comp] = ("ea_eva_layer_fwd" in calls, "ea_eva_layer_bwd" in calls)
-        pooled_three_nodes = (not module_fn) and dim == 192
+        pooled_three_nodes = (not module_fn) and dim == 192 and _ops.USE_PROJ_POOL
         assert used[True] == ((False, False) if pooled_three_nodes else (True, True)), used
         assert used[False] == (False, False)
         assert torch.equal(res[True][0], res[False][0])
@@ -948,7 +950,11 @@ def test_wgrad_pair_matches_two_launches(dtype, rows):
     x1 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
     dy2 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
     x2 = torch.randn(rows, 192, device="cuda", generator=g).to(td)
-    assert _ops.wgrad_pair_usable(dy1, x1, dy2, x2)
+    _ops.USE_WGRAD_PAIR, keep_switch = True, _ops.USE_WGRAD_PAIR        # (EA_WGRAD_PAIR=0 runs of the suite still test the kernel)
+    try:
+        assert _ops.wgrad_pair_usable(dy1, x1, dy2, x2)
+    finally:
+        _ops.USE_WGRAD_PAIR = keep_switch
     (p1, m1), (p2, m2) = _ops.wgrad_pair(dy1, x1, True, dy2, x2, True)
     assert p1.shape[0] == p2.shape[0] and p1.shape[0] < _ops.nv.lib().ea_wgrad_parts(rows, 576, 192) + (1 if rows < 4096 else 0)
     s1, s2 = _ops.multi_sum([p1, p2])
@@ -991,6 +997,8 @@ def test_module_backward_with_paired_weight_gradients(attn, monkeypatch):
     x0 = torch.randn(4, 28, 28, 192, device="cuda")
     g = torch.randn(4, 28, 28, 192, device="cuda").bfloat16()
     res, used = {}, {}
+    for sw in ("USE_MULTI_SUM", "USE_LARA_MODULE_FN", "USE_EVA_MODULE_FN"):     # what the paired launch builds on
+        monkeypatch.setattr(_ops, sw, True)
     for pair in (True, False):
         monkeypatch.setattr(_ops, "USE_WGRAD_PAIR", pair)
         calls = []
@@ -1041,6 +1049,8 @@ def test_rounded_weight_from_the_projection_launch(attn, monkeypatch):
     x0 = torch.randn(2, 28, 28, 192, device="cuda")
     g = torch.randn(2, 28, 28, 192, device="cuda").to(torch.float16)
     res, seen = {}, []
+    for sw in ("USE_PROJ_POOL", "USE_LARA_MODULE_FN", "USE_EVA_MODULE_FN"):     # the path that has the output
+        monkeypatch.setattr(_ops, sw, True)
     orig = _ops.project_qkv_pooled
     for keep in (True, False):
         def wrapped(*a, w_cast=None, _keep=keep, **k):
