@@ -1582,6 +1582,8 @@ int64_t ea_eva_layer_ws(const ea_eva_layer* c, int32_t which) {
     case 6: return (int64_t)P.b_dvec;
     case 7: return (int64_t)P.ld;
     case 8: return (int64_t)P.o_lse;
+    case 9: return (int64_t)P.b_dbp;
+    case 10: return (int64_t)P.bparts * c->B;
     default: return EA_E_BADARG;
   }
 }
@@ -1614,7 +1616,7 @@ int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, cons
   EvaLayerPlan P;
   int rc = eva_layer_plan(c, P);
   if (rc != EA_OK) return rc;
-  if (!saved || !tmp || !params || (c->has_bias != 0) != (bias != nullptr) || (c->has_bias && !dbias)) return EA_E_BADARG;
+  if (!saved || !tmp || !params || (c->has_bias != 0) != (bias != nullptr)) return EA_E_BADARG;
   const int D = c->D;
   const size_t LD = (size_t)P.BH * P.L * D;
   const float *qm = saved + P.o_qm, *km = saved + P.o_km, *omega = saved + P.o_omega, *beta = saved + P.o_beta, *rfk = saved + P.o_rfk;
@@ -1626,7 +1628,7 @@ int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, cons
   if (rc != EA_OK) return rc;
   rc = ea_slice_sum(2, P.parts, (int32_t)LD, 1.f, nullptr, dl_p, dl, stream);
   if (rc != EA_OK) return rc;
-  if (c->has_bias) {
+  if (c->has_bias && dbias) {        // dbias == NULL: the partials stay in tmp for the caller's reduction (selectors 9 / 10)
     rc = ea_colsum_f32(P.bparts * c->B, c->H * P.Wq * P.ld, dbp, dbias, stream);
     if (rc != EA_OK) return rc;
   }

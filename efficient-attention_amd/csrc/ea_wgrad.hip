@@ -246,17 +246,17 @@ __global__ __launch_bounds__(256) void part_sum_kernel(const float* __restrict__
 // own.  Segment k: out_k[j] = sum_s part_k[s * ld_k + j]; blocks [blk0_k, blk0_{k+1}) work on it, same order of additions
 // as part_sum_kernel.
 struct MultiSumP {
-  const float* part[4];
-  float* out[4];
-  int S[4], n4[4], blk0[5];
-  long ld4[4];
+  const float* part[6];
+  float* out[6];
+  int S[6], n4[6], blk0[7];
+  long ld4[6];
   int nseg;
 };
 __global__ __launch_bounds__(256) void multi_sum_kernel(const MultiSumP p) {
   __shared__ f32x4 red[8][32];
   int k = 0;
 #pragma unroll
-  for (int i = 1; i < 4; ++i) k += (i < p.nseg && (int)blockIdx.x >= p.blk0[i]) ? 1 : 0;
+  for (int i = 1; i < 6; ++i) k += (i < p.nseg && (int)blockIdx.x >= p.blk0[i]) ? 1 : 0;
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int j = ((int)blockIdx.x - p.blk0[k]) * 32 + c;
   const int S = p.S[k], n4 = p.n4[k];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void multi_sum_kernel(const MultiSumP p) {
 
 int multi_sum_dispatch(int K, const float* const* part, const int* S, const int* n, const long long* ld, float* const* out,
                        hipStream_t st) {
-  if (K <= 0 || K > 4) return EA_E_BADARG;
+  if (K <= 0 || K > 6) return EA_E_BADARG;
   MultiSumP p = {};
   int blk = 0;
   for (int k = 0; k < K; ++k) {

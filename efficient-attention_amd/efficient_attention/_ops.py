@@ -397,7 +397,7 @@ def _eva_layer_cfg_dims(B, h, d, io, icfg, fcfg, adaptive_proj, has_bias, masked
     hit = _EVA_LAYER_CFG.get(key)
     if hit is None:
         cfg = nv.ea_eva_layer(B, h, d, io, s0, s1, window, chunk, int(has_bias), float(d) ** -0.5)
-        sizes = [int(nv.lib().ea_eva_layer_ws(ctypes.byref(cfg), w)) for w in (0, 2, 3, 4, 5, 6)]
+        sizes = [int(nv.lib().ea_eva_layer_ws(ctypes.byref(cfg), w)) for w in (0, 2, 3, 4, 5, 6, 9, 10)]
         hit = (cfg, sizes) if min(sizes) >= 0 else (None, None)
         if len(_EVA_LAYER_CFG) < 256:
             _EVA_LAYER_CFG[key] = hit
@@ -512,7 +512,9 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
         tmp = torch.empty(sizes[1], dtype=torch.float32, device=dev)
         noise_c = None if noise is None else noise.float().contiguous()
         ps = [_f32c(p) for p in mlp_params]
-        dbias = None if bias_p is None else torch.empty_like(bias_p)
+        # deferred sums: the bias-gradient partials join the caller's terminal reductions too (one launch for all of them)
+        defer_bias = bool(defer_param_sums and bias_p is not None)
+        dbias = None if (bias_p is None or defer_bias) else torch.empty_like(bias_p)
         dpar = None if defer_param_sums else torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev)
         nv.call("ea_eva_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
                 nv.ptr(bias_p), nv.ptr(noise_c), _param_ptrs(ps), ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
@@ -522,8 +524,12 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
         BH = B * h
         if defer_param_sums:
             o_dW, o_dvec = sizes[4], sizes[5]
+            extra = ()
+            if defer_bias:
+                o_db, rows_db, n_db = sizes[6], sizes[7], bias_p.numel()
+                extra = (tmp[o_db:o_db + rows_db * n_db].view(rows_db, n_db), tuple(bias_p.shape))
             return [dqkv5, _e(dbias, ws), ("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
-                                          tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))]
+                                          tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d)) + extra]
         dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
         return [dqkv5, _e(dbias, ws), dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
     geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
@@ -745,6 +751,8 @@ class EvaModuleFn(torch.autograd.Function):
         if pgrads and isinstance(pgrads[0], tuple):
             pend.append(("mu_W", pgrads[0][1], None))
             pend.append(("mu_v", pgrads[0][2], None))
+            if len(pgrads[0]) > 3:                                  # bias-gradient partials of the composite backward
+                pend.append(("dbias", pgrads[0][3], pgrads[0][4]))
             pgrads = []
         need_bq = bqd is not None and need[2]
         if pair:
@@ -775,6 +783,8 @@ class EvaModuleFn(torch.autograd.Function):
             if "mu_W" in res:
                 dWs, dvs = res["mu_W"][0].view(2, d, d), res["mu_v"][0].view(2, 3, d)
                 pgrads = [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+            if "dbias" in res:
+                dbias = res["dbias"][0].view(res["dbias"][1])[..., :bias_cols].contiguous()
         pgrads = [t.to(dt) for t, dt in zip(pgrads, pdtypes)]
         if dbias is not None and bias_dt is not None:
             dbias = dbias.to(bias_dt)
@@ -2421,7 +2431,7 @@ def _wgrad_split(out, meta):
 
 
 def multi_sum(parts):
-    """parts: up to four contiguous fp32 [S_k, n_k] tensors (n_k % 4 == 0) -> [sum over S_k] in ONE launch (ea_multi_sum)."""
+    """parts: up to six contiguous fp32 [S_k, n_k] tensors (n_k % 4 == 0) -> [sum over S_k] in ONE launch (ea_multi_sum)."""
     K = len(parts)
     outs = [torch.empty(p.shape[1], dtype=torch.float32, device=p.device) for p in parts]
     P = (ctypes.c_void_p * K)(*[p.data_ptr() for p in parts])

@@ -522,7 +522,7 @@ int32_t ea_wgrad_pair_parts(int32_t rows, int32_t out1, int32_t in1, int32_t out
 int ea_wgrad_pair(int32_t dtype, int32_t rows, int32_t out1, int32_t in1, const void* dy1, const void* x1, float* dw_part1,
                   float* db_part1, int64_t part_ld1, int32_t out2, int32_t in2, const void* dy2, const void* x2,
                   float* dw_part2, float* db_part2, int64_t part_ld2, void* stream);
-/* K <= 4 such reductions in one launch: out[k][j] = sum_s parts[k][s * ld[k] + j], j < n[k] (same order of additions as
+/* K <= 6 such reductions in one launch: out[k][j] = sum_s parts[k][s * ld[k] + j], j < n[k] (same order of additions as
  * ea_part_sum).  The terminal sums of a layer's backward -- both projections' slice partials and the per-(b,h) partials of
  * the landmark parameters (ea_lara_layer_bwd with dparams == NULL) -- share one launch this way. */
 int ea_multi_sum(int32_t K, const float* const* parts, const int32_t* S, const int32_t* n, const int64_t* ld, float* const* out,
@@ -629,7 +629,9 @@ int ea_lara_layer_bwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, 
  *       (negative: EA_E_*; EA_E_UNSUPPORTED: L > 64 or a window geometry whose backward needs scratch slices -- use the
  *       step-by-step entry points).
  *   bias: fp32 [H, w*w, ld] dense per-head bias multiplied by log2(e), rows padded to ld (as for ea_window_attn_fwd), or
- *       NULL (then cfg->has_bias == 0); dbias: fp32 [H, w*w, ld], gradient with respect to the NATURAL-unit bias.
+ *       NULL (then cfg->has_bias == 0); dbias: fp32 [H, w*w, ld], gradient with respect to the NATURAL-unit bias, or NULL:
+ *       its partial sums then stay in the backward scratch -- ea_eva_layer_ws(cfg, 9) = their offset, (cfg, 10) = their row
+ *       count, rows of H * w*w * ld floats -- for the caller's own reduction (ea_multi_sum, with the other terminal sums).
  *   params: 8 pointers (W, b, gamma, beta of the q and of the k mu network: eva.py:93-103); noise: [B*H, L, D] or NULL.
  *   keep_for_backward: bit 0 = keep the intermediates; bit 1 (EA_LARA_POOLED_READY) = the chunk means are already in
  *       `saved` (ea_linear_w32_pool wrote them).  dparams: [2 D D + 6 D] fp32 as for ea_lara_layer_bwd, or NULL (partials

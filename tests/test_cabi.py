@@ -85,13 +85,14 @@ def test_eva_composite_entry_points_report_their_workspaces(lib):
     from efficient_attention import _native
     L = _native.lib()
     cfg = _native.ea_eva_layer(128, 3, 64, 0, 28, 28, 7, 4, 1, 0.125)              # cfg3: 7 x 7 windows, 49 chunks of 4 x 4
-    n = [L.ea_eva_layer_ws(ctypes.byref(cfg), w) for w in range(9)]
+    n = [L.ea_eva_layer_ws(ctypes.byref(cfg), w) for w in range(11)]
     BH, Lm, D, N = 384, 49, 64, 784
     assert n[0] >= BH * N + 5 * BH * Lm * D and n[1] == 0 and n[2] >= 5 * BH * Lm * D + BH * (2 * D * D + 6 * D)
     assert 0 <= n[8] < n[3] < n[4] < n[0] and 0 <= n[5] < n[6] < n[2] and n[7] >= 49
     geom = _native.make_geom(128, 3, N, 64, 0, True, (28, 28), 7, 0, 4, 49)
     assert n[7] == L.ea_window_bias_ld(ctypes.byref(geom))
-    assert L.ea_eva_layer_ws(ctypes.byref(cfg), 9) == -1
+    assert 0 <= n[9] < n[2] and n[10] >= 128 and n[9] + n[10] * 3 * 49 * n[7] <= n[2]      # bias-gradient partials in the scratch
+    assert L.ea_eva_layer_ws(ctypes.byref(cfg), 11) == -1
     bad = _native.ea_eva_layer(128, 3, 64, 0, 28, 28, 8, 4, 1, 0.125)              # grid not divisible by the window side
     assert L.ea_eva_layer_ws(ctypes.byref(bad), 0) == -1
     big = _native.ea_eva_layer(2, 3, 64, 0, 28, 28, 7, 2, 0, 0.125)                # 196 landmarks: step-by-step path
