@@ -1610,6 +1610,135 @@ class LaraModuleFn(torch.autograd.Function):
         return (dx, dwq, dbq, dwp, dbp, None, None, None, None, None) + tuple(pgrads)
 
 
+USE_CORE_MODULE_FN = os.environ.get("EA_CORE_MODULE_FN", "1") == "1"
+
+
+class SoftmaxCore:
+    """Core spec of CoreModuleFn: dropout(softmax(s QK^T)) V (softmax_fwd_impl / softmax_bwd_impl)."""
+    n_inputs = 0
+
+    def __init__(self, mask_u8, keep=None, keep_scale=1.0):
+        self.mask_u8, self.keep, self.keep_scale = mask_u8, keep, float(keep_scale)
+
+    def fwd(self, qkv5, inputs):
+        out, lse = softmax_fwd_impl(qkv5, self.mask_u8, self.keep, self.keep_scale)
+        return out, (lse,)
+
+    def bwd(self, dout, qkv5, out, saved):
+        return softmax_bwd_impl(dout, qkv5, self.mask_u8, out, saved[0], self.keep, self.keep_scale), ()
+
+
+class LocalCore:
+    """Core spec of CoreModuleFn: per-window softmax attention with the dense per-head bias (local_fwd_impl / local_bwd_impl);
+    its one differentiable input is the bias [h, Wq, Wk] (or None)."""
+    n_inputs = 1
+
+    def __init__(self, mask_u8, attn_2d, seq_shape, window, ext):
+        self.mask_u8, self.geo = mask_u8, _geo(attn_2d, seq_shape, window, ext)
+        self.bias_cols = 0
+
+    def fwd(self, qkv5, inputs):
+        bias = inputs[0]
+        self.bias_cols = 0 if bias is None else bias.shape[-1]
+        out, lse, bias_p = local_fwd_impl(qkv5, bias, self.mask_u8, self.geo)
+        return out, (lse, bias_p)
+
+    def bwd(self, dout, qkv5, out, saved):
+        dqkv5, dbias = local_bwd_impl(dout, None, qkv5, _opt(saved[1]), self.mask_u8, out, saved[0], self.geo, self.bias_cols)
+        return dqkv5, (_opt(dbias),)
+
+
+class CoreModuleFn(torch.autograd.Function):
+    """qkv projection -> attention core -> output projection as ONE autograd node for the softmax and local-window baselines
+    (round 4; LaraModuleFn's scheme for cores without landmark parameters): the projections read the fp32 master weights, both
+    weight gradients leave in one launch (ea_wgrad_pair) and their slice partials are added up by one ea_multi_sum.
+    args: x [B, *seq, C], qkv weight / bias, proj weight / bias, core spec (SoftmaxCore / LocalCore: non-differentiable state
+    and the two core calls), compute dtype, heads, then the core's differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wp, bp, core, cdtype, heads, *inputs):
+        C = x.shape[-1]
+        B = x.shape[0]
+        N = x.numel() // (B * C)
+        d = C // heads
+        x2 = x.reshape(-1, C)
+        elem = _ELEM[cdtype]
+        bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
+        bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
+        want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
+        y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
+        xl = x2 if x2.dtype == cdtype else (xc if want else None)
+        qkv5 = y.view(B, N, 3, heads, d)
+        out, saved = core.fwd(qkv5, inputs)
+        o2 = out.reshape(-1, C)
+        y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
+        ctx.save_for_backward(xl, qkv5, o2, wq, wp, *saved)
+        ctx.core = core
+        ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
+                    heads, [None if t is None else t.dtype for t in inputs])
+        return y2.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xl, qkv5, o2, wq, wp, *saved = ctx.saved_tensors
+        xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, heads, in_dtypes = ctx.meta
+        C = xshape[-1]
+        d = C // heads
+        elem = _ELEM[cdtype]
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(-1, C)
+        if dy2.dtype != cdtype:
+            dy2 = dy2.to(cdtype)
+        d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
+        B, N = qkv5.shape[:2]
+        dqkv5, extra = ctx.core.bwd(d_o2.view(B, N, heads, d), qkv5, o2.view(B, N, heads, d), saved)
+        dqkv2 = dqkv5.view(-1, 3 * C)
+        need_bq, need_bp = bqd is not None and need[2], bpd is not None and need[4]
+        dwq = dbq = dwp = dbp = dx = None
+        pend = []
+        if need[1] and xl is None:
+            raise RuntimeError("CoreModuleFn: the weight gradient was requested but the forward did not keep its input")
+        if need[1] and need[3] and USE_MULTI_SUM and wgrad_pair_usable(dqkv2, xl, dy2, o2):
+            rq, rp = wgrad_pair(dqkv2, xl, need_bq, dy2, o2, need_bp)
+            pend = [("qkv", rq[0], rq[1]), ("proj", rp[0], rp[1])]
+        else:
+            if need[3]:
+                r_ = wgrad(dy2, o2, need_bp, defer=USE_MULTI_SUM)
+                if USE_MULTI_SUM:
+                    pend.append(("proj", r_[0], r_[1]))
+                else:
+                    dwp, dbp = r_[0].to(wpd), (r_[1].to(bpd) if need_bp else None)
+            elif need_bp:
+                dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
+            if need[1]:
+                r_ = wgrad(dqkv2, xl, need_bq, defer=USE_MULTI_SUM)
+                if USE_MULTI_SUM:
+                    pend.append(("qkv", r_[0], r_[1]))
+                else:
+                    dwq, dbq = r_[0].to(wqd), (r_[1].to(bqd) if need_bq else None)
+            elif need_bq:
+                dbq = bias_grad(dqkv2).to(bqd)
+        if need[0]:
+            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+        if pend:
+            sums = multi_sum([t for _, t, _ in pend])
+            for (what, _, meta), o in zip(pend, sums):
+                dw_, db_ = _wgrad_split(o, meta)
+                if what == "proj":
+                    dwp, dbp = dw_.to(wpd), (db_.to(bpd) if need_bp else None)
+                else:
+                    dwq, dbq = dw_.to(wqd), (db_.to(bqd) if need_bq else None)
+        egrads = tuple(None if (g is None or dt is None) else g.to(dt) for g, dt in zip(extra, in_dtypes))
+        return (dx, dwq, dbq, dwp, dbp, None, None, None) + egrads
+
+
+def core_module_fn_supported(x, qkv, proj, cdtype):
+    """The single-node path of the softmax / local-window baselines (CoreModuleFn): what LaraModuleFn asks of the projections,
+    direct calls only."""
+    return (USE_CORE_MODULE_FN and _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+            and lara_module_fn_supported(x, qkv, proj, cdtype))
+
+
 def lara_module_fn_supported(x, qkv, proj, cdtype):
     """The single-node path of LinearRA (LaraModuleFn): 16-bit autocast dtype, fp32 master weights both projection kernels
     cover (forward of both layers, the output projection's transposed input gradient), the one-pass weight gradient."""

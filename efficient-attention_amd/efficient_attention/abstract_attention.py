@@ -89,9 +89,25 @@ class MultiheadAttention(nn.Module):
     def forward(self, x, key_padding_mask=None):
         B, *seq_shape, C = x.shape
         N = int(math.prod(seq_shape))
+        # the common training case as ONE autograd node (projections + core, round 4): decided before anything is launched
+        if (torch.is_autocast_enabled() and x.is_cuda and (self.proj_drop.p == 0.0 or not self.training)
+                and _ops.core_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda"))):
+            core, inputs = self._core_spec(B, N, seq_shape, key_padding_mask, x.device)
+            if core is not None:
+                y = _ops.CoreModuleFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, core,
+                                            torch.get_autocast_dtype("cuda"), self.num_heads, *inputs)
+                return self.proj_drop(y)
         qkv5 = self.project_qkv(x.reshape(B, N, C))
         out = self._attend(qkv5, key_padding_mask, seq_shape)        # [B, N, h, d]
         return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+    def _core_spec(self, B, N, seq_shape, key_padding_mask, device):
+        """(core spec for _ops.CoreModuleFn, its differentiable inputs), or (None, ()) for subclasses that only override
+        _attend: they keep the three-node path."""
+        if type(self)._attend is not MultiheadAttention._attend:
+            return None, ()
+        mask = _ops._mask_u8(key_padding_mask, B, N, device)
+        return _ops.SoftmaxCore(mask, *self._attn_keep(B, N, device)), ()
 
     def _attend(self, qkv5, key_padding_mask, seq_shape):
         B, N = qkv5.shape[:2]

@@ -124,6 +124,18 @@ class LocalAttention(MultiheadAttention):
         return _ops.LocalAttnFn.apply(qkv5, self._table_bias(), mask, attn_2d, shape,
                                       self.window_size, self.ext_size)
 
+    def _core_spec(self, B, N, seq_shape, key_padding_mask, device):
+        if type(self)._attend is not LocalAttention._attend:
+            return None, ()
+        attn_2d, shape = self._geometry(N, seq_shape)
+        if attn_2d:
+            H = W = int(math.sqrt(N))
+            assert H * W == N, "LocalAttention with attn_2d expects a square grid"
+            assert H % self.window_size == 0
+            shape = (H, W)
+        mask = _ops._mask_u8(key_padding_mask, B, N, device)
+        return _ops.LocalCore(mask, attn_2d, shape, self.window_size, self.ext_size), (self._table_bias(),)
+
     @staticmethod
     def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):
         parent_parser = MultiheadAttention.add_attn_specific_args(parent_parser, struct_name=struct_name, prefix=prefix)

@@ -1108,3 +1108,56 @@ def test_layernorm_kernels_match_torch(xdtype, rows, C):
     close(x.grad, xr.grad, {"bf16": 8e-3, "fp16": 1e-3, "fp32": 5e-6}[xdtype], "dx")       # dx is rounded to x's type
     close(w.grad, wr.grad, 1e-5, "dgamma")
     close(b.grad, br.grad, 1e-5, "dbeta")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["softmax", "local", "local_norpe", "softmax_dropout"])
+def test_core_module_single_node_equals_three_nodes(attn, monkeypatch):
+    """CoreModuleFn (softmax / local-window baselines: projections + core as one autograd node, paired weight gradients,
+    one terminal reduction) against the three-node path: same kernels for the activations -- y, dx and the bias-table
+    gradient bit for bit -- and the projection gradients to fp32 summation order."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    name = "local" if attn.startswith("local") else "softmax"
+    args = dict(dim=192, num_heads=3)
+    if name == "local":
+        args.update(window_size=7, attn_2d=True, use_rpe=attn == "local")
+    if attn == "softmax_dropout":
+        args.update(attn_drop=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(18)
+        m = ea.AttentionFactory.build_attention(name, args).cuda()
+    m.train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    if attn == "softmax_dropout":
+        gk = torch.Generator().manual_seed(9)
+        keep = (torch.rand(4, 3, 196, 196, generator=gk) >= 0.1)
+        m._keep_mask_fn = lambda shape: keep
+    x0 = torch.randn(4, 14, 14, 192, device="cuda")
+    g = torch.randn(4, 14, 14, 192, device="cuda").bfloat16()
+    for sw in ("USE_MULTI_SUM", "USE_WGRAD_PAIR", "USE_LARA_MODULE_FN"):
+        monkeypatch.setattr(_ops, sw, True)
+    res = {}
+    for single in (True, False):
+        monkeypatch.setattr(_ops, "USE_CORE_MODULE_FN", single)
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        assert type(y.grad_fn).__name__.startswith("CoreModuleFn") == single
+        y.backward(g)
+        res[single] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert res[True][2].keys() == res[False][2].keys()
+    for n in res[True][2]:
+        a, b = res[True][2][n], res[False][2][n]
+        if n.startswith(("qkv.", "proj.")):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, n
+        else:
+            assert torch.equal(a, b), n
