@@ -1648,6 +1648,22 @@ class LocalCore:
         return dqkv5, (_opt(dbias),)
 
 
+class PerformerCore:
+    """Core spec of CoreModuleFn: the Performer core in exact fp32 arithmetic on the 16-bit qkv of an autocast step
+    (performer_f32_fwd / performer_f32_bwd); the random features W [h, m, d] carry no gradient."""
+    n_inputs = 0
+
+    def __init__(self, mask_u8, W):
+        self.mask_u8, self.W = mask_u8, W
+
+    def fwd(self, qkv5, inputs):
+        out, p_max, kv, ksum = performer_f32_fwd(qkv5, self.mask_u8, self.W)
+        return out, (p_max, kv, ksum)
+
+    def bwd(self, dout, qkv5, out, saved):
+        return performer_f32_bwd(dout, qkv5, self.mask_u8, self.W, saved[0], saved[1], saved[2]), ()
+
+
 class CoreModuleFn(torch.autograd.Function):
     """qkv projection -> attention core -> output projection as ONE autograd node for the softmax and local-window baselines
     (round 4; LaraModuleFn's scheme for cores without landmark parameters): the projections read the fp32 master weights, both

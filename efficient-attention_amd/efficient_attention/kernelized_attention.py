@@ -83,6 +83,14 @@ class KernelizedAttention(MultiheadAttention):
             return _ops.linear(x, self.qkv).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         return super().project_qkv(x)
 
+    def _core_spec(self, B, N, seq_shape, key_padding_mask, device):
+        """The single-node path (_ops.CoreModuleFn, round 4) for the exact-fp32 core; everything else keeps the three nodes."""
+        if (type(self)._attend is not KernelizedAttention._attend or _ops.PERFORMER_16BIT or self.head_dim != 64
+                or self.approx_attn_dim > 96 or self.approx_attn_dim % 16 != 0):
+            return None, ()
+        proj = self.get_proj_matrix(device=device, dtype=torch.float32)
+        return _ops.PerformerCore(_ops._mask_u8(key_padding_mask, B, N, device), proj), ()
+
     def _attend(self, qkv5, key_padding_mask, seq_shape):
         B, N = qkv5.shape[:2]
         proj = self.get_proj_matrix(device=qkv5.device, dtype=torch.float32)

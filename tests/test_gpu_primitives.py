@@ -1111,7 +1111,7 @@ def test_layernorm_kernels_match_torch(xdtype, rows, C):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("attn", ["softmax", "local", "local_norpe", "softmax_dropout"])
+@pytest.mark.parametrize("attn", ["softmax", "local", "local_norpe", "softmax_dropout", "performer"])
 def test_core_module_single_node_equals_three_nodes(attn, monkeypatch):
     """CoreModuleFn (softmax / local-window baselines: projections + core as one autograd node, paired weight gradients,
     one terminal reduction) against the three-node path: same kernels for the activations -- y, dx and the bias-table
@@ -1120,8 +1120,12 @@ def test_core_module_single_node_equals_three_nodes(attn, monkeypatch):
     import torch
     import efficient_attention as ea
     from efficient_attention import _ops
-    name = "local" if attn.startswith("local") else "softmax"
+    name = "local" if attn.startswith("local") else ("performer" if attn == "performer" else "softmax")
     args = dict(dim=192, num_heads=3)
+    if name == "performer":
+        if _ops.PERFORMER_16BIT:
+            pytest.skip("EA_PERFORMER_16BIT=1: the single node wraps the fp32 core only")
+        args.update(approx_attn_dim=64, proj_method="favorp")
     if name == "local":
         args.update(window_size=7, attn_2d=True, use_rpe=attn == "local")
     if attn == "softmax_dropout":
@@ -1148,6 +1152,7 @@ def test_core_module_single_node_equals_three_nodes(attn, monkeypatch):
         for p in m.parameters():
             p.grad = None
         x = x0.clone().requires_grad_(True)
+        torch.manual_seed(6)                                   # (Performer draws its random features per training call)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = m(x)
         assert type(y.grad_fn).__name__.startswith("CoreModuleFn") == single
