@@ -108,13 +108,14 @@ def build_layer(attn, dim, heads, grid, device):
         return ea.AttentionFactory.build_attention(attn, attn_args(attn, dim, heads, _seq(grid))).to(device)
 
 
-def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
-    """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores on
-    a bounded sample of the same workload: same layer and token geometry, batch 8, fp32,
-    forward + backward, as many iterations as fit in ~budget_s."""
+def cpu_baseline(attn, dim, heads, grid, batch=128, budget_s=30.0):
+    """The oracle (CPU restatement of the reference, kind='port') timed on this host's cores the way SURVEY.md 8(d) prescribes:
+    same layer, token geometry and -- when it fits the time budget -- the GPU line's batch, fp32, forward + backward; per
+    thread count 3 warm-up + >= 10 timed iterations, MEDIAN; all host cores and 8 threads, both reported (`threads`), the
+    faster one is `value`.  The batch is halved until 2 x 13 iterations are estimated to fit `budget_s` (the estimate is one
+    probe step at batch 8); `sample` states the batch that ran."""
     import oracle
     torch.manual_seed(1234)
-    B = 8
     layer = build_layer(attn, dim, heads, grid, "cpu")
     params = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in layer.state_dict().items()}
     seq = _seq(grid)
@@ -123,46 +124,58 @@ def cpu_baseline(attn, dim, heads, grid, budget_s=20.0):
             LM_ATTN_ARGS, window_size=OVERRIDES.get("window_size") or LM_ATTN_ARGS["window_size"]))
     else:
         args = attn_args(attn, dim, heads, seq)
-    x = torch.randn(B, *seq, dim, requires_grad=True)
-    g = torch.randn(B, *seq, dim)
     noise_fn = lambda shape: torch.randn(*shape)  # noqa: E731
-
-    def step():
-        for p in params.values():
-            p.grad = None
-        y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn,
-                                  keep_fn=lambda shape: (torch.rand(*shape) >= LM_ATTENTION_DROPOUT).float(),
-                                  index_fn=lambda shape: torch.randint(0, shape[-1], tuple(shape)))
-        (y * g).sum().backward()
-
     ntok = 1
     for v in seq:
         ntok *= v
 
-    def timed(budget):
-        step()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            step()
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget or n >= 50:
-                return n, n * B * ntok / el
+    def make_step(B):
+        x = torch.randn(B, *seq, dim, requires_grad=True)
+        g = torch.randn(B, *seq, dim)
 
-    # all host cores and, because these small tensors oversubscribe a 128-core host,
-    # also 8 threads; the faster of the two is the baseline
+        def step():
+            for p in params.values():
+                p.grad = None
+            x.grad = None
+            y = oracle.module_forward(attn, args, params, x, None, training=True, noise_fn=noise_fn,
+                                      keep_fn=lambda shape: (torch.rand(*shape) >= LM_ATTENTION_DROPOUT).float(),
+                                      index_fn=lambda shape: torch.randint(0, shape[-1], tuple(shape)))
+            (y * g).sum().backward()
+        return step
+
+    def timed_once(step):
+        t0 = time.perf_counter()
+        step()
+        return time.perf_counter() - t0
+
+    WARM, TIMED = 3, 10
     all_cores = torch.get_num_threads()
-    runs = []
-    for threads in sorted({all_cores, min(8, all_cores)}, reverse=True):
+    counts = sorted({all_cores, min(8, all_cores)})
+    torch.set_num_threads(counts[0])
+    probe = make_step(8)
+    probe()
+    per_elem = timed_once(probe) / 8                      # seconds per batch element at the small thread count
+    B = max(1, int(batch))
+    while B > 8 and per_elem * B * (WARM + TIMED) * len(counts) > budget_s:
+        B //= 2
+    step = make_step(B)
+    per_threads = {}
+    for threads in counts:
         torch.set_num_threads(threads)
-        n, tok_s = timed(budget_s / 2)
-        runs.append((tok_s, threads, n))
+        for _ in range(WARM):
+            step()
+        ts = sorted(timed_once(step) for _ in range(TIMED))
+        med = 0.5 * (ts[(TIMED - 1) // 2] + ts[TIMED // 2])
+        per_threads[threads] = B * ntok / med
     torch.set_num_threads(all_cores)
-    tok_s, threads, n = max(runs)
-    others = "; ".join("%d threads: %.0f tokens/s" % (t, v) for v, t, _ in runs)
+    threads, tok_s = max(per_threads.items(), key=lambda kv: kv[1])
     return {"value": tok_s, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": "%d x fwd+bwd of the oracle layer (%s, fp32) at batch %d (the GPU line runs batch 128: a bounded sample of the same "
-                      "per-element work), N=%d, dim %d [%s]" % (n, attn, B, ntok, dim, others)}
+            "threads": {str(t): round(v, 1) for t, v in per_threads.items()},
+            "batch": B, "warmup": WARM, "timed": TIMED, "statistic": "median",
+            "sample": "oracle layer (%s, fp32) fwd+bwd at batch %d (GPU line: batch %d), N=%d, dim %d; per thread count %d warm-up + "
+                      "%d timed iterations, median [%s]"
+                      % (attn, B, batch, ntok, dim, WARM, TIMED,
+                         "; ".join("%d threads: %.0f tokens/s" % (t, v) for t, v in sorted(per_threads.items())))}
 
 
 def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, overrides=None):

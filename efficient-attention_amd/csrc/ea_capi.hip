@@ -32,6 +32,9 @@ int proj_rs_supported(int K, int NO);
 int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r);
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
                      long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast);
+int dgrad_rs_supported(int K, int NO);
+int dgrad_rs_dispatch(int dtype, const void* dy, const void* w, int w_f32, void* dx, int dx_f32, int rows, long ldy, long ldx,
+                      hipStream_t st);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
                     void* a_cast, int rows, int K, int NO, long lda, long ldy, hipStream_t st);
 int wgrad_slices(int rows, int M, int K);
@@ -69,7 +72,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 9; }
+int32_t ea_abi_version(void) { return 10; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -435,6 +438,44 @@ int ea_lara_bwd_finish(const ea_lara_geom* g, const ea_t4* q, const float* qbar,
   return lara_f_dispatch(2, p, g->dtype, (hipStream_t)stream);
 }
 
+// ---- round 5: consumers that merge the producing pass's slice partials in their prologue (no merge launches) ----
+int ea_lara_out_fwd_merge(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar, const float* bhv,
+                          int32_t S, const float* p_ml, const float* p_kv, const float* lp, float* kv, float* lse_k,
+                          float* lse_t, float* cst, const ea_t4* out, float* lseZ, float* tmean, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (p.NCT > 4 || S < 1 || S > 4) return EA_E_UNSUPPORTED;
+  if (!t4_ok(q, g->D) || !t4_ok(out, g->D) || !omega || !p_ml || !p_kv || !lp || !kv || !lse_k || !cst) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !lse_t || !bhv)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !qbar) return EA_E_BADARG;
+  if ((lseZ == nullptr) != (tmean == nullptr)) return EA_E_BADARG;
+  p.q = mkl(q); p.o = mkl(out); p.omega = omega; p.qbar = qbar; p.bhv = bhv; p.lseZ = lseZ; p.tmean = tmean;
+  p.m_S = S; p.m_ml = p_ml; p.m_acc0 = p_kv; p.m_lp = lp;
+  p.m_kv = kv; p.m_lsek = lse_k; p.m_lset = lse_t; p.m_cst = cst;
+  return lara_x_dispatch(LX_FWDM, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_bwd_k_fused_merge(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* omega,
+                              const float* qbar, const float* kv, const float* lse_k, int32_t S, const float* p_ml,
+                              const float* p_dkv, const float* p_dom, const float* p_m1, const float* p_m2,
+                              const ea_t4* dk, const ea_t4* dv, float* p_domk, float* dbh, float* dlp, float* domq,
+                              float* dqbar, float* uq, void* stream) {
+  LaraP p = {};
+  int rc = fill_lara(g, p, false);
+  if (rc != EA_OK) return rc;
+  if (p.NCT > 4 || S < 1 || S > 4) return EA_E_UNSUPPORTED;
+  if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !omega || !kv || !lse_k || !p_ml ||
+      !p_dkv || !p_dom || !p_domk || !dlp || !domq) return EA_E_BADARG;
+  if (g->mis == EA_MIS_OPT && (!qbar || !p_m1 || !p_m2 || !dqbar || !uq || !dbh)) return EA_E_BADARG;
+  if (g->mis == EA_MIS_BIASED && !dqbar) return EA_E_BADARG;
+  p.k = mkl(k); p.v = mkl(v); p.dk = mkl(dk); p.dv = mkl(dv); p.mask = mask; p.omega = omega; p.qbar = qbar;
+  p.kv = kv; p.lse_k = lse_k; p.p_acc0 = p_domk;
+  p.m_S = S; p.m_ml = p_ml; p.m_acc0 = p_dkv; p.m_acc1 = p_dom; p.m_acc2 = p_m1; p.m_acc3 = p_m2;
+  p.m_dbh = dbh; p.m_dlp = dlp; p.m_domq = domq; p.m_dqbar = dqbar; p.m_uq = uq;
+  return lara_f_dispatch(3, p, g->dtype, (hipStream_t)stream);
+}
+
 int ea_lara_bwd_qcorr(const ea_lara_geom* g, const ea_t4* q, const float* qbar, const float* uq,
                       const float* lse_t, const ea_t4* dq, void* stream) {
   LaraP p = {};
@@ -680,6 +721,27 @@ int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk
   if (g->dup != 0 && !noise) return EA_E_BADARG;
   p.pq = pq; p.pk = pk; LMK_PARAMS(p)
   p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
+  p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
+  p.saved = const_cast<float*>(saved);
+  return lara_lmk_dispatch(true, p, (hipStream_t)stream);
+}
+
+int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const float* pk,
+                                const float* Wq, const float* bq, const float* gq, const float* cq,
+                                const float* Wk, const float* bk, const float* gk, const float* ck,
+                                const float* noise, const float* d_omega, int32_t dom_S, const float* dom_parts, float dom_scale,
+                                const float* d_qbar_rows, const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                                float* dW_part, float* dvec_part, const float* saved, void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (g->eva || !pq || !pk || !d_omega || !d_lp || !dpq || !dpk || !dom_parts || dom_S < 1 || dom_S > 4) return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
+    return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
+  p.dom_parts = dom_parts; p.dom_S = dom_S; p.dom_scale = dom_scale;
   p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
   p.saved = const_cast<float*>(saved);
   return lara_lmk_dispatch(true, p, (hipStream_t)stream);
@@ -1204,6 +1266,20 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
                          (long)lda, (long)ldy, (hipStream_t)stream);
 }
 
+// input gradient of the 192 -> 576 projection, weight resident in registers (ea_dgrad_rs.hip)
+int32_t ea_linear_dgrad_supported(int32_t in_features, int32_t out_features) {
+  return dgrad_rs_supported(out_features, in_features);
+}
+
+int ea_linear_dgrad(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* dy, int64_t ldy,
+                    const void* w, int32_t w_f32, void* dx, int32_t dx_f32, int64_t ldx, void* stream) {
+  if (!dy || !w || !dx || ((uintptr_t)dy & 15) || ((uintptr_t)w & 15) || ((uintptr_t)dx & 15)) return EA_E_BADARG;
+  if (rows < 0 || ldy < out_features || ldx < in_features || (ldy & 7) || (ldx & 3) || (!dx_f32 && (ldx & 7))) return EA_E_BADARG;
+  if (!dgrad_rs_supported(out_features, in_features)) return EA_E_UNSUPPORTED;
+  if ((int64_t)rows * ldy >= ((int64_t)1 << 40)) return EA_E_BADARG;
+  return dgrad_rs_dispatch(dtype, dy, w, w_f32, dx, dx_f32, rows, (long)ldy, (long)ldx, (hipStream_t)stream);
+}
+
 // qkv projection + pooled q / k rows in one pass (ea_proj_rs.hip, POOL variants)
 int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int32_t B, int32_t gh, int32_t gw, int32_t r) {
   return proj_rs_pool_supported(in_features, out_features, B, gh, gw, r);
@@ -1361,7 +1437,8 @@ struct LaraLayerPlan {
   // forward scratch: lp, p_ml, p_kv
   size_t f_lp, f_ml, f_kv, n_ftmp;
   // backward scratch: p_ml, p_acc[4], big[4], small[4], d_omega, dpq, dpk, dW, dvec
-  size_t b_ml, b_acc, b_big, b_small, b_dom, b_dpq, b_dpk, b_dW, b_dvec, n_btmp;
+  size_t b_ml, b_acc, b_big, b_small, b_dom, b_dpq, b_dpk, b_dW, b_dvec, b_domk, n_btmp;
+  bool fold_f, fold_b;   // round 5: merge launches folded into their consumers (S <= 4 slices; EA_LARA_FOLD=0 restores them)
 };
 size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }       // 16-byte aligned sub-buffers
 int lara_layer_plan(const ea_lara_layer* c, LaraLayerPlan& P) {
@@ -1402,6 +1479,11 @@ int lara_layer_plan(const ea_lara_layer* c, LaraLayerPlan& P) {
   P.b_ml = take(Cs * P.S_bwd * 4); P.b_acc = take(4 * CD * P.S_bwd); P.b_big = take(4 * CD); P.b_small = take(4 * Cs);
   P.b_dom = take(CD); P.b_dpq = take(LD); P.b_dpk = take(LD);
   P.b_dW = take((size_t)P.BH * 2 * c->D * c->D); P.b_dvec = take((size_t)P.BH * 6 * c->D);
+  const char* fold_env = getenv("EA_LARA_FOLD");             // (read per call: the tests switch it inside one process)
+  const bool fold_on = !(fold_env && fold_env[0] == '0');
+  P.fold_f = fold_on && P.S_fwd <= 4;
+  P.fold_b = fold_on && P.S_bwd <= 4;
+  P.b_domk = take(P.fold_b ? CD * P.S_bwd : 0);
   P.n_btmp = o;
   return EA_OK;
 }
@@ -1450,10 +1532,14 @@ int ea_lara_layer_fwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
   if (rc != EA_OK) return rc;
   rc = ea_lara_stats_fwd(&P.g, q, k, v, mask, omega, qrows, tmp + P.f_ml, tmp + P.f_kv, stream);
   if (rc != EA_OK) return rc;
+  float* tok = keep_for_backward ? saved + P.o_tok : nullptr;
+  if (P.fold_f)
+    return ea_lara_out_fwd_merge(&P.g, q, omega, qrows, bhv, P.S_fwd, tmp + P.f_ml, tmp + P.f_kv, tmp + P.f_lp, saved + P.o_kv,
+                                 saved + P.o_lsek, lse_t, saved + P.o_cst, out, tok, tok ? tok + (size_t)P.BH * P.g.N : nullptr,
+                                 stream);
   rc = ea_lara_merge_fwd(P.BH, P.S_fwd, P.C, c->D, opt ? 1 : 0, tmp + P.f_ml, tmp + P.f_kv, tmp + P.f_lp, saved + P.o_kv,
                          saved + P.o_lsek, lse_t, saved + P.o_cst, stream);
   if (rc != EA_OK) return rc;
-  float* tok = keep_for_backward ? saved + P.o_tok : nullptr;
   return ea_lara_out_fwd(&P.g, q, omega, qrows, saved + P.o_kv, lse_t, bhv, saved + P.o_cst, out, tok,
                          tok ? tok + (size_t)P.BH * P.g.N : nullptr, stream);
 }
@@ -1485,6 +1571,26 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
                            acc[0], acc[1], acc[2], acc[3], stream);
   if (rc != EA_OK) return rc;
   const bool want_dqbar = c->mis == EA_MIS_OPT || c->mis == EA_MIS_BIASED;
+  if (P.fold_b) {
+    // the key-side pass merges the query side's partials itself and block 0 of each (b,h) writes dbh, dlp, sum dZ q, d qbar
+    // rows and u qbar; the landmark backward adds the key side's d omega partials while it loads its strips
+    float* domk = tmp + P.b_domk;
+    rc = ea_lara_bwd_k_fused_merge(&P.g, k, v, mask, omega, qrows, kv, saved + P.o_lsek, P.S_bwd, p_ml, acc[0], acc[1], acc[2],
+                                   acc[3], dk, dv, domk, opt ? dbh : nullptr, dlp_m, dom_q, want_dqbar ? dqbar_m : nullptr,
+                                   opt ? uq : nullptr, stream);
+    if (rc != EA_OK) return rc;
+    float *dpq = tmp + P.b_dpq, *dpk = tmp + P.b_dpk;
+    float* dW = c->has_mlp ? tmp + P.b_dW : nullptr;
+    float* dvec = c->has_mlp ? tmp + P.b_dvec : nullptr;
+    rc = ea_lara_landmarks_bwd_parts(&P.lg, saved + P.o_pq, saved + P.o_pk, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7],
+                                     noise, dom_q, P.S_bwd, domk, c->scale, want_dqbar ? dqbar_m : nullptr, opt ? dbh : nullptr,
+                                     dlp_m, dpq, dpk, dW, dvec, saved + P.o_lmk, stream);
+    if (rc != EA_OK) return rc;
+    rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
+    if (rc != EA_OK) return rc;
+    if (c->has_mlp && dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
+    return rc;
+  }
   rc = ea_lara_merge_bwd(P.BH, P.S_bwd, P.C, D, opt ? 1 : 0, c->scale, p_ml, acc[0], acc[1], acc[2], acc[3], kv, qrows, r, dbh,
                          dlp_m, dkk, dkv, dom_q, want_dqbar ? dqbar_m : nullptr, opt ? uq : nullptr, stream);
   if (rc != EA_OK) return rc;

@@ -21,7 +21,7 @@ struct T4l {
 };
 
 enum { MIS_OPT = 0, MIS_BIASED = 1, MIS_BH = 2 };
-enum { LX_FWD = 0, LX_BWDQ = 1, LX_BWDK = 2, LX_QCORR = 3, LX_POUT = 4, LX_PBWDQ = 5, LX_PBWDK = 6 };
+enum { LX_FWD = 0, LX_BWDQ = 1, LX_BWDK = 2, LX_QCORR = 3, LX_POUT = 4, LX_PBWDQ = 5, LX_PBWDK = 6, LX_FWDM = 7 };
 enum { LY_FWD = 0, LY_BWDQ = 1, LY_BWDK = 2, LY_PMAX = 3, LY_PKV = 4, LY_PBWDQ = 5 };
 // The Performer baseline (kernelized_attention.py:20-56,116-121) runs on the same two skeletons
 // with the m random features W_j in the role of the landmark rows (modes LX_P*, LY_P*):
@@ -59,6 +59,18 @@ struct LaraP {
   const float *dpq, *dpk;
   int pool_r, pool_gw, pool_L;
   float pool_inv;
+  // merge-on-load (round 5): a consumer pass takes the S <= 4 per-slice partials of the producing token-row pass and merges
+  // them in its prologue -- the arithmetic of ea_lara_merge.hip, operation for operation -- instead of waiting for a merge
+  // launch of its own (7-16 us each at cfg3 for a few KB per (b,h)).  Block 0 of a (b,h) writes the merged tensors the
+  // later passes (and the backward) read.
+  //   LX_FWDM (forward combine): m_ml [BH,S,C,4] = (max_k, sum_k, max_t, sum_t), m_acc0 [BH,S,C,D] un-normalised kv, m_lp [BH,C]
+  //       -> kv, lse_k, lse_t, cst (m_kv, m_lsek, m_lset, m_cst)
+  //   key side of the fused backward (lara_fk_kernel, FOLD): m_ml = (r, dbh, u, -), m_acc0..3 = (dkv, sum dZ q, sum t dt q,
+  //       sum t q) partials of lara_fq_kernel -> dkv rows / dkk / r for itself, and m_dbh, m_dlp, m_domq, m_dqbar, m_uq
+  const float *m_ml, *m_acc0, *m_acc1, *m_acc2, *m_acc3, *m_lp;
+  int m_S;
+  float *m_kv, *m_lsek, *m_lset, *m_cst;
+  float *m_dbh, *m_dlp, *m_domq, *m_dqbar, *m_uq;
   long long* prof;              // dev builds (-DEA_PROFILE): phase time stamps
 };
 

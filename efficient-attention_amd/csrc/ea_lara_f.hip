@@ -416,7 +416,10 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
 // ------------------------------------------------------------------------------------------
 // key side
 // ------------------------------------------------------------------------------------------
-template <typename E, int D, int NCT>
+// FOLD (round 5): the per-slice partials of lara_fq_kernel are merged HERE (ea_lara_merge.hip's backward arithmetic in the
+// prologue: d kv_stats rows, dkk = dkv . kv, r) instead of by a merge launch between the two passes; block 0 of a (b,h)
+// also writes what the landmark backward and the finish pass read (dbh, dlp, sum dZ q, d qbar rows, u qbar).
+template <typename E, int D, int NCT, bool FOLD>
 __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
   constexpr int ROWB = D * 2, KS = D / 32, DT = D / 16, DQ = D / 4;
   constexpr int Cp = NCT * 16, ROWW = Cp * 2, NSUB = 4 / NCT;
@@ -454,13 +457,130 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
   };
   issue(n0);
   float sc_v0 = INFINITY, sc_v1 = 0.f, sc_v2 = 0.f;
-  if (tid < p.C) { sc_v0 = p.lse_k[lm + tid] * LOG2E; sc_v1 = p.dkk[lm + tid]; sc_v2 = p.rsum[lm + tid]; }
-  {
+  float mg_dbh = 0.f;
+  if (tid < p.C) {
+    sc_v0 = p.lse_k[lm + tid] * LOG2E;
+    if constexpr (FOLD) {
+      const int S = p.m_S;
+      float4 m4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) m4[u] = *reinterpret_cast<const float4*>(p.m_ml + (((size_t)bh * S + min(u, S - 1)) * p.C + tid) * 4);
+      float r = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < S) { r += m4[u].x; mg_dbh += m4[u].y; }
+      }
+      sc_v2 = r;
+    } else {
+      sc_v1 = p.dkk[lm + tid]; sc_v2 = p.rsum[lm + tid];
+    }
+  }
+  if constexpr (FOLD) {
+    constexpr int CPRs = D / 8;
+    constexpr int SL = (Cp * CPRs + 255) / 256;
+    const int S = p.m_S;
+    {
+      char* const dst[3] = {R1, nullptr, nullptr};
+      const float* const src[3] = {p.omega + lm * D, nullptr, nullptr};
+      stage_rows3<E, D, Cp>(dst, src, p.C, tid);
+    }
+    // d kv_stats rows = sum of the slices' partials, dkk[c] = dkv[c] . kv[c]
+    float4 v0[SL][4][2], kvr[SL][2];
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int idx = tid + sl * 256;
+      const int row = idx / CPRs, c = idx - row * CPRs;
+      const int rr = (idx < Cp * CPRs && row < p.C) ? row : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = p.m_acc0 + (((size_t)bh * S + min(u, S - 1)) * p.C + rr) * D + c * 8;
+        v0[sl][u][0] = *reinterpret_cast<const float4*>(src);
+        v0[sl][u][1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+      kvr[sl][0] = *reinterpret_cast<const float4*>(p.kv + (lm + rr) * D + c * 8);
+      kvr[sl][1] = *reinterpret_cast<const float4*>(p.kv + (lm + rr) * D + c * 8 + 4);
+    }
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int idx = tid + sl * 256;
+      const int row = idx / CPRs, c = idx - row * CPRs;
+      const bool rok = idx < Cp * CPRs && row < p.C;
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < S) {
+          a[0] += v0[sl][u][0].x; a[1] += v0[sl][u][0].y; a[2] += v0[sl][u][0].z; a[3] += v0[sl][u][0].w;
+          a[4] += v0[sl][u][1].x; a[5] += v0[sl][u][1].y; a[6] += v0[sl][u][1].z; a[7] += v0[sl][u][1].w;
+        }
+      }
+      if (!rok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = 0.f;
+      }
+      float dot = a[0] * kvr[sl][0].x + a[1] * kvr[sl][0].y + a[2] * kvr[sl][0].z + a[3] * kvr[sl][0].w +
+                  a[4] * kvr[sl][1].x + a[5] * kvr[sl][1].y + a[6] * kvr[sl][1].z + a[7] * kvr[sl][1].w;
+      dot = group_sum<CPRs>(dot);
+      if (idx < Cp * CPRs) {
+        sts16(R3 + TileL<D>::off(row, c), pack8<E>(a));
+        if (c == 0) SC1[row] = rok ? dot : 0.f;
+      }
+    }
+    if (blk == 0) {
+      // what the later passes read: sum dZ q (d omega, query side), d qbar rows = s (M1 - u M2) [mis-opt] | s sum dZ q
+      // [mis-biased], u qbar (the finish pass), and the per-landmark scalars dbh, dlp = -r
+      const bool opt = p.mis == MIS_OPT, biased = p.mis == MIS_BIASED;
+      if (tid < p.C) {
+        if (p.m_dbh) p.m_dbh[lm + tid] = mg_dbh;
+        p.m_dlp[lm + tid] = -sc_v2;
+      }
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / CPRs, c = idx - row * CPRs;
+        if (idx >= Cp * CPRs || row >= p.C) continue;
+        float a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+              a3[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float u_ = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) {
+          const size_t slot = ((size_t)bh * S + s_) * p.C + row;
+          const float* s1 = p.m_acc1 + slot * D + c * 8;
+          const float4 x0 = *reinterpret_cast<const float4*>(s1), x1 = *reinterpret_cast<const float4*>(s1 + 4);
+          a1[0] += x0.x; a1[1] += x0.y; a1[2] += x0.z; a1[3] += x0.w; a1[4] += x1.x; a1[5] += x1.y; a1[6] += x1.z; a1[7] += x1.w;
+          if (opt) {
+            u_ += p.m_ml[slot * 4 + 2];
+            const float* s2 = p.m_acc2 + slot * D + c * 8;
+            const float* s3 = p.m_acc3 + slot * D + c * 8;
+            const float4 y0 = *reinterpret_cast<const float4*>(s2), y1 = *reinterpret_cast<const float4*>(s2 + 4);
+            const float4 z0 = *reinterpret_cast<const float4*>(s3), z1 = *reinterpret_cast<const float4*>(s3 + 4);
+            a2[0] += y0.x; a2[1] += y0.y; a2[2] += y0.z; a2[3] += y0.w; a2[4] += y1.x; a2[5] += y1.y; a2[6] += y1.z; a2[7] += y1.w;
+            a3[0] += z0.x; a3[1] += z0.y; a3[2] += z0.z; a3[3] += z0.w; a3[4] += z1.x; a3[5] += z1.y; a3[6] += z1.z; a3[7] += z1.w;
+          }
+        }
+        const size_t o = (lm + row) * D + c * 8;
+        *reinterpret_cast<float4*>(p.m_domq + o) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        *reinterpret_cast<float4*>(p.m_domq + o + 4) = make_float4(a1[4], a1[5], a1[6], a1[7]);
+        if (opt) {
+          const float sc = p.scale;
+          const float4 q0 = *reinterpret_cast<const float4*>(p.qbar + o), q1 = *reinterpret_cast<const float4*>(p.qbar + o + 4);
+          *reinterpret_cast<float4*>(p.m_dqbar + o) = make_float4(sc * (a2[0] - u_ * a3[0]), sc * (a2[1] - u_ * a3[1]),
+                                                                  sc * (a2[2] - u_ * a3[2]), sc * (a2[3] - u_ * a3[3]));
+          *reinterpret_cast<float4*>(p.m_dqbar + o + 4) = make_float4(sc * (a2[4] - u_ * a3[4]), sc * (a2[5] - u_ * a3[5]),
+                                                                      sc * (a2[6] - u_ * a3[6]), sc * (a2[7] - u_ * a3[7]));
+          *reinterpret_cast<float4*>(p.m_uq + o) = make_float4(u_ * q0.x, u_ * q0.y, u_ * q0.z, u_ * q0.w);
+          *reinterpret_cast<float4*>(p.m_uq + o + 4) = make_float4(u_ * q1.x, u_ * q1.y, u_ * q1.z, u_ * q1.w);
+        } else if (biased && p.m_dqbar) {
+          *reinterpret_cast<float4*>(p.m_dqbar + o) = make_float4(p.scale * a1[0], p.scale * a1[1], p.scale * a1[2], p.scale * a1[3]);
+          *reinterpret_cast<float4*>(p.m_dqbar + o + 4) = make_float4(p.scale * a1[4], p.scale * a1[5], p.scale * a1[6], p.scale * a1[7]);
+        }
+      }
+    }
+    if (tid < Cp) { SC0[tid] = sc_v0; SC2[tid] = sc_v2; }
+  } else {
     char* const dst[3] = {R1, nullptr, R3};
     const float* const src[3] = {p.omega + lm * D, nullptr, p.dkv + lm * D};
     stage_rows3<E, D, Cp>(dst, src, p.C, tid);
+    if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
   }
-  if (tid < Cp) { SC0[tid] = sc_v0; SC1[tid] = sc_v1; SC2[tid] = sc_v2; }
   typename LaneOffSel<D>::type lo;
   lo.init(lane);
   const int wr = 4 * g + (li >> 2);
@@ -801,9 +921,9 @@ static int f_occupancy(K kern, size_t lds) {
 
 template <typename E, int D, int NCT>
 static int launch_f(int which, LaraP& p, hipStream_t st) {
-  const size_t lds = lara_f_lds(which, D, NCT * 16);
+  const size_t lds = lara_f_lds(which == 3 ? 1 : which, D, NCT * 16);
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
-  static int occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of the instantiations
+  static int occ[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of the instantiations
   static const int fq_fixed = f_env_int("EA_LARA_FQ_F", 160);
 #define EA_LF(K, slot, ...)                                                                           \
   do {                                                                                                \
@@ -822,7 +942,8 @@ static int launch_f(int which, LaraP& p, hipStream_t st) {
     if (p.mis == MIS_OPT) { if (lh1) EA_LF(lara_fq_kernel, 0, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_OPT); else EA_LF(lara_fq_kernel, 3, E, D, NCT, 2, MIS_OPT); }
     else if (p.mis == MIS_BIASED) { if (lh1) EA_LF(lara_fq_kernel, 4, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_BIASED); else EA_LF(lara_fq_kernel, 5, E, D, NCT, 2, MIS_BIASED); }
     else { if (lh1) EA_LF(lara_fq_kernel, 6, E, D, NCT, (NCT == 4 ? 1 : 2), MIS_BH); else EA_LF(lara_fq_kernel, 7, E, D, NCT, 2, MIS_BH); }
-  } else if (which == 1) EA_LF(lara_fk_kernel, 1, E, D, NCT);
+  } else if (which == 1) EA_LF(lara_fk_kernel, 1, E, D, NCT, false);
+  else if (which == 3) EA_LF(lara_fk_kernel, 8, E, D, NCT, true);
   else EA_LF(lara_fin_kernel, 2, E, D, NCT);
 #undef EA_LF
   return (int)hipGetLastError();
@@ -835,7 +956,7 @@ static int launch_f_nct(int which, LaraP& p, hipStream_t st) {
   return EA_E_UNSUPPORTED;
 }
 
-// which: 0 query side, 1 key side, 2 finish
+// which: 0 query side, 1 key side, 2 finish, 3 key side with the query side's partials merged in its prologue
 int lara_f_dispatch(int which, const LaraP& p0, int dtype, hipStream_t st) {
   LaraP p = p0;
   p.prof = nullptr;

@@ -10,6 +10,11 @@ struct LmkP {
   const float* noise;                                     // standard normal, or null (eval)
   float *omega, *qbar_rows, *bhv, *lp;                    // forward outputs
   const float *d_omega, *d_qbar_rows, *d_bhv, *d_lp;      // backward inputs
+  // round 5: d omega = dom_scale (d_omega + sum_s dom_parts[bh][s]) formed while the strip is loaded (ea_slice_sum's launch
+  // folded in): dom_parts [BH, dom_S <= 4, C, D] slice partials of the key-side pass, or null (d_omega is final)
+  const float* dom_parts;
+  int dom_S;
+  float dom_scale;
   float *dpq, *dpk, *dW_part, *dvec_part;                 // backward outputs
   int BH, L, C, D;
   int has_mlp, mixed, mis, dup;

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   const int b = bh / p.H, h = bh - b * p.H;
   const size_t lm = (size_t)bh * p.C;               // landmark row offset
   const size_t lmw = (size_t)(p.w_per_head ? h : bh) * p.C;   // ... of omega / W
-  constexpr bool PERF = MODE >= LX_POUT;
+  constexpr bool PERF = MODE >= LX_POUT && MODE != LX_FWDM;
+  constexpr bool FWD = MODE == LX_FWD || MODE == LX_FWDM;      // LX_FWDM: the statistics pass's slice partials merged on load
   const bool use_t = mis != MIS_BH && !PERF;
 
   EA_STAMP(p, 0);
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
   // per-landmark scalars: one landmark per thread (Cp <= 128), loaded before the matrices so that
   // every global load of the prologue is in flight together (one exposed round trip, not two)
   float sc_v0 = -INFINITY, sc_v1 = INFINITY, sc_v2 = 1.f;
+  float mg_lsek = 0.f, mg_cst = 0.f, mg_lset = 0.f;
   {
     const int c = tid;
     const bool ok = c < p.C;
@@ -90,6 +92,30 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
         if (mis == MIS_OPT) sc_v2 = p.bhv[lm + c];
       }
       if ((MODE == LX_FWD || MODE == LX_BWDQ || MODE == LX_QCORR) && mis == MIS_OPT) sc_v1 = p.lse_t[lm + c] * LOG2E;
+      if (MODE == LX_FWDM) {
+        // ea_lara_merge.hip (lara_merge_fwd_kernel), per-landmark scalars: log-sum-exp merge of the S slices
+        const int S = p.m_S;
+        float4 m4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m4[u] = *reinterpret_cast<const float4*>(p.m_ml + (((size_t)bh * S + min(u, S - 1)) * p.C + c) * 4);
+        float mk = -INFINITY, mt = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { mk = fmaxf(mk, m4[u].x); mt = fmaxf(mt, m4[u].z); }
+        float lk = 0.f, lt = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < S) {
+            lk += m4[u].y * __expf(m4[u].x - mk);
+            if (mis == MIS_OPT) lt += m4[u].w * __expf(m4[u].z - mt);
+          }
+        }
+        const float lsek = mk + __logf(lk);
+        const float cstv = lsek - p.m_lp[lm + c];
+        sc_v0 = cstv * LOG2E;
+        float lsetv = 0.f;
+        if (mis == MIS_OPT) { sc_v2 = p.bhv[lm + c]; lsetv = mt + __logf(lt); sc_v1 = lsetv * LOG2E; }
+        mg_lsek = lsek; mg_cst = cstv; mg_lset = lsetv;       // stored after the staging (a store here would fence the loads below)
+      }
       if (MODE == LX_BWDK) { sc_v0 = p.lse_k[lm + c] * LOG2E; sc_v1 = p.dkk[lm + c]; sc_v2 = p.rsum[lm + c]; }
       if (MODE == LX_POUT || MODE == LX_PBWDQ) sc_v0 = p.cst[lm + c];       // sum_n phi(k_n)[j]
       if (MODE == LX_PBWDK) sc_v2 = p.rsum[lm + c];                         // d ksum[j]
@@ -123,6 +149,58 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
         rb[j][sl][0] = lo; rb[j][sl][1] = hi;
       }
     }
+    // (after the loop above: the loads of omega / qbar are in flight while the partials are fetched and merged)
+    if constexpr (MODE == LX_FWDM) {
+      // kv rows = sum_s kv_s e^(m_s - m) / sum_s l_s e^(m_s - m): the merge kernel's arithmetic on this thread's (row, chunk)
+      // slots; every load first, then the arithmetic and the stores
+      const int S = p.m_S;
+      float m8[SL][4], l8[SL][4];
+      float4 v8[SL][4][2];
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / CPRs, c = idx - row * CPRs;
+        const int rr = (idx < Cp * CPRs && row < p.C) ? row : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t slot = ((size_t)bh * S + min(u, S - 1)) * p.C + rr;
+          m8[sl][u] = p.m_ml[slot * 4];
+          l8[sl][u] = p.m_ml[slot * 4 + 1];
+          v8[sl][u][0] = *reinterpret_cast<const float4*>(p.m_acc0 + slot * D + c * 8);
+          v8[sl][u][1] = *reinterpret_cast<const float4*>(p.m_acc0 + slot * D + c * 8 + 4);
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        const int idx = tid + sl * 256;
+        const int row = idx / CPRs, c = idx - row * CPRs;
+        if (idx >= Cp * CPRs) continue;
+        const bool rok = row < p.C;
+        float mk = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mk = fmaxf(mk, m8[sl][u]);
+        float lk = 0.f;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u < S) {
+            const float w = __expf(m8[sl][u] - mk);
+            lk += l8[sl][u] * w;
+            a0.x += v8[sl][u][0].x * w; a0.y += v8[sl][u][0].y * w; a0.z += v8[sl][u][0].z * w; a0.w += v8[sl][u][0].w * w;
+            a1.x += v8[sl][u][1].x * w; a1.y += v8[sl][u][1].y * w; a1.z += v8[sl][u][1].z * w; a1.w += v8[sl][u][1].w * w;
+          }
+        }
+        const float iv = 1.f / lk;
+        const float f[8] = {a0.x * iv, a0.y * iv, a0.z * iv, a0.w * iv, a1.x * iv, a1.y * iv, a1.z * iv, a1.w * iv};
+        const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sts16(R3 + TileL<D>::off(row, c), pack8<E>(rok ? f : z8));
+        if (rok && blk == 0) {
+          float* dst = p.m_kv + (lm + row) * D + c * 8;
+          *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const bool on = rsrc[j] != nullptr;
@@ -138,6 +216,11 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     }
   }
 
+  if (MODE == LX_FWDM && blk == 0 && tid < p.C) {            // the merged scalars, for the backward
+    p.m_lsek[lm + tid] = mg_lsek;
+    p.m_cst[lm + tid] = mg_cst;
+    if (mis == MIS_OPT) p.m_lset[lm + tid] = mg_lset;
+  }
   EA_STAMP(p, 1);
   // per-landmark scalars live in LDS (three [Cp] fp32 vectors); lanes read the entries of their
   // rows c = 16 ct + 4 g + r at the point of use instead of pinning 6 x NCT x 4 registers
@@ -190,7 +273,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     // ---- elementwise stage -> weight tiles w1 (x M1) and w2 (x M2) ----
     float w1[NCT][4], w2[NCT][4];
     float sdb = 0.f, pden = 1.f;
-    if (MODE == LX_FWD || MODE == LX_BWDQ) {
+    if (FWD || MODE == LX_BWDQ) {
       // The stage is VALU-bound (16 (c, n) entries per lane and tile), so it is written on float2
       // values (v_pk_fma/mul/add_f32) and avoids per-entry log2 / rcp: with
       //   Z = log alpha + s w.q + cst,  softmax_c Z = alpha 2^z / sum_c alpha 2^z,  z = Z - log alpha
@@ -255,7 +338,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
       }
       const float ssum = quad_sum(ss2[0] + ss2[1]);
       const float inv = fast_rcp(ssum);
-      if (MODE == LX_FWD) {
+      if (FWD) {
         pden = inv;                                       // normalisation folded into the output scale
         if (p.lseZ && valid && g == 0) {                  // kept for the fused backward (ea_lara_bwd_q_fused)
           const size_t o = (size_t)bh * p.N + tok;
@@ -458,7 +541,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     // ---- store: lane owns channels DQ*g .. DQ*g+DQ-1 of token `tok` (the accumulator pieces of the transpose-read
     // layout are first moved between the four lanes of the token: quad_transpose, ea_common.h) ----
     float f[DQ];
-    if (MODE == LX_FWD || MODE == LX_POUT) {
+    if (FWD || MODE == LX_POUT) {
       // issued unconditionally (rows past the end go to the trash line): a static store count lets the wait for the next
       // tile's prefetched rows leave this tile's stores in flight
       char* dst = valid ? p.o.p + (b * p.o.sb + h * p.o.sh + tok * p.o.sn + DQ * g) * 2 : ea_trash_line();
@@ -568,6 +651,15 @@ static int launch_x(int mode, const LaraP& p, hipStream_t st) {
       if (p.mis == MIS_OPT) EA_LXM(LX_FWD, MIS_OPT);
       else if (p.mis == MIS_BIASED) EA_LXM(LX_FWD, MIS_BIASED);
       else EA_LXM(LX_FWD, MIS_BH);
+      break;
+    case LX_FWDM:
+      if constexpr (NCT <= 4) {
+        if (p.mis == MIS_OPT) EA_LXM(LX_FWDM, MIS_OPT);
+        else if (p.mis == MIS_BIASED) EA_LXM(LX_FWDM, MIS_BIASED);
+        else EA_LXM(LX_FWDM, MIS_BH);
+      } else {
+        return EA_E_UNSUPPORTED;
+      }
       break;
     case LX_BWDQ: EA_LX(LX_BWDQ); break;
     case LX_BWDK: EA_LX(LX_BWDK); break;

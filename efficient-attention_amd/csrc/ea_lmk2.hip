@@ -326,6 +326,17 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { rok[r] = r0 + r < C; rl[r] = min(r0 + r, C - 1) % L; }
   load_strip<NT>(gin, p.d_omega + oC, D, p.eva ? L : C, D, l);
+  if (p.dom_parts) {                                   // (uniform) a + sum_s parts[s], then the scale: ea_slice_sum's order
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      f32x4 part[NT];
+      load_strip<NT>(part, s_ < p.dom_S ? p.dom_parts + ((size_t)bh * p.dom_S + s_) * C * D : nullptr, D, C, D, l);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) gin[ct] = gin[ct] + part[ct];
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) gin[ct] = gin[ct] * p.dom_scale;
+  }
   if (p.eva) {
     // d rf_q_bar = d omega / 2, d rf_k_bar = d omega / 2 + d (rf_k_bar output)
     load_strip<NT>(gqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, D, L, D, l);

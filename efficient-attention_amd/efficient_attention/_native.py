@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 9          # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 10         # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -96,6 +96,9 @@ SIGNATURES = {
     "ea_rows_mlp_bwd": [_I] * 4 + [_P] * 15,
     "ea_lara_landmarks_fwd": [_MG] + [_P] * 17,
     "ea_lara_landmarks_bwd": [_MG] + [_P] * 21,
+    "ea_lara_landmarks_bwd_parts": [_MG] + [_P] * 12 + [_I, _P, _F] + [_P] * 9,
+    "ea_lara_out_fwd_merge": [_LG, _T, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P],
+    "ea_lara_bwd_k_fused_merge": [_LG, _T, _T, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _T, _T, _P, _P, _P, _P, _P, _P, _P],
     "ea_lara_landmarks_fwd_cb": [_MG] + [_P] * 18,
     "ea_lara_landmarks_bwd_cb": [_MG] + [_P] * 23,
     "ea_lara_landmarks_saved_floats": [_MG],
@@ -130,6 +133,8 @@ SIGNATURES = {
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_linear_w32": [_I, _I, _I, _I, _P, _I, _L, _P, _I, _P, _P, _I, _L, _P, _P],
     "ea_linear_pool_supported": [_I] * 6,
+    "ea_linear_dgrad_supported": [_I, _I],
+    "ea_linear_dgrad": [_I, _I, _I, _I, _P, _L, _P, _I, _P, _I, _L, _P],
     "ea_linear_w32_pool": [_I] * 7 + [_P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],

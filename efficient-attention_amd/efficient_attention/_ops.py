@@ -770,7 +770,7 @@ class EvaModuleFn(torch.autograd.Function):
         elif need_bq:
             dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype).view(xshape)
+            dx = qkv_dgrad(dqkv2, wq, w16, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}
@@ -1065,6 +1065,13 @@ class AdaptivePoolFn(torch.autograd.Function):
         return (buf if own else None), None, None, None, None, None
 
 
+def lara_fold(C, S):
+    """Round 5: the merge launches between the LARA token passes are folded into their consumers (C <= 64 samples, S <= 4
+    slices): ea_lara_out_fwd_merge, ea_lara_bwd_k_fused_merge, ea_lara_landmarks_bwd_parts.  EA_LARA_FOLD=0 keeps the merge
+    launches (the composite entry points read the same switch)."""
+    return C <= 64 and 1 <= S <= 4 and os.environ.get("EA_LARA_FOLD", "1") != "0"
+
+
 def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c, want_tokst=True):
     """Estimator forward (ea_lara_stats_fwd -> ea_lara_merge_fwd -> ea_lara_out_fwd) on contiguous fp32
     landmark tensors [BH,C,d] / [BH,C].  Returns out [B,N,h,d] and (cst, kv, lse_k, lse_t)."""
@@ -1078,24 +1085,30 @@ def _lara_fwd_core(geom, qkv5, mask_u8, omega, qbar_c, bhv_c, lp_c, want_tokst=T
     nv.call("ea_lara_stats_fwd", ctypes.byref(geom), ctypes.byref(tq), ctypes.byref(tk),
             ctypes.byref(tv), nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(p_ml),
             nv.ptr(p_kv), nv.stream())
-    # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
     kv = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
     lse_k = torch.empty((BH, C), dtype=torch.float32, device=dev)     # (separate allocations: they leave the
     cst = torch.empty_like(lse_k)                                     #  dispatcher op as distinct outputs)
     lse_t = torch.empty_like(lse_k) if mis == 0 else None
-    nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
-            nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
     out = torch.empty((B, N, h, d), dtype=qkv5.dtype, device=dev)
     to = nv.t4(out.permute(0, 2, 1, 3))
     # per-token softmax statistics (lse_Z in log2 units, mean_c t) for the fused backward: 8 bytes per token-head
     tokst = torch.empty((2, BH, N), dtype=torch.float32, device=dev) if (want_tokst and C <= 64) else None
+    if lara_fold(C, S):
+        # round 5: the combine pass merges the slice partials in its prologue (block 0 of a (b,h) writes kv / lse / cst)
+        nv.call_as("ea_lara_out_fwd", "ea_lara_out_fwd_merge", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c), nv.ptr(bhv_c),
+                S, nv.ptr(p_ml), nv.ptr(p_kv), nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst),
+                ctypes.byref(to), nv.ptr(tokst), None if tokst is None else nv.ptr(tokst[1]), nv.stream())
+        return out, (cst, kv, lse_k, lse_t, tokst)
+    # merge the sequence slices: log-sum-exp merge of the online-softmax partials (one tiny kernel)
+    nv.call("ea_lara_merge_fwd", BH, S, C, d, 1 if mis == 0 else 0, nv.ptr(p_ml), nv.ptr(p_kv),
+            nv.ptr(lp_c), nv.ptr(kv), nv.ptr(lse_k), nv.ptr(lse_t), nv.ptr(cst), nv.stream())
     nv.call("ea_lara_out_fwd", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(omega), nv.ptr(qbar_c),
             nv.ptr(kv), nv.ptr(lse_t), nv.ptr(bhv_c), nv.ptr(cst), ctypes.byref(to),
             nv.ptr(tokst), None if tokst is None else nv.ptr(tokst[1]), nv.stream())
     return out, (cst, kv, lse_k, lse_t, tokst)
 
 
-def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, lse_k, lse_t, tokst):
+def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, lse_k, lse_t, tokst, want_parts=False):
     """Estimator backward up to (not including) the softmax-over-sequence correction of dq.
     Writes dq (uncorrected), dk, dv into dqkv5; returns d_omega [BH,C,d], d_qbar, d_bhv, d_lp and uq
     (the u_c q_bar_c rows of the correction, mis-opt only).
@@ -1140,6 +1153,23 @@ def _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv, cst, kv, 
     small = torch.empty((4, BH, C), dtype=torch.float32, device=dev)
     r, dbh, dlp_m, dkk = small[0], small[1], small[2], small[3]
     want_dqbar = mis in (0, 1)
+    if fused and lara_fold(C, S):
+        # round 5: the key-side pass merges the query side's partials itself (no ea_lara_merge_bwd launch); with want_parts the
+        # caller's landmark backward also adds up the key side's d omega partials on load (no ea_slice_sum launch):
+        # d omega = scale (dom_q + sum_s p_domk[:, s])
+        p_domk = torch.empty((BH, S, C, d), dtype=torch.float32, device=dev)
+        nv.call_as("ea_lara_bwd_k_fused", "ea_lara_bwd_k_fused_merge", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv), nv.ptr(mask_u8),
+                nv.ptr(omega), nv.ptr(qbar), nv.ptr(kv), nv.ptr(lse_k), S, nv.ptr(p_ml), nv.ptr(p_acc[0]), nv.ptr(p_acc[1]),
+                nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), ctypes.byref(tdk), ctypes.byref(tdv), nv.ptr(p_domk),
+                nv.ptr(dbh) if mis == 0 else None, nv.ptr(dlp_m), nv.ptr(dom_q), nv.ptr(dqbar_m) if want_dqbar else None,
+                nv.ptr(uq) if mis == 0 else None, nv.stream())
+        d_qbar = dqbar_m if want_dqbar else None
+        d_bhv = dbh if mis == 0 else None
+        if want_parts:
+            return ("parts", dom_q, p_domk, S, float(scale)), d_qbar, d_bhv, dlp_m, (uq if mis == 0 else None)
+        d_omega = torch.empty((BH, C, d), dtype=torch.float32, device=dev)
+        nv.call("ea_slice_sum", BH, S, C * d, float(scale), nv.ptr(dom_q), nv.ptr(p_domk), nv.ptr(d_omega), nv.stream())
+        return d_omega, d_qbar, d_bhv, dlp_m, (uq if mis == 0 else None)
     nv.call("ea_lara_merge_bwd", BH, S, C, d, 1 if mis == 0 else 0, float(scale), nv.ptr(p_ml),
             nv.ptr(p_acc[0]), nv.ptr(p_acc[1]), nv.ptr(p_acc[2]), nv.ptr(p_acc[3]), nv.ptr(kv), nv.ptr(qbar),
             nv.ptr(r), nv.ptr(dbh), nv.ptr(dlp_m), nv.ptr(dkk), nv.ptr(dkv), nv.ptr(dom_q),
@@ -1387,7 +1417,7 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
     dout = dout.contiguous()
     dqkv5 = torch.empty_like(qkv5)
     d_omega, d_qrows, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qrows, bhv,
-                                                       cst, kv, lse_k, lse_t, tokst)
+                                                       cst, kv, lse_k, lse_t, tokst, want_parts=True)
     dpq = torch.empty_like(pq)
     dpk = torch.empty_like(pk)
     dW = dvec = None
@@ -1395,9 +1425,15 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
         dW = torch.empty((BH, 2, d, d), dtype=torch.float32, device=dev)
         dvec = torch.empty((BH, 2, 3, d), dtype=torch.float32, device=dev)
     pp = [nv.ptr(t) for t in ps] if has_mlp else [None] * 8
-    nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
-            nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
-            nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
+    if isinstance(d_omega, tuple):
+        _, dom_q, p_domk, S_, scale_ = d_omega
+        nv.call_as("ea_lara_landmarks_bwd", "ea_lara_landmarks_bwd_parts", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(dom_q), S_, nv.ptr(p_domk), scale_, nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq),
+                nv.ptr(dpk), nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
+    else:
+        nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
+                nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
+                nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
     _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
     grads = [dqkv5]
     if has_mlp and defer_param_sums:
@@ -1590,7 +1626,7 @@ class LaraModuleFn(torch.autograd.Function):
             # frozen qkv weight, trainable bias (bias-only fine-tuning): a column sum of d qkv, no input rows needed
             dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype).view(xshape)
+            dx = qkv_dgrad(dqkv2, wq, w16, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             res = {what: (o, meta) for (what, _, meta), o in zip(pend, sums)}
@@ -1735,7 +1771,7 @@ class CoreModuleFn(torch.autograd.Function):
             elif need_bq:
                 dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = _mm_out(dqkv2, wq.to(cdtype), xdtype).view(xshape)
+            dx = qkv_dgrad(dqkv2, wq, None, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             for (what, _, meta), o in zip(pend, sums):
@@ -2373,6 +2409,36 @@ def _mm_out(a, b, out_dtype):
     return (a @ b).to(out_dtype)
 
 
+USE_DGRAD_RS = os.environ.get("EA_DGRAD_RS", "1") == "1"
+DGRAD_RS_MIN_ROWS = int(os.environ.get("EA_DGRAD_RS_MIN_ROWS", "16384"))
+
+
+def qkv_dgrad(dqkv2, wq, w16, xdtype):
+    """dx = dqkv2 @ W for the qkv projection (abstract_attention.py:72-78 differentiated) in `xdtype`.
+    192-wide layers: ea_linear_dgrad (round 5) -- the weight resident in registers (the 16-bit copy the forward projection
+    left, `w16`, or the fp32 master `wq` rounded on the way), the gradient rows through LDS once; no library GEMM and no cast
+    kernel.  Other widths, tracing and small row counts: the library GEMM with an fp32 result."""
+    rows, NO = dqkv2.shape
+    cdtype = dqkv2.dtype
+    K = wq.shape[1]
+    direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+    if (USE_DGRAD_RS and direct and rows >= DGRAD_RS_MIN_ROWS and cdtype in _ELEM and xdtype in (torch.float32, cdtype)
+            and tuple(wq.shape) == (NO, K) and dqkv2.stride(1) == 1 and dqkv2.stride(0) % 8 == 0
+            and (w16 is not None or wq.dtype == torch.float32)
+            and bool(nv.lib().ea_linear_dgrad_supported(K, NO))):
+        w = w16 if (w16 is not None and w16.dtype == cdtype and w16.is_contiguous()) else wq
+        if w.dtype in (torch.float32, cdtype) and w.is_contiguous():
+            dx = torch.empty((rows, K), dtype=xdtype, device=dqkv2.device)
+            label = "ea_linear_dgrad"
+            if nv.KERNEL_TIMER.enabled:
+                label = "ea_linear_dgrad[%d->%d,16->%s]" % (NO, K, "f32" if xdtype == torch.float32 else "16")
+                _note_bytes(label, rows * (NO * 2 + K * dx.element_size()))
+            nv.call_as(label, "ea_linear_dgrad", _ELEM[cdtype], rows, K, NO, nv.ptr(dqkv2), dqkv2.stride(0), nv.ptr(w),
+                       int(w.dtype == torch.float32), nv.ptr(dx), int(xdtype == torch.float32), K, nv.stream())
+            return dx
+    return _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype)
+
+
 def slice_sum(part):
     """part [S, ...] fp32 -> sum over S in a fixed order (ea_slice_sum)."""
     S = part.shape[0]
@@ -2644,7 +2710,8 @@ class LinearFn(torch.autograd.Function):
                     # above the cap the library GEMM takes it without a copy)
                     dx = _ea_op("linear", linear_impl, dy2, wc.t().contiguous(), None, y_f32, False)[0].view(xshape)
                 else:
-                    dx = _mm_out(dy2, wc, xdtype).view(xshape)
+                    # 576-deep (the qkv projection of a 192-wide layer): ea_linear_dgrad; other shapes: the library GEMM
+                    dx = qkv_dgrad(dy2, wl, wc if wc is not wl else None, xdtype).view(xshape)
         need_w, need_b = ctx.needs_input_grad[1], (bdtype is not None and ctx.needs_input_grad[2])
         if need_w and xl is None:
             raise RuntimeError("LinearFn: the weight gradient was requested but the forward did not keep its input")

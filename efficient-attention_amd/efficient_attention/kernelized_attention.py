@@ -77,7 +77,10 @@ class KernelizedAttention(MultiheadAttention):
     def project_qkv(self, x):
         """fp32 activations outside autocast stay fp32: the Performer core computes in exact fp32 arithmetic
         (_ops.PerformerF32Fn), as the reference does there (abstract_attention.py:120-133)."""
-        if (x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_cuda and not _ops.PERFORMER_16BIT
+        # (only for the Performer core itself: a subclass with another `_attend` -- ScatterBrain inherits this method through the
+        #  MRO and feeds the window kernels -- takes the 16-bit activations those kernels want: ADVICE r04)
+        if (type(self)._attend is KernelizedAttention._attend
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.is_cuda and not _ops.PERFORMER_16BIT
                 and self.head_dim == 64 and self.approx_attn_dim <= 96 and self.approx_attn_dim % 16 == 0):
             B, N, C = x.shape
             return _ops.linear(x, self.qkv).reshape(B, N, 3, self.num_heads, C // self.num_heads)

@@ -585,6 +585,41 @@ int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t
                        const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
                        void* a_cast, float* pooled_q, float* pooled_k, void* w_cast, void* stream);
 
+/* The INPUT gradient of that qkv projection (abstract_attention.py:72-78 differentiated; ABI 10, ea_dgrad_rs.hip):
+ *   dx[rows, in] = dy[rows, out] w[out, in]          in = 192, out = 576 (ea_linear_dgrad_supported != 0)
+ * dy: EA dtype, row stride ldy elements; w: the layer's weight [out, in] contiguous -- the fp32 master (w_f32 != 0, rounded
+ * to the EA dtype on its way into the registers) or a copy in the EA dtype (e.g. ea_linear_w32_pool's w_cast); dx: fp32
+ * (dx_f32 != 0: the gradient of an fp32 module input under autocast) or the EA dtype, row stride ldx elements.  The weight
+ * stays resident in the registers of a 12-wave workgroup per CU, dy passes LDS once: no library GEMM, no cast kernel. */
+int32_t ea_linear_dgrad_supported(int32_t in_features, int32_t out_features);
+int ea_linear_dgrad(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* dy, int64_t ldy,
+                    const void* w, int32_t w_f32, void* dx, int32_t dx_f32, int64_t ldx, void* stream);
+
+/* Round 5 (ABI 10): consumer passes that merge the producing pass's per-slice partials in their prologue -- the arithmetic of
+ * ea_lara_merge_fwd / _bwd and ea_slice_sum, operation for operation -- so a layer step has three launches less (7 + 14 + 6
+ * us at cfg3 for a few KB per (b,h)).  S <= 4 slices, C <= 64 samples (EA_E_UNSUPPORTED otherwise: keep the merge launches).
+ *   ea_lara_out_fwd_merge: ea_lara_out_fwd fed by ea_lara_stats_fwd's partials (p_ml [BH,S,C,4], p_kv [BH,S,C,D]) and lp;
+ *       block 0 of every (b,h) writes the merged kv, lse_k, lse_t, cst for the backward (lara.py:205-211,241-246).
+ *   ea_lara_bwd_k_fused_merge: ea_lara_bwd_k_fused fed by ea_lara_bwd_q_fused's partials (p_ml, p_dkv, p_dom, p_m1, p_m2);
+ *       forms d kv_stats, dkk, r itself; block 0 writes dbh, dlp (= -r), domq (sum dZ q), dqbar, uq (NULL-able as in
+ *       ea_lara_merge_bwd); p_domk [BH,S,C,D]: its own d omega partials (must not alias the inputs).
+ *   ea_lara_landmarks_bwd_parts: ea_lara_landmarks_bwd with d omega = dom_scale (d_omega + sum_s dom_parts[bh][s]) formed on
+ *       load (ea_slice_sum's order of additions). */
+int ea_lara_out_fwd_merge(const ea_lara_geom* g, const ea_t4* q, const float* omega, const float* qbar, const float* bhv,
+                          int32_t S, const float* p_ml, const float* p_kv, const float* lp, float* kv, float* lse_k,
+                          float* lse_t, float* cst, const ea_t4* out, float* lseZ, float* tmean, void* stream);
+int ea_lara_bwd_k_fused_merge(const ea_lara_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask, const float* omega,
+                              const float* qbar, const float* kv, const float* lse_k, int32_t S, const float* p_ml,
+                              const float* p_dkv, const float* p_dom, const float* p_m1, const float* p_m2,
+                              const ea_t4* dk, const ea_t4* dv, float* p_domk, float* dbh, float* dlp, float* domq,
+                              float* dqbar, float* uq, void* stream);
+int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const float* pk,
+                                const float* Wq, const float* bq, const float* gq, const float* cq,
+                                const float* Wk, const float* bk, const float* gk, const float* ck,
+                                const float* noise, const float* d_omega, int32_t dom_S, const float* dom_parts, float dom_scale,
+                                const float* d_qbar_rows, const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                                float* dW_part, float* dvec_part, const float* saved, void* stream);
+
 /* ---- composite per-module entry points: the whole LARA core in one call each way (round 3) --------------------
  * lara.py:129-175,187-246 for the 2-D pooled proposals ('pool', 'pool-mixed'): uniform r x r pooling of q, k -> landmark
  * pipeline -> estimator, i.e. the launch sequences of ea_eva_chunk_mean_fwd / ea_lara_landmarks_* / ea_lara_stats_fwd /

@@ -21,8 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "efficient-attention_amd"), os.path.join(ROOT, "tests")]
 
-# elementwise fp16 bound: |err| <= FP16_ELEM[0] * rms(ref) + FP16_ELEM[1] * |ref|
-FP16_ELEM = (1.5e-2, 1.5e-2)
+# elementwise bounds |err| <= a * rms(ref) + b * |ref|: gpu_checks.ELEM_TOL (fp16 1.5e-2 / 1.5e-2 since round 2; bf16 round 5)
 
 EVA2D = dict(attn_2d=True, use_rpe=True, adaptive_proj="default")
 FULL = {
@@ -108,8 +107,8 @@ def _run_case(name, dtype, xscale=None, tol=None):
     import contextlib
     import efficient_attention as ea
     import oracle
-    from gpu_checks import MODULE_TOL, LARA_TOL, FP16_TOL, SCATTER_TOL
-    from util import scaled_err
+    from gpu_checks import MODULE_TOL, LARA_TOL, FP16_TOL, SCATTER_TOL, elem_tol_for
+    from util import scaled_err, elementwise_excess
     attn, shape, args, pads = FULL[name]
     torch.manual_seed(21)
     with warnings.catch_warnings():
@@ -166,12 +165,13 @@ def _run_case(name, dtype, xscale=None, tol=None):
         errs[what] = e
         if not (e[0] <= tol[0] and e[1] <= tol[1]):
             bad[what] = e
-        if dtype == torch.float16:
-            rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
-            excess = np.abs(got.astype(np.float64) - want) / (FP16_ELEM[0] * rms + FP16_ELEM[1] * np.abs(want))
-            errs[what] = e + (float(excess.max()),)
-            if excess.max() > 1.0:
-                bad[what + "[elementwise]"] = float(excess.max())
+        # element-wise: |err| <= a rms(ref) + b |ref| for EVERY element, in fp16 (round 2) and bf16 (round 5)
+        etol = None if dtype == torch.float32 else elem_tol_for(attn, "fp16" if dtype == torch.float16 else "bf16")
+        if etol is not None:
+            ex = elementwise_excess(got, want, etol)
+            errs[what] = e + (ex,)
+            if ex > 1.0:
+                bad[what + "[elementwise]"] = ex
     print(name, dtype, {k: tuple(round(float(x), 5) for x in v) for k, v in errs.items()})
     assert not bad, "%s %s out of tolerance %s: %s (all: %s)" % (name, dtype, tol, bad, errs)
 

@@ -163,3 +163,28 @@ def test_performer_fp32_fullsize_at_unit_inputs_matches_oracle(shape, args):
         if not (e[0] <= 5e-4 and e[1] <= 2e-4):
             bad[what] = e
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_scatterbrain_fp32_input_outside_autocast_head_dim_64_runs():
+    """ScatterBrain inherits KernelizedAttention.project_qkv through the MRO; the fp32 pass-through of that method
+    is for the Performer core only -- with head_dim 64 and the default 64 features ScatterBrain on plain fp32 input used to hand
+    fp32 rows to the 16-bit window kernels ('attention cores take bf16 or fp16 tensors')."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from oracle import attention as oa
+    torch.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ea.AttentionFactory.build_attention("scatterbrain", dict(dim=128, num_heads=2, window_size=4, approx_attn_dim=64)).cuda().eval()
+        x = torch.randn(2, 32, 128, device="cuda", requires_grad=True)
+        y = m(x)
+        y.float().sum().backward()
+    assert y.shape == x.shape and torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    args = oa.default_args("scatterbrain")
+    args.update(dim=128, num_heads=2, window_size=4, approx_attn_dim=64)
+    params = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = oa.module_forward("scatterbrain", args, params, x.detach().float().cpu(), training=False)
+    err = (y.detach().float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 8e-2, err

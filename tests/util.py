@@ -124,6 +124,21 @@ def assert_close(got, ref, rtol, atol, what=""):
                                                 got.reshape(-1)[i], ref.reshape(-1)[i], np.abs(ref).max()))
 
 
+def elementwise_excess(got, ref, coef):
+    """max over the elements of |got - ref| / (coef[0] * rms(ref) + coef[1] * |ref|): <= 1 <=> EVERY element obeys
+    |err| <= coef[0] rms(ref) + coef[1] |ref|.  The norm-wise figures of scaled_err() let one wrong small-magnitude channel
+    hide under max|ref|; this one does not (VERDICT r04 weak #1)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    rms = float(np.sqrt((ref * ref).mean()))
+    ex = float((np.abs(got - ref) / np.maximum(coef[0] * rms + coef[1] * np.abs(ref), 1e-300)).max())
+    log = os.environ.get("EA_TEST_ERR_LOG")
+    if log:
+        with open(log + ".elem", "a") as f:
+            f.write("%s\t%.6g\t%.6g\t%.6g\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?"), coef[0], coef[1], ex))
+    return ex
+
+
 def scaled_err(got, ref):
     """max |got-ref| / max|ref| and rms(got-ref)/rms(ref): the two figures the bf16 tolerances
     are stated in."""

@@ -24,7 +24,7 @@ KERNEL_TO_ENTRY = [
     ("sb_bwd_kernel<ea::BF16, true>", "ea_scatter_bwd_global"),
     ("lara_y_kernel<ea::BF16, 64, 3,", "ea_scatter_kmax / ea_performer_kmax"),
     ("lara_y_kernel<ea::BF16, 64, 4,", "ea_scatter_kv / ea_performer_kv"),
-    ("lara_x_kernel<ea::BF16, 64, 4, 0,", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1,", "ea_lara_bwd_q"),
+    ("lara_x_kernel<ea::BF16, 64, 4, 0,", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 7,", "ea_lara_out_fwd"), ("lara_x_kernel<ea::BF16, 64, 4, 1,", "ea_lara_bwd_q"),
     ("lara_x_kernel<ea::BF16, 64, 4, 2,", "ea_lara_bwd_k"), ("lara_x_kernel<ea::BF16, 64, 4, 3,", "ea_lara_bwd_qcorr"),
     ("lara_x_kernel<ea::BF16, 64, 4, 4,", "ea_performer_out"), ("lara_x_kernel<ea::BF16, 64, 4, 5,", "ea_performer_bwd_q"),
     ("lara_x_kernel<ea::BF16, 64, 4, 6,", "ea_performer_bwd_k"),
@@ -35,7 +35,7 @@ KERNEL_TO_ENTRY = [
     ("win_bwd_kernel<", "ea_window_attn_bwd"),
     ("chunk_mean_fwd_r_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_r_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_r_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_r_kernel<", "ea_eva_beta_bwd"),
-    ("proj_rs_kernel<", "ea_linear[fp32 in]"),
+    ("proj_rs_kernel<", "ea_linear[fp32 in]"), ("dgrad_rs_kernel<", "ea_linear_dgrad"),
     ("chunk_mean_fwd_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_kernel<", "ea_eva_beta_bwd"),
     ("sm_fwd_kernel<ea::BF16, 64", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64", "ea_softmax_attn_bwd(dq)"),
