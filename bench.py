@@ -394,21 +394,8 @@ def main():
         # On a single-rank RCCL group the pipelined form costs 0.83 ms against 0.89 ms; with two
         # ranks time-slicing ONE device over gloo (the dev configuration) it was 100x slower, so the
         # choice is not hard-wired.
-        def update_and_pack():
-            bucket.sgd_step(LR)
-            fwd_bwd()
-            bucket.pack()
-
-        def pack():
-            fwd_bwd()
-            bucket.pack()
-
-        def reduce():
-            bucket.all_reduce()
-
-        def apply():
-            bucket.sgd_step(LR)
-        schemes = {"pipelined": [update_and_pack, reduce], "three_part": [pack, reduce, apply]}
+        from efficient_attention.data_parallel import ddp_schedules, select_schedule
+        schemes = ddp_schedules(fwd_bwd, bucket, LR)
         forced = os.environ.get("EA_BENCH_DDP_SCHEME")
         if forced:
             schemes = {forced: schemes[forced]}
@@ -455,27 +442,14 @@ def main():
     if not ddp:
         run_parts, graphed = prepare(parts)
     else:
-        # time a few steps of every schedule (max over ranks, so all ranks take the same decision)
-        best = None
-        for name, fns in schemes.items():
-            rp, gr = prepare(fns)
-            for _ in range(3):
-                for f in rp:
-                    f()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(5):
-                for f in rp:
-                    f()
-            torch.cuda.synchronize()
-            tsel = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        # time a few steps of every schedule (max over ranks, so all ranks take the same decision): the selection itself is
+        # efficient_attention.data_parallel.select_schedule, unit-tested on CPU with a fake clock and with two gloo ranks
+        def _reduce_max(sec):
+            tsel = torch.tensor([sec], dtype=torch.float64, device=dev)
             dist.all_reduce(tsel, op=dist.ReduceOp.MAX)
-            tsel = float(tsel.item())
-            if best is None or tsel < best[0]:
-                best = (tsel, name, rp, gr)
-        _, ddp_scheme, run_parts, graphed = best
+            return float(tsel.item())
+        ddp_scheme, run_parts, graphed, _ = select_schedule(
+            schemes, prepare, torch.cuda.synchronize, _reduce_max, barrier=dist.barrier if world > 1 else None)
 
     def run():
         for f in run_parts:

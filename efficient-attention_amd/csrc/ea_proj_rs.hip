@@ -154,7 +154,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
       const int cols[3] = {pc0 + 8 * g, pc0 + 8 * g + 4, pc0 + 32 + 4 * g};
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const int side = cols[j] >= RS_K, hc = cols[j] - side * RS_K, head = hc >> 6, ch = hc & 63;
+        // (q or k is a property of the WAVE -- waves 0-3 own the q columns, 4-7 the k columns -- so the base pointer stays in
+        //  scalar registers; taken per lane from cols[j] it cost a 64-bit VGPR select and an 8-byte spill at 168 VGPRs)
+        const int side = wave >> 2, hc = cols[j] - side * RS_K, head = hc >> 6, ch = hc & 63;
         float* dst = (side ? p.pk : p.pq) + ((size_t)(img * 3 + head) * p.Lc + cl) * 64 + ch;
         *reinterpret_cast<f32x4*>(dst) = pa[j] + *reinterpret_cast<const f32x4*>(bias_s + cols[j]);
       }

@@ -6,6 +6,8 @@ latency-bound RCCL call beats per-bucket hooks), with the 1/world averaging fold
 optimiser step.  Numerically this is DistributedDataParallel + SGD; unlike the DDP wrapper it adds
 no per-iteration host work, so the forward/backward and the update can stay inside captured
 hipGraphs with the all-reduce as the only eager call between them (bench.py)."""
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -45,3 +47,60 @@ class FlatGradBucket:
         """p -= lr * mean-over-ranks(grad), straight from the bucket."""
         with torch.no_grad():
             torch._foreach_add_(self.params, self.views, alpha=-lr / dist.get_world_size())
+
+
+def ddp_schedules(fwd_bwd, bucket, lr):
+    """The two equivalent schedules of one data-parallel step around a FlatGradBucket (bench.py, N > 1):
+      pipelined : [update from the previous step's bucket + forward/backward + pack] | all-reduce
+      three_part: [forward/backward + pack] | all-reduce | [update]
+    Each is a list of callables; the one named `reduce` is the eager collective, the others may be captured in hipGraphs.
+    With the bucket zero before the first step both hold one update, one forward/backward and one all-reduce per step."""
+    def update_and_pack():
+        bucket.sgd_step(lr)
+        fwd_bwd()
+        bucket.pack()
+
+    def pack():
+        fwd_bwd()
+        bucket.pack()
+
+    def reduce():
+        bucket.all_reduce()
+
+    def apply():
+        bucket.sgd_step(lr)
+    return {"pipelined": [update_and_pack, reduce], "three_part": [pack, reduce, apply]}
+
+
+def select_schedule(schemes, prepare, sync, reduce_max, barrier=None, clock=time.perf_counter, warm=3, timed=5, forced=None):
+    """Pick the faster of several equivalent step schedules by MEASURING them: for each (name, callables) of `schemes`,
+    `prepare(callables)` -> (runnable callables, captured?) (e.g. hipGraph capture of everything but the collective), `warm`
+    untimed steps, [barrier], sync, `timed` steps between two `clock()` readings with a `sync()` before the second, and
+    `reduce_max(seconds)` -> the maximum over all ranks -- every rank therefore sees the same figures and takes the same
+    decision (ties: the first schedule).  `forced` names the schedule to take without timing the others.
+    Returns (name, runnable callables, captured?, {name: seconds per `timed` steps})."""
+    if forced is not None:
+        if forced not in schemes:
+            raise KeyError("unknown schedule %r (have: %s)" % (forced, ", ".join(schemes)))
+        schemes = {forced: schemes[forced]}
+    best, seen = None, {}
+    for name, fns in schemes.items():
+        run, captured = prepare(fns)
+        for _ in range(warm):
+            for f in run:
+                f()
+        if barrier is not None:
+            barrier()
+        sync()
+        t0 = clock()
+        for _ in range(timed):
+            for f in run:
+                f()
+        sync()
+        el = float(reduce_max(clock() - t0))
+        seen[name] = el
+        if best is None or el < best[0]:
+            best = (el, name, run, captured)
+    if best is None:
+        raise ValueError("select_schedule: no schedule given")
+    return best[1], best[2], best[3], seen

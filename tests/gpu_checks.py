@@ -52,8 +52,12 @@ CASE_TOL = {("performer_2d_clamp", "bf16"): (1.4e-1, 7e-2)}
 # the norm-wise bounds above scale by max|ref| and would let a single wrong small-magnitude output channel pass.  fp16 is the
 # round-2 bound of tests/test_gpu_fullsize.py; bf16 operands carry 8x its unit round-off.  Cases whose gradient is
 # DISCONTINUOUS in the operands (the Performer clamp fixture) are exempt (None).
+# Observed on MI355X (round 5, whole suite, EA_TEST_ERR_LOG -> *.elem): worst excess 0.61 of the bf16 bound (eva_2d_overlap_rpe),
+# 0.34 of the fp16 bound; LARA's gradients (three more rounded stages, see the module docstring) reach 0.098 rms + 0.098 |ref|
+# in bf16 and 0.015 / 0.015 in fp16 (lara_2d_dense_antithetic), ScatterBrain 0.068 / 0.014: their bounds are ~1.5x those.
 ELEM_TOL = {"fp16": (1.5e-2, 1.5e-2), "bf16": (8e-2, 8e-2)}
-ELEM_TOL_VARIANT = {("lara", "bf16"): (1e-1, 1e-1), ("scatterbrain", "bf16"): (1.6e-1, 1.6e-1)}
+ELEM_TOL_VARIANT = {("lara", "bf16"): (1.5e-1, 1.5e-1), ("lara", "fp16"): (2.5e-2, 2.5e-2),
+                    ("scatterbrain", "bf16"): (1.2e-1, 1.2e-1), ("scatterbrain", "fp16"): (2.5e-2, 2.5e-2)}
 ELEM_EXEMPT = {("performer_2d_clamp", "bf16")}
 
 

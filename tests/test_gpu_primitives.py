@@ -191,6 +191,50 @@ def test_linear_matches_fp64(rows, K, NO, a_f32, y_f32, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("rows,w_f32,dx_f32,wide", [(100352, 0, 1, 0), (100352, 1, 1, 0), (25088, 0, 0, 0), (1000, 1, 0, 1),
+                                                      (33, 0, 1, 1), (1, 1, 1, 0)])
+def test_linear_dgrad_matches_fp64(rows, w_f32, dx_f32, wide, dtype):
+    """ea_linear_dgrad (round 5: the qkv projection's input gradient dx = dqkv W, 576 -> 192, weight resident in registers;
+    abstract_attention.py:72-78 differentiated) against fp64 on the same rounded operands: fp32 accumulation of exact
+    products (one rounding when the result is 16-bit), from the fp32 master weight (rounded like .to(dtype)) or its 16-bit copy,
+    on contiguous and strided gradient rows, bit-reproducible; _ops.qkv_dgrad falls back to the library outside 576 x 192."""
+    import torch
+    from efficient_attention import _ops, _native as nv
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(rows + 7 * w_f32 + dx_f32)
+    buf = (0.5 * torch.randn(rows, 576 + (64 if wide else 0), device="cuda", generator=g)).to(td)
+    dy = buf[:, :576]
+    w = torch.randn(576, 192, device="cuda", generator=g) * 0.05
+    w16 = w.to(td)
+    xd = torch.float32 if dx_f32 else td
+    assert nv.lib().ea_linear_dgrad_supported(192, 576) and not nv.lib().ea_linear_dgrad_supported(512, 1536)
+    old = _ops.DGRAD_RS_MIN_ROWS
+    _ops.DGRAD_RS_MIN_ROWS = 1
+    try:
+        calls = []
+        real = nv.call_as
+        nv.call_as = lambda label, name, *a: (calls.append(name), real(label, name, *a))[1]
+        try:
+            dx = _ops.qkv_dgrad(dy, w, None if w_f32 else w16, xd)
+            dx2 = _ops.qkv_dgrad(dy, w, None if w_f32 else w16, xd)
+        finally:
+            nv.call_as = real
+        assert calls == ["ea_linear_dgrad"] * 2, calls
+    finally:
+        _ops.DGRAD_RS_MIN_ROWS = old
+    assert dx.dtype == xd and tuple(dx.shape) == (rows, 192) and torch.equal(dx, dx2)
+    ref = dy.double() @ w16.double()
+    mag = dy.double().abs() @ w16.double().abs()
+    tol = 4e-6 * mag + (0 if dx_f32 else 1) * (2.0 ** (-8 if dtype == "bf16" else -11)) * ref.abs() + 1e-6
+    assert bool(((dx.double() - ref).abs() <= tol).all()), float((dx.double() - ref).abs().max())
+    # another width: the library GEMM takes it (no HIP entry for it), same contract
+    w2 = torch.randn(576, 128, device="cuda", generator=g) * 0.05
+    dx3 = _ops.qkv_dgrad(dy, w2, None, torch.float32)
+    assert torch.allclose(dx3.double(), dy.double() @ w2.to(td).double(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("rows,K,NO,a_f32,y_f32,transposed", [
     (100352, 192, 576, 1, 0, 0), (100352, 192, 192, 0, 0, 0), (100352, 192, 192, 0, 1, 1), (1001, 64, 128, 1, 1, 0),
     (50017, 128, 384, 0, 0, 1), (30001, 256, 256, 1, 1, 1), (77, 192, 576, 1, 0, 0), (4097, 256, 512, 0, 0, 1)])
