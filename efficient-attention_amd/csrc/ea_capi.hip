@@ -33,6 +33,9 @@ int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r);
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
                      long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast);
 int dgrad_rs_supported(int K, int NO);
+int dgrad_fin_launch(int dtype, const void* dqkv, long ldy, const void* qkv, long ldq, const void* w, int w_f32, void* dx, int dx_f32,
+                     long ldx, int B, int gh, int gw, int pool_r, int C, float scale, const float* qbar, const float* uq,
+                     const float* lse_t, const float* dpq, const float* dpk, hipStream_t st);
 int dgrad_rs_dispatch(int dtype, const void* dy, const void* w, int w_f32, void* dx, int dx_f32, int rows, long ldy, long ldx,
                       hipStream_t st);
 int linear_dispatch(int dtype, const void* a, int a_f32, const void* w, int w_mode, const float* bias, void* y, int y_f32,
@@ -1280,6 +1283,24 @@ int ea_linear_dgrad(int32_t dtype, int32_t rows, int32_t in_features, int32_t ou
   return dgrad_rs_dispatch(dtype, dy, w, w_f32, dx, dx_f32, rows, (long)ldy, (long)ldx, (hipStream_t)stream);
 }
 
+// the same product fused with the last corrections of dq / dk (ea_dgrad_rs.hip, dgrad_fin_kernel)
+int ea_linear_dgrad_finish(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t pool_r, int32_t C, float scale,
+                           void* dqkv, int64_t ldy, const void* qkv, int64_t ldq, const void* w, int32_t w_f32, void* dx,
+                           int32_t dx_f32, int64_t ldx, const float* qbar, const float* uq, const float* lse_t,
+                           const float* dpq, const float* dpk, void* stream) {
+  if (!dqkv || !w || !dx || ((uintptr_t)dqkv & 15) || ((uintptr_t)w & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)qkv & 15))
+    return EA_E_BADARG;
+  if (B <= 0 || gh <= 0 || gw <= 0 || ldy < 576 || ldx < 192 || (ldy & 7) || (ldx & 3) || (!dx_f32 && (ldx & 7))) return EA_E_BADARG;
+  if ((dpq == nullptr) != (dpk == nullptr)) return EA_E_BADARG;
+  if (dpq && (pool_r <= 0 || gh % pool_r || gw % pool_r)) return EA_E_BADARG;
+  if (uq && (!qkv || !qbar || !lse_t || ldq < 192 || (ldq & 7) || C <= 0)) return EA_E_BADARG;
+  if (uq && C > 64) return EA_E_UNSUPPORTED;
+  if (!uq && !dpq) return EA_E_BADARG;                        // nothing to correct: ea_linear_dgrad
+  if ((int64_t)B * gh * gw >= ((int64_t)1 << 31)) return EA_E_BADARG;
+  return dgrad_fin_launch(dtype, dqkv, (long)ldy, qkv, (long)ldq, w, w_f32, dx, dx_f32, (long)ldx, B, gh, gw, pool_r, C, scale,
+                          qbar, uq, lse_t, dpq, dpk, (hipStream_t)stream);
+}
+
 // qkv projection + pooled q / k rows in one pass (ea_proj_rs.hip, POOL variants)
 int32_t ea_linear_pool_supported(int32_t in_features, int32_t out_features, int32_t B, int32_t gh, int32_t gw, int32_t r) {
   return proj_rs_pool_supported(in_features, out_features, B, gh, gw, r);
@@ -1503,6 +1524,13 @@ int64_t ea_lara_layer_ws(const ea_lara_layer* c, int32_t which) {
     case 4: return (int64_t)P.o_pk;
     case 5: return (int64_t)P.b_dW;
     case 6: return (int64_t)P.b_dvec;
+    // round 5 (ea_lara_layer_bwd2 with EA_LARA_DEFER_FINISH): what ea_linear_dgrad_finish needs -- in the backward scratch
+    // u qbar rows (7), d(pooled q) (8), d(pooled k) (9); in `saved` the qbar rows (10) and lse_t (11)
+    case 7: return (int64_t)(P.b_big + 3 * (size_t)P.BH * P.C * c->D);
+    case 8: return (int64_t)P.b_dpq;
+    case 9: return (int64_t)P.b_dpk;
+    case 10: return (int64_t)P.o_qrows;
+    case 11: return (int64_t)P.o_lset;
     default: return EA_E_BADARG;
   }
 }
@@ -1547,6 +1575,13 @@ int ea_lara_layer_fwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
 int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                       const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
                       const ea_t4* dv, const float* saved, float* tmp, float* dparams, void* stream) {
+  return ea_lara_layer_bwd2(c, q, k, v, mask, noise, params, dout, dq, dk, dv, saved, tmp, dparams, 0, stream);
+}
+
+int ea_lara_layer_bwd2(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                       const ea_t4* dv, const float* saved, float* tmp, float* dparams, int32_t flags, void* stream) {
+  const bool defer_finish = (flags & EA_LARA_DEFER_FINISH) != 0;
   LaraLayerPlan P;
   int rc = lara_layer_plan(c, P);
   if (rc != EA_OK) return rc;
@@ -1586,8 +1621,10 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
                                      noise, dom_q, P.S_bwd, domk, c->scale, want_dqbar ? dqbar_m : nullptr, opt ? dbh : nullptr,
                                      dlp_m, dpq, dpk, dW, dvec, saved + P.o_lmk, stream);
     if (rc != EA_OK) return rc;
-    rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
-    if (rc != EA_OK) return rc;
+    if (!defer_finish) {
+      rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
+      if (rc != EA_OK) return rc;
+    }
     if (c->has_mlp && dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
     return rc;
   }
@@ -1606,8 +1643,10 @@ int ea_lara_layer_bwd(const ea_lara_layer* c, const ea_t4* q, const ea_t4* k, co
                              d_omega, want_dqbar ? dqbar_m : nullptr, opt ? dbh : nullptr, dlp_m, dpq, dpk, dW, dvec,
                              saved + P.o_lmk, stream);
   if (rc != EA_OK) return rc;
-  rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
-  if (rc != EA_OK) return rc;
+  if (!defer_finish) {
+    rc = ea_lara_bwd_finish(&P.g, q, qrows, opt ? uq : nullptr, lse_t, dpq, dpk, c->pool_r, c->gh, c->gw, dq, dk, stream);
+    if (rc != EA_OK) return rc;
+  }
   // dparams == NULL: the caller adds the per-(b,h) partials up itself (tmp + ea_lara_layer_ws(cfg, 5 / 6): [B*H, 2 D D] and
   // [B*H, 6 D]), e.g. together with other terminal sums of its backward in one ea_multi_sum launch
   if (c->has_mlp && dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
@@ -1690,6 +1729,9 @@ int64_t ea_eva_layer_ws(const ea_eva_layer* c, int32_t which) {
     case 8: return (int64_t)P.o_lse;
     case 9: return (int64_t)P.b_dbp;
     case 10: return (int64_t)P.bparts * c->B;
+    // round 5 (ea_eva_layer_bwd2 with EA_EVA_DEFER_CHUNK_MEAN): the chunk-mean gradients ea_linear_dgrad_finish adds to dq / dk
+    case 11: return (int64_t)P.b_dqm;
+    case 12: return (int64_t)P.b_dkm;
     default: return EA_E_BADARG;
   }
 }
@@ -1719,6 +1761,13 @@ int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, cons
                      const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
                      const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
                      void* stream) {
+  return ea_eva_layer_bwd2(c, q, k, v, bias, noise, params, out, dout, dq, dk, dv, saved, tmp, dbias, dparams, 0, stream);
+}
+
+int ea_eva_layer_bwd2(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                      const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
+                      const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
+                      int32_t flags, void* stream) {
   EvaLayerPlan P;
   int rc = eva_layer_plan(c, P);
   if (rc != EA_OK) return rc;
@@ -1745,8 +1794,10 @@ int ea_eva_layer_bwd(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, cons
   rc = ea_lara_landmarks_bwd(&P.lg, qm, km, params[0], params[1], params[2], params[3], params[4], params[5], params[6],
                              params[7], noise, d_omega, dl, nullptr, nullptr, dqm, dkm, dW, dvec, saved + P.o_lmk, stream);
   if (rc != EA_OK) return rc;
-  rc = ea_eva_chunk_mean_bwd(&P.g, dqm, dkm, nullptr, dq, dk, stream);
-  if (rc != EA_OK) return rc;
+  if (!(flags & EA_EVA_DEFER_CHUNK_MEAN)) {
+    rc = ea_eva_chunk_mean_bwd(&P.g, dqm, dkm, nullptr, dq, dk, stream);
+    if (rc != EA_OK) return rc;
+  }
   // dparams == NULL: the per-(b,h) partials stay in tmp (offsets ea_eva_layer_ws(cfg, 5 / 6)) for the caller's own reduction
   if (dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
   return rc;

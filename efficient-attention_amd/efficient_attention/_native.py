@@ -135,6 +135,7 @@ SIGNATURES = {
     "ea_linear_pool_supported": [_I] * 6,
     "ea_linear_dgrad_supported": [_I, _I],
     "ea_linear_dgrad": [_I, _I, _I, _I, _P, _L, _P, _I, _P, _I, _L, _P],
+    "ea_linear_dgrad_finish": [_I, _I, _I, _I, _I, _I, _F, _P, _L, _P, _L, _P, _I, _P, _I, _L, _P, _P, _P, _P, _P, _P],
     "ea_linear_w32_pool": [_I] * 7 + [_P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P],
     "ea_wgrad_parts": [_I, _I, _I],
     "ea_wgrad": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P],
@@ -148,9 +149,11 @@ SIGNATURES = {
     "ea_lara_layer_ws": [_LL, _I],
     "ea_lara_layer_fwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _P, _P, _I, _P],
     "ea_lara_layer_bwd": [_LL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _P, _P, _P, _P],
+    "ea_lara_layer_bwd2": [_LL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _P, _P, _P, _I, _P],
     "ea_eva_layer_ws": [_EL, _I],
     "ea_eva_layer_fwd": [_EL, _T, _T, _T, _P, _P, _P, _T, _P, _I, _P],
     "ea_eva_layer_bwd": [_EL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P],
+    "ea_eva_layer_bwd2": [_EL, _T, _T, _T, _P, _P, _P, _T, _T, _T, _T, _T, _P, _P, _P, _P, _I, _P],
     "ea_scatter_parts": [_SG],
     "ea_scatter_kmax": [_SG, _T, _P, _P, _P, _P],
     "ea_scatter_kv": [_SG, _T, _T, _P, _P, _P, _P, _P, _P],

@@ -397,7 +397,7 @@ def _eva_layer_cfg_dims(B, h, d, io, icfg, fcfg, adaptive_proj, has_bias, masked
     hit = _EVA_LAYER_CFG.get(key)
     if hit is None:
         cfg = nv.ea_eva_layer(B, h, d, io, s0, s1, window, chunk, int(has_bias), float(d) ** -0.5)
-        sizes = [int(nv.lib().ea_eva_layer_ws(ctypes.byref(cfg), w)) for w in (0, 2, 3, 4, 5, 6, 9, 10)]
+        sizes = [int(nv.lib().ea_eva_layer_ws(ctypes.byref(cfg), w)) for w in (0, 2, 3, 4, 5, 6, 9, 10, 11, 12)]   # 8, 9: d(chunk means)
         hit = (cfg, sizes) if min(sizes) >= 0 else (None, None)
         if len(_EVA_LAYER_CFG) < 256:
             _EVA_LAYER_CFG[key] = hit
@@ -494,7 +494,7 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
 
 
 def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, adaptive_proj, bias_cols, mlp_params,
-                 defer_param_sums=False):
+                 defer_param_sums=False, defer_chunk_mean=False):
     """torch.ops.ea.eva_bwd -> [dqkv, dbias | empty, *parameter gradients (fp32, in the order of mlp_params)]."""
     if len(saved_list) == 2:
         # the forward went through ea_eva_layer_fwd: (bias_padded | empty, saved workspace)
@@ -516,12 +516,20 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
         defer_bias = bool(defer_param_sums and bias_p is not None)
         dbias = None if (bias_p is None or defer_bias) else torch.empty_like(bias_p)
         dpar = None if defer_param_sums else torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev)
-        nv.call("ea_eva_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+        # defer_chunk_mean (direct calls only, round 5): the chunk-mean backward is left to ea_linear_dgrad_finish, which adds
+        # d(chunk mean) / r^2 to dq, dk on its way through the gradient rows (the last element of the result says where they are)
+        nv.call("ea_eva_layer_bwd2", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
                 nv.ptr(bias_p), nv.ptr(noise_c), _param_ptrs(ps), ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
-                ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dbias), nv.ptr(dpar), nv.stream())
+                ctypes.byref(ts[6]), ctypes.byref(ts[7]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dbias), nv.ptr(dpar),
+                1 if defer_chunk_mean else 0, nv.stream())
         if dbias is not None:
             dbias = dbias[..., :bias_cols].contiguous()
         BH = B * h
+        fin_ = []
+        if defer_chunk_mean:
+            Lc = (lcfg.gh // lcfg.chunk) * (lcfg.gw // lcfg.chunk)
+            fin_ = [("finish", dict(B=B, gh=lcfg.gh, gw=lcfg.gw, r=lcfg.chunk, C=Lc, scale=float(lcfg.scale), uq=None, qbar=None,
+                                    lse_t=None, dpq=tmp[sizes[8]:sizes[8] + BH * Lc * d], dpk=tmp[sizes[9]:sizes[9] + BH * Lc * d]))]
         if defer_param_sums:
             o_dW, o_dvec = sizes[4], sizes[5]
             extra = ()
@@ -529,9 +537,11 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
                 o_db, rows_db, n_db = sizes[6], sizes[7], bias_p.numel()
                 extra = (tmp[o_db:o_db + rows_db * n_db].view(rows_db, n_db), tuple(bias_p.shape))
             return [dqkv5, _e(dbias, ws), ("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
-                                          tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d)) + extra]
+                                          tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d)) + extra] + fin_
         dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
-        return [dqkv5, _e(dbias, ws), dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+        return [dqkv5, _e(dbias, ws), dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]] + fin_
+    if defer_chunk_mean:
+        raise RuntimeError("eva_bwd: defer_chunk_mean needs the composite entry points")
     geom, L, mu_scale, keep_scale, fused_mu = _eva_cfg(qkv5, icfg, fcfg, adaptive_proj)
     bias_p, lse, qmean, kmean, omega, beta, rf_k_bar, saved, zhat, rstd = [_opt(t) for t in saved_list]
     noise_c = None if noise is None else noise.float().contiguous()
@@ -743,9 +753,15 @@ class EvaModuleFn(torch.autograd.Function):
         elif need_bp and not pair:
             dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
+        # round 5: with the composite workspace saved and the input gradient wanted, the chunk-mean backward is left to the
+        # input-gradient kernel (ea_linear_dgrad_finish adds the d(chunk mean) / r^2 terms on its way: one pass instead of two)
+        use_fin = bool(need[0] and len(saved) == 2 and dgrad_finish_usable(qkv5.view(-1, 3 * C), wq, xdtype, heads, d))
         g = eva_bwd_impl(d_o2.view(B, N, heads, d), qkv5, mask_u8, None, noise, o2.view(B, N, heads, d), list(saved), ctx.icfg,
-                         ctx.fcfg, ctx.adaptive, bias_cols, list(params), defer_param_sums=defer)
+                         ctx.fcfg, ctx.adaptive, bias_cols, list(params), defer_param_sums=defer, defer_chunk_mean=use_fin)
+        fin = g.pop()[1] if use_fin else None
         dqkv2 = g[0].view(-1, 3 * C)
+        if fin is not None:
+            dx = qkv_dgrad_finish(dqkv2, None, wq, w16, xdtype, fin).view(xshape)    # (corrects dq / dk in place: before the weight gradient)
         dbias = _opt(g[1])
         pgrads = list(g[2:])
         if pgrads and isinstance(pgrads[0], tuple):
@@ -769,7 +785,7 @@ class EvaModuleFn(torch.autograd.Function):
                 dwq, dbq = r_[0].to(wqd), (r_[1].to(bqd) if need_bq else None)
         elif need_bq:
             dbq = bias_grad(dqkv2).to(bqd)
-        if need[0]:
+        if need[0] and dx is None:
             dx = qkv_dgrad(dqkv2, wq, w16, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
@@ -1291,7 +1307,7 @@ def _lara_layer_cfg_dims(B, h, d, io, icfg, fcfg):
         H, W, r, has_mlp, mixed, mis, dup = key[4:11]
         kappa, scale = key[11:13]
         cfg = nv.ea_lara_layer(B, h, d, io, H, W, r, has_mlp, mixed, mis, dup, kappa, scale)
-        sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in (0, 1, 2, 3, 4, 5, 6)]
+        sizes = [int(nv.lib().ea_lara_layer_ws(ctypes.byref(cfg), w)) for w in range(12)]   # 7-11: operands of the deferred finish
         hit = (cfg, sizes) if min(sizes) >= 0 else (None, None)
         if len(_LARA_LAYER_CFG) < 256:
             _LARA_LAYER_CFG[key] = hit
@@ -1373,7 +1389,7 @@ def lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, params, pooled=None):
     return [out, omega, _e(qrows, e), _e(bhv, e), cst, kv, lse_k, _e(lse_t, e), pq, pk, _e(saved, e), _e(tokst, e)]
 
 
-def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, defer_param_sums=False):
+def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, defer_param_sums=False, defer_finish=False):
     """torch.ops.ea.lara_bwd -> [dqkv, *parameter gradients (fp32, in the order of params)].  saved_list is what lara_fwd
     returned after `out`: the composite workspace (one tensor -> ea_lara_layer_bwd) or the step-by-step tensors."""
     if len(saved_list) == 1:
@@ -1394,21 +1410,36 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
         pp = _param_ptrs(ps) if ps else None
         defer = bool(defer_param_sums and ps)
         dpar = torch.empty(2 * d * d + 6 * d, dtype=torch.float32, device=dev) if (ps and not defer) else None
-        nv.call("ea_lara_layer_bwd", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
+        # defer_finish (direct calls only, round 5): the finish pass is left to ea_linear_dgrad_finish, which applies the
+        # softmax-over-sequence correction of dq and the pooling terms of dq / dk on its way through the gradient rows
+        nv.call("ea_lara_layer_bwd2", ctypes.byref(lcfg), ctypes.byref(ts[0]), ctypes.byref(ts[1]), ctypes.byref(ts[2]),
                 nv.ptr(mask_u8), nv.ptr(noise_c), pp, ctypes.byref(ts[3]), ctypes.byref(ts[4]), ctypes.byref(ts[5]),
-                ctypes.byref(ts[6]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dpar), nv.stream())
+                ctypes.byref(ts[6]), nv.ptr(ws), nv.ptr(tmp), nv.ptr(dpar), 1 if defer_finish else 0, nv.stream())
         grads = [dqkv5]
+        if defer_finish:
+            BH, L = B * h, (lcfg.gh // lcfg.pool_r) * (lcfg.gw // lcfg.pool_r)
+            C = L * (2 if lcfg.dup else 1)
+            opt = lcfg.mis == 0
+            fin = dict(B=B, gh=lcfg.gh, gw=lcfg.gw, r=lcfg.pool_r, C=C, scale=float(lcfg.scale),
+                       uq=tmp[sizes[7]:sizes[7] + BH * C * d] if opt else None,
+                       dpq=tmp[sizes[8]:sizes[8] + BH * L * d], dpk=tmp[sizes[9]:sizes[9] + BH * L * d],
+                       qbar=ws[sizes[10]:sizes[10] + BH * C * d] if opt else None,
+                       lse_t=ws[sizes[11]:sizes[11] + BH * C] if opt else None)
+            grads.append(("finish", fin))
         if defer:
             # (direct calls only) the per-(b,h) partials, still to be added up: [B*h, 2 d d], [B*h, 6 d]
             o_dW, o_dvec = sizes[5], sizes[6]
             BH = B * h
-            return grads + [("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
-                             tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))]
+            return grads[:1] + [("partials", tmp[o_dW:o_dW + BH * 2 * d * d].view(BH, 2 * d * d),
+                                 tmp[o_dvec:o_dvec + BH * 6 * d].view(BH, 6 * d))] + grads[1:]
         if ps:
             dWs, dvs = dpar[:2 * d * d].view(2, d, d), dpar[2 * d * d:].view(2, 3, d)
-            grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
+            fin_ = grads[1:]
+            grads = grads[:1] + [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]] + fin_
         return grads
     (H, W, r, has_mlp, mixed, mis, dup, L, C), pgeom, lg, geom = _lara_cfg(qkv5, icfg, fcfg)
+    if defer_finish and C > 64:
+        raise RuntimeError("lara_bwd: defer_finish needs C <= 64 samples")
     omega, qrows, bhv, cst, kv, lse_k, lse_t, pq, pk, saved, tokst = [_opt(t) for t in saved_list]
     noise_c = None if noise is None else noise.float().contiguous()
     B, N, _, h, d = qkv5.shape
@@ -1434,15 +1465,20 @@ def lara_bwd_impl(dout, qkv5, mask_u8, noise, saved_list, icfg, fcfg, params, de
         nv.call("ea_lara_landmarks_bwd", ctypes.byref(lg), nv.ptr(pq), nv.ptr(pk), *pp, nv.ptr(noise_c),
                 nv.ptr(d_omega), nv.ptr(d_qrows), nv.ptr(d_bhv), nv.ptr(d_lp), nv.ptr(dpq), nv.ptr(dpk),
                 nv.ptr(dW), nv.ptr(dvec), nv.ptr(saved), nv.stream())
-    _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
+    fin_ = []
+    if defer_finish:
+        fin_ = [("finish", dict(B=B, gh=H, gw=W, r=r, C=C, scale=float(fcfg[1]), uq=uq, dpq=dpq, dpk=dpk,
+                                qbar=qrows if uq is not None else None, lse_t=lse_t if uq is not None else None))]
+    else:
+        _lara_finish(geom, qkv5, dqkv5, qrows, uq, lse_t, dpq, dpk, (r, H, W))
     grads = [dqkv5]
     if has_mlp and defer_param_sums:
-        return grads + [("partials", dW.view(BH, -1), dvec.view(BH, -1))]
+        return grads + [("partials", dW.view(BH, -1), dvec.view(BH, -1))] + fin_
     if has_mlp:
         dWs, dvs = colsum2_f32(dW.view(BH, -1), dvec.view(BH, -1))
         dWs, dvs = dWs.view(2, d, d), dvs.view(2, 3, d)
         grads += [dWs[0], dvs[0, 0], dvs[0, 1], dvs[0, 2], dWs[1], dvs[1, 0], dvs[1, 1], dvs[1, 2]]
-    return grads
+    return grads + fin_
 
 
 class LaraPooledFn(torch.autograd.Function):
@@ -1595,9 +1631,16 @@ class LaraModuleFn(torch.autograd.Function):
         elif need_bp and not pair:
             dbp = bias_grad(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(bpd)
         B, N = qkv5.shape[:2]
+        fin = None
         if defer:
+            # round 5: with a single composite workspace saved and the input gradient wanted, the finish pass of the core is
+            # left to the input-gradient kernel (ea_linear_dgrad_finish: one pass over the gradient rows instead of two)
+            use_fin = bool(need[0] and ctx.icfg[6] == 0 and dgrad_finish_usable(qkv5.view(-1, 3 * C), wq, xdtype, heads, C // heads)
+                           and (ctx.icfg[0] // ctx.icfg[2]) * (ctx.icfg[1] // ctx.icfg[2]) <= 64)
             grads = lara_bwd_impl(d_o2.view(B, N, heads, C // heads), qkv5, mask_u8, noise, list(saved), ctx.icfg, ctx.fcfg,
-                                  list(params), defer_param_sums=True)
+                                  list(params), defer_param_sums=True, defer_finish=use_fin)
+            if use_fin:
+                fin = grads.pop()[1]
             if grads[1:] and isinstance(grads[1], tuple):
                 pend.append(("lmk_W", grads[1][1], None))
                 pend.append(("lmk_v", grads[1][2], None))
@@ -1608,6 +1651,9 @@ class LaraModuleFn(torch.autograd.Function):
         dqkv2 = grads[0].view(-1, 3 * C)
         dwq = dbq = dx = None
         need_bq = bqd is not None and need[2]
+        if fin is not None:
+            # corrects the dq / dk columns of dqkv2 in place: BEFORE the weight gradient reads them
+            dx = qkv_dgrad_finish(dqkv2, qkv5.view(-1, 3 * C), wq, w16, xdtype, fin).view(xshape)
         if pair:
             rq, rp = wgrad_pair(dqkv2, xl, need_bq, dy2, o2, need_bp)
             pend.append(("qkv", rq[0], rq[1]))
@@ -1625,7 +1671,7 @@ class LaraModuleFn(torch.autograd.Function):
         elif need_bq:
             # frozen qkv weight, trainable bias (bias-only fine-tuning): a column sum of d qkv, no input rows needed
             dbq = bias_grad(dqkv2).to(bqd)
-        if need[0]:
+        if need[0] and dx is None:
             dx = qkv_dgrad(dqkv2, wq, w16, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
@@ -2437,6 +2483,39 @@ def qkv_dgrad(dqkv2, wq, w16, xdtype):
                        int(w.dtype == torch.float32), nv.ptr(dx), int(xdtype == torch.float32), K, nv.stream())
             return dx
     return _mm_out(dqkv2, w16 if w16 is not None else wq.to(cdtype), xdtype)
+
+
+USE_DGRAD_FIN = os.environ.get("EA_DGRAD_FIN", "1") == "1"
+
+
+def dgrad_finish_usable(dqkv2, wq, xdtype, heads, d):
+    """ea_linear_dgrad_finish: 192-wide, three heads of 64 channels, contiguous 576-column gradient rows."""
+    direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+    return (USE_DGRAD_FIN and USE_DGRAD_RS and direct and heads == 3 and d == 64 and dqkv2.dtype in _ELEM
+            and xdtype in (torch.float32, dqkv2.dtype) and tuple(wq.shape) == (576, 192) and dqkv2.is_contiguous()
+            and dqkv2.shape[0] >= DGRAD_RS_MIN_ROWS)
+
+
+def qkv_dgrad_finish(dqkv2, qkv2, wq, w16, xdtype, fin):
+    """dx = dqkv2 @ W after the LAST corrections of the dq / dk columns of dqkv2 (in place) -- ea_linear_dgrad_finish, one pass:
+    LARA: fin = dict(B, gh, gw, r, C, scale, qbar, uq, lse_t, dpq, dpk) from lara_bwd_impl(defer_finish=True) (lara.py:223,
+    43,48,145-151 differentiated); EVA: uq = qbar = lse_t = None, dpq / dpk = the chunk-mean gradients (eva.py:178-181)."""
+    rows = dqkv2.shape[0]
+    cdtype = dqkv2.dtype
+    w = w16 if (w16 is not None and w16.dtype == cdtype and w16.is_contiguous()) else wq
+    if not (w.dtype in (torch.float32, cdtype) and w.is_contiguous()):
+        w = wq.to(cdtype).contiguous()
+    dx = torch.empty((rows, 192), dtype=xdtype, device=dqkv2.device)
+    label = "ea_linear_dgrad_finish"
+    if nv.KERNEL_TIMER.enabled:
+        label = "ea_linear_dgrad_finish[576->192,16->%s%s]" % ("f32" if xdtype == torch.float32 else "16", ",+t" if fin.get("uq") is not None else "")
+        # dqkv read + dq, dk rewritten, dx written, q read for the t correction
+        _note_bytes(label, rows * (576 * 2 + 384 * 2 + 192 * dx.element_size() + (192 * 2 if fin.get("uq") is not None else 0)))
+    nv.call_as(label, "ea_linear_dgrad_finish", _ELEM[cdtype], fin["B"], fin["gh"], fin["gw"], fin["r"], fin["C"], fin["scale"],
+               nv.ptr(dqkv2), dqkv2.stride(0), nv.ptr(qkv2), 0 if qkv2 is None else qkv2.stride(0), nv.ptr(w),
+               int(w.dtype == torch.float32), nv.ptr(dx), int(xdtype == torch.float32), 192, nv.ptr(fin.get("qbar")),
+               nv.ptr(fin.get("uq")), nv.ptr(fin.get("lse_t")), nv.ptr(fin.get("dpq")), nv.ptr(fin.get("dpk")), nv.stream())
+    return dx
 
 
 def slice_sum(part):

@@ -37,6 +37,12 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
         self._slot_cache = {}
         self.apply(self._init_weights)
 
+    def project_qkv(self, x):
+        """The window kernels take 16-bit rows: the fp32 pass-through of KernelizedAttention.project_qkv (for the exact-fp32
+        Performer core) must not reach them through the MRO (plain fp32 input, head_dim 64, 64 features crashed)."""
+        from .abstract_attention import MultiheadAttention
+        return MultiheadAttention.project_qkv(self, x)
+
     def _key_slots(self, seq_shape, device):
         """[G, Wk] token index of every slot of every extended key window, N (one past the end) for the slots that
         leave the sequence (attn_utils.py:155-166 / 190-210 as an index table)."""

@@ -595,6 +595,20 @@ int32_t ea_linear_dgrad_supported(int32_t in_features, int32_t out_features);
 int ea_linear_dgrad(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_features, const void* dy, int64_t ldy,
                     const void* w, int32_t w_f32, void* dx, int32_t dx_f32, int64_t ldx, void* stream);
 
+/* ... and the same product FUSED with the last corrections of dq / dk of a 192-wide, three-head layer (ABI 10): one pass over
+ * the gradient rows instead of ea_lara_bwd_finish (or ea_eva_chunk_mean_bwd) followed by the product:
+ *     dq_n -= s sum_c t[c,n] (u_c qbar_c)     (uq != NULL; lara.py:223 differentiated; qbar, uq [B*3, C, 64], lse_t [B*3, C], C <= 64;
+ *                                              qkv: the forward's [B*gh*gw, 576] rows, q = columns 0 .. 191)
+ *     dq_n += dpq[cell(n)] / r^2,  dk_n += dpk[cell(n)] / r^2   (dpq != NULL: fp32 [B*3, (gh/r)(gw/r), 64]; lara.py:43,48,145-151,
+ *                                              eva.py:178-181 differentiated)
+ *     dx = [dq | dk | dv] w
+ * dqkv [B*gh*gw, 576] (EA dtype) is read AND its dq / dk columns rewritten with the corrected rows (the weight-gradient pass
+ * reads them).  w, dx as for ea_linear_dgrad. */
+int ea_linear_dgrad_finish(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t pool_r, int32_t C, float scale,
+                           void* dqkv, int64_t ldy, const void* qkv, int64_t ldq, const void* w, int32_t w_f32, void* dx,
+                           int32_t dx_f32, int64_t ldx, const float* qbar, const float* uq, const float* lse_t,
+                           const float* dpq, const float* dpk, void* stream);
+
 /* Round 5 (ABI 10): consumer passes that merge the producing pass's per-slice partials in their prologue -- the arithmetic of
  * ea_lara_merge_fwd / _bwd and ea_slice_sum, operation for operation -- so a layer step has three launches less (7 + 14 + 6
  * us at cfg3 for a few KB per (b,h)).  S <= 4 slices, C <= 64 samples (EA_E_UNSUPPORTED otherwise: keep the merge launches).
@@ -651,6 +665,13 @@ int ea_lara_layer_fwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, 
 int ea_lara_layer_bwd(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
                       const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
                       const ea_t4* dv, const float* saved, float* tmp, float* dparams, void* stream);
+/* ABI 10: flags = EA_LARA_DEFER_FINISH leaves out the finish pass -- dq lacks the softmax-over-sequence correction and dq, dk the
+ * pooling terms; ea_linear_dgrad_finish applies them on its way (operands at ea_lara_layer_ws(cfg, 7..9) inside the backward
+ * scratch and (10, 11) inside `saved`). */
+#define EA_LARA_DEFER_FINISH 1
+int ea_lara_layer_bwd2(const ea_lara_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                       const float* noise, const float* const* params, const ea_t4* dout, const ea_t4* dq, const ea_t4* dk,
+                       const ea_t4* dv, const float* saved, float* tmp, float* dparams, int32_t flags, void* stream);
 
 /* ---- composite per-module entry points, EVA (round 4) -----------------------------------------------------------
  * The 2-D EVA core (eva.py:145-227: non-overlapping w x w windows, r x r landmark chunks, adaptive_proj 'default', no pad
@@ -688,6 +709,14 @@ int ea_eva_layer_bwd(const ea_eva_layer* cfg, const ea_t4* q, const ea_t4* k, co
                      const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
                      const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
                      void* stream);
+/* ABI 10: flags = EA_EVA_DEFER_CHUNK_MEAN leaves out the chunk-mean backward (eva.py:178-181 differentiated): dq / dk lack the
+ * d(chunk mean) / r^2 terms, which ea_linear_dgrad_finish adds on its way (their gradients [B*H, L, D] fp32 sit at
+ * ea_eva_layer_ws(cfg, 11 / 12) inside the backward scratch). */
+#define EA_EVA_DEFER_CHUNK_MEAN 1
+int ea_eva_layer_bwd2(const ea_eva_layer* cfg, const ea_t4* q, const ea_t4* k, const ea_t4* v, const float* bias,
+                      const float* noise, const float* const* params, const ea_t4* out, const ea_t4* dout, const ea_t4* dq,
+                      const ea_t4* dk, const ea_t4* dv, const float* saved, float* tmp, float* dbias, float* dparams,
+                      int32_t flags, void* stream);
 
 /* ---- row LayerNorm (ea_layernorm.hip) -------------------------------------------------------------------------
  * The LayerNorm of LinearRA's model-wide ('dense') landmark generators (lara.py:34-44,64-71: Linear(dim, dim) + LayerNorm(dim)

@@ -56,8 +56,13 @@ CASE_TOL = {("performer_2d_clamp", "bf16"): (1.4e-1, 7e-2)}
 # 0.34 of the fp16 bound; LARA's gradients (three more rounded stages, see the module docstring) reach 0.098 rms + 0.098 |ref|
 # in bf16 and 0.015 / 0.015 in fp16 (lara_2d_dense_antithetic), ScatterBrain 0.068 / 0.014: their bounds are ~1.5x those.
 ELEM_TOL = {"fp16": (1.5e-2, 1.5e-2), "bf16": (8e-2, 8e-2)}
+# Performer (bf16 q, k into an exponential feature map): 0.079 / 0.079 observed (performer_1d_mask).  ScatterBrain's input
+# gradient is heavy-tailed (max|ref| ~ 7.5 rms in scatterbrain_2d) and its rounding error is that of the row's LARGE entries
+# spread over every channel by the projection product: elements with a small reference value carry errors of 0.44 rms in bf16
+# (0.033 rms in fp16) while the norm-wise figures stay at 5.9e-2 / 3.0e-2 -- its bound says so instead of pretending otherwise.
 ELEM_TOL_VARIANT = {("lara", "bf16"): (1.5e-1, 1.5e-1), ("lara", "fp16"): (2.5e-2, 2.5e-2),
-                    ("scatterbrain", "bf16"): (1.2e-1, 1.2e-1), ("scatterbrain", "fp16"): (2.5e-2, 2.5e-2)}
+                    ("performer", "bf16"): (1.2e-1, 1.2e-1),
+                    ("scatterbrain", "bf16"): (7e-1, 7e-1), ("scatterbrain", "fp16"): (5e-2, 5e-2)}
 ELEM_EXEMPT = {("performer_2d_clamp", "bf16")}
 
 

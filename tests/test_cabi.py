@@ -92,7 +92,8 @@ def test_eva_composite_entry_points_report_their_workspaces(lib):
     geom = _native.make_geom(128, 3, N, 64, 0, True, (28, 28), 7, 0, 4, 49)
     assert n[7] == L.ea_window_bias_ld(ctypes.byref(geom))
     assert 0 <= n[9] < n[2] and n[10] >= 128 and n[9] + n[10] * 3 * 49 * n[7] <= n[2]      # bias-gradient partials in the scratch
-    assert L.ea_eva_layer_ws(ctypes.byref(cfg), 11) == -1
+    assert 0 <= n[2] and 0 <= L.ea_eva_layer_ws(ctypes.byref(cfg), 11) < L.ea_eva_layer_ws(ctypes.byref(cfg), 12) < n[2]   # d(chunk means) (ABI 10)
+    assert L.ea_eva_layer_ws(ctypes.byref(cfg), 13) == -1
     bad = _native.ea_eva_layer(128, 3, 64, 0, 28, 28, 8, 4, 1, 0.125)              # grid not divisible by the window side
     assert L.ea_eva_layer_ws(ctypes.byref(bad), 0) == -1
     big = _native.ea_eva_layer(2, 3, 64, 0, 28, 28, 7, 2, 0, 0.125)                # 196 landmarks: step-by-step path

@@ -235,6 +235,70 @@ def test_linear_dgrad_matches_fp64(rows, w_f32, dx_f32, wide, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W,r,C,has_t,dx_f32,w_f32", [(8, 28, 28, 4, 49, 1, 1, 0), (128, 14, 14, 2, 49, 1, 1, 1), (3, 28, 28, 4, 49, 0, 0, 0),
+                                                          (5, 16, 16, 4, 16, 1, 0, 1), (300, 8, 8, 2, 16, 0, 1, 0)])
+def test_linear_dgrad_finish_equals_finish_then_dgrad(B, H, W, r, C, has_t, dx_f32, w_f32, dtype):
+    """ea_linear_dgrad_finish (round 5: the last corrections of dq / dk -- lara.py:223 and the pooling backward of lara.py:43,48,
+    145-151 / eva.py:178-181 -- fused into the input-gradient pass) against the two launches it replaces, ea_lara_bwd_finish
+    followed by ea_linear_dgrad: the same arithmetic in the same order -> the corrected gradient rows and dx are BIT-identical."""
+    import ctypes
+    import torch
+    from efficient_attention import _ops, _native as nv
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(B * 31 + H + C)
+    N, h, d = H * W, 3, 64
+    L = (H // r) * (W // r)
+    rn = lambda *shape, s=1.0: s * torch.randn(*shape, device="cuda", generator=g)   # noqa: E731
+    qkv = rn(B, N, 3, h, d, s=0.5).to(td)
+    dqkv = rn(B, N, 3, h, d, s=0.5).to(td)
+    w = rn(576, 192, s=0.05)
+    w16 = w.to(td)
+    scale = d ** -0.5
+    qbar = rn(B * h, C, d)
+    uq = rn(B * h, C, d) if has_t else None
+    q = qkv[:, :, 0].permute(0, 2, 1, 3).float()
+    lse_t = torch.logsumexp(scale * torch.einsum("bhnd,bhcd->bhcn", q, qbar.view(B, h, C, d)), -1).reshape(B * h, C).contiguous()
+    dpq, dpk = rn(B * h, L, d), rn(B * h, L, d)
+    io = nv.io_dtype(qkv)
+    geom = nv.ea_lara_geom(B, h, N, d, io, C, 0, 2.0, scale)
+    # A: finish pass, then the plain input-gradient kernel
+    da = dqkv.clone()
+    qv, _, _ = _ops._qkv_views(qkv)
+    dqv, dkv_, _ = _ops._qkv_views(da)
+    tq, tdq, tdk = nv.t4(qv), nv.t4(dqv), nv.t4(dkv_)
+    nv.call("ea_lara_bwd_finish", ctypes.byref(geom), ctypes.byref(tq), nv.ptr(qbar), nv.ptr(uq), nv.ptr(lse_t) if has_t else None,
+            nv.ptr(dpq), nv.ptr(dpk), r, H, W, ctypes.byref(tdq), ctypes.byref(tdk), nv.stream())
+    old = _ops.DGRAD_RS_MIN_ROWS
+    _ops.DGRAD_RS_MIN_ROWS = 1
+    try:
+        xd = torch.float32 if dx_f32 else td
+        dxa = _ops.qkv_dgrad(da.view(-1, 576), w, None if w_f32 else w16, xd)
+        # B: one pass
+        db = dqkv.clone()
+        fin = dict(B=B, gh=H, gw=W, r=r, C=C, scale=scale, qbar=qbar if has_t else None, uq=uq, lse_t=lse_t if has_t else None,
+                   dpq=dpq, dpk=dpk)
+        dxb = _ops.qkv_dgrad_finish(db.view(-1, 576), qkv.view(-1, 576), w, None if w_f32 else w16, xd, fin)
+        dxb2 = _ops.qkv_dgrad_finish(dqkv.clone().view(-1, 576), qkv.view(-1, 576), w, None if w_f32 else w16, xd, fin)
+    finally:
+        _ops.DGRAD_RS_MIN_ROWS = old
+    assert torch.equal(db[:, :, 2], dqkv[:, :, 2])                       # dv untouched
+    assert not torch.equal(db[:, :, 1], dqkv[:, :, 1])                   # dk took the pooling term
+    assert torch.equal(da, db), float((da.float() - db.float()).abs().max())
+    assert torch.equal(dxa, dxb) and torch.equal(dxb, dxb2)
+    # and against the definition in fp64 (the t correction and both pooling terms)
+    ref = dqkv.double().clone()
+    cell = (torch.arange(N, device="cuda") // W // r) * (W // r) + (torch.arange(N, device="cuda") % W) // r
+    ref[:, :, 0] += dpq.view(B, h, L, d).double()[:, :, cell].permute(0, 2, 1, 3) / (r * r)
+    ref[:, :, 1] += dpk.view(B, h, L, d).double()[:, :, cell].permute(0, 2, 1, 3) / (r * r)
+    if has_t:
+        t = torch.exp(scale * torch.einsum("bhnd,bhcd->bhcn", q.double(), qbar.view(B, h, C, d).double()) - lse_t.view(B, h, C, 1).double())
+        ref[:, :, 0] -= scale * torch.einsum("bhcn,bhcd->bnhd", t, uq.view(B, h, C, d).double())
+    err = float((db.double() - ref).abs().max() / ref.abs().max())
+    assert err < (2e-2 if dtype == "bf16" else 3e-3), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("rows,K,NO,a_f32,y_f32,transposed", [
     (100352, 192, 576, 1, 0, 0), (100352, 192, 192, 0, 0, 0), (100352, 192, 192, 0, 1, 1), (1001, 64, 128, 1, 1, 0),
     (50017, 128, 384, 0, 0, 1), (30001, 256, 256, 1, 1, 1), (77, 192, 576, 1, 0, 0), (4097, 256, 512, 0, 0, 1)])
@@ -974,7 +1038,7 @@ def test_eva_composite_equals_step_by_step(dtype, dim, heads, grid, window, land
             y.backward(g)
             monkeypatch.setattr(_ops.nv, "call", orig)
             res[comp] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
-            used[comp] = ("ea_eva_layer_fwd" in calls, "ea_eva_layer_bwd" in calls)
+            used[comp] = ("ea_eva_layer_fwd" in calls, "ea_eva_layer_bwd" in calls or "ea_eva_layer_bwd2" in calls)
         pooled_three_nodes = (not module_fn) and dim == 192 and _ops.USE_PROJ_POOL
         assert used[True] == ((False, False) if pooled_three_nodes else (True, True)), used
         assert used[False] == (False, False)
