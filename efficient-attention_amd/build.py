@@ -24,7 +24,7 @@ LIB_SOURCES = ["ea_capi.hip", "ea_window_fwd.hip", "ea_window_bwd.hip", "ea_eva_
                "ea_lara_x.hip", "ea_lara_y.hip", "ea_lara_f.hip", "ea_softmax.hip",
                "ea_lara_merge.hip", "ea_proj.hip", "ea_lara_segment.hip",
                "ea_rows_mlp.hip", "ea_wgrad.hip", "ea_linear.hip", "ea_lmk2.hip", "ea_scatter.hip", "ea_proj_rs.hip",
-               "ea_performer_f32.hip", "ea_fold.hip", "ea_lara_seglin.hip", "ea_layernorm.hip", "ea_dgrad_rs.hip"]
+               "ea_performer_f32.hip", "ea_fold.hip", "ea_lara_seglin.hip", "ea_layernorm.hip", "ea_dgrad_rs.hip", "ea_f32_attn.hip"]
 
 
 def _cuid(src):

@@ -19,6 +19,7 @@ int window_bwd_dispatch(const WinP& p, const ea_geom& geom, const T4& outp, cons
 #include "ea_scatter.h"
 #include "ea_rows_mlp.h"
 #include "ea_performer_f32.h"
+#include "ea_f32_attn.h"
 namespace ea {
 int rows_mlp_dispatch(const RowsP& p, int D, int sides, int layer_norm, bool bwd, hipStream_t st);
 int rows_mlp_blocks(int R, int D);
@@ -1801,6 +1802,80 @@ int ea_eva_layer_bwd2(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, con
   // dparams == NULL: the per-(b,h) partials stay in tmp (offsets ea_eva_layer_ws(cfg, 5 / 6)) for the caller's own reduction
   if (dparams) rc = ea_colsum2_f32(P.BH, 2 * D * D, dW, dparams, 6 * D, dvec, dparams + (size_t)2 * D * D, stream);
   return rc;
+}
+
+}  // extern "C"
+
+// ---- fp32-faithful gathered attention (ea_f32_attn.hip) ----
+static bool f32_t4_ok(const ea_t4* t, int D) {
+  return t && t->ptr && ((uintptr_t)t->ptr % 16 == 0) && t->sb % 4 == 0 && t->sh % 4 == 0 && t->sn % 4 == 0 && t->sn >= D;
+}
+static F32T f32_mk(const ea_t4* t) {
+  F32T r;
+  r.p = t ? (const float*)t->ptr : nullptr;
+  r.sb = t ? t->sb : 0; r.sh = t ? t->sh : 0; r.sn = t ? t->sn : 0;
+  return r;
+}
+static int fill_ga(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
+                   const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
+                   const uint8_t* keep, GaP& p) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->Nq <= 0 || g->Nk <= 0 || g->G <= 0 || g->Wq <= 0 || g->Wk < 0 || g->L < 0 ||
+      g->Wk + g->L <= 0 || !idx_q || (g->Wk > 0 && !idx_k)) return EA_E_BADARG;
+  if (g->D != 32 && g->D != 64 && g->D != 128) return EA_E_UNSUPPORTED;
+  if (!f32_t4_ok(q, g->D) || !f32_t4_ok(k, g->D) || !f32_t4_ok(v, g->D)) return EA_E_BADARG;
+  if (g->L > 0 && (!f32_t4_ok(ek, g->D) || !f32_t4_ok(ev, g->D))) return EA_E_BADARG;
+  if (bias && g->bias_ld < g->Wk) return EA_E_BADARG;
+  if (keep && g->keep_ld < g->Wk + g->L) return EA_E_BADARG;
+  p.q = f32_mk(q); p.k = f32_mk(k); p.v = f32_mk(v); p.ek = f32_mk(g->L > 0 ? ek : nullptr); p.ev = f32_mk(g->L > 0 ? ev : nullptr);
+  p.idx_q = idx_q; p.idx_k = idx_k; p.bias = bias; p.bias_hs = g->bias_hs; p.bias_ld = g->bias_ld;
+  p.kmask = kmask; p.qmask = qmask; p.keep = keep; p.keep_ld = g->keep_ld; p.keep_scale = g->keep_scale;
+  p.B = g->B; p.H = g->H; p.Nq = g->Nq; p.Nk = g->Nk; p.D = g->D; p.G = g->G; p.Wq = g->Wq; p.Wk = g->Wk; p.L = g->L;
+  p.knorm = g->knorm; p.neg_inf = g->neg_inf; p.causal_e = g->causal_e; p.chunk = g->chunk; p.lm_base = g->lm_base;
+  p.scale = g->scale;
+  return EA_OK;
+}
+
+extern "C" {
+
+int ea_f32_attn_fwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
+                    const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
+                    const uint8_t* keep, const ea_t4* out, float* lse, void* stream) {
+  GaP p = {};
+  int rc = fill_ga(g, q, k, v, ek, ev, idx_q, idx_k, bias, kmask, qmask, keep, p);
+  if (rc != EA_OK) return rc;
+  if (!f32_t4_ok(out, g->D)) return EA_E_BADARG;
+  p.o = f32_mk(out); p.lse = lse;
+  return ga_dispatch(false, p, (hipStream_t)stream);
+}
+
+int ea_f32_attn_bwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
+                    const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
+                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* lse, const float* dlse,
+                    const ea_t4* dq, float* dk, float* dv, float* dek, float* dev, float* dbias, void* stream) {
+  GaP p = {};
+  int rc = fill_ga(g, q, k, v, ek, ev, idx_q, idx_k, bias, kmask, qmask, keep, p);
+  if (rc != EA_OK) return rc;
+  if (!f32_t4_ok(out, g->D) || !f32_t4_ok(dout, g->D) || !f32_t4_ok(dq, g->D) || !lse) return EA_E_BADARG;
+  if (dbias && !bias) return EA_E_BADARG;
+  p.o = f32_mk(out); p.dout = f32_mk(dout); p.dq = f32_mk(dq); p.lse = const_cast<float*>(lse); p.dlse = dlse;
+  p.dk = dk; p.dv = dv; p.dek = g->L > 0 ? dek : nullptr; p.dev = g->L > 0 ? dev : nullptr; p.dbias = dbias;
+  return ga_dispatch(true, p, (hipStream_t)stream);
+}
+
+int ea_f32_gather_mean_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t Cn, int32_t J, const ea_t4* x, const int32_t* idx,
+                           const uint8_t* mask, float* mean, void* stream) {
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || (D & 3) || Cn <= 0 || J <= 0 || !f32_t4_ok(x, D) || !idx || !mean) return EA_E_BADARG;
+  GmP p = {};
+  p.x = f32_mk(x); p.idx = idx; p.mask = mask; p.mean = mean; p.B = B; p.H = H; p.N = N; p.D = D; p.Cn = Cn; p.J = J;
+  return gm_dispatch(false, p, (hipStream_t)stream);
+}
+
+int ea_f32_gather_mean_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t Cn, int32_t J, const int32_t* idx,
+                           const uint8_t* mask, const float* dmean, float* dx, void* stream) {
+  if (B <= 0 || H <= 0 || N <= 0 || D <= 0 || (D & 3) || Cn <= 0 || J <= 0 || !idx || !dmean || !dx) return EA_E_BADARG;
+  GmP p = {};
+  p.idx = idx; p.mask = mask; p.dmean = dmean; p.dx = dx; p.B = B; p.H = H; p.N = N; p.D = D; p.Cn = Cn; p.J = J;
+  return gm_dispatch(true, p, (hipStream_t)stream);
 }
 
 }  // extern "C"

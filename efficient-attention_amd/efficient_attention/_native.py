@@ -57,6 +57,14 @@ class ea_lara_layer(ctypes.Structure):
                 ("kappa", ctypes.c_float), ("scale", ctypes.c_float)]
 
 
+class ea_f32_attn(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("Nq", ctypes.c_int32), ("Nk", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("G", ctypes.c_int32), ("Wq", ctypes.c_int32), ("Wk", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("knorm", ctypes.c_int32), ("neg_inf", ctypes.c_int32), ("causal_e", ctypes.c_int32), ("chunk", ctypes.c_int32),
+                ("lm_base", ctypes.c_int32), ("bias_ld", ctypes.c_int32), ("bias_hs", ctypes.c_int64), ("keep_ld", ctypes.c_int64),
+                ("keep_scale", ctypes.c_float), ("scale", ctypes.c_float)]
+
+
 class ea_eva_layer(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("D", ctypes.c_int32), ("dtype", ctypes.c_int32),
                 ("gh", ctypes.c_int32), ("gw", ctypes.c_int32), ("window", ctypes.c_int32), ("chunk", ctypes.c_int32),
@@ -81,6 +89,7 @@ _T = ctypes.POINTER(ea_t4)
 _SG = ctypes.POINTER(ea_sb_geom)
 _LL = ctypes.POINTER(ea_lara_layer)
 _EL = ctypes.POINTER(ea_eva_layer)
+_FA = ctypes.POINTER(ea_f32_attn)
 
 # name -> argtypes; every symbol include/ea_hip.h declares (tests check the list is complete)
 SIGNATURES = {
@@ -133,6 +142,10 @@ SIGNATURES = {
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_linear_w32": [_I, _I, _I, _I, _P, _I, _L, _P, _I, _P, _P, _I, _L, _P, _P],
     "ea_linear_pool_supported": [_I] * 6,
+    "ea_f32_attn_fwd": [_FA, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P],
+    "ea_f32_attn_bwd": [_FA, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P, _T, _P, _P, _P, _P, _P, _P],
+    "ea_f32_gather_mean_fwd": [_I, _I, _I, _I, _I, _I, _T, _P, _P, _P, _P],
+    "ea_f32_gather_mean_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "ea_linear_dgrad_supported": [_I, _I],
     "ea_linear_dgrad": [_I, _I, _I, _I, _P, _L, _P, _I, _P, _I, _L, _P],
     "ea_linear_dgrad_finish": [_I, _I, _I, _I, _I, _I, _F, _P, _L, _P, _L, _P, _I, _P, _I, _L, _P, _P, _P, _P, _P, _P],

@@ -634,6 +634,42 @@ int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const flo
                                 const float* d_qbar_rows, const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
                                 float* dW_part, float* dvec_part, const float* saved, void* stream);
 
+/* ---- fp32-FAITHFUL cores (round 5, ABI 10; ea_f32_attn.hip) -------------------------------------------------------------
+ * Outside torch.autocast the reference computes attention in fp32 (abstract_attention.py:120-133, local_attention.py:134-182,
+ * eva.py:138-233, causal_eva.py:666-783).  One gathered-attention pair in exact fp32 arithmetic (operands, products on
+ * v_mfma_f32_16x16x4_f32, softmax) covers every softmax-shaped core, stated as the reference states them:
+ *   group g (a window, a landmark chunk, or the whole sequence), query slot i -> token idx_q[g][i] of q [B,H,Nq,D],
+ *   Wk local key slots j -> token idx_k[g][j] of k, v [B,H,Nk,D] (-1: absent = zero row, masked), then L extra keys / values
+ *   ek, ev [B,H,L,D] shared by all groups (EVA: rf_k_bar / beta):
+ *     logit_ij = scale q_i.k_j [- scale |k_j|^2 / 2 (knorm)] [+ bias[h bias_hs + i bias_ld + j]]
+ *     masked (padded / absent key; padded query (qmask); causal_e >= 0 and j > i + causal_e): -5e4, or -inf for padded keys when
+ *     neg_inf; extra key c masked (-5e4) when chunk > 0 and c >= lm_base + token(i) / chunk  (causal_eva.py:716-738)
+ *     out_i = softmax over the Wk + L columns . [v ; ev] (dropout: keep [B,H,Nq,keep_ld] over those columns, kept entries x
+ *     keep_scale in the value product only), lse_i = log-sum-exp (natural log).
+ * All tensors fp32 (ea_t4 strides in elements).  Backward: dq stored; dk, dv [B,H,Nk,D], dek, dev [B,H,L,D], dbias (bias layout)
+ * are contiguous fp32 buffers ACCUMULATED into with atomics (the caller zeroes them; windows overlap); dlse optional. */
+typedef struct {
+  int32_t B, H, Nq, Nk, D;           /* D in {32, 64, 128} */
+  int32_t G, Wq, Wk, L;
+  int32_t knorm, neg_inf, causal_e, chunk, lm_base;
+  int32_t bias_ld;
+  int64_t bias_hs, keep_ld;
+  float   keep_scale, scale;
+} ea_f32_attn;
+int ea_f32_attn_fwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
+                    const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
+                    const uint8_t* keep, const ea_t4* out, float* lse, void* stream);
+int ea_f32_attn_bwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
+                    const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
+                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* lse, const float* dlse,
+                    const ea_t4* dq, float* dk, float* dv, float* dek, float* dev, float* dbias, void* stream);
+/* mean[b,h,c,:] = (1/J) sum_j x[b,h,idx[c][j],:] over the present, unpadded tokens (EVA's masked chunk means, eva.py:167-181;
+ * uniform pooling); backward accumulates into dx [B,H,N,D] contiguous fp32 (atomics). */
+int ea_f32_gather_mean_fwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t Cn, int32_t J, const ea_t4* x, const int32_t* idx,
+                           const uint8_t* mask, float* mean, void* stream);
+int ea_f32_gather_mean_bwd(int32_t B, int32_t H, int32_t N, int32_t D, int32_t Cn, int32_t J, const int32_t* idx,
+                           const uint8_t* mask, const float* dmean, float* dx, void* stream);
+
 /* ---- composite per-module entry points: the whole LARA core in one call each way (round 3) --------------------
  * lara.py:129-175,187-246 for the 2-D pooled proposals ('pool', 'pool-mixed'): uniform r x r pooling of q, k -> landmark
  * pipeline -> estimator, i.e. the launch sequences of ea_eva_chunk_mean_fwd / ea_lara_landmarks_* / ea_lara_stats_fwd /
