@@ -1830,7 +1830,7 @@ static int fill_ga(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const e
   p.idx_q = idx_q; p.idx_k = idx_k; p.bias = bias; p.bias_hs = g->bias_hs; p.bias_ld = g->bias_ld;
   p.kmask = kmask; p.qmask = qmask; p.keep = keep; p.keep_ld = g->keep_ld; p.keep_scale = g->keep_scale;
   p.B = g->B; p.H = g->H; p.Nq = g->Nq; p.Nk = g->Nk; p.D = g->D; p.G = g->G; p.Wq = g->Wq; p.Wk = g->Wk; p.L = g->L;
-  p.knorm = g->knorm; p.neg_inf = g->neg_inf; p.causal_e = g->causal_e; p.chunk = g->chunk; p.lm_base = g->lm_base;
+  p.knorm = g->knorm & 1; p.zero_mv = (g->knorm >> 1) & 1; p.neg_inf = g->neg_inf; p.causal_e = g->causal_e; p.chunk = g->chunk; p.lm_base = g->lm_base;
   p.scale = g->scale;
   return EA_OK;
 }

@@ -27,6 +27,7 @@ struct GaP {
   const float* dlse;          // bwd: gradient of lse or null
   int B, H, Nq, Nk, D, G, Wq, Wk, L;
   int knorm;                  // logits -= s |k_j|^2 / 2 on the local keys (prm_projection, attn_utils.py:324-336)
+  int zero_mv;                // masked local keys carry a ZERO value row (EVA's beta: `cv = v * keep`, eva.py:167-176,196)
   int neg_inf;                // padded keys take -inf (softmax baseline, lara.py:205-208) instead of the finite -5e4
   int causal_e;               // >= 0: local key slot j is visible to query slot i iff j <= i + causal_e; -1: no rule
   int chunk, lm_base;         // chunk > 0: extra key c is visible to a query token t iff c < lm_base + t / chunk

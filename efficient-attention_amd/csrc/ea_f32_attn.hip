@@ -76,7 +76,8 @@ EA_DEV void stage_keys(const GaP& p, int b, int h, int g, int kc0, float* Ks, fl
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
     if (tk >= 0 && kind == 0) {
       kv = *reinterpret_cast<const f32x4*>(p.k.p + (size_t)b * p.k.sb + (size_t)h * p.k.sh + (size_t)tk * p.k.sn + c);
-      vv = *reinterpret_cast<const f32x4*>(p.v.p + (size_t)b * p.v.sb + (size_t)h * p.v.sh + (size_t)tk * p.v.sn + c);
+      if (!(p.zero_mv && kflag[r] != 0))
+        vv = *reinterpret_cast<const f32x4*>(p.v.p + (size_t)b * p.v.sb + (size_t)h * p.v.sh + (size_t)tk * p.v.sn + c);
     } else if (kind == 1) {
       kv = *reinterpret_cast<const f32x4*>(p.ek.p + (size_t)b * p.ek.sb + (size_t)h * p.ek.sh + (size_t)tk * p.ek.sn + c);
       vv = *reinterpret_cast<const f32x4*>(p.ev.p + (size_t)b * p.ev.sb + (size_t)h * p.ev.sh + (size_t)tk * p.ev.sn + c);
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
         float* const bv_ = kind == 0 ? p.dv : p.dev;
         const size_t off = (kind == 0 ? bh * p.Nk + tk : bh * p.L + tk) * D + c;
         if (bk_) unsafeAtomicAdd(bk_ + off, dkv);
-        if (bv_) unsafeAtomicAdd(bv_ + off, dv_[r]);
+        if (bv_ && !(p.zero_mv && kind == 0 && kflag[jl] != 0)) unsafeAtomicAdd(bv_ + off, dv_[r]);
       }
     }
     __syncthreads();

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 
 
 class AbstractAttention(nn.Module):
@@ -32,6 +33,10 @@ class AbstractAttention(nn.Module):
 
 
 class MultiheadAttention(nn.Module):
+    # fp32 activations outside autocast stay fp32 and take the fp32-faithful kernels (_f32.py): the softmax baseline,
+    # LocalAttention and EVA; subclasses whose cores only exist with 16-bit operands set this to False
+    _F32_CORE = True
+
     def __init__(self, dim, num_heads, fp32=False, qkv_bias=True, attn_drop=0., proj_drop=0.):
         super().__init__()
         self.dim = dim
@@ -68,6 +73,10 @@ class MultiheadAttention(nn.Module):
         kernels compute bf16 x bf16 -> fp32, the autocast contract of vit/engine.py:47)."""
         B, N, C = x.shape
         qkv = _ops.linear(x, self.qkv)
+        if self._F32_CORE and _f32.usable(qkv) and self.head_dim in (32, 64, 128):
+            # round 5: fp32 activations outside autocast stay fp32 -- the core then runs on the fp32-faithful kernels
+            # (ea_f32_attn_*), as the reference computes there (abstract_attention.py:120-133)
+            return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
         qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
 
@@ -112,6 +121,8 @@ class MultiheadAttention(nn.Module):
     def _attend(self, qkv5, key_padding_mask, seq_shape):
         B, N = qkv5.shape[:2]
         mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
+        if qkv5.dtype == torch.float32:
+            return _f32.softmax_core(qkv5, mask, *self._attn_keep(B, N, qkv5.device))
         return _ops.SoftmaxAttnFn.apply(qkv5, mask, *self._attn_keep(B, N, qkv5.device))
 
     def _attn_keep(self, B, N, device):

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 from .local_attention import LocalAttention
 
 
@@ -124,6 +125,14 @@ class EVA(LocalAttention):
         k = self.adaptive_mu_k
         return [k[0].weight, k[0].bias, k[1].weight, k[1].bias]
 
+    def _mu_f32(self, q_mean, k_mean):
+        """(rf_k_bar, mu) from the chunk means [B,h,L,d] (eva.py:178-185), the module's own Linear / LayerNorm layers in fp32."""
+        if self.adaptive_proj in ('default', 'no-ln'):
+            rq, rk = self.adaptive_mu_q(q_mean), self.adaptive_mu_k(k_mean)
+            return rk, 0.5 * (rq + rk)
+        rk = self.adaptive_mu_k(k_mean)
+        return rk, torch.zeros_like(rk)
+
     def _process_input(self, x, key_padding_mask):
         """2-D: validate the grid; 1-D: pad x to a multiple of the window and build/extend the
         padding mask (reference :119-136)."""
@@ -207,7 +216,11 @@ class EVA(LocalAttention):
         cfg = (self.attn_2d, tuple(seq_shape), w, e, r, L, self.adaptive_proj)
         if pooled is not None:
             cfg = cfg + (0, 0.5, None, 1.0, pooled)
-        out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask, cfg, *self._mu_params())
+        if qkv5.dtype == torch.float32:
+            # fp32 outside autocast (round 5): the core on the fp32-faithful kernels, the mu networks as the module's own layers
+            out = _f32.eva_core(qkv5, bias, noise, mask, self.attn_2d, tuple(seq_shape), w, e, r, self._mu_f32)
+        else:
+            out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask, cfg, *self._mu_params())
         y = self.merge_and_project(out, B, seq_shape, C, x.dtype)
         if not self.attn_2d:
             y = y[..., :orig_n, :]

@@ -42,6 +42,7 @@ def create_proj_matrix(num_heads, proj_dim, input_dim, ortho=False, seed=0, devi
 
 
 class KernelizedAttention(MultiheadAttention):
+    _F32_CORE = False           # no fp32-operand kernels for this core's estimator (the Performer core has its own fp32 path)
     def __init__(self, approx_attn_dim=64, proj_method='favorp', cos_weighting=False,
                  sample_scheme='default', *args, **kwargs):
         super().__init__(*args, **kwargs)

@@ -20,6 +20,7 @@ from .attn_utils import FlattenTranspose
 
 
 class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
+    _F32_CORE = False           # (no fp32-operand kernels for this variant yet: fp32 input is rounded to bf16 with a warning)
     def __init__(self, num_landmarks=49, kernel_size=None, proposal_gen='pool',
                  use_antithetics=False, use_multisample=False, pool_module_type='light',
                  mis_type='mis-opt', alpha_coeff=1.0, *args, **kwargs):

@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 from .abstract_attention import MultiheadAttention
 
 
@@ -121,6 +122,8 @@ class LocalAttention(MultiheadAttention):
             assert H % self.window_size == 0
             shape = (H, W)
         mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
+        if qkv5.dtype == torch.float32:
+            return _f32.local_core(qkv5, self._table_bias(), mask, attn_2d, shape, self.window_size, self.ext_size)
         return _ops.LocalAttnFn.apply(qkv5, self._table_bias(), mask, attn_2d, shape,
                                       self.window_size, self.ext_size)
 

@@ -32,6 +32,7 @@ from .local_attention import LocalAttention
 
 
 class ScatterBrain(KernelizedAttention, LocalAttention):
+    _F32_CORE = False           # (no fp32-operand kernels for this variant yet: fp32 input is rounded to bf16 with a warning)
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._slot_cache = {}

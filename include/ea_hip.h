@@ -651,7 +651,8 @@ int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const flo
 typedef struct {
   int32_t B, H, Nq, Nk, D;           /* D in {32, 64, 128} */
   int32_t G, Wq, Wk, L;
-  int32_t knorm, neg_inf, causal_e, chunk, lm_base;
+  int32_t knorm;                     /* bit 0: the key-norm term; bit 1: masked local keys carry a zero VALUE row (eva.py:167-176) */
+  int32_t neg_inf, causal_e, chunk, lm_base;
   int32_t bias_ld;
   int64_t bias_hs, keep_ld;
   float   keep_scale, scale;

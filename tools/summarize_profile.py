@@ -35,7 +35,7 @@ KERNEL_TO_ENTRY = [
     ("win_bwd_kernel<", "ea_window_attn_bwd"),
     ("chunk_mean_fwd_r_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_r_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_r_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_r_kernel<", "ea_eva_beta_bwd"),
-    ("proj_rs_kernel<", "ea_linear[fp32 in]"), ("dgrad_rs_kernel<", "ea_linear_dgrad"),
+    ("proj_rs_kernel<", "ea_linear[fp32 in]"), ("dgrad_rs_kernel<", "ea_linear_dgrad"), ("dgrad_fin_kernel<", "ea_linear_dgrad_finish"),
     ("chunk_mean_fwd_kernel<", "ea_eva_chunk_mean_fwd"), ("chunk_mean_bwd_kernel<", "ea_eva_chunk_mean_bwd"),
     ("beta_fwd_kernel<", "ea_eva_beta_fwd"), ("beta_bwd_kernel<", "ea_eva_beta_bwd"),
     ("sm_fwd_kernel<ea::BF16, 64", "ea_softmax_attn_fwd"), ("sm_bwd_dq_kernel<ea::BF16, 64", "ea_softmax_attn_bwd(dq)"),
