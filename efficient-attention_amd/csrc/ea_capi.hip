@@ -1839,25 +1839,25 @@ extern "C" {
 
 int ea_f32_attn_fwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
                     const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
-                    const uint8_t* keep, const ea_t4* out, float* lse, void* stream) {
+                    const uint8_t* keep, const ea_t4* out, float* lse, float* stat, void* stream) {
   GaP p = {};
   int rc = fill_ga(g, q, k, v, ek, ev, idx_q, idx_k, bias, kmask, qmask, keep, p);
   if (rc != EA_OK) return rc;
   if (!f32_t4_ok(out, g->D)) return EA_E_BADARG;
-  p.o = f32_mk(out); p.lse = lse;
+  p.o = f32_mk(out); p.lse = lse; p.stat = stat;
   return ga_dispatch(false, p, (hipStream_t)stream);
 }
 
 int ea_f32_attn_bwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
                     const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
-                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* lse, const float* dlse,
+                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* stat, const float* dlse,
                     const ea_t4* dq, float* dk, float* dv, float* dek, float* dev, float* dbias, void* stream) {
   GaP p = {};
   int rc = fill_ga(g, q, k, v, ek, ev, idx_q, idx_k, bias, kmask, qmask, keep, p);
   if (rc != EA_OK) return rc;
-  if (!f32_t4_ok(out, g->D) || !f32_t4_ok(dout, g->D) || !f32_t4_ok(dq, g->D) || !lse) return EA_E_BADARG;
+  if (!f32_t4_ok(out, g->D) || !f32_t4_ok(dout, g->D) || !f32_t4_ok(dq, g->D) || !stat) return EA_E_BADARG;
   if (dbias && !bias) return EA_E_BADARG;
-  p.o = f32_mk(out); p.dout = f32_mk(dout); p.dq = f32_mk(dq); p.lse = const_cast<float*>(lse); p.dlse = dlse;
+  p.o = f32_mk(out); p.dout = f32_mk(dout); p.dq = f32_mk(dq); p.stat = const_cast<float*>(stat); p.dlse = dlse;
   p.dk = dk; p.dv = dv; p.dek = g->L > 0 ? dek : nullptr; p.dev = g->L > 0 ? dev : nullptr; p.dbias = dbias;
   return ga_dispatch(true, p, (hipStream_t)stream);
 }

@@ -23,7 +23,10 @@ struct GaP {
   const uint8_t* keep;        // [B,H,Nq,keep_ld] dropout keep decisions over the Wk + L columns, or null
   int64_t keep_ld;
   float keep_scale;
-  float* lse;                 // [B,H,Nq] natural log (fwd: written or null; bwd: read)
+  float* lse;                 // [B,H,Nq] natural log (fwd: written or null)
+  float* stat;                // [B,H,Nq,2] = (row max m, sum l of e^(x - m)): fwd writes, bwd reads.  Kept apart because
+                              // lse = m + log l loses l's digits when |m| is large (a fully masked row has m = -5e4: one fp32
+                              // ulp of lse is 4e-3 there, i.e. a 0.4 % error in every recomputed probability)
   const float* dlse;          // bwd: gradient of lse or null
   int B, H, Nq, Nk, D, G, Wq, Wk, L;
   int knorm;                  // logits -= s |k_j|^2 / 2 on the local keys (prm_projection, attn_utils.py:324-336)

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(NT) void ga_fwd_kernel(const GaP p) {
     float* o = const_cast<float*>(p.o.p) + (size_t)b * p.o.sb + (size_t)h * p.o.sh + (size_t)qi[r].tok * p.o.sn;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[16 * dt + li] = oacc[dt][r] * inv;
-    if (p.lse && li == 0) p.lse[(size_t)(b * p.H + h) * p.Nq + qi[r].tok] = m[r] + __logf(l[r]);
+    if (li == 0) {
+      const size_t o = (size_t)(b * p.H + h) * p.Nq + qi[r].tok;
+      if (p.lse) p.lse[o] = m[r] + __logf(l[r]);
+      if (p.stat) { p.stat[2 * o] = m[r]; p.stat[2 * o + 1] = l[r]; }
+    }
   }
 }
 
@@ -230,8 +234,9 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
   float* kadd = dSs + QB * PLD;         // [KC]
   float* csum = kadd + KC;              // [KC] column sums of dS (key-norm term)
   float* delta = csum + KC;             // [QB]
-  float* lses = delta + QB;             // [QB]
-  int* ktok = reinterpret_cast<int*>(lses + QB);
+  float* lses = delta + QB;             // [QB] row max
+  float* linv = lses + QB;              // [QB] 1 / row sum
+  int* ktok = reinterpret_cast<int*>(linv + QB);
   int* kkind = ktok + KC;
   int* kflag = kkind + KC;
   int* qtok = kflag + KC;               // [QB]
@@ -250,24 +255,25 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
   load_rows<D>(Ks, p.o, b, h, qtok, QB, tid);
   __syncthreads();
   if (tid < QB) {
-    float dl = 0.f, ls = 0.f;
+    float dl = 0.f, ls = 0.f, li_ = 0.f;
     const int tk = qtok[tid];
     if (tk >= 0) {
       for (int d = 0; d < D; ++d) dl += dOs[tid * LD + d] * Ks[tid * LD + d];
       const size_t o = (size_t)(b * p.H + h) * p.Nq + tk;
       if (p.dlse) dl -= p.dlse[o];
-      ls = p.lse[o];
+      ls = p.stat[2 * o];
+      li_ = 1.f / p.stat[2 * o + 1];
     }
-    delta[tid] = dl; lses[tid] = ls;
+    delta[tid] = dl; lses[tid] = ls; linv[tid] = li_;
   }
   __syncthreads();
   QInfo qi[4];
-  float dlt[4], lsr[4];
+  float dlt[4], lsr[4], lir[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 16 * wave + 4 * gq + r;
     qi[r] = query_info(p, b, g, qb * QB + row);
-    dlt[r] = delta[row]; lsr[r] = lses[row];
+    dlt[r] = delta[row]; lsr[r] = lses[row]; lir[r] = linv[row];
   }
   f32x4 dqacc[DT];
 #pragma unroll
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
         const float x = logit_of(p, acc[r], h, qi[r], j, kkind[jl], kflag[jl], kadd[jl], live);
         float pv = 0.f, ds = 0.f, kf = 1.f;
         if (qi[r].tok >= 0 && x != -INFINITY) {
-          pv = __expf(x - lsr[r]);
+          pv = __expf(x - lsr[r]) * lir[r];
           if (p.keep) kf = p.keep[(bh * p.Nq + qi[r].tok) * p.keep_ld + j] ? p.keep_scale : 0.f;
           ds = pv * (dp[r] * kf - dlt[r]);
           if (!live) ds = 0.f;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void gm_bwd_kernel(const GmP p) {
 template <int D, int KC> size_t ga_lds(bool bwd) {
   const size_t LD = D + 1, PLD = KC + 1;
   if (!bwd) return (QB * LD + 2 * KC * LD + QB * PLD + KC) * 4 + (3 * KC + QB) * 4;
-  return (2 * QB * LD + 2 * KC * LD + 2 * QB * PLD + 2 * KC + 2 * QB) * 4 + (3 * KC + QB) * 4;
+  return (2 * QB * LD + 2 * KC * LD + 2 * QB * PLD + 2 * KC + 3 * QB) * 4 + (3 * KC + QB) * 4;
 }
 
 template <int D, int KC>

@@ -112,6 +112,7 @@ class GatherAttnFn(torch.autograd.Function):
         # (query slots outside the sequence write nothing: zeros there when the table has such slots -- asked once per table)
         out = (torch.zeros if _has_absent(idx_q) else torch.empty)((B, Nq, H, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        stat = torch.empty((B, H, Nq, 2), dtype=torch.float32, device=q.device)     # (row max, row sum): what the backward reads
         ov = out.permute(0, 2, 1, 3)
         tq, tk, tv, to = _t4(q), _t4(k), _t4(v), _t4(ov)
         tek = _t4(ek) if ek is not None else None
@@ -119,8 +120,8 @@ class GatherAttnFn(torch.autograd.Function):
         nv.call("ea_f32_attn_fwd", ctypes.byref(g), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
                 ctypes.byref(tek) if tek is not None else None, ctypes.byref(tev) if tev is not None else None,
                 nv.ptr(idx_q), nv.ptr(idx_k), nv.ptr(bias), nv.ptr(spec.get("kmask")), nv.ptr(spec.get("qmask")), nv.ptr(keep),
-                ctypes.byref(to), nv.ptr(lse), nv.stream())
-        ctx.save_for_backward(q, k, v, ek, ev, bias, ov, lse, idx_q, idx_k, spec.get("kmask"), spec.get("qmask"), keep)
+                ctypes.byref(to), nv.ptr(lse), nv.ptr(stat), nv.stream())
+        ctx.save_for_backward(q, k, v, ek, ev, bias, ov, stat, idx_q, idx_k, spec.get("kmask"), spec.get("qmask"), keep)
         ctx.g = g
         ctx.set_materialize_grads(False)
         return ov, lse
@@ -128,7 +129,7 @@ class GatherAttnFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout, dlse):
-        q, k, v, ek, ev, bias, ov, lse, idx_q, idx_k, kmask, qmask, keep = ctx.saved_tensors
+        q, k, v, ek, ev, bias, ov, stat, idx_q, idx_k, kmask, qmask, keep = ctx.saved_tensors
         g = ctx.g
         B, H, Nq, D = q.shape
         Nk = k.shape[2]
@@ -150,7 +151,7 @@ class GatherAttnFn(torch.autograd.Function):
         nv.call("ea_f32_attn_bwd", ctypes.byref(g), ctypes.byref(tq), ctypes.byref(tk), ctypes.byref(tv),
                 ctypes.byref(tek) if tek is not None else None, ctypes.byref(tev) if tev is not None else None,
                 nv.ptr(idx_q), nv.ptr(idx_k), nv.ptr(bias), nv.ptr(kmask), nv.ptr(qmask), nv.ptr(keep),
-                ctypes.byref(to), ctypes.byref(tdo), nv.ptr(lse), nv.ptr(dlse_c), ctypes.byref(tdq), nv.ptr(dk), nv.ptr(dv),
+                ctypes.byref(to), ctypes.byref(tdo), nv.ptr(stat), nv.ptr(dlse_c), ctypes.byref(tdq), nv.ptr(dk), nv.ptr(dv),
                 nv.ptr(dek), nv.ptr(dev), nv.ptr(dbias), nv.stream())
         return dq, dk, dv, dek, dev, dbias, None
 

@@ -142,7 +142,7 @@ SIGNATURES = {
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],
     "ea_linear_w32": [_I, _I, _I, _I, _P, _I, _L, _P, _I, _P, _P, _I, _L, _P, _P],
     "ea_linear_pool_supported": [_I] * 6,
-    "ea_f32_attn_fwd": [_FA, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P],
+    "ea_f32_attn_fwd": [_FA, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P, _P, _T, _P, _P, _P],
     "ea_f32_attn_bwd": [_FA, _T, _T, _T, _T, _T, _P, _P, _P, _P, _P, _P, _T, _T, _P, _P, _T, _P, _P, _P, _P, _P, _P],
     "ea_f32_gather_mean_fwd": [_I, _I, _I, _I, _I, _I, _T, _P, _P, _P, _P],
     "ea_f32_gather_mean_bwd": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],

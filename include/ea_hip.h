@@ -645,7 +645,9 @@ int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const flo
  *     masked (padded / absent key; padded query (qmask); causal_e >= 0 and j > i + causal_e): -5e4, or -inf for padded keys when
  *     neg_inf; extra key c masked (-5e4) when chunk > 0 and c >= lm_base + token(i) / chunk  (causal_eva.py:716-738)
  *     out_i = softmax over the Wk + L columns . [v ; ev] (dropout: keep [B,H,Nq,keep_ld] over those columns, kept entries x
- *     keep_scale in the value product only), lse_i = log-sum-exp (natural log).
+ *     keep_scale in the value product only), lse_i = log-sum-exp (natural log, optional); stat [B,H,Nq,2] = (row max, sum of
+ *     e^(logit - max)) is what the backward recomputes the probabilities from (lse alone loses the sum's digits when the
+ *     maximum is the -5e4 fill of a fully masked row).
  * All tensors fp32 (ea_t4 strides in elements).  Backward: dq stored; dk, dv [B,H,Nk,D], dek, dev [B,H,L,D], dbias (bias layout)
  * are contiguous fp32 buffers ACCUMULATED into with atomics (the caller zeroes them; windows overlap); dlse optional. */
 typedef struct {
@@ -659,10 +661,10 @@ typedef struct {
 } ea_f32_attn;
 int ea_f32_attn_fwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
                     const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
-                    const uint8_t* keep, const ea_t4* out, float* lse, void* stream);
+                    const uint8_t* keep, const ea_t4* out, float* lse, float* stat, void* stream);
 int ea_f32_attn_bwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
                     const int32_t* idx_q, const int32_t* idx_k, const float* bias, const uint8_t* kmask, const uint8_t* qmask,
-                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* lse, const float* dlse,
+                    const uint8_t* keep, const ea_t4* out, const ea_t4* dout, const float* stat, const float* dlse,
                     const ea_t4* dq, float* dk, float* dv, float* dek, float* dev, float* dbias, void* stream);
 /* mean[b,h,c,:] = (1/J) sum_j x[b,h,idx[c][j],:] over the present, unpadded tokens (EVA's masked chunk means, eva.py:167-181;
  * uniform pooling); backward accumulates into dx [B,H,N,D] contiguous fp32 (atomics). */
