@@ -1827,7 +1827,7 @@ static int fill_ga(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const e
   if (bias && g->bias_ld < g->Wk) return EA_E_BADARG;
   if (keep && g->keep_ld < g->Wk + g->L) return EA_E_BADARG;
   p.q = f32_mk(q); p.k = f32_mk(k); p.v = f32_mk(v); p.ek = f32_mk(g->L > 0 ? ek : nullptr); p.ev = f32_mk(g->L > 0 ? ev : nullptr);
-  p.idx_q = idx_q; p.idx_k = idx_k; p.bias = bias; p.bias_hs = g->bias_hs; p.bias_ld = g->bias_ld;
+  p.idx_q = idx_q; p.idx_k = idx_k; p.bias = bias; p.bias_hs = g->bias_hs; p.bias_bs = g->bias_bs; p.bias_ld = g->bias_ld;
   p.kmask = kmask; p.qmask = qmask; p.keep = keep; p.keep_ld = g->keep_ld; p.keep_scale = g->keep_scale;
   p.B = g->B; p.H = g->H; p.Nq = g->Nq; p.Nk = g->Nk; p.D = g->D; p.G = g->G; p.Wq = g->Wq; p.Wk = g->Wk; p.L = g->L;
   p.knorm = g->knorm & 1; p.zero_mv = (g->knorm >> 1) & 1; p.neg_inf = g->neg_inf; p.causal_e = g->causal_e; p.chunk = g->chunk; p.lm_base = g->lm_base;

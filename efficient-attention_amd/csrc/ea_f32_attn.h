@@ -15,8 +15,8 @@ struct GaP {
   float *dk, *dv;             // bwd: fp32 [B,H,Nk,D] contiguous, ACCUMULATED into (atomics; the caller zeroes them)
   float *dek, *dev;           // bwd: fp32 [B,H,L,D] contiguous, accumulated into; or null
   const int32_t *idx_q, *idx_k;   // [G,Wq], [G,Wk] token tables, -1 = absent
-  const float* bias;          // [*, Wq, bias_ld] added to the local logits, head stride bias_hs (0: shared); or null
-  int64_t bias_hs;
+  const float* bias;          // [*, *, Wq, bias_ld] added to the local logits: batch stride bias_bs and head stride bias_hs
+  int64_t bias_hs, bias_bs;   // (0: shared); or null.  A per-TOKEN bias is the one-group case (Wq = Nq): LARA's log alpha
   int bias_ld;
   float* dbias;               // bwd: same layout, accumulated into; or null
   const uint8_t *kmask, *qmask;   // [B,Nk] padded keys, [B,Nq] padded queries (causal EVA), or null

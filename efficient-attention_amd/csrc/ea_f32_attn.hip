@@ -102,12 +102,12 @@ EA_DEV void stage_keys(const GaP& p, int b, int h, int g, int kc0, float* Ks, fl
 
 // logit of (query row i of the block, key jl of the chunk) from the raw product `dot`; *live: the entry keeps its gradient
 struct QInfo { int tok, slot, lm_lim; bool pad; };
-EA_DEV float logit_of(const GaP& p, float dot, int h, const QInfo& qi, int j, int kind, int kflag, float kadd, bool& live) {
+EA_DEV float logit_of(const GaP& p, float dot, int b, int h, const QInfo& qi, int j, int kind, int kflag, float kadd, bool& live) {
   live = false;
   if (kind == 2 || kflag == 2) return -INFINITY;
   float x = dot * p.scale + kadd;
   if (kind == 0) {
-    if (p.bias && qi.tok >= 0) x += p.bias[(size_t)h * p.bias_hs + (size_t)qi.slot * p.bias_ld + j];
+    if (p.bias && qi.tok >= 0) x += p.bias[(size_t)b * p.bias_bs + (size_t)h * p.bias_hs + (size_t)qi.slot * p.bias_ld + j];
     if (kflag == 1 || qi.pad || (p.causal_e >= 0 && j > qi.slot + p.causal_e)) return MASK_FILL;
   } else {
     if (p.chunk > 0 && (j - p.Wk) >= qi.lm_lim) return MASK_FILL;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void ga_fwd_kernel(const GaP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         bool live;
-        s[ct][r] = logit_of(p, acc[r], h, qi[r], kc0 + jl, kkind[jl], kflag[jl], kadd[jl], live);
+        s[ct][r] = logit_of(p, acc[r], b, h, qi[r], kc0 + jl, kkind[jl], kflag[jl], kadd[jl], live);
         mx[r] = fmaxf(mx[r], s[ct][r]);
       }
     }
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         bool live;
-        const float x = logit_of(p, acc[r], h, qi[r], j, kkind[jl], kflag[jl], kadd[jl], live);
+        const float x = logit_of(p, acc[r], b, h, qi[r], j, kkind[jl], kflag[jl], kadd[jl], live);
         float pv = 0.f, ds = 0.f, kf = 1.f;
         if (qi[r].tok >= 0 && x != -INFINITY) {
           pv = __expf(x - lsr[r]) * lir[r];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NT) void ga_bwd_kernel(const GaP p) {
           ds = pv * (dp[r] * kf - dlt[r]);
           if (!live) ds = 0.f;
           else if (p.dbias && kkind[jl] == 0)
-            unsafeAtomicAdd(p.dbias + (size_t)h * p.bias_hs + (size_t)qi[r].slot * p.bias_ld + j, ds);
+            unsafeAtomicAdd(p.dbias + (size_t)b * p.bias_bs + (size_t)h * p.bias_hs + (size_t)qi[r].slot * p.bias_ld + j, ds);
         }
         const int row = 16 * wave + 4 * gq + r;
         Ps[row * PLD + jl] = pv * kf;

@@ -100,14 +100,20 @@ class GatherAttnFn(torch.autograd.Function):
         L = 0 if ek is None else ek.shape[2]
         if ek is not None:
             ek, ev = ek.contiguous(), ev.contiguous()
+        bias_hs = bias_bs = 0
         if bias is not None:
+            # [Hb, Wq, Wk] (Hb = H or 1) shared by the batch, or [B, H, Wq, Wk] (per-token bias of the one-group case)
             bias = bias.float().contiguous()
             assert bias.shape[-2] >= Wq and bias.shape[-1] >= Wk, (bias.shape, Wq, Wk)
+            plane = bias.shape[-2] * bias.shape[-1]
+            if bias.dim() == 4:
+                bias_hs, bias_bs = plane, plane * bias.shape[1]
+            elif bias.shape[0] != 1:
+                bias_hs = plane
         keep = spec.get("keep")
         g = nv.ea_f32_attn(B, H, Nq, Nk, D, G, Wq, Wk, L, int(spec.get("knorm", 0)) | (2 if spec.get("zero_masked_v") else 0),
                            int(spec.get("neg_inf", 0)), int(spec.get("causal_e", -1)), int(spec.get("chunk", 0)),
-                           int(spec.get("lm_base", 0)), 0 if bias is None else bias.shape[-1],
-                           0 if (bias is None or bias.shape[0] == 1) else bias.shape[-2] * bias.shape[-1],
+                           int(spec.get("lm_base", 0)), 0 if bias is None else bias.shape[-1], bias_hs, bias_bs,
                            0 if keep is None else keep.shape[-1], float(spec.get("keep_scale", 1.0)), float(spec["scale"]))
         # (query slots outside the sequence write nothing: zeros there when the table has such slots -- asked once per table)
         out = (torch.zeros if _has_absent(idx_q) else torch.empty)((B, Nq, H, D), dtype=torch.float32, device=q.device)
@@ -237,4 +243,64 @@ def eva_core(qkv5, bias, noise, mask_u8, attn_2d, seq_shape, window, ext, chunk,
     idx_q, idx_k = window_tables(attn_2d, seq_shape, window, ext, dev)
     out, _ = GatherAttnFn.apply(q, k, v, rf_k_bar.contiguous(), beta.contiguous(), bias,
                                 dict(idx_q=idx_q, idx_k=idx_k, kmask=m8, scale=scale))
+    return out.permute(0, 2, 1, 3)
+
+
+def _prm(data, proj, scale):
+    """prm_projection(normalize=False) (attn_utils.py:324-336,347): s proj.data^T - s |data|^2 / 2 -> [B,h,C,M] (tiny matrices)."""
+    return scale * proj @ data.transpose(-1, -2) - 0.5 * scale * (data * data).sum(-1).unsqueeze(-2)
+
+
+def lara_core(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scale):
+    """LinearRA's estimator (lara.py:187-246) in fp32.  The two contractions over the sequence -- kv_stats = softmax_m(log_proj_k) v
+    with its log-sum-exp, and the self-normalised combine out_n = sum_c softmax_c(log alpha + log_proj_q + lse_k - log_prop) kv_c --
+    run on the fp32 gathered-attention kernels (queries = the omega rows over all keys with the key-norm term; queries = the
+    tokens over the C sample rows with a per-token bias).  The [N x C] weight algebra in between (t = softmax over the sequence,
+    alpha, its clamp) and the [C x C] proposal densities are torch element-wise / reduction ops on fp32 tensors: a fidelity path.
+    mode: 0 one sample per landmark, 1 antithetic, 2 multi-sample (noise [B,h,2L,d])."""
+    q, k, v = _qkv(qkv5)
+    B, h, N, d = q.shape
+    dev = q.device
+    q_bar, mu = q_bar.float(), mu.float()
+    dup = False
+    if noise is None:
+        omega = mu
+    elif mode == 2:
+        omega, dup = mu.repeat(1, 1, 2, 1) + noise.float(), True
+    elif mode == 1:
+        omega, dup = torch.cat([mu + noise.float(), mu - noise.float()], -2), True
+    else:
+        omega = mu + noise.float()
+    omega = omega.contiguous()
+    C = omega.shape[2]
+    m8 = _mask(mask_u8)
+    rows_c = _cached(("row", C, str(dev)), lambda: torch.arange(C, device=dev, dtype=torch.int32).view(1, C))
+    all_n = _cached(("all", N, str(dev)), lambda: torch.arange(N, device=dev, dtype=torch.int32).view(1, N))
+    kv, lse_k = GatherAttnFn.apply(omega, k, v, None, None, None,
+                                   dict(idx_q=rows_c, idx_k=all_n, kmask=m8, neg_inf=1, knorm=1, scale=scale))
+    if mis_type == "mis-biased":
+        lpmu = _prm(mu, omega, scale)
+        log_alpha = scale * q @ mu.transpose(-1, -2)                       # [B,h,N,L]
+        if dup:
+            log_alpha = log_alpha.repeat(1, 1, 1, 2)
+        log_prop = torch.logsumexp(lpmu, -1)
+    elif mis_type == "mis-opt":
+        t = torch.softmax(scale * q @ q_bar.transpose(-1, -2), dim=-2)     # softmax over the SEQUENCE (lara.py:223): [B,h,N,L]
+        mu_c = mu
+        if dup:
+            mu_c, t = mu.repeat(1, 1, 2, 1), t.repeat(1, 1, 1, 2)
+        lpmu = _prm(mu_c, omega, scale)                                    # [B,h,C,C]
+        log_prop = torch.diagonal(lpmu, dim1=-1, dim2=-2)
+        bh = torch.exp(log_prop - torch.logsumexp(lpmu, -1))
+        alpha = bh.unsqueeze(-2) + alpha_coeff * (t - t.mean(-1, keepdim=True))
+        log_alpha = torch.log(alpha.clamp(min=1e-8))
+    elif mis_type == "mis-bh":
+        lpmu = _prm(mu, omega, scale)
+        log_alpha = None
+        log_prop = torch.logsumexp(lpmu, -1)
+    else:
+        raise NotImplementedError(mis_type)
+    cst = (lse_k - log_prop).unsqueeze(-2)                                 # [B,h,1,C]
+    bias = cst.expand(B, h, N, C) if log_alpha is None else log_alpha + cst
+    out, _ = GatherAttnFn.apply(q, omega, kv.contiguous(), None, None, bias, dict(idx_q=all_n, idx_k=rows_c, scale=scale))
     return out.permute(0, 2, 1, 3)

@@ -61,7 +61,8 @@ class ea_f32_attn(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("H", ctypes.c_int32), ("Nq", ctypes.c_int32), ("Nk", ctypes.c_int32), ("D", ctypes.c_int32),
                 ("G", ctypes.c_int32), ("Wq", ctypes.c_int32), ("Wk", ctypes.c_int32), ("L", ctypes.c_int32),
                 ("knorm", ctypes.c_int32), ("neg_inf", ctypes.c_int32), ("causal_e", ctypes.c_int32), ("chunk", ctypes.c_int32),
-                ("lm_base", ctypes.c_int32), ("bias_ld", ctypes.c_int32), ("bias_hs", ctypes.c_int64), ("keep_ld", ctypes.c_int64),
+                ("lm_base", ctypes.c_int32), ("bias_ld", ctypes.c_int32), ("bias_hs", ctypes.c_int64), ("bias_bs", ctypes.c_int64),
+                ("keep_ld", ctypes.c_int64),
                 ("keep_scale", ctypes.c_float), ("scale", ctypes.c_float)]
 
 

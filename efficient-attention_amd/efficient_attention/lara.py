@@ -15,12 +15,12 @@ import torch.nn.functional as F
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 from .abstract_attention import MultiheadAttention
 from .attn_utils import FlattenTranspose
 
 
 class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
-    _F32_CORE = False           # (no fp32-operand kernels for this variant yet: fp32 input is rounded to bf16 with a warning)
     def __init__(self, num_landmarks=49, kernel_size=None, proposal_gen='pool',
                  use_antithetics=False, use_multisample=False, pool_module_type='light',
                  mis_type='mis-opt', alpha_coeff=1.0, *args, **kwargs):
@@ -53,14 +53,15 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         self.apply(self._init_weights)
 
     # ---- landmark proposals (tiny [B,h,L,d] tensors; pooling reads q,k once) -------------
-    def _proposal_gen_2d(self, qkv5, H, W, slot=None, mix=True):
+    def _proposal_gen_2d(self, qkv5, H, W, slot=None, mix=True, pooled=None):
         """Adaptive 2-D average pool of q,k -> [Linear+LN] -> optional softmax mixing of k_bar
         (reference :129-175).  Returns q_bar, k_bar [B,h,L,d] fp32 and the '-vmixed' column bias of the
         mixing logits (or None); with mix=False the mixing itself is left to the landmark kernel."""
         B, N, _, h, d = qkv5.shape
         side = int(math.sqrt(self.num_landmarks))
         gen = self.proposal_gen
-        pq, pk, pv = _ops.pool2d_qkv(qkv5, H, W, side, slot, need_v=gen.endswith('-vmixed'))
+        # pooled: (pq, pk, pv | None) [B,h,L,d] computed by the caller (the fp32 path pools with nn.AdaptiveAvgPool2d itself)
+        pq, pk, pv = pooled if pooled is not None else _ops.pool2d_qkv(qkv5, H, W, side, slot, need_v=gen.endswith('-vmixed'))
         if gen.startswith('pool'):
             if self.pool_module_type == 'dense':
                 def dense(p, net):
@@ -183,6 +184,41 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
                                             lq.bias, lk.bias, nq.weight, nq.bias, nk.weight, nk.bias)
         return pq, pk, qkvE
 
+    def _forward_f32(self, x, key_padding_mask):
+        """fp32 activations outside autocast: fp32 Linear layers, the proposals as the reference forms them (adaptive pooling /
+        segment means, the generators' own Linear + LayerNorm, softmax mixing: tiny [B,h,L,d] tensors), the estimator on the
+        fp32 gathered-attention kernels (_f32.lara_core) -- lara.py:129-251 in the precision the reference computes it."""
+        B, *seq_shape, C = x.shape
+        N = int(math.prod(seq_shape))
+        h, d = self.num_heads, self.head_dim
+        qkv5 = self.project_qkv(x.reshape(B, N, C))
+        assert qkv5.dtype == torch.float32
+        mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+        mode = 0
+        if self.training:
+            mode = 2 if self.use_multisample else (1 if self.use_antithetics else 0)
+        if len(seq_shape) == 2:
+            H, W = seq_shape
+            side = int(math.sqrt(self.num_landmarks))
+            need_v = self.proposal_gen.endswith('-vmixed')
+
+            def pool(t):                                  # t [B,N,h,d] -> [B,h,side*side,d] (lara.py:43,48,145-151)
+                m = t.permute(0, 2, 3, 1).reshape(B * h, d, H, W)
+                return F.adaptive_avg_pool2d(m, side).reshape(B, h, d, side * side).transpose(-1, -2)
+            pooled = (pool(qkv5[:, :, 0]), pool(qkv5[:, :, 1]), pool(qkv5[:, :, 2]) if need_v else None)
+            q_bar, k_bar, _ = self._proposal_gen_2d(qkv5, H, W, None, mix=True, pooled=pooled)
+        else:
+            q_bar, k_bar, qkv5 = self._proposal_gen_1d(qkv5, key_padding_mask)
+        noise = None
+        if self.training:
+            nl = q_bar.shape[-2]
+            if self.use_multisample:
+                noise = torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=x.device)
+            else:
+                noise = torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=x.device))
+        out = _f32.lara_core(qkv5, mask, q_bar, q_bar + k_bar, noise, self.mis_type, float(self.alpha_coeff), mode, float(self.scale))
+        return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
     def _mlp_params(self):
         q, k = self.q_bar_gen, self.k_bar_gen
         return [q[2].weight, q[2].bias, q[3].weight, q[3].bias, k[2].weight, k[2].bias, k[3].weight, k[3].bias]
@@ -196,6 +232,9 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         # 'adaptive-1d' on the GPU.  Round 4: generator Linear + LayerNorm + segment mean in one HIP pass over the stored
         # q / k rows (_ops.SegLinLnMeanFn; d = 64), the projection stays 3C wide.  Otherwise (rounds 1-3) the per-token Linear
         # of q_bar_gen / k_bar_gen rides along in the qkv GEMM (two more groups of output columns).
+        # fp32 activations outside autocast (round 5): fp32 end to end -- _forward_f32
+        if self._F32_CORE and _f32.usable(x) and d in (32, 64, 128) and len(seq_shape) in (1, 2):
+            return self._forward_f32(x, key_padding_mask)
         ad1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and x.is_cuda)
         seglin = ad1d and d == 64 and _ops.USE_SEGLIN
         fold_1d = ad1d and not seglin and d in (32, 64)

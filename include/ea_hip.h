@@ -641,7 +641,7 @@ int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const flo
  *   group g (a window, a landmark chunk, or the whole sequence), query slot i -> token idx_q[g][i] of q [B,H,Nq,D],
  *   Wk local key slots j -> token idx_k[g][j] of k, v [B,H,Nk,D] (-1: absent = zero row, masked), then L extra keys / values
  *   ek, ev [B,H,L,D] shared by all groups (EVA: rf_k_bar / beta):
- *     logit_ij = scale q_i.k_j [- scale |k_j|^2 / 2 (knorm)] [+ bias[h bias_hs + i bias_ld + j]]
+ *     logit_ij = scale q_i.k_j [- scale |k_j|^2 / 2 (knorm)] [+ bias[b bias_bs + h bias_hs + i bias_ld + j]]
  *     masked (padded / absent key; padded query (qmask); causal_e >= 0 and j > i + causal_e): -5e4, or -inf for padded keys when
  *     neg_inf; extra key c masked (-5e4) when chunk > 0 and c >= lm_base + token(i) / chunk  (causal_eva.py:716-738)
  *     out_i = softmax over the Wk + L columns . [v ; ev] (dropout: keep [B,H,Nq,keep_ld] over those columns, kept entries x
@@ -656,7 +656,7 @@ typedef struct {
   int32_t knorm;                     /* bit 0: the key-norm term; bit 1: masked local keys carry a zero VALUE row (eva.py:167-176) */
   int32_t neg_inf, causal_e, chunk, lm_base;
   int32_t bias_ld;
-  int64_t bias_hs, keep_ld;
+  int64_t bias_hs, bias_bs, keep_ld;  /* bias index = b bias_bs + h bias_hs + i bias_ld + j (0 strides: shared) */
   float   keep_scale, scale;
 } ea_f32_attn;
 int ea_f32_attn_fwd(const ea_f32_attn* g, const ea_t4* q, const ea_t4* k, const ea_t4* v, const ea_t4* ek, const ea_t4* ev,
