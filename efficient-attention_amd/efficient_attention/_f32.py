@@ -304,3 +304,31 @@ def lara_core(qkv5, mask_u8, q_bar, mu, noise, mis_type, alpha_coeff, mode, scal
     bias = cst.expand(B, h, N, C) if log_alpha is None else log_alpha + cst
     out, _ = GatherAttnFn.apply(q, omega, kv.contiguous(), None, None, bias, dict(idx_q=all_n, idx_k=rows_c, scale=scale))
     return out.permute(0, 2, 1, 3)
+
+
+def causal_eva_core(qkv5, bias, noise, mask_u8, window, ext, chunk, causal, mu_fn, keep=None, keep_scale=1.0):
+    """CausalEVAttention's q, k, v -> out core (causal_eva.py:666-783) in fp32: chunks are never extended, the window extension
+    lies on the LEFT only, padded queries are masked as well as padded keys, and with `causal` a query sees the local keys up
+    to itself and the control variates of the chunks before its own; attention dropout over the Wk + L columns (keep
+    [B,h,N,Wk+L], the reference's layout).  qkv5 [B,N,3,h,d] (any strides with contiguous channels)."""
+    q, k, v = _qkv(qkv5)
+    B, h, N, d = q.shape
+    scale = d ** -0.5
+    dev = q.device
+    m8 = _mask(mask_u8)
+    idx_c = window_table_1d(N, chunk, 0, dev)
+    Cn = idx_c.shape[0]
+    qm = GatherMeanFn.apply(q, idx_c, m8)
+    km = GatherMeanFn.apply(k, idx_c, m8)
+    rf_k_bar, mu = mu_fn(qm, km)
+    omega = mu if noise is None else mu + noise.float()
+    rows = _cached(("rows", Cn, str(dev)), lambda: torch.arange(Cn, device=dev, dtype=torch.int32).view(Cn, 1))
+    beta, _ = GatherAttnFn.apply(omega.contiguous(), k, v, None, None, None,
+                                 dict(idx_q=rows, idx_k=idx_c, kmask=m8, knorm=1, zero_masked_v=1, scale=scale))
+    idx_q = window_table_1d(N, window, 0, dev)
+    idx_k = window_table_1d(N, window, ext, dev, left_only=True)
+    spec = dict(idx_q=idx_q, idx_k=idx_k, kmask=m8, qmask=m8, scale=scale, keep=keep, keep_scale=keep_scale)
+    if causal:
+        spec.update(causal_e=ext, chunk=chunk)
+    out, _ = GatherAttnFn.apply(q, k, v, rf_k_bar.contiguous(), beta.contiguous(), bias, spec)
+    return out.permute(0, 2, 1, 3)

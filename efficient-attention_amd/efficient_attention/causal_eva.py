@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 from .eva import T5RelativePositionBias
 
 
@@ -35,6 +36,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                  self_attention=False, q_noise=0.0, qn_block_size=8, attn_args=None):
         super().__init__()
         self._incremental_state_id = str(uuid.uuid4())
+        self._f32_full = False
         self.embed_dim = embed_dim
         self.kdim = embed_dim if kdim is None else kdim
         self.vdim = embed_dim if vdim is None else vdim
@@ -131,7 +133,8 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                 "the windowed path needs keys/values aligned with the queries"
             qkv = torch.stack([_ops.linear(query, self.q_proj), _ops.linear(key, self.k_proj),
                                _ops.linear(value, self.v_proj)], dim=2)
-        qkv = _ops.to_io_dtype(qkv)
+        if not (self._f32_full and _f32.usable(qkv) and self.head_dim in (32, 64, 128)):
+            qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(N, B, 3, self.num_heads, self.head_dim)
 
     def forward(self, query, key, value, key_padding_mask=None, incremental_state=None,
@@ -160,10 +163,14 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             if key_padding_mask is not None:
                 mask[:, :tgt_len] = key_padding_mask.to(torch.bool)
             mask[:, tgt_len:] = True
-        if self.self_attention:
-            qkv5 = self._project(x, None, None)
-        else:
-            qkv5 = self._project(x, padded(key), padded(value))
+        self._f32_full = True                             # (the full-sequence path has fp32 cores; decoding does not)
+        try:
+            if self.self_attention:
+                qkv5 = self._project(x, None, None)
+            else:
+                qkv5 = self._project(x, padded(key), padded(value))
+        finally:
+            self._f32_full = False
         qkv5 = qkv5.transpose(0, 1)                       # [B, N, 3, h, d] view of the time-first buffer
 
         r = self.chunk_size if self.chunk_size is not None else int(N // self.num_chunks)
@@ -178,10 +185,19 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         noise = None
         if self.training:
             noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
-        cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
-               2 if self.causal else 1, 1.0) + self._dropout_keep(B, h, N, w + e, L, x.device)
-        out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
-                                   *self._mu_params())
+        if qkv5.dtype == torch.float32:
+            # fp32 activations outside autocast (round 5): the core on the fp32-faithful kernels (causal_eva.py:666-783 in the
+            # precision the reference computes it), the mu networks as the module's own layers
+            def mu_fn(qm, km):
+                rq, rk = self.adaptive_mu_q(qm), self.adaptive_mu_k(km)
+                return rk, rq + rk
+            out = _f32.causal_eva_core(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), w, e, r, bool(self.causal), mu_fn,
+                                       *self._dropout_keep(B, h, N, w + e, L, x.device, raw=True))
+        else:
+            cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
+                   2 if self.causal else 1, 1.0) + self._dropout_keep(B, h, N, w + e, L, x.device)
+            out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
+                                       *self._mu_params())
         # out [B, N, h, d] comes back as a view of a time-first buffer (it follows qkv's layout)
         y = _ops.linear(out.transpose(0, 1).reshape(N, B, C), self.out_proj)
         if not torch.is_autocast_enabled() and y.dtype != query.dtype:
@@ -301,7 +317,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             y = y.to(query.dtype)
         return y.contiguous(), None
 
-    def _dropout_keep(self, B, h, N, Wk, L, device):
+    def _dropout_keep(self, B, h, N, Wk, L, device, raw=False):
         """Attention dropout (reference :778, `attn = dropout(attn)` on the [.., Wk + L] softmax rows):
         the Bernoulli keep decisions are drawn here -- one per (query, column), the reference's
         layout -- and handed to the kernels as a uint8 mask; -> (keep, 1/(1-p)) or ()."""
@@ -314,6 +330,8 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             keep = self._keep_mask_fn((B, h, N, Wk + L)).to(device=device, dtype=torch.uint8)
         else:
             keep = torch.empty((B, h, N, Wk + L), device=device, dtype=torch.uint8).bernoulli_(1 - p)
+        if raw:                                                    # the reference's own layout (the fp32 cores take it as is)
+            return (keep.contiguous(), 1.0 / (1.0 - p))
         # kernel layout: local columns padded to whole 16-key tiles, then the landmarks
         ld_local, ld_lm = -(-Wk // 16) * 16, -(-L // 16) * 16
         if ld_local != Wk or ld_lm != L:

@@ -18,18 +18,44 @@ import torch
 
 from . import add_nested_argument
 from . import _ops
+from . import _f32
 from .abstract_attention import MultiheadAttention
 
 
 class RandomizedAttention(MultiheadAttention):
-    _F32_CORE = False           # (no fp32-operand kernels for this variant yet: fp32 input is rounded to bf16 with a warning)
     def __init__(self, num_samples=1, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.num_samples = num_samples
         self._sample_index_fn = None                   # tests: injected draws
         self.apply(self._init_weights)
 
+    def _attend_f32(self, qkv5):
+        """fp32 activations outside autocast (round 5): both softmax passes on the fp32 gathered-attention kernels
+        (randomized_attention.py:21-52 in the precision the reference computes it)."""
+        q, k, v = _f32._qkv(qkv5)
+        B, h, N, d = q.shape
+        all_n = _f32._cached(("all", N, str(q.device)), lambda: torch.arange(N, device=q.device, dtype=torch.int32).view(1, N))
+        spec = dict(idx_q=all_n, idx_k=all_n, scale=self.scale)
+        if self.num_samples == 0:
+            mu = q + k.mean(dim=-2, keepdim=True)
+        elif self.num_samples == -1:
+            mu = q + _f32.GatherAttnFn.apply(q, k, k, None, None, None, spec)[0]
+        else:
+            with torch.no_grad():
+                if self._sample_index_fn is not None:
+                    index = self._sample_index_fn((B, h, N)).to(device=q.device, dtype=torch.int64)
+                else:
+                    # the draw itself comes from the 16-bit Gumbel-max pass (a sample, not a value: its logits carry bf16 rounding)
+                    q16, k16, _ = _ops._qkv_views(qkv5.detach().to(torch.bfloat16))
+                    index = _ops.softmax_sample(q16, k16)
+            mu = q + torch.gather(k, 2, index.unsqueeze(-1).expand(B, h, N, d))
+        w = mu + torch.randn_like(mu) if self.training else mu
+        out, _ = _f32.GatherAttnFn.apply(w.contiguous(), k, v, None, None, None, dict(spec, knorm=1))
+        return out.permute(0, 2, 1, 3)
+
     def _attend(self, qkv5, key_padding_mask, seq_shape):
+        if qkv5.dtype == torch.float32:
+            return self._attend_f32(qkv5)
         q, k, v = _ops._qkv_views(qkv5)                 # [B,h,N,d] views of the projection output
         B, h, N, d = q.shape
         if self.num_samples == 0:

@@ -15,7 +15,7 @@ for p in (ROOT, os.path.join(ROOT, "efficient-attention_amd"), HERE, os.path.joi
     if p not in sys.path:
         sys.path.insert(0, p)
 
-F32_FIXTURES = sorted(os.path.basename(f)[:-4] for pat in ("softmax_*", "local_*", "eva_*", "lara_*")
+F32_FIXTURES = sorted(os.path.basename(f)[:-4] for pat in ("softmax_*", "local_*", "eva_*", "lara_*", "ra_*", "causal_eva_*")
                       for f in glob.glob(os.path.join(HERE, "golden", pat + ".npz")))
 F32_TOL = (2e-4, 1e-4)
 
@@ -44,7 +44,7 @@ def test_module_fp32_outside_autocast_matches_reference(name, mode):
     finally:
         nv.call = real
     assert errs and "ea_f32_attn_fwd" in calls and "ea_f32_attn_bwd" in calls, sorted(set(calls))
-    assert not [c for c in calls if c.startswith(("ea_window", "ea_softmax", "ea_eva_", "ea_lara_"))], sorted(set(calls))
+    assert not [c for c in calls if c.startswith(("ea_window", "ea_softmax", "ea_eva_", "ea_lara_", "ea_rows_mlp"))], sorted(set(calls))
 
 
 def _rel(a, b):
@@ -137,15 +137,15 @@ def test_f32_local_and_eva_cores_match_fp64_oracle(attn_2d, shape, w, e, d, mask
 
 @pytest.mark.gpu
 def test_other_variants_still_round_fp32_input_with_a_warning():
-    """RA / ScatterBrain have no fp32-operand cores yet: fp32 input outside autocast is rounded to bf16 and the caller is
+    """ScatterBrain has no fp32-operand core yet: fp32 input outside autocast is rounded to bf16 and the caller is
     told (once per process: _ops._FP32_WARNED is reset here)."""
     import warnings
     import torch
     import efficient_attention as ea
     from efficient_attention import _ops
-    m = ea.AttentionFactory.build_attention("ra", dict(dim=128, num_heads=2)).cuda().eval()
+    m = ea.AttentionFactory.build_attention("scatterbrain", dict(dim=128, num_heads=2, window_size=4)).cuda().eval()
     _ops._FP32_WARNED[0] = False
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        y = m(torch.randn(2, 8, 8, 128, device="cuda"))
+        y = m(torch.randn(2, 32, 128, device="cuda"))
     assert y.dtype == torch.float32 and any("rounded to bf16" in str(w.message) for w in rec)
