@@ -80,6 +80,8 @@ class MultiheadAttention(nn.Module):
         qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads)
 
+    project_qkv._ea_builtin = True
+
     def proj_and_split_heads(self, x):
         """Reference-compatible helper (:72-78): three [B, h, N, d] strided views."""
         B, *seq_shape, C = x.shape
@@ -99,7 +101,11 @@ class MultiheadAttention(nn.Module):
         B, *seq_shape, C = x.shape
         N = int(math.prod(seq_shape))
         # the common training case as ONE autograd node (projections + core, round 4): decided before anything is launched
+        # (a subclass that overrides project_qkv / merge_and_project -- q/k norms, LoRA on qkv ... -- keeps the three-node path
+        #  that calls them: ADVICE r04)
         if (torch.is_autocast_enabled() and x.is_cuda and (self.proj_drop.p == 0.0 or not self.training)
+                and getattr(type(self).project_qkv, "_ea_builtin", False)
+                and type(self).merge_and_project is MultiheadAttention.merge_and_project
                 and _ops.core_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda"))):
             core, inputs = self._core_spec(B, N, seq_shape, key_padding_mask, x.device)
             if core is not None:

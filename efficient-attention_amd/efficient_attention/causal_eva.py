@@ -245,6 +245,12 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                                       "depends on the final sequence length)")
         dev = query.device
         state = self._get_input_buffer(incremental_state)
+        # the 64-landmark limit is checked BEFORE anything is projected or any state buffer is created: the window
+        # kernel takes at most 64 landmark rows (ea_window.h), and every completed chunk is one
+        t_seen = int(self.get_incremental_state(incremental_state, "attn_pos") or 0) if "qkv" in state else 0
+        if (t_seen + T_new - 1) // r > 64:
+            raise NotImplementedError("incremental decoding beyond 65 chunks (%d tokens at chunk size %d): the window kernel "
+                                      "holds 64 landmark rows" % (65 * r, r))
         qkv_new = self._project(query, None, None)                 # [T_new, B, 3, h, d]
         if "qkv" not in state:
             cap = max(2 * w, 64)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from . import add_nested_argument
 from . import _ops
 from . import _f32
+from .abstract_attention import MultiheadAttention
 from .local_attention import LocalAttention
 
 
@@ -162,7 +163,8 @@ class EVA(LocalAttention):
         pooled = None
         # the common training case as ONE autograd node (projections + core, round 4): decided before anything is launched
         if (torch.is_autocast_enabled() and x.is_cuda and (self.proj_drop.p == 0.0 or not self.training)
-                and w > 0 and self.num_landmarks > 0):
+                and w > 0 and self.num_landmarks > 0 and getattr(type(self).project_qkv, "_ea_builtin", False)
+                and type(self).merge_and_project is MultiheadAttention.merge_and_project):
             r0 = int(math.sqrt(N // self.num_landmarks)) if self.attn_2d else int(N // self.num_landmarks)
             ok_geo = r0 > 0 and (e > 0 or (all(s_ % r0 == 0 for s_ in seq_shape) if self.attn_2d else N % r0 == 0))
             L0 = ((seq_shape[0] // r0) * (seq_shape[1] // r0) if self.attn_2d else N // r0) if r0 > 0 else 0
@@ -188,7 +190,7 @@ class EVA(LocalAttention):
                 assert seq_shape[0] % r == 0 and seq_shape[1] % r == 0
             Wq, Wk = w * w, (w + 2 * e) ** 2
             grid = (B, seq_shape[0], seq_shape[1], r)
-            if e == 0 and key_padding_mask is None and _ops.linear_pool_usable(x, self.qkv, grid, h):
+            if e == 0 and key_padding_mask is None and L <= 64 and _ops.linear_pool_usable(x, self.qkv, grid, h):
                 # the chunk means of q, k (eva.py:178-181 on 2-D chunks without extension) leave the projection kernel
                 # with qkv: no second pass over q, k (round 4)
                 y, pq, pk = _ops.LinearPoolFn.apply(x.reshape(B, N, C), self.qkv.weight, self.qkv.bias,
@@ -219,6 +221,12 @@ class EVA(LocalAttention):
         if qkv5.dtype == torch.float32:
             # fp32 outside autocast (round 5): the core on the fp32-faithful kernels, the mu networks as the module's own layers
             out = _f32.eva_core(qkv5, bias, noise, mask, self.attn_2d, tuple(seq_shape), w, e, r, self._mu_f32)
+        elif L > 64 and _f32.ENABLED:
+            # more landmarks than the 16-bit window kernels hold (64): the generic fp32 kernels on the 16-bit activations
+            # (exact in fp32) -- the reference takes any --num-landmarks (eva.py:155-164)
+            with torch.autocast(device_type="cuda", enabled=False):
+                out = _f32.eva_core(qkv5.float(), None if bias is None else bias.float(), noise, mask, self.attn_2d,
+                                    tuple(seq_shape), w, e, r, self._mu_f32).to(qkv5.dtype)
         else:
             out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask, cfg, *self._mu_params())
         y = self.merge_and_project(out, B, seq_shape, C, x.dtype)

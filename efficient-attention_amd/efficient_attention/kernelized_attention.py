@@ -87,6 +87,8 @@ class KernelizedAttention(MultiheadAttention):
             return _ops.linear(x, self.qkv).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         return super().project_qkv(x)
 
+    project_qkv._ea_builtin = True
+
     def _core_spec(self, B, N, seq_shape, key_padding_mask, device):
         """The single-node path (_ops.CoreModuleFn, round 4) for the exact-fp32 core; everything else keeps the three nodes."""
         if (type(self)._attend is not KernelizedAttention._attend or _ops.PERFORMER_16BIT or self.head_dim != 64

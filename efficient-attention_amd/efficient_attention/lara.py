@@ -184,16 +184,23 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
                                             lq.bias, lk.bias, nq.weight, nq.bias, nk.weight, nk.bias)
         return pq, pk, qkvE
 
-    def _forward_f32(self, x, key_padding_mask):
+    def _forward_f32(self, x, key_padding_mask, qkv5=None):
         """fp32 activations outside autocast: fp32 Linear layers, the proposals as the reference forms them (adaptive pooling /
         segment means, the generators' own Linear + LayerNorm, softmax mixing: tiny [B,h,L,d] tensors), the estimator on the
         fp32 gathered-attention kernels (_f32.lara_core) -- lara.py:129-251 in the precision the reference computes it."""
         B, *seq_shape, C = x.shape
         N = int(math.prod(seq_shape))
         h, d = self.num_heads, self.head_dim
-        qkv5 = self.project_qkv(x.reshape(B, N, C))
-        assert qkv5.dtype == torch.float32
-        mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+        if qkv5 is None or qkv5.shape[2] != 3:
+            qkv5 = self.project_qkv(x.reshape(B, N, C))
+        io = qkv5.dtype
+        with torch.autocast(device_type="cuda", enabled=False):
+            out = self._core_f32(qkv5.float(), key_padding_mask, seq_shape).to(io)
+        return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+    def _core_f32(self, qkv5, key_padding_mask, seq_shape):
+        B, N, _, h, d = qkv5.shape
+        mask = _ops._mask_u8(key_padding_mask, B, N, qkv5.device)
         mode = 0
         if self.training:
             mode = 2 if self.use_multisample else (1 if self.use_antithetics else 0)
@@ -213,11 +220,10 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         if self.training:
             nl = q_bar.shape[-2]
             if self.use_multisample:
-                noise = torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=x.device)
+                noise = torch.randn(B, h, nl * 2, d, dtype=torch.float32, device=qkv5.device)
             else:
-                noise = torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=x.device))
-        out = _f32.lara_core(qkv5, mask, q_bar, q_bar + k_bar, noise, self.mis_type, float(self.alpha_coeff), mode, float(self.scale))
-        return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+                noise = torch.randn_like(torch.empty(B, h, nl, d, dtype=torch.float32, device=qkv5.device))
+        return _f32.lara_core(qkv5, mask, q_bar, q_bar + k_bar, noise, self.mis_type, float(self.alpha_coeff), mode, float(self.scale))
 
     def _mlp_params(self):
         q, k = self.q_bar_gen, self.k_bar_gen
@@ -236,10 +242,14 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         if self._F32_CORE and _f32.usable(x) and d in (32, 64, 128) and len(seq_shape) in (1, 2):
             return self._forward_f32(x, key_padding_mask)
         ad1d = (len(seq_shape) == 1 and gen.startswith('adaptive-1d') and N > L and x.is_cuda)
-        seglin = ad1d and d == 64 and _ops.USE_SEGLIN
+        # (ea_lara_seglin_* evaluates nn.LayerNorm with its default eps = 1e-5: another eps keeps the folded path -- ADVICE r04)
+        seglin = (ad1d and d == 64 and _ops.USE_SEGLIN and self.q_bar_gen[1].eps == 1e-5 and self.k_bar_gen[1].eps == 1e-5
+                  and _ops._DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0)
         fold_1d = ad1d and not seglin and d in (32, 64)
         # the common 2-D training case as ONE autograd node (projections + core): decided before anything is launched
         module_fn = (len(seq_shape) == 2 and not fold_1d and torch.is_autocast_enabled()
+                     and getattr(type(self).project_qkv, "_ea_builtin", False)
+                     and type(self).merge_and_project is MultiheadAttention.merge_and_project
                      and (self.proj_drop.p == 0.0 or not self.training)
                      and _ops.lara_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda")))
         qkv5 = None
@@ -255,6 +265,10 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         # ---- landmark proposals.  Fused HIP pipeline whenever the sample count fits (C <= 64) ----
         side = int(math.sqrt(L))
         n_lm = side * side if len(seq_shape) == 2 else min(L, N)
+        if n_lm * (2 if dup else 1) > 128 and _f32.ENABLED and x.is_cuda and d in (32, 64, 128):
+            # more samples than the 16-bit estimator kernels hold (128): the generic fp32 kernels on the 16-bit activations
+            # (exact in fp32) -- the reference takes any --num-landmarks (lara.py:188-196)
+            return self._forward_f32(x, key_padding_mask, qkv5=qkv5)
         fused_b = n_lm * (2 if dup else 1) <= 64 and d in (32, 64)
         fused_a = (fused_b and len(seq_shape) == 2 and self.pool_module_type == 'light'
                    and not gen.endswith('-vmixed') and (gen.startswith('pool') or gen.startswith('no-param-pool'))

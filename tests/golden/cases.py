@@ -40,6 +40,10 @@ CASES = {
         attn="eva", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2, window_size=7, attn_2d=True, use_t5_rpe=True,
                   num_landmarks=49, adaptive_proj="no-ln")),
+    "eva_2d_L100": dict(  # 100 landmarks (> the 64 the 16-bit window kernels hold): the generic fp32 kernels take it (round 5)
+        attn="eva", x_shape=(1, 20, 20, 64), mask=None,
+        args=dict(dim=64, num_heads=2, window_size=5, attn_2d=True, use_rpe=True,
+                  num_landmarks=100, adaptive_proj="default")),
     "eva_1d_mask_overlap_t5": dict(  # N=50 not a multiple of w=8 -> padded to 56, 7 chunks of 8
         attn="eva", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
         args=dict(dim=128, num_heads=2, window_size=8, attn_2d=False, use_t5_rpe=True,
@@ -56,6 +60,10 @@ CASES = {
     "lara_2d_poolmixed_784": dict(  # BASELINE.json configs[2] geometry (headline metric)
         attn="lara", x_shape=(1, 28, 28, 192), mask=None,
         args=dict(dim=192, num_heads=3, num_landmarks=49, proposal_gen="pool-mixed",
+                  mis_type="mis-opt", alpha_coeff=2.0)),
+    "lara_2d_L144": dict(  # 144 samples (> the 128 of the 16-bit estimator kernels): the generic fp32 kernels take it (round 5)
+        attn="lara", x_shape=(1, 24, 24, 64), mask=None,
+        args=dict(dim=64, num_heads=2, num_landmarks=144, proposal_gen="pool-mixed",
                   mis_type="mis-opt", alpha_coeff=2.0)),
     "lara_2d_pool_biased": dict(
         attn="lara", x_shape=(1, 14, 14, 128), mask=None,
