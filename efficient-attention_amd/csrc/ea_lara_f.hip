@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
         if (c == 0) SC1[row] = rok ? dot : 0.f;
       }
     }
-    if (blk == 0) {
+    if (blk == p.nsplit - 1) {                   // (the LAST slice of a (b,h): with uneven slices it is the short one)
       // what the later passes read: sum dZ q (d omega, query side), d qbar rows = s (M1 - u M2) [mis-opt] | s sum dZ q
       // [mis-biased], u qbar (the finish pass), and the per-landmark scalars dbh, dlp = -r
       const bool opt = p.mis == MIS_OPT, biased = p.mis == MIS_BIASED;

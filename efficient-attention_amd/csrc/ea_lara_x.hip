@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
         const float f[8] = {a0.x * iv, a0.y * iv, a0.z * iv, a0.w * iv, a1.x * iv, a1.y * iv, a1.z * iv, a1.w * iv};
         const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         sts16(R3 + TileL<D>::off(row, c), pack8<E>(rok ? f : z8));
-        if (rok && blk == 0) {
+        if (rok && blk == p.nsplit - 1) {
           float* dst = p.m_kv + (lm + row) * D + c * 8;
           *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
           *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, NCT <= 4 ? 3 : 1) void lara_x_kernel(const Lar
     }
   }
 
-  if (MODE == LX_FWDM && blk == 0 && tid < p.C) {            // the merged scalars, for the backward
+  if (MODE == LX_FWDM && blk == p.nsplit - 1 && tid < p.C) {            // the merged scalars, for the backward
     p.m_lsek[lm + tid] = mg_lsek;
     p.m_cst[lm + tid] = mg_cst;
     if (mis == MIS_OPT) p.m_lset[lm + tid] = mg_lset;

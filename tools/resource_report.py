@@ -23,12 +23,14 @@ LLVM = os.environ.get("EA_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
 def _demangle(names):
-    try:
-        out = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")], input="\n".join(names), stdout=subprocess.PIPE, text=True,
-                             check=True).stdout.splitlines()
-        return dict(zip(names, out))
-    except Exception:
-        return {n: n for n in names}
+    for tool in (os.path.join(LLVM, "llvm-cxxfilt"), "c++filt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+            if len(out) == len(names):
+                return dict(zip(names, out))
+        except Exception:
+            pass
+    return {n: n for n in names}
 
 
 def kernels(lib=LIB):
