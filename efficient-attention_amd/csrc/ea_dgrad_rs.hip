@@ -100,8 +100,8 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_rs_kernel(const DgP p)
     char* const tb = buf ? tile1 : tile0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) sts16(tb + dg_off(s_ch[i] >> 3, s_tok[i], s_ch[i] & 7), nb[i]);
-    if (t + (int)gridDim.x < p.ntiles) issue(t + gridDim.x);
-    __syncthreads();
+    issue(min(t + (int)gridDim.x, p.ntiles - 1));         // unconditional (the last tile is fetched once more): a static count of
+    __syncthreads();                                      // memory operations lets the next commit wait for ITS loads only
     // ---- [16 columns x 32 tokens] piece of this wave: four accumulation chains (two per token half) ----
     f32x4 acc[2][2];
 #pragma unroll
@@ -158,7 +158,7 @@ constexpr int DG_QT = 3 * DG_TOK * 128;                   // q rows of a tile: 1
 constexpr int DG_LMR = 64 * 128;                          // one [64][64] landmark matrix, 16-bit: 8 KB
 constexpr int DG_FIN_LDS = 2 * DG_TILE + 2 * DG_QT + 6 * DG_LMR + 3 * 64 * 4;
 
-template <typename E, bool WF32, bool OF32, bool HAS_T>
+template <typename E, bool WF32, bool OF32, bool HAS_T, bool POOL>
 __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const tile0 = smem;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
   float* const LS = reinterpret_cast<float*>(R2 + 3 * DG_LMR);   // lse_t in log2 units, +inf beyond C
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool pool = p.dpq != nullptr;
+  constexpr bool pool = POOL;                             // (compile-time: the loop's memory-operation counts must be static)
   // ---- staging slot of this thread: token s_tok of the tile, 16-byte chunk s_c of its q, its k and its v columns (32 tokens
   // x 24 chunks = 768 threads; chunk s_c = head s_c >> 3, channels 8 (s_c & 7) ..) -- which slot is q / k / v is static, so
   // only the rows that take a pooling term carry one in flight ----
@@ -258,17 +258,22 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         const int idx = tid + j * (DG_WAVES * 64);          // 6 matrices x 64 rows x 8 chunks = 3072 slots
         const int m = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
         const float* src = (m < 3 ? p.uq : p.qbar) + ((size_t)(b * 3 + (m < 3 ? m : m - 3)) * p.C + min(row, p.C - 1)) * 64 + c * 8;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[j][0] = row < p.C ? *reinterpret_cast<const f32x4*>(src) : z;
-        rb[j][1] = row < p.C ? *reinterpret_cast<const f32x4*>(src + 4) : z;
+        // unconditional loads from clamped rows, pinned (`cond ? load : 0` comes back as a predicated load with a full wait
+        // behind it: DESIGN section 4, round 3): all eight are in flight together, rows beyond C are zeroed afterwards
+        rb[j][0] = *reinterpret_cast<const f32x4*>(src);
+        rb[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        asm volatile("" : "+v"(rb[j][0]), "+v"(rb[j][1]));
       }
-      float lsv = INFINITY;
-      if (tid < 192 && (tid & 63) < p.C) lsv = p.lse_t[(size_t)(b * 3 + (tid >> 6)) * p.C + (tid & 63)] * LOG2E;
+      float lsv = p.lse_t[(size_t)(b * 3 + min(tid >> 6, 2)) * p.C + min(tid & 63, p.C - 1)] * LOG2E;
+      asm volatile("" : "+v"(lsv));
+      if (!(tid < 192 && (tid & 63) < p.C)) lsv = INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = tid + j * (DG_WAVES * 64);
         const int m = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
-        const float f[8] = {rb[j][0][0], rb[j][0][1], rb[j][0][2], rb[j][0][3], rb[j][1][0], rb[j][1][1], rb[j][1][2], rb[j][1][3]};
+        const float zr = row < p.C ? 1.f : 0.f;
+        const float f[8] = {rb[j][0][0] * zr, rb[j][0][1] * zr, rb[j][0][2] * zr, rb[j][0][3] * zr,
+                            rb[j][1][0] * zr, rb[j][1][1] * zr, rb[j][1][2] * zr, rb[j][1][3] * zr};
         sts16((m < 3 ? R1 + m * DG_LMR : R2 + (m - 3) * DG_LMR) + TileL<64>::off(row, c), pack8<E>(f));
       }
       if (tid < 192) LS[tid] = lsv;
@@ -300,19 +305,21 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         sts16(tb + dg_off(6 + (s_c >> 3), s_tok, s_c & 7), nb[2]);
         if constexpr (HAS_T) sts16(qb + dg_off(s_c >> 3, s_tok, s_c & 7), nq);
       }
-      if (t + 1 < ntile) issue(t + 1);
+      // the pooled-q rows of this wave's correction piece: requested BEFORE the next tile's rows, so that waiting for them
+      // (the memory counter retires in order) leaves that prefetch in flight
+      f32x4 pq4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if constexpr (HAS_T && POOL) {
+        const float* src = p.dpq + ((size_t)(b * 3 + fh) * p.L + cell_of(tok_of(t, 16 * fnt + li))) * 64 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pq4[j] = *reinterpret_cast<const f32x4*>(src + 16 * (2 * fdh + j));
+      }
+      issue(min(t + 1, ntile - 1));                        // unconditional (static operation count; the last tile is fetched twice)
       __syncthreads();
       if constexpr (HAS_T) {
         // ---- dq -= s sum_c t[c,n] (u qbar)_c (+ the pooled-q term) for (head fh, tokens 16 fnt .., channels 32 fdh ..) ----
         const char* R1h = R1 + fh * DG_LMR;
         const char* R2h = R2 + fh * DG_LMR;
         const float* LSh = LS + fh * 64;
-        f32x4 pq4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        if (pool) {                                        // (latency hidden behind the score products below)
-          const float* src = p.dpq + ((size_t)(b * 3 + fh) * p.L + cell_of(tok_of(t, 16 * fnt + li))) * 64 + 4 * g;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) pq4[j] = *reinterpret_cast<const f32x4*>(src + 16 * (2 * fdh + j));
-        }
         typename E::x8 f1[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) f1[ks] = as_x8<E>(lds16(qb + dg_off(fh, 16 * fnt + li, g * 2 + ks)));
@@ -418,12 +425,17 @@ int dgrad_fin_dispatch(int dtype, const DgFinP& p0, int w_f32, int dx_f32, bool 
   int grid = ea_device_cus();
   if (grid > p.nunits) grid = p.nunits;
   const dim3 g((unsigned)grid), b(DG_WAVES * 64);
-#define EA_DF_LAUNCH(E_, WF_, OF_, T_)                                                    \
-  do {                                                                                    \
-    EA_SET_LDS_ONCE((&dgrad_fin_kernel<E_, WF_, OF_, T_>), DG_FIN_LDS);                   \
-    hipLaunchKernelGGL((dgrad_fin_kernel<E_, WF_, OF_, T_>), g, b, DG_FIN_LDS, st, p);    \
+#define EA_DF_LAUNCH(E_, WF_, OF_, T_, P_)                                                    \
+  do {                                                                                        \
+    EA_SET_LDS_ONCE((&dgrad_fin_kernel<E_, WF_, OF_, T_, P_>), DG_FIN_LDS);                   \
+    hipLaunchKernelGGL((dgrad_fin_kernel<E_, WF_, OF_, T_, P_>), g, b, DG_FIN_LDS, st, p);    \
   } while (0)
-#define EA_DF_SEL2(E_, WF_, OF_) do { if (has_t) EA_DF_LAUNCH(E_, WF_, OF_, true); else EA_DF_LAUNCH(E_, WF_, OF_, false); } while (0)
+#define EA_DF_SEL2(E_, WF_, OF_)                                                              \
+  do {                                                                                        \
+    if (has_t && p.dpq) EA_DF_LAUNCH(E_, WF_, OF_, true, true);                               \
+    else if (has_t) EA_DF_LAUNCH(E_, WF_, OF_, true, false);                                  \
+    else EA_DF_LAUNCH(E_, WF_, OF_, false, true);                                             \
+  } while (0)
 #define EA_DF_SEL(E_)                                                                     \
   do {                                                                                    \
     if (w_f32) { if (dx_f32) EA_DF_SEL2(E_, true, true); else EA_DF_SEL2(E_, true, false); }   \

@@ -65,19 +65,6 @@ def window_tables(attn_2d, seq_shape, side, ext, device):
     return window_table_1d(n, side, 0, device), window_table_1d(n, side, ext, device)
 
 
-_ABSENT = {}
-
-
-def _has_absent(idx):
-    key = (idx.data_ptr(), tuple(idx.shape))
-    v = _ABSENT.get(key)
-    if v is None:
-        v = bool((idx < 0).any())
-        if len(_ABSENT) < 1024:
-            _ABSENT[key] = v
-    return v
-
-
 def _t4(t):
     assert t.dim() == 4 and t.stride(3) == 1 and t.dtype == torch.float32, (t.shape, t.stride(), t.dtype)
     return nv.t4(t)
@@ -115,8 +102,9 @@ class GatherAttnFn(torch.autograd.Function):
                            int(spec.get("neg_inf", 0)), int(spec.get("causal_e", -1)), int(spec.get("chunk", 0)),
                            int(spec.get("lm_base", 0)), 0 if bias is None else bias.shape[-1], bias_hs, bias_bs,
                            0 if keep is None else keep.shape[-1], float(spec.get("keep_scale", 1.0)), float(spec["scale"]))
-        # (query slots outside the sequence write nothing: zeros there when the table has such slots -- asked once per table)
-        out = (torch.zeros if _has_absent(idx_q) else torch.empty)((B, Nq, H, D), dtype=torch.float32, device=q.device)
+        # (every token of the sequence is the query slot of exactly one group, so every row of `out` is written; slots of the
+        #  table that leave the sequence (-1) write nothing)
+        out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
         stat = torch.empty((B, H, Nq, 2), dtype=torch.float32, device=q.device)     # (row max, row sum): what the backward reads
         ov = out.permute(0, 2, 1, 3)
