@@ -138,6 +138,9 @@ CASES = {
     "performer_1d_mask": dict(
         attn="performer", x_shape=(2, 50, 128), mask=("tail", [0, 9]),
         args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),
+    "performer_2d_d32": dict(  # head_dim 32, as the pvt_*2 variants have (vit/models/pvt_legacy.py:419-430)
+        attn="performer", x_shape=(1, 14, 14, 128), mask=None,
+        args=dict(dim=128, num_heads=4, approx_attn_dim=64, proj_method="favorp"), x_scale=0.25),
     "performer_2d": dict(
         attn="performer", x_shape=(1, 14, 14, 128), mask=None,
         args=dict(dim=128, num_heads=2, approx_attn_dim=64, proj_method="favorp")),

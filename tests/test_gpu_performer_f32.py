@@ -17,7 +17,10 @@ for p in (ROOT, os.path.join(ROOT, "efficient-attention_amd"), HERE, os.path.joi
 # the module-level tests need the default (exact fp32) core; EA_PERFORMER_16BIT=1 selects the 16-bit kernels for the process
 NEEDS_F32_DEFAULT = pytest.mark.skipif(os.environ.get("EA_PERFORMER_16BIT", "0") == "1",
                                        reason="EA_PERFORMER_16BIT=1: the 16-bit Performer kernels are the process default")
-PERFORMER_FIXTURES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(HERE, "golden", "performer_*.npz")))
+# (performer_2d_d32: head_dim 32 runs on the 16-bit kernels -- the exact-fp32 core is built for head_dim 64 -- and is held to the
+#  bf16 / fp16 bounds by tests/test_gpu_modules.py; in fp32 outside autocast it takes the documented rounding path)
+PERFORMER_FIXTURES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(HERE, "golden", "performer_*.npz"))
+                            if not f.endswith("_d32.npz"))
 
 
 def _oracle(q, k, v, mask, W):
