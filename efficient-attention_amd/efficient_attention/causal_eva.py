@@ -185,14 +185,21 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         noise = None
         if self.training:
             noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
+        def mu_fn(qm, km):
+            rq, rk = self.adaptive_mu_q(qm), self.adaptive_mu_k(km)
+            return rk, rq + rk
         if qkv5.dtype == torch.float32:
             # fp32 activations outside autocast (round 5): the core on the fp32-faithful kernels (causal_eva.py:666-783 in the
             # precision the reference computes it), the mu networks as the module's own layers
-            def mu_fn(qm, km):
-                rq, rk = self.adaptive_mu_q(qm), self.adaptive_mu_k(km)
-                return rk, rq + rk
             out = _f32.causal_eva_core(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), w, e, r, bool(self.causal), mu_fn,
                                        *self._dropout_keep(B, h, N, w + e, L, x.device, raw=True))
+        elif L > 64 and _f32.ENABLED:
+            # more chunks than the 16-bit window kernels hold landmark rows (64; the recipe's 512-token samples have exactly
+            # 64): the generic fp32 kernels on the 16-bit activations -- the reference takes any length (causal_eva.py:680-700)
+            with torch.autocast(device_type="cuda", enabled=False):
+                out = _f32.causal_eva_core(qkv5.float(), None if bias is None else bias.float(), noise,
+                                           _ops._mask_u8(mask, B, N, x.device), w, e, r, bool(self.causal), mu_fn,
+                                           *self._dropout_keep(B, h, N, w + e, L, x.device, raw=True)).to(qkv5.dtype)
         else:
             cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
                    2 if self.causal else 1, 1.0) + self._dropout_keep(B, h, N, w + e, L, x.device)
@@ -224,7 +231,8 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         A step projects the new token, closes a chunk when one completes (chunk means -> mu networks -> beta, the same HIP
         entry points as the full path on the chunk's rows) and runs the window kernel of the training path on the suffix
         [previous window, current window] against the landmarks of all completed chunks (`ea_geom.lm_base` re-bases the
-        chunk visibility rule of :716-738); rows after the current token are masked."""
+        chunk visibility rule of :716-738); rows after the current token are masked.  Past 64 completed chunks (the landmark rows
+        the 16-bit window kernel holds) the same suffix runs on the generic fp32 kernel: no length limit."""
         if not self.self_attention:
             raise NotImplementedError("incremental decoding of encoder-decoder attention")
         if not self.causal:
@@ -245,12 +253,6 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                                       "depends on the final sequence length)")
         dev = query.device
         state = self._get_input_buffer(incremental_state)
-        # the 64-landmark limit is checked BEFORE anything is projected or any state buffer is created: the window
-        # kernel takes at most 64 landmark rows (ea_window.h), and every completed chunk is one
-        t_seen = int(self.get_incremental_state(incremental_state, "attn_pos") or 0) if "qkv" in state else 0
-        if (t_seen + T_new - 1) // r > 64:
-            raise NotImplementedError("incremental decoding beyond 65 chunks (%d tokens at chunk size %d): the window kernel "
-                                      "holds 64 landmark rows" % (65 * r, r))
         qkv_new = self._project(query, None, None)                 # [T_new, B, 3, h, d]
         if "qkv" not in state:
             cap = max(2 * w, 64)
@@ -263,11 +265,6 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         # (the token count also lives on the host, under its own key of the incremental state -- reading `pos` back would
         #  synchronise every step, and reorder_incremental_state only touches the tensors of the buffer)
         t0 = int(self.get_incremental_state(incremental_state, "attn_pos") or 0)
-        if (t0 + T_new - 1) // r > 64:
-            # checked BEFORE the cache is touched: the window kernel takes at most 64 landmark rows (ea_window.h), and every
-            # completed chunk is one.  Per-token cost is O(w (w + e + L)): the training kernel re-runs over the suffix.
-            raise NotImplementedError("incremental decoding beyond 64 completed chunks (%d tokens at chunk size %d): the "
-                                      "window kernel holds at most 64 landmark rows" % (65 * r, r))
         if state["qkv"].shape[0] != B:
             raise RuntimeError("incremental state holds batch %d, the step has %d" % (state["qkv"].shape[0], B))
         need = ((t0 + T_new + w - 1) // w) * w
@@ -300,12 +297,22 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             ctx = cache[:, b0 * w:b0 * w + Nc]                      # [B, Nc, 3, h, d] view
             mask = torch.zeros((B, Nc), dtype=torch.uint8, device=dev)
             mask[:, t - b0 * w + 1:] = 1                            # rows after the current token: not decoded yet
-            geom = _ops.nv.make_geom(B, h, Nc, d, io, False, (Nc,), w, e, r, nvis, 2, (b0 * w) // r)
             lk = state["rf_k_bar"][:, :, :nvis].contiguous() if nvis else None
             lv = state["beta"][:, :, :nvis].contiguous() if nvis else None
-            bias_p = _ops._bias_padded(bias, geom)
-            out, _ = _ops._window_fwd(geom, ctx, lk, lv, bias_p, mask)
-            outs.append(out[:, t - b0 * w])                         # [B, h, d]
+            if nvis <= 64:
+                geom = _ops.nv.make_geom(B, h, Nc, d, io, False, (Nc,), w, e, r, nvis, 2, (b0 * w) // r)
+                bias_p = _ops._bias_padded(bias, geom)
+                out, _ = _ops._window_fwd(geom, ctx, lk, lv, bias_p, mask)
+                outs.append(out[:, t - b0 * w])                     # [B, h, d]
+            else:
+                # more completed chunks than the window kernel holds landmark rows: the same suffix on the generic fp32
+                # kernel (exact on the 16-bit rows; `lm_base` re-bases the visibility rule exactly as ea_geom's does)
+                q32, k32, v32 = [ctx[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]
+                spec = dict(idx_q=_f32.window_table_1d(Nc, w, 0, dev), idx_k=_f32.window_table_1d(Nc, w, e, dev, left_only=True),
+                            kmask=mask, qmask=mask, scale=d ** -0.5, causal_e=e, chunk=r, lm_base=(b0 * w) // r)
+                with torch.autocast(device_type="cuda", enabled=False):
+                    out, _ = _f32.GatherAttnFn.apply(q32, k32, v32, lk, lv, None if bias is None else bias.float(), spec)
+                outs.append(out[:, :, t - b0 * w].to(cache.dtype))  # [B, h, d]
             # ---- this token closes chunk c: its landmark becomes visible from the next chunk on ----
             if (t + 1) % r == 0:
                 c = t // r

@@ -51,7 +51,7 @@ def _oracle(m, embed, heads, attn_args, x_bf, mask, g_bf=None, keep=None, p_drop
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_mask", "recipe_d128_dropout",
-                                     "overlap_dropout", "overlap_w128_d64", "overlap_w64_d128"])
+                                     "overlap_dropout", "overlap_w128_d64", "overlap_w64_d128", "many_chunks"])
 def test_recipe_geometry_matches_oracle(variant, dtype):
     from gpu_checks import MODULE_TOL, FP16_TOL
     from util import scaled_err
@@ -71,6 +71,10 @@ def test_recipe_geometry_matches_oracle(variant, dtype):
     elif variant == "overlap_dropout":
         embed, heads, T, B, pads = 128, 2, 100, 2, [0, 11]
         aa = dict(RECIPE, window_size=24, chunk_size=8, overlap_window=True)   # Wk = 48, L = 15: padded mask columns
+    elif variant == "many_chunks":
+        # 80 chunks > the 64 landmark rows of the 16-bit window kernels: the generic fp32 kernels on the 16-bit activations
+        embed, heads, T, B, pads = 256, 4, 310, 2, [0, 23]
+        aa = dict(RECIPE, window_size=32, chunk_size=4, overlap_window=True)
     elif variant == "recipe_d128":
         # transformer_lm_wiki103: embed 1024, 8 heads.  128 queries x 128 keys at d = 128 exceed one
         # LDS image in backward: the window runs as 4 query blocks (ea_window_bwd_query_blocks)
@@ -209,12 +213,12 @@ def test_separate_key_value_inputs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_d64", "no_rpe_noln"])
+@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128", "overlap_d64", "no_rpe_noln", "many_chunks"])
 def test_incremental_decoding_equals_full_forward(variant):
     """Token-by-token decoding with fairseq's incremental state (reference causal_eva.py:537-665, dead code there: `N`
     unbound) reproduces the pinned full-sequence causal path row by row -- the definition this build gives it
     (causal_eva.py::_decode).  Checked on the recipe geometry (w = 128, chunks of 8, T5 bias) at d = 64 and d = 128, with
-    left-extended windows, and without the bias / LayerNorm; chunks of several steps at once; beam reordering."""
+    left-extended windows, without the bias / LayerNorm, and beyond 64 chunks; chunks of several steps at once; beam reordering."""
     aa = dict(RECIPE)
     embed, heads, T, B = 512, 8, 300, 2
     if variant == "recipe_d128":
@@ -225,6 +229,11 @@ def test_incremental_decoding_equals_full_forward(variant):
     elif variant == "no_rpe_noln":
         aa.update(use_t5_rpe=False, adaptive_proj="no-ln", window_size=64, chunk_size=16)
         T = 200
+    elif variant == "many_chunks":
+        # 80 chunks: past the 64 landmark rows of the 16-bit window kernels both the full path and the decoding steps run
+        # the generic fp32 kernels on the 16-bit rows (round 5; no length limit left)
+        aa.update(overlap_window=True, window_size=32, chunk_size=4)
+        embed, heads, T = 256, 4, 300
     m = _build(embed, heads, aa)
     torch.manual_seed(11)
     x = torch.randn(T, B, embed, device="cuda")
