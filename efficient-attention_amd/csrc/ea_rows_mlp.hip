@@ -24,7 +24,12 @@ namespace ea {
 template <int D> struct RowsCfg {
   static constexpr int RB = D == 128 ? 32 : 64;      // rows per tile (three row tiles + W within 160 KB)
   static constexpr int LD = D + 1;
-  static constexpr int TPR = 256 / RB;               // lanes per row in the row phases
+  // threads per workgroup: the LDS image (W + three row tiles, 115 KB at D = 128) allows ONE workgroup per CU, so at D = 128
+  // it is a 16-wave one -- a row tile's 16 dx tiles and 64 dW tiles spread over 16 waves instead of 4 (round 5: the LM
+  // recipe's 9216 rows x 2 sides: 46 -> us backward)
+  static constexpr int NT = D == 128 ? 1024 : 256;
+  static constexpr int NW = NT / 64;
+  static constexpr int TPR = NT / RB;                // lanes per row in the row phases
 };
 
 // acc += A(m0.., k) B(k, n0..) over K (multiple of 16); TA / TB: operand stored transposed
@@ -53,14 +58,15 @@ EA_DEV void tile_mm(f32x4& acc, const float* A, int lda, const float* B, int ldb
 // W [D, D] -> LDS rows of stride D + 1; batches of eight 16-B loads in flight per thread (a load per
 // loop trip would be a global round trip per trip)
 template <int D> EA_DEV void stage_weight(float* Ws, const float* W, int tid) {
-  constexpr int LD = D + 1, N4 = D * D / 4, NB = N4 / 256 < 8 ? N4 / 256 : 8;
-  for (int base = 0; base < N4; base += 256 * NB) {
+  constexpr int NT = RowsCfg<D>::NT;
+  constexpr int LD = D + 1, N4 = D * D / 4, NB = N4 / NT < 8 ? N4 / NT : 8;
+  for (int base = 0; base < N4; base += NT * NB) {
     float4 v[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) v[i] = reinterpret_cast<const float4*>(W)[base + i * 256 + tid];
+    for (int i = 0; i < NB; ++i) v[i] = reinterpret_cast<const float4*>(W)[base + i * NT + tid];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int idx = base + i * 256 + tid;
+      const int idx = base + i * NT + tid;
       float* d = Ws + (idx * 4 / D) * LD + (idx * 4) % D;
       d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
     }
@@ -74,9 +80,10 @@ template <int TPR> EA_DEV float row_sum(float v) {
 }
 
 template <int D, bool LN>
-__global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
+__global__ __launch_bounds__(RowsCfg<D>::NT) void rows_mlp_fwd_kernel(const RowsP p) {
   using C = RowsCfg<D>;
   constexpr int RB = C::RB, LD = C::LD, TPR = C::TPR, CPT = D / TPR;   // columns per lane in a row phase
+  constexpr int NT = C::NT, NW = C::NW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ws = sm;
   float* Xs = Ws + D * LD;
@@ -93,7 +100,7 @@ __global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int r0 = tile * RB;
     __syncthreads();
-    for (int idx = tid; idx < RB * D / 4; idx += 256) {
+    for (int idx = tid; idx < RB * D / 4; idx += NT) {
       const int row = idx * 4 / D, c = (idx * 4) % D;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 + row < p.R) v = *reinterpret_cast<const float4*>(x + (size_t)(r0 + row) * D + c);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    for (int t = wave; t < (RB / 16) * (D / 16); t += 4) {
+    for (int t = wave; t < (RB / 16) * (D / 16); t += NW) {
       const int m0 = (t / (D / 16)) * 16, n0 = (t % (D / 16)) * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       tile_mm<false, true>(acc, Xs, LD, Ws, LD, m0, n0, D, lane);
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
       }
       __syncthreads();
     }
-    for (int idx = tid; idx < RB * D / 4; idx += 256) {
+    for (int idx = tid; idx < RB * D / 4; idx += NT) {
       const int row = idx * 4 / D, c = (idx * 4) % D;
       if (r0 + row >= p.R) continue;
       const float* z = Zs + row * LD + c;
@@ -143,10 +150,11 @@ __global__ __launch_bounds__(256) void rows_mlp_fwd_kernel(const RowsP p) {
 }
 
 template <int D, bool LN>
-__global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
+__global__ __launch_bounds__(RowsCfg<D>::NT) void rows_mlp_bwd_kernel(const RowsP p) {
   using C = RowsCfg<D>;
   constexpr int RB = C::RB, LD = C::LD, TPR = C::TPR, CPT = D / TPR;
-  constexpr int WT = (D / 16) * (D / 16) / 4;         // dW tiles per wave
+  constexpr int NT = C::NT, NW = C::NW;
+  constexpr int WT = (D / 16) * (D / 16) / NW;        // dW tiles per wave
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ws = sm;
   float* Xs = Ws + D * LD;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
     const int r0 = tile * RB;
     __syncthreads();
     // ---- stage X, a = gamma o dy (LN) or dy, zhat; the feed planes that need no row statistics ----
-    for (int idx = tid; idx < RB * D / 4; idx += 256) {
+    for (int idx = tid; idx < RB * D / 4; idx += NT) {
       const int row = idx * 4 / D, c = (idx * 4) % D;
       const bool ok = r0 + row < p.R;
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv, hv = xv;
@@ -212,14 +220,14 @@ __global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
       __syncthreads();
     }
     // ---- feed plane 0: dz (its column sum is the Linear's bias gradient) ----
-    for (int idx = tid; idx < RB * D / 4; idx += 256) {
+    for (int idx = tid; idx < RB * D / 4; idx += NT) {
       const int row = idx * 4 / D, c = (idx * 4) % D;
       if (r0 + row >= p.R) continue;
       const float* a = As + row * LD + c;
       *reinterpret_cast<float4*>(p.feed + (((size_t)(r0 + row) * planes) * S + s) * D + c) = make_float4(a[0], a[1], a[2], a[3]);
     }
     // ---- dx = dz W ----
-    for (int t = wave; t < (RB / 16) * (D / 16); t += 4) {
+    for (int t = wave; t < (RB / 16) * (D / 16); t += NW) {
       const int m0 = (t / (D / 16)) * 16, n0 = (t % (D / 16)) * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       tile_mm<false, false>(acc, As, LD, Ws, LD, m0, n0, D, lane);
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
     // ---- dW += dz^T X  (rows beyond R hold zeros) ----
 #pragma unroll
     for (int i = 0; i < WT; ++i) {
-      const int t = wave + 4 * i;
+      const int t = wave + NW * i;
       const int m0 = (t / (D / 16)) * 16, n0 = (t % (D / 16)) * 16;
       tile_mm<true, false>(dW[i], As, LD, Xs, LD, m0, n0, RB, lane);
     }
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void rows_mlp_bwd_kernel(const RowsP p) {
   float* dst = p.dW_part + ((size_t)blockIdx.x * S + s) * D * D;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
-    const int t = wave + 4 * i;
+    const int t = wave + NW * i;
     const int m0 = (t / (D / 16)) * 16, n0 = (t % (D / 16)) * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[(size_t)(m0 + 4 * g + r) * D + n0 + li] = dW[i][r];
@@ -268,8 +276,8 @@ static int launch_rows(const RowsP& p, int sides, bool bwd, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid((unsigned)rows_mlp_blocks(p.R, D), (unsigned)sides);
-  if (bwd) hipLaunchKernelGGL((rows_mlp_bwd_kernel<D, LN>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((rows_mlp_fwd_kernel<D, LN>), grid, dim3(256), lds, st, p);
+  if (bwd) hipLaunchKernelGGL((rows_mlp_bwd_kernel<D, LN>), grid, dim3(RowsCfg<D>::NT), lds, st, p);
+  else hipLaunchKernelGGL((rows_mlp_fwd_kernel<D, LN>), grid, dim3(RowsCfg<D>::NT), lds, st, p);
   return (int)hipGetLastError();
 }
 

@@ -35,6 +35,9 @@ struct WinTiling {
   int slice;                  // merged query-block launch: this block's slice of the dk/dv scratch
   int bblk0;                  // offset of this launch's workgroups in dbias_part (query blocks write
                               // disjoint rows, so merged blocks share the slabs: bblk0 = 0)
+  int dbd;                    // causal 1-D backward, one window per workgroup: the bias-gradient entries are stored straight
+                              // to dbias_part (each is produced exactly once) -- no [Wq][ld] fp32 accumulator in LDS, so a
+                              // 128-token window at D = 128 needs 2 query blocks instead of 4 (round 5)
   int cdirect;                // 1-D windows extended by HALF a window on both sides (2 e = w, two colour classes): the
                               // even windows' key ranges tile the sequence (but its last e tokens) and so do the odd
                               // ones' (but the first e): class 0 STORES dk / dv in the I/O dtype, class 1 adds to them
@@ -62,7 +65,7 @@ inline size_t window_bwd_lds(const WinTiling& t, int D, bool bias, bool bias_lds
   const int nQTe = (t.nQT + 1) & ~1;
   const size_t rowsQ = (size_t)t.wpi * nQTe * 16;
   size_t b = (size_t)t.rowsTotal * D * 2 * 2 + rowsQ * D * 2 * 2 + rowsQ * 4 * 2;
-  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * (bias_lds ? 2 : 1);
+  if (bias) b += (size_t)t.Wq * (t.biasLd + 1) * 4 * ((t.dbd ? 0 : 1) + (bias_lds ? 1 : 0));
   b += (size_t)t.rowsTotal * 8 + (size_t)(t.nLT * 16 + nQTe * 16) * 4 + 128 * 4;
   if (t.causal) b += rowsQ * 8;                       // per-query visibility limits
   return b;
@@ -76,6 +79,7 @@ constexpr size_t WIN_LDS_MAX = 160 * 1024;
 // partly filled last round idles the chip (B*h = 384, 6 workgroups each: 4.5 rounds on 512 slots
 // -> 5).  Pick the count that minimises rounds x (windows per workgroup + prologue).
 inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
+  if (backward && t.dbd) { t.ipb = 1; t.nblk = t.niter; return; }    // (direct bias gradient: one iteration per workgroup)
   const long bh = (long)g.B * g.H;
   // resident workgroups per CU: the kernels' launch bounds, or one when the LDS image takes over
   // half of the CU's 160 KB
@@ -104,7 +108,7 @@ inline void win_derive(const ea_geom& g, WinTiling& t, bool backward) {
   t.nLT = ceil_div(t.Wk, 16);
   t.nCT = ceil_div(g.L, 16);
   t.nchunks = ceil_div(t.nLT + t.nCT, 4);
-  t.wpi = t.nQT >= 3 ? 1 : (t.nQT == 2 ? 2 : 4);
+  t.wpi = (t.nQT >= 3 || (backward && t.dbd)) ? 1 : (t.nQT == 2 ? 2 : 4);
   if (t.wpi > t.nwin) t.wpi = t.nwin;
   for (;;) {
     t.rowsLocal = t.wpi * t.nLT * 16;
@@ -180,6 +184,11 @@ inline int win_bwd_bias_parts(const ea_geom& g, const WinTiling& t) {
   return m;
 }
 
+// dev switch: EA_WIN_DBD=0 keeps the LDS bias-gradient accumulator (and the 4 query blocks of the LM geometry)
+inline bool win_dbd_on() {
+  static const bool v = [] { const char* e = getenv("EA_WIN_DBD"); return !e || atoi(e) != 0; }();
+  return v;
+}
 // dev switch: EA_WIN_CDIRECT=0 keeps the scratch slices + finish pass for half-window overlap
 inline bool win_cdirect_on() {
   static const bool v = [] { const char* e = getenv("EA_WIN_CDIRECT"); return !e || atoi(e) != 0; }();
@@ -204,7 +213,7 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
   }
   t.WqFull = t.Wq;
   t.biasLd = ceil_div(t.Wk, 16) * 16;
-  t.qsplit = 1; t.qoff = 0; t.slice = 0; t.bblk0 = 0; t.cdirect = 0;
+  t.qsplit = 1; t.qoff = 0; t.slice = 0; t.bblk0 = 0; t.cdirect = 0; t.dbd = 0;
   t.ncx = t.ncy = 1;
   t.col_x = t.col_y = 0; t.sub_x = 0; t.blk0 = 0;
   win_derive(g, t, backward);
@@ -212,6 +221,12 @@ inline int win_tiling(const ea_geom& g, WinTiling& t, bool backward) {
     // a window whose rows do not fit the LDS image is processed in query blocks (halved until it
     // fits; a block keeps whole 32-query MFMA steps), one launch per block
     while (window_bwd_lds(t, g.D, true, false) > WIN_LDS_MAX && t.Wq % 64 == 0) {
+      if (!t.dbd && g.causal && t.wpi == 1 && win_dbd_on()) {
+        // first give up the bias-gradient accumulator (one window per workgroup, entries stored directly)
+        t.dbd = 1;
+        win_derive(g, t, true);
+        continue;
+      }
       t.qsplit *= 2;
       t.Wq /= 2;
       win_derive(g, t, true);

@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   // the 64 lanes on distinct banks
   const int BLD = biasLd + 1;
   float* dbias_s = HAND ? reinterpret_cast<float*>(slabC + NQW * SG::NCT * 1024) : delta_s + rowsQ;
-  const int nbias = (p.bias && !HAND) ? t.Wq * BLD : 0;
+  const int ntable = (p.bias && !HAND) ? t.Wq * BLD : 0;
+  const bool dbd = CA && t.dbd != 0;                   // bias-gradient entries go straight to dbias_part (ea_window.h)
+  const int nbias = dbd ? 0 : ntable;
   float* bias_s = dbias_s + nbias;
-  float* zero64 = bias_s + (p.bias_lds ? nbias : 0);   // bias reads without a bias table land here
+  float* zero64 = bias_s + (p.bias_lds ? ntable : 0);  // bias reads without a bias table land here
   float* trash64 = zero64 + 64;                        // bias-gradient writes of padded entries
   float* kmul = trash64 + 64;
   const float* bread = p.bias_lds ? bias_s : zero64;
@@ -112,6 +114,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
   lo.init(lane);
   const int bh = bid / t.nblk, blk = bid - bh * t.nblk;
   const int b = bh / p.H, h = bh - b * p.H;
+  float* const dbias_g = (dbd && p.bias) ? p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)biasLd
+                                         : nullptr;
   const char* qb = p.q.p + (b * p.q.sb + h * p.q.sh) * 2;
   const char* kb = p.k.p + (b * p.k.sb + h * p.k.sh) * 2;
   const char* vb = p.v.p + (b * p.v.sb + h * p.v.sh) * 2;
@@ -615,7 +619,10 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                 }
                 ds[r] = gm * pr[r] * (dpr - dd[r]);
                 if (DR) pr[r] *= km;                        // dV sees the dropped probabilities
-                if (BM == 1) {
+                if (BM == 3) {
+                  // one window per workgroup: this lane produces the entry exactly once (padded columns of the row as zeros)
+                  if (qs < t.Wq) dbias_g[(size_t)qs * biasLd + kslot] = bias_on ? ds[r] : 0.f;
+                } else if (BM == 1) {
                   float* dst = bias_on ? dbias_s + qs * BLD + kslot : trash64 + lane;
                   *dst += ds[r];
                 } else if (BM == 2) {
@@ -664,6 +671,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           }
         }
       } else if (is_lm || !p.bias) sweep(std::integral_constant<int, 0>{});
+      else if (CA && dbd) { if constexpr (CA) sweep(std::integral_constant<int, 3>{}); }
       else if (wpi == 1) sweep(std::integral_constant<int, 1>{});
       else sweep(std::integral_constant<int, 2>{});
       if (prof_it == 0) EA_STAMP(p, pb + 9);
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       }
     }
   }
-  if (p.bias) {
+  if (p.bias && !dbd) {
     float* dst = p.dbias_part + ((((size_t)(t.bblk0 + blk) * p.B + b) * p.H + h) * t.WqFull + t.qoff) * (size_t)biasLd;
     if constexpr (HAND && SG::WPI == 1) {
       const int qs = wave * 16 + li;
