@@ -37,7 +37,7 @@ template <typename E, int CPR> EA_DEV float key_norm_term(u32x4 kw, float scale_
 // compare and a select: the forward is bound by its VALU work (v_exp_f32 alone takes as long as the two MFMAs a score
 // costs), not by the matrix cores.
 template <typename E, int D, bool DR, bool KB, int QT>
-__global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
+__global__ __launch_bounds__(256, 2) void sm_fwd_kernel(const SmP p) {
   constexpr int ROWB = D * 2, CPR = D / 8, KS = D / 32, DT = D / 16, DQ = D / 4;
   __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
   __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[u][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-
   // the next chunk's K/V rows are in flight (registers) while this chunk computes; loads are unconditional from
   // clamped rows (no exec-mask branches), rows past the sequence are zeroed when they are committed to LDS.
   constexpr int NSL = (64 * CPR + 255) / 256;
@@ -90,29 +89,13 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
       nm[i] = mrow ? mrow[tok] : (uint8_t)0;
     }
   };
-  issue(0);
-  for (int kc = 0; kc < p.N; kc += 64) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NSL; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / CPR, c = idx - row * CPR;
-      if (64 * CPR % 256 != 0 && idx >= 64 * CPR) continue;
-      const bool in = kc + row < p.N;
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      const u32x4 kw = in ? nk[i] : z, vw = in ? nv[i] : z;
-      sts16(Ks + TileL<D>::off(row, c), kw);
-      sts16(Vs + TileL<D>::off(row, c), vw);
-      float kn = 0.f;
-      if (KB) kn = key_norm_term<E, CPR>(kw, p.scale_log2);
-      if (c == 0) kadd_s[row] = (!in || nm[i]) ? -INFINITY : kn;
-    }
-    __syncthreads();
-    if (kc + 64 < p.N) issue(kc + 64);
-    // A chunk without padded / masked keys and without the KB term (the common case: no mask, N a multiple of 64) needs
-    // no additive term: the row maximum is taken over the raw scores and the scale is applied together with the shift,
-    // exp2(s * scale - m), one fma per score instead of an fma and a subtraction.  (uniform condition)
-    const bool plain = !KB && !mrow && kc + 64 <= p.N;
+  // One 64-key chunk.  PL (a template tag, so that the loop body carries no branch: with `plain` tested inside it the
+  // compiler kept the S tiles in one set of registers on both arms and copied them out -- 64 v_mov per chunk): a chunk
+  // without padded / masked keys and without the KB term (the common case: no mask, N a multiple of 64) needs no additive
+  // term: the row maximum is taken over the raw scores and the scale is applied together with the shift,
+  // exp2(s * scale - m), one fma per score instead of an fma and a subtraction.
+  auto chunk = [&](auto plain_tag, int kc) {
+    constexpr bool PL = decltype(plain_tag)::value;
     f32x4 s[QT][4];
     float mloc[QT];
 #pragma unroll
@@ -120,67 +103,68 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       const int row = tt * 16 + li;
-      f32x4 acc[QT];
 #pragma unroll
-      for (int u = 0; u < QT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < QT; ++u) s[u][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const typename E::x8 kfr = as_x8<E>(lds16(Ks + TileL<D>::off(row, g * KS + ks)));
 #pragma unroll
-        for (int u = 0; u < QT; ++u) acc[u] = E::mma(kfr, qf[u][ks], acc[u]);
+        for (int u = 0; u < QT; ++u) s[u][tt] = E::mma(kfr, qf[u][ks], s[u][tt]);
       }
-      if (plain) {
+      if constexpr (PL) {
 #pragma unroll
-        for (int u = 0; u < QT; ++u) {
+        for (int u = 0; u < QT; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mloc[u] = fmaxf(mloc[u], acc[u][r]);
-          s[u][tt] = acc[u];
-        }
+          for (int r = 0; r < 4; ++r) mloc[u] = fmaxf(mloc[u], s[u][tt][r]);
       } else {
         const float4 ka4 = *reinterpret_cast<const float4*>(kadd_s + tt * 16 + 4 * g);
         const float kav[4] = {ka4.x, ka4.y, ka4.z, ka4.w};
 #pragma unroll
-        for (int u = 0; u < QT; ++u) {
+        for (int u = 0; u < QT; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = fmaf(acc[u][r], p.scale_log2, kav[r]);
-            acc[u][r] = x;
+            const float x = fmaf(s[u][tt][r], p.scale_log2, kav[r]);
+            s[u][tt][r] = x;
             mloc[u] = fmaxf(mloc[u], x);
           }
-          s[u][tt] = acc[u];
-        }
       }
     }
     uint32_t pw[QT][4][2];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
       float ml = quad_max(mloc[u]);
-      if (plain) ml *= p.scale_log2;                     // (scale > 0: the maximum commutes with it)
+      if (PL) ml *= p.scale_log2;                        // (scale > 0: the maximum commutes with it)
       const float mnew = fmaxf(m[u], ml);
       const float msafe = mnew == -INFINITY ? 0.f : mnew;
       // the running maximum moves in the first few chunks of a row and then hardly ever: the rescale of the 16
-      // accumulators (which costs 32 moves between the MFMA accumulation registers and the VALU's on top of the
-      // multiplications) is skipped when no lane of the wave needs it -- alpha is exactly 1 there
+      // accumulators is skipped when no lane of the wave needs it -- alpha is exactly 1 there
       const bool moved = mnew != m[u];
       const float alpha = fast_exp2(m[u] - msafe);
       m[u] = mnew;
-      float psum = 0.f;
+      // (two scores per instruction: the shift-and-scale as v_pk_fma_f32, the row sum as v_pk_add_f32 -- the forward is
+      //  bound by its VALU issue, exp2 alone taking 4 of the ~8 issue slots a score costs against 4 for its two MFMAs)
+      f32x2 psum2 = {0.f, 0.f};
       const uint8_t* krow = DR ? p.keep + ((size_t)bh * p.N + (qvalid[u] ? qtok[u] : 0)) * p.keep_ld + kc + 4 * g : nullptr;
-      const float sc = plain ? p.scale_log2 : 1.f;
+      const float sc = PL ? p.scale_log2 : 1.f;
+      const f32x2 sc2 = {sc, sc}, nm2 = {-msafe, -msafe};
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        float pv[4];
         uint32_t k4 = 0;
         if (DR) k4 = *reinterpret_cast<const uint32_t*>(krow + tt * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pv[r] = fast_exp2(fmaf(s[u][tt][r], sc, -msafe));
-          psum += pv[r];
-          if (DR) pv[r] = ((k4 >> (8 * r)) & 0xffu) ? pv[r] * p.keep_scale : 0.f;
+        const f32x2 xa = f32x2{s[u][tt][0], s[u][tt][1]} * sc2 + nm2, xb = f32x2{s[u][tt][2], s[u][tt][3]} * sc2 + nm2;
+        f32x2 pa = {fast_exp2(xa[0]), fast_exp2(xa[1])}, pb = {fast_exp2(xb[0]), fast_exp2(xb[1])};
+        psum2 += pa;
+        psum2 += pb;
+        if (DR) {
+          pa[0] = (k4 & 0xffu) ? pa[0] * p.keep_scale : 0.f;
+          pa[1] = ((k4 >> 8) & 0xffu) ? pa[1] * p.keep_scale : 0.f;
+          pb[0] = ((k4 >> 16) & 0xffu) ? pb[0] * p.keep_scale : 0.f;
+          pb[1] = ((k4 >> 24) & 0xffu) ? pb[1] * p.keep_scale : 0.f;
         }
-        pw[u][tt][0] = pack2<E>(pv[0], pv[1]);
-        pw[u][tt][1] = pack2<E>(pv[2], pv[3]);
+        pw[u][tt][0] = pack2<E>(pa[0], pa[1]);
+        pw[u][tt][1] = pack2<E>(pb[0], pb[1]);
       }
+      const float psum = psum2[0] + psum2[1];
       if (__any(moved)) {
         lsum[u] = lsum[u] * alpha + psum;
 #pragma unroll
@@ -208,7 +192,41 @@ __global__ __launch_bounds__(256) void sm_fwd_kernel(const SmP p) {
         for (int u = 0; u < QT; ++u) o[u][dt] = E::mma(vfr, pf[u], o[u][dt]);
       }
     }
-  }
+  };
+  // The chunk loop, once per variant of the body (two loops one after the other, not two arms inside one loop: values live
+  // across both arms cost registers the kernel does not have): the full unmasked chunks first, then whatever is left.
+  auto run = [&](auto plain_tag, int kc0, int kc1) {
+    constexpr bool PL = decltype(plain_tag)::value;
+    for (int kc = kc0; kc < kc1; kc += 64) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NSL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / CPR, c = idx - row * CPR;
+        if (64 * CPR % 256 != 0 && idx >= 64 * CPR) continue;
+        const bool in = PL || kc + row < p.N;
+        u32x4 kw = nk[i], vw = nv[i];
+        if (!PL) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          kw = in ? kw : z; vw = in ? vw : z;
+        }
+        sts16(Ks + TileL<D>::off(row, c), kw);
+        sts16(Vs + TileL<D>::off(row, c), vw);
+        if (!PL) {
+          float kn = 0.f;
+          if (KB) kn = key_norm_term<E, CPR>(kw, p.scale_log2);
+          if (c == 0) kadd_s[row] = (!in || nm[i]) ? -INFINITY : kn;
+        }
+      }
+      __syncthreads();
+      if (kc + 64 < p.N) issue(kc + 64);
+      chunk(plain_tag, kc);
+    }
+  };
+  const int nfull = (!KB && !mrow) ? (p.N / 64) * 64 : 0;
+  issue(0);
+  run(std::true_type{}, 0, nfull);
+  run(std::false_type{}, nfull, p.N);
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const float ltot = quad_sum(lsum[u]);
@@ -694,9 +712,9 @@ static int launch_sm_dr(int which, const SmP& p, hipStream_t st) {
     if (bh * ((p.N + 127) / 128) >= 2 * ea_device_cus()) qt = 2;
     if (D <= 64 && bh * ((p.N + 255) / 256) >= 2 * ea_device_cus()) qt = 4;
     if (qt_env > 0) qt = qt_env;
-    if (D > 64 && qt > 2) qt = 2;
+    if ((D > 64 || DR) && qt > 2) qt = 2;              // (with the keep-mask reads four query tiles do not fit 256 VGPRs)
     const dim3 gq((unsigned)(bh * ((p.N + 64 * qt - 1) / (64 * qt))));
-    if (qt == 4) { if constexpr (D <= 64) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 4>), gq, block, 0, st, p); }
+    if (qt == 4) { if constexpr (D <= 64 && !DR) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 4>), gq, block, 0, st, p); }
     else if (qt == 2) hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 2>), gq, block, 0, st, p);
     else hipLaunchKernelGGL((sm_fwd_kernel<E, D, DR, KB, 1>), gq, block, 0, st, p);
   } else {
