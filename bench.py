@@ -195,8 +195,10 @@ def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, ove
         OVERRIDES.clear()
         OVERRIDES.update(keep)
     layer.train()
-    x = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev, requires_grad=True)
-    g = torch.randn(*((B,) + tuple(seq) + (C,)), device=dev).to(torch.bfloat16)
+    lm = attn == "causal_eva"                                        # fairseq decoder self-attention: time-first, (q, k, v) call
+    xshape = (seq[0], B, C) if lm else (B,) + tuple(seq) + (C,)
+    x = torch.randn(*xshape, device=dev, requires_grad=True)
+    g = torch.randn(*xshape, device=dev).to(torch.bfloat16)
     params = list(layer.parameters())
     big = [prm for prm in params if prm.numel() >= 16384]
     small = [prm for prm in params if prm.numel() < 16384]
@@ -206,7 +208,7 @@ def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, ove
             prm.grad = None
         x.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = layer(x)
+            y = layer(x, x, x)[0] if lm else layer(x)
         y.backward(g)
         for prm in big:
             if prm.grad is not None:
@@ -623,6 +625,8 @@ def main():
             pvt = dict(window_size=8, num_landmarks=36)
             runs += [("cfg4_stage1_N9216_eva", "eva", (32, 64, 1, (96, 96)), pvt), ("cfg4_stage2_N2304_eva", "eva", (32, 128, 2, (48, 48)), pvt),
                      ("cfg4_stage3_N576_eva", "eva", (32, 320, 5, (24, 24)), pvt), ("cfg4_stage4_N144_softmax", "softmax", (32, 512, 8, (12, 12)))]
+            # the wikitext-103 decoder self-attention (`--attn causal_eva --workload lm`): the recipe's 18 samples x 512 tokens
+            runs.append(("lm_N512_B18_causal_eva", "causal_eva", (18, 1024, 8, (512,))))
             for key, attn_o, (Bo, Co, Ho, so), *ov in runs:
                 try:
                     others[key] = measure_workload(attn_o, Bo, Co, Ho, so, dev, tune=tune, overrides=ov[0] if ov else None)
