@@ -381,6 +381,24 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       // PW (HAND launches without a padding mask whose windows are all complete): key validity is static, so the
       // logit is ONE fma -- s * scale + (bias | -inf) -- and dS needs no gradient mask; otherwise the masked_fill form
       constexpr bool PW = HAND && SG::PW;
+      // PFA (round 5, like PF of phase B below): the bias piece read from global memory (GB) and the keep-mask word (DR) of a
+      // key tile are requested TWO tiles ahead, unconditionally, from clamped addresses (scalars in rotation, not arrays: the
+      // tile loop is not always unrolled and an indexed array would live in scratch)
+      constexpr bool PFA = D == 128 && ((PHASE_A_GLOBAL_BIAS && !HAND) || DR);
+      const uint8_t* keep_row = DR ? p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + 4 * g : nullptr;
+      f32x4 pb0 = {0.f, 0.f, 0.f, 0.f}, pb1 = pb0, pb2 = pb0;     // (vector values, not structs: selects stay in registers)
+      uint32_t pk0 = 0, pk1 = 0, pk2 = 0;
+      const int ntiles_a = nchunks * 4;
+      auto fetchA = [&](int tile_, f32x4& bq, uint32_t& kq) {
+        const int tile = min(tile_, ntiles_a - 1);
+        const bool local = tile < nLT;
+        if (PHASE_A_GLOBAL_BIAS && !HAND) bq = *reinterpret_cast<const f32x4*>(brow + min(tile, nLT - 1) * 16);
+        if (DR) {
+          const int col = local ? tile * 16 : biasLd + max(min(tile - nLT, nCT - 1), 0) * 16;
+          kq = *reinterpret_cast<const uint32_t*>(keep_row + ((nCT > 0 || local) ? col : 0));
+        }
+      };
+      if (PFA) { fetchA(0, pb0, pk0); fetchA(1, pb1, pk1); }
       for (int ch = 0; ch < nchunks; ++ch) {
         int rowbase[4];
         const char* kt_p[4];
@@ -389,6 +407,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         for (int tt = 0; tt < 4; ++tt) {
           const int tile = ch * 4 + tt;
           const bool local = tile < nLT;
+          if (PFA) fetchA(tile + 2, pb2, pk2);
           rowbase[tt] = local ? (wi * nLT + tile) * 16
                               : (tile < nLT + nCT ? rowsLocal + (tile - nLT) * 16
                                                       : rowsLocal + rowsLm);
@@ -408,7 +427,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           if constexpr (HAND) {
             if (local) b4 = make_float4(breg[tile][0], breg[tile][1], breg[tile][2], breg[tile][3]);
           } else if (PHASE_A_GLOBAL_BIAS) {
-            if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
+            if (PFA) { if (local) b4 = make_float4(pb0[0], pb0[1], pb0[2], pb0[3]); }
+            else if (brow && local) b4 = *reinterpret_cast<const float4*>(brow + tile * 16);
           } else {
             const float* bs = brow_s + (local ? tile : 0) * btm;
             const float lf = local ? 1.f : 0.f;
@@ -420,9 +440,11 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           uint32_t keep4 = 0x01010101u;
           if (DR) {
             const bool real = tile < nLT + nCT;
-            const int col = local ? tile * 16 : biasLd + (tile - nLT) * 16;
-            keep4 = real ? *reinterpret_cast<const uint32_t*>(
-                               p.keep + ((size_t)bh * p.G.N + (qtok >= 0 ? qtok : 0)) * p.keep_ld + col + 4 * g) : 0u;
+            if (PFA) keep4 = real ? pk0 : 0u;
+            else {
+              const int col = local ? tile * 16 : biasLd + (tile - nLT) * 16;
+              keep4 = real ? *reinterpret_cast<const uint32_t*>(keep_row + col) : 0u;
+            }
           }
           float ds[4], prr[4];
 #pragma unroll
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
           }
           dsw[tt][0] = pack2<E>(ds[0], ds[1]);
           dsw[tt][1] = pack2<E>(ds[2], ds[3]);
+          if (PFA) { pb0 = pb1; pb1 = pb2; pk0 = pk1; pk1 = pk2; }
           if constexpr (HAND) {
             if (tile < NKT) {
               hp[tile][0] = pack2<E>(prr[0], prr[1]); hp[tile][1] = pack2<E>(prr[2], prr[3]);
@@ -555,11 +578,40 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       // windows in flight: LDS atomics.  Padded entries write to a trash line instead of branching.
       auto sweep = [&](auto bm_tag) {
         constexpr int BM = decltype(bm_tag)::value;
+        // PF (round 5): the global-memory operands of a step's elementwise stage -- the 16-B piece of the transposed bias
+        // table (GB) and the four keep-mask bytes (DR) of each of the two query tiles -- are requested one step AHEAD, from
+        // clamped addresses (no exec-mask branch), so that their latency overlaps the previous step's products.  These
+        // instantiations run at one wave per SIMD (the 143 KB image of the LM geometry): a load issued where it is used parks
+        // the whole SIMD (SQ counters, LM backward: 48 % of the wave cycles parked).
+        constexpr bool PF = D == 128 && ((GB && BM != 0) || DR);     // (the 256-register instantiations have no room for it)
+        auto fetch1 = [&](int wi, int qt_, f32x4& bq, uint32_t& kq) {
+          const int q0c = min(qt_, nQT - 1) * 16 + 4 * g;
+          if (GB && BM != 0)
+            bq = *reinterpret_cast<const f32x4*>(
+                biasT + ((size_t)h * biasLd + min(kslot, t.Wk - 1)) * (ceil_div(t.WqFull, 16) * 16) + t.qoff + q0c);
+          if (DR) {
+            const int qbase = colour_win(t, p.G, p.w, it * wpi + wi) * p.w + t.qoff;
+            const int kcol = is_lm ? biasLd + kslot : kslot;
+            const uint8_t* kp = p.keep + ((size_t)bh * p.G.N + qbase) * p.keep_ld + kcol;
+            uint32_t w = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w |= (uint32_t)kp[(size_t)min(q0c + r, t.Wq - 1) * p.keep_ld] << (8 * r);
+            kq = w;
+          }
+        };
         for (int wi = wi_lo; wi < wi_hi; ++wi) {
           if (it * wpi + wi >= t.nwin) break;
+          f32x4 cb0 = {0.f, 0.f, 0.f, 0.f}, cb1 = cb0, nb0 = cb0, nb1 = cb0;
+          uint32_t ck0 = 0, ck1 = 0, nk0 = 0, nk1 = 0;
+          if (PF) { fetch1(wi, 0, cb0, ck0); fetch1(wi, 1, cb1, ck1); }
           for (int qq = 0; qq < nQTe / 2; ++qq) {
             uint32_t pw[2][2], dsw[2][2];
             int rq[2];
+            if (PF) {
+              const int qn = min(qq + 1, nQTe / 2 - 1);
+              fetch1(wi, 2 * qn, nb0, nk0);
+              fetch1(wi, 2 * qn + 1, nb1, nk1);
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int qt = 2 * qq + u;
@@ -581,8 +633,11 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
               const int q0 = qt * 16 + 4 * g;            // first of this lane's four query slots
               float bt[4] = {0.f, 0.f, 0.f, 0.f};
               if (BM != 0) {
-                if (GB) {
-                  // from the transposed copy in global memory: one 16-B load
+                if (GB && PF) {
+                  // from the transposed copy in global memory: one 16-B load (requested a step ahead)
+                  const f32x4 cb = u == 0 ? cb0 : cb1;
+                  bt[0] = cb[0]; bt[1] = cb[1]; bt[2] = cb[2]; bt[3] = cb[3];
+                } else if (GB) {
                   if (kslot < t.Wk) {
                     const float4 bt4 = *reinterpret_cast<const float4*>(
                         biasT + ((size_t)h * biasLd + kslot) * (ceil_div(t.WqFull, 16) * 16) + t.qoff + q0);
@@ -611,10 +666,15 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
                 float dpr = dp[r];
                 float km = 1.f;
                 if (DR) {
-                  // 1-D windows: token of query slot qs of window wi; this lane's softmax column
-                  const int qtk = colour_win(t, p.G, p.w, it * wpi + wi) * p.w + t.qoff + min(qs, t.Wq - 1);
-                  const int kcol = is_lm ? biasLd + kslot : kslot;
-                  km = p.keep[((size_t)bh * p.G.N + qtk) * p.keep_ld + kcol] ? p.keep_scale : 0.f;
+                  // 1-D windows: token of query slot qs of window wi; this lane's softmax column (byte r of the word
+                  // fetched a step ahead)
+                  if (PF) {
+                    km = (((u == 0 ? ck0 : ck1) >> (8 * r)) & 0xffu) ? p.keep_scale : 0.f;
+                  } else {
+                    const int qtk = colour_win(t, p.G, p.w, it * wpi + wi) * p.w + t.qoff + min(qs, t.Wq - 1);
+                    const int kcol = is_lm ? biasLd + kslot : kslot;
+                    km = p.keep[((size_t)bh * p.G.N + qtk) * p.keep_ld + kcol] ? p.keep_scale : 0.f;
+                  }
                   dpr *= km;
                 }
                 ds[r] = gm * pr[r] * (dpr - dd[r]);
@@ -643,6 +703,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
               dv[dt] = E::mma(as_x8<E>(E::tr4(dOs + o0), E::tr4(dOs + o1)), pf, dv[dt]);
               dk[dt] = E::mma(as_x8<E>(E::tr4(Qs + o0), E::tr4(Qs + o1)), dsf, dk[dt]);
             }
+            if (PF) { cb0 = nb0; cb1 = nb1; ck0 = nk0; ck1 = nk1; }
           }
         }
       };
