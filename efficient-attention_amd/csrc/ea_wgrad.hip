@@ -15,6 +15,7 @@
 // the workgroups of in-tile 0 add up the dY rows they stage anyway.  Slice partials [S, out, in] fp32
 // are summed in a fixed order by ea_slice_sum (deterministic; no atomics).
 #include <stdlib.h>
+#include <algorithm>
 #include "ea_common.h"
 
 namespace ea {
@@ -71,22 +72,53 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   const int r1 = min(p.rows, r0 + p.rows_per_slice);
   const bool with_bias = dbp != nullptr && tn == 0;
 
+  // Round 5 (from the loop's disassembly: 161 of its 333 VALU instructions were v_mov -- every `t < r1 ? load : 0` built a
+  // 64-bit address pair per load and selected around it): the loads are unconditional, from a 32-bit byte offset per staged
+  // chunk that advances by 64 rows per stage (base pointer in SGPRs); only the LAST stage of a slice can reach past it, and
+  // only there the rows are clamped (issue) and zeroed (commit) -- a uniform branch.
   u32x4 pa[SA], pb[SB];
+  uint32_t offa[SA], offb[SB];
+#pragma unroll
+  for (int k = 0; k < SA; ++k) {
+    const int idx = tid + k * 512;
+    const int row = idx / CPRA, ch = idx - row * CPRA;
+    offa[k] = (uint32_t)(((size_t)row * pM + m0 + ch * 8) * 2);   // relative to the slice's first row (dys / xs below)
+  }
+#pragma unroll
+  for (int k = 0; k < SB; ++k) {
+    const int idx = tid + k * 512;
+    const int row = idx / CPRB, ch = idx - row * CPRB;
+    offb[k] = (uint32_t)(((size_t)row * pK + n0 + ch * 8) * 2);
+  }
+  const uint32_t stepa = (uint32_t)(64 * pM * 2), stepb = (uint32_t)(64 * pK * 2);
+  const char* const dys = dyp + (size_t)r0 * pM * 2;       // (a slice spans < 4 GB: checked at dispatch)
+  const char* const xs = xp + (size_t)r0 * pK * 2;
   auto issue = [&](int rb) {
+    if (rb + 64 <= r1) {
 #pragma unroll
-    for (int k = 0; k < SA; ++k) {
-      const int idx = tid + k * 512;
-      const int row = idx / CPRA, ch = idx - row * CPRA;
-      const int t = rb + row;
-      pa[k] = t < r1 ? ldg16(dyp + ((size_t)t * pM + m0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
+      for (int k = 0; k < SA; ++k) pa[k] = ldg16(dys + offa[k]);
+#pragma unroll
+      for (int k = 0; k < SB; ++k) pb[k] = ldg16(xs + offb[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < SA; ++k) {
+        const int idx = tid + k * 512;
+        const int row = idx / CPRA, ch = idx - row * CPRA;
+        const int t = min(rb + row, r1 - 1);
+        pa[k] = ldg16(dyp + ((size_t)t * pM + m0 + ch * 8) * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        const int idx = tid + k * 512;
+        const int row = idx / CPRB, ch = idx - row * CPRB;
+        const int t = min(rb + row, r1 - 1);
+        pb[k] = ldg16(xp + ((size_t)t * pK + n0 + ch * 8) * 2);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < SB; ++k) {
-      const int idx = tid + k * 512;
-      const int row = idx / CPRB, ch = idx - row * CPRB;
-      const int t = rb + row;
-      pb[k] = t < r1 ? ldg16(xp + ((size_t)t * pK + n0 + ch * 8) * 2) : u32x4{0u, 0u, 0u, 0u};
-    }
+    for (int k = 0; k < SA; ++k) offa[k] += stepa;
+#pragma unroll
+    for (int k = 0; k < SB; ++k) offb[k] += stepb;
   };
   // bias partials: a thread's staged chunks all sit in ONE 8-channel group when 512 is a multiple of the chunks per row
   // (BM = 64, 128, 256), so they share one set of accumulators
@@ -96,7 +128,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
   for (int k = 0; k < NB; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) accb[k][e] = 0.f;
-  auto commit = [&](char* st) {
+  auto commit = [&](char* st, int rb) {
+    if (rb + 64 > r1) {                                // (uniform) the slice's last stage: rows past it count as zeros
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < SA; ++k) { if (rb + (tid + k * 512) / CPRA >= r1) pa[k] = z; }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) { if (rb + (tid + k * 512) / CPRB >= r1) pb[k] = z; }
+    }
 #pragma unroll
     for (int k = 0; k < SA; ++k) {
       const int idx = tid + k * 512;
@@ -144,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
     for (int c = 0; c < FB; ++c) acc[f][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   issue(r0);
-  commit(smem);
+  commit(smem, r0);
   __syncthreads();
   int buf = 0;
   for (int rb = r0; rb < r1; rb += 64) {
@@ -167,7 +206,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgP p) {
         for (int f = 0; f < FA; ++f) acc[f][c] = E::mma(af[f], bf, acc[f][c]);
       }
     }
-    if (more) commit(smem + (buf ^ 1) * STAGE);
+    if (more) commit(smem + (buf ^ 1) * STAGE, rb + 64);
     __syncthreads();
     buf ^= 1;
   }
@@ -343,6 +382,9 @@ static int launch_wg(const WgP& p, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM / 64 + BN / 64) * 64 * 128;
   if (lds > 64 * 1024) EA_SET_LDS_ONCE((&wgrad_kernel<E, BM, BN>), lds);
   const int T = p.tiles_m * p.tiles_n + p.T2;
+  // (the staging addresses are 32-bit byte offsets from a slice's first row)
+  const long widest = std::max(std::max(p.M, p.K), std::max(p.M2, p.K2));
+  if ((long)(p.rows_per_slice + 64) * widest * 2 >= (1L << 32)) return EA_E_UNSUPPORTED;
   const dim3 grid((unsigned)(((p.S & 7) == 0 ? ((p.S + 7) / 8) * 8 : p.S) * T)), block(512);
   hipLaunchKernelGGL((wgrad_kernel<E, BM, BN>), grid, block, lds, st, p);
   return (int)hipGetLastError();
