@@ -282,39 +282,43 @@ __global__ __launch_bounds__(256) void part_sum_kernel(const float* __restrict__
 
 // Several such reductions in ONE launch (round 4): the terminal sums of a layer's backward -- the slice partials of both
 // projections' weight gradients and the per-(b,h) partials of the landmark parameters -- each cost a 6-10 us launch of their
-// own.  Segment k: out_k[j] = sum_s part_k[s * ld_k + j]; blocks [blk0_k, blk0_{k+1}) work on it, same order of additions
-// as part_sum_kernel.
+// own.  Segment k: out_k[j] = sum_s part_k[s * ld_k + j]; blocks [blk0_k, blk0_{k+1}) work on it, in part_sum_kernel's order
+// of additions for segments of up to 96 slices (a fixed order of their own for the wide ones).
 struct MultiSumP {
   const float* part[6];
   float* out[6];
   int S[6], n4[6], blk0[7];
   long ld4[6];
   int nseg;
+  int wide;          // bit k: segment k has many slices (the per-(b,h) partials of the landmark parameters, S = B*h): a block
+                     // owns 8 float4 columns with 32 slice lanes instead of 32 columns with 8 -- a thread of the narrow
+                     // layout walked 48 slices in 12 dependent rounds of loads, the launch's whole duration (round 5)
 };
 __global__ __launch_bounds__(256) void multi_sum_kernel(const MultiSumP p) {
-  __shared__ f32x4 red[8][32];
+  __shared__ f32x4 red[256];
   int k = 0;
 #pragma unroll
   for (int i = 1; i < 6; ++i) k += (i < p.nseg && (int)blockIdx.x >= p.blk0[i]) ? 1 : 0;
-  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int j = ((int)blockIdx.x - p.blk0[k]) * 32 + c;
+  const bool wide = (p.wide >> k) & 1;
+  const int cols = wide ? 8 : 32, lanes = wide ? 32 : 8;
+  const int c = wide ? (threadIdx.x & 7) : (threadIdx.x & 31), sl = wide ? (threadIdx.x >> 3) : (threadIdx.x >> 5);
+  const int j = ((int)blockIdx.x - p.blk0[k]) * cols + c;
   const int S = p.S[k], n4 = p.n4[k];
   const long ld4 = p.ld4[k];
   const f32x4* src = reinterpret_cast<const f32x4*>(p.part[k]) + min(j, n4 - 1);
   f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
   int s = sl;
-  for (; s + 24 < S; s += 32) {
-    const f32x4 v0 = src[(size_t)s * ld4], v1 = src[(size_t)(s + 8) * ld4];
-    const f32x4 v2 = src[(size_t)(s + 16) * ld4], v3 = src[(size_t)(s + 24) * ld4];
+  for (; s + 3 * lanes < S; s += 4 * lanes) {
+    const f32x4 v0 = src[(size_t)s * ld4], v1 = src[(size_t)(s + lanes) * ld4];
+    const f32x4 v2 = src[(size_t)(s + 2 * lanes) * ld4], v3 = src[(size_t)(s + 3 * lanes) * ld4];
     a0 += v0; a1 += v1; a2 += v2; a3 += v3;
   }
-  for (; s < S; s += 8) a0 += src[(size_t)s * ld4];
-  red[sl][c] = (a0 + a1) + (a2 + a3);
+  for (; s < S; s += lanes) a0 += src[(size_t)s * ld4];
+  red[sl * cols + c] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && j < n4) {
-    f32x4 t = red[0][c];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) t += red[i][c];
+    f32x4 t = red[c];
+    for (int i = 1; i < lanes; ++i) t += red[i * cols + c];
     reinterpret_cast<f32x4*>(p.out[k])[j] = t;
   }
 }
@@ -329,7 +333,9 @@ int multi_sum_dispatch(int K, const float* const* part, const int* S, const int*
         ((uintptr_t)part[k] & 15) || ((uintptr_t)out[k] & 15)) return EA_E_BADARG;
     p.part[k] = part[k]; p.out[k] = out[k]; p.S[k] = S[k]; p.n4[k] = n[k] / 4; p.ld4[k] = (long)(ld[k] / 4);
     p.blk0[k] = blk;
-    blk += (p.n4[k] + 31) / 32;
+    const bool wide = S[k] > 96;
+    if (wide) p.wide |= 1 << k;
+    blk += (p.n4[k] + (wide ? 7 : 31)) / (wide ? 8 : 32);
   }
   p.blk0[K] = blk;
   p.nseg = K;

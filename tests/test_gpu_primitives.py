@@ -602,8 +602,9 @@ def test_lara_module_single_node_equals_three_nodes(gen, train):
 
 @pytest.mark.gpu
 def test_multi_sum_equals_fp64_sums_and_single_reductions():
-    """ea_multi_sum: up to six slice reductions in one launch -- bit-identical to ea_part_sum on each segment, and equal to
-    fp64 sums to fp32 accuracy; reproducible."""
+    """ea_multi_sum: up to six slice reductions in one launch -- equal to fp64 sums to fp32 accuracy, reproducible, and
+    bit-identical to ea_part_sum on the segments of up to 96 slices (the many-slice segments -- the per-(b,h) partials of
+    the landmark parameters -- take a wider slice-lane layout with its own fixed order of additions, round 5)."""
     import torch
     from efficient_attention import _ops
     from efficient_attention import _native as nv
@@ -618,7 +619,10 @@ def test_multi_sum_equals_fp64_sums_and_single_reductions():
         assert float((o.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) * max(1.0, p.shape[0] ** 0.5 / 4)
         single = torch.empty_like(o)
         nv.call("ea_part_sum", p.shape[0], p.shape[1], p.shape[1], nv.ptr(p), nv.ptr(single), nv.stream())
-        assert torch.equal(o, single)
+        if p.shape[0] <= 96:
+            assert torch.equal(o, single)
+        else:
+            assert float((o - single).abs().max()) <= 1e-5 * float(ref.abs().max())
     one = _ops.multi_sum(parts[:1])
     assert torch.equal(one[0], outs[0])
 
