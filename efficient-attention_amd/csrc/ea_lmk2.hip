@@ -254,16 +254,23 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     __syncthreads();
     // F4: omega rows of this strip (sample rows c), outputs
     f32x4 qr[NT];
+    {
+      // (round 5: reads unconditional from clamped rows + selects -- written as `if (c < C) read` every element became an
+      //  exec-mask branch with an LDS round trip inside it, and c % L was redone per element)
+      int rowl[4];
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
+      for (int r = 0; r < 4; ++r) rowl[r] = (min(r0 + r, C - 1) % L) * D;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = r0 + r, col = 16 * ct + l.li;
-        float m = 0.f, q = 0.f;
-        if (c < C) { m = XMU[(c % L) * D + col]; q = XQB[(c % L) * D + col]; }
-        om[ct][r] = c < C ? m + nz[ct][r] : 0.f;
-        qr[ct][r] = p.mis == 0 ? q : m;
-      }
+      for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = r0 + r, col = 16 * ct + l.li;
+          const float mv = XMU[rowl[r] + col], qv = XQB[rowl[r] + col];
+          const float m = c < C ? mv : 0.f, q = c < C ? qv : 0.f;
+          om[ct][r] = c < C ? m + nz[ct][r] : 0.f;
+          qr[ct][r] = p.mis == 0 ? q : m;
+        }
+    }
     gsave_strip<NT>(p.omega + oC, om, D, C, D, l);
     if (p.mis != 2) gsave_strip<NT>(p.qbar_rows + oC, qr, D, C, D, l);
     store_t<H, NT>(T3, om, 1.f, C, D, l);               // OMT [o][c]
@@ -273,15 +280,20 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     zero<4>(M);
     mm<H, 64, true, 64, false, 4>(M, T3, T2, KD, l);
     float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, d0[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
+    int cml[4];                                          // c mod L of this lane's four sample rows, once
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int r = 0; r < 4; ++r) cml[r] = min(r0 + r, C - 1) % L;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = 16 * ct + l.li;
+      const float hm = 0.5f * s * musq[col];             // (musq holds 64 entries: the read needs no guard)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = 16 * ct + l.li, c = r0 + r;
-        M[ct][r] = (col < L) ? s * M[ct][r] - 0.5f * s * musq[col] : -INFINITY;
+        M[ct][r] = (col < L) ? s * M[ct][r] - hm : -INFINITY;
         mx[r] = fmaxf(mx[r], M[ct][r]);
-        if (c < C && col == c % L) d0[r] = M[ct][r];
+        d0[r] = (r0 + r < C && col == cml[r]) ? M[ct][r] : d0[r];
       }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); d0[r] = row16_sum(d0[r]); }
 #pragma unroll
@@ -424,15 +436,20 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
       zero<4>(M);
       mm<H, 64, true, 64, false, 4>(M, T1, T0, KD, l);
       float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, d0[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
+      int cml[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+      for (int r = 0; r < 4; ++r) cml[r] = min(r0 + r, C - 1) % L;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = 16 * ct + l.li;
+        const float hm = 0.5f * s * musq[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int col = 16 * ct + l.li, c = r0 + r;
-          M[ct][r] = (col < L) ? s * M[ct][r] - 0.5f * s * musq[col] : -INFINITY;
+          M[ct][r] = (col < L) ? s * M[ct][r] - hm : -INFINITY;
           mx[r] = fmaxf(mx[r], M[ct][r]);
-          if (c < C && col == c % L) d0[r] = M[ct][r];
+          d0[r] = (r0 + r < C && col == cml[r]) ? M[ct][r] : d0[r];
         }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { mx[r] = row16_max(mx[r]); d0[r] = row16_sum(d0[r]); }
 #pragma unroll
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           const int col = 16 * ct + l.li;
-          dM[ct][r] = (c < C && col < L) ? dlse * __expf(M[ct][r] - lse) * mult + ((p.mis == 0 && col == c % L) ? dlp : 0.f) : 0.f;
+          dM[ct][r] = (c < C && col < L) ? dlse * __expf(M[ct][r] - lse) * mult + ((p.mis == 0 && col == cml[r]) ? dlp : 0.f) : 0.f;
         }
       }
     }
@@ -479,13 +496,18 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
     mm<H, 64, true, 64, true, NT>(dom, T4, T0, 2, l);    // A = dM rows c (DMT = [k][m]),   B = MU (MUT = [n][k])
     {
       const float al = s / sdm;
+      float dmc[4];                                      // column sums of dM for this lane's four rows, once (cpart: 4 x 64)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + r;
+        const float v = cpart[row] + cpart[64 + row] + cpart[128 + row] + cpart[192 + row];
+        dmc[r] = row < L ? v : 0.f;
+      }
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = r0 + r;
-          const float dmc = row < L ? cpart[row] + cpart[64 + row] + cpart[128 + row] + cpart[192 + row] : 0.f;
-          dmu[ct][r] = al * dmu[ct][r] - s * dmc * mu[ct][r];
+          dmu[ct][r] = al * dmu[ct][r] - s * dmc[r] * mu[ct][r];
           dom[ct][r] = gin[ct][r] + gqr[ct][r] + al * dom[ct][r];
         }
     }
