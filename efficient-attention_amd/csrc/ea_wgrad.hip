@@ -380,6 +380,8 @@ int wgrad_slices(int rows, int M, int K) {
     while (Sf > 1 && rows / Sf < 256) --Sf;
     if (Sf * T > S * T && (Sf & 7) != 0) S = Sf;
   }
+  // (the kernel addresses a slice's rows by 32-bit byte offsets: more slices before a slice reaches 4 GB)
+  while ((long)((rows + S - 1) / S + 64) * std::max(M, K) * 2 >= (1L << 32)) S += 8;
   return S;
 }
 
@@ -416,6 +418,7 @@ int wgrad_pair_slices(int rows, int M1, int K1, int M2, int K2) {
   int S = per_xcd / T * 8;
   if (S < 8) S = 8;
   while (S > 8 && rows / S < 256) S -= 8;
+  while ((long)((rows + S - 1) / S + 64) * std::max(std::max(M1, K1), std::max(M2, K2)) * 2 >= (1L << 32)) S += 8;
   return S;
 }
 
