@@ -333,10 +333,12 @@ def main():
 
     from efficient_attention import _ops
 
-    # The qkv / output projections are plain library GEMMs (hipBLASLt / rocBLAS).  Their default
-    # heuristic picks poor tiles for these skinny shapes (N = 192 / 576), so the untimed warm-up
-    # steps run with PyTorch's TunableOp selecting the solution per shape; selection is frozen
-    # before the step is captured / timed.
+    # Which projections are library GEMMs depends on the width: a 64..256-wide layer runs every product on this library's
+    # own kernels (ea_linear*, ea_wgrad*, ea_linear_dgrad*) and has NO library GEMM in its step; wider layers (cfg5, the LM
+    # workload, PvT stages 3-4) take the kernels of ea_gemm.hip for widths it covers and hipBLASLt / rocBLAS otherwise.  For
+    # the latter the untimed warm-up steps run with PyTorch's TunableOp selecting the solution per shape (the default
+    # heuristic picks poor tiles for skinny shapes); selection is frozen before the step is captured / timed.
+    # `config.gemm_tunableop` says whether a library GEMM actually ran under it (TunableOp recorded a result).
     tune = not a.no_gemm_tune
     if tune:
         import torch.cuda.tunable as tunable
@@ -410,8 +412,13 @@ def main():
     for _ in range(max(a.warmup, 1)):
         step()
     torch.cuda.synchronize()
+    gemm_tuned = False
     if tune:
         tunable.tuning_enable(False)
+        try:                                   # did a library GEMM run at all?  (192-wide steps have none)
+            gemm_tuned = len(tunable.get_results()) > 0
+        except Exception:
+            gemm_tuned = None
 
     def capture(fn):
         s = torch.cuda.Stream()
@@ -549,17 +556,26 @@ def main():
                 return {}
             rec = json.load(open(path))
             return rec if rec.get("_lib_sha256") == sha else {}
-        pmc, sq = _stamped("pmc_%s.json" % a.attn), _stamped("sq_%s.json" % a.attn)
+        wl_sfx = "_" + a.workload if a.workload in ("cfg2", "cfg5") else ""
+        pmc, sq = _stamped("pmc_%s%s.json" % (a.attn, wl_sfx)), _stamped("sq_%s%s.json" % (a.attn, wl_sfx))
 
         def _entry(name, st, algo_bytes):
             # achieved = SUMMED algorithmic bytes / SUMMED time of every launch under the label (== bytes / avg duration
             # when all launches of the label have one shape, which the per-shape labels guarantee)
             ach = algo_bytes * st["n"] / (st["total_ms"] * 1e-3) / 1e9
             mu = sq.get(name, {}).get("mfma_util") if isinstance(sq.get(name), dict) else None
-            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc.get(name), "avg_us": round(st["avg_ms"] * 1e3, 2),
-                    "launches": st["n"], "algo_bytes_per_launch": algo_bytes,
-                    "mfma_util": None if mu is None else round(mu, 4)}
+            # two clocks: `avg_us` / `achieved` / `frac` = HIP events around every launch of an EAGER instrumented pass, live in
+            # this run; `rocprof_avg_us` / `frac_rocprof` = the kernel's average duration in the rocprofv3 kernel trace of the
+            # CAPTURED step (profiles/pmc_<attn>.json, only while it is stamped with this build of the library).  The event
+            # clock includes the record overhead: it read 58.9 us where the trace read 54.0
+            rp = (pmc.get("_rocprof_avg_us") or {}).get(name.split("[")[0])
+            e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc.get(name), "avg_us": round(st["avg_ms"] * 1e3, 2),
+                 "clock": "hip_events_eager",
+                 "rocprof_avg_us": rp, "frac_rocprof": None if not rp else round(algo_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                 "launches": st["n"], "algo_bytes_per_launch": algo_bytes,
+                 "mfma_util": None if mu is None else round(mu, 4)}
+            return e
         # `roofline`: the kernel with the largest total time AMONG THOSE SURVEY 8(d) PRICES -- the attention kernels that
         # stream q, k, v, out and their gradients (KERNEL_ALGO_UNITS: [B,H,N,D] tensors read + written per launch).  The
         # projection kernels (the module edges) have no 8(d) bytes: they are reported under
@@ -570,13 +586,13 @@ def main():
             roof = _entry(name, st, _ops.KERNEL_ALGO_UNITS[name] * unit_bytes)
             roof["attention_kernels"] = {k: _entry(k, v, _ops.KERNEL_ALGO_UNITS[k] * unit_bytes) for k, v in priced}
             for v in roof["attention_kernels"].values():
-                del v["kernel"], v["bound"], v["peak"], v["unit"]
+                del v["kernel"], v["bound"], v["peak"], v["unit"], v["clock"]
             roof["projection_kernels"] = {}
             for k, v in ktimes.items():
                 rec = _ops.LABEL_ALGO_BYTES.get(k)
                 if rec and rec[1]:
                     e = _entry(k, v, rec[0] // rec[1])
-                    del e["kernel"], e["bound"], e["peak"], e["unit"], e["traffic"], e["mfma_util"]
+                    del e["kernel"], e["bound"], e["peak"], e["unit"], e["traffic"], e["mfma_util"], e["clock"]
                     roof["projection_kernels"][k] = e
             roof["all_kernels_avg_us"] = {k: round(v["avg_ms"] * 1e3, 2) for k, v in ktimes.items()}
             if name.startswith("ea_softmax_attn") and N >= 600:
@@ -649,7 +665,7 @@ def main():
                        # one flat fp32 bucket of every parameter gradient per step (efficient_attention.data_parallel); a
                        # ring all-reduce moves 2 (N - 1) / N of it over each GPU's links
                        "allreduce_bytes_per_step": (sum(prm.numel() for prm in params) * 4) if ddp else None,
-                       "gemm_tunableop": tune},
+                       "gemm_tunableop": gemm_tuned},
             "hbm_roofline_tokens_per_s_per_gpu": HBM_PEAK_GBS * 1e9 / (BYTES_PER_TOKEN_HEAD * H * d / 64),
             # whole layer priced on the op-level q,k,v -> out traffic (1536*h bytes per token at d = 64)
             "layer_algorithmic_gbs": value / world * BYTES_PER_TOKEN_HEAD * H * d / 64 / 1e9,

@@ -1505,7 +1505,9 @@ int lara_layer_plan(const ea_lara_layer* c, LaraLayerPlan& P) {
   const bool fold_on = !(fold_env && fold_env[0] == '0');
   P.fold_f = fold_on && P.S_fwd <= 4;
   P.fold_b = fold_on && P.S_bwd <= 4;
-  P.b_domk = take(P.fold_b ? CD * P.S_bwd : 0);
+  // reserved whatever the switch says: the caller memoises the workspace sizes per geometry, and a size that followed the
+  // environment would let a later call with the fold ON write p_domk past a buffer sized with it OFF
+  P.b_domk = take(P.S_bwd <= 4 ? CD * P.S_bwd : 0);
   P.n_btmp = o;
   return EA_OK;
 }

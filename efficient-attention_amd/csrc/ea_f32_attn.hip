@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NT) void ga_fwd_kernel(const GaP p) {
         const float pv = m[r] == -INFINITY ? 0.f : __expf(s[ct][r] - m[r]);
         ps[r] += pv;
         float kf = 1.f;
-        if (p.keep && qi[r].tok >= 0)
+        if (p.keep && qi[r].tok >= 0 && kkind[jl] != 2)     // (columns past the key list: the mask row ends at Wk + L)
           kf = p.keep[((size_t)(b * p.H + h) * p.Nq + qi[r].tok) * p.keep_ld + kc0 + jl] ? p.keep_scale : 0.f;
         Ps[(16 * wave + 4 * gq + r) * PLD + jl] = pv * kf;
       }

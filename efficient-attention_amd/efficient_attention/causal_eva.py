@@ -36,7 +36,6 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                  self_attention=False, q_noise=0.0, qn_block_size=8, attn_args=None):
         super().__init__()
         self._incremental_state_id = str(uuid.uuid4())
-        self._f32_full = False
         self.embed_dim = embed_dim
         self.kdim = embed_dim if kdim is None else kdim
         self.vdim = embed_dim if vdim is None else vdim
@@ -112,7 +111,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                     k[0].weight, k[0].bias, k[1].weight, k[1].bias]
         return [q[0].weight, q[0].bias, k[0].weight, k[0].bias]
 
-    def _project(self, query, key, value):
+    def _project(self, query, key, value, keep_f32=False):
         """Time-first [N, B, C] inputs -> fused [N, B, 3, h, d] in the kernels' I/O dtype."""
         N, B, C = query.shape
         if self.self_attention:
@@ -133,7 +132,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                 "the windowed path needs keys/values aligned with the queries"
             qkv = torch.stack([_ops.linear(query, self.q_proj), _ops.linear(key, self.k_proj),
                                _ops.linear(value, self.v_proj)], dim=2)
-        if not (self._f32_full and _f32.usable(qkv) and self.head_dim in (32, 64, 128)):
+        if not (keep_f32 and _f32.usable(qkv) and self.head_dim in (32, 64, 128)):
             qkv = _ops.to_io_dtype(qkv)
         return qkv.reshape(N, B, 3, self.num_heads, self.head_dim)
 
@@ -163,14 +162,12 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             if key_padding_mask is not None:
                 mask[:, :tgt_len] = key_padding_mask.to(torch.bool)
             mask[:, tgt_len:] = True
-        self._f32_full = True                             # (the full-sequence path has fp32 cores; decoding does not)
-        try:
-            if self.self_attention:
-                qkv5 = self._project(x, None, None)
-            else:
-                qkv5 = self._project(x, padded(key), padded(value))
-        finally:
-            self._f32_full = False
+        # (the full-sequence path has fp32 cores; decoding does not -- an explicit argument, not module state: forward stays
+        #  re-entrant)
+        if self.self_attention:
+            qkv5 = self._project(x, None, None, keep_f32=True)
+        else:
+            qkv5 = self._project(x, padded(key), padded(value), keep_f32=True)
         qkv5 = qkv5.transpose(0, 1)                       # [B, N, 3, h, d] view of the time-first buffer
 
         r = self.chunk_size if self.chunk_size is not None else int(N // self.num_chunks)

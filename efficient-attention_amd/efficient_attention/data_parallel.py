@@ -78,7 +78,12 @@ def select_schedule(schemes, prepare, sync, reduce_max, barrier=None, clock=time
     untimed steps, [barrier], sync, `timed` steps between two `clock()` readings with a `sync()` before the second, and
     `reduce_max(seconds)` -> the maximum over all ranks -- every rank therefore sees the same figures and takes the same
     decision (ties: the first schedule).  `forced` names the schedule to take without timing the others.
-    Returns (name, runnable callables, captured?, {name: seconds per `timed` steps})."""
+    Returns (name, runnable callables, captured?, {name: seconds per `timed` steps}).
+    BENCHMARK-ONLY side effects: the candidates are timed by running REAL steps on the one shared bucket, so
+    an update may be dropped (a candidate's pack() overwrites the reduced gradient the previous one left) or applied
+    twice (a stale bucket re-applied) while the race runs, and `pipelined` always leaves its last step's gradient in the
+    bucket.  A training loop that cares races on throw-away steps, then calls `flush_schedule(name, bucket, lr)` once when
+    it stops stepping (applies the trailing bucket of `pipelined`; a no-op for `three_part`)."""
     if forced is not None:
         if forced not in schemes:
             raise KeyError("unknown schedule %r (have: %s)" % (forced, ", ".join(schemes)))
@@ -104,3 +109,11 @@ def select_schedule(schemes, prepare, sync, reduce_max, barrier=None, clock=time
     if best is None:
         raise ValueError("select_schedule: no schedule given")
     return best[1], best[2], best[3], seen
+
+
+def flush_schedule(name, bucket, lr):
+    """Finalizer of a run of `ddp_schedules` steps: `pipelined` applies step t's reduced gradient at the start of step
+    t + 1, so the last step's is still in the bucket -- apply it and zero the bucket; `three_part` has nothing pending."""
+    if name == "pipelined":
+        bucket.sgd_step(lr)
+        bucket.flat.zero_()

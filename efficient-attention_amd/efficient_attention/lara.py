@@ -252,10 +252,22 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
                      and type(self).merge_and_project is MultiheadAttention.merge_and_project
                      and (self.proj_drop.p == 0.0 or not self.training)
                      and _ops.lara_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda")))
+        dup = self.training and (self.use_multisample or self.use_antithetics)
+        # more samples than the 16-bit estimator kernels hold (128): decided BEFORE a projection is chosen, so that the plain
+        # 3-slot projection runs once (the folded 5-slot one would be thrown away and redone)
+        side = int(math.sqrt(L))
+        n_lm = side * side if len(seq_shape) == 2 else min(L, N)
+        over128 = n_lm * (2 if dup else 1) > 128
+        if over128 and not (_f32.ENABLED and x.is_cuda and d in (32, 64, 128)):
+            raise NotImplementedError(
+                "LinearRA: %d samples exceed the 128 the 16-bit estimator kernels hold and the generic fp32 kernels are "
+                "%s" % (n_lm * (2 if dup else 1), "switched off (EA_F32_CORES=0)" if not _f32.ENABLED else
+                        "not available for head_dim %d / this device" % d))
         qkv5 = None
+        if over128:
+            fold_1d = module_fn = False
         if not module_fn:
             qkv5 = self._project_qkv_folded(x.reshape(B, N, C)) if fold_1d else self.project_qkv(x.reshape(B, N, C))
-        dup = self.training and (self.use_multisample or self.use_antithetics)
         mode = 0
         if self.training:
             mode = 2 if self.use_multisample else (1 if self.use_antithetics else 0)
@@ -263,11 +275,9 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
 
         # ---- landmark proposals.  Fused HIP pipeline whenever the sample count fits (C <= 64) ----
-        side = int(math.sqrt(L))
-        n_lm = side * side if len(seq_shape) == 2 else min(L, N)
-        if n_lm * (2 if dup else 1) > 128 and _f32.ENABLED and x.is_cuda and d in (32, 64, 128):
-            # more samples than the 16-bit estimator kernels hold (128): the generic fp32 kernels on the 16-bit activations
-            # (exact in fp32) -- the reference takes any --num-landmarks (lara.py:188-196)
+        if over128:
+            # the generic fp32 kernels on the 16-bit activations (exact in fp32) -- the reference takes any --num-landmarks
+            # (lara.py:188-196)
             return self._forward_f32(x, key_padding_mask, qkv5=qkv5)
         fused_b = n_lm * (2 if dup else 1) <= 64 and d in (32, 64)
         fused_a = (fused_b and len(seq_shape) == 2 and self.pool_module_type == 'light'

@@ -62,14 +62,19 @@ ELEM_TOL = {"fp16": (1.5e-2, 1.5e-2), "bf16": (8e-2, 8e-2)}
 # (0.033 rms in fp16) while the norm-wise figures stay at 5.9e-2 / 3.0e-2 -- its bound says so instead of pretending otherwise.
 ELEM_TOL_VARIANT = {("lara", "bf16"): (1.5e-1, 1.5e-1), ("lara", "fp16"): (2.5e-2, 2.5e-2),
                     ("performer", "bf16"): (1.2e-1, 1.2e-1),
-                    ("scatterbrain", "bf16"): (7e-1, 7e-1), ("scatterbrain", "fp16"): (5e-2, 5e-2)}
+                    # ScatterBrain in bf16 is checked NORM-WISE ONLY (SCATTER_TOL above): a (0.7, 0.7) "bound" admits a 70 % wrong
+                    # element and was a bound in name only.  Its element-wise evidence is the fp16 run of the
+                    # same fixtures (5e-2 / 5e-2) and tools/sb_check.py (kernels vs an fp32 evaluation of the same bf16 qkv: 6e-3)
+                    ("scatterbrain", "bf16"): None, ("scatterbrain", "fp16"): (5e-2, 5e-2)}
 ELEM_EXEMPT = {("performer_2d_clamp", "bf16")}
 
 
 def elem_tol_for(attn, dtype, name=None):
     if (name, dtype) in ELEM_EXEMPT:
         return None
-    return ELEM_TOL_VARIANT.get((attn, dtype), ELEM_TOL[dtype])
+    if (attn, dtype) in ELEM_TOL_VARIANT:
+        return ELEM_TOL_VARIANT[(attn, dtype)]            # (None: no element-wise bound for this variant / dtype)
+    return ELEM_TOL[dtype]
 _OBSERVED = None
 
 

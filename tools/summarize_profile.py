@@ -102,8 +102,13 @@ def main(src, tag, attn, outdir, workload="default workload"):
         lines.append("")
         lines.append("Per step (all ea:: kernels x launches per step): %.1f MB; attention kernels only: %.1f MB."
                      % (out["_step_traffic_bytes"] / 1e6, out["_step_traffic_bytes_attention"] / 1e6))
+    # kernel durations of the CAPTURED step (the kernel trace of the same command): bench.py reports them next to its own
+    # eager HIP-event timings (roofline.rocprof_avg_us / frac_rocprof) -- the eager clock reads ~9 % long on short kernels
+    out["_rocprof_avg_us"] = {e: round(v / 1e3, 3) for e, v in avg_ns.items() if e != "ea_stream_copy"}
     out["_lib_sha256"] = lib_sha()            # bench.py ignores the file once the library has changed
-    json.dump(out, open(os.path.join(outdir, "pmc_%s.json" % attn), "w"), indent=1)
+    # one counter file per (variant, workload): the default cfg3 (and causal_eva's lm) keep pmc_<attn>.json, cfg2 / cfg5 get a suffix
+    sfx = "_" + workload if workload in ("cfg2", "cfg5") else ""
+    json.dump(out, open(os.path.join(outdir, "pmc_%s%s.json" % (attn, sfx)), "w"), indent=1)
     open(os.path.join(outdir, "%s_%s_hbm.md" % (tag, attn)), "w").write(
         "HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --attn %s "
         "%s.\nFETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B; "
