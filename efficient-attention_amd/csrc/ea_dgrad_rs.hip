@@ -11,6 +11,7 @@
 // The weight reaches the registers TRANSPOSED without a transposed copy in memory: the [576][192] matrix (fp32 master, rounded
 // on the way, or the 16-bit copy the forward projection left) passes LDS in 18 pieces of 32 rows, stored row-permuted so that
 // two ds_read_b64_tr_b16 per piece hand lane (g, li) the values W[32 p + 8 g .. + 7][16 w + li] -- its eight k-slots.
+#include <stdlib.h>
 #include "ea_common.h"
 
 namespace ea {
@@ -152,14 +153,24 @@ struct DgFinP {
   float pool_inv, scale, scale_log2;
   int splits, tps, nunits;            // token ranges per image, tokens per range (multiple of 32), B * splits
   unsigned m_gw, m_r;                 // floor(2^32 / gw) + 1, floor(2^32 / pool_r) + 1
+  // cell-major token order (PR = 2 / 4, round 6): a tile = 32 / (PR PR) WHOLE pooling cells, a unit = `cps` cells of an image
+  int cps;                            // cells per unit (multiple of the cells per tile)
+  unsigned m_cw;                      // floor(2^32 / cw) + 1
 };
 
 constexpr int DG_QT = 3 * DG_TOK * 128;                   // q rows of a tile: 12 KB
 constexpr int DG_LMR = 64 * 128;                          // one [64][64] landmark matrix, 16-bit: 8 KB
 constexpr int DG_FIN_LDS = 2 * DG_TILE + 2 * DG_QT + 6 * DG_LMR + 3 * 64 * 4;
 
-template <typename E, bool WF32, bool OF32, bool HAS_T, bool POOL>
+// PR (round 6): 0 = a tile is 32 consecutive tokens of the image (any pooling cell size); 2 / 4 = a tile is 8 / 2 whole
+// PR x PR pooling cells, tokens cell-major (every row is still read and written whole, only the order inside a tile changes
+// -- ea_proj_rs.hip walks the forward the same way).  In row-major order a 32-token tile of a 28-wide grid touches 8-9 cells
+// per head and side: 12 KB of pooled-gradient rows per tile next to the tile's own 48 KB, a quarter more through the CU's
+// L2 port (measured with the reads compiled out: 86 -> 76 us at cfg3); cell-major it is 2 cells = 3 KB.
+template <typename E, bool WF32, bool OF32, bool HAS_T, bool POOL, int PR>
 __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFinP p) {
+  static_assert(PR == 0 || (POOL && (PR == 2 || PR == 4)), "cell-major order needs 2 x 2 or 4 x 4 pooling cells");
+  constexpr int TPC = PR * PR, CPT = PR ? DG_TOK / (PR * PR) : 1;      // tokens per cell, cells per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const tile0 = smem;
   char* const tile1 = smem + DG_TILE;
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
   // ---- staging slot of this thread: token s_tok of the tile, 16-byte chunk s_c of its q, its k and its v columns (32 tokens
   // x 24 chunks = 768 threads; chunk s_c = head s_c >> 3, channels 8 (s_c & 7) ..) -- which slot is q / k / v is static, so
   // only the rows that take a pooling term carry one in flight ----
-  const int s_tok = tid / 24, s_c = tid - s_tok * 24;
+  // (computed where they are used, from an opaque copy of the thread index per tile: as loop invariants they and the LDS /
+  //  global offsets derived from them sat in ~16 registers that the tile loop does not have -- they were spilled and re-read)
   // ---- W^T -> registers (as dgrad_rs_kernel) ----
   typename E::x8 wr[DG_KT];
   {
@@ -218,28 +230,49 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
   int buf = 0;
   for (int u = blockIdx.x; u < p.nunits; u += gridDim.x) {
     const int b = u / p.splits, sp = u - b * p.splits;
-    const int n0 = sp * p.tps, n1 = min(p.ntok, n0 + p.tps);
+    // PR == 0: token range [n0, n1) of the image; PR > 0: cell range [n0, n1)
+    const int n0 = PR ? sp * p.cps : sp * p.tps, n1 = PR ? min(p.L, n0 + p.cps) : min(p.ntok, n0 + p.tps);
     const size_t row0 = (size_t)b * p.ntok;
-    const int ntile = (n1 - n0 + DG_TOK - 1) / DG_TOK;
-    // token (within the image) behind slot row r of tile t, clamped to the range (duplicates recompute and rewrite identical values)
-    auto tok_of = [&](int t, int r) { return min(n0 + t * DG_TOK + r, n1 - 1); };
+    const int ntile = PR ? (n1 - n0 + CPT - 1) / CPT : (n1 - n0 + DG_TOK - 1) / DG_TOK;
+    // pooling cell behind slot row r of tile t (PR > 0), clamped to the unit (duplicates recompute and rewrite identical values)
+    auto slot_cell = [&](int t, int r) { return min(n0 + t * CPT + r / (TPC ? TPC : 1), n1 - 1); };
+    // token (within the image) behind slot row r of tile t, clamped likewise
     // (divisions as multiply-high by floor(2^32 / d) + 1, exact for n d < 2^32: three integer divisions per slot and tile were
     //  ~1.2 us of VALU time per tile on a kernel whose tile takes 6)
-    auto cell_of = [&](int tok) {
+    auto tok_of = [&](int t, int r) {
+      if constexpr (PR == 0) {
+        return min(n0 + t * DG_TOK + r, n1 - 1);
+      } else {
+        const int cell = slot_cell(t, r), w = r % TPC;
+        const int cy = (int)__umulhi((unsigned)cell, p.m_cw), cx = cell - cy * p.cw;
+        return (cy * PR + w / PR) * p.gw + cx * PR + w % PR;
+      }
+    };
+    auto cell_of_tok = [&](int tok) {
       const int y = (int)__umulhi((unsigned)tok, p.m_gw), x = tok - y * p.gw;
       return (int)__umulhi((unsigned)y, p.m_r) * p.cw + (int)__umulhi((unsigned)x, p.m_r);
     };
+    // cell of slot row r of tile t
+    auto cell_of = [&](int t, int r) {
+      if constexpr (PR == 0) return cell_of_tok(tok_of(t, r));
+      else return slot_cell(t, r);
+    };
     u32x4 nb[3], nq;                                       // dq, dk, dv chunk of the slot; its q chunk (HAS_T)
     f32x4 npk[2], npq[2];                                  // pooled-row gradients of the slot's dk chunk (dq chunk: !HAS_T)
-    auto issue = [&](int t) {
+    auto issue = [&](int t, int s_tok, int s_c) {
       const int tok = tok_of(t, s_tok);
       const char* rowp = p.d.dy + ((row0 + tok) * p.d.ldy + s_c * 8) * 2;
       nb[0] = ldg16(rowp);
       nb[1] = ldg16(rowp + 192 * 2);
       nb[2] = ldg16(rowp + 384 * 2);
       if constexpr (HAS_T) nq = ldg16(p.qkv + ((row0 + tok) * p.ldq + s_c * 8) * 2);
+#ifdef EA_DGF_NOPOOLREAD        // dev (timing only, wrong results): what do the pooled-gradient reads cost?
+      npk[0] = npk[1] = npq[0] = npq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (false) {
+#else
       if (pool) {
-        const size_t o = ((size_t)(b * 3 + (s_c >> 3)) * p.L + cell_of(tok)) * 64 + (s_c & 7) * 8;
+#endif
+        const size_t o = ((size_t)(b * 3 + (s_c >> 3)) * p.L + cell_of(t, s_tok)) * 64 + (s_c & 7) * 8;
         npk[0] = *reinterpret_cast<const f32x4*>(p.dpk + o);
         npk[1] = *reinterpret_cast<const f32x4*>(p.dpk + o + 4);
         if constexpr (!HAS_T) {
@@ -248,14 +281,25 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         }
       }
     };
-    issue(0);
+    {
+      int tid_i = tid;
+      asm volatile("" : "+v"(tid_i));
+      const int st = tid_i / 24;
+      issue(0, st, tid_i - st * 24);
+    }
     if constexpr (HAS_T) {
       // landmark rows of the image's three heads: (u qbar) and qbar as swizzled 16-bit rows, zero beyond C; lse_t (log2)
       // (the previous unit's readers are past the second barrier of its last tile: nobody reads these any more)
+      // The slot arithmetic below is a function of the thread index alone: left alone, hipcc hoists all of it (~40 registers
+      // of offsets and flags) out of the unit loop and parks it in scratch for the duration of the tile loop (160 B / lane,
+      // profiles/r05_resources.md).  An opaque copy of the thread index per unit keeps it where it is used -- a few dozen
+      // integer instructions once per 13 tiles.
+      int tid_u = tid;
+      asm volatile("" : "+v"(tid_u));
       f32x4 rb[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = tid + j * (DG_WAVES * 64);          // 6 matrices x 64 rows x 8 chunks = 3072 slots
+        const int idx = tid_u + j * (DG_WAVES * 64);        // 6 matrices x 64 rows x 8 chunks = 3072 slots
         const int m = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
         const float* src = (m < 3 ? p.uq : p.qbar) + ((size_t)(b * 3 + (m < 3 ? m : m - 3)) * p.C + min(row, p.C - 1)) * 64 + c * 8;
         // unconditional loads from clamped rows, pinned (`cond ? load : 0` comes back as a predicated load with a full wait
@@ -264,23 +308,26 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         rb[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
         asm volatile("" : "+v"(rb[j][0]), "+v"(rb[j][1]));
       }
-      float lsv = p.lse_t[(size_t)(b * 3 + min(tid >> 6, 2)) * p.C + min(tid & 63, p.C - 1)] * LOG2E;
+      float lsv = p.lse_t[(size_t)(b * 3 + min(tid_u >> 6, 2)) * p.C + min(tid_u & 63, p.C - 1)] * LOG2E;
       asm volatile("" : "+v"(lsv));
-      if (!(tid < 192 && (tid & 63) < p.C)) lsv = INFINITY;
+      if (!(tid_u < 192 && (tid_u & 63) < p.C)) lsv = INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = tid + j * (DG_WAVES * 64);
+        const int idx = tid_u + j * (DG_WAVES * 64);
         const int m = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
         const float zr = row < p.C ? 1.f : 0.f;
         const float f[8] = {rb[j][0][0] * zr, rb[j][0][1] * zr, rb[j][0][2] * zr, rb[j][0][3] * zr,
                             rb[j][1][0] * zr, rb[j][1][1] * zr, rb[j][1][2] * zr, rb[j][1][3] * zr};
         sts16((m < 3 ? R1 + m * DG_LMR : R2 + (m - 3) * DG_LMR) + TileL<64>::off(row, c), pack8<E>(f));
       }
-      if (tid < 192) LS[tid] = lsv;
+      if (tid_u < 192) LS[tid_u] = lsv;
     }
     for (int t = 0; t < ntile; ++t, buf ^= 1) {
       char* const tb = buf ? tile1 : tile0;
       char* const qb = qt0 + buf * DG_QT;
+      int tid_t = tid;
+      asm volatile("" : "+v"(tid_t));
+      const int s_tok = tid_t / 24, s_c = tid_t - s_tok * 24;
       // ---- commit: pooling terms added on the way (one rounding), changed rows written back at once ----
       {
         char* grow = const_cast<char*>(p.d.dy) + ((row0 + tok_of(t, s_tok)) * p.d.ldy + s_c * 8) * 2;
@@ -308,12 +355,16 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
       // the pooled-q rows of this wave's correction piece: requested BEFORE the next tile's rows, so that waiting for them
       // (the memory counter retires in order) leaves that prefetch in flight
       f32x4 pq4[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#ifdef EA_DGF_NOPOOLREAD
+      if constexpr (false) {
+#else
       if constexpr (HAS_T && POOL) {
-        const float* src = p.dpq + ((size_t)(b * 3 + fh) * p.L + cell_of(tok_of(t, 16 * fnt + li))) * 64 + 4 * g;
+#endif
+        const float* src = p.dpq + ((size_t)(b * 3 + fh) * p.L + cell_of(t, 16 * fnt + li)) * 64 + 4 * g;
 #pragma unroll
         for (int j = 0; j < 2; ++j) pq4[j] = *reinterpret_cast<const f32x4*>(src + 16 * (2 * fdh + j));
       }
-      issue(min(t + 1, ntile - 1));                        // unconditional (static operation count; the last tile is fetched twice)
+      issue(min(t + 1, ntile - 1), s_tok, s_c);            // unconditional (static operation count; the last tile is fetched twice)
       __syncthreads();
       if constexpr (HAS_T) {
         // ---- dq -= s sum_c t[c,n] (u qbar)_c (+ the pooled-q term) for (head fh, tokens 16 fnt .., channels 32 fdh ..) ----
@@ -419,22 +470,28 @@ int dgrad_rs_dispatch(int dtype, const void* dy, const void* w, int w_f32, void*
   return (int)hipGetLastError();
 }
 
-int dgrad_fin_dispatch(int dtype, const DgFinP& p0, int w_f32, int dx_f32, bool has_t, hipStream_t st) {
+int dgrad_fin_dispatch(int dtype, const DgFinP& p0, int w_f32, int dx_f32, bool has_t, int pr, hipStream_t st) {
   DgFinP p = p0;
   if (p.d.rows <= 0) return EA_OK;
   int grid = ea_device_cus();
   if (grid > p.nunits) grid = p.nunits;
   const dim3 g((unsigned)grid), b(DG_WAVES * 64);
-#define EA_DF_LAUNCH(E_, WF_, OF_, T_, P_)                                                    \
+#define EA_DF_LAUNCH(E_, WF_, OF_, T_, P_, R_)                                                    \
+  do {                                                                                            \
+    EA_SET_LDS_ONCE((&dgrad_fin_kernel<E_, WF_, OF_, T_, P_, R_>), DG_FIN_LDS);                   \
+    hipLaunchKernelGGL((dgrad_fin_kernel<E_, WF_, OF_, T_, P_, R_>), g, b, DG_FIN_LDS, st, p);    \
+  } while (0)
+#define EA_DF_SEL3(E_, WF_, OF_, T_)                                                          \
   do {                                                                                        \
-    EA_SET_LDS_ONCE((&dgrad_fin_kernel<E_, WF_, OF_, T_, P_>), DG_FIN_LDS);                   \
-    hipLaunchKernelGGL((dgrad_fin_kernel<E_, WF_, OF_, T_, P_>), g, b, DG_FIN_LDS, st, p);    \
+    if (pr == 4) EA_DF_LAUNCH(E_, WF_, OF_, T_, true, 4);                                     \
+    else if (pr == 2) EA_DF_LAUNCH(E_, WF_, OF_, T_, true, 2);                                \
+    else EA_DF_LAUNCH(E_, WF_, OF_, T_, true, 0);                                             \
   } while (0)
 #define EA_DF_SEL2(E_, WF_, OF_)                                                              \
   do {                                                                                        \
-    if (has_t && p.dpq) EA_DF_LAUNCH(E_, WF_, OF_, true, true);                               \
-    else if (has_t) EA_DF_LAUNCH(E_, WF_, OF_, true, false);                                  \
-    else EA_DF_LAUNCH(E_, WF_, OF_, false, true);                                             \
+    if (has_t && p.dpq) EA_DF_SEL3(E_, WF_, OF_, true);                                       \
+    else if (has_t) EA_DF_LAUNCH(E_, WF_, OF_, true, false, 0);                               \
+    else EA_DF_SEL3(E_, WF_, OF_, false);                                                     \
   } while (0)
 #define EA_DF_SEL(E_)                                                                     \
   do {                                                                                    \
@@ -446,6 +503,7 @@ int dgrad_fin_dispatch(int dtype, const DgFinP& p0, int w_f32, int dx_f32, bool 
   else return EA_E_BADARG;
 #undef EA_DF_SEL
 #undef EA_DF_SEL2
+#undef EA_DF_SEL3
 #undef EA_DF_LAUNCH
   return (int)hipGetLastError();
 }
@@ -471,8 +529,20 @@ int dgrad_fin_launch(int dtype, const void* dqkv, long ldy, const void* qkv, lon
   if (tps < 2 * DG_TOK) tps = 2 * DG_TOK;
   p.tps = tps;
   p.splits = (p.ntok + tps - 1) / tps;
+  // 2 x 2 / 4 x 4 pooling cells: cell-major tiles, units of whole cells (EA_DGF_CELLS=0: the row-major order)
+  static const bool cells_on = !(getenv("EA_DGF_CELLS") && getenv("EA_DGF_CELLS")[0] == '0');
+  int pr = 0;
+  if (dpq && cells_on && (pool_r == 2 || pool_r == 4) && gh % pool_r == 0 && gw % pool_r == 0) {
+    pr = pool_r;
+    const int cpt = DG_TOK / (pr * pr);
+    int cps = ((p.L + splits - 1) / splits + cpt - 1) / cpt * cpt;
+    if (cps < 2 * cpt) cps = 2 * cpt;
+    p.cps = cps;
+    p.splits = (p.L + cps - 1) / cps;
+    p.m_cw = (unsigned)((1ull << 32) / (unsigned)p.cw) + 1u;
+  }
   p.nunits = B * p.splits;
-  return dgrad_fin_dispatch(dtype, p, w_f32, dx_f32, uq != nullptr, st);
+  return dgrad_fin_dispatch(dtype, p, w_f32, dx_f32, uq != nullptr, pr, st);
 }
 
 }  // namespace ea

@@ -66,6 +66,21 @@ EA_DEV void stage_rows3(char* const dst[3], const float* const src[3], int C, in
   }
 }
 
+// Reduce-scatter over the 16 lanes of a DPP row: every lane brings 16 values, lane li leaves with the row's sum of value li.
+// Four halving steps (partners li ^ 8, half-row mirror, quad reverse, li ^ 1: each flips the bit that decides which half of the
+// remaining values a lane keeps), 15 adds + 30 selects -- against 16 running sums held in registers for the whole launch.
+EA_DEV float row_reduce_scatter16(const float (&v)[16], int li) {
+  float w8[8], w4[4], w2[2];
+  const bool h8 = (li & 8) != 0, h4 = (li & 4) != 0, h2 = (li & 2) != 0, h1 = (li & 1) != 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w8[j] = (h8 ? v[8 + j] : v[j]) + dpp_mov<0x128>(h8 ? v[j] : v[8 + j]);        // row_ror:8
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w4[j] = (h4 ? w8[4 + j] : w8[j]) + dpp_mov<0x141>(h4 ? w8[j] : w8[4 + j]);    // row_half_mirror
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w2[j] = (h2 ? w4[2 + j] : w4[j]) + dpp_mov<0x1B>(h2 ? w4[j] : w4[2 + j]);     // quad_perm [3,2,1,0]
+  return (h1 ? w2[1] : w2[0]) + dpp_mov<0xB1>(h1 ? w2[0] : w2[1]);                                          // quad_perm [1,0,3,2]
+}
+
 template <typename E> EA_DEV typename E::x8 ones_x8() {
   const uint32_t o = (uint32_t)E::from_f(1.f) * 0x00010001u;
   return as_x8<E>(u32x4{o, o, o, o});
@@ -118,13 +133,15 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   float nlz, ntm;
   const float* lzb = p.lseZ + (size_t)bh * p.N;
   const float* tmb = p.tmean + (size_t)bh * p.N;
+  // (row offsets inside a (b,h) in 32 bits, as on the key side: the dispatcher checks N * stride < 2^30 elements)
+  const unsigned qsn = (unsigned)p.q.sn, dosn = (unsigned)p.dout.sn;
   auto issue = [&](int cb_) {
-    const int tok_ = min(cb_ + wave * 16 + li, last_tok);
+    const unsigned tok_ = (unsigned)min(cb_ + wave * 16 + li, last_tok);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int eo = (g * KS + ks) * 8;
-      nx1[ks] = ldg16(qb + (tok_ * p.q.sn + eo) * 2);
-      nx2[ks] = ldg16(dob + (tok_ * p.dout.sn + eo) * 2);
+      const unsigned eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(qb + (size_t)((tok_ * qsn + eo) * 2u));
+      nx2[ks] = ldg16(dob + (size_t)((tok_ * dosn + eo) * 2u));
     }
     nlz = lzb[tok_];
     ntm = tmb[tok_];
@@ -155,9 +172,14 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   f32x4 acc0[DT], acc1[DT], acc2[DT], acc3[DT], accR = {0.f, 0.f, 0.f, 0.f}, accU = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc0[dt] = acc1[dt] = acc2[dt] = acc3[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2 sdbh[NCT][2];
+  // per-landmark sums of d alpha (d bh).  Full last tile (LH == 2, four tiles): the 16 running sums per lane are what pushed
+  // this instantiation over the 256-register budget (72 B / lane of scratch, an accumulator quad spilled and re-read per
+  // chunk) -> one running sum per lane, the chunk's 16 values reduce-scattered over the row's 16 token lanes
+  constexpr bool RS = opt && LH == 2 && NCT == 4;
+  f32x2 sdbh[RS ? 1 : NCT][2];
+  float sdb1 = 0.f;
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) sdbh[ct][0] = sdbh[ct][1] = f32x2{0.f, 0.f};
+  for (int ct = 0; ct < (RS ? 1 : NCT); ++ct) sdbh[ct][0] = sdbh[ct][1] = f32x2{0.f, 0.f};
   const typename E::x8 ones = ones_x8<E>();
   __syncthreads();
   EA_STAMP(p, 1);
@@ -254,13 +276,21 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         if (opt) {
           da[ct][hh] = ez[ct][hh] * dd;                                    // dZ / alpha
           sda2 += da[ct][hh];
-          sdbh[ct][hh] += da[ct][hh];
+          if constexpr (!RS) sdbh[ct][hh] += da[ct][hh];
         }
       }
       Wp[ct] = u32x2{pack2<E>(wv[ct][0][0], wv[ct][0][1]), EA_LIVE(ct, 1) ? pack2<E>(wv[ct][1][0], wv[ct][1][1]) : 0u};
       dZp[ct] = u32x2{pack2<E>(dz[0][0], dz[0][1]), EA_LIVE(ct, 1) ? pack2<E>(dz[1][0], dz[1][1]) : 0u};
     }
     const float sda = quad_sum(sda2[0] + sda2[1]);
+    if constexpr (RS) {
+      float dflat[16];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) { dflat[4 * ct + 2 * hh] = da[ct][hh][0]; dflat[4 * ct + 2 * hh + 1] = da[ct][hh][1]; }
+      sdb1 += row_reduce_scatter16(dflat, li);       // lane li: landmark 16 (li >> 2) + 4 g + (li & 3)
+    }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       if (opt) {
@@ -379,7 +409,9 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
   EA_STAMP(p, 60);
   EA_BLKX(p, 1);
   // ---- per-landmark sums of d alpha: over the 16 token lanes, then over the four waves ----
-  if (opt) {
+  if constexpr (RS) {
+    DB[wave * Cp + 16 * (li >> 2) + 4 * g + (li & 3)] = sdb1;
+  } else if (opt) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -392,20 +424,25 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
         }
   }
   __syncthreads();
-  const int c = yct * 16 + li;
-  if (!ywave || c >= p.C) { EA_BLK(p, 1); return; }
+  // (epilogue coordinates re-derived from an opaque copy of the thread index, as in lara_fk_kernel)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int wave_e = tid_e >> 6, li_e = tid_e & 15, g_e = (tid_e & 63) >> 4;
+  const int yct_e = wave_e % NCT, ysub_e = wave_e / NCT;
+  const int c = yct_e * 16 + li_e;
+  if (!(wave_e < NCT * NSUB) || c >= p.C) { EA_BLK(p, 1); return; }
   const int S = p.nsplit * NSUB;
-  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub) * p.C + c;
-  if (g == 0) {
+  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub_e) * p.C + c;
+  if (g_e == 0) {
     float* ml = p.p_ml + slot * 4;
     float dbh = 0.f;
-    if (opt && ysub == 0) dbh = DB[c] + DB[Cp + c] + DB[2 * Cp + c] + DB[3 * Cp + c];
+    if (opt && ysub_e == 0) dbh = DB[c] + DB[Cp + c] + DB[2 * Cp + c] + DB[3 * Cp + c];
     ml[0] = accR[0]; ml[1] = dbh; ml[2] = accU[0]; ml[3] = 0.f;
   }
   auto put = [&](float* base, const f32x4* av) {
     float* d = base + slot * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g)) = make_float4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g_e)) = make_float4(av[dt][0], av[dt][1], av[dt][2], av[dt][3]);
   };
   put(p.p_acc0, acc0);
   put(p.p_acc1, acc1);
@@ -446,13 +483,16 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
 
   EA_BLK(p, 0);
   u32x4 nx1[KS], nx2[KS];
+  // row offsets inside a (b,h) in 32 bits (the dispatcher checks N * stride < 2^30 elements): the 64-bit products kept a
+  // register pair alive across the chunk loop that it does not have (spilled and re-read per chunk until round 6)
+  const unsigned ksn = (unsigned)p.k.sn, vsn = (unsigned)p.v.sn;
   auto issue = [&](int cb_) {
-    const int tok_ = min(cb_ + wave * 16 + li, last_tok);
+    const unsigned tok_ = (unsigned)min(cb_ + wave * 16 + li, last_tok);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const int eo = (g * KS + ks) * 8;
-      nx1[ks] = ldg16(kb_ + (tok_ * p.k.sn + eo) * 2);
-      nx2[ks] = ldg16(vb_ + (tok_ * p.v.sn + eo) * 2);
+      const unsigned eo = (g * KS + ks) * 8;
+      nx1[ks] = ldg16(kb_ + (size_t)((tok_ * ksn + eo) * 2u));
+      nx2[ks] = ldg16(vb_ + (size_t)((tok_ * vsn + eo) * 2u));
     }
   };
   issue(n0);
@@ -724,13 +764,19 @@ __global__ __launch_bounds__(256, 3) void lara_fk_kernel(const LaraP p) {
       }
     }
   }
-  const int c = yct * 16 + li;
-  if (!ywave || c >= p.C) { EA_BLK(p, 1); return; }
+  // (the epilogue's lane coordinates are re-derived from an opaque copy of the thread index: kept alive across the chunk
+  //  loop they cost three registers the loop does not have -- 16 B / lane of scratch until round 6)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int wave_e = tid_e >> 6, li_e = tid_e & 15, g_e = (tid_e & 63) >> 4;
+  const int yct_e = wave_e % NCT, ysub_e = wave_e / NCT;
+  const int c = yct_e * 16 + li_e;
+  if (!(wave_e < NCT * NSUB) || c >= p.C) { EA_BLK(p, 1); return; }
   const int S = p.nsplit * NSUB;
-  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub) * p.C + c;
+  const size_t slot = ((size_t)bh * S + blk * NSUB + ysub_e) * p.C + c;
   float* d = p.p_acc0 + slot * D;
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g)) = make_float4(acc0[dt][0], acc0[dt][1], acc0[dt][2], acc0[dt][3]);
+  for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<float4*>(d + acc_chan<D>(dt, g_e)) = make_float4(acc0[dt][0], acc0[dt][1], acc0[dt][2], acc0[dt][3]);
   EA_BLK(p, 1);
 }
 
@@ -960,6 +1006,9 @@ static int launch_f_nct(int which, LaraP& p, hipStream_t st) {
 int lara_f_dispatch(int which, const LaraP& p0, int dtype, hipStream_t st) {
   LaraP p = p0;
   p.prof = nullptr;
+  // key side: row offsets inside a (b,h) are formed in 32 bits (lara_fk_kernel)
+  if ((which == 1 || which == 3) && ((int64_t)p.N * p.k.sn >= (1ll << 30) || (int64_t)p.N * p.v.sn >= (1ll << 30))) return EA_E_UNSUPPORTED;
+  if (which == 0 && ((int64_t)p.N * p.q.sn >= (1ll << 30) || (int64_t)p.N * p.dout.sn >= (1ll << 30))) return EA_E_UNSUPPORTED;
 #ifdef EA_PROFILE
   ProfReport rep;
   p.prof = rep.arm(st, "lara_f", which);

@@ -32,6 +32,19 @@ namespace ea {
 // attention, 8 x 8 windows with 36 landmarks (PvT) -- the counts are template constants and the loops unroll into
 // straight-line code; SGdyn keeps the general kernel.
 
+// EA_RELANE (round 6): the run-time-geometry instantiations (SGdyn) keep ~40 lane-derived offsets alive from the prologue
+// through both phases and spill them (68-160 B / lane of scratch; stores in the prologue, reloads at the phase boundaries).
+// Each phase re-derives its lane coordinates from an opaque copy of the thread index instead (a dozen integer instructions
+// per phase and iteration); for the static geometries the copy is transparent and the code is unchanged.
+#define EA_RELANE(tag)                                                                                   \
+  int tid_##tag = threadIdx.x;                                                                           \
+  if constexpr (!STATIC) asm volatile("" : "+v"(tid_##tag));                                             \
+  const int tid = tid_##tag, lane = tid & 63, g = lane >> 4, li = lane & 15;                             \
+  const int wave = STATIC ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);                       \
+  typename LaneOffSel<D>::type lo;                                                                       \
+  lo.init(lane);                                                                                         \
+  (void)tid; (void)g; (void)li; (void)wave
+
 template <typename E, int D, bool GB, bool CA, bool DR, typename SG>
 __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const WinP p, const T4 outp, const float* biasT) {
   constexpr int ROWB = D * 2;
@@ -347,6 +360,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
 
     // =============================== phase A: dQ ===============================
     bool qact = false;                                 // HAND: this wave produced hand-over tiles in this iteration
+    {
+    EA_RELANE(A);
     for (int qi = wave; qi < wpi * nQT; qi += 4) {
       const int wi = qi / nQT, qt = qi - wi * nQT;
       const int win = it * wpi + wi;
@@ -513,6 +528,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
         for (int c = 0; c < DQ / 8; ++c) stg16(dst + c * 16, pack8<E>(f + 8 * c));
       }
     }
+    }
 
     if constexpr (HAND) {
       __syncthreads();                                 // every wave is done with the local K / V rows
@@ -530,6 +546,7 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     if (prof_it < 4) EA_STAMP(p, 6 + prof_it * 6);
     // =============================== phase B: dK, dV ===============================
     // work items: (window wi, local tile lt) for all staged windows, then landmark tile = wave
+    EA_RELANE(B);
     const int nLocalItems = wpi * nLT;
     // (is_lm as a compile-time tag: the local and the landmark items are two straight-line instances of the body)
     auto process_item = [&](auto lm_tag, int item) {
@@ -819,6 +836,8 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
     ++prof_it;
   }
   EA_STAMP(p, 60);
+  {
+  EA_RELANE(E);
 
   // ---- per-workgroup partial sums of the landmark and bias gradients ----
   if constexpr (HAND && SG::WPI > 1 && SG::NCT == 1) {
@@ -889,9 +908,11 @@ __global__ __launch_bounds__(256, D == 128 ? 1 : 2) void win_bwd_kernel(const Wi
       for (int idx = tid; idx < t.Wq * biasLd; idx += 256) dst[idx] = dbias_s[(idx / biasLd) * BLD + (idx % biasLd)];
     }
   }
+  }
   EA_STAMP(p, 61);
   EA_BLK(p, 1);
 }
+#undef EA_RELANE
 
 // fp32 scratch -> I/O dtype for the overlapping-window path
 template <typename E, int D>

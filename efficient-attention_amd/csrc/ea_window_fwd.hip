@@ -157,6 +157,15 @@ __global__ __launch_bounds__(256, D == 128 ? 2 : 4) void win_fwd_kernel(const Wi
     }
     __syncthreads();
 
+    // (run-time geometries: the query phase re-derives its lane coordinates from an opaque copy of the thread index -- one of
+    //  the prologue's lane offsets was spilled across the iteration loop: 8 B / lane of scratch until round 6; the copy is
+    //  transparent for the static geometries)
+    int tid_q = threadIdx.x;
+    if constexpr (!STATIC) asm volatile("" : "+v"(tid_q));
+    const int lane = tid_q & 63, g = lane >> 4, li = lane & 15;
+    const int wave = STATIC ? (tid_q >> 6) : __builtin_amdgcn_readfirstlane(tid_q >> 6);
+    typename LaneOffSel<D>::type lo;
+    lo.init(lane);
     for (int qi = wave; qi < wpi * nQT; qi += 4) {
       const int wi = qi / nQT, qt = qi - wi * nQT;
       const int win = it * wpi + wi;

@@ -38,6 +38,10 @@ FULL = {
     # 36 landmarks on a 28 x 28 grid: overlapping adaptive-pool bins (ea_adaptive_pool2d_*), '-vmixed' column bias
     "cfg3_lara_vmixed_uneven": ("lara", (32, 28, 28, 192), dict(dim=192, num_heads=3, num_landmarks=36,
                                                                  proposal_gen="pool-vmixed", mis_type="mis-bh"), None),
+    # 64 landmarks (8 x 8 pooling of a 32 x 32 grid): the last 16-landmark tile is FULL -- the LH = 2 instantiation of the fused
+    # query-side backward (row reduce-scatter of the d alpha sums, round 6), which no 49- / 36- / 16-landmark case selects
+    "lara_L64": ("lara", (24, 32, 32, 192), dict(dim=192, num_heads=3, num_landmarks=64, proposal_gen="pool-mixed",
+                                                  mis_type="mis-opt", alpha_coeff=2.0), None),
     "cfg3_scatterbrain": ("scatterbrain", (32, 28, 28, 192), dict(dim=192, num_heads=3, window_size=7, attn_2d=True, use_rpe=True,
                                                                    approx_attn_dim=64), None),
     # cfg2 (N = 196) at the DeiT batch
