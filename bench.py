@@ -633,6 +633,8 @@ def main():
             for other in ("eva", "softmax"):
                 if other != a.attn:
                     runs.append(("cfg3_N784_%s" % other, other, (B, C, H, seq)))
+                    if other == "eva":
+                        runs.append(("cfg2_N196_eva", "eva", (128, 192, 3, (14, 14))))      # BASELINE.json configs[1]
                     runs.append(("cfg5_N4096_B16_%s" % other, other, (16, 512, 8, (4096,))))
             # cfg4 (BASELINE.json config 4): the attention layers of the four PvTv2-b2 stages at 384 x 384, batch 32 per GPU
             # (pvt_legacy.py:309-319,349-359: dims 64/128/320/512, heads 1/2/5/8; grids 96/48/24/12).  The reference's own

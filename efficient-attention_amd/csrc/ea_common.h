@@ -260,7 +260,7 @@ EA_DEV float wave_sum(float v) {
 // `valid ? dst : ea_trash_line()` keeps the number of memory operations in a loop static, so the compiler can wait for
 // the prefetched loads alone (`s_waitcnt vmcnt(n_stores)`) instead of for everything (`vmcnt(0)`, which also waits for the
 // stores of the previous tile).  64 bytes per thread; nobody reads it.
-static __device__ char ea_trash[512 * 64];
+static __device__ __attribute__((aligned(64))) char ea_trash[512 * 64];
 EA_DEV char* ea_trash_line() { return ea_trash + threadIdx.x * 64; }
 
 #ifdef EA_NT_LOADS

@@ -236,6 +236,21 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
     const int ntile = PR ? (n1 - n0 + CPT - 1) / CPT : (n1 - n0 + DG_TOK - 1) / DG_TOK;
     // pooling cell behind slot row r of tile t (PR > 0), clamped to the unit (duplicates recompute and rewrite identical values)
     auto slot_cell = [&](int t, int r) { return min(n0 + t * CPT + r / (TPC ? TPC : 1), n1 - 1); };
+    // slot row r of tile t lies beyond the unit: a DUPLICATE of the unit's last cell / token.  It loads, computes and stores like
+    // every slot (static memory-operation counts), but its stores go to the trash line: two waves own the two copies of such a
+    // row and no barrier separates one's write-back from the other's load, so a copy that read the corrected row would add
+    // the pooling term twice and race the owner's stores (round 6: seen as run-to-run differences of dx at B = 3, 28 x 28, r = 4)
+    auto dup = [&](int t, int r) {
+      if constexpr (PR == 0) return n0 + t * DG_TOK + r > n1 - 1;
+      else return n0 + t * CPT + r / (TPC ? TPC : 1) > n1 - 1;
+    };
+    // (its address re-derived from an opaque copy of the thread index at every use: as a loop invariant it costs the two registers
+    //  that push the PR = 2 instantiations into scratch)
+    auto trash_line = [&]() {
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      return ea_trash + (t_ & 511) * 64;
+    };
     // token (within the image) behind slot row r of tile t, clamped likewise
     // (divisions as multiply-high by floor(2^32 / d) + 1, exact for n d < 2^32: three integer divisions per slot and tile were
     //  ~1.2 us of VALU time per tile on a kernel whose tile takes 6)
@@ -331,6 +346,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
       // ---- commit: pooling terms added on the way (one rounding), changed rows written back at once ----
       {
         char* grow = const_cast<char*>(p.d.dy) + ((row0 + tok_of(t, s_tok)) * p.d.ldy + s_c * 8) * 2;
+        const bool dp = dup(t, s_tok);
         u32x4 wq = nb[0], wk = nb[1];
         if (pool) {
           float f[8];
@@ -338,13 +354,13 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
 #pragma unroll
           for (int e = 0; e < 4; ++e) { f[e] += npk[0][e] * p.pool_inv; f[4 + e] += npk[1][e] * p.pool_inv; }
           wk = pack8<E>(f);
-          stg16(grow + 192 * 2, wk);
+          stg16(dp ? trash_line() : grow + 192 * 2, wk);
           if constexpr (!HAS_T) {
             unpack8<E>(wq, f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { f[e] += npq[0][e] * p.pool_inv; f[4 + e] += npq[1][e] * p.pool_inv; }
             wq = pack8<E>(f);
-            stg16(grow, wq);
+            stg16(dp ? trash_line() + 16 : grow, wq);
           }
         }
         sts16(tb + dg_off(s_c >> 3, s_tok, s_c & 7), wq);
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         }
         __syncthreads();
         // corrected dq chunk of this thread's slot back to memory (the weight-gradient pass reads it)
-        stg16(const_cast<char*>(p.d.dy) + ((row0 + tok_of(t, s_tok)) * p.d.ldy + s_c * 8) * 2,
+        stg16(dup(t, s_tok) ? trash_line() : const_cast<char*>(p.d.dy) + ((row0 + tok_of(t, s_tok)) * p.d.ldy + s_c * 8) * 2,
               lds16(tb + dg_off(s_c >> 3, s_tok, s_c & 7)));
       }
       // ---- input gradient of the corrected tile ----
@@ -425,15 +441,19 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
         acc[0][ks & 1] = E::mma(wr[ks], b0, acc[0][ks & 1]);
         acc[1][ks & 1] = E::mma(wr[ks], b1, acc[1][ks & 1]);
       }
+      int li_x = lane;                                     // (opaque: the token arithmetic of the two stores stays in the loop,
+      asm volatile("" : "+v"(li_x));                       //  not in registers / scratch across it)
+      li_x &= 15;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const size_t row = row0 + tok_of(t, 16 * rt + li);
+        const size_t row = row0 + tok_of(t, 16 * rt + li_x);
+        const bool dpx = dup(t, 16 * rt + li_x);
         const f32x4 v = acc[rt][0] + acc[rt][1];
         const int col = 16 * wave + 4 * g;
         if constexpr (OF32) {
-          *reinterpret_cast<f32x4*>(p.d.dx + (row * p.d.ldx + col) * 4) = v;
+          *reinterpret_cast<f32x4*>(dpx ? trash_line() : p.d.dx + (row * p.d.ldx + col) * 4) = v;
         } else {
-          *reinterpret_cast<u32x2*>(p.d.dx + (row * p.d.ldx + col) * 2) = u32x2{pack2<E>(v[0], v[1]), pack2<E>(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(dpx ? trash_line() : p.d.dx + (row * p.d.ldx + col) * 2) = u32x2{pack2<E>(v[0], v[1]), pack2<E>(v[2], v[3])};
         }
       }
     }

@@ -191,12 +191,79 @@ def to_io_dtype(t):
     return t.to(torch.bfloat16)
 
 
+USE_TABLE_BIAS = os.environ.get("EA_TABLE_BIAS", "1") == "1"
+
+
+class TableBias:
+    """A dense window bias that is a table read through a fixed index (round 6):
+        bias[hd, i, j] = scale * table[idx[i, j], hd]
+    -- `relative_position_bias_table[relative_position_index]` of the 2-D windows (local_attention.py:70-79) and the bucketed T5
+    bias (eva.py:53-65).  dense() builds it in the layout and units the window kernels stage ([h, Wq, ld] fp32, log2 units) in
+    ONE launch (ea_table_bias_fwd) and grad() takes the kernels' bias gradient back to the table in one (ea_table_bias_bwd):
+    the framework spent an index_select, a permute copy, a scalar multiply, a pad (fill + copy) and, in the backward, a slice
+    copy and the transposed chain on it -- six to eight launches of ~4 us in every EVA / local-window step.
+    The single-node module paths (EvaModuleFn, CoreModuleFn + LocalCore) take the TABLE as their differentiable input together
+    with this spec; every other path keeps the dense [h, Wq, Wk] bias."""
+
+    def __init__(self, idx, rows, Wq, Wk, scale, inv=None):
+        flat = idx.detach().reshape(-1).cpu().long()
+        if flat.numel() != Wq * Wk:
+            raise ValueError("TableBias: the index does not cover [Wq, Wk]")
+        self.rows, self.Wq, self.Wk, self.scale = int(rows), int(Wq), int(Wk), float(scale)
+        self._idx = flat.to(torch.int32)
+        self._inv = inv.detach().cpu().to(torch.int32) if inv is not None else None
+        self._dev = {}
+        self._ld = {}
+
+    def _on(self, device):
+        hit = self._dev.get(device)
+        if hit is None:
+            if self._inv is None:
+                from .local_attention import _inverse_index
+                self._inv = _inverse_index(self._idx.long(), self.rows)
+            hit = (self._idx.to(device), self._inv.contiguous().to(device))
+            self._dev[device] = hit
+        return hit
+
+    def ld(self, B, h, N, d, io, attn_2d, seq_shape, window, ext, chunk=0, L=0, causal=0):
+        key = (B, h, N, d, io, bool(attn_2d), tuple(seq_shape), window, ext, chunk, L, causal)
+        v = self._ld.get(key)
+        if v is None:
+            geom = nv.make_geom(B, h, N, d, io, bool(attn_2d), tuple(seq_shape), window, ext, chunk, L, causal)
+            v = int(nv.query("ea_window_bias_ld", geom))
+            if len(self._ld) < 64:
+                self._ld[key] = v
+        return v
+
+    def dense(self, table, ld):
+        """-> [h, Wq, ld] fp32, already in the kernels' log2 units and padded (marked `_ea_ready`: _bias_padded hands it on)."""
+        idx, _ = self._on(table.device)
+        t32 = _f32c(table)
+        h = t32.shape[1]
+        out = torch.empty((h, self.Wq, ld), dtype=torch.float32, device=table.device)
+        nv.call("ea_table_bias_fwd", h, self.Wq, self.Wk, ld, self.scale * _LOG2E, nv.ptr(t32), nv.ptr(idx), nv.ptr(out), nv.stream())
+        out._ea_ready = True
+        return out
+
+    def grad(self, g):
+        """g [h, Wq, ld] fp32 = d loss / d (natural-unit bias) as the window backward returns it -> d table [rows, h] fp32."""
+        _, inv = self._on(g.device)
+        g = _f32c(g)
+        h, Wq, ld = g.shape
+        out = torch.empty((self.rows, h), dtype=torch.float32, device=g.device)
+        nv.call("ea_table_bias_bwd", self.rows, inv.shape[1], h, Wq, self.Wk, ld, self.scale, nv.ptr(g), nv.ptr(inv), nv.ptr(out),
+                nv.stream())
+        return out
+
+
 def _bias_padded(bias, geom):
     """[h, Wq, Wk] fp32 -> rows padded to the kernel's leading dimension, pre-multiplied by
     log2(e): the kernels evaluate the softmax in the log2 domain (the bias GRADIENT they return is
     with respect to the natural-unit bias)."""
     if bias is None:
         return None
+    if getattr(bias, "_ea_ready", False):       # TableBias.dense(): padded and in log2 units already
+        return bias
     ld = nv.query("ea_window_bias_ld", geom)
     b = bias.float() * _LOG2E
     if b.shape[-1] != ld:
@@ -680,13 +747,17 @@ class EvaModuleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wp, bp, bias, mask_u8, noise, cfg, cdtype, heads, *params):
-        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg
+        attn_2d, seq_shape, window, ext, chunk, L, adaptive_proj = cfg[:7]
+        tb = cfg[7] if len(cfg) > 7 else None         # TableBias: `bias` is then the TABLE [rows, h]
         C = x.shape[-1]
         B = x.shape[0]
         N = x.numel() // (B * C)
         d = C // heads
         x2 = x.reshape(-1, C)
         elem = _ELEM[cdtype]
+        bias_dt_in = None if bias is None else bias.dtype
+        if tb is not None:
+            bias = tb.dense(bias, tb.ld(B, heads, N, d, elem, attn_2d, seq_shape, window, ext, int(chunk), int(L), 0))
         bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
         bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
         want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
@@ -723,7 +794,8 @@ class EvaModuleFn(torch.autograd.Function):
         ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved, ctx.adaptive = icfg, fcfg, len(outs) - 1, adaptive_proj
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
-                    [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], None if bias is None else bias.dtype)
+                    [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], bias_dt_in)
+        ctx.tb = tb
         return y2.view(x.shape)
 
     @staticmethod
@@ -802,6 +874,8 @@ class EvaModuleFn(torch.autograd.Function):
             if "dbias" in res:
                 dbias = res["dbias"][0].view(res["dbias"][1])[..., :bias_cols].contiguous()
         pgrads = [t.to(dt) for t, dt in zip(pgrads, pdtypes)]
+        if dbias is not None and ctx.tb is not None:
+            dbias = ctx.tb.grad(dbias)                 # [h, Wq, ld] -> d table [rows, h], one launch
         if dbias is not None and bias_dt is not None:
             dbias = dbias.to(bias_dt)
         return (dx, dwq, dbq, dwp, dbp, dbias, None, None, None, None, None) + tuple(pgrads)
@@ -1715,19 +1789,27 @@ class LocalCore:
     its one differentiable input is the bias [h, Wq, Wk] (or None)."""
     n_inputs = 1
 
-    def __init__(self, mask_u8, attn_2d, seq_shape, window, ext):
+    def __init__(self, mask_u8, attn_2d, seq_shape, window, ext, tb=None):
         self.mask_u8, self.geo = mask_u8, _geo(attn_2d, seq_shape, window, ext)
         self.bias_cols = 0
+        self.tb = tb                                   # TableBias: the differentiable input is then the TABLE [rows, h]
 
     def fwd(self, qkv5, inputs):
         bias = inputs[0]
+        if self.tb is not None and bias is not None:
+            B, N, _, h, d = qkv5.shape
+            a2, s0, s1, window, ext = self.geo
+            bias = self.tb.dense(bias, self.tb.ld(B, h, N, d, nv.io_dtype(qkv5), bool(a2), (s0, s1) if a2 else (s0,), window, ext))
         self.bias_cols = 0 if bias is None else bias.shape[-1]
         out, lse, bias_p = local_fwd_impl(qkv5, bias, self.mask_u8, self.geo)
         return out, (lse, bias_p)
 
     def bwd(self, dout, qkv5, out, saved):
         dqkv5, dbias = local_bwd_impl(dout, None, qkv5, _opt(saved[1]), self.mask_u8, out, saved[0], self.geo, self.bias_cols)
-        return dqkv5, (_opt(dbias),)
+        dbias = _opt(dbias)
+        if self.tb is not None and dbias is not None:
+            dbias = self.tb.grad(dbias)
+        return dqkv5, (dbias,)
 
 
 class PerformerCore:

@@ -80,6 +80,14 @@ class T5RelativePositionBias(nn.Module):
             vals = self._bucket_onehot(i, j, device) @ self.relative_attention_bias.weight.float()
         return vals.view(i, j, -1).permute(2, 0, 1) * self.scale
 
+    def table_spec(self, i, j):
+        """_ops.TableBias of the [i, j] bias: bias[h, i, j] = scale * weight[bucket(i, j), h] (one launch each way, round 6)."""
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        key = (i, j, "spec")
+        if key not in cache:
+            cache[key] = _ops.TableBias(self.bucket_table(i, j, torch.device("cpu")), self.num_buckets, i, j, self.scale)
+        return cache[key]
+
     def forward(self, x):
         i, j = x.shape[-2:]
         return self.dense(i, j, x.device).unsqueeze(0).unsqueeze(2)
@@ -171,12 +179,20 @@ class EVA(LocalAttention):
             cdt = torch.get_autocast_dtype("cuda")
             if ok_geo and _ops.eva_module_fn_supported(x, self.qkv, self.proj, cdt, self.adaptive_proj, L0, d):
                 Wq_, Wk_ = (w * w, (w + 2 * e) ** 2) if self.attn_2d else (w, w + 2 * e)
-                bias = self.rel_pos_bias.dense(Wq_, Wk_, x.device) if self.use_t5_rpe else self._table_bias()
+                tb = None
+                if self.use_t5_rpe and _ops.USE_TABLE_BIAS:
+                    bias, tb = self.rel_pos_bias.relative_attention_bias.weight, self.rel_pos_bias.table_spec(Wq_, Wk_)
+                elif self.use_t5_rpe:
+                    bias = self.rel_pos_bias.dense(Wq_, Wk_, x.device)
+                else:
+                    bias, tb = self._table_spec()
+                    if tb is None:
+                        bias = self._table_bias()
                 noise = None
                 if self.training:
                     noise = torch.randn_like(torch.empty(B, h, L0, d, device=x.device, dtype=torch.float32))
                 mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
-                cfg = (self.attn_2d, tuple(seq_shape), w, e, r0, L0, self.adaptive_proj)
+                cfg = (self.attn_2d, tuple(seq_shape), w, e, r0, L0, self.adaptive_proj) + ((tb,) if tb is not None else ())
                 y = _ops.EvaModuleFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, bias, mask, noise,
                                            cfg, cdt, h, *self._mu_params())
                 y = self.proj_drop(y)

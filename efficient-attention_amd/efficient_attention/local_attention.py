@@ -99,6 +99,19 @@ class LocalAttention(MultiheadAttention):
         return _TableGather.apply(tab, idx.reshape(-1), self._rpe_inv).reshape(
             idx.shape[0], idx.shape[1], -1).permute(2, 0, 1)
 
+    def _table_spec(self):
+        """(table parameter, _ops.TableBias) for the single-node module paths, which build the dense bias from the table in one
+        launch each way (round 6), or (None, None): no 2-D table, EA_TABLE_BIAS=0."""
+        if not (self.use_rpe and self.attn_2d and _ops.USE_TABLE_BIAS):
+            return None, None
+        tb = self.__dict__.get("_tb")
+        if tb is None:
+            idx = self.relative_position_index
+            tb = _ops.TableBias(idx, self.local_relative_position_bias_table.shape[0], idx.shape[0], idx.shape[1], 1.0,
+                                inv=self._rpe_inv)
+            self.__dict__["_tb"] = tb
+        return self.local_relative_position_bias_table, tb
+
     def add_rel_pos_bias(self, local_dots):
         """Reference-compatible helper (:70-79): local_dots [b,h,w,i,j] + bias."""
         return local_dots + self._table_bias().unsqueeze(0).unsqueeze(2)
@@ -137,6 +150,9 @@ class LocalAttention(MultiheadAttention):
             assert H % self.window_size == 0
             shape = (H, W)
         mask = _ops._mask_u8(key_padding_mask, B, N, device)
+        table, tb = self._table_spec()
+        if tb is not None and device.type == "cuda":
+            return _ops.LocalCore(mask, attn_2d, shape, self.window_size, self.ext_size, tb=tb), (table,)
         return _ops.LocalCore(mask, attn_2d, shape, self.window_size, self.ext_size), (self._table_bias(),)
 
     @staticmethod

@@ -447,6 +447,17 @@ int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, in
  * local_attention.py:70-79): out[row][c] = sum_k g[inv[row][k]][c], inv [rows, K] int32 = the gather positions that read
  * table row `row` (-1 = unused slot), g [n, cols] fp32.  Fixed order (deterministic). */
 int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream);
+/* Round 6: the dense per-head bias of the window kernels straight out of its table, in ONE launch each way (replaces the
+ * index_select / permute / multiply / pad / copy chain around `relative_position_bias_table[relative_position_index]`,
+ * local_attention.py:70-79, and around T5RelativePositionBias.forward, eva.py:53-65):
+ *   fwd: out[hd][i][j] = scale * table[idx[i*Wk + j]][hd] for j < Wk, 0 for Wk <= j < ld      (table [rows, h] fp32, idx int32
+ *        [Wq*Wk], out [h, Wq, ld] fp32 -- ld = ea_window_bias_ld(geom); `scale` carries log2(e), the kernels' logit unit)
+ *   bwd: dtable[row][hd] = scale * sum_k g[hd][p / Wk][p % Wk], p = inv[row][k] >= 0           (g [h, Wq, ld] fp32 = the bias
+ *        gradient the window backward returns; inv [rows, K] int32 as for ea_gather_sum).  Fixed order (deterministic). */
+int ea_table_bias_fwd(int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx, float* out,
+                      void* stream);
+int ea_table_bias_bwd(int32_t rows, int32_t K, int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* g,
+                      const int32_t* inv, float* dtable, void* stream);
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream);
 /* Measurement aid, not on the path: dst[0 .. bytes) = src[0 .. bytes) by a plain 16-byte-per-lane device copy kernel

@@ -236,7 +236,10 @@ def test_linear_dgrad_matches_fp64(rows, w_f32, dx_f32, wide, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,H,W,r,C,has_t,dx_f32,w_f32", [(8, 28, 28, 4, 49, 1, 1, 0), (128, 14, 14, 2, 49, 1, 1, 1), (3, 28, 28, 4, 49, 0, 0, 0),
-                                                          (5, 16, 16, 4, 16, 1, 0, 1), (300, 8, 8, 2, 16, 0, 1, 0)])
+                                                          (5, 16, 16, 4, 16, 1, 0, 1), (300, 8, 8, 2, 16, 0, 1, 0),
+                                                          # units that end in a half-filled tile (49 cells of two-cell tiles, 49
+                                                          # cells of eight-cell tiles): the duplicate slots of round 6
+                                                          (7, 28, 28, 4, 49, 0, 1, 1), (6, 14, 14, 2, 49, 1, 0, 0), (9, 14, 14, 2, 49, 0, 0, 1)])
 def test_linear_dgrad_finish_equals_finish_then_dgrad(B, H, W, r, C, has_t, dx_f32, w_f32, dtype):
     """ea_linear_dgrad_finish (round 5: the last corrections of dq / dk -- lara.py:223 and the pooling backward of lara.py:43,48,
     145-151 / eva.py:178-181 -- fused into the input-gradient pass) against the two launches it replaces, ea_lara_bwd_finish
@@ -1289,3 +1292,75 @@ def test_core_module_single_node_equals_three_nodes(attn, monkeypatch):
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, n
         else:
             assert torch.equal(a, b), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rpe_2d_w7", "rpe_2d_w7_e3", "t5_16x32", "t5_128x256"])
+def test_table_bias_matches_the_framework_chain(case):
+    """_ops.TableBias (ea_table_bias_fwd / _bwd, round 6): the dense window bias out of its table in one launch each way, against
+    the framework chain it replaces -- table[index] -> permute -> * log2(e) -> pad -- and that chain's autograd gradient."""
+    import math
+    import torch
+    from efficient_attention import _ops
+    from efficient_attention.local_attention import relative_position_index_2d
+    from efficient_attention.eva import T5RelativePositionBias
+    g = torch.Generator(device="cuda").manual_seed(len(case))
+    if case.startswith("rpe"):
+        w, e = (7, 0) if case == "rpe_2d_w7" else (7, 3)
+        idx = relative_position_index_2d(w, e)
+        rows, h, scale = int(idx.max()) + 3, 3, 1.0    # a few table rows nobody reads: their gradient is zero
+    else:
+        i, j = (16, 32) if case == "t5_16x32" else (128, 256)
+        t5 = T5RelativePositionBias(0.125, num_heads=8, causal=False, num_buckets=16 if i == 16 else 64, max_distance=j)
+        idx = t5.bucket_table(i, j, torch.device("cpu"))
+        rows, h, scale = t5.num_buckets, 8, 0.125
+    Wq, Wk = idx.shape
+    ld = (Wk + 15) // 16 * 16 + 16
+    table = torch.randn(rows, h, device="cuda", generator=g, requires_grad=True)
+    tb = _ops.TableBias(idx, rows, Wq, Wk, scale)
+    got = tb.dense(table.detach(), ld)
+    ref = (table[idx.to("cuda").reshape(-1)].view(Wq, Wk, h).permute(2, 0, 1) * scale) * math.log2(math.e)
+    assert got.shape == (h, Wq, ld) and bool((got[..., Wk:] == 0).all())
+    assert torch.allclose(got[..., :Wk], ref, rtol=1e-6, atol=1e-7)
+    gb = torch.randn(h, Wq, ld, device="cuda", generator=g)
+    dt = tb.grad(gb)
+    # the kernels' bias gradient is with respect to the natural-unit bias: scale * table[index]
+    (ref / math.log2(math.e) * gb[..., :Wk]).sum().backward()
+    assert torch.allclose(dt, table.grad, rtol=1e-5, atol=1e-5 * float(table.grad.abs().max()))
+    assert torch.equal(dt, tb.grad(gb))                # fixed order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["eva_rpe", "eva_t5", "local_rpe"])
+def test_table_bias_module_path_equals_dense_bias_path(attn, monkeypatch):
+    """The single-node module paths with the table handed over (TableBias) against the same modules on the dense-bias chain
+    (EA_TABLE_BIAS=0): same kernels downstream, so y and every gradient agree to fp32 rounding of the bias values."""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    kw = dict(dim=192, num_heads=3, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, window_size=7, attn_2d=True,
+              overlap_window=False, fp32=False)
+    if attn == "eva_rpe":
+        kw.update(use_rpe=True, adaptive_proj="default", num_landmarks=49, use_t5_rpe=False)
+    elif attn == "eva_t5":
+        kw.update(use_rpe=False, adaptive_proj="default", num_landmarks=49, use_t5_rpe=True)
+    else:
+        kw.update(use_rpe=True)
+    torch.manual_seed(3)
+    m = ea.AttentionFactory.build_attention("local" if attn == "local_rpe" else "eva", kw).cuda().train()
+    x = torch.randn(64, 28, 28, 192, device="cuda")
+    gy = torch.randn(64, 28, 28, 192, device="cuda")
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_TABLE_BIAS", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [p.grad.clone() for p in m.parameters()])
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, *res):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), n
