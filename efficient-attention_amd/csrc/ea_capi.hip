@@ -221,17 +221,25 @@ int ea_eva_beta_fwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint
   return landmark_dispatch(2, p, g->dtype, g->D, (hipStream_t)stream);
 }
 
-int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
-                    const float* omega, const float* beta, const float* dbeta,
-                    const ea_t4* dk, const ea_t4* dv, float* domega, void* stream) {
+// dbeta_S > 1 (composite EVA backward, round 6): dbeta = slice 0 of dbeta_S <= 4 slice partials `dbeta_stride` floats apart
+static int eva_beta_bwd_parts(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                              const float* omega, const float* beta, const float* dbeta, int dbeta_S, long dbeta_stride,
+                              const ea_t4* dk, const ea_t4* dv, float* domega, void* stream) {
   LmP p = {};
   int rc = fill_lm(g, p);
   if (rc != EA_OK) return rc;
   if (!t4_ok(k, g->D) || !t4_ok(v, g->D) || !t4_ok(dk, g->D) || !t4_ok(dv, g->D) || !omega ||
-      !beta || !dbeta || !domega) return EA_E_BADARG;
+      !beta || !dbeta || !domega || dbeta_S < 1 || dbeta_S > 4) return EA_E_BADARG;
   SET3(k, k); SET3(v, v); SET3(dk, dk); SET3(dv, dv);
   p.mask = mask; p.omega = omega; p.beta = beta; p.dbeta = dbeta; p.domega = domega;
+  p.dbeta_S = dbeta_S; p.dbeta_stride = dbeta_stride;
   return landmark_dispatch(3, p, g->dtype, g->D, (hipStream_t)stream);
+}
+
+int ea_eva_beta_bwd(const ea_geom* g, const ea_t4* k, const ea_t4* v, const uint8_t* mask,
+                    const float* omega, const float* beta, const float* dbeta,
+                    const ea_t4* dk, const ea_t4* dv, float* domega, void* stream) {
+  return eva_beta_bwd_parts(g, k, v, mask, omega, beta, dbeta, 1, 0, dk, dv, domega, stream);
 }
 
 }  // extern "C"
@@ -709,25 +717,38 @@ int64_t ea_lara_landmarks_saved_floats(const ea_lmk_geom* g) {
   return (int64_t)g->BH * (int64_t)lara_lmk_saved_per_bh(g->L, g->D);
 }
 
+// dqr_S > 1 (composite EVA backward, round 6): d_qbar_rows = slice 0 of dqr_S <= 4 slice partials `dqr_stride` floats apart
+static int lara_landmarks_bwd_qparts(const ea_lmk_geom* g, const float* pq, const float* pk,
+                                     const float* Wq, const float* bq, const float* gq, const float* cq,
+                                     const float* Wk, const float* bk, const float* gk, const float* ck,
+                                     const float* noise, const float* d_omega, const float* d_qbar_rows, int dqr_S, long dqr_stride,
+                                     const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
+                                     float* dW_part, float* dvec_part, const float* saved, void* stream) {
+  LmkP p = {};
+  int rc = fill_lmk(g, p);
+  if (rc != EA_OK) return rc;
+  if (!pq || !pk || !d_omega || (!d_lp && !g->eva) || !dpq || !dpk) return EA_E_BADARG;
+  if (g->eva && !d_qbar_rows) return EA_E_BADARG;
+  if (dqr_S < 1 || dqr_S > 4 || (dqr_S > 1 && !g->eva)) return EA_E_BADARG;
+  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
+    return EA_E_BADARG;
+  if (g->dup != 0 && !noise) return EA_E_BADARG;
+  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
+  p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
+  p.dqr_S = dqr_S; p.dqr_stride = dqr_stride;
+  p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
+  p.saved = const_cast<float*>(saved);
+  return lara_lmk_dispatch(true, p, (hipStream_t)stream);
+}
+
 int ea_lara_landmarks_bwd(const ea_lmk_geom* g, const float* pq, const float* pk,
                           const float* Wq, const float* bq, const float* gq, const float* cq,
                           const float* Wk, const float* bk, const float* gk, const float* ck,
                           const float* noise, const float* d_omega, const float* d_qbar_rows,
                           const float* d_bhv, const float* d_lp, float* dpq, float* dpk,
                           float* dW_part, float* dvec_part, const float* saved, void* stream) {
-  LmkP p = {};
-  int rc = fill_lmk(g, p);
-  if (rc != EA_OK) return rc;
-  if (!pq || !pk || !d_omega || (!d_lp && !g->eva) || !dpq || !dpk) return EA_E_BADARG;
-  if (g->eva && !d_qbar_rows) return EA_E_BADARG;
-  if (g->has_mlp && (!Wq || !bq || !gq || !cq || !Wk || !bk || !gk || !ck || !dW_part || !dvec_part))
-    return EA_E_BADARG;
-  if (g->dup != 0 && !noise) return EA_E_BADARG;
-  p.pq = pq; p.pk = pk; LMK_PARAMS(p)
-  p.noise = noise; p.d_omega = d_omega; p.d_qbar_rows = d_qbar_rows; p.d_bhv = d_bhv; p.d_lp = d_lp;
-  p.dpq = dpq; p.dpk = dpk; p.dW_part = dW_part; p.dvec_part = dvec_part;
-  p.saved = const_cast<float*>(saved);
-  return lara_lmk_dispatch(true, p, (hipStream_t)stream);
+  return lara_landmarks_bwd_qparts(g, pq, pk, Wq, bq, gq, cq, Wk, bk, gk, ck, noise, d_omega, d_qbar_rows, 1, 0, d_bhv, d_lp, dpq,
+                                   dpk, dW_part, dvec_part, saved, stream);
 }
 
 int ea_lara_landmarks_bwd_parts(const ea_lmk_geom* g, const float* pq, const float* pk,
@@ -1799,18 +1820,26 @@ int ea_eva_layer_bwd2(const ea_eva_layer* c, const ea_t4* q, const ea_t4* k, con
   rc = ea_window_attn_bwd(&P.g, q, k, v, rfk, beta, bias, nullptr, out, dout, saved + P.o_lse, dq, dk, dv, dl_p,
                           dl_p + (size_t)P.parts * LD, dbp, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, stream);
   if (rc != EA_OK) return rc;
-  rc = ea_slice_sum(2, P.parts, (int32_t)LD, 1.f, nullptr, dl_p, dl, stream);
-  if (rc != EA_OK) return rc;
+  // round 6: up to four slice partials are added up by their two consumers while they load them (ea_slice_sum's order of
+  // additions: bit-identical) -- one launch less; more slices keep the reduction launch (EA_EVA_FOLD_SLICES=0: always)
+  static const bool fold_on = !(getenv("EA_EVA_FOLD_SLICES") && getenv("EA_EVA_FOLD_SLICES")[0] == '0');
+  const bool fold = fold_on && P.parts <= 4;
+  if (!fold) {
+    rc = ea_slice_sum(2, P.parts, (int32_t)LD, 1.f, nullptr, dl_p, dl, stream);
+    if (rc != EA_OK) return rc;
+  }
   if (c->has_bias && dbias) {        // dbias == NULL: the partials stay in tmp for the caller's reduction (selectors 9 / 10)
     rc = ea_colsum_f32(P.bparts * c->B, c->H * P.Wq * P.ld, dbp, dbias, stream);
     if (rc != EA_OK) return rc;
   }
   float* d_omega = tmp + P.b_dom;
-  rc = ea_eva_beta_bwd(&P.g, k, v, nullptr, omega, beta, dl + LD, dk, dv, d_omega, stream);
+  rc = fold ? eva_beta_bwd_parts(&P.g, k, v, nullptr, omega, beta, dl_p + (size_t)P.parts * LD, P.parts, (long)LD, dk, dv, d_omega, stream)
+            : ea_eva_beta_bwd(&P.g, k, v, nullptr, omega, beta, dl + LD, dk, dv, d_omega, stream);
   if (rc != EA_OK) return rc;
   float *dqm = tmp + P.b_dqm, *dkm = tmp + P.b_dkm, *dW = tmp + P.b_dW, *dvec = tmp + P.b_dvec;
-  rc = ea_lara_landmarks_bwd(&P.lg, qm, km, params[0], params[1], params[2], params[3], params[4], params[5], params[6],
-                             params[7], noise, d_omega, dl, nullptr, nullptr, dqm, dkm, dW, dvec, saved + P.o_lmk, stream);
+  rc = lara_landmarks_bwd_qparts(&P.lg, qm, km, params[0], params[1], params[2], params[3], params[4], params[5], params[6],
+                                 params[7], noise, d_omega, fold ? dl_p : dl, fold ? P.parts : 1, fold ? (long)LD : 0, nullptr,
+                                 nullptr, dqm, dkm, dW, dvec, saved + P.o_lmk, stream);
   if (rc != EA_OK) return rc;
   if (!(flags & EA_EVA_DEFER_CHUNK_MEAN)) {
     rc = ea_eva_chunk_mean_bwd(&P.g, dqm, dkm, nullptr, dq, dk, stream);

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
     const size_t off = (size_t)chunk_id * D + c * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { om[i] = p.omega[off + i]; db[i] = p.dbeta[off + i]; bt[i] = p.beta[off + i]; }
+    for (int s_ = 1; s_ < p.dbeta_S; ++s_)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) db[i] += p.dbeta[(size_t)s_ * p.dbeta_stride + off + i];
   }
   float bd = 0.f;
 #pragma unroll
@@ -625,6 +628,12 @@ __global__ __launch_bounds__(256) void beta_bwd_r_kernel(const LmP p, int colour
   {
     const size_t off = (size_t)chunk_id * D + c * 8;
     ld8(p.omega + off, om); ld8(p.dbeta + off, db); ld8(p.beta + off, bt);
+    for (int s_ = 1; s_ < p.dbeta_S; ++s_) {               // (uniform) slice partials of the window backward, added in slice order
+      float ps[8];
+      ld8(p.dbeta + (size_t)s_ * p.dbeta_stride + off, ps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) db[i] += ps[i];
+    }
   }
   pin_regs(kr); pin_regs(vr); pin_regs(dkr); pin_regs(dvr); R.pin();
   float bd = 0.f;

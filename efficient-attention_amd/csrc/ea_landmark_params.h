@@ -15,6 +15,10 @@ struct LmP {
   Geo G;
   int B, H, L, r, e, J;     // J = slots per chunk (r+2e)^dims
   float scale;
+  // round 6: d beta = sum_s dbeta[s * dbeta_stride + ...], s < dbeta_S, formed while it is loaded (the window backward's slice
+  // partials, ea_slice_sum's order of additions: that launch folded in); dbeta_S <= 1: dbeta is final
+  int dbeta_S;
+  long dbeta_stride;
 };
 
 int landmark_dispatch(int which, const LmP& p, int dtype, int D, hipStream_t st);

@@ -15,6 +15,10 @@ struct LmkP {
   const float* dom_parts;
   int dom_S;
   float dom_scale;
+  // round 6 (EVA): d rf_k_bar = sum_s d_qbar_rows[s * dqr_stride + ...], s < dqr_S <= 4 (the window backward's slice partials,
+  // ea_slice_sum's order); dqr_S <= 1: d_qbar_rows is final
+  int dqr_S;
+  long dqr_stride;
   float *dpq, *dpk, *dW_part, *dvec_part;                 // backward outputs
   int BH, L, C, D;
   int has_mlp, mixed, mis, dup;

@@ -352,6 +352,15 @@ __global__ __launch_bounds__(256, 2) void lmk2_kernel(const LmkP p) {
   if (p.eva) {
     // d rf_q_bar = d omega / 2, d rf_k_bar = d omega / 2 + d (rf_k_bar output)
     load_strip<NT>(gqr, p.d_qbar_rows ? p.d_qbar_rows + oC : nullptr, D, L, D, l);
+    if (p.dqr_S > 1) {                                 // (uniform) slice partials of the window backward, added in slice order
+#pragma unroll
+      for (int s_ = 1; s_ < 4; ++s_) {
+        f32x4 part[NT];
+        load_strip<NT>(part, s_ < p.dqr_S ? p.d_qbar_rows + (size_t)s_ * p.dqr_stride + oC : nullptr, D, L, D, l);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) gqr[ct] = gqr[ct] + part[ct];
+      }
+    }
     if (p.has_mlp) {
       commit_rows<D>(WQt, sb0, D, tid); commit_rows<D>(WKt, sb1, D, tid);
       commit_rows<D>(PQt, sb2, L, tid); commit_rows<D>(PKt, sb3, L, tid);

@@ -239,6 +239,53 @@ int table_bias_bwd_dispatch(const float* g, const int* inv, float* dtable, int r
   return (int)hipGetLastError();
 }
 
+// The autocast casts of a layer's parameters in ONE launch (round 6): dst_k[i] = (16-bit) src_k[i], up to eight fp32 tensors
+// (both projections' weights and biases of a 320 / 512 / 1024-wide layer, whose projections are library GEMMs on 16-bit
+// operands: four `bfloat16_copy` launches of ~4-10 us each per step until now).  Round to nearest even, exactly `.to(dtype)`.
+struct MultiCastP {
+  const float* src[8];
+  uint16_t* dst[8];
+  long n[8];
+  int blk0[9];
+  int nseg;
+};
+template <typename E>
+__global__ __launch_bounds__(256) void multi_cast_kernel(const MultiCastP p) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) k += (i < p.nseg && (int)blockIdx.x >= p.blk0[i]) ? 1 : 0;
+  const long n = p.n[k];
+  const long i0 = ((long)((int)blockIdx.x - p.blk0[k]) * 256 + threadIdx.x) * 8;
+  if (i0 >= n) return;
+  const float* s = p.src[k] + i0;
+  uint16_t* d = p.dst[k] + i0;
+  if (i0 + 8 <= n && (((uintptr_t)s & 15) == 0) && (((uintptr_t)d & 15) == 0)) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *reinterpret_cast<u32x4*>(d) = pack8<E>(f);
+  } else {
+    for (int e = 0; e < 8 && i0 + e < n; ++e) d[e] = (uint16_t)(pack2<E>(s[e], 0.f) & 0xffffu);
+  }
+}
+
+int multi_cast_dispatch(int dtype, int K, const float* const* src, const long long* n, void* const* dst, hipStream_t st) {
+  if (K <= 0 || K > 8) return EA_E_BADARG;
+  MultiCastP p = {};
+  int blk = 0;
+  for (int k = 0; k < K; ++k) {
+    if (!src[k] || !dst[k] || n[k] <= 0) return EA_E_BADARG;
+    p.src[k] = src[k]; p.dst[k] = (uint16_t*)dst[k]; p.n[k] = (long)n[k];
+    p.blk0[k] = blk;
+    blk += (int)((n[k] + 2047) / 2048);
+  }
+  p.blk0[K] = blk;
+  p.nseg = K;
+  if (dtype == EA_BF16) hipLaunchKernelGGL(multi_cast_kernel<BF16>, dim3((unsigned)blk), dim3(256), 0, st, p);
+  else if (dtype == EA_F16) hipLaunchKernelGGL(multi_cast_kernel<F16>, dim3((unsigned)blk), dim3(256), 0, st, p);
+  else return EA_E_BADARG;
+  return (int)hipGetLastError();
+}
+
 // Bandwidth yardstick (bench.py `hbm_measured_copy_gbs`, SURVEY 8d "babel-stream-style copy kernel on the same GPU"):
 // dst[i] = src[i] in 16-byte pieces.  Measured on MI355X over 512 MB (tools/probe/copy_probe.hip): a workgroup walking
 // CONTIGUOUS 16 KB pieces (four 4 KB rows of its 256 lanes in flight) with non-temporal loads / stores reaches 6.25 TB/s
