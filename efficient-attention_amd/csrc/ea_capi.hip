@@ -76,7 +76,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 11; }
+int32_t ea_abi_version(void) { return 12; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -834,6 +834,7 @@ int colsum_dispatch(int dtype, const void* x, float* part, float* out, int rows,
 int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, const float* x2, float* out2, int cols2, hipStream_t st);
 int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st);
 int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
+int multi_cast_dispatch(int dtype, int K, const float* const* src, const long long* n, void* const* dst, hipStream_t st);
 int table_bias_fwd_dispatch(const float* table, const int* idx, float* out, int h, int Wq, int Wk, int ld, float scale, hipStream_t st);
 int table_bias_bwd_dispatch(const float* g, const int* inv, float* dtable, int rows, int K, int h, int Wq, int Wk, int ld, float scale,
                             hipStream_t st);
@@ -863,6 +864,11 @@ int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, in
 int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream) {
   if (!g || !inv || !out) return EA_E_BADARG;
   return ea::gather_sum_dispatch(g, inv, out, rows, K, cols, (hipStream_t)stream);
+}
+
+int ea_multi_cast(int32_t dtype, int32_t K, const float* const* src, const int64_t* n, void* const* dst, void* stream) {
+  if (!src || !n || !dst) return EA_E_BADARG;
+  return ea::multi_cast_dispatch(dtype, K, src, (const long long*)n, dst, (hipStream_t)stream);
 }
 
 int ea_table_bias_fwd(int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx, float* out,

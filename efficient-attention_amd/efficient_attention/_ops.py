@@ -733,7 +733,7 @@ def eva_module_fn_supported(x, qkv, proj, cdtype, adaptive_proj, L, d):
     """The single-node path of EVA (EvaModuleFn): what LaraModuleFn needs of the projections, plus the fused landmark
     kernel for the mu networks (adaptive_proj 'default', L <= 64, d in {32, 64})."""
     return (USE_EVA_MODULE_FN and adaptive_proj == "default" and L <= 64 and d in (32, 64)
-            and lara_module_fn_supported(x, qkv, proj, cdtype)
+            and lara_module_fn_supported(x, qkv, proj, cdtype, allow_lib=True)
             and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0 and _DIRECT)
 
 
@@ -767,7 +767,15 @@ class EvaModuleFn(torch.autograd.Function):
         comp = _eva_use_composite()
         lcfg, sizes = (_eva_layer_cfg_dims(B, heads, d, elem, icfg, fcfg, adaptive_proj, bias is not None, mask_u8 is not None)
                        if comp else (None, None))
-        if (attn_2d and ext == 0 and mask_u8 is None
+        lib = module_proj_lib(C)
+        w16p = b16p = None
+        if lib:
+            # 320 / 512 / 1024-wide layers (round 6): library GEMMs on 16-bit operands inside the node -- the four parameter
+            # casts in one launch, the rounded weights kept for the backward's two input-gradient GEMMs
+            w16, b16q, w16p, b16p = lib_casts(wq, bq, wp, bp, cdtype)
+            y, xc = lib_project(x2, wq, bq32, w16, b16q, cdtype)
+            want = True
+        elif (attn_2d and ext == 0 and mask_u8 is None
                 and proj_pool_supported(x2, wq, cdtype, B, seq_shape[0], seq_shape[1], chunk, heads)):
             if lcfg is not None:
                 # the projection kernel writes the chunk means straight into the composite entry's workspace
@@ -790,8 +798,12 @@ class EvaModuleFn(torch.autograd.Function):
         outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, None, icfg, fcfg, adaptive_proj, list(params), pooled=pooled,
                             composite=lcfg is not None)
         o2 = outs[0].reshape(-1, C)
-        y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *outs[1:], *params)
+        if lib:
+            with torch.autocast(device_type="cuda", enabled=False):
+                y2 = F.linear(o2, w16p, b16p)
+        else:
+            y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved, ctx.adaptive = icfg, fcfg, len(outs) - 1, adaptive_proj
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], bias_dt_in)
@@ -800,7 +812,7 @@ class EvaModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *rest = ctx.saved_tensors
+        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads, bias_cols, bias_dt = ctx.meta
         C = xshape[-1]
@@ -810,12 +822,17 @@ class EvaModuleFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, C)
         if dy2.dtype != cdtype:
             dy2 = dy2.to(cdtype)
-        d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
+        if w16p is not None:                          # library flavour (module_proj_lib): d out = dy W_proj on the rounded weight
+            dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            d_o2 = dy2 @ w16p
+        else:
+            d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
         defer = USE_MULTI_SUM
         pend = []
         dwp = dbp = dwq = dbq = dx = None
         need_bp = bpd is not None and need[4]
-        pair = bool(defer and need[3] and need[1] and wgrad_pair_usable(dy2, o2, qkv5.view(-1, 3 * C), xl))
+        pair = bool(defer and need[3] and need[1] and xl is not None
+                    and wgrad_pair_usable(qkv5.view(-1, 3 * C), xl, dy2, o2))
         if need[3] and not pair:
             r_ = wgrad(dy2, o2, need_bp, defer=defer)
             if defer:
@@ -1846,13 +1863,25 @@ class CoreModuleFn(torch.autograd.Function):
         bq32 = None if bq is None else (bq if bq.dtype == torch.float32 else bq.float())
         bp32 = None if bp is None else (bp if bp.dtype == torch.float32 else bp.float())
         want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
-        y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
+        lib = module_proj_lib(C)
+        w16q = w16p = b16p = None
+        if lib:
+            # 320 / 512 / 1024-wide layers (round 6): library GEMMs on 16-bit operands inside the node (see EvaModuleFn)
+            w16q, b16q, w16p, b16p = lib_casts(wq, bq, wp, bp, cdtype)
+            y, xc = lib_project(x2, wq, bq32, w16q, b16q, cdtype)
+            want = True
+        else:
+            y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
         xl = x2 if x2.dtype == cdtype else (xc if want else None)
         qkv5 = y.view(B, N, 3, heads, d)
         out, saved = core.fwd(qkv5, inputs)
         o2 = out.reshape(-1, C)
-        y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, o2, wq, wp, *saved)
+        if lib:
+            with torch.autocast(device_type="cuda", enabled=False):
+                y2 = F.linear(o2, w16p, b16p)
+        else:
+            y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
+        ctx.save_for_backward(xl, qkv5, o2, wq, wp, w16q, w16p, *saved)
         ctx.core = core
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     heads, [None if t is None else t.dtype for t in inputs])
@@ -1860,7 +1889,7 @@ class CoreModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, o2, wq, wp, *saved = ctx.saved_tensors
+        xl, qkv5, o2, wq, wp, w16q, w16p, *saved = ctx.saved_tensors
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, heads, in_dtypes = ctx.meta
         C = xshape[-1]
         d = C // heads
@@ -1869,7 +1898,11 @@ class CoreModuleFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, C)
         if dy2.dtype != cdtype:
             dy2 = dy2.to(cdtype)
-        d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
+        if w16p is not None:
+            dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            d_o2 = dy2 @ w16p
+        else:
+            d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
         B, N = qkv5.shape[:2]
         dqkv5, extra = ctx.core.bwd(d_o2.view(B, N, heads, d), qkv5, o2.view(B, N, heads, d), saved)
         dqkv2 = dqkv5.view(-1, 3 * C)
@@ -1899,7 +1932,7 @@ class CoreModuleFn(torch.autograd.Function):
             elif need_bq:
                 dbq = bias_grad(dqkv2).to(bqd)
         if need[0]:
-            dx = qkv_dgrad(dqkv2, wq, None, xdtype).view(xshape)
+            dx = qkv_dgrad(dqkv2, wq, w16q, xdtype).view(xshape)
         if pend:
             sums = multi_sum([t for _, t, _ in pend])
             for (what, _, meta), o in zip(pend, sums):
@@ -1912,16 +1945,60 @@ class CoreModuleFn(torch.autograd.Function):
         return (dx, dwq, dbq, dwp, dbp, None, None, None) + egrads
 
 
+USE_WIDE_MODULE_FN = os.environ.get("EA_WIDE_MODULE_FN", "1") == "1"
+
+
+def multi_cast(ts, dtype):
+    """fp32 tensors -> their `dtype` copies in ONE launch (ea_multi_cast; round 6): the autocast casts of a wide layer's two
+    weights and two biases, four `.to(dtype)` launches until now."""
+    ts = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in ts]
+    outs = [torch.empty(t.shape, dtype=dtype, device=t.device) for t in ts]
+    K = len(ts)
+    src = (ctypes.c_void_p * K)(*[t.data_ptr() for t in ts])
+    dst = (ctypes.c_void_p * K)(*[o.data_ptr() for o in outs])
+    n = (ctypes.c_int64 * K)(*[t.numel() for t in ts])
+    nv.call("ea_multi_cast", _ELEM[dtype], K, src, n, dst, nv.stream())
+    return outs
+
+
+def module_proj_lib(C):
+    """The single-node module paths run their two projections on this library's streaming kernels where those exist (64 ..
+    256 input channels) and, round 6, as library GEMMs on 16-bit operands elsewhere (320 / 512 / 1024-wide layers): True = the
+    library-GEMM flavour."""
+    return not (_lin_geometry(C, 3 * C) and _lin_geometry(C, C))
+
+
+def lib_project(x2, w32, b32, w16, b16, cdtype):
+    """(y = x2 @ w^T + b in cdtype by the library GEMM, the 16-bit x it ran on)."""
+    xl = x2 if x2.dtype == cdtype else x2.to(cdtype)        # the one activation-sized cast of the layer
+    with torch.autocast(device_type="cuda", enabled=False):
+        y = F.linear(xl, w16, b16)
+    return y, xl
+
+
+def lib_casts(wq, bq, wp, bp, cdtype):
+    """16-bit copies of (qkv weight, qkv bias | None, proj weight, proj bias | None), one launch."""
+    src = [t for t in (wq, bq, wp, bp) if t is not None]
+    if all(t.dtype == torch.float32 for t in src):
+        cs = multi_cast(src, cdtype)
+    else:
+        cs = [t if t.dtype == cdtype else t.to(cdtype) for t in src]
+    it = iter(cs)
+    return tuple(None if t is None else next(it) for t in (wq, bq, wp, bp))
+
+
 def core_module_fn_supported(x, qkv, proj, cdtype):
     """The single-node path of the softmax / local-window baselines (CoreModuleFn): what LaraModuleFn asks of the projections,
     direct calls only."""
     return (USE_CORE_MODULE_FN and _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
-            and lara_module_fn_supported(x, qkv, proj, cdtype))
+            and lara_module_fn_supported(x, qkv, proj, cdtype, allow_lib=True))
 
 
-def lara_module_fn_supported(x, qkv, proj, cdtype):
+def lara_module_fn_supported(x, qkv, proj, cdtype, allow_lib=False):
     """The single-node path of LinearRA (LaraModuleFn): 16-bit autocast dtype, fp32 master weights both projection kernels
-    cover (forward of both layers, the output projection's transposed input gradient), the one-pass weight gradient."""
+    cover (forward of both layers, the output projection's transposed input gradient), the one-pass weight gradient.
+    allow_lib (EvaModuleFn, CoreModuleFn; round 6): widths outside the streaming kernels' 64 .. 256 channels qualify too --
+    their projections run as library GEMMs inside the node (module_proj_lib)."""
     if not (USE_LARA_MODULE_FN and x.is_cuda and cdtype in _ELEM and x.dtype in (torch.float32, cdtype)):
         return False
     C = x.shape[-1]
@@ -1930,8 +2007,9 @@ def lara_module_fn_supported(x, qkv, proj, cdtype):
     def w_ok(w, out):
         return (w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous() and tuple(w.shape) == (out, C)
                 and (w.storage_offset() * 4) % 16 == 0)
-    return (w_ok(qkv.weight, 3 * C) and w_ok(proj.weight, C) and _lin_rows_ok(x2, cdtype) and _lin_geometry(C, 3 * C)
-            and _lin_geometry(C, C) and USE_WGRAD and C % 64 == 0 and x2.shape[0] >= 64)
+    geo = (_lin_geometry(C, 3 * C) and _lin_geometry(C, C)) or (allow_lib and USE_WIDE_MODULE_FN)
+    return (w_ok(qkv.weight, 3 * C) and w_ok(proj.weight, C) and _lin_rows_ok(x2, cdtype) and geo
+            and USE_WGRAD and C % 64 == 0 and x2.shape[0] >= 64)
 
 
 def _lmk_saved(geom, device):

@@ -456,6 +456,11 @@ int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const i
  *        gradient the window backward returns; inv [rows, K] int32 as for ea_gather_sum).  Fixed order (deterministic). */
 int ea_table_bias_fwd(int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx, float* out,
                       void* stream);
+/* Round 6 (ABI 12): the autocast casts of a layer's parameters in ONE launch -- dst[k][i] = (dtype) src[k][i], i < n[k], for
+ * K <= 8 fp32 tensors (round to nearest even, exactly torch's `.to(dtype)`).  The 320 / 512 / 1024-wide layers run their two
+ * projections (abstract_attention.py:72-78,86-87) as library GEMMs on 16-bit operands; their weights and biases were four
+ * separate cast launches per step. */
+int ea_multi_cast(int32_t dtype, int32_t K, const float* const* src, const int64_t* n, void* const* dst, void* stream);
 int ea_table_bias_bwd(int32_t rows, int32_t K, int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* g,
                       const int32_t* inv, float* dtable, void* stream);
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,

@@ -1364,3 +1364,62 @@ def test_table_bias_module_path_equals_dense_bias_path(attn, monkeypatch):
     names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
     for n, a, b in zip(names, *res):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_multi_cast_equals_to_dtype(dtype):
+    """ea_multi_cast (round 6): the autocast casts of a layer's parameters in one launch, bit-equal to `.to(dtype)` -- aligned
+    bulk, ragged tails, a one-element tensor, values on rounding ties."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ts = [torch.randn(1536, 512, device="cuda", generator=g) * 0.02, torch.randn(1536, device="cuda", generator=g),
+          torch.randn(320, 320, device="cuda", generator=g), torch.randn(333, device="cuda", generator=g) * 100,
+          torch.randn(1, device="cuda", generator=g), torch.randn(2051, device="cuda", generator=g)[3:]]
+    # exact ties of the 16-bit grid (round to nearest even) and non-finite values
+    tie = torch.tensor([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, float("inf"), -0.0, 65519.0, 1e-45],
+                       device="cuda")
+    ts.append(tie)
+    outs = _ops.multi_cast(ts, td)
+    for t, o in zip(ts, outs):
+        assert o.dtype == td and o.shape == t.shape
+        assert torch.equal(o.view(torch.int16), t.to(td).view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn,dim,heads,grid", [("eva", 320, 5, 24), ("softmax", 512, 8, 12), ("local", 320, 5, 24), ("eva", 512, 8, 14)])
+def test_wide_module_path_equals_three_node_path(attn, dim, heads, grid, monkeypatch):
+    """320 / 512-wide layers as ONE autograd node with library-GEMM projections (round 6: EvaModuleFn / CoreModuleFn with
+    module_proj_lib) against the three-node path (LinearFn, core, LinearFn; EA_WIDE_MODULE_FN=0): the same GEMMs and kernels,
+    so y and every gradient agree to the rounding of the weight-gradient slice order."""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    w = 8 if grid % 8 == 0 else 7
+    kw = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, fp32=False)
+    if attn != "softmax":
+        kw.update(window_size=w, attn_2d=True, overlap_window=False, use_rpe=True)
+    if attn == "eva":
+        kw.update(adaptive_proj="default", num_landmarks=36 if w == 8 else 49, use_t5_rpe=False)
+    torch.manual_seed(5)
+    m = ea.AttentionFactory.build_attention(attn, kw).cuda().train()
+    x = torch.randn(16, grid, grid, dim, device="cuda")
+    gy = torch.randn(16, grid, grid, dim, device="cuda")
+    res, nodes = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_WIDE_MODULE_FN", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        nodes.append(type(y.grad_fn).__name__)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [p.grad.clone() for p in m.parameters()])
+    assert "ModuleFn" in nodes[0] and "ModuleFn" not in nodes[1], nodes
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, *res):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
