@@ -76,7 +76,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 12; }
+int32_t ea_abi_version(void) { return 13; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -835,9 +835,10 @@ int colsum_f32_dispatch(const float* x, float* out, int rows, int cols, const fl
 int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, int K, int cols, hipStream_t st);
 int slice_sum_dispatch(const float* a, const float* p, float* out, int BH, int S, int n, float scale, hipStream_t st);
 int multi_cast_dispatch(int dtype, int K, const float* const* src, const long long* n, void* const* dst, hipStream_t st);
-int table_bias_fwd_dispatch(const float* table, const int* idx, float* out, int h, int Wq, int Wk, int ld, float scale, hipStream_t st);
-int table_bias_bwd_dispatch(const float* g, const int* inv, float* dtable, int rows, int K, int h, int Wq, int Wk, int ld, float scale,
+int table_bias_fwd_dispatch(const float* table, const int* idx, float* out, int h, int th, int Wq, int Wk, int ld, float scale,
                             hipStream_t st);
+int table_bias_bwd_dispatch(const float* g, const int* inv, float* dtable, int rows, int K, int h, int Wq, int Wk, int ld,
+                            float scale, hipStream_t st);
 int stream_copy_dispatch(const void* src, void* dst, size_t bytes, hipStream_t st);
 }  // namespace ea
 
@@ -871,10 +872,10 @@ int ea_multi_cast(int32_t dtype, int32_t K, const float* const* src, const int64
   return ea::multi_cast_dispatch(dtype, K, src, (const long long*)n, dst, (hipStream_t)stream);
 }
 
-int ea_table_bias_fwd(int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx, float* out,
-                      void* stream) {
+int ea_table_bias_fwd(int32_t h, int32_t th, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx,
+                      float* out, void* stream) {
   if (!table || !idx || !out) return EA_E_BADARG;
-  return ea::table_bias_fwd_dispatch(table, idx, out, h, Wq, Wk, ld, scale, (hipStream_t)stream);
+  return ea::table_bias_fwd_dispatch(table, idx, out, h, th, Wq, Wk, ld, scale, (hipStream_t)stream);
 }
 
 int ea_table_bias_bwd(int32_t rows, int32_t K, int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* g,

@@ -195,47 +195,54 @@ int gather_sum_dispatch(const float* g, const int* inv, float* out, int rows, in
 //     out[hd][i][j] = scale * table[idx[i Wk + j]][hd]   (j < Wk),   0   (Wk <= j < ld)
 // in the layout and units the kernels stage (rows padded to `ld`, `scale` carries log2 e): one launch for the index_select,
 // permute, scalar multiply, pad (fill + copy) and contiguous copy the framework spent on it.
+// th = heads of the TABLE: h (one column per head) or 1 (causal_eva.py's single-head T5 table, broadcast over the heads).
 __global__ __launch_bounds__(256) void table_bias_fwd_kernel(const float* __restrict__ table, const int* __restrict__ idx,
-                                                              float* __restrict__ out, int h, int Wq, int Wk, int ld, float scale) {
+                                                              float* __restrict__ out, int h, int th, int Wq, int Wk, int ld,
+                                                              float scale) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= h * Wq * ld) return;
   const int hd = e / (Wq * ld), rem = e - hd * (Wq * ld);
   const int i = rem / ld, j = rem - i * ld;
-  out[e] = j < Wk ? scale * table[(size_t)idx[i * Wk + j] * h + hd] : 0.f;
+  out[e] = j < Wk ? scale * table[(size_t)idx[i * Wk + j] * th + (th == 1 ? 0 : hd)] : 0.f;
 }
 
 // ... and its gradient from the padded gradient image g [h][Wq][ld]:
 //     dtable[row][hd] = scale * sum_k g[hd][p / Wk][p % Wk],  p = inv[row][k] >= 0   (fixed order: lanes, then a butterfly)
-__global__ __launch_bounds__(64) void table_bias_bwd_kernel(const float* __restrict__ g, const int* __restrict__ inv,
-                                                             float* __restrict__ dtable, int K, int h, int Wq, int Wk, int ld,
-                                                             float scale) {
-  const int row = blockIdx.x, lane = threadIdx.x;
-  for (int hd = 0; hd < h; ++hd) {
-    float s = 0.f;
-    for (int k = lane; k < K; k += 64) {
-      const int p = inv[(size_t)row * K + k];
-      const int pc = p >= 0 ? p : 0;
-      const int i = pc / Wk, j = pc - i * Wk;
-      const float v = g[((size_t)hd * Wq + i) * ld + j];
-      s += p >= 0 ? v : 0.f;
-    }
-    s = wave_sum(s);
-    if (lane == 0) dtable[(size_t)row * h + hd] = s * scale;
+__global__ __launch_bounds__(256) void table_bias_bwd_kernel(const float* __restrict__ g, const int* __restrict__ inv,
+                                                              float* __restrict__ dtable, int K, int h, int Wq, int Wk, int ld,
+                                                              float scale) {
+  // block = (table row, head): 256 lanes walk the row's position list (a far T5 bucket of a 128 x 256 window holds thousands
+  // of positions: one wave per row took 0.4 ms there), lane sums -> wave butterflies -> the four wave sums added in order.
+  // Every block writes its own (row, head) cell of dtable [rows, h]; the caller adds the heads of a one-column table.
+  __shared__ float red[4];
+  const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
+  float s = 0.f;
+  for (int k = tid; k < K; k += 256) {
+    const int p = inv[(size_t)row * K + k];
+    const int pc = p >= 0 ? p : 0;
+    const int i = pc / Wk, j = pc - i * Wk;
+    const float v = g[((size_t)hd * Wq + i) * ld + j];
+    s += p >= 0 ? v : 0.f;
   }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) dtable[(size_t)row * h + hd] = (((red[0] + red[1]) + red[2]) + red[3]) * scale;
 }
 
-int table_bias_fwd_dispatch(const float* table, const int* idx, float* out, int h, int Wq, int Wk, int ld, float scale,
+int table_bias_fwd_dispatch(const float* table, const int* idx, float* out, int h, int th, int Wq, int Wk, int ld, float scale,
                             hipStream_t st) {
-  if (h <= 0 || Wq <= 0 || Wk <= 0 || ld < Wk) return EA_E_BADARG;
+  if (h <= 0 || (th != h && th != 1) || Wq <= 0 || Wk <= 0 || ld < Wk) return EA_E_BADARG;
   const int n = h * Wq * ld;
-  hipLaunchKernelGGL(table_bias_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, idx, out, h, Wq, Wk, ld, scale);
+  hipLaunchKernelGGL(table_bias_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, idx, out, h, th, Wq, Wk, ld, scale);
   return (int)hipGetLastError();
 }
 
 int table_bias_bwd_dispatch(const float* g, const int* inv, float* dtable, int rows, int K, int h, int Wq, int Wk, int ld,
                             float scale, hipStream_t st) {
   if (rows <= 0 || K <= 0 || h <= 0 || Wq <= 0 || Wk <= 0 || ld < Wk) return EA_E_BADARG;
-  hipLaunchKernelGGL(table_bias_bwd_kernel, dim3((unsigned)rows), dim3(64), 0, st, g, inv, dtable, K, h, Wq, Wk, ld, scale);
+  hipLaunchKernelGGL(table_bias_bwd_kernel, dim3((unsigned)rows, (unsigned)h), dim3(256), 0, st, g, inv, dtable, K, h, Wq, Wk, ld,
+                     scale);
   return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 12         # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 13         # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -139,7 +139,7 @@ SIGNATURES = {
     "ea_adaptive_pool2d_fwd": [_I, _I, _I, _I, _I, _I, _I, _T, _P, _P],
     "ea_adaptive_pool2d_bwd": [_I, _I, _I, _I, _I, _I, _I, _P, _T, _P],
     "ea_gather_sum": [_I, _I, _I, _P, _P, _P, _P],
-    "ea_table_bias_fwd": [_I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "ea_table_bias_fwd": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "ea_multi_cast": [_I, _I, _P, _P, _P, _P],
     "ea_table_bias_bwd": [_I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "ea_linear_supported": [_I, _I],

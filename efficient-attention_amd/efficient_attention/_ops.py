@@ -235,24 +235,32 @@ class TableBias:
                 self._ld[key] = v
         return v
 
-    def dense(self, table, ld):
-        """-> [h, Wq, ld] fp32, already in the kernels' log2 units and padded (marked `_ea_ready`: _bias_padded hands it on)."""
+    def dense(self, table, ld, heads=None):
+        """-> [h, Wq, ld] fp32, already in the kernels' log2 units and padded (marked `_ea_ready`: _bias_padded hands it on).
+        heads: a one-column table (causal EVA's single-head T5 table) is broadcast over that many heads."""
         idx, _ = self._on(table.device)
         t32 = _f32c(table)
-        h = t32.shape[1]
+        th = t32.shape[1]
+        h = th if heads is None else int(heads)
+        if th != h and th != 1:
+            raise ValueError("TableBias: a table of %d columns for %d heads" % (th, h))
         out = torch.empty((h, self.Wq, ld), dtype=torch.float32, device=table.device)
-        nv.call("ea_table_bias_fwd", h, self.Wq, self.Wk, ld, self.scale * _LOG2E, nv.ptr(t32), nv.ptr(idx), nv.ptr(out), nv.stream())
+        nv.call("ea_table_bias_fwd", h, th, self.Wq, self.Wk, ld, self.scale * _LOG2E, nv.ptr(t32), nv.ptr(idx), nv.ptr(out),
+                nv.stream())
         out._ea_ready = True
         return out
 
-    def grad(self, g):
-        """g [h, Wq, ld] fp32 = d loss / d (natural-unit bias) as the window backward returns it -> d table [rows, h] fp32."""
+    def grad(self, g, table_heads=None):
+        """g [h, Wq, ld] fp32 = d loss / d (natural-unit bias) as the window backward returns it -> d table [rows, th] fp32
+        (th = table_heads or h; th = 1: summed over the heads)."""
         _, inv = self._on(g.device)
         g = _f32c(g)
         h, Wq, ld = g.shape
         out = torch.empty((self.rows, h), dtype=torch.float32, device=g.device)
         nv.call("ea_table_bias_bwd", self.rows, inv.shape[1], h, Wq, self.Wk, ld, self.scale, nv.ptr(g), nv.ptr(inv), nv.ptr(out),
                 nv.stream())
+        if table_heads is not None and int(table_heads) == 1 and h != 1:
+            out = out.sum(1, keepdim=True)
         return out
 
 
@@ -698,6 +706,17 @@ class EvaAttnFn(torch.autograd.Function):
         fcfg = [float(mu_scale), float(keep_scale)]
         pooled = cfg[-1][1:] if (isinstance(cfg[-1], tuple) and cfg[-1][:1] == ("pooled",)) else None
         direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+        # a TableBias anywhere in cfg (round 6; direct calls only): `bias` is the TABLE ([rows, h] or [rows, 1]) and the dense
+        # bias is built from it / its gradient taken back to it in one launch each way
+        tb = next((c for c in cfg if isinstance(c, TableBias)), None)
+        ctx.tb, ctx.tb_heads = tb, None
+        if tb is not None:
+            if not direct:
+                raise RuntimeError("EvaAttnFn: a TableBias spec needs the direct (untraced) call path")
+            B_, N_, _, h_, d_ = qkv5.shape
+            ctx.tb_heads = bias.shape[1]
+            bias = tb.dense(bias, tb.ld(B_, h_, N_, d_, nv.io_dtype(qkv5), attn_2d, seq_shape, window, ext, int(chunk), int(L),
+                                        int(causal)), heads=h_)
         if pooled is not None:
             outs = eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, list(mlp_params), pooled=pooled)
         elif direct:
@@ -723,7 +742,10 @@ class EvaAttnFn(torch.autograd.Function):
             g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
                        bias_cols, list(params))
         pgrads = [t.to(dt) for t, dt in zip(g[2:], ctx.pdtypes)]
-        return (g[0], _opt(g[1]), None, None, None) + tuple(pgrads)
+        dbias = _opt(g[1])
+        if ctx.tb is not None and dbias is not None:
+            dbias = ctx.tb.grad(dbias, ctx.tb_heads)
+        return (g[0], dbias, None, None, None) + tuple(pgrads)
 
 
 USE_EVA_MODULE_FN = os.environ.get("EA_EVA_MODULE_FN", "1") == "1"
@@ -2911,7 +2933,13 @@ class LinearFn(torch.autograd.Function):
             xl = x2 if x2.dtype == dtype else (xc if want else None)
             wl = weight
         else:
-            wl = weight if weight.dtype == dtype else weight.to(dtype)
+            bl_pre = None
+            if (weight.dtype == torch.float32 and dtype in _ELEM and weight.is_cuda and bias is not None
+                    and bias.dtype == torch.float32 and _DIRECT and not torch.compiler.is_compiling()
+                    and torch._C._len_torch_dispatch_stack() == 0):
+                wl, bl_pre = multi_cast([weight, bias], dtype)       # both autocast casts of the layer in one launch (round 6)
+            else:
+                wl = weight if weight.dtype == dtype else weight.to(dtype)
             if ea_linear_supported(x2, wl):
                 # an fp32 x is rounded on the way in (no cast pass), its rounded copy comes back only when the weight
                 # gradient will need it
@@ -2919,7 +2947,7 @@ class LinearFn(torch.autograd.Function):
                 xl = x2 if x2.dtype == dtype else (xc if want else None)
             else:
                 xl = x2 if x2.dtype == dtype else x2.to(dtype)
-                bl = None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype))
+                bl = bl_pre if bl_pre is not None else (None if bias is None else (bias if bias.dtype == dtype else bias.to(dtype)))
                 y = F.linear(xl, wl, bl)
         ctx.save_for_backward(xl, wl)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype, dtype)

@@ -177,7 +177,11 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         assert N % r == 0, "sequence length %d is not a multiple of the chunk size %d" % (N, r)
         L = N // r
         bias = None
-        if self.use_t5_rpe:
+        # (the 16-bit kernel branch below takes the table itself: decided here so that the dense bias is not built twice)
+        tb_ok = bool(self.use_t5_rpe and _ops.USE_TABLE_BIAS and x.is_cuda and qkv5.dtype != torch.float32
+                     and not (L > 64 and _f32.ENABLED) and _ops._DIRECT and not torch.compiler.is_compiling()
+                     and torch._C._len_torch_dispatch_stack() == 0)
+        if self.use_t5_rpe and not tb_ok:
             bias = self.rel_pos_bias.dense(w, w + e, x.device).expand(h, w, w + e)
         noise = None
         if self.training:
@@ -199,7 +203,12 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                                            *self._dropout_keep(B, h, N, w + e, L, x.device, raw=True)).to(qkv5.dtype)
         else:
             cfg = (False, (N,), w, e, r, L, "default" if self.adaptive_proj == "qk" else "no-ln",
-                   2 if self.causal else 1, 1.0) + self._dropout_keep(B, h, N, w + e, L, x.device)
+                   2 if self.causal else 1, 1.0) + (self._dropout_keep(B, h, N, w + e, L, x.device) or (None, 1.0))
+            if tb_ok:
+                # round 6: the single-head T5 table handed over as it is -- the [h, w, w + e] bias built from it, and its
+                # gradient taken back to it, by one launch each way inside the core's node (_ops.TableBias)
+                bias = self.rel_pos_bias.relative_attention_bias.weight
+                cfg = cfg + (self.rel_pos_bias.table_spec(w, w + e),)
             out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
                                        *self._mu_params())
         # out [B, N, h, d] comes back as a view of a time-first buffer (it follows qkv's layout)

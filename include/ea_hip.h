@@ -449,20 +449,22 @@ int ea_colsum2_f32(int32_t rows, int32_t cols1, const float* x1, float* out1, in
 int ea_gather_sum(int32_t rows, int32_t K, int32_t cols, const float* g, const int32_t* inv, float* out, void* stream);
 /* Round 6: the dense per-head bias of the window kernels straight out of its table, in ONE launch each way (replaces the
  * index_select / permute / multiply / pad / copy chain around `relative_position_bias_table[relative_position_index]`,
- * local_attention.py:70-79, and around T5RelativePositionBias.forward, eva.py:53-65):
- *   fwd: out[hd][i][j] = scale * table[idx[i*Wk + j]][hd] for j < Wk, 0 for Wk <= j < ld      (table [rows, h] fp32, idx int32
+ * local_attention.py:70-79, and around T5RelativePositionBias.forward, eva.py:53-65, causal_eva.py:206-300):
+ *   fwd: out[hd][i][j] = scale * table[idx[i*Wk + j]][hd] for j < Wk, 0 for Wk <= j < ld      (table [rows, th] fp32, idx int32
  *        [Wq*Wk], out [h, Wq, ld] fp32 -- ld = ea_window_bias_ld(geom); `scale` carries log2(e), the kernels' logit unit)
  *   bwd: dtable[row][hd] = scale * sum_k g[hd][p / Wk][p % Wk], p = inv[row][k] >= 0           (g [h, Wq, ld] fp32 = the bias
- *        gradient the window backward returns; inv [rows, K] int32 as for ea_gather_sum).  Fixed order (deterministic). */
-int ea_table_bias_fwd(int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx, float* out,
-                      void* stream);
+ *        gradient the window backward returns; inv [rows, K] int32 as for ea_gather_sum).  Fixed order (deterministic).
+ *   th (fwd, ABI 13) = heads of the table: h, or 1 = one column broadcast over the h heads (causal EVA's single-head T5
+ *        table); bwd always fills dtable [rows, h] -- the gradient of a one-column table is its sum over the heads. */
+int ea_table_bias_fwd(int32_t h, int32_t th, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* table, const int32_t* idx,
+                      float* out, void* stream);
+int ea_table_bias_bwd(int32_t rows, int32_t K, int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* g,
+                      const int32_t* inv, float* dtable, void* stream);
 /* Round 6 (ABI 12): the autocast casts of a layer's parameters in ONE launch -- dst[k][i] = (dtype) src[k][i], i < n[k], for
  * K <= 8 fp32 tensors (round to nearest even, exactly torch's `.to(dtype)`).  The 320 / 512 / 1024-wide layers run their two
  * projections (abstract_attention.py:72-78,86-87) as library GEMMs on 16-bit operands; their weights and biases were four
  * separate cast launches per step. */
 int ea_multi_cast(int32_t dtype, int32_t K, const float* const* src, const int64_t* n, void* const* dst, void* stream);
-int ea_table_bias_bwd(int32_t rows, int32_t K, int32_t h, int32_t Wq, int32_t Wk, int32_t ld, float scale, const float* g,
-                      const int32_t* inv, float* dtable, void* stream);
 int ea_slice_sum(int32_t BH, int32_t S, int32_t n, float scale, const float* a, const float* parts,
                  float* out, void* stream);
 /* Measurement aid, not on the path: dst[0 .. bytes) = src[0 .. bytes) by a plain 16-byte-per-lane device copy kernel

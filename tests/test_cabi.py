@@ -44,6 +44,19 @@ def test_binding_table_matches_header():
     assert bound == set(declared_symbols())
 
 
+def test_binding_table_argument_counts_match_header():
+    """Every ctypes signature has as many arguments as the header's declaration (round 6: a binding that lagged one argument
+    behind its declaration passed the name-only check and failed on the GPU box)."""
+    from efficient_attention import _native
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    counts = {}
+    for m in re.finditer(r"\b(ea_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        counts[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    bad = {n: (len(sig), counts.get(n)) for n, sig in _native.SIGNATURES.items() if counts.get(n) != len(sig)}
+    assert not bad, bad
+
+
 def test_version_and_argument_validation(lib):
     from efficient_attention import _native
     assert _native.version().startswith("ea_hip") and "gfx950" in _native.version()

@@ -128,7 +128,8 @@ def test_rows_mlp_matches_fp64(R, D, sides, ln):
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("rows,M,K", [(100352, 576, 192), (100352, 192, 192), (25088, 576, 192), (4096, 1536, 512),
                                       (1000, 64, 64), (777, 128, 320), (294912, 192, 64), (65, 960, 320),
-                                      (8192, 2560, 512), (3000, 512, 512), (700, 768, 256), (1025, 256, 192)])
+                                      (8192, 2560, 512), (3000, 512, 512), (700, 768, 256), (1025, 256, 192),
+                                      (18432, 960, 320), (18432, 320, 320), (5001, 640, 640), (333, 128, 640)])
 def test_wgrad_matches_fp64(rows, M, K, dtype):
     """ea_wgrad (weight + bias gradient of a projection in one pass) against fp64 on the same bf16/fp16 data:
     fp32 accumulation of exact products -> error far below one operand ulp of the result; deterministic."""
@@ -1328,6 +1329,12 @@ def test_table_bias_matches_the_framework_chain(case):
     (ref / math.log2(math.e) * gb[..., :Wk]).sum().backward()
     assert torch.allclose(dt, table.grad, rtol=1e-5, atol=1e-5 * float(table.grad.abs().max()))
     assert torch.equal(dt, tb.grad(gb))                # fixed order
+    # a one-column table broadcast over the heads (causal EVA's single-head T5 table): bias rows repeat, gradients add up
+    t1 = table.detach()[:, :1].contiguous()
+    got1 = tb.dense(t1, ld, heads=h)
+    assert torch.equal(got1, tb.dense(t1.expand(rows, h).contiguous(), ld))
+    d1 = tb.grad(gb, 1)
+    assert d1.shape == (rows, 1) and torch.allclose(d1[:, 0], dt.sum(1), rtol=1e-5, atol=1e-5 * float(dt.abs().max()) * h)
 
 
 @pytest.mark.gpu
