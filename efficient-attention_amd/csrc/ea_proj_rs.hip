@@ -90,7 +90,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
         const f32x4 lo = *reinterpret_cast<const f32x4*>(s), hi = *reinterpret_cast<const f32x4*>(s + 4);
         const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         wr[j][ks] = as_x8<E>(pack8<E>(f));
-        if (p.w_cast && blockIdx.x == 0)
+        // the rounded copy for the backward: piece (wave, j, ks) -- 1 KB -- leaves with workgroup `piece mod grid` (round 6;
+        // until then workgroup 0 stored all 221 KB: ~13 us of its CU's store pipe, the tail of the launch)
+        if (p.w_cast && (unsigned)((wave * 3 + j) * RS_KT + ks) % gridDim.x == blockIdx.x)
           stg16(p.w_cast + ((size_t)col[j] * RS_K + ks * 32 + 8 * g) * 2, __builtin_bit_cast(u32x4, wr[j][ks]));
       }
   }

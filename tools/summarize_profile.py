@@ -43,6 +43,10 @@ KERNEL_TO_ENTRY = [
     ("colsum_part_kernel", "ea_bias_grad"), ("colsum_f32_kernel", "ea_colsum_f32 / ea_bias_grad(finish)"),
     ("slice_sum_kernel", "ea_slice_sum"),
     ("rows_mlp_fwd_kernel", "ea_rows_mlp_fwd"), ("rows_mlp_bwd_kernel", "ea_rows_mlp_bwd"),
+    ("table_bias_fwd_kernel", "ea_table_bias_fwd"), ("table_bias_bwd_kernel", "ea_table_bias_bwd"),
+    ("multi_cast_kernel", "ea_multi_cast"),
+    ("seglin_col_kernel<ea::BF16, false>", "ea_lara_seglin_fwd"), ("seglin_col_kernel<ea::BF16, true>", "ea_lara_seglin_bwd(dq/dk)"),
+    ("seglin_dg_kernel<", "ea_lara_seglin_bwd(dG)"), ("fold_", "ea_lara_fold"),
 ]
 
 
