@@ -146,13 +146,14 @@ __global__ __launch_bounds__(256, 2) void lara_fq_kernel(const LaraP p) {
     nlz = lzb[tok_];
     ntm = tmb[tok_];
   };
-  issue(n0);
+  const bool empty = n0 >= n1;                      // (uniform) an empty second slice (lara_f_plan): zero partials, no staging
+  if (!empty) issue(n0);
   float sc_v0 = -INFINITY, sc_v1 = INFINITY, sc_v2 = 1.f;
-  if (tid < p.C) {
+  if (tid < p.C && !empty) {
     sc_v0 = p.cst[lm + tid] * LOG2E;
     if (opt) { sc_v2 = p.bhv[lm + tid]; sc_v1 = p.lse_t[lm + tid] * LOG2E; }
   }
-  {
+  if (!empty) {
     char* const dst[3] = {R1, R2, R3};
     const float* const src[3] = {p.omega + lm * D, use_t ? p.qbar + lm * D : nullptr, p.kv + lm * D};
     stage_rows3<E, D, Cp>(dst, src, p.C, tid);
@@ -944,6 +945,11 @@ static void lara_f_plan(LaraP& p, int slots, int F) {
     static const int b_env = f_env_int("EA_LARA_FQ_B", 0);      // dev knob: tokens of the second slice (query side)
     if (b_env > 0 && F != 96) b = b_env;
     if (b >= 16 && b < p.N) p.tok_begin[1] = p.N - b;
+    // Short sequences (round 6, N = 196 at B*h = 384): a second slice cannot even carry its own fixed cost -- equal halves run
+    // as 1.5 rounds of (F + N / 2) each, i.e. 2 F + N, where ONE slice per (b,h) takes F + N in a single round (-7 us of 28
+    // at cfg2, workgroup timelines of the -DEA_PROFILE build).  The slice count stays 2 (the partial buffers are laid out
+    // for it): the second slice is EMPTY -- its workgroups skip the staging and write zero partials.
+    else if (b < 16 && F != 96) p.tok_begin[1] = p.N;
   }
 }
 

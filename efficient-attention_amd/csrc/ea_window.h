@@ -78,6 +78,14 @@ constexpr size_t WIN_LDS_MAX = 160 * 1024;
 // workgroups are cheaper; but the launch runs in rounds of (CUs x resident workgroups per CU), and a
 // partly filled last round idles the chip (B*h = 384, 6 workgroups each: 4.5 rounds on 512 slots
 // -> 5).  Pick the count that minimises rounds x (windows per workgroup + prologue).
+// Backward (round 6, workgroup timelines of the -DEA_PROFILE build at cfg3: 19.3 k cycles of staging before the first window,
+// 16.5 k per window): the prologue is ~1.1 window-iterations, not the 0.4 measured for the forward in round 1 -- with 0.4 the
+// N = 196 backward (4 windows per (b,h), B*h = 384) was cut into one-window workgroups, 3 rounds of (prologue + 1 window)
+// = 49 us where one 4-window workgroup per (b,h) takes one round of (prologue + 4 windows).  EA_WIN_BWD_PROLOGUE: dev knob.
+inline double win_bwd_prologue() {
+  static const double v = [] { const char* e = getenv("EA_WIN_BWD_PROLOGUE"); return e ? atof(e) : 1.1; }();
+  return v;
+}
 inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
   if (backward && t.dbd) { t.ipb = 1; t.nblk = t.niter; return; }    // (direct bias gradient: one iteration per workgroup)
   const long bh = (long)g.B * g.H;
@@ -93,7 +101,7 @@ inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
     const int ipb = ceil_div(t.niter, nb);
     if (ceil_div(t.niter, ipb) != nb) continue;                        // same schedule as a smaller count
     const long rounds = (bh * nb + slots - 1) / slots;
-    const double cost = (double)rounds * (ipb + 0.4);
+    const double cost = (double)rounds * (ipb + (backward ? win_bwd_prologue() : 0.4));
     if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
   }
   t.ipb = ceil_div(t.niter, best);
