@@ -934,10 +934,20 @@ static int f_env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
 }
-static void lara_f_plan(LaraP& p, int slots, int F) {
+static void lara_f_plan(LaraP& p, int slots, int F, int last_extra = 0) {
   if (p.nsplit != 2) return;
   const int BH = p.B * p.H, gran = 64;
   p.tok_begin[0] = 0; p.tok_begin[1] = p.tok_per_block < p.N ? p.tok_per_block : p.N; p.tok_begin[2] = p.N;
+  // Key side with the query side's partials merged in its prologue (round 6, workgroup timelines: the LAST slice of a (b,h)
+  // also forms and writes the merged tensors the later passes read -- two dependent rounds of loads before its first chunk;
+  // with equal halves the second slices ended 8 us after the first ones, 42 vs 34 us at cfg3, 20.7 vs 13.7 at cfg2): the last
+  // slice is shorter by that work, `last_extra` token-times, when both slices of every (b,h) are resident at once.
+  if (last_extra > 0 && slots >= 2 * BH) {
+    int first = ((p.N + last_extra) / 2 + gran / 2) / gran * gran;
+    if (first >= p.N) first = (p.N - 1) / gran * gran;          // (the last slice keeps at least one token: it writes the merged tensors)
+    if (first >= gran && first < p.N) p.tok_begin[1] = first;
+    return;
+  }
   if (BH < slots && slots < 2 * BH) {
     const int rb = (BH + (slots - BH) - 1) / (slots - BH);
     // F: fixed prologue / epilogue of a workgroup, in token-times (query side, round 3: ~8 us against 0.05 us per token)
@@ -977,6 +987,7 @@ static int launch_f(int which, LaraP& p, hipStream_t st) {
   const dim3 grid((unsigned)(p.B * p.H * p.nsplit)), block(256);
   static int occ[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident workgroups per CU of the instantiations
   static const int fq_fixed = f_env_int("EA_LARA_FQ_F", 160);
+  static const int fk_extra = f_env_int("EA_LARA_FK_X", 128);      // dev knob: the merging slice's extra work in token-times
 #define EA_LF(K, slot, ...)                                                                           \
   do {                                                                                                \
     if (lds > 64 * 1024) {                                                                            \
@@ -985,7 +996,7 @@ static int launch_f(int which, LaraP& p, hipStream_t st) {
       if (e != hipSuccess) return (int)e;                                                             \
     }                                                                                                 \
     if (!occ[slot]) occ[slot] = f_occupancy(&K<__VA_ARGS__>, lds);                                    \
-    lara_f_plan(p, occ[slot] * f_device_cus(), which == 0 ? fq_fixed : 96);                           \
+    lara_f_plan(p, occ[slot] * f_device_cus(), which == 0 ? fq_fixed : 96, which == 3 ? fk_extra : 0); \
     hipLaunchKernelGGL((K<__VA_ARGS__>), grid, block, lds, st, p);                                    \
   } while (0)
   if (which == 0) {

@@ -86,6 +86,12 @@ inline double win_bwd_prologue() {
   static const double v = [] { const char* e = getenv("EA_WIN_BWD_PROLOGUE"); return e ? atof(e) : 1.1; }();
   return v;
 }
+// Forward (sweep of round 6 on one box, EVA cfg3 / cfg2, local cfg3, PvT stages, cfg5): 1.2 with landmark rows to stage (EVA cfg3
+// forward 50 -> 47 us), 0.4 without (local: 36 us at 0.4, 44 at 1.2).  EA_WIN_FWD_PROLOGUE: dev knob.
+inline double win_fwd_prologue(int L) {
+  static const double v = [] { const char* e = getenv("EA_WIN_FWD_PROLOGUE"); return e ? atof(e) : -1.0; }();
+  return v >= 0 ? v : (L > 0 ? 1.2 : 0.4);
+}
 inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
   if (backward && t.dbd) { t.ipb = 1; t.nblk = t.niter; return; }    // (direct bias gradient: one iteration per workgroup)
   const long bh = (long)g.B * g.H;
@@ -101,7 +107,7 @@ inline void win_blocks(const ea_geom& g, WinTiling& t, bool backward) {
     const int ipb = ceil_div(t.niter, nb);
     if (ceil_div(t.niter, ipb) != nb) continue;                        // same schedule as a smaller count
     const long rounds = (bh * nb + slots - 1) / slots;
-    const double cost = (double)rounds * (ipb + (backward ? win_bwd_prologue() : 0.4));
+    const double cost = (double)rounds * (ipb + (backward ? win_bwd_prologue() : win_fwd_prologue(g.L)));
     if (cost < best_cost - 1e-9) { best_cost = cost; best = nb; }
   }
   t.ipb = ceil_div(t.niter, best);

@@ -21,6 +21,12 @@ SWITCHED_OFF = {
     "EA_F32_CORES": (lambda it: it.fspath.basename == "test_gpu_f32_cores.py" or "eva_2d_L100" in it.name
                      or "lara_2d_L144" in it.name or "many_chunks" in it.name,
                      "the fp32 cores are switched off (EA_F32_CORES=0): fp32-path tests and the geometries only they cover"),
+    # the single-node module paths are what these two tests compare against the three-node / dense-bias paths
+    "EA_EVA_MODULE_FN": (lambda it: ("test_wide_module_path" in it.name or "test_table_bias_module_path" in it.name) and "eva" in it.name,
+                         "EvaModuleFn is switched off (EA_EVA_MODULE_FN=0)"),
+    "EA_CORE_MODULE_FN": (lambda it: ("test_wide_module_path" in it.name and ("softmax" in it.name or "local" in it.name))
+                          or ("test_table_bias_module_path" in it.name and "local" in it.name),
+                          "CoreModuleFn is switched off (EA_CORE_MODULE_FN=0)"),
 }
 
 
