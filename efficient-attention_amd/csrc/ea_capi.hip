@@ -32,7 +32,9 @@ int linear_supported(int K, int NO);
 int proj_rs_supported(int K, int NO);
 int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r);
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast);
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast,
+                     const void* wsw);
+int w192_prepare_dispatch(int dtype, const float* wq, const float* wp, void* w16q, void* wsw, void* w16p, void* w16pT, hipStream_t st);
 int dgrad_rs_supported(int K, int NO);
 int dgrad_fin_launch(int dtype, const void* dqkv, long ldy, const void* qkv, long ldq, const void* w, int w_f32, void* dx, int dx_f32,
                      long ldx, int B, int gh, int gw, int pool_r, int C, float scale, const float* qbar, const float* uq,
@@ -76,7 +78,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 13; }
+int32_t ea_abi_version(void) { return 14; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -1308,7 +1310,7 @@ int ea_linear_w32(int32_t dtype, int32_t rows, int32_t in_features, int32_t out_
   //  at N = 196 x batch 128 the LDS-resident kernel is faster, 25.7 against 30.1 us)
   if (rs_on && !w_transposed && !y_f32 && rows >= 65536 && proj_rs_supported(in_features, out_features))
     return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream, 0, 0, 0, 0,
-                            nullptr, nullptr, nullptr);
+                            nullptr, nullptr, nullptr, nullptr);
   return linear_dispatch(dtype, a, a_f32, w, w_transposed ? 2 : 1, bias, y, y_f32, a_cast, rows, in_features, out_features,
                          (long)lda, (long)ldy, (hipStream_t)stream);
 }
@@ -1360,7 +1362,31 @@ int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t
   if (lda < in_features || ldy < out_features || (lda & 7) || (ldy & 7)) return EA_E_BADARG;
   if (!proj_rs_pool_supported(in_features, out_features, B, gh, gw, r)) return EA_E_UNSUPPORTED;
   return proj_rs_dispatch(dtype, a, a_f32, w, bias, y, a_cast, B * gh * gw, (long)lda, (long)ldy, (hipStream_t)stream, B, gh, gw,
-                          r, pooled_q, pooled_k, w_cast);
+                          r, pooled_q, pooled_k, w_cast, nullptr);
+}
+
+int ea_linear_w192_prepare(int32_t dtype, const float* wq, const float* wp, void* w16q, void* wq_sw, void* w16p, void* w16pT,
+                           void* stream) {
+  if (!wq || !w16q || !wq_sw || ((uintptr_t)wq & 15) || ((uintptr_t)wp & 15) || ((uintptr_t)w16q & 15) || ((uintptr_t)wq_sw & 15) ||
+      ((uintptr_t)w16p & 15) || ((uintptr_t)w16pT & 15))
+    return EA_E_BADARG;
+  if (wp && (!w16p || !w16pT)) return EA_E_BADARG;
+  return w192_prepare_dispatch(dtype, wq, wp, w16q, wq_sw, w16p, w16pT, (hipStream_t)stream);
+}
+
+int ea_linear_wsw(int32_t dtype, int32_t rows, int32_t B, int32_t gh, int32_t gw, int32_t r, const void* a, int32_t a_f32, int64_t lda,
+                  const void* wq_sw, const float* bias, void* y, int64_t ldy, void* a_cast, float* pooled_q, float* pooled_k,
+                  void* stream) {
+  if (!a || !wq_sw || !y || ((uintptr_t)a & 15) || ((uintptr_t)wq_sw & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)a_cast & 15) || ((uintptr_t)pooled_q & 15) || ((uintptr_t)pooled_k & 15))
+    return EA_E_BADARG;
+  if (lda < 192 || ldy < 576 || (lda & 7) || (ldy & 7) || rows <= 0) return EA_E_BADARG;
+  if (r != 0) {
+    if (!pooled_q || !pooled_k || rows != B * gh * gw) return EA_E_BADARG;
+    if (!proj_rs_pool_supported(192, 576, B, gh, gw, r)) return EA_E_UNSUPPORTED;
+  }
+  return proj_rs_dispatch(dtype, a, a_f32, nullptr, bias, y, a_cast, rows, (long)lda, (long)ldy, (hipStream_t)stream, B, gh, gw, r,
+                          r ? pooled_q : nullptr, r ? pooled_k : nullptr, nullptr, wq_sw);
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@ struct DgP {
   char* dx;             // [rows, 192] fp32 (OF32) or element type, row stride ldx elements
   int rows, ntiles;
   long ldy, ldx;
+  long long* prof;      // dev builds (-DEA_PROFILE): workgroup time stamps
 };
 
 constexpr int DG_K = 576, DG_NO = 192, DG_WAVES = 12, DG_TOK = 32, DG_KT = DG_K / 32, DG_SLABS = DG_K / 64;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr bool pool = POOL;                             // (compile-time: the loop's memory-operation counts must be static)
+  EA_BLK(p.d, 0);
   // ---- staging slot of this thread: token s_tok of the tile, 16-byte chunk s_c of its q, its k and its v columns (32 tokens
   // x 24 chunks = 768 threads; chunk s_c = head s_c >> 3, channels 8 (s_c & 7) ..) -- which slot is q / k / v is static, so
   // only the rows that take a pooling term carry one in flight ----
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
   lo.init(lane);
   const int fh = wave >> 2, fnt = (wave >> 1) & 1, fdh = wave & 1;   // t correction: head, 16-token half, channel half of this wave
   int buf = 0;
+  EA_BLKX(p.d, 0);
   for (int u = blockIdx.x; u < p.nunits; u += gridDim.x) {
     const int b = u / p.splits, sp = u - b * p.splits;
     // PR == 0: token range [n0, n1) of the image; PR > 0: cell range [n0, n1)
@@ -459,6 +462,8 @@ __global__ __launch_bounds__(DG_WAVES * 64, 3) void dgrad_fin_kernel(const DgFin
     }
     if constexpr (HAS_T) __syncthreads();     // the next unit restages the landmark rows: this unit's correction stages are done
   }
+  EA_BLKX(p.d, 1);
+  EA_BLK(p.d, 1);
 }
 
 int dgrad_rs_supported(int K, int NO) { return K == DG_K && NO == DG_NO; }
@@ -496,6 +501,10 @@ int dgrad_fin_dispatch(int dtype, const DgFinP& p0, int w_f32, int dx_f32, bool 
   int grid = ea_device_cus();
   if (grid > p.nunits) grid = p.nunits;
   const dim3 g((unsigned)grid), b(DG_WAVES * 64);
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.d.prof = rep.arm(st, "dgrad_fin", pr);
+#endif
 #define EA_DF_LAUNCH(E_, WF_, OF_, T_, P_, R_)                                                    \
   do {                                                                                            \
     EA_SET_LDS_ONCE((&dgrad_fin_kernel<E_, WF_, OF_, T_, P_, R_>), DG_FIN_LDS);                   \

@@ -30,6 +30,9 @@ struct RsP {
   float *pq, *pk;
   int gw, cw, Lc, ntok, ncell;        // cw = gw / r cells per grid row, Lc cells per image, ntok = gh gw, ncell = B Lc
   unsigned m_Lc, m_cw;                // floor(2^32 / d) + 1: n / d == umulhi(n, m) for n d < 2^32
+  long long* prof;                    // dev builds (-DEA_PROFILE): workgroup time stamps
+  const char* wsw;                    // WSW: the weight in the element type, PRE-ARRANGED per (wave, column group, k-step, lane)
+                                      // by w192_prepare_kernel: the staging below is 18 coalesced 1-KB loads per wave
 };
 
 constexpr int RS_K = 192, RS_NO = 576, RS_WAVES = 12, RS_TOK = 32, RS_KT = RS_K / 32, RS_SLABS = RS_K / 64;
@@ -38,7 +41,17 @@ constexpr int RS_K = 192, RS_NO = 576, RS_WAVES = 12, RS_TOK = 32, RS_KT = RS_K 
 EA_DEV int rs_off(int slab, int tok, int chunk16) { return slab * (RS_TOK * 128) + lds_off2<64>(tok, chunk16); }
 
 // POOL: tokens per pooling cell (0: none; 16: 4 x 4 cells, two per tile; 4: 2 x 2 cells, eight per tile)
-template <typename E, bool AF32, int POOL>
+// lane (g, li) of wave `wave`, column group j: the output column whose weight row it holds as MFMA A operand
+EA_DEV int rs_col(int wave, int j, int li) {
+  const int c0 = 48 * wave;
+  return j == 2 ? c0 + 32 + li : c0 + 8 * (li >> 2) + (li & 3) + 4 * j;
+}
+
+// WSW (round 6): the weight arrives in the element type, pre-arranged (w192_prepare_kernel).  Workgroup timelines of the
+// -DEA_PROFILE build: with the fp32 master weight every CU pulls 442 KB through its L2 port in 16-byte pieces that use half a
+// line each -- 13.0 us before the first tile at ANY row count, 56 % of the kernel at N = 196; the prepared copy is 221 KB in
+// whole lines.
+template <typename E, bool AF32, int POOL, bool WSW>
 __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) {
   __shared__ __attribute__((aligned(16))) char tile[2][RS_SLABS * RS_TOK * 128];
   __shared__ __attribute__((aligned(16))) float bias_s[RS_NO];          // rounded to the element type
@@ -74,14 +87,20 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     if constexpr (AF32) nb[1] = ldg16(ap + 16);
   };
   int t = blockIdx.x;
+  EA_BLK(p, 0);
   if (t < p.ntiles) issue(t);
   // ---- the weight slice of this wave -> registers (A operands).  MFMA row li of the tile pair (0, 1) <-> output column
   // 8 (li >> 2) + (li & 3) [+ 4] of the wave's first 32 columns, of tile 2 <-> column 32 + li ----
   typename E::x8 wr[3][RS_KT];
   for (int i = tid; i < RS_NO; i += RS_WAVES * 64) bias_s[i] = p.bias ? E::to_f(E::from_f(p.bias[i])) : 0.f;
-  {
-    const int c0 = 48 * wave;
-    const int col[3] = {c0 + 8 * (li >> 2) + (li & 3), c0 + 8 * (li >> 2) + (li & 3) + 4, c0 + 32 + li};
+  if constexpr (WSW) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int ks = 0; ks < RS_KT; ++ks)
+        wr[j][ks] = as_x8<E>(ldg16(p.wsw + ((size_t)((wave * 3 + j) * RS_KT + ks) * 64 + lane) * 16));
+  } else {
+    const int col[3] = {rs_col(wave, 0, li), rs_col(wave, 1, li), rs_col(wave, 2, li)};
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -165,6 +184,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     }
   };
   int buf = 0, tprev = -1;
+  EA_BLKX(p, 0);
   for (; t < p.ntiles; tprev = t, t += gridDim.x, buf ^= 1) {
     // ---- commit this tile's slot: round, park in LDS, write the rounded copy ----
     {
@@ -238,12 +258,14 @@ __global__ __launch_bounds__(RS_WAVES * 64, 3) void proj_rs_kernel(const RsP p) 
     }
 #endif
   }
+  EA_BLKX(p, 1);
   if constexpr (POOL > 0) {
     if (tprev >= 0) {                                                  // the last tile's cells
       __syncthreads();
       pool_out(tprev, buf ^ 1);
     }
   }
+  EA_BLK(p, 1);
 }
 
 int proj_rs_supported(int K, int NO) { return K == RS_K && NO == RS_NO; }
@@ -257,12 +279,60 @@ int proj_rs_pool_supported(int K, int NO, int B, int gh, int gw, int r) {
   return ncell * Lc < (1l << 32) && (long)B * gh * gw < (1l << 31);
 }
 
+// The 16-bit copies of a 192-wide layer's two weights in ONE launch (round 6): wq [576, 192], wp [192, 192] fp32 ->
+//   w16q [576, 192] (input gradient), wsw = the same values in proj_rs_kernel<.., WSW>'s staging order, w16p [192, 192] (output
+//   projection), w16pT = its transpose (the output projection's input gradient as the same streaming kernel).
+// One thread per 8-element piece; round to nearest even like every cast of the library.
+template <typename E>
+__global__ __launch_bounds__(256) void w192_prepare_kernel(const float* __restrict__ wq, const float* __restrict__ wp,
+                                                            char* __restrict__ w16q, char* __restrict__ wsw,
+                                                            char* __restrict__ w16p, char* __restrict__ w16pT) {
+  constexpr int NQ = RS_WAVES * 3 * RS_KT * 64, NP = RS_K * RS_K / 8;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NQ) {
+    const int lane = i & 63, pc = i >> 6, ks = pc % RS_KT, wj = pc / RS_KT, j = wj % 3, wave = wj / 3;
+    const int g = lane >> 4, li = lane & 15;
+    const size_t e = (size_t)rs_col(wave, j, li) * RS_K + ks * 32 + 8 * g;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(wq + e), hi = *reinterpret_cast<const f32x4*>(wq + e + 4);
+    const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const u32x4 w8 = pack8<E>(f);
+    stg16(wsw + (size_t)i * 16, w8);
+    stg16(w16q + e * 2, w8);
+  } else if (i < NQ + NP && wp) {
+    const int k = i - NQ, row = k / (RS_K / 8), c = k - row * (RS_K / 8);
+    const size_t e = (size_t)row * RS_K + c * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(wp + e), hi = *reinterpret_cast<const f32x4*>(wp + e + 4);
+    const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const u32x4 w8 = pack8<E>(f);
+    stg16(w16p + e * 2, w8);
+    uint16_t* t = reinterpret_cast<uint16_t*>(w16pT);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[(size_t)(c * 8 + 2 * q) * RS_K + row] = (uint16_t)(w8[q] & 0xffffu);
+      t[(size_t)(c * 8 + 2 * q + 1) * RS_K + row] = (uint16_t)(w8[q] >> 16);
+    }
+  }
+}
+
+int w192_prepare_dispatch(int dtype, const float* wq, const float* wp, void* w16q, void* wsw, void* w16p, void* w16pT,
+                          hipStream_t st) {
+  constexpr int N = RS_WAVES * 3 * RS_KT * 64 + RS_K * RS_K / 8;
+  const dim3 g((N + 255) / 256), b(256);
+  if (dtype == EA_BF16) hipLaunchKernelGGL(w192_prepare_kernel<BF16>, g, b, 0, st, wq, wp, (char*)w16q, (char*)wsw, (char*)w16p, (char*)w16pT);
+  else if (dtype == EA_F16) hipLaunchKernelGGL(w192_prepare_kernel<F16>, g, b, 0, st, wq, wp, (char*)w16q, (char*)wsw, (char*)w16p, (char*)w16pT);
+  else return EA_E_BADARG;
+  return (int)hipGetLastError();
+}
+
+// wsw != NULL: the prepared weight (w is then unused and may be NULL)
 int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const float* bias, void* y, void* a_cast, int rows,
-                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast) {
+                     long lda, long ldy, hipStream_t st, int B, int gh, int gw, int r, float* pq, float* pk, void* w_cast,
+                     const void* wsw) {
   if (rows <= 0) return EA_OK;
   RsP p = {};
   p.a = (const char*)a; p.w = w; p.bias = bias; p.y = (char*)y; p.a_cast = a_f32 ? (char*)a_cast : nullptr;
-  p.w_cast = (char*)w_cast;
+  p.w_cast = wsw ? nullptr : (char*)w_cast;
+  p.wsw = (const char*)wsw;
   p.rows = rows; p.ntiles = (rows + RS_TOK - 1) / RS_TOK; p.lda = lda; p.ldy = ldy;
   const int pool = r * r;
   if (pool) {
@@ -274,11 +344,20 @@ int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const 
   int grid = ea_device_cus();
   if (grid > p.ntiles) grid = p.ntiles;
   const dim3 g((unsigned)grid), b(RS_WAVES * 64);
+#ifdef EA_PROFILE
+  ProfReport rep;
+  p.prof = rep.arm(st, "proj_rs", pool);
+#endif
+#define EA_RS_LAUNCH2(E_, AF_, W_)                                                                             \
+  do {                                                                                                         \
+    if (pool == 16) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 16, W_>), g, b, 0, st, p);                     \
+    else if (pool == 4) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 4, W_>), g, b, 0, st, p);                  \
+    else hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 0, W_>), g, b, 0, st, p);                                 \
+  } while (0)
 #define EA_RS_LAUNCH(E_, AF_)                                                                                  \
   do {                                                                                                         \
-    if (pool == 16) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 16>), g, b, 0, st, p);                         \
-    else if (pool == 4) hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 4>), g, b, 0, st, p);                      \
-    else hipLaunchKernelGGL((proj_rs_kernel<E_, AF_, 0>), g, b, 0, st, p);                                     \
+    if (p.wsw) EA_RS_LAUNCH2(E_, AF_, true);                                                                   \
+    else EA_RS_LAUNCH2(E_, AF_, false);                                                                        \
   } while (0)
   if (dtype == EA_BF16) {
     if (a_f32) EA_RS_LAUNCH(BF16, true);
@@ -290,6 +369,7 @@ int proj_rs_dispatch(int dtype, const void* a, int a_f32, const float* w, const 
     return EA_E_BADARG;
   }
 #undef EA_RS_LAUNCH
+#undef EA_RS_LAUNCH2
   return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 13         # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 14         # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -141,6 +141,8 @@ SIGNATURES = {
     "ea_gather_sum": [_I, _I, _I, _P, _P, _P, _P],
     "ea_table_bias_fwd": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "ea_multi_cast": [_I, _I, _P, _P, _P, _P],
+    "ea_linear_w192_prepare": [_I, _P, _P, _P, _P, _P, _P, _P],
+    "ea_linear_wsw": [_I, _I, _I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P],
     "ea_table_bias_bwd": [_I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "ea_linear_supported": [_I, _I],
     "ea_linear": [_I, _I, _I, _I, _P, _I, _L, _P, _P, _P, _I, _L, _P, _P],

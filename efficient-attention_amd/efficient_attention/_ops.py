@@ -791,6 +791,8 @@ class EvaModuleFn(torch.autograd.Function):
                        if comp else (None, None))
         lib = module_proj_lib(C)
         w16p = b16p = None
+        w192 = prepare_w192(wq, wp, cdtype) if (not lib and w192_usable(wq, wp, cdtype)) else None
+        w16pT = None if w192 is None else w192[3]
         if lib:
             # 320 / 512 / 1024-wide layers (round 6): library GEMMs on 16-bit operands inside the node -- the four parameter
             # casts in one launch, the rounded weights kept for the backward's two input-gradient GEMMs
@@ -809,8 +811,16 @@ class EvaModuleFn(torch.autograd.Function):
                 pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
                 pk = torch.empty_like(pq)
                 pooled = (pq, pk)
-            w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
-            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk, w_cast=w16)
+            if w192 is not None:
+                w16 = w192[0]
+                y, xc = project_qkv_wsw(x2, w192[1], w16, bq32, cdtype, want, (B, seq_shape[0], seq_shape[1], chunk), pq, pk)
+            else:
+                w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
+                y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, seq_shape[0], seq_shape[1], chunk, pq, pk, w_cast=w16)
+        elif w192 is not None:
+            w16 = w192[0]
+            y, xc = project_qkv_wsw(x2, w192[1], w16, bq32, cdtype, want)
+            xc = xc if want else None
         else:
             w16 = None
             y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
@@ -823,9 +833,11 @@ class EvaModuleFn(torch.autograd.Function):
         if lib:
             with torch.autocast(device_type="cuda", enabled=False):
                 y2 = F.linear(o2, w16p, b16p)
+        elif w192 is not None:
+            y2 = ea_linear(o2, w192[2], bp32, cdtype)[0]
         else:
             y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, *outs[1:], *params)
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, w16pT, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved, ctx.adaptive = icfg, fcfg, len(outs) - 1, adaptive_proj
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     [t.dtype for t in params], heads, 0 if bias is None else bias.shape[-1], bias_dt_in)
@@ -834,7 +846,7 @@ class EvaModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, *rest = ctx.saved_tensors
+        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16p, w16pT, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads, bias_cols, bias_dt = ctx.meta
         C = xshape[-1]
@@ -847,6 +859,8 @@ class EvaModuleFn(torch.autograd.Function):
         if w16p is not None:                          # library flavour (module_proj_lib): d out = dy W_proj on the rounded weight
             dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
             d_o2 = dy2 @ w16p
+        elif w16pT is not None and _lin_rows_ok(dy2, cdtype):   # prepared transposed copy (round 6)
+            d_o2 = ea_linear(dy2, w16pT, None, cdtype)[0]
         else:
             d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
         defer = USE_MULTI_SUM
@@ -1653,6 +1667,55 @@ def project_qkv_pooled(x2, wq, bq32, cdtype, want_cast, B, H, W, r, pq, pk, w_ca
     return y, a_cast
 
 
+USE_W192 = os.environ.get("EA_W192_PREPARE", "1") == "1"
+
+
+def w192_usable(wq, wp, cdtype):
+    """The prepared-weight flavour of a 192-wide layer's projections (round 6): fp32 master weights [576, 192] / [192, 192] of
+    a direct (untraced) call."""
+    return (USE_W192 and _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+            and cdtype in _ELEM and wq.is_cuda and wq.dtype == torch.float32 and wp.dtype == torch.float32
+            and tuple(wq.shape) == (576, 192) and tuple(wp.shape) == (192, 192) and wq.is_contiguous() and wp.is_contiguous()
+            and (wq.storage_offset() * 4) % 16 == 0 and (wp.storage_offset() * 4) % 16 == 0)
+
+
+def prepare_w192(wq, wp, cdtype):
+    """(w16q [576, 192], wq_sw, w16p [192, 192], w16p^T) in `cdtype`, ONE launch (ea_linear_w192_prepare): the rounded qkv weight
+    for the input-gradient kernels, the same values in the staging order of the register-resident projection kernel, the
+    rounded output-projection weight and its transpose (its input gradient through the same streaming kernel).  The kernels
+    fed by the fp32 master weights pull twice the bytes through every CU's L2 port before their first tile: 13 us of the
+    pooled projection at any row count (workgroup timelines of round 6)."""
+    dev = wq.device
+    w16q = torch.empty((576, 192), dtype=cdtype, device=dev)
+    wsw = torch.empty((576 * 192,), dtype=cdtype, device=dev)
+    w16p = torch.empty((192, 192), dtype=cdtype, device=dev)
+    w16pT = torch.empty((192, 192), dtype=cdtype, device=dev)
+    nv.call("ea_linear_w192_prepare", _ELEM[cdtype], nv.ptr(wq.detach()), nv.ptr(wp.detach()), nv.ptr(w16q), nv.ptr(wsw),
+            nv.ptr(w16p), nv.ptr(w16pT), nv.stream())
+    return w16q, wsw, w16p, w16pT
+
+
+def project_qkv_wsw(x2, wsw, w16q, bq32, cdtype, want_cast, grid=None, pq=None, pk=None):
+    """qkv = x2 @ wq.T + bq from the prepared weight: the register-resident kernel (ea_linear_wsw; with grid = (B, H, W, r) the
+    pooled q / k rows leave with it as from project_qkv_pooled) from 65 536 rows on or whenever the pooled rows are wanted, the
+    LDS-resident streaming kernel on the rounded weight below that -> (y [rows, 576], rounded copy of an fp32 x2 or None)."""
+    rows, K = x2.shape
+    a_f32 = x2.dtype == torch.float32
+    if grid is None and rows < 65536:
+        y, ac = ea_linear(x2, w16q, bq32, cdtype, want_cast)
+        return y, ac
+    y = torch.empty((rows, 576), dtype=cdtype, device=x2.device)
+    a_cast = torch.empty((rows, K), dtype=cdtype, device=x2.device) if (a_f32 and want_cast) else None
+    B, H, W, r = grid if grid is not None else (0, 0, 0, 0)
+    label = "ea_linear_wsw"
+    if nv.KERNEL_TIMER.enabled:
+        label = "ea_linear[192->576,%s->16%s]" % ("f32" if a_f32 else "16", ",+pool" if grid is not None else "")
+        _note_bytes(label, rows * (K * x2.element_size() + 576 * 2 + (K * 2 if a_cast is not None else 0)))
+    nv.call_as(label, "ea_linear_wsw", _ELEM[cdtype], rows, B, H, W, r, nv.ptr(x2), int(a_f32), x2.stride(0), nv.ptr(wsw),
+               nv.ptr(bq32), nv.ptr(y), 576, nv.ptr(a_cast), nv.ptr(pq), nv.ptr(pk), nv.stream())
+    return y, a_cast
+
+
 class LaraModuleFn(torch.autograd.Function):
     """qkv projection -> 2-D pooled LARA core -> output projection as ONE autograd node (round 3): the same launches as
     LinearFn + LaraPooledFn + LinearFn, without two of the three nodes' host cost (ctx objects, saved-tensor packing, engine
@@ -1676,6 +1739,7 @@ class LaraModuleFn(torch.autograd.Function):
                 int(any(ctx.needs_input_grad))]
         fcfg = [float(kappa), float(scale)]
         direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
+        w192 = prepare_w192(wq, wp, cdtype) if (direct and w192_usable(wq, wp, cdtype)) else None
         if direct and proj_pool_supported(x2, wq, cdtype, B, H, W, r, heads):
             # round 4: the projection kernel walks the tokens cell by cell and emits the pooled q / k rows itself -- the
             # pooling pass (ea_eva_chunk_mean_fwd: q, k read once more, 87 MB / 17 us at cfg3) is gone
@@ -1691,21 +1755,34 @@ class LaraModuleFn(torch.autograd.Function):
                 pq = torch.empty((B * heads, L, d), dtype=torch.float32, device=x.device)
                 pk = torch.empty_like(pq)
                 pooled = (None, pq, pk)
-            # the rounded weight for the backward's input-gradient GEMM leaves with the same launch (no cast kernel there)
-            w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
-            y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, H, W, r, pq, pk, w_cast=w16)
+            if w192 is not None:
+                # round 6: both weights rounded (and the qkv weight arranged for this kernel) by one launch up front
+                w16 = w192[0]
+                y, xc = project_qkv_wsw(x2, w192[1], w16, bq32, cdtype, want, (B, H, W, r), pq, pk)
+            else:
+                # the rounded weight for the backward's input-gradient GEMM leaves with the same launch (no cast kernel there)
+                w16 = torch.empty((3 * C, C), dtype=cdtype, device=x.device) if ctx.needs_input_grad[0] else None
+                y, xc = project_qkv_pooled(x2, wq, bq32, cdtype, want, B, H, W, r, pq, pk, w_cast=w16)
             xl = x2 if x2.dtype == cdtype else (xc if want else None)
             qkv5 = y.view(B, N, 3, heads, d)
             outs = lara_fwd_impl(qkv5, mask_u8, noise, icfg, fcfg, list(params), pooled=pooled)
         else:
             w16 = None
-            y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
+            if w192 is not None:
+                w16 = w192[0]
+                y, xc = project_qkv_wsw(x2, w192[1], w16, bq32, cdtype, want)
+            else:
+                y, xc = _ea_op("linear_w32", linear_w32_impl, x2, wq, bq32, elem, False, False, want)
             xl = x2 if x2.dtype == cdtype else (xc if want else None)
             qkv5 = y.view(B, N, 3, heads, C // heads)
             outs = _ea_op("lara_fwd", lara_fwd_impl, qkv5, mask_u8, noise, icfg, fcfg, list(params))
         o2 = outs[0].reshape(-1, C)
-        y2 = _ea_op("linear_w32", linear_w32_impl, o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *outs[1:], *params)
+        if w192 is not None:
+            y2 = ea_linear(o2, w192[2], bp32, cdtype)[0]
+        else:
+            y2 = _ea_op("linear_w32", linear_w32_impl, o2, wp, bp32, elem, False, False, False)[0]
+        w16pT = None if w192 is None else w192[3]
+        ctx.save_for_backward(xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16pT, *outs[1:], *params)
         ctx.icfg, ctx.fcfg, ctx.nsaved = icfg, fcfg, len(outs) - 1
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     [t.dtype for t in params], heads)
@@ -1713,7 +1790,7 @@ class LaraModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, *rest = ctx.saved_tensors
+        xl, qkv5, mask_u8, noise, o2, wq, wp, w16, w16pT, *rest = ctx.saved_tensors
         saved, params = rest[:ctx.nsaved], rest[ctx.nsaved:]
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, pdtypes, heads = ctx.meta
         C = xshape[-1]
@@ -1722,8 +1799,12 @@ class LaraModuleFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, C)
         if dy2.dtype != cdtype:
             dy2 = dy2.to(cdtype)
-        # output projection: input gradient from the master weight read transposed, weight + bias gradient in one pass
-        d_o2 = _ea_op("linear_w32", linear_w32_impl, dy2, wp, None, elem, True, False, False)[0]
+        # output projection: input gradient from the master weight read transposed (or from the prepared transposed copy of
+        # round 6), weight + bias gradient in one pass
+        if w16pT is not None and _lin_rows_ok(dy2, cdtype):
+            d_o2 = ea_linear(dy2, w16pT, None, cdtype)[0]
+        else:
+            d_o2 = _ea_op("linear_w32", linear_w32_impl, dy2, wp, None, elem, True, False, False)[0]
         direct = _DIRECT and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0
         # round 4: the terminal sums of this backward -- slice partials of both weight gradients, per-(b,h) partials of the
         # landmark parameters -- are added up by ONE launch at the end (ea_multi_sum) instead of three
@@ -1887,11 +1968,16 @@ class CoreModuleFn(torch.autograd.Function):
         want = x2.dtype == torch.float32 and ctx.needs_input_grad[1]
         lib = module_proj_lib(C)
         w16q = w16p = b16p = None
+        w192 = prepare_w192(wq, wp, cdtype) if (not lib and w192_usable(wq, wp, cdtype)) else None
+        w16pT = None if w192 is None else w192[3]
         if lib:
             # 320 / 512 / 1024-wide layers (round 6): library GEMMs on 16-bit operands inside the node (see EvaModuleFn)
             w16q, b16q, w16p, b16p = lib_casts(wq, bq, wp, bp, cdtype)
             y, xc = lib_project(x2, wq, bq32, w16q, b16q, cdtype)
             want = True
+        elif w192 is not None:
+            w16q = w192[0]
+            y, xc = project_qkv_wsw(x2, w192[1], w16q, bq32, cdtype, want)
         else:
             y, xc = linear_w32_impl(x2, wq, bq32, elem, False, False, want)
         xl = x2 if x2.dtype == cdtype else (xc if want else None)
@@ -1901,9 +1987,11 @@ class CoreModuleFn(torch.autograd.Function):
         if lib:
             with torch.autocast(device_type="cuda", enabled=False):
                 y2 = F.linear(o2, w16p, b16p)
+        elif w192 is not None:
+            y2 = ea_linear(o2, w192[2], bp32, cdtype)[0]
         else:
             y2 = linear_w32_impl(o2, wp, bp32, elem, False, False, False)[0]
-        ctx.save_for_backward(xl, qkv5, o2, wq, wp, w16q, w16p, *saved)
+        ctx.save_for_backward(xl, qkv5, o2, wq, wp, w16q, w16p, w16pT, *saved)
         ctx.core = core
         ctx.meta = (x.shape, x.dtype, cdtype, None if bq is None else bq.dtype, None if bp is None else bp.dtype, wq.dtype, wp.dtype,
                     heads, [None if t is None else t.dtype for t in inputs])
@@ -1911,7 +1999,7 @@ class CoreModuleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xl, qkv5, o2, wq, wp, w16q, w16p, *saved = ctx.saved_tensors
+        xl, qkv5, o2, wq, wp, w16q, w16p, w16pT, *saved = ctx.saved_tensors
         xshape, xdtype, cdtype, bqd, bpd, wqd, wpd, heads, in_dtypes = ctx.meta
         C = xshape[-1]
         d = C // heads
@@ -1923,6 +2011,8 @@ class CoreModuleFn(torch.autograd.Function):
         if w16p is not None:
             dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
             d_o2 = dy2 @ w16p
+        elif w16pT is not None and _lin_rows_ok(dy2, cdtype):
+            d_o2 = ea_linear(dy2, w16pT, None, cdtype)[0]
         else:
             d_o2 = linear_w32_impl(dy2, wp, None, elem, True, False, False)[0]
         B, N = qkv5.shape[:2]

@@ -603,6 +603,22 @@ int ea_linear_w32_pool(int32_t dtype, int32_t B, int32_t gh, int32_t gw, int32_t
                        const void* a, int32_t a_f32, int64_t lda, const float* w, const float* bias, void* y, int64_t ldy,
                        void* a_cast, float* pooled_q, float* pooled_k, void* w_cast, void* stream);
 
+/* Round 6 (ABI 14): the 16-bit copies of a 192-wide layer's two weights in ONE launch, and the qkv projection fed by them.
+ *   ea_linear_w192_prepare: wq fp32 [576, 192], wp fp32 [192, 192] (or NULL) -> w16q [576, 192] (what ea_linear_dgrad* take),
+ *       wq_sw (576 * 192 elements: the same values in the order the register-resident projection kernel stages them),
+ *       w16p [192, 192] and w16pT = its transpose (the output projection and its input gradient through ea_linear).
+ *       Round to nearest even, as every cast of the library.
+ *   ea_linear_wsw: y[rows, 576] = a[rows, 192] W^T + bias with W given as wq_sw; r = 0: plain rows; r = 2 | 4: tokens of
+ *       B images of gh x gw, pooled q / k rows written as by ea_linear_w32_pool.
+ * With the fp32 master weight every CU pulls 442 KB through its L2 port before its first tile -- 13 us at ANY row count
+ * (workgroup timelines) -- and the two 192 x 192 projections another 2 x 147 KB per workgroup; the prepared
+ * copies halve all of it for one ~4 us launch per step. */
+int ea_linear_w192_prepare(int32_t dtype, const float* wq, const float* wp, void* w16q, void* wq_sw, void* w16p, void* w16pT,
+                           void* stream);
+int ea_linear_wsw(int32_t dtype, int32_t rows, int32_t B, int32_t gh, int32_t gw, int32_t r, const void* a, int32_t a_f32, int64_t lda,
+                  const void* wq_sw, const float* bias, void* y, int64_t ldy, void* a_cast, float* pooled_q, float* pooled_k,
+                  void* stream);
+
 /* The INPUT gradient of that qkv projection (abstract_attention.py:72-78 differentiated; ABI 10, ea_dgrad_rs.hip):
  *   dx[rows, in] = dy[rows, out] w[out, in]          in = 192, out = 576 (ea_linear_dgrad_supported != 0)
  * dy: EA dtype, row stride ldy elements; w: the layer's weight [out, in] contiguous -- the fp32 master (w_f32 != 0, rounded

@@ -751,7 +751,10 @@ def test_eva_pooled_projection_close_to_separate_chunk_means(dtype, grid, window
         _ops.USE_PROJ_POOL = pool
         calls = []
         orig = _ops.project_qkv_pooled
+        orig_w = _ops.project_qkv_wsw                  # (round 6: the prepared-weight flavour of the same kernel)
         _ops.project_qkv_pooled = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        _ops.project_qkv_wsw = lambda *a, **k: (calls.append(1) if (len(a) > 6 and a[6] is not None) or k.get("grid") is not None
+                                                else None, orig_w(*a, **k))[1]
         try:
             for p in m.parameters():
                 p.grad = None
@@ -764,6 +767,7 @@ def test_eva_pooled_projection_close_to_separate_chunk_means(dtype, grid, window
         finally:
             _ops.USE_PROJ_POOL = old
             _ops.project_qkv_pooled = orig
+            _ops.project_qkv_wsw = orig_w
         assert len(calls) == (1 if pool else 0)
     tol = 1.6e-2 if dtype == "bf16" else 2e-3           # two ulps of the 16-bit outputs at the largest value
 
@@ -1180,6 +1184,7 @@ def test_rounded_weight_from_the_projection_launch(attn, monkeypatch):
     res, seen = {}, []
     for sw in ("USE_PROJ_POOL", "USE_LARA_MODULE_FN", "USE_EVA_MODULE_FN"):     # the path that has the output
         monkeypatch.setattr(_ops, sw, True)
+    monkeypatch.setattr(_ops, "USE_W192", False)           # (round 6: the prepared weights replace this output by default)
     orig = _ops.project_qkv_pooled
     for keep in (True, False):
         def wrapped(*a, w_cast=None, _keep=keep, **k):
@@ -1430,3 +1435,72 @@ def test_wide_module_path_equals_three_node_path(attn, dim, heads, grid, monkeyp
     names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
     for n, a, b in zip(names, *res):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_w192_prepare_and_wsw_projection(dtype):
+    """ea_linear_w192_prepare (round 6): the rounded copies of a 192-wide layer's weights in one launch -- bit-equal to
+    `.to(dtype)` / its transpose -- and ea_linear_wsw fed by the pre-arranged copy: BIT-identical to ea_linear_w32_pool on the
+    fp32 master weight (outputs, rounded copy of x, pooled rows), pooled and plain, 2 x 2 and 4 x 4 cells."""
+    import torch
+    from efficient_attention import _ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    g = torch.Generator(device="cuda").manual_seed(17)
+    wq = torch.randn(576, 192, device="cuda", generator=g) * 0.05
+    wp = torch.randn(192, 192, device="cuda", generator=g) * 0.05
+    bq = torch.randn(576, device="cuda", generator=g) * 0.1
+    w16q, wsw, w16p, w16pT = _ops.prepare_w192(wq, wp, td)
+    assert torch.equal(w16q, wq.to(td)) and torch.equal(w16p, wp.to(td)) and torch.equal(w16pT, wp.to(td).t().contiguous())
+    assert torch.equal(torch.sort(wsw.view(torch.int16).flatten())[0], torch.sort(w16q.view(torch.int16).flatten())[0])
+    for (B, H, W, r) in [(8, 28, 28, 4), (16, 14, 14, 2), (3, 8, 8, 2)]:
+        x = torch.randn(B * H * W, 192, device="cuda", generator=g)
+        L = (H // r) * (W // r)
+        pq0, pk0 = torch.empty(B * 3, L, 64, device="cuda"), torch.empty(B * 3, L, 64, device="cuda")
+        pq1, pk1 = torch.empty_like(pq0), torch.empty_like(pk0)
+        y0, xc0 = _ops.project_qkv_pooled(x, wq, bq, td, True, B, H, W, r, pq0, pk0)
+        y1, xc1 = _ops.project_qkv_wsw(x, wsw, w16q, bq, td, True, (B, H, W, r), pq1, pk1)
+        assert torch.equal(y0, y1) and torch.equal(xc0, xc1) and torch.equal(pq0, pq1) and torch.equal(pk0, pk1)
+    # plain rows: the register-resident kernel from 65 536 rows on, the LDS-resident one below
+    for rows in (70000, 5000):
+        x = torch.randn(rows, 192, device="cuda", generator=g)
+        y0, _ = _ops.ea_linear(x, wq, bq, td, False, elem_dtype=td)
+        y1, _ = _ops.project_qkv_wsw(x, wsw, w16q, bq, td, False)
+        assert torch.equal(y0, y1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["lara", "eva", "softmax", "local"])
+def test_prepared_weight_path_is_bit_identical(attn, monkeypatch):
+    """The 192-wide single-node paths with the prepared 16-bit weights (EA_W192_PREPARE, round 6) against the same paths on the
+    fp32 master weights: the same rounded operands reach the same kernels, so y and every gradient are BIT-identical."""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    kw = dict(dim=192, num_heads=3, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, fp32=False)
+    if attn in ("eva", "local"):
+        kw.update(window_size=7, attn_2d=True, overlap_window=False, use_rpe=True)
+    if attn == "eva":
+        kw.update(adaptive_proj="default", num_landmarks=49, use_t5_rpe=False)
+    if attn == "lara":
+        kw.update(num_landmarks=49, kernel_size=None, pool_module_type="light", mis_type="mis-opt", proposal_gen="pool-mixed",
+                  use_antithetics=False, use_multisample=False, alpha_coeff=2.0)
+    torch.manual_seed(5)
+    m = ea.AttentionFactory.build_attention(attn, kw).cuda().train()
+    for B in (96, 8):                                  # above / below the row count of the register-resident plain projection
+        x = torch.randn(B, 28, 28, 192, device="cuda")
+        gy = torch.randn(B, 28, 28, 192, device="cuda")
+        res = []
+        for on in (True, False):
+            monkeypatch.setattr(_ops, "USE_W192", on)
+            for p in m.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            torch.manual_seed(11)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(xi)
+            y.backward(gy.to(y.dtype))
+            res.append([y, xi.grad] + [p.grad.clone() for p in m.parameters()])
+        names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+        for n, a, b in zip(names, *res):
+            assert torch.equal(a, b), (attn, B, n, float((a.float() - b.float()).abs().max()))

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objd
 # across a loop or a phase boundary; they are re-derived from an opaque copy of the thread index where they are used).
 KNOWN_SPILLS = {}
 # the launches of the default bench step (LARA, cfg3, bf16) that must stay spill-free
-HEADLINE = ["proj_rs_kernel<BF16, true, 16>", "lmk2::lmk2_kernel<64, false>", "lmk2::lmk2_kernel<64, true>", "lara_y_kernel<BF16, 64, 0, 0>",
+HEADLINE = ["proj_rs_kernel<BF16, true, 16, true>", "proj_rs_kernel<BF16, true, 16, false>", "lmk2::lmk2_kernel<64, false>", "lmk2::lmk2_kernel<64, true>", "lara_y_kernel<BF16, 64, 0, 0>",
             "lara_x_kernel<BF16, 64, 4, 7, 0>", "lara_fq_kernel<BF16, 64, 4, 1, 0>", "wgrad_kernel<BF16, 192, 192>", "dgrad_rs_kernel<BF16, false, true>",
             "lin_kernel<BF16, 6, 2, false, 6, false>"]
 
