@@ -24,6 +24,8 @@ SWITCHED_OFF = {
     # the single-node module paths are what these two tests compare against the three-node / dense-bias paths
     "EA_EVA_MODULE_FN": (lambda it: ("test_wide_module_path" in it.name or "test_table_bias_module_path" in it.name) and "eva" in it.name,
                          "EvaModuleFn is switched off (EA_EVA_MODULE_FN=0)"),
+    # (USE_LARA_MODULE_FN gates lara_module_fn_supported, which every single-node path asks)
+    "EA_LARA_MODULE_FN": (lambda it: "test_wide_module_path" in it.name, "the single-node paths are switched off (EA_LARA_MODULE_FN=0)"),
     "EA_CORE_MODULE_FN": (lambda it: ("test_wide_module_path" in it.name and ("softmax" in it.name or "local" in it.name))
                           or ("test_table_bias_module_path" in it.name and "local" in it.name),
                           "CoreModuleFn is switched off (EA_CORE_MODULE_FN=0)"),
