@@ -59,9 +59,26 @@ EA_DEV int seg_len(const SegLinP& p, int l) { return l < p.nshort ? p.segs : p.s
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
+// Cursor over the (segment, step) pairs of a wave's group of consecutive segments -- uniform values.  Round 6: a wave walks
+// its segments as ONE stream of TS-token steps with the row loads of the next DEPTH steps in flight ACROSS the segment
+// boundaries.  Until then every 84-token segment (cfg5: N = 4096, 49 segments) started cold -- two row loads issued, a full
+// memory round trip waited for, then 6 steps with two more steps' rows requested past the segment's end and dropped: the three
+// passes ran at 1.4 - 3.6 TB/s (profiles/r06cfg5_lara_kernel_stats.csv: 48 + 111 + 108 us).
+template <int TS> struct SegCur {
+  int l, it, s0, len, steps;
+  EA_DEV void set(const SegLinP& p, int l_) {
+    l = l_; it = 0; s0 = seg_start(p, l_); len = seg_len(p, l_); steps = (len + TS - 1) / TS;
+  }
+  EA_DEV int tok(int o) const { return s0 + min(it * TS + o, len - 1); }          // row o of the step, clamped to the segment
+  EA_DEV void advance(const SegLinP& p, int l1) {                                  // past the group's end: its last step again
+    if (++it == steps) { if (l + 1 < l1) set(p, l + 1); else it = steps - 1; }    // (a harmless re-read nobody consumes)
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
 // token-column passes: forward (BWD = false) and the dq / dk pass (BWD = true)
 template <typename E, bool BWD>
-__global__ __launch_bounds__(256) void seglin_col_kernel(const SegLinP p) {
+__global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegLinP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   // a wave = (b, h, side, group of consecutive segments): the generator operands (64 + 64 registers' worth of loads, the
   // transposed one a 64-way gather) are fetched once per wave, not once per 84-token segment
@@ -69,27 +86,35 @@ __global__ __launch_bounds__(256) void seglin_col_kernel(const SegLinP p) {
   if (unit >= p.B * p.H * p.cgroups * 2) return;
   const int side = unit & 1, rest = unit >> 1;
   const int grp = rest % p.cgroups, bh = rest / p.cgroups, b = bh / p.H, h = bh - b * p.H;
+  const int l0 = grp * p.cseg_per_group, l1 = min(p.L, l0 + p.cseg_per_group);
+  if (l0 >= l1) return;
   const char* src = side ? p.k + (b * p.k_sb + h * p.k_sh) * 2 : p.q + (b * p.q_sb + h * p.q_sh) * 2;
   const int sn = (int)(side ? p.k_sn : p.q_sn);
   const float* G = side ? p.Gk : p.Gq;
+  // wave-private LDS: the LayerNorm weight / bias (needed once per segment -- 32 registers that pay for two more steps of rows
+  // in flight) and, in the backward, the segment's incoming gradient row on its way from "lane = channel" to the D layout
+  __shared__ float wl[4][3][64];
+  float* const wlw = wl[wave][0];
+  float* const wlb = wl[wave][1];
+  float* const wdb = wl[wave][2];
+  wlw[lane] = (side ? p.lnk_w : p.lnq_w)[lane];
+  wlb[lane] = (side ? p.lnk_b : p.lnq_b)[lane];
   GenA<E> ga;
   ga.load(G, g, li);
   // per-lane channel constants: channel 16 mt + 4 g + r
-  float gb[4][4], lw[4][4], lb[4][4];
+  float gb[4][4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int ch = 16 * mt + 4 * g;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>((side ? p.gkb : p.gqb) + ch);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>((side ? p.lnk_w : p.lnq_w) + ch);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>((side ? p.lnk_b : p.lnq_b) + ch);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>((side ? p.gkb : p.gqb) + 16 * mt + 4 * g);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { gb[mt][r] = v0[r]; lw[mt][r] = v1[r]; lb[mt][r] = v2[r]; }
+    for (int r = 0; r < 4; ++r) gb[mt][r] = v0[r];
   }
   // backward state
   typename E::x8 gt[4][2];             // G^T as the A operand of dx^T = G^T dz^T: lane (g, li): in 16 mi + li, k-slots (out)
-  float a_[4][4], dy[4][4], s1 = 0.f;
+  float a_[4][4], s1 = 0.f, ndb = 0.f;
   char* dst = nullptr;
   int dsn = 0;
+  const float* dbar_bh = nullptr;
   if constexpr (BWD) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -105,153 +130,170 @@ __global__ __launch_bounds__(256) void seglin_col_kernel(const SegLinP p) {
       }
     dst = side ? p.dk + (b * p.dk_sb + h * p.dk_sh) * 2 : p.dq + (b * p.dq_sb + h * p.dq_sh) * 2;
     dsn = (int)(side ? p.dk_sn : p.dq_sn);
+    dbar_bh = (side ? p.d_kbar : p.d_qbar) + (size_t)bh * p.L * 64;
+    ndb = dbar_bh[(size_t)l0 * 64 + lane];         // lane = channel; the NEXT segment's row is requested a segment ahead
   }
-  const int l0 = grp * p.cseg_per_group, l1 = min(p.L, l0 + p.cseg_per_group);
-  for (int l = l0; l < l1; ++l) {
-  const int s0 = seg_start(p, l), len = seg_len(p, l);
-  const float inv_len = 1.f / (float)len;
-  if constexpr (BWD) {
-    const float* dbar = (side ? p.d_kbar : p.d_qbar) + ((size_t)bh * p.L + l) * 64;
-    float s = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(dbar + 16 * mt + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dy[mt][r] = v[r] * inv_len;
-        a_[mt][r] = dy[mt][r] * lw[mt][r];
-        s += a_[mt][r];
-      }
-    }
-    s1 = quad_sum(s) * (1.f / 64);
-  }
-  float accy[4][4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) accy[mt][r] = 0.f;
-
-  const int steps = (len + 15) >> 4;
-  // rows of the NEXT TWO steps in flight (a wave is one of 8 per CU: with one step ahead the passes ran at 2-3 TB/s), and in
-  // the backward the gradient row piece (channels 16 g .. + 15) the next step adds to
-  u32x4 nxa[2], nxb[2], nog[2];
-  auto issue = [&](int it, u32x4* dstv) {
-    const int tok_ = s0 + min(it * 16 + li, len - 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) dstv[ks] = ldg16(src + (tok_ * sn + 32 * ks + 8 * g) * 2);
-  };
-  auto issue_g = [&](int it) {
+  // rows of the next DEPTH steps in flight (a wave is one of 8 - 12 per CU), in the backward also the gradient-row pieces
+  // (channels 16 g .. + 15) those steps add to.  Slot d of the queue is refilled by the step that consumes it: the step loop
+  // is unrolled DEPTH times, no register of an outstanding load is ever moved.
+  constexpr int DEPTH = BWD ? 3 : 4;
+  u32x4 qx[DEPTH][2], qg[BWD ? DEPTH : 1][2];
+  SegCur<16> pc, cc;
+  pc.set(p, l0);
+  cc.set(p, l0);
+  auto issue = [&](u32x4 (&x)[2], u32x4 (&og)[2]) {
+    const int tok_ = pc.tok(li);
+    x[0] = ldg16(src + (tok_ * sn + 8 * g) * 2);
+    x[1] = ldg16(src + (tok_ * sn + 32 + 8 * g) * 2);
     if constexpr (BWD) {
-      const int tok_ = s0 + min(it * 16 + li, len - 1);
-      nog[0] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g) * 2);
-      nog[1] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g + 8) * 2);
+      og[0] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g) * 2);
+      og[1] = ldg16(dst + ((size_t)tok_ * dsn + 16 * g + 8) * 2);
     }
+    pc.advance(p, l1);
   };
-  issue(0, nxa);
-  issue_g(0);
-  issue(1, nxb);                                   // (clamped to the segment: a harmless re-read when steps == 1)
-  for (int it = 0; it < steps; ++it) {
-    const typename E::x8 bx0 = as_x8<E>(nxa[0]), bx1 = as_x8<E>(nxa[1]);
-    const u32x4 oldg[2] = {nog[0], nog[1]};
-    const int off = it * 16 + li;
-    const bool valid = off < len;
-    const int tok = s0 + min(off, len - 1);
-    nxa[0] = nxb[0]; nxa[1] = nxb[1];
-    issue(it + 2, nxb);
-    issue_g(it + 1);
-    f32x4 z[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      z[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      z[mt] = E::mma(ga.a[mt][0], bx0, z[mt]);
-      z[mt] = E::mma(ga.a[mt][1], bx1, z[mt]);
-    }
-    float s = 0.f;
+  for (int d = 0; d < DEPTH; ++d) issue(qx[d], qg[BWD ? d : 0]);
+  float accz[4][4];                    // forward: sum of the normalised rows of the segment (weight / bias applied at its end)
+  float inv_len = 0.f;
+  bool done = false;
+  while (!done) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int d = 0; d < DEPTH; ++d) {
+      if (done) break;
+      if (cc.it == 0) {                // ---- a segment begins ----
+        inv_len = 1.f / (float)cc.len;
+        if constexpr (BWD) {
+          wdb[lane] = ndb;
+          ndb = dbar_bh[(size_t)min(cc.l + 1, l1 - 1) * 64 + lane];
+          float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { z[mt][r] += gb[mt][r]; s += z[mt][r]; }
-    const float mean = quad_sum(s) * (1.f / 64);
-    float v = 0.f;
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wdb + 16 * mt + 4 * g);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wlw + 16 * mt + 4 * g);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+            for (int r = 0; r < 4; ++r) {
+              a_[mt][r] = v[r] * inv_len * w[r];
+              s += a_[mt][r];
+            }
+          }
+          s1 = quad_sum(s) * (1.f / 64);
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { z[mt][r] -= mean; v += z[mt][r] * z[mt][r]; }
-    const float rstd = rsqrtf(quad_sum(v) * (1.f / 64) + 1e-5f);
+          for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[mt][r] *= rstd;                   // z = xhat from here on
-    if constexpr (!BWD) {
-      const float w = valid ? 1.f : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) accy[mt][r] += w * (lw[mt][r] * z[mt][r] + lb[mt][r]);
-    } else {
-      float s2 = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s2 += a_[mt][r] * z[mt][r];
-      s2 = quad_sum(s2) * (1.f / 64);
-      // the token's LayerNorm statistics for the dG pass (which would otherwise redo them with 16-lane reductions)
-      if (g == 0 && valid) p.stats[((size_t)(bh * 2 + side) * p.N + tok)] = f32x4{mean, rstd, s2, 0.f};
-      const float w = valid ? rstd : 0.f;
-      float dz[4][4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dz[mt][r] = w * (a_[mt][r] - s1 - z[mt][r] * s2);
+            for (int r = 0; r < 4; ++r) accz[mt][r] = 0.f;
         }
-      // dx^T[in][token] = G^T dz^T: the D values of out-tiles (2 kk, 2 kk + 1) are the k-slots of step kk
-      f32x4 dx[4];
-      const typename E::x8 bz0 = as_x8<E>(u32x4{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[0][2], dz[0][3]),
-                                               pack2<E>(dz[1][0], dz[1][1]), pack2<E>(dz[1][2], dz[1][3])});
-      const typename E::x8 bz1 = as_x8<E>(u32x4{pack2<E>(dz[2][0], dz[2][1]), pack2<E>(dz[2][2], dz[2][3]),
-                                               pack2<E>(dz[3][0], dz[3][1]), pack2<E>(dz[3][2], dz[3][3])});
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        dx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dx[mi] = E::mma(gt[mi][0], bz0, dx[mi]);
-        dx[mi] = E::mma(gt[mi][1], bz1, dx[mi]);
       }
-      // accumulate into the gradient rows.  The four lanes of a token trade their 4-channel pieces (quad_transpose) so that a
-      // lane owns 16 contiguous channels: two 16-byte accesses, the row's 128-byte line complete per instruction pair (8-byte
-      // pieces of four different lines per instruction ran this pass at 2 TB/s)
-      float f[16];
-      quad_transpose_f32(dx, f);
-      if (valid) {
-        float o[16];
-        unpack8<E>(oldg[0], o); unpack8<E>(oldg[1], o + 8);
+      const typename E::x8 bx0 = as_x8<E>(qx[d][0]), bx1 = as_x8<E>(qx[d][1]);
+      const u32x4 oldg[2] = {qg[BWD ? d : 0][0], qg[BWD ? d : 0][1]};
+      const int off = cc.it * 16 + li;
+      const bool valid = off < cc.len;
+      const int tok = cc.s0 + min(off, cc.len - 1);
+      const bool seg_end = cc.it + 1 == cc.steps;
+      issue(qx[d], qg[BWD ? d : 0]);
+      f32x4 z[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] += f[i];
-        stg16(dst + ((size_t)tok * dsn + 16 * g) * 2, pack8<E>(o));
-        stg16(dst + ((size_t)tok * dsn + 16 * g + 8) * 2, pack8<E>(o + 8));
+      for (int mt = 0; mt < 4; ++mt) {
+        z[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        z[mt] = E::mma(ga.a[mt][0], bx0, z[mt]);
+        z[mt] = E::mma(ga.a[mt][1], bx1, z[mt]);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[mt][r] += gb[mt][r]; s += z[mt][r]; }
+      const float mean = quad_sum(s) * (1.f / 64);
+      float v = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z[mt][r] -= mean; v += z[mt][r] * z[mt][r]; }
+      const float rstd = rsqrtf(quad_sum(v) * (1.f / 64) + 1e-5f);
+      if constexpr (!BWD) {
+        const float w = valid ? rstd : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accz[mt][r] += w * z[mt][r];
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[mt][r] *= rstd;                   // z = xhat from here on
+        float s2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s2 += a_[mt][r] * z[mt][r];
+        s2 = quad_sum(s2) * (1.f / 64);
+        // the token's LayerNorm statistics for the dG pass (which would otherwise redo them with 16-lane reductions)
+        if (g == 0 && valid) p.stats[((size_t)(bh * 2 + side) * p.N + tok)] = f32x4{mean, rstd, s2, 0.f};
+        const float w = valid ? rstd : 0.f;
+        float dz[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dz[mt][r] = w * (a_[mt][r] - s1 - z[mt][r] * s2);
+          }
+        // dx^T[in][token] = G^T dz^T: the D values of out-tiles (2 kk, 2 kk + 1) are the k-slots of step kk
+        f32x4 dx[4];
+        const typename E::x8 bz0 = as_x8<E>(u32x4{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[0][2], dz[0][3]),
+                                                 pack2<E>(dz[1][0], dz[1][1]), pack2<E>(dz[1][2], dz[1][3])});
+        const typename E::x8 bz1 = as_x8<E>(u32x4{pack2<E>(dz[2][0], dz[2][1]), pack2<E>(dz[2][2], dz[2][3]),
+                                                 pack2<E>(dz[3][0], dz[3][1]), pack2<E>(dz[3][2], dz[3][3])});
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          dx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dx[mi] = E::mma(gt[mi][0], bz0, dx[mi]);
+          dx[mi] = E::mma(gt[mi][1], bz1, dx[mi]);
+        }
+        // accumulate into the gradient rows.  The four lanes of a token trade their 4-channel pieces (quad_transpose) so that
+        // a lane owns 16 contiguous channels: two 16-byte accesses, the row's 128-byte line complete per instruction pair
+        // (8-byte pieces of four different lines per instruction ran this pass at 2 TB/s)
+        float f[16];
+        quad_transpose_f32(dx, f);
+        if (valid) {
+          float o[16];
+          unpack8<E>(oldg[0], o); unpack8<E>(oldg[1], o + 8);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[i] += f[i];
+          stg16(dst + ((size_t)tok * dsn + 16 * g) * 2, pack8<E>(o));
+          stg16(dst + ((size_t)tok * dsn + 16 * g + 8) * 2, pack8<E>(o + 8));
+        }
+      }
+      if (seg_end) {                   // ---- the segment ends ----
+        if constexpr (!BWD) {
+          float* out = (side ? p.kbar : p.qbar) + ((size_t)bh * p.L + cc.l) * 64;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wlw + 16 * mt + 4 * g);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(wlb + 16 * mt + 4 * g);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = w[r] * (group_sum<16>(accz[mt][r]) * inv_len) + bb[r];
+            if (li == 0) *reinterpret_cast<f32x4*>(out + 16 * mt + 4 * g) = o;
+          }
+        }
+        if (cc.l + 1 < l1) cc.set(p, cc.l + 1);
+        else done = true;
+      } else {
+        ++cc.it;
       }
     }
   }
-  if constexpr (!BWD) {
-    float* out = (side ? p.kbar : p.qbar) + ((size_t)bh * p.L + l) * 64;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = group_sum<16>(accy[mt][r]) * inv_len;
-      if (li == 0) *reinterpret_cast<f32x4*>(out + 16 * mt + 4 * g) = o;
-    }
-  }
-  }  // segments of the group
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // token-row pass: dG partials.  z[token = 4 g + r][out = 16 nt + li]
 template <typename E>
-__global__ __launch_bounds__(256) void seglin_dg_kernel(const SegLinP p) {
+__global__ __launch_bounds__(256, 2) void seglin_dg_kernel(const SegLinP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-  // a unit = (b, h, group of segments, side, half of the out-tiles): two waves share a (group, side) -- 32 accumulator
-  // registers each instead of 64, which pays for the prefetch of the next step's rows
+  // a unit = (b, h, group of segments, side, half of the out-tiles): two waves share a (group, side).  Round 6: a wave
+  // evaluates ONLY its two out-tiles (z, dz, the channel sums of d ln_w / d ln_b / d g_b and the generator operand of those
+  // tiles: half the registers and half the z products of the version whose waves both evaluated all four) -- 292 registers
+  // had meant one wave per SIMD and the 2048 waves of cfg5 in two rounds.
   const int unit = blockIdx.x * 4 + wave;
   if (unit >= p.B * p.H * p.groups * 4) return;
   const int half = unit & 1, side = (unit >> 1) & 1, rest = unit >> 2;
@@ -259,9 +301,18 @@ __global__ __launch_bounds__(256) void seglin_dg_kernel(const SegLinP p) {
   const char* src = side ? p.k + (b * p.k_sb + h * p.k_sh) * 2 : p.q + (b * p.q_sb + h * p.q_sh) * 2;
   const int sn = (int)(side ? p.k_sn : p.q_sn);
   const float* G = side ? p.Gk : p.Gq;
-  // B operand of z = X G^T: lane (g, li): G[16 nt + li][32 ks + 8 g ..] -- the same registers as GenA
-  GenA<E> gbop;
-  gbop.load(G, g, li);
+  const int ch0 = 32 * half;                             // first out-channel of this wave
+  // B operand of z = X G^T for out-tile j of this wave: lane (g, li): G[ch0 + 16 j + li][32 ks + 8 g ..]
+  typename E::x8 gbop[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* s_ = G + (ch0 + 16 * j + li) * 64 + 32 * ks + 8 * g;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(s_), hi = *reinterpret_cast<const f32x4*>(s_ + 4);
+      const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      gbop[j][ks] = as_x8<E>(pack8<E>(f));
+    }
   // 0 / 1 pattern that brings X into the D layout: XD[token][in = 16 it + li] = sum_ch X[token][ch] I[ch][16 it + li];
   // only k-step ks = it >> 1 has a non-zero: slot j of lane (g, li) is channel 32 ks + 8 g + j
   typename E::x8 iop[4];
@@ -276,114 +327,147 @@ __global__ __launch_bounds__(256) void seglin_dg_kernel(const SegLinP p) {
       iop[it] = as_x8<E>(w);
     }
   }
-  float gb[4], lw[4];
+  float gb[2], lw[2];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    gb[nt] = (side ? p.gkb : p.gqb)[16 * nt + li];
-    lw[nt] = (side ? p.lnk_w : p.lnq_w)[16 * nt + li];
+  for (int j = 0; j < 2; ++j) {
+    gb[j] = (side ? p.gkb : p.gqb)[ch0 + 16 * j + li];
+    lw[j] = (side ? p.lnk_w : p.lnq_w)[ch0 + 16 * j + li];
   }
   __shared__ f32x4 stat_lds[4][32];
+  __shared__ float row_lds[4][2][64];
   f32x4* stw = stat_lds[wave];
+  float* const wdb = row_lds[wave][0];                   // the segment's incoming gradient row (lane = channel -> D layout)
+  float* const wlw = row_lds[wave][1];                   // LayerNorm weight, all 64 channels: the row's mean of dy lw
+  wlw[lane] = (side ? p.lnk_w : p.lnq_w)[lane];
   f32x4 dg[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int it = 0; it < 4; ++it) dg[nt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // partial sums of d ln_w, d ln_b, d g_b over the group's tokens: lane (g, li) owns channel 16 nt + li of rows 4 g + r
-  float p_dw[4] = {0.f, 0.f, 0.f, 0.f}, p_db[4] = {0.f, 0.f, 0.f, 0.f}, p_dgb[4] = {0.f, 0.f, 0.f, 0.f};
+  // partial sums of d ln_w, d ln_b, d g_b over the group's tokens: lane (g, li) owns channel ch0 + 16 j + li of rows 4 g + r
+  float p_dw[2] = {0.f, 0.f}, p_db[2] = {0.f, 0.f}, p_dgb[2] = {0.f, 0.f};
   const int l0 = grp * p.seg_per_group, l1 = min(p.L, l0 + p.seg_per_group);
-  for (int l = l0; l < l1; ++l) {
-    const int s0 = seg_start(p, l), len = seg_len(p, l);
-    const float inv_len = 1.f / (float)len;
-    const float* dbar = (side ? p.d_kbar : p.d_qbar) + ((size_t)bh * p.L + l) * 64;
-    float a_[4], dyv[4], s = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { dyv[nt] = dbar[16 * nt + li] * inv_len; a_[nt] = dyv[nt] * lw[nt]; s += a_[nt]; p_db[nt] += dyv[nt] * (float)len; }
-    const float s1 = group_sum<16>(s) * (1.f / 64);
-    const int steps = (len + 31) >> 5;
-    u32x4 nx[2][2];
-    f32x4 nst;                                      // statistics of token (step base + (lane & 31)): one coalesced load per step
-    const f32x4* stb = p.stats + (size_t)(bh * 2 + side) * p.N + s0;
-    auto issue = [&](int i2) {
+  if (l0 < l1) {
+    // one stream of 32-token steps over the group's segments, the rows and statistics of the next DEPTH steps in flight across
+    // the segment boundaries (SegCur, above); the NEXT segment's incoming gradient row is requested a segment ahead (lane =
+    // channel) and reaches the D layout through the wave's LDS slot
+    constexpr int DEPTH = 2;
+    const float* dbar_bh = (side ? p.d_kbar : p.d_qbar) + (size_t)bh * p.L * 64;
+    const f32x4* stb = p.stats + (size_t)(bh * 2 + side) * p.N;
+    float ndb = dbar_bh[(size_t)l0 * 64 + lane];
+    u32x4 qx[DEPTH][2][2];
+    f32x4 qs[DEPTH];                                  // statistics of token (step base + (lane & 31)): one coalesced load per step
+    SegCur<32> pc, cc;
+    pc.set(p, l0);
+    cc.set(p, l0);
+    auto issue = [&](u32x4 (&x)[2][2], f32x4& st) {
 #pragma unroll
       for (int tl = 0; tl < 2; ++tl) {
-        const int tok = s0 + min(i2 * 32 + tl * 16 + li, len - 1);    // A-operand row li of tile tl
-        nx[tl][0] = ldg16(src + (tok * sn + 8 * g) * 2);
-        nx[tl][1] = ldg16(src + (tok * sn + 32 + 8 * g) * 2);
+        const int tok = pc.tok(tl * 16 + li);                          // A-operand row li of tile tl
+        x[tl][0] = ldg16(src + (tok * sn + 8 * g) * 2);
+        x[tl][1] = ldg16(src + (tok * sn + 32 + 8 * g) * 2);
       }
-      nst = stb[min(i2 * 32 + (lane & 31), len - 1)];
+      st = stb[pc.tok(lane & 31)];
+      pc.advance(p, l1);
     };
-    issue(0);
-    for (int it2 = 0; it2 < steps; ++it2) {
-      u32x4 pz[2], px[2][2];                                          // packed pieces of the two 16-token tiles
-      const u32x4 cur[2][2] = {{nx[0][0], nx[0][1]}, {nx[1][0], nx[1][1]}};
-      // the step's 32 statistics go through this wave's LDS slot: a lane needs those of its four rows 4 g + r of either tile
-      // (fetching them from global memory where they are needed was a dependent round trip per tile: 110 -> 161 us)
-      if (lane < 32) stw[lane] = nst;
-      if (it2 + 1 < steps) issue(it2 + 1);
 #pragma unroll
-      for (int tl = 0; tl < 2; ++tl) {
-        const int base = it2 * 32 + tl * 16;
-        const typename E::x8 ax0 = as_x8<E>(cur[tl][0]);
-        const typename E::x8 ax1 = as_x8<E>(cur[tl][1]);
-        f32x4 z[4], xd[4];
+    for (int d = 0; d < DEPTH; ++d) issue(qx[d], qs[d]);
+    float a_[2] = {0.f, 0.f}, dyv[2] = {0.f, 0.f}, s1 = 0.f;
+    bool done = false;
+    while (!done) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          z[nt] = E::mma(ax0, gbop.a[nt][0], z[nt]);
-          z[nt] = E::mma(ax1, gbop.a[nt][1], z[nt]);
-          xd[nt] = E::mma((nt >> 1) ? ax1 : ax0, iop[nt], f32x4{0.f, 0.f, 0.f, 0.f});
-        }
-        // rows r = tokens base + 4 g + r; their LayerNorm statistics (mean, rstd, mean(a xhat)) come from the dq / dk pass
-        float dzr[4][4];
+      for (int d = 0; d < DEPTH; ++d) {
+        if (done) break;
+        if (cc.it == 0) {              // ---- a segment begins ----
+          const float inv_len = 1.f / (float)cc.len;
+          wdb[lane] = ndb;
+          ndb = dbar_bh[(size_t)min(cc.l + 1, l1 - 1) * 64 + lane];
+          float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 st = stw[tl * 16 + 4 * g + r];
-          const bool live = base + 4 * g + r < len;
-          const float w = live ? st[1] : 0.f;
+          for (int nt = 0; nt < 4; ++nt) s += wdb[16 * nt + li] * inv_len * wlw[16 * nt + li];
+          s1 = group_sum<16>(s) * (1.f / 64);
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const float xh = (z[nt][r] + gb[nt] - st[0]) * st[1];
-            dzr[nt][r] = w * (a_[nt] - s1 - xh * st[2]);
-            if (live) p_dw[nt] += dyv[nt] * xh;
-            p_dgb[nt] += dzr[nt][r];
+          for (int j = 0; j < 2; ++j) {
+            dyv[j] = wdb[ch0 + 16 * j + li] * inv_len;
+            a_[j] = dyv[j] * lw[j];
+            p_db[j] += dyv[j] * (float)cc.len;
           }
         }
-        // this tile's four tokens of the lane = four k-slots: out-tile nt of dz, in-tile nt of X
-        // (this wave's half of the out-tiles: 2 half, 2 half + 1)
-        if (half == 0)
+        u32x4 pz[2], px[2][2];                                          // packed pieces of the two 16-token tiles
+        const u32x4 cur[2][2] = {{qx[d][0][0], qx[d][0][1]}, {qx[d][1][0], qx[d][1][1]}};
+        // the step's 32 statistics go through this wave's LDS slot: a lane needs those of its four rows 4 g + r of either tile
+        // (fetching them from global memory where they are needed was a dependent round trip per tile: 110 -> 161 us)
+        if (lane < 32) stw[lane] = qs[d];
+        const int sbase = cc.it * 32, slen = cc.len;
+        const bool seg_end = cc.it + 1 == cc.steps;
+        issue(qx[d], qs[d]);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const int base = sbase + tl * 16;
+          const typename E::x8 ax0 = as_x8<E>(cur[tl][0]);
+          const typename E::x8 ax1 = as_x8<E>(cur[tl][1]);
+          f32x4 z[2], xd[4];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            z[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            z[j] = E::mma(ax0, gbop[j][0], z[j]);
+            z[j] = E::mma(ax1, gbop[j][1], z[j]);
+          }
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) xd[nt] = E::mma((nt >> 1) ? ax1 : ax0, iop[nt], f32x4{0.f, 0.f, 0.f, 0.f});
+          // rows r = tokens base + 4 g + r; their LayerNorm statistics (mean, rstd, mean(a xhat)) come from the dq / dk pass
+          float dzr[2][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 st = stw[tl * 16 + 4 * g + r];
+            const bool live = base + 4 * g + r < slen;
+            const float w = live ? st[1] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const float xh = (z[j][r] + gb[j] - st[0]) * st[1];
+              dzr[j][r] = w * (a_[j] - s1 - xh * st[2]);
+              if (live) p_dw[j] += dyv[j] * xh;
+              p_dgb[j] += dzr[j][r];
+            }
+          }
+          // this tile's four tokens of the lane = four k-slots: out-tile j of dz, in-tile nt of X
           pz[tl] = u32x4{pack2<E>(dzr[0][0], dzr[0][1]), pack2<E>(dzr[0][2], dzr[0][3]), pack2<E>(dzr[1][0], dzr[1][1]), pack2<E>(dzr[1][2], dzr[1][3])};
-        else
-          pz[tl] = u32x4{pack2<E>(dzr[2][0], dzr[2][1]), pack2<E>(dzr[2][2], dzr[2][3]), pack2<E>(dzr[3][0], dzr[3][1]), pack2<E>(dzr[3][2], dzr[3][3])};
-        px[tl][0] = u32x4{pack2<E>(xd[0][0], xd[0][1]), pack2<E>(xd[0][2], xd[0][3]), pack2<E>(xd[1][0], xd[1][1]), pack2<E>(xd[1][2], xd[1][3])};
-        px[tl][1] = u32x4{pack2<E>(xd[2][0], xd[2][1]), pack2<E>(xd[2][2], xd[2][3]), pack2<E>(xd[3][0], xd[3][1]), pack2<E>(xd[3][2], xd[3][3])};
-      }
-      // dG[out 16 nt + ..][in 16 it + ..] += sum over the 32 tokens: k-slots (tile 0 rows 4 g + r, tile 1 rows 4 g + r)
+          px[tl][0] = u32x4{pack2<E>(xd[0][0], xd[0][1]), pack2<E>(xd[0][2], xd[0][3]), pack2<E>(xd[1][0], xd[1][1]), pack2<E>(xd[1][2], xd[1][3])};
+          px[tl][1] = u32x4{pack2<E>(xd[2][0], xd[2][1]), pack2<E>(xd[2][2], xd[2][3]), pack2<E>(xd[3][0], xd[3][1]), pack2<E>(xd[3][2], xd[3][3])};
+        }
+        // dG[out ch0 + 16 nt + ..][in 16 it + ..] += sum over the 32 tokens: k-slots (tile 0 rows 4 g + r, tile 1 rows 4 g + r)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int qn = nt * 2;
-        const typename E::x8 aop = as_x8<E>(u32x4{pz[0][qn], pz[0][qn + 1], pz[1][qn], pz[1][qn + 1]});
+        for (int nt = 0; nt < 2; ++nt) {
+          const int qn = nt * 2;
+          const typename E::x8 aop = as_x8<E>(u32x4{pz[0][qn], pz[0][qn + 1], pz[1][qn], pz[1][qn + 1]});
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int hi_ = it >> 1, qi = (it & 1) * 2;
-          const typename E::x8 bop = as_x8<E>(u32x4{px[0][hi_][qi], px[0][hi_][qi + 1], px[1][hi_][qi], px[1][hi_][qi + 1]});
-          dg[nt][it] = E::mma(aop, bop, dg[nt][it]);
+          for (int it = 0; it < 4; ++it) {
+            const int hi_ = it >> 1, qi = (it & 1) * 2;
+            const typename E::x8 bop = as_x8<E>(u32x4{px[0][hi_][qi], px[0][hi_][qi + 1], px[1][hi_][qi], px[1][hi_][qi + 1]});
+            dg[nt][it] = E::mma(aop, bop, dg[nt][it]);
+          }
+        }
+        if (seg_end) {
+          if (cc.l + 1 < l1) cc.set(p, cc.l + 1);
+          else done = true;
+        } else {
+          ++cc.it;
         }
       }
     }
   }
-  if (half == 0) {
+  {
     // [group][side][4][64]: (d ln_w, d ln_b, d g_b, 0); the four lane rows g hold different tokens of the same channel
     float* pr = p.part + (((size_t)bh * p.groups + grp) * 2 + side) * 4 * 64;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const float v0 = quad_sum(p_dw[nt]), v2 = quad_sum(p_dgb[nt]);
+    for (int j = 0; j < 2; ++j) {
+      const float v0 = quad_sum(p_dw[j]), v2 = quad_sum(p_dgb[j]);
       if (g == 0) {
-        pr[16 * nt + li] = v0;
-        pr[64 + 16 * nt + li] = p_db[nt];
-        pr[128 + 16 * nt + li] = v2;
-        pr[192 + 16 * nt + li] = 0.f;
+        pr[ch0 + 16 * j + li] = v0;
+        pr[64 + ch0 + 16 * j + li] = p_db[j];
+        pr[128 + ch0 + 16 * j + li] = v2;
+        pr[192 + ch0 + 16 * j + li] = 0.f;
       }
     }
   }
