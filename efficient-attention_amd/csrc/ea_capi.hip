@@ -78,7 +78,7 @@ static Geo mk_geo(const ea_geom* g) {
 extern "C" {
 
 const char* ea_version(void) { return "ea_hip 0.1.0 gfx950"; }
-int32_t ea_abi_version(void) { return 14; }
+int32_t ea_abi_version(void) { return 15; }
 
 int32_t ea_window_bias_ld(const ea_geom* g) {
   WinTiling t;
@@ -958,6 +958,9 @@ struct SegLinP {
   void* stats;
   float* dG_part;
   int B, H, N, L, segs, nshort, groups, seg_per_group, cgroups, cseg_per_group;
+  const float *fin_qbar, *fin_uq, *fin_lse;
+  int C;
+  float fin_scale, fin_scale_log2;
 };
 int seglin_groups(int BH, int L);
 int seglin_dispatch(int which, const SegLinP& p, int dtype, hipStream_t st);
@@ -994,22 +997,46 @@ int ea_lara_seglin_fwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const f
   return ea::seglin_dispatch(0, p, g->dtype, (hipStream_t)stream);
 }
 
-int ea_lara_seglin_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
-                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
-                       const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
-                       float* stats, void* stream) {
+static int seglin_bwd_impl(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                           const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                           const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
+                           float* stats, const float* fin_qbar, const float* fin_uq, const float* fin_lse, int32_t C, float scale,
+                           bool fin, void* stream) {
   ea::SegLinP p = {};
   int rc = fill_seglin(g, p);
   if (rc != EA_OK) return rc;
   if (!t4_ok32(q, 64, g->N) || !t4_ok32(k, 64, g->N) || !t4_ok32(dq, 64, g->N) || !t4_ok32(dk, 64, g->N) || !Gq || !gq_b || !Gk ||
       !gk_b || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !d_qbar || !d_kbar || !part || !dG_part || !stats || ((uintptr_t)stats & 15))
     return EA_E_BADARG;
+  if (fin) {
+    if (!fin_qbar || !fin_uq || !fin_lse || C < 1 || !(scale > 0.f)) return EA_E_BADARG;
+    if (C > 64) return EA_E_UNSUPPORTED;
+    p.fin_qbar = fin_qbar; p.fin_uq = fin_uq; p.fin_lse = fin_lse; p.C = C;
+    p.fin_scale = scale; p.fin_scale_log2 = scale * 1.4426950408889634f;
+  }
   SET3(q, q); SET3(k, k); SET3(dq, dq); SET3(dk, dk);
   p.Gq = Gq; p.gqb = gq_b; p.Gk = Gk; p.gkb = gk_b; p.lnq_w = lnq_w; p.lnq_b = lnq_b; p.lnk_w = lnk_w; p.lnk_b = lnk_b;
   p.d_qbar = d_qbar; p.d_kbar = d_kbar; p.part = part; p.dG_part = dG_part; p.stats = stats;
-  rc = ea::seglin_dispatch(1, p, g->dtype, (hipStream_t)stream);
+  rc = ea::seglin_dispatch(fin ? 3 : 1, p, g->dtype, (hipStream_t)stream);
   if (rc != EA_OK) return rc;
   return ea::seglin_dispatch(2, p, g->dtype, (hipStream_t)stream);
+}
+
+int ea_lara_seglin_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                       const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                       const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
+                       float* stats, void* stream) {
+  return seglin_bwd_impl(g, q, k, Gq, gq_b, Gk, gk_b, lnq_w, lnq_b, lnk_w, lnk_b, d_qbar, d_kbar, dq, dk, part, dG_part, stats,
+                         nullptr, nullptr, nullptr, 0, 0.f, false, stream);
+}
+
+int ea_lara_seglin_bwd_fin(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                           const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                           const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part,
+                           float* dG_part, float* stats, const float* fin_qbar, const float* fin_uq, const float* fin_lse_t,
+                           int32_t C, float scale, void* stream) {
+  return seglin_bwd_impl(g, q, k, Gq, gq_b, Gk, gk_b, lnq_w, lnq_b, lnk_w, lnk_b, d_qbar, d_kbar, dq, dk, part, dG_part, stats,
+                         fin_qbar, fin_uq, fin_lse_t, C, scale, true, stream);
 }
 
 }  // extern "C"

@@ -34,6 +34,10 @@ struct SegLinP {
   f32x4* stats;                      // backward scratch [B*H, 2, N]: (mean, rstd, mean(a xhat), -) of every token's LayerNorm
   float* dG_part;                    // backward: [nG, 2, 64, 64] partial sums of dG (nG = B*H*groups)
   int B, H, N, L, segs, nshort, groups, seg_per_group, cgroups, cseg_per_group;
+  // the estimator's last dq correction riding on the dq / dk pass (ea_lara_seglin_bwd_fin, round 6): dq_n -= s sum_c t[c,n] (u qbar)_c
+  const float *fin_qbar, *fin_uq, *fin_lse;   // [B*H, C, 64], [B*H, C, 64], [B*H, C]; null: none
+  int C;
+  float fin_scale, fin_scale_log2;
 };
 
 namespace {
@@ -77,8 +81,14 @@ template <int TS> struct SegCur {
 
 // ------------------------------------------------------------------------------------------------------------
 // token-column passes: forward (BWD = false) and the dq / dk pass (BWD = true)
-template <typename E, bool BWD>
+// NCT > 0 (backward only): the q-side waves also apply the correction ea_lara_bwd_finish applies (lara.py:223 differentiated:
+// t = softmax over the sequence of s qbar_c . q_n) to the rows they rewrite anyway -- the q rows are in their registers as the B
+// operand of the generator product, t = 2^(s qbar_c . q_n - lse_t) takes NCT x 2 MFMAs against the (b,h)'s qbar rows (wave-
+// private LDS image) and the correction rows (u qbar)^T t another NCT x 2, in the D layout of dx itself.  One read-modify-write
+// of dq less per step: lara_fin_kernel was 57 us / 201 MB of the 1.1 ms cfg5 step.
+template <typename E, bool BWD, int NCT>
 __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegLinP p) {
+  static_assert(NCT == 0 || BWD, "the fused finish belongs to the backward pass");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   // a wave = (b, h, side, group of consecutive segments): the generator operands (64 + 64 registers' worth of loads, the
   // transposed one a 64-way gather) are fetched once per wave, not once per 84-token segment
@@ -99,6 +109,46 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
   float* const wdb = wl[wave][2];
   wlw[lane] = (side ? p.lnk_w : p.lnq_w)[lane];
   wlb[lane] = (side ? p.lnk_b : p.lnq_b)[lane];
+  // fused finish: the (b,h)'s (u qbar) and qbar rows as element-type images in this wave's LDS region, lse_t in log2 units
+  constexpr int Cp = NCT * 16, FINB = 2 * Cp * 128 + Cp * 4;
+  char *R1 = nullptr, *R2 = nullptr;
+  float* SC1 = nullptr;
+  LaneOff2<64> lo;
+  bool fin = false;
+  if constexpr (NCT > 0) {
+    fin = side == 0;
+    if (fin) {
+      extern __shared__ __attribute__((aligned(16))) char smem[];
+      R1 = smem + wave * FINB;
+      R2 = R1 + Cp * 128;
+      SC1 = reinterpret_cast<float*>(R2 + Cp * 128);
+      lo.init(lane);
+      const size_t lm = (size_t)bh * p.C;
+      constexpr int SL = Cp * 8 / 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* srcm = (j ? p.fin_qbar : p.fin_uq) + lm * 64;
+        char* dstm = j ? R2 : R1;
+        f32x4 rb[SL][2];
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          const int idx = lane + sl * 64, row = idx >> 3, c = idx & 7;
+          rb[sl][0] = rb[sl][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < p.C) {
+            rb[sl][0] = *reinterpret_cast<const f32x4*>(srcm + (size_t)row * 64 + c * 8);
+            rb[sl][1] = *reinterpret_cast<const f32x4*>(srcm + (size_t)row * 64 + c * 8 + 4);
+          }
+        }
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          const int idx = lane + sl * 64, row = idx >> 3, c = idx & 7;
+          const float f[8] = {rb[sl][0][0], rb[sl][0][1], rb[sl][0][2], rb[sl][0][3], rb[sl][1][0], rb[sl][1][1], rb[sl][1][2], rb[sl][1][3]};
+          sts16(dstm + lds_off2<64>(row, c), pack8<E>(f));
+        }
+      }
+      if (lane < Cp) SC1[lane] = lane < p.C ? p.fin_lse[lm + lane] * LOG2E : INFINITY;     // (rows beyond C: t = 0)
+    }
+  }
   GenA<E> ga;
   ga.load(G, g, li);
   // per-lane channel constants: channel 16 mt + 4 g + r
@@ -248,6 +298,40 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
           dx[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
           dx[mi] = E::mma(gt[mi][0], bz0, dx[mi]);
           dx[mi] = E::mma(gt[mi][1], bz1, dx[mi]);
+        }
+        if constexpr (NCT > 0) {
+          if (fin) {                     // (uniform) dq_n -= s sum_c t[c, n] (u qbar)_c
+            f32x4 acc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NCT / 2; ++kk) {          // two landmark tiles = the 32 k-slots of one product
+              u32x4 p1;
+#pragma unroll
+              for (int c2 = 0; c2 < 2; ++c2) {
+                const int ct = 2 * kk + c2;
+                f32x4 tt = {0.f, 0.f, 0.f, 0.f};
+                const int row = ct * 16 + li;
+                tt = E::mma(as_x8<E>(lds16(R2 + lds_off2<64>(row, g))), bx0, tt);          // channels 8 g ..: chunk g
+                tt = E::mma(as_x8<E>(lds16(R2 + lds_off2<64>(row, 4 + g))), bx1, tt);      // channels 32 + 8 g ..: chunk 4 + g
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(SC1 + ct * 16 + 4 * g);
+                float w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = fast_exp2(tt[r] * p.fin_scale_log2 - ls[r]);
+                p1[2 * c2] = pack2<E>(w[0], w[1]);
+                p1[2 * c2 + 1] = pack2<E>(w[2], w[3]);
+              }
+#pragma unroll
+              for (int dt = 0; dt < 4; ++dt) {
+                const char* r1 = R1 + (32 * kk) * 128 + lo.tr[dt];
+                acc[dt] = E::mma(as_x8<E>(E::tr4(r1), E::tr4(r1 + 16 * 128)), as_x8<E>(p1), acc[dt]);
+              }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dx[mi][r] -= acc[mi][r] * p.fin_scale;
+          }
         }
         // accumulate into the gradient rows.  The four lanes of a token trade their 4-channel pieces (quad_transpose) so that
         // a lane owns 16 contiguous channels: two 16-byte accesses, the row's 128-byte line complete per instruction pair
@@ -494,7 +578,7 @@ int seglin_dispatch(int which, const SegLinP& p0, int dtype, hipStream_t st) {
   {
     // forward / dq-dk passes: ONE resident round of waves (12 per CU at 166 registers, 8 at 222) -- 3328 waves on 3072 / 2048
     // slots ran as two rounds, the second nearly empty -- every wave at least one segment
-    const long cap = (long)ea_device_cus() * (which == 0 ? 12 : 8);
+    const long cap = (long)ea_device_cus() * (which == 0 ? 12 : 8);      // (which: 0 forward, 1 dq / dk pass, 3 the same with the fused finish, 2 dG)
     int per = (int)(((long)p.B * p.H * 2 * p.L + cap - 1) / cap);
     if (per < 1) per = 1;
     p.cgroups = (p.L + per - 1) / per;
@@ -506,14 +590,28 @@ int seglin_dispatch(int which, const SegLinP& p0, int dtype, hipStream_t st) {
   const dim3 ggrid((unsigned)((gunits + 3) / 4));
 #define EA_SL(E_)                                                                                                  \
   do {                                                                                                             \
-    if (which == 0) hipLaunchKernelGGL((seglin_col_kernel<E_, false>), grid, block, 0, st, p);                    \
-    else if (which == 1) hipLaunchKernelGGL((seglin_col_kernel<E_, true>), grid, block, 0, st, p);                \
+    if (which == 0) hipLaunchKernelGGL((seglin_col_kernel<E_, false, 0>), grid, block, 0, st, p);                 \
+    else if (which == 1) hipLaunchKernelGGL((seglin_col_kernel<E_, true, 0>), grid, block, 0, st, p);             \
+    else if (which == 3 && p.C <= 32) EA_SLF(E_, 2);                                                               \
+    else if (which == 3) EA_SLF(E_, 4);                                                                            \
     else hipLaunchKernelGGL((seglin_dg_kernel<E_>), ggrid, block, 0, st, p);                                      \
   } while (0)
+#define EA_SLF(E_, NCT_)                                                                                           \
+  do {                                                                                                             \
+    constexpr int lds_ = 4 * (2 * NCT_ * 16 * 128 + NCT_ * 16 * 4);                                                \
+    if (lds_ > 48 * 1024) {                                                                                        \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&seglin_col_kernel<E_, true, NCT_>),       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                      \
+      if (e_ != hipSuccess) return (int)e_;                                                                        \
+    }                                                                                                              \
+    hipLaunchKernelGGL((seglin_col_kernel<E_, true, NCT_>), grid, block, lds_, st, p);                             \
+  } while (0)
+  if (which == 3 && (p.C < 1 || p.C > 64 || !p.fin_qbar || !p.fin_uq || !p.fin_lse)) return EA_E_BADARG;
   if (dtype == EA_BF16) EA_SL(BF16);
   else if (dtype == EA_F16) EA_SL(F16);
   else return EA_E_UNSUPPORTED;
 #undef EA_SL
+#undef EA_SLF
   return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ class ea_t4(ctypes.Structure):
                 ("sn", ctypes.c_int64)]
 
 
-ABI_VERSION = 14         # ea_abi_version() of include/ea_hip.h this file mirrors
+ABI_VERSION = 15         # ea_abi_version() of include/ea_hip.h this file mirrors
 
 
 class ea_geom(ctypes.Structure):
@@ -190,6 +190,7 @@ SIGNATURES = {
     "ea_lara_seglin_groups": [_G],
     "ea_lara_seglin_fwd": [_G, _T, _T] + [_P] * 11,
     "ea_lara_seglin_bwd": [_G, _T, _T] + [_P] * 10 + [_T, _T, _P, _P, _P, _P],
+    "ea_lara_seglin_bwd_fin": [_G, _T, _T] + [_P] * 10 + [_T, _T, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_float, _P],
     "ea_lara_fold_fwd": [_I, _I, _I] + [_P] * 11,
     "ea_lara_fold_parts": [_I],
     "ea_lara_fold_bwd": [_I, _I, _P, _P, _P, _P, _P, _L] + [_P] * 10,

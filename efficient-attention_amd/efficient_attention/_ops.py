@@ -948,6 +948,10 @@ class _GradSlot:
 
     def __init__(self):
         self.buf = None
+        # LARA 'adaptive-1d' (round 6): the core's backward leaves its last dq correction (ea_lara_bwd_finish's operands) here
+        # instead of running it when `defer_fin` is set; the segment backward, which rewrites the dq rows anyway, applies it
+        self.defer_fin = False
+        self.fin = None
 
 
 class PoolMeanFn(torch.autograd.Function):
@@ -1034,6 +1038,8 @@ class SegmentLnMeanFn(torch.autograd.Function):
 
 
 USE_SEGLIN = os.environ.get("EA_SEGLIN", "1") == "1"
+# dev switch: the estimator's last dq correction applied by the segment backward (ea_lara_seglin_bwd_fin) instead of a pass of its own
+USE_SEGLIN_FIN = os.environ.get("EA_SEGLIN_FIN", "1") == "1"
 
 
 class SegLinLnMeanFn(torch.autograd.Function):
@@ -1075,11 +1081,19 @@ class SegLinLnMeanFn(torch.autograd.Function):
         part = torch.empty((B * h * groups, 2 * 4 * d), dtype=torch.float32, device=dev)
         dG_part = torch.empty((B * h * groups, 2 * d * d), dtype=torch.float32, device=dev)
         stats = torch.empty((B * h * 2 * N, 4), dtype=torch.float32, device=dev)
-        nv.call("ea_lara_seglin_bwd", ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), *[nv.ptr(t) for t in ps],
-                nv.ptr(dqb.float().contiguous()), nv.ptr(dkb.float().contiguous()), ctypes.byref(ts[2]), ctypes.byref(ts[3]),
-                nv.ptr(part), nv.ptr(dG_part), nv.ptr(stats), nv.stream())
+        fin = None if (own or slot is None) else slot.fin
+        common = [ctypes.byref(geom), ctypes.byref(ts[0]), ctypes.byref(ts[1]), *[nv.ptr(t) for t in ps],
+                  nv.ptr(dqb.float().contiguous()), nv.ptr(dkb.float().contiguous()), ctypes.byref(ts[2]), ctypes.byref(ts[3]),
+                  nv.ptr(part), nv.ptr(dG_part), nv.ptr(stats)]
+        if fin is not None:
+            f_qbar, f_uq, f_lse, f_C, f_scale = fin
+            nv.call("ea_lara_seglin_bwd_fin", *common, nv.ptr(f_qbar), nv.ptr(f_uq), nv.ptr(f_lse), int(f_C), float(f_scale),
+                    nv.stream())
+        else:
+            nv.call("ea_lara_seglin_bwd", *common, nv.stream())
         if slot is not None:
             slot.buf = None
+            slot.fin = None
         # tall, narrow partial matrices: the column-sum kernel (64 row lanes per 16 columns), not the slice reduction
         sums, dGs = colsum2_f32(part, dG_part)                        # (same number of rows: one launch)
         sums, dGs = sums.view(2, 4, d), dGs.view(2, d, d)
@@ -1393,7 +1407,11 @@ class LaraAttnFn(torch.autograd.Function):
         dqkv5 = torch.empty_like(qkv5)
         d_omega, d_qbar, d_bhv, d_lp, uq = _lara_bwd_core(geom, qkv5, mask_u8, dout, dqkv5, omega, qbar, bhv,
                                                           cst, kv, lse_k, lse_t, tokst)
-        _lara_finish(geom, qkv5, dqkv5, qbar, uq, lse_t)
+        slot = ctx.slot
+        if slot is not None and slot.defer_fin and uq is not None and C <= 64 and d == 64:
+            slot.fin = (qbar, uq, lse_t, C, float(d) ** -0.5)
+        else:
+            _lara_finish(geom, qkv5, dqkv5, qbar, uq, lse_t)
         has_qbar, has_bhv = ctx.has
         if ctx.slot is not None:
             ctx.slot.buf = dqkv5          # the pooling backward accumulates into this buffer in place

@@ -319,6 +319,9 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             lq, nq, lk, nk = self.q_bar_gen[0], self.q_bar_gen[1], self.k_bar_gen[0], self.k_bar_gen[1]
             pq, pk = _ops.SegLinLnMeanFn.apply(qkv5, L, slot, lq.weight, lq.bias, lk.weight, lk.bias,
                                                nq.weight, nq.bias, nk.weight, nk.bias)
+            # the segment backward runs after the estimator's and rewrites the same dq rows: it applies the estimator's last
+            # correction too (ea_lara_seglin_bwd_fin) whenever it is going to run, i.e. the rows it reads carry a gradient
+            slot.defer_fin = bool(_ops.USE_SEGLIN_FIN and fused_b and pq.requires_grad and torch.is_grad_enabled())
         elif fold_1d:
             pq, pk, qkv5 = self._proposal_gen_1d_folded(qkv5, key_padding_mask, mask, slot)
         elif len(seq_shape) == 1:

@@ -307,6 +307,17 @@ int ea_lara_seglin_bwd(const ea_geom* g, const ea_t4* q, const ea_t4* k, const f
                        const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
                        const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part, float* dG_part,
                        float* stats, void* stream);
+/* round 6: the same backward with the estimator's LAST correction of dq riding on the dq / dk pass -- what ea_lara_bwd_finish
+ * applies in a pass of its own (lara.py:223 differentiated: t = softmax over the sequence of s qbar_c . q_n,
+ *     dq_n -= s sum_c t[c, n] (u qbar)_c ),
+ * added to the rows this pass rewrites anyway (the q rows are its MFMA operand already): one read-modify-write of dq less per
+ * step.  fin_qbar, fin_uq [B*H, C, 64], fin_lse_t [B*H, C] fp32 as ea_lara_bwd_finish takes them (qbar, uq, lse_t); C <= 64
+ * samples (EA_E_UNSUPPORTED beyond); scale = d^-1/2.  The caller must NOT run ea_lara_bwd_finish for the same step. */
+int ea_lara_seglin_bwd_fin(const ea_geom* g, const ea_t4* q, const ea_t4* k, const float* Gq, const float* gq_b, const float* Gk,
+                           const float* gk_b, const float* lnq_w, const float* lnq_b, const float* lnk_w, const float* lnk_b,
+                           const float* d_qbar, const float* d_kbar, const ea_t4* dq, const ea_t4* dk, float* part,
+                           float* dG_part, float* stats, const float* fin_qbar, const float* fin_uq, const float* fin_lse_t,
+                           int32_t C, float scale, void* stream);
 
 /* ---- LARA 'adaptive-1d' proposals: the generators' per-token Linear folded into the qkv projection (ea_fold.hip) ----
  * q_bar_gen / k_bar_gen start with Linear(d, d) on every token's q / k row (lara.py:56-63,100-103).  The module computes

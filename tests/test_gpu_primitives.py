@@ -1000,6 +1000,75 @@ def test_lara_adaptive_1d_seglin_matches_folded_path(dtype, masked):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("landmarks,masked", [(49, False), (16, False), (16, True), (33, False)])
+def test_lara_seglin_fused_finish_matches_separate_pass(dtype, landmarks, masked):
+    """ea_lara_seglin_bwd_fin (round 6): the estimator's last dq correction (lara.py:223 differentiated) applied by the segment
+    backward's dq / dk pass against the same step with ea_lara_bwd_finish as a pass of its own (EA_SEGLIN_FIN=0).  The two
+    differ only in where dq is rounded to the I/O type (once instead of twice): y identical, dx and the parameter gradients
+    within the rounding of one more 16-bit store."""
+    import warnings
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    if not (_ops.USE_SEGLIN and _ops.USE_SEGLIN_FIN):
+        pytest.skip("dev switch EA_SEGLIN / EA_SEGLIN_FIN = 0")
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(29)
+        m = ea.AttentionFactory.build_attention("lara", dict(dim=512, num_heads=8, num_landmarks=landmarks,
+                                                             proposal_gen="adaptive-1d", mis_type="mis-opt")).cuda()
+    m.train()
+    B, N = 2, 1000
+    x0 = torch.randn(B, N, 512, device="cuda")
+    g = torch.randn(B, N, 512, device="cuda").to(td)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, N, dtype=torch.bool, device="cuda")
+        mask[1, 870:] = True
+    calls = {"fin": 0, "sep": 0}
+    orig_call = _ops.nv.call
+
+    def counting(name, *a):
+        if name == "ea_lara_seglin_bwd_fin":
+            calls["fin"] += 1
+        if name == "ea_lara_bwd_finish":
+            calls["sep"] += 1
+        return orig_call(name, *a)
+    res = {}
+    _ops.nv.call = counting
+    try:
+        for fused in (True, False):
+            old = _ops.USE_SEGLIN_FIN
+            _ops.USE_SEGLIN_FIN = fused
+            try:
+                for p in m.parameters():
+                    p.grad = None
+                x = x0.clone().requires_grad_(True)
+                torch.manual_seed(5)
+                with torch.autocast("cuda", dtype=td):
+                    y = m(x, mask)
+                y.backward(g)
+                res[fused] = (y.detach().float(), x.grad, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+            finally:
+                _ops.USE_SEGLIN_FIN = old
+    finally:
+        _ops.nv.call = orig_call
+    assert calls == {"fin": 1, "sep": 1}, calls
+    assert torch.equal(res[True][0], res[False][0])
+    tol = 8e-3 if dtype == "bf16" else 1e-3
+
+    def close(a, b, what, t):
+        sc = float(b.abs().max())
+        assert float((a - b).abs().max()) <= t * sc, (what, float((a - b).abs().max()) / sc)
+    close(res[True][1], res[False][1], "dx", tol)
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 8
+    for n in res[True][2]:
+        close(res[True][2][n], res[False][2][n], n, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("dim,heads,grid,window,landmarks,module_fn", [
     (192, 3, (28, 28), 7, 49, True),        # cfg3: single node, chunk means from the projection kernel into the workspace
     (192, 3, (14, 14), 7, 49, True),        # cfg2
