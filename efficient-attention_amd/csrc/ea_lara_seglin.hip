@@ -17,6 +17,7 @@
 //     16-lane DPP sums, and dz as well as X (brought into the same layout by four exact MFMAs with a 0 / 1 pattern) are the
 //     k-slots of dG[out][in] = sum_tokens dz[token][out] x[token][in] without any LDS transpose.
 // One wave per (b, h, side, segment) -- the dG pass: per group of segments, its [64 x 64] partial in registers.
+#include <stdlib.h>
 #include "ea_lara_segment.h"
 
 namespace ea {
@@ -152,16 +153,13 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
   GenA<E> ga;
   ga.load(G, g, li);
   // per-lane channel constants: channel 16 mt + 4 g + r
-  float gb[4][4];
+  f32x4 gb[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>((side ? p.gkb : p.gqb) + 16 * mt + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) gb[mt][r] = v0[r];
-  }
+  for (int mt = 0; mt < 4; ++mt) gb[mt] = *reinterpret_cast<const f32x4*>((side ? p.gkb : p.gqb) + 16 * mt + 4 * g);
   // backward state
   typename E::x8 gt[4][2];             // G^T as the A operand of dx^T = G^T dz^T: lane (g, li): in 16 mi + li, k-slots (out)
-  float a_[4][4], s1 = 0.f, ndb = 0.f;
+  f32x4 as1[4];                        // a - mean(a) of the segment, a = dy ln_w (the LayerNorm backward's row constants)
+  float ndb = 0.f;
   char* dst = nullptr;
   int dsn = 0;
   const float* dbar_bh = nullptr;
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
   };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(qx[d], qg[BWD ? d : 0]);
-  float accz[4][4];                    // forward: sum of the normalised rows of the segment (weight / bias applied at its end)
+  f32x4 accz[4];                       // forward: sum of the normalised rows of the segment (weight / bias applied at its end)
   float inv_len = 0.f;
   bool done = false;
   while (!done) {
@@ -215,23 +213,20 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
         if constexpr (BWD) {
           wdb[lane] = ndb;
           ndb = dbar_bh[(size_t)min(cc.l + 1, l1 - 1) * 64 + lane];
-          float s = 0.f;
+          f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(wdb + 16 * mt + 4 * g);
             const f32x4 w = *reinterpret_cast<const f32x4*>(wlw + 16 * mt + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              a_[mt][r] = v[r] * inv_len * w[r];
-              s += a_[mt][r];
-            }
+            as1[mt] = v * w * inv_len;
+            s4 += as1[mt];
           }
-          s1 = quad_sum(s) * (1.f / 64);
+          const float s1 = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.f / 64);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) as1[mt] -= s1;
         } else {
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) accz[mt][r] = 0.f;
+          for (int mt = 0; mt < 4; ++mt) accz[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
       const typename E::x8 bx0 = as_x8<E>(qx[d][0]), bx1 = as_x8<E>(qx[d][1]);
@@ -248,45 +243,32 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
         z[mt] = E::mma(ga.a[mt][0], bx0, z[mt]);
         z[mt] = E::mma(ga.a[mt][1], bx1, z[mt]);
       }
-      float s = 0.f;
+      // LayerNorm over the token's 64 channels = 16 in-lane values x the 4 lanes of its quad: whole-vector arithmetic (two
+      // v_pk_*_f32 per f32x4) -- the scalar form of this stage was ~2/3 of the pass's VALU issue
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt) { z[mt] += gb[mt]; s4 += z[mt]; }
+      const float mean = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.f / 64);
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { z[mt][r] += gb[mt][r]; s += z[mt][r]; }
-      const float mean = quad_sum(s) * (1.f / 64);
-      float v = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { z[mt][r] -= mean; v += z[mt][r] * z[mt][r]; }
-      const float rstd = rsqrtf(quad_sum(v) * (1.f / 64) + 1e-5f);
+      for (int mt = 0; mt < 4; ++mt) { z[mt] -= mean; v4 += z[mt] * z[mt]; }
+      const float rstd = rsqrtf(quad_sum((v4[0] + v4[1]) + (v4[2] + v4[3])) * (1.f / 64) + 1e-5f);
       if constexpr (!BWD) {
         const float w = valid ? rstd : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) accz[mt][r] += w * z[mt][r];
+        for (int mt = 0; mt < 4; ++mt) accz[mt] += z[mt] * w;
       } else {
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) z[mt][r] *= rstd;                   // z = xhat from here on
-        float s2 = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s2 += a_[mt][r] * z[mt][r];
-        s2 = quad_sum(s2) * (1.f / 64);
+        for (int mt = 0; mt < 4; ++mt) { z[mt] *= rstd; t4 += as1[mt] * z[mt]; }    // z = xhat from here on
+        // mean(a xhat) = mean((a - mean a) xhat) since the normalised row sums to zero
+        const float s2 = quad_sum((t4[0] + t4[1]) + (t4[2] + t4[3])) * (1.f / 64);
         // the token's LayerNorm statistics for the dG pass (which would otherwise redo them with 16-lane reductions)
         if (g == 0 && valid) p.stats[((size_t)(bh * 2 + side) * p.N + tok)] = f32x4{mean, rstd, s2, 0.f};
         const float w = valid ? rstd : 0.f;
-        float dz[4][4];
+        f32x4 dz[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            dz[mt][r] = w * (a_[mt][r] - s1 - z[mt][r] * s2);
-          }
+        for (int mt = 0; mt < 4; ++mt) dz[mt] = (as1[mt] - z[mt] * s2) * w;
         // dx^T[in][token] = G^T dz^T: the D values of out-tiles (2 kk, 2 kk + 1) are the k-slots of step kk
         f32x4 dx[4];
         const typename E::x8 bz0 = as_x8<E>(u32x4{pack2<E>(dz[0][0], dz[0][1]), pack2<E>(dz[0][2], dz[0][3]),
@@ -356,7 +338,7 @@ __global__ __launch_bounds__(256, BWD ? 2 : 3) void seglin_col_kernel(const SegL
             const f32x4 bb = *reinterpret_cast<const f32x4*>(wlb + 16 * mt + 4 * g);
             f32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = w[r] * (group_sum<16>(accz[mt][r]) * inv_len) + bb[r];
+            for (int r = 0; r < 4; ++r) { const float a = accz[mt][r]; o[r] = w[r] * (group_sum<16>(a) * inv_len) + bb[r]; }
             if (li == 0) *reinterpret_cast<f32x4*>(out + 16 * mt + 4 * g) = o;
           }
         }
