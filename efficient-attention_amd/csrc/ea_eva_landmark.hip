@@ -23,6 +23,10 @@ template <int CPR> EA_DEV float rows_sum(float v) { return stride_sum<CPR>(v); }
 // reduce across the CPR lanes of one row
 template <int CPR> EA_DEV float chan_sum(float v) { return group_sum<CPR>(v); }
 
+// row steps requested per memory round trip by the streaming loops below (round 6): long chunks shared by four waves stream
+// hundreds of rows per wave, one-wave chunks at most 16 row steps
+template <int WPC> struct LmU { static constexpr int value = WPC == 4 ? 8 : 4; };
+
 // ------------------------------------------------------------------------------------------
 template <typename E, int D, int WPC>
 __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
@@ -39,16 +43,36 @@ __global__ __launch_bounds__(256) void chunk_mean_fwd_kernel(const LmP p) {
   float aq[8], ak[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) aq[i] = ak[i] = 0.f;
-  for (int j = sub * RPW + rg; j < p.J; j += WPC * RPW) {
-    const int tok = part_token(p.G, cidx, j, p.r, p.e);
-    if (tok >= 0 && !(mrow && mrow[tok])) {
-      float f[8];
-      unpack8<E>(ldg16(qb + (tok * p.q_sn + c * 8) * 2), f);
+  // Round 6: U row steps per memory round trip -- every row (and mask byte) of a macro step is requested up front from a
+  // clamped address, then the steps are consumed in the old order (the same additions in the same order: bit-identical).
+  // The one-step loop waited a full round trip per 8 (D = 64) rows: 17 dependent trips for a 528-slot chunk of cfg5.
+  constexpr int U = LmU<WPC>::value, STRIDE = WPC * RPW;
+  for (int jb = sub * RPW; jb < p.J; jb += U * STRIDE) {
+    u32x4 rq[U], rk[U];
+    int tk[U];
+    uint8_t mk[U];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) aq[i] += f[i];
-      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), f);
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= p.J) break;                       // (uniform)
+      const int j = jb + u * STRIDE + rg;
+      tk[u] = j < p.J ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+      const int tc = max(tk[u], 0);
+      rq[u] = ldg16(qb + (tc * p.q_sn + c * 8) * 2);
+      rk[u] = ldg16(kb + (tc * p.k_sn + c * 8) * 2);
+      mk[u] = mrow ? mrow[tc] : (uint8_t)0;
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ak[i] += f[i];
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= p.J) break;
+      if (tk[u] >= 0 && !mk[u]) {
+        float f[8];
+        unpack8<E>(rq[u], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) aq[i] += f[i];
+        unpack8<E>(rk[u], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ak[i] += f[i];
+      }
     }
   }
   const float inv = 1.f / (float)p.J;
@@ -198,31 +222,48 @@ __global__ __launch_bounds__(256) void beta_fwd_kernel(const LmP p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   const int jmax = (p.J + WPC * RPW - 1) / (WPC * RPW) * (WPC * RPW);
-  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
-    const bool exists = j < p.J;
-    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
-    const bool live = tok >= 0 && !(mrow && mrow[tok]);
-    float kf[8], vf[8];
+  constexpr int U = LmU<WPC>::value, STRIDE = WPC * RPW;      // U row steps per memory round trip (see chunk_mean_fwd_kernel)
+  for (int jb = sub * RPW; jb < jmax; jb += U * STRIDE) {
+    u32x4 rk[U], rv[U];
+    int tk[U];
+    uint8_t mk[U];
+    bool ex[U];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = vf[i] = 0.f;
-    if (live) {
-      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
-      unpack8<E>(ldg16(vb + (tok * p.v_sn + c * 8) * 2), vf);
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= jmax) break;                      // (uniform: jmax is a multiple of STRIDE)
+      const int j = jb + u * STRIDE + rg;
+      ex[u] = j < p.J;
+      tk[u] = ex[u] ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+      const int tc = max(tk[u], 0);
+      rk[u] = ldg16(kb + (tc * p.k_sn + c * 8) * 2);
+      rv[u] = ldg16(vb + (tc * p.v_sn + c * 8) * 2);
+      mk[u] = mrow ? mrow[tc] : (uint8_t)0;
     }
-    float dot = 0.f, nrm = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
-    dot = chan_sum<CPR>(dot);
-    nrm = chan_sum<CPR>(nrm);
-    float x = p.scale * (dot - 0.5f * nrm);
-    x = live ? x : (exists ? MASK_FILL : -INFINITY);
-    const float mn = fmaxf(m, x);
-    const float ms = mn == -INFINITY ? 0.f : mn;
-    const float a = __expf(m - ms), pj = __expf(x - ms);
-    l = l * a + pj;
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= jmax) break;
+      const bool exists = ex[u];
+      const bool live = tk[u] >= 0 && !mk[u];
+      float kf[8], vf[8];
+      unpack8<E>(rk[u], kf);
+      unpack8<E>(rv[u], vf);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pj * vf[i];
-    m = mn;
+      for (int i = 0; i < 8; ++i) { kf[i] = live ? kf[i] : 0.f; vf[i] = live ? vf[i] : 0.f; }
+      float dot = 0.f, nrm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
+      dot = chan_sum<CPR>(dot);
+      nrm = chan_sum<CPR>(nrm);
+      float x = p.scale * (dot - 0.5f * nrm);
+      x = live ? x : (exists ? MASK_FILL : -INFINITY);
+      const float mn = fmaxf(m, x);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      const float a = __expf(m - ms), pj = __expf(x - ms);
+      l = l * a + pj;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pj * vf[i];
+      m = mn;
+    }
   }
   // merge the RPW row-groups (lanes with equal c)
 #pragma unroll
@@ -307,25 +348,43 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
   const int jmax = (p.J + WPC * RPW - 1) / (WPC * RPW) * (WPC * RPW);
   // pass 1: log-sum-exp of the chunk's logits
   float m = -INFINITY, l = 0.f;
-  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
-    const bool exists = j < p.J;
-    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
-    const bool live = tok >= 0 && !(mrow && mrow[tok]);
-    float kf[8];
+  constexpr int U = LmU<WPC>::value, STRIDE = WPC * RPW;      // U row steps per memory round trip (see chunk_mean_fwd_kernel)
+  for (int jb = sub * RPW; jb < jmax; jb += U * STRIDE) {
+    u32x4 rk[U];
+    int tk[U];
+    uint8_t mk[U];
+    bool ex[U];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = 0.f;
-    if (live) unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
-    float dot = 0.f, nrm = 0.f;
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= jmax) break;
+      const int j = jb + u * STRIDE + rg;
+      ex[u] = j < p.J;
+      tk[u] = ex[u] ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+      const int tc = max(tk[u], 0);
+      rk[u] = ldg16(kb + (tc * p.k_sn + c * 8) * 2);
+      mk[u] = mrow ? mrow[tc] : (uint8_t)0;
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
-    dot = chan_sum<CPR>(dot);
-    nrm = chan_sum<CPR>(nrm);
-    float x = p.scale * (dot - 0.5f * nrm);
-    x = live ? x : (exists ? MASK_FILL : -INFINITY);
-    const float mn = fmaxf(m, x);
-    const float ms = mn == -INFINITY ? 0.f : mn;
-    l = l * __expf(m - ms) + __expf(x - ms);
-    m = mn;
+    for (int u = 0; u < U; ++u) {
+      if (jb + u * STRIDE >= jmax) break;
+      const bool exists = ex[u];
+      const bool live = tk[u] >= 0 && !mk[u];
+      float kf[8];
+      unpack8<E>(rk[u], kf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kf[i] = live ? kf[i] : 0.f;
+      float dot = 0.f, nrm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; }
+      dot = chan_sum<CPR>(dot);
+      nrm = chan_sum<CPR>(nrm);
+      float x = p.scale * (dot - 0.5f * nrm);
+      x = live ? x : (exists ? MASK_FILL : -INFINITY);
+      const float mn = fmaxf(m, x);
+      const float ms = mn == -INFINITY ? 0.f : mn;
+      l = l * __expf(m - ms) + __expf(x - ms);
+      m = mn;
+    }
   }
 #pragma unroll
   for (int o = CPR; o < 64; o <<= 1) {
@@ -353,38 +412,57 @@ __global__ __launch_bounds__(256) void beta_bwd_kernel(const LmP p, int colour, 
   float dom[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) dom[i] = 0.f;
-  for (int j = sub * RPW + rg; j < jmax; j += WPC * RPW) {
-    const bool exists = j < p.J;
-    const int tok = exists ? part_token(p.G, cidx, j, p.r, p.e) : -1;
-    const bool live = tok >= 0 && !(mrow && mrow[tok]);
-    float kf[8], vf[8];
+  // (round 6) the rows AND the gradient rows they are added to, U row steps per round trip: the one-step loop made three
+  // dependent trips per step (k / v, then dv, then dk) -- 2 x 90 us for the two colour classes of cfg5 at 2.2 TB/s.  The rows
+  // of a macro step are distinct tokens (clamped slots load token 0 and store nothing), so loading every gradient row before
+  // the first store of the macro step reads what the one-step loop read.
+  constexpr int U2 = WPC == 4 ? 6 : 4;
+  for (int jb = sub * RPW; jb < jmax; jb += U2 * STRIDE) {
+    u32x4 rk[U2], rv[U2], rdk[U2], rdv[U2];
+    int tk[U2];
+    uint8_t mk[U2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = vf[i] = 0.f;
-    if (live) {
-      unpack8<E>(ldg16(kb + (tok * p.k_sn + c * 8) * 2), kf);
-      unpack8<E>(ldg16(vb + (tok * p.v_sn + c * 8) * 2), vf);
+    for (int u = 0; u < U2; ++u) {
+      if (jb + u * STRIDE >= jmax) break;
+      const int j = jb + u * STRIDE + rg;
+      tk[u] = j < p.J ? part_token(p.G, cidx, j, p.r, p.e) : -1;
+      const int tc = max(tk[u], 0);
+      rk[u] = ldg16(kb + (tc * p.k_sn + c * 8) * 2);
+      rv[u] = ldg16(vb + (tc * p.v_sn + c * 8) * 2);
+      rdv[u] = ldg16(dvb + (tc * p.dv_sn + c * 8) * 2);
+      rdk[u] = ldg16(dkb + (tc * p.dk_sn + c * 8) * 2);
+      mk[u] = mrow ? mrow[tc] : (uint8_t)0;
     }
-    float dot = 0.f, nrm = 0.f, vd = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; vd += vf[i] * db[i]; }
-    dot = chan_sum<CPR>(dot);
-    nrm = chan_sum<CPR>(nrm);
-    vd = chan_sum<CPR>(vd);
-    if (live) {
-      const float x = p.scale * (dot - 0.5f * nrm);
-      const float pj = __expf(x - lse);
-      const float dx = pj * (vd - bd) * p.scale;
-      float f[8];
-      char* a = dvb + (tok * p.dv_sn + c * 8) * 2;
-      unpack8<E>(ldg16(a), f);
+    for (int u = 0; u < U2; ++u) {
+      if (jb + u * STRIDE >= jmax) break;
+      const int tok = tk[u];
+      const bool live = tok >= 0 && !mk[u];
+      float kf[8], vf[8];
+      unpack8<E>(rk[u], kf);
+      unpack8<E>(rv[u], vf);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] += pj * db[i];
-      stg16(a, pack8<E>(f));
-      a = dkb + (tok * p.dk_sn + c * 8) * 2;
-      unpack8<E>(ldg16(a), f);
+      for (int i = 0; i < 8; ++i) { kf[i] = live ? kf[i] : 0.f; vf[i] = live ? vf[i] : 0.f; }
+      float dot = 0.f, nrm = 0.f, vd = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { f[i] += dx * (om[i] - kf[i]); dom[i] += dx * kf[i]; }
-      stg16(a, pack8<E>(f));
+      for (int i = 0; i < 8; ++i) { dot += om[i] * kf[i]; nrm += kf[i] * kf[i]; vd += vf[i] * db[i]; }
+      dot = chan_sum<CPR>(dot);
+      nrm = chan_sum<CPR>(nrm);
+      vd = chan_sum<CPR>(vd);
+      if (live) {
+        const float x = p.scale * (dot - 0.5f * nrm);
+        const float pj = __expf(x - lse);
+        const float dx = pj * (vd - bd) * p.scale;
+        float f[8];
+        unpack8<E>(rdv[u], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += pj * db[i];
+        stg16(dvb + (tok * p.dv_sn + c * 8) * 2, pack8<E>(f));
+        unpack8<E>(rdk[u], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { f[i] += dx * (om[i] - kf[i]); dom[i] += dx * kf[i]; }
+        stg16(dkb + (tok * p.dk_sn + c * 8) * 2, pack8<E>(f));
+      }
     }
   }
 #pragma unroll
