@@ -45,7 +45,8 @@ KERNEL_TO_ENTRY = [
     ("rows_mlp_fwd_kernel", "ea_rows_mlp_fwd"), ("rows_mlp_bwd_kernel", "ea_rows_mlp_bwd"),
     ("table_bias_fwd_kernel", "ea_table_bias_fwd"), ("table_bias_bwd_kernel", "ea_table_bias_bwd"),
     ("multi_cast_kernel", "ea_multi_cast"),
-    ("seglin_col_kernel<ea::BF16, false>", "ea_lara_seglin_fwd"), ("seglin_col_kernel<ea::BF16, true>", "ea_lara_seglin_bwd(dq/dk)"),
+    ("seglin_col_kernel<ea::BF16, false", "ea_lara_seglin_fwd"), ("seglin_col_kernel<ea::BF16, true, 0>", "ea_lara_seglin_bwd(dq/dk)"),
+    ("seglin_col_kernel<ea::BF16, true", "ea_lara_seglin_bwd_fin(dq/dk + finish)"),
     ("seglin_dg_kernel<", "ea_lara_seglin_bwd(dG)"), ("fold_", "ea_lara_fold"),
 ]
 
