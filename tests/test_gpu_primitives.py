@@ -885,7 +885,9 @@ def test_lara_adaptive_1d_fold_kernels_match_framework_fold(dtype, masked, bias)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,h,N,L", [(2, 8, 4096, 49), (1, 2, 1000, 16), (2, 3, 333, 7), (1, 1, 130, 64)])
+@pytest.mark.parametrize("B,h,N,L", [(2, 8, 4096, 49), (1, 2, 1000, 16), (2, 3, 333, 7), (1, 1, 130, 64),
+                                     (8, 8, 2048, 49),      # several segments per wave: the row queue crosses segment boundaries
+                                     (1, 1, 17, 16)])       # one- and two-token segments
 def test_lara_seglin_matches_fp64_torch(dtype, B, h, N, L):
     """ea_lara_seglin_fwd / _bwd (round 4): segment means of LayerNorm(G x + b) straight from the stored q / k rows, the
     generator Linear on the MFMA inside the kernel -- against fp64 torch on the same 16-bit-rounded rows and generator
