@@ -11,8 +11,9 @@ The training / evaluation path (reference :666-790: chunk means -> mu -> beta, w
 whose extension lies on the left only, padded queries masked, causal local mask and per-chunk causal
 control-variate mask under one softmax) runs in libea_hip.so through `_ops.EvaAttnFn` with
 `ea_geom.causal` set, attention dropout included (keep mask drawn here, applied in the kernels);
-there is no CPU fallback.  Token-by-token decoding with an incremental state
-(reference :542-665) is not built yet and raises.
+there is no CPU fallback.  Quantization noise on the projections (`q_noise > 0`, reference :118-213) is applied
+to the parameters in front of the projection kernels exactly as the reference's forward pre-hooks do.  Token-by-token
+decoding with an incremental state (reference :542-665): `_decode`.
 """
 import math
 import uuid
@@ -48,8 +49,11 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         self.self_attention = self_attention
         assert not self_attention or self.qkv_same_dim, \
             "Self-attention requires query, key and value to be of the same size"
-        if q_noise > 0:
-            raise NotImplementedError("quantization noise on the projections (q_noise > 0)")
+        # quantization noise (reference :118-213, 339-351: fairseq's quant_noise wrapper around the four projections)
+        self.q_noise, self.qn_block_size = float(q_noise), int(qn_block_size)
+        if self.q_noise > 0:
+            for in_features in (embed_dim, self.kdim, self.vdim):
+                assert in_features % self.qn_block_size == 0, "Input features must be a multiple of block sizes"
         self.k_proj = nn.Linear(self.kdim, embed_dim, bias=bias)
         self.v_proj = nn.Linear(self.vdim, embed_dim, bias=bias)
         self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
@@ -79,6 +83,30 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         self.reset_parameters()
         self.onnx_trace = False
         self._keep_mask_fn = None
+        self._qnoise_mask_fn = None                     # tests: block-drop decisions of a fixture instead of bernoulli_
+
+    # ---- quantization noise (reference :165-213) -------------------------------------------
+    def _quant_noise_(self, lin):
+        """What the reference's forward pre-hook does to a projection before every TRAINING-mode call: each run of
+        `qn_block_size` consecutive input features of each output row is zeroed with probability q_noise, the rest scaled by
+        1 / (1 - q_noise), and the result written through `weight.data` -- the parameter itself changes and receives the
+        gradient with respect to the noised values.  Parameter-sized work (one draw + one masked scale per projection) in
+        front of the projection kernels, which then read the weight as they always do."""
+        p = self.q_noise
+        if not (self.training and p > 0):
+            return
+        w = lin.weight
+        out_f, in_f = w.shape
+        bs = self.qn_block_size
+        n = in_f // bs * out_f
+        with torch.no_grad():
+            if self._qnoise_mask_fn is not None:
+                mask = self._qnoise_mask_fn(n).to(device=w.device, dtype=torch.float32).reshape(-1)
+            else:
+                mask = torch.zeros(n, device=w.device)
+                mask.bernoulli_(p)
+            mask = mask.repeat_interleave(bs, -1).view(-1, in_f).to(torch.bool)
+            w.data = (1.0 / (1.0 - p)) * w.data.masked_fill(mask, 0)
 
     # ---- initialisation (reference :397-424) ----------------------------------------------
     @staticmethod
@@ -114,6 +142,8 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
     def _project(self, query, key, value, keep_f32=False):
         """Time-first [N, B, C] inputs -> fused [N, B, 3, h, d] in the kernels' I/O dtype."""
         N, B, C = query.shape
+        for lin in (self.q_proj, self.k_proj, self.v_proj):       # the hooks' firing order (reference :511-518)
+            self._quant_noise_(lin)
         if self.self_attention:
             # one GEMM over the stacked weights instead of three over the same activations
             biases = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
@@ -212,6 +242,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             out = _ops.EvaAttnFn.apply(qkv5, bias, noise, _ops._mask_u8(mask, B, N, x.device), cfg,
                                        *self._mu_params())
         # out [B, N, h, d] comes back as a view of a time-first buffer (it follows qkv's layout)
+        self._quant_noise_(self.out_proj)
         y = _ops.linear(out.transpose(0, 1).reshape(N, B, C), self.out_proj)
         if not torch.is_autocast_enabled() and y.dtype != query.dtype:
             y = y.to(query.dtype)

@@ -546,16 +546,17 @@ def _local_bias(params, args, h, e, scale, Wq=None, Wk=None):
 
 
 def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=None, keep_fn=None,
-                   index_fn=None):
+                   index_fn=None, qmask_fn=None):
     """y = module(x, key_padding_mask) for attn in {softmax, local, eva, lara, performer,
     causal_eva (batch-first x; training/evaluation path)}.
 
     args: constructor kwargs (missing ones take default_args); params: dict of tensors with
     the reference's state_dict keys; noise_fn(shape) -> standard-normal tensor for the i-th
     sampling call of a training-mode forward; keep_fn(shape) -> 0/1 keep decisions of an attention
-    dropout; index_fn(shape) -> the key indices randomized attention draws."""
+    dropout; index_fn(shape) -> the key indices randomized attention draws; qmask_fn(n) -> the 0/1 block-drop
+    decisions of a quantization-noise draw (causal EVA with q_noise > 0)."""
     if attn == "causal_eva":
-        return _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn)
+        return _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn, qmask_fn)
     a = default_args(attn)
     a.update(args)
     h = a["num_heads"]
@@ -691,11 +692,25 @@ def module_forward(attn, args, params, x, mask=None, training=False, noise_fn=No
     raise KeyError(attn)
 
 
-def _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn=None):
+def quant_noise_(params, name, p, block, qmask_fn):
+    """Quantization noise on one projection, as the forward pre-hook of causal_eva.py:165-213 applies it in training mode:
+    every run of `block` consecutive INPUT features of every output row is dropped with probability p and the survivors are
+    scaled by 1 / (1 - p).  The reference writes the result through `weight.data`, i.e. the parameter itself changes and the
+    gradient it receives is the one with respect to the noised values (dropped blocks get gradient too): so does this."""
+    w = params[name + ".weight"]
+    out_f, in_f = w.shape
+    assert in_f % block == 0, "Input features must be a multiple of block sizes"      # :149-151
+    m = qmask_fn(in_f // block * out_f).to(torch.float32).reshape(-1)
+    m = m.repeat_interleave(block, -1).view(-1, in_f).to(torch.bool)
+    w.data = (1.0 / (1.0 - p)) * w.data.masked_fill(m, 0)
+
+
+def _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn=None, qmask_fn=None):
     """CausalEVAttention.forward without incremental state (causal_eva.py:458-536,666-790) on
     batch-first x [B,T,C] (the module itself is time-first; callers transpose).  args: the
     constructor kwargs with `attn_args` as a dict (window_size, overlap_window, causal,
-    num_chunks, chunk_size, use_t5_rpe, adaptive_proj)."""
+    num_chunks, chunk_size, use_t5_rpe, adaptive_proj) and optionally q_noise / qn_block_size
+    (:339-351; the hooks fire in call order q, k, v (:511-513), then out (:785))."""
     aa = dict(adaptive_proj="default", num_chunks=None, chunk_size=None, causal=False,
               use_t5_rpe=False, window_size=4, overlap_window=False)
     aa.update(args["attn_args"])
@@ -712,7 +727,12 @@ def _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn=None)
     if mask is not None:
         pad_mask[:, :T] = mask.bool()
 
+    qn = float(args.get("q_noise", 0.0)) if training else 0.0
+    qn_block = int(args.get("qn_block_size", 8))
+
     def heads(name):
+        if qn > 0:
+            quant_noise_(params, name, qn, qn_block, qmask_fn)
         y = F.linear(xs, params[name + ".weight"], params.get(name + ".bias"))
         return y.reshape(B, n, h, d).transpose(1, 2)
     q, k, v = heads("q_proj"), heads("k_proj"), heads("v_proj")
@@ -735,6 +755,8 @@ def _causal_eva_forward(args, params, x, mask, training, noise_fn, keep_fn=None)
     keep = keep_fn((B, h, n, w + e + n // r)) if (training and p_drop > 0) else None
     out = causal_eva_core(q, k, v, pad_mask, w, e, r, mu_fn, noise, bias, aa["causal"], scale,
                           keep, p_drop)
+    if qn > 0:
+        quant_noise_(params, "out_proj", qn, qn_block, qmask_fn)
     y = F.linear(out.transpose(1, 2).reshape(B, n, C), params["out_proj.weight"],
                  params.get("out_proj.bias"))
     return y[:, :T]

@@ -188,6 +188,11 @@ CASES = {
         args=dict(embed_dim=128, num_heads=2, dropout=0.1, self_attention=True,
                   attn_args=dict(window_size=16, chunk_size=4, causal=True, adaptive_proj="qk",
                                  use_t5_rpe=True, num_chunks=None, overlap_window=True))),
+    "causal_eva_qnoise": dict(  # quantization noise on the four projections (causal_eva.py:118-213, 339-351): blocks of 8
+        attn="causal_eva", x_shape=(2, 48, 128), mask=("tail", [3, 0]),      # input features dropped with p = 0.25 in training
+        args=dict(embed_dim=128, num_heads=2, self_attention=True, q_noise=0.25, qn_block_size=8,
+                  attn_args=dict(window_size=16, chunk_size=4, causal=True, adaptive_proj="qk",
+                                 use_t5_rpe=True, num_chunks=None, overlap_window=False))),
 }
 
 MODES = ("eval", "train")
@@ -282,6 +287,13 @@ def make_keep(name, shape, p_drop, call_idx=0):
     """0/1 keep decisions of an attention-dropout call (probability p_drop of dropping)."""
     u = rng_for(name, "keep%d" % call_idx).random(tuple(shape), dtype=np.float32)
     return (u >= p_drop).astype(np.float32)
+
+
+def make_block_mask(name, n, p, call_idx=0):
+    """0/1 drop decisions of one quantization-noise draw (`mask.bernoulli_(p)` over the n weight blocks of a projection,
+    causal_eva.py:175-179): 1 = the block is zeroed."""
+    u = rng_for(name, "qnoise%d" % call_idx).random((int(n),), dtype=np.float32)
+    return (u < p).astype(np.float32)
 
 
 GRAD_FULL_MAX = 16384     # parameter grads larger than this are stored as a subsample

@@ -93,12 +93,24 @@ class _NoisePatch:
             return torch.from_numpy(arr).to(t.dtype)
 
         torch.randn, torch.randn_like = randn, randn_like
+        # quantization noise (causal_eva.py:175-179): `mask = torch.zeros(n); mask.bernoulli_(p)` per projection
+        self._bernoulli_ = torch.Tensor.bernoulli_
+        self.qn = []
+
+        def bernoulli_(t, p=0.5, **kw):
+            assert t.dim() == 1
+            arr = cases.make_block_mask(self.name, t.numel(), float(p), len(self.qn))
+            self.qn.append(int(t.numel()))
+            return t.copy_(torch.from_numpy(arr))
+
+        torch.Tensor.bernoulli_ = bernoulli_
         return self
 
     def __exit__(self, *exc):
         torch.randn, torch.randn_like = self._randn, self._randn_like
         torch.nn.functional.dropout = self._dropout
         torch.multinomial = self._multinomial
+        torch.Tensor.bernoulli_ = self._bernoulli_
 
 
 def run_case(ref, name):
@@ -135,6 +147,8 @@ def run_case(ref, name):
         out["%s.noise_shapes" % mode] = np.array(json.dumps(np_patch.calls))
         out["%s.drop_shapes" % mode] = np.array(json.dumps(np_patch.drops))
         out["%s.draw_shapes" % mode] = np.array(json.dumps(np_patch.draws))
+        if np_patch.qn:
+            out["%s.qn_blocks" % mode] = np.array(json.dumps(np_patch.qn))
         for k, p in mod.named_parameters():
             gnp = np.zeros(tuple(p.shape), np.float32) if p.grad is None else p.grad.numpy()
             for suffix, arr in cases.pack_grad(name, k, gnp).items():

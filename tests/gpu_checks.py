@@ -147,6 +147,9 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
     keep_fn = fx.keep_fn(device="cuda")
     if hasattr(mod, "_keep_mask_fn"):
         mod._keep_mask_fn = keep_fn                      # attention dropout: the fixture's decisions
+    qmask_fn = fx.qmask_fn(device="cuda")
+    if hasattr(mod, "_qnoise_mask_fn"):
+        mod._qnoise_mask_fn = qmask_fn                   # quantization noise: the fixture's block drops
     if hasattr(mod, "_sample_index_fn"):
         mod._sample_index_fn = fx.index_fn(device="cuda")  # randomized attention: the fixture's draws
     x = torch.from_numpy(fx.x_np).cuda().requires_grad_(True)
@@ -157,6 +160,7 @@ def check_module_case(name, mode, backward=True, dtype=torch.bfloat16, tol=None)
             y = cases.call_module(fx.case, mod, x, mask)
     assert calls == fx.expected_noise_shapes(mode), (calls, fx.expected_noise_shapes(mode))
     assert [int(np.prod(s)) for s in keep_fn.calls] == fx.expected_drop_elems(mode)
+    assert qmask_fn.calls == fx.expected_qn_blocks(mode)
     assert y.shape == x.shape and y.dtype in (dtype, torch.float32)
     elem = {}
 

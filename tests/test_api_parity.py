@@ -145,8 +145,26 @@ def test_causal_eva_flags_and_loud_failures():
         _causal_eva(attn_args=dict(causal=False)).eval()(x[:1], x[:1], x[:1], incremental_state={})
     with pytest.raises(NotImplementedError, match="incremental"):
         _causal_eva().train()(x[:1], x[:1], x[:1], incremental_state={})
-    with pytest.raises(NotImplementedError, match="quantization"):
-        _causal_eva(q_noise=0.1)
+    # quantization noise: the reference's size check (causal_eva.py:149-151) and its weight update (:165-213) -- the noise
+    # itself is parameter arithmetic, testable without a GPU
+    with pytest.raises(AssertionError, match="multiple of block sizes"):
+        _causal_eva(q_noise=0.1, qn_block_size=7)
+    qn = _causal_eva(q_noise=0.25, qn_block_size=8).train()
+    w0 = qn.q_proj.weight.detach().clone()
+    drop = (torch.arange(w0.numel() // 8) % 3 == 0).float()
+    qn._qnoise_mask_fn = lambda n: drop[:n]
+    qn._quant_noise_(qn.q_proj)
+    blocks = drop.bool().repeat_interleave(8).view_as(w0)
+    assert torch.equal(qn.q_proj.weight.detach(), torch.where(blocks, torch.zeros_like(w0), w0 * (1 / 0.75)))
+    qn.eval()._quant_noise_(qn.k_proj)                          # evaluation mode: no noise
+    qn._qnoise_mask_fn = None
+    torch.manual_seed(0)
+    k0 = qn.k_proj.weight.detach().clone()
+    qn.train()._quant_noise_(qn.k_proj)
+    zero_blocks = (qn.k_proj.weight.detach().view(-1, 8) == 0).all(-1)
+    assert 0.15 < zero_blocks.float().mean() < 0.35
+    kept = ~zero_blocks.repeat_interleave(8).view_as(k0)
+    assert torch.allclose(qn.k_proj.weight.detach()[kept], k0[kept] / 0.75)
     with pytest.raises(AssertionError):
         _causal_eva(attn_args=dict(chunk_size=3))               # window % chunk != 0 (causal_eva.py:362)
     # legacy fused in_proj checkpoints are split like the reference does (:876-903)

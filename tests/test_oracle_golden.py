@@ -19,11 +19,12 @@ def test_oracle_matches_reference(name, mode):
     params = fx.params(requires_grad=True)
     x = torch.from_numpy(fx.x_np).clone().requires_grad_(True)
     mask = None if fx.mask_np is None else torch.from_numpy(fx.mask_np)
-    noise_fn, keep_fn = fx.noise_fn(mode), fx.keep_fn()
+    noise_fn, keep_fn, qmask_fn = fx.noise_fn(mode), fx.keep_fn(), fx.qmask_fn()
     y = oracle.module_forward(case["attn"], case["args"], params, x, mask,
                               training=(mode == "train"), noise_fn=noise_fn, keep_fn=keep_fn,
-                              index_fn=fx.index_fn())
+                              index_fn=fx.index_fn(), qmask_fn=qmask_fn)
     assert noise_fn.calls == fx.expected_noise_shapes(mode)
+    assert qmask_fn.calls == fx.expected_qn_blocks(mode)
     assert [int(np.prod(s)) for s in keep_fn.calls] == fx.expected_drop_elems(mode)
     assert_close(y.detach().numpy(), fx.y(mode), 1e-4, 2e-5, "%s/%s y" % (name, mode))
     (y * torch.from_numpy(fx.g_np)).sum().backward()

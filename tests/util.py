@@ -51,6 +51,23 @@ class Fixture:
         fn.calls = calls
         return fn
 
+    def qmask_fn(self, device="cpu"):
+        """i-th quantization-noise draw -> the block-drop decisions the generator fed to the reference."""
+        calls = []
+        p = float(self.case["args"].get("q_noise", 0.0))
+
+        def fn(n):
+            arr = cases.make_block_mask(self.name, int(n), p, len(calls))
+            calls.append(int(n))
+            return torch.from_numpy(arr).to(device)
+
+        fn.calls = calls
+        return fn
+
+    def expected_qn_blocks(self, mode):
+        key = "%s.qn_blocks" % mode
+        return json.loads(str(self.z[key])) if key in self.z.files else []
+
     def index_fn(self, device="cpu"):
         """i-th multinomial call of randomized attention -> the draws the generator fed to the reference
         (there as [B*h*N, 1] of N-way draws, here as [B,h,N])."""
