@@ -265,6 +265,9 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             rf_k_bar  [B, h, Lcap, d]     fp32, the landmark keys of the COMPLETED chunks (:588-634)
             beta      [B, h, Lcap, d]     fp32, their control variates
             pos       [B]                 tokens decoded so far
+            pad       [B, cap]            uint8, 1 = padded position (`key_padding_mask`, e.g. left-padded prompts of a batch):
+                                          handed to the kernels exactly as the full path hands them its mask -- a padded key
+                                          is invisible, a padded query sees no local key, a chunk's means skip its padded rows
         A step projects the new token, closes a chunk when one completes (chunk means -> mu networks -> beta, the same HIP
         entry points as the full path on the chunk's rows) and runs the window kernel of the training path on the suffix
         [previous window, current window] against the landmarks of all completed chunks (`ea_geom.lm_base` re-bases the
@@ -280,9 +283,13 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         if self.adaptive_proj not in ("qk", "no-ln"):
             raise NotImplementedError("Other adaptive projection methods are not implemented yet.")
         _ops.nv.require_cuda(query, "query")                       # (before any state is built: no CPU fallback)
-        if key_padding_mask is not None and bool(key_padding_mask.any()):
-            raise NotImplementedError("padded positions during incremental decoding")
         T_new, B, C = query.shape
+        if key_padding_mask is not None:
+            # fairseq hands the decoder either the flags of the new positions [B, T_new] or of every position so far
+            # [B, t0 + T_new] (`self_attn_padding_mask`): the last T_new columns are this step's in both cases
+            if key_padding_mask.dim() != 2 or key_padding_mask.shape[0] != B or key_padding_mask.shape[1] < T_new:
+                raise ValueError("key_padding_mask %s does not cover the %d new positions of a batch of %d"
+                                 % (tuple(key_padding_mask.shape), T_new, B))
         w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
         r = self.chunk_size
         if r is None:
@@ -298,7 +305,9 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             state["rf_k_bar"] = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
             state["beta"] = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
             state["pos"] = torch.zeros((B,), dtype=torch.long, device=dev)
+            state["pad"] = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
             self.set_incremental_state(incremental_state, "attn_pos", 0)
+            self.set_incremental_state(incremental_state, "attn_has_pad", False)
         # (the token count also lives on the host, under its own key of the incremental state -- reading `pos` back would
         #  synchronise every step, and reorder_incremental_state only touches the tensors of the buffer)
         t0 = int(self.get_incremental_state(incremental_state, "attn_pos") or 0)
@@ -310,6 +319,9 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             grown = torch.zeros((B, cap, 3, h, d), dtype=state["qkv"].dtype, device=dev)
             grown[:, :state["qkv"].shape[1]] = state["qkv"]
             state["qkv"] = grown
+            gpad = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+            gpad[:, :state["pad"].shape[1]] = state["pad"]
+            state["pad"] = gpad
             lcap = cap // r
             for name in ("rf_k_bar", "beta"):
                 g2 = torch.zeros((B, h, lcap, d), dtype=torch.float32, device=dev)
@@ -317,6 +329,15 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                 state[name] = g2
         cache = state["qkv"]
         cache[:, t0:t0 + T_new] = qkv_new.transpose(0, 1)
+        # (whether a mask was ever given lives on the host: the unpadded case keeps its mask-free chunk kernels without
+        #  reading a flag back from the device)
+        has_pad = bool(self.get_incremental_state(incremental_state, "attn_has_pad"))
+        if key_padding_mask is not None:
+            state["pad"][:, t0:t0 + T_new] = key_padding_mask[:, -T_new:].to(device=dev, dtype=torch.uint8)
+            if not has_pad:
+                has_pad = True
+                self.set_incremental_state(incremental_state, "attn_has_pad", True)
+        pad = state["pad"]
         bias = None
         if self.use_t5_rpe:
             bias = self.rel_pos_bias.dense(w, w + e, dev).expand(h, w, w + e)
@@ -332,7 +353,7 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             b0 = max(b - 1, 0) if e > 0 else b
             Nc = (b - b0 + 1) * w
             ctx = cache[:, b0 * w:b0 * w + Nc]                      # [B, Nc, 3, h, d] view
-            mask = torch.zeros((B, Nc), dtype=torch.uint8, device=dev)
+            mask = pad[:, b0 * w:b0 * w + Nc].clone() if has_pad else torch.zeros((B, Nc), dtype=torch.uint8, device=dev)
             mask[:, t - b0 * w + 1:] = 1                            # rows after the current token: not decoded yet
             lk = state["rf_k_bar"][:, :, :nvis].contiguous() if nvis else None
             lv = state["beta"][:, :, :nvis].contiguous() if nvis else None
@@ -355,7 +376,8 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
                 c = t // r
                 sub = cache[:, c * r:(c + 1) * r]
                 icfg = [0, r, 0, r, 0, r, 1, 1, 0]
-                res = torch.ops.ea.eva_fwd(sub, None, None, None, None, icfg, [1.0, 1.0], adaptive, list(mlp))
+                cmask = pad[:, c * r:(c + 1) * r].contiguous() if has_pad else None
+                res = torch.ops.ea.eva_fwd(sub, None, None, cmask, None, icfg, [1.0, 1.0], adaptive, list(mlp))
                 state["beta"][:, :, c] = res[6][:, :, 0]
                 state["rf_k_bar"][:, :, c] = res[7][:, :, 0]
         self.set_incremental_state(incremental_state, "attn_pos", t0 + T_new)

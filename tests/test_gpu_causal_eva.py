@@ -262,6 +262,58 @@ def test_incremental_decoding_equals_full_forward(variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["recipe_d64", "overlap_d64", "many_chunks"])
+def test_incremental_decoding_with_padded_positions(variant):
+    """`key_padding_mask` during decoding (left-padded prompts of unequal length in one batch): every non-padded row equals
+    the row of the full-sequence forward given the same mask.  Batch element 1 starts with 19 padded positions -- two whole
+    chunks of 8 (their landmarks are built from no row at all) and part of a third --, element 2 with 3; the mask arrives in
+    both shapes fairseq uses (flags of the new positions / of every position so far)."""
+    aa = dict(RECIPE)
+    embed, heads, T, B = 512, 8, 200, 3
+    if variant == "overlap_d64":
+        aa.update(overlap_window=True, window_size=32)
+        T = 150
+    elif variant == "many_chunks":
+        aa.update(overlap_window=True, window_size=32, chunk_size=4)
+        embed, heads, T = 256, 4, 300
+    m = _build(embed, heads, aa)
+    torch.manual_seed(13)
+    x = torch.randn(T, B, embed, device="cuda")
+    pad = torch.zeros(B, T, dtype=torch.bool, device="cuda")
+    pad[1, :19] = True
+    pad[2, :3] = True
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full, _ = m(x, x, x, key_padding_mask=pad)
+        state = {}
+        m.init_incremental_state()
+        rows = []
+        t = 0
+        for i, step in enumerate([1, 1, 6, 1, 20, 1, 2, 64] + [1] * T):
+            if t >= T:
+                break
+            n = min(step, T - t)
+            kpm = pad[:, t:t + n] if i % 2 == 0 else pad[:, :t + n]
+            y, _ = m(x[t:t + n], x[t:t + n], x[t:t + n], key_padding_mask=kpm, incremental_state=state)
+            rows.append(y)
+            t += n
+    inc = torch.cat(rows, 0)
+    assert inc.shape == full.shape
+    live = (~pad).t().unsqueeze(-1).float()                      # [T, B, 1]
+    err = ((inc.float() - full.float()).abs() * live).max().item()
+    ref = (full.float().abs() * live).max().item()
+    assert err <= 2e-2 * ref, (variant, err, ref)
+    # an unpadded batch given an all-False mask takes the same steps as one given none
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        s1, s2 = {}, {}
+        m.init_incremental_state()
+        none = torch.zeros(B, 1, dtype=torch.bool, device="cuda")
+        for t in range(40):
+            a, _ = m(x[t:t + 1], x[t:t + 1], x[t:t + 1], incremental_state=s1)
+            b, _ = m(x[t:t + 1], x[t:t + 1], x[t:t + 1], key_padding_mask=none, incremental_state=s2)
+            assert (a.float() - b.float()).abs().max().item() <= 2e-2 * a.float().abs().max().item()
+
+
+@pytest.mark.gpu
 def test_incremental_state_reorders_with_the_beam():
     aa = dict(RECIPE, window_size=32)
     m = _build(256, 4, aa)
