@@ -480,13 +480,13 @@ def main():
     # (`ms_per_step` 0.507 vs `ms_per_step_blocks.median` 0.497 on one box).  The same captured step is replayed for
     # EA_BENCH_PREWARM_MS (default 50) milliseconds of wall time first; `prewarm_ms` in the JSON line says so.
     prewarm_ms = float(os.environ.get("EA_BENCH_PREWARM_MS", "50"))
-    if prewarm_ms > 0:
-        torch.cuda.synchronize()
-        tpw = time.perf_counter()
-        while (time.perf_counter() - tpw) * 1e3 < prewarm_ms:
-            for _ in range(8):
-                run()
-            torch.cuda.synchronize()
+    # (N > 1: a step holds the gradient all-reduce, so the ranks must replay the same number of steps -- rank 0's clock decides)
+    def _agree(done):
+        flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, 0)
+        return bool(flag.item())
+    from efficient_attention.data_parallel import prewarm_replays
+    prewarm_replays(run, prewarm_ms, torch.cuda.synchronize, agree=_agree if world > 1 else None)
     for _ in range(a.warmup):
         run()
 

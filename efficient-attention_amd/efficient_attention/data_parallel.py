@@ -117,3 +117,27 @@ def flush_schedule(name, bucket, lr):
     if name == "pipelined":
         bucket.sgd_step(lr)
         bucket.flat.zero_()
+
+
+def prewarm_replays(run, prewarm_ms, sync, agree=None, clock=time.perf_counter, chunk=8):
+    """Replay `run` (one whole step) for about `prewarm_ms` milliseconds of wall time before a timed region (bench.py: the
+    GPU's clocks settle while the captured step is replayed).  With more than one rank a step holds a collective, so every
+    rank has to leave this loop after the SAME number of steps: `agree(done) -> bool` turns one rank's "my time is up" into a
+    decision all ranks share (bench.py broadcasts rank 0's) -- a loop that each rank ends on its own clock leaves the ranks
+    with different numbers of all-reduces issued, i.e. a hang or gradients summed across different steps.
+    Returns the number of steps replayed."""
+    if prewarm_ms <= 0:
+        return 0
+    n = 0
+    sync()
+    t0 = clock()
+    while True:
+        for _ in range(chunk):
+            run()
+        n += chunk
+        sync()
+        done = (clock() - t0) * 1e3 >= prewarm_ms
+        if agree is not None:
+            done = bool(agree(done))
+        if done:
+            return n

@@ -214,3 +214,49 @@ def test_two_rank_gloo_schedule_selection_agrees_across_ranks():
     assert r0[1] == r1[1]                                          # identical (max-reduced) timings on both ranks
     assert r0[1]["pipelined"] == pytest.approx(5 * 9.1) and r0[1]["three_part"] == pytest.approx(5 * 2.6)
     assert r0[2] == pytest.approx(r1[2])                           # replicas stay in step through the selection runs
+
+
+# ---- bench.py's clock pre-warm with more than one rank: the ranks leave it after the same number of steps ----
+def _prewarm_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from efficient_attention.data_parallel import prewarm_replays
+        clock = _FakeClock()
+        buf = torch.zeros(4)
+        count = [0]
+
+        def run():                                               # a step = one collective; rank 1's clock runs 5x faster
+            dist.all_reduce(buf)
+            count[0] += 1
+            clock.t += [1e-3, 5e-3][rank]
+
+        def agree(done):
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32)
+            dist.broadcast(flag, 0)
+            return bool(flag.item())
+        n = prewarm_replays(run, 50.0, lambda: None, agree=agree, clock=clock)
+        dist.barrier()                                           # would hang / mismatch if the collective counts differed
+        ret[rank] = (n, count[0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prewarm_replays_same_step_count_on_every_rank():
+    from efficient_attention.data_parallel import prewarm_replays
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_prewarm_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret[0] == ret[1] == (56, 56), dict(ret)           # rank 0's clock: 50 ms / 1 ms per step, in chunks of 8
+    # single rank: its own clock; nothing to replay when switched off
+    clock, calls = _FakeClock(), []
+
+    def run():
+        calls.append(1)
+        clock.t += 2e-3
+    assert prewarm_replays(run, 50.0, lambda: None, clock=clock) == 32 and len(calls) == 32
+    assert prewarm_replays(run, 0.0, lambda: None, clock=clock) == 0
