@@ -2699,12 +2699,40 @@ def _split_k(rows):
     return best
 
 
-def colsum_f32(x2):
-    """x2.sum(0) of a contiguous fp32 [rows, cols] tensor through ea_colsum_f32 (fixed order)."""
+def _colsum_raw(x2):
     rows, cols = x2.shape
     out = torch.empty(cols, dtype=torch.float32, device=x2.device)
     nv.call("ea_colsum_f32", rows, cols, nv.ptr(x2), nv.ptr(out), nv.stream())
     return out
+
+
+COLSUM_TWO_STAGE = os.environ.get("EA_COLSUM_TWO_STAGE", "1") == "1"
+
+
+def _colsum_fold(rows, cols):
+    """k > 1: read a TALL [rows, cols] matrix as [rows / k, k * cols] (the same memory) -- ea_colsum_f32 gives a block 16
+    columns, so a 768-column matrix of 9216 rows (the mu networks' feed buffer of the LM step) ran on 48 workgroups; folded by
+    k = 32 it is 1536 workgroups, and the k partial rows [k, cols] take one more (tiny) launch.  Fixed order either way."""
+    # (measured, tools/colsum_bench.py on one box, eager: 9216 x 768 20.9 -> 14.0 us, 65536 x 768 137 -> 62 us; below ~16 MB the
+    #  second launch costs more than the first gains -- 4096 x 768: 6.0 us in one stage, 13.8 in two)
+    if not COLSUM_TWO_STAGE or cols >= 8192 or rows * cols < (4 << 20):
+        return 1
+    best = 1
+    for k in (64, 32, 16, 12, 8, 4):
+        if rows % k == 0 and rows // k >= 64 and k * cols <= 32768:
+            best = k
+            break
+    return best
+
+
+def colsum_f32(x2):
+    """x2.sum(0) of a contiguous fp32 [rows, cols] tensor through ea_colsum_f32 (fixed order); tall matrices in two
+    stages (_colsum_fold)."""
+    rows, cols = x2.shape
+    k = _colsum_fold(rows, cols)
+    if k > 1:
+        return _colsum_raw(_colsum_raw(x2.view(rows // k, k * cols)).view(k, cols))
+    return _colsum_raw(x2)
 
 
 def colsum2_f32(x1, x2):

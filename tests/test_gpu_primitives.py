@@ -1575,3 +1575,22 @@ def test_prepared_weight_path_is_bit_identical(attn, monkeypatch):
         names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
         for n, a, b in zip(names, *res):
             assert torch.equal(a, b), (attn, B, n, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(9216, 768), (18816, 384), (65536, 768), (4096, 768), (18, 196608)])
+def test_colsum_f32_two_stage_view_matches_sum(rows, cols):
+    """_ops.colsum_f32 reads a tall matrix as [rows / k, k * cols] and adds the k partial rows with a second launch
+    (_colsum_fold): same sums as one stage, in a fixed order (two calls agree bit for bit)."""
+    import torch
+    from efficient_attention import _ops
+    torch.manual_seed(rows + cols)
+    x = torch.randn(rows, cols, device="cuda")
+    ref = x.double().sum(0)
+    got = _ops.colsum_f32(x)
+    assert got.shape == (cols,)
+    assert (got.double() - ref).abs().max().item() <= 1e-5 * (rows ** 0.5) * 4
+    assert torch.equal(got, _ops.colsum_f32(x))
+    one = _ops._colsum_raw(x)
+    assert (one.double() - ref).abs().max().item() <= 1e-5 * (rows ** 0.5) * 4
+    assert (_ops._colsum_fold(rows, cols) > 1) == (rows * cols >= (4 << 20) and cols < 8192)
