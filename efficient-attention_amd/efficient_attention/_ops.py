@@ -192,6 +192,9 @@ def to_io_dtype(t):
 
 
 USE_TABLE_BIAS = os.environ.get("EA_TABLE_BIAS", "1") == "1"
+TABLE_BIAS_SPLIT = os.environ.get("EA_TABLE_BIAS_SPLIT", "1") == "1"      # dev switch: long position lists in pieces
+BIAS_HEAD_SUM = os.environ.get("EA_BIAS_HEAD_SUM", "1") == "1"            # dev switch: heads of a one-column table added by the colsum
+_BIAS_HEAD_SUM = [False]                                                   # set by EvaAttnFn.backward around its (direct) call
 
 
 class TableBias:
@@ -214,6 +217,7 @@ class TableBias:
         self._inv = inv.detach().cpu().to(torch.int32) if inv is not None else None
         self._dev = {}
         self._ld = {}
+        self._parts = 1
 
     def _on(self, device):
         hit = self._dev.get(device)
@@ -221,7 +225,19 @@ class TableBias:
             if self._inv is None:
                 from .local_attention import _inverse_index
                 self._inv = _inverse_index(self._idx.long(), self.rows)
-            hit = (self._idx.to(device), self._inv.contiguous().to(device))
+            inv = self._inv.contiguous()
+            # a far T5 bucket of a causal 128 x 128 window holds ~8 k positions and ea_table_bias_bwd gives a (row, head) ONE
+            # 256-lane workgroup: the longest list is the launch (26.7 us in the LM step).  Lists longer than 1024 are cut into
+            # P pieces -- the kernel sees rows * P shorter rows, grad() adds the P partial cells in a fixed order
+            K = inv.shape[1]
+            P = max(1, min(16, K // 512)) if TABLE_BIAS_SPLIT else 1
+            if P > 1:
+                K2 = -(-K // P) * P
+                if K2 != K:
+                    inv = F.pad(inv, (0, K2 - K), value=-1)
+                inv = inv.view(self.rows * P, K2 // P).contiguous()
+            self._parts = P
+            hit = (self._idx.to(device), inv.to(device))
             self._dev[device] = hit
         return hit
 
@@ -255,11 +271,17 @@ class TableBias:
         (th = table_heads or h; th = 1: summed over the heads)."""
         _, inv = self._on(g.device)
         g = _f32c(g)
-        h, Wq, ld = g.shape
-        out = torch.empty((self.rows, h), dtype=torch.float32, device=g.device)
-        nv.call("ea_table_bias_bwd", self.rows, inv.shape[1], h, Wq, self.Wk, ld, self.scale, nv.ptr(g), nv.ptr(inv), nv.ptr(out),
-                nv.stream())
-        if table_heads is not None and int(table_heads) == 1 and h != 1:
+        h, Wq, ld = g.shape                    # (h = 1: the heads of a one-column table were added up on the way here)
+        P = self._parts
+        out = torch.empty((self.rows * P, h), dtype=torch.float32, device=g.device)
+        nv.call("ea_table_bias_bwd", self.rows * P, inv.shape[1], h, Wq, self.Wk, ld, self.scale, nv.ptr(g), nv.ptr(inv),
+                nv.ptr(out), nv.stream())
+        one_col = table_heads is not None and int(table_heads) == 1 and h != 1
+        if P > 1 and one_col:
+            return out.view(self.rows, P * h).sum(1, keepdim=True)
+        if P > 1:
+            out = out.view(self.rows, P, h).sum(1)
+        if one_col:
             out = out.sum(1, keepdim=True)
         return out
 
@@ -345,7 +367,13 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
         nv.call("ea_slice_sum", 2, parts, n, 1.0, None, nv.ptr(dl_p), nv.ptr(dl), nv.stream())
         dlk, dlv = dl[0], dl[1]
     if bias_p is not None:
-        dbias = colsum_f32(dbias_p.view(dbias_p.shape[0] * B, -1)).view(bias_p.shape)
+        if _BIAS_HEAD_SUM[0] and bias_p.shape[0] > 1:
+            # the bias is a one-column table broadcast over the heads (causal EVA's T5 table): its gradient wants the SUM over
+            # the heads, so the heads join the rows of this reduction -- [parts * B * h, Wq * ld] instead of [parts * B, h * Wq * ld]
+            # (LM step: 144 rows x 24 k columns instead of 18 x 197 k: 21.9 -> ~9 us) and the table kernel sees one head
+            dbias = colsum_f32(dbias_p.view(dbias_p.shape[0] * B * bias_p.shape[0], -1)).view((1,) + tuple(bias_p.shape[1:]))
+        else:
+            dbias = colsum_f32(dbias_p.view(dbias_p.shape[0] * B, -1)).view(bias_p.shape)
     return dlk, dlv, dbias
 
 
@@ -738,6 +766,14 @@ class EvaAttnFn(torch.autograd.Function):
         icfg, fcfg, adaptive_proj, bias_cols = ctx.cfg
         if len(saved) == 2:             # composite workspace: only a direct forward saves one
             g = eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols, list(params))
+        elif ctx.tb is not None and ctx.tb_heads == 1 and BIAS_HEAD_SUM:
+            # (a TableBias means a direct call: the implementation runs right here, in this thread)
+            _BIAS_HEAD_SUM[0] = True
+            try:
+                g = eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols,
+                                 list(params))
+            finally:
+                _BIAS_HEAD_SUM[0] = False
         else:
             g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
                        bias_cols, list(params))

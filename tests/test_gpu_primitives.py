@@ -1411,6 +1411,22 @@ def test_table_bias_matches_the_framework_chain(case):
     assert torch.equal(got1, tb.dense(t1.expand(rows, h).contiguous(), ld))
     d1 = tb.grad(gb, 1)
     assert d1.shape == (rows, 1) and torch.allclose(d1[:, 0], dt.sum(1), rtol=1e-5, atol=1e-5 * float(dt.abs().max()) * h)
+    # ... and with the heads added up before the table kernel sees them (what EvaAttnFn's backward hands over for such a table)
+    d1s = tb.grad(gb.sum(0, keepdim=True), 1)
+    assert d1s.shape == (rows, 1) and torch.allclose(d1s, d1, rtol=1e-5, atol=1e-5 * float(dt.abs().max()) * h)
+    # long position lists are cut into pieces (a far bucket of the 128 x 256 window holds thousands of positions)
+    assert (tb._parts > 1) == (case == "t5_128x256")
+    if tb._parts > 1:
+        import efficient_attention._ops as o
+        old = o.TABLE_BIAS_SPLIT
+        try:
+            o.TABLE_BIAS_SPLIT = False
+            tb1 = _ops.TableBias(idx, rows, Wq, Wk, scale)
+            whole = tb1.grad(gb)
+            assert tb1._parts == 1
+        finally:
+            o.TABLE_BIAS_SPLIT = old
+        assert torch.allclose(dt, whole, rtol=1e-5, atol=1e-5 * float(whole.abs().max()))
 
 
 @pytest.mark.gpu
