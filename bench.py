@@ -178,6 +178,20 @@ def cpu_baseline(attn, dim, heads, grid, batch=128, budget_s=30.0):
                          "; ".join("%d threads: %.0f tokens/s" % (t, v) for t, v in sorted(per_threads.items())))}
 
 
+def _sgd(big, small, lr):
+    """Plain SGD, p -= lr * grad (what torch.optim.SGD(lr).step() computes): one element-wise launch per weight matrix
+    (>= 16384 elements) and ONE multi-tensor launch for the small vectors.  The multi-tensor kernel walks 65536-element chunks
+    per workgroup: it would run the two matrices of a 192-wide layer on ~3 workgroups (17 us against 2 x 4.6), and for the LM
+    layer's six large matrices (66 chunks) it measured 8 us SLOWER per step than six separate launches (A/B on one box,
+    profiles/r06_lm_stacked_sgd_ab.txt: 0.9616 against 0.9525 ms) -- so the rule is the same at every width."""
+    for prm in big:
+        if prm.grad is not None:
+            prm.data.add_(prm.grad, alpha=-lr)
+    ps = [prm for prm in small if prm.grad is not None]
+    if ps:
+        torch._foreach_add_([prm.data for prm in ps], [prm.grad for prm in ps], alpha=-lr)
+
+
 def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, overrides=None):
     """One more workload of BASELINE.json next to the headline one (N = 196 / 4096): the same layer step -- fwd + bwd + SGD
     under bf16 autocast, captured in a hipGraph -- timed over `steps` replays.  Returns tokens/s and the layer-level
@@ -210,12 +224,7 @@ def measure_workload(attn, B, C, H, seq, dev, steps=10, warmup=3, tune=True, ove
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = layer(x, x, x)[0] if lm else layer(x)
         y.backward(g)
-        for prm in big:
-            if prm.grad is not None:
-                prm.data.add_(prm.grad, alpha=-1e-3)
-        ps = [prm for prm in small if prm.grad is not None]
-        if ps:
-            torch._foreach_add_([prm.data for prm in ps], [prm.grad for prm in ps], alpha=-1e-3)
+        _sgd(big, small, 1e-3)
     if tune:
         import torch.cuda.tunable as tunable
         tunable.tuning_enable(True)
@@ -379,12 +388,7 @@ def main():
         small = [prm for prm in params if prm.numel() < 16384]
 
         def sgd_step():
-            for prm in big:
-                if prm.grad is not None:
-                    prm.data.add_(prm.grad, alpha=-LR)
-            ps = [prm for prm in small if prm.grad is not None]
-            if ps:
-                torch._foreach_add_([prm.data for prm in ps], [prm.grad for prm in ps], alpha=-LR)
+            _sgd(big, small, LR)
 
         def step():
             fwd_bwd()

@@ -585,8 +585,18 @@ def eva_fwd_impl(qkv5, bias, noise, mask_u8, keep, icfg, fcfg, adaptive_proj, ml
                 nv.ptr(xs[0]), nv.ptr(xs[1] if sides == 2 else None), *pick(0), *pick(1), *pick(2), *pick(3),
                 nv.ptr(ys[0]), nv.ptr(ys[1] if sides == 2 else None), nv.ptr(zhat), nv.ptr(rstd), nv.stream())
         rf_k_bar = ys[-1]
-        mu = mu_scale * (ys[0] + ys[1]) if sides == 2 else torch.zeros_like(rf_k_bar)
-        omega = (mu if noise is None else mu + noise.float()).contiguous()
+        # omega = mu_scale (rq + rk) [+ noise] in two launches (one without noise at mu_scale = 1): the scale rides on the second
+        # addition's alpha -- exact for the two scales in use (1: causal EVA, 0.5: a power of two, so the fused multiply-add
+        # rounds once at the same place as multiply-then-add)
+        if sides == 2:
+            s_ = torch.add(ys[0], ys[1])
+            if noise is not None:
+                omega = torch.add(noise.float(), s_, alpha=mu_scale)
+            else:
+                omega = s_ if mu_scale == 1.0 else s_.mul_(mu_scale)
+        else:
+            omega = torch.zeros_like(rf_k_bar) if noise is None else noise.float().clone()
+        omega = omega.contiguous()
     beta = torch.empty_like(qmean)
     nv.call("ea_eva_beta_fwd", ctypes.byref(geom), ctypes.byref(tk), ctypes.byref(tv),
             nv.ptr(mask_u8), nv.ptr(omega), nv.ptr(beta), nv.stream())
@@ -689,7 +699,7 @@ def eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, saved_list, icfg, fcfg, 
     R = B * h * L
     d_rfk = d_rfk.contiguous()
     if sides == 2:
-        d_rq = (mu_scale * d_omega).contiguous()
+        d_rq = d_omega.contiguous() if mu_scale == 1.0 else (mu_scale * d_omega).contiguous()
         dys = [d_rq, d_rq + d_rfk]
         xs = [qmean, kmean]
     else:
@@ -3274,6 +3284,117 @@ def linear_pool_usable(x, layer, grid, heads):
     x2 = x.reshape(-1, x.shape[-1])
     return (dtype in _ELEM and x2.dtype in (torch.float32, dtype) and layer.weight.is_contiguous()
             and _lin_rows_ok(x2, dtype) and proj_pool_supported(x2, layer.weight, dtype, B, H, W, r, heads))
+
+
+def multi_cast_into(srcs, dsts, dtype):
+    """fp32 tensors -> `dtype` copies written into caller-provided contiguous destinations (slices of one stacked buffer), ONE
+    launch (ea_multi_cast)."""
+    K = len(srcs)
+    srcs = [t.detach() if t.is_contiguous() else t.detach().contiguous() for t in srcs]
+    src = (ctypes.c_void_p * K)(*[t.data_ptr() for t in srcs])
+    dst = (ctypes.c_void_p * K)(*[o.data_ptr() for o in dsts])
+    n = (ctypes.c_int64 * K)(*[t.numel() for t in srcs])
+    nv.call("ea_multi_cast", _ELEM[dtype], K, src, n, dst, nv.stream())
+
+
+USE_STACKED_LINEAR = os.environ.get("EA_STACKED_LINEAR", "1") == "1"
+
+
+def stacked_linear_usable(x, weights, biases, dtype):
+    """StackedLinearFn applies: a layer whose projection LinearFn would hand to the library GEMM anyway (widths outside
+    ea_linear's 64 .. 256 input channels), fp32 master weights / biases of one width on the GPU, a 16-bit autocast dtype, the
+    one-pass weight gradient, nobody tracing."""
+    if not (USE_STACKED_LINEAR and USE_WGRAD and _DIRECT and x.is_cuda and dtype in _ELEM
+            and not torch.compiler.is_compiling() and torch._C._len_torch_dispatch_stack() == 0):
+        return False
+    K = x.shape[-1]
+    outs = sum(w.shape[0] for w in weights)
+    has_b = [b is not None for b in biases]
+    return (all(w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == K and w.is_cuda for w in weights)
+            and (all(has_b) or not any(has_b)) and all(b is None or b.dtype == torch.float32 for b in biases)
+            and len(weights) * (2 if all(has_b) else 1) <= 8
+            and not _lin_geometry(K, outs) and K % 64 == 0 and all(w.shape[0] % 64 == 0 for w in weights)
+            and x.dtype in (torch.float32, dtype) and x.numel() // K >= 64)
+
+
+class StackedLinearFn(torch.autograd.Function):
+    """y = x [W_1; W_2; ...]^T + [b_1; b_2; ...] for the separate fp32 master weights of ONE fused projection (causal EVA's
+    q_proj / k_proj / v_proj, causal_eva.py:511-513) on the library GEMM: the 16-bit stacked operand is written by one
+    ea_multi_cast launch straight into the slices of one buffer -- `torch.cat` of the masters (12.6 MB read + written at
+    C = 1024) followed by the cast of the copy was two launches and twice the bytes -- and the weight gradient of the stack
+    leaves as views of one [sum out, in] result (ea_wgrad, bias gradient riding along).
+    args: x [..., in], compute dtype, n, then n weights and n biases (all None or all given)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, n, *wb):
+        ws, bs = list(wb[:n]), list(wb[n:])
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        outs = [w.shape[0] for w in ws]
+        tot = sum(outs)
+        w16 = torch.empty((tot, K), dtype=dtype, device=x.device)
+        has_b = bs[0] is not None
+        b16 = torch.empty((tot,), dtype=dtype, device=x.device) if has_b else None
+        dsts, o = [], 0
+        for m in outs:
+            dsts.append(w16[o:o + m])
+            o += m
+        if has_b:
+            o = 0
+            for m in outs:
+                dsts.append(b16[o:o + m])
+                o += m
+        multi_cast_into(ws + (bs if has_b else []), dsts, dtype)
+        xl = x2 if x2.dtype == dtype else x2.to(dtype)          # the one activation-sized cast of the layer
+        xl = xl if xl.is_contiguous() else xl.contiguous()
+        with torch.autocast(device_type="cuda", enabled=False):
+            y = F.linear(xl, w16, b16)
+        ctx.save_for_backward(xl, w16)
+        ctx.meta = (x.shape, x.dtype, [w.dtype for w in ws], [None if b is None else b.dtype for b in bs], dtype, outs)
+        return y.view(x.shape[:-1] + (tot,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xl, w16 = ctx.saved_tensors
+        xshape, xdtype, wdts, bdts, cdtype, outs = ctx.meta
+        n = len(outs)
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != cdtype:
+            dy2 = dy2.to(cdtype)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = qkv_dgrad(dy2, w16, w16, xdtype).view(xshape)
+        need_w = any(ctx.needs_input_grad[3:3 + n])
+        need_b = bdts[0] is not None and any(ctx.needs_input_grad[3 + n:3 + 2 * n])
+        dws, dbs = [None] * n, [None] * n
+        if need_w:
+            dw, db32 = wgrad(dy2, xl, need_b)
+            o = 0
+            for i, m in enumerate(outs):
+                dws[i] = dw[o:o + m].to(wdts[i])
+                if need_b:
+                    dbs[i] = db32[o:o + m].to(bdts[i])
+                o += m
+        elif need_b:
+            db32 = bias_grad(dy2)
+            o = 0
+            for i, m in enumerate(outs):
+                dbs[i] = db32[o:o + m].to(bdts[i])
+                o += m
+        return (dx, None, None) + tuple(dws) + tuple(dbs)
+
+
+def linear_stacked(x, layers):
+    """The fused projection of several nn.Linear layers over the same input (-> [..., sum out]); None when StackedLinearFn
+    does not apply (the caller then stacks the parameters itself)."""
+    if not torch.is_autocast_enabled():
+        return None
+    dtype = torch.get_autocast_dtype("cuda")
+    ws, bs = [l.weight for l in layers], [l.bias for l in layers]
+    if not stacked_linear_usable(x, ws, bs, dtype):
+        return None
+    return StackedLinearFn.apply(x, dtype, len(ws), *ws, *bs)
 
 
 def linear_wb(x, weight, bias):

@@ -144,7 +144,15 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         N, B, C = query.shape
         for lin in (self.q_proj, self.k_proj, self.v_proj):       # the hooks' firing order (reference :511-518)
             self._quant_noise_(lin)
-        if self.self_attention:
+        qkv = None
+        if self.self_attention and (self.training or torch.is_grad_enabled()):
+            # wide layers whenever the derived-weight cache below cannot be used (training, or autograd on; round 6): the stacked
+            # 16-bit operand straight from the three master weights, no fp32 concatenation in between (_ops.StackedLinearFn);
+            # None = not applicable
+            qkv = _ops.linear_stacked(query, [self.q_proj, self.k_proj, self.v_proj])
+        if qkv is not None:
+            pass
+        elif self.self_attention:
             # one GEMM over the stacked weights instead of three over the same activations
             biases = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
 

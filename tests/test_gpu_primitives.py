@@ -1610,3 +1610,41 @@ def test_colsum_f32_two_stage_view_matches_sum(rows, cols):
     one = _ops._colsum_raw(x)
     assert (one.double() - ref).abs().max().item() <= 1e-5 * (rows ** 0.5) * 4
     assert (_ops._colsum_fold(rows, cols) > 1) == (rows * cols >= (4 << 20) and cols < 8192)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,bias", [(512, True), (1024, True), (320, False)])
+def test_stacked_linear_equals_linear_on_the_concatenated_weights(C, bias):
+    """_ops.StackedLinearFn (causal EVA's q / k / v projections of a wide layer): the 16-bit stacked operand cast straight from
+    the three master weights -- same GEMM, same weight-gradient kernel on the same 16-bit operands as LinearFn on
+    torch.cat(weights): y, dx and the gradients of all six parameters are identical."""
+    import torch
+    from efficient_attention import _ops
+    torch.manual_seed(C)
+    lins = [torch.nn.Linear(C, C, bias=bias).cuda() for _ in range(3)]
+    x = torch.randn(96, 4, C, device="cuda")
+    gy = torch.randn(96, 4, 3 * C, device="cuda")
+    res = []
+    for stacked in (True, False):
+        for l in lins:
+            l.weight.grad = None
+            if bias:
+                l.bias.grad = None
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if stacked:
+                y = _ops.linear_stacked(xi, lins)
+                assert y is not None
+            else:
+                w = torch.cat([l.weight for l in lins], 0)
+                b = torch.cat([l.bias for l in lins], 0) if bias else None
+                y = _ops.linear_wb(xi, w, b)
+        assert y.dtype == torch.bfloat16 and y.shape == (96, 4, 3 * C)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [l.weight.grad.clone() for l in lins] + ([l.bias.grad.clone() for l in lins] if bias else []))
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), i
+    # narrow layers stay on this library's own projection kernels
+    small = [torch.nn.Linear(128, 128).cuda() for _ in range(3)]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert _ops.linear_stacked(torch.randn(64, 2, 128, device="cuda"), small) is None
