@@ -9,6 +9,7 @@ copies exist here.
 """
 import ctypes
 import os
+import threading
 import warnings
 
 import torch
@@ -194,7 +195,12 @@ def to_io_dtype(t):
 USE_TABLE_BIAS = os.environ.get("EA_TABLE_BIAS", "1") == "1"
 TABLE_BIAS_SPLIT = os.environ.get("EA_TABLE_BIAS_SPLIT", "1") == "1"      # dev switch: long position lists in pieces
 BIAS_HEAD_SUM = os.environ.get("EA_BIAS_HEAD_SUM", "1") == "1"            # dev switch: heads of a one-column table added by the colsum
-_BIAS_HEAD_SUM = [False]                                                   # set by EvaAttnFn.backward around its (direct) call
+class _Hint(threading.local):
+    """(per thread: autograd runs a device's backward on its own thread)"""
+    on = False
+
+
+_BIAS_HEAD_SUM = _Hint()                                                   # set by EvaAttnFn.backward around its (direct) call
 
 
 class TableBias:
@@ -367,7 +373,7 @@ def _window_bwd(geom, qkv5, lk, lv, bias_p, mask_u8, out, dout, lse, dqkv5, keep
         nv.call("ea_slice_sum", 2, parts, n, 1.0, None, nv.ptr(dl_p), nv.ptr(dl), nv.stream())
         dlk, dlv = dl[0], dl[1]
     if bias_p is not None:
-        if _BIAS_HEAD_SUM[0] and bias_p.shape[0] > 1:
+        if _BIAS_HEAD_SUM.on and bias_p.shape[0] > 1:
             # the bias is a one-column table broadcast over the heads (causal EVA's T5 table): its gradient wants the SUM over
             # the heads, so the heads join the rows of this reduction -- [parts * B * h, Wq * ld] instead of [parts * B, h * Wq * ld]
             # (LM step: 144 rows x 24 k columns instead of 18 x 197 k: 21.9 -> ~9 us) and the table kernel sees one head
@@ -778,12 +784,12 @@ class EvaAttnFn(torch.autograd.Function):
             g = eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols, list(params))
         elif ctx.tb is not None and ctx.tb_heads == 1 and BIAS_HEAD_SUM:
             # (a TableBias means a direct call: the implementation runs right here, in this thread)
-            _BIAS_HEAD_SUM[0] = True
+            _BIAS_HEAD_SUM.on = True
             try:
                 g = eva_bwd_impl(dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj, bias_cols,
                                  list(params))
             finally:
-                _BIAS_HEAD_SUM[0] = False
+                _BIAS_HEAD_SUM.on = False
         else:
             g = _ea_op("eva_bwd", eva_bwd_impl, dout, qkv5, mask_u8, keep, noise, out, list(saved), icfg, fcfg, adaptive_proj,
                        bias_cols, list(params))
