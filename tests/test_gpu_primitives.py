@@ -1415,7 +1415,7 @@ def test_table_bias_matches_the_framework_chain(case):
     d1s = tb.grad(gb.sum(0, keepdim=True), 1)
     assert d1s.shape == (rows, 1) and torch.allclose(d1s, d1, rtol=1e-5, atol=1e-5 * float(dt.abs().max()) * h)
     # long position lists are cut into pieces (a far bucket of the 128 x 256 window holds thousands of positions)
-    assert (tb._parts > 1) == (case == "t5_128x256")
+    assert (tb._parts > 1) == (case == "t5_128x256" and _ops.TABLE_BIAS_SPLIT)
     if tb._parts > 1:
         import efficient_attention._ops as o
         old = o.TABLE_BIAS_SPLIT
@@ -1609,7 +1609,7 @@ def test_colsum_f32_two_stage_view_matches_sum(rows, cols):
     assert torch.equal(got, _ops.colsum_f32(x))
     one = _ops._colsum_raw(x)
     assert (one.double() - ref).abs().max().item() <= 1e-5 * (rows ** 0.5) * 4
-    assert (_ops._colsum_fold(rows, cols) > 1) == (rows * cols >= (4 << 20) and cols < 8192)
+    assert (_ops._colsum_fold(rows, cols) > 1) == (_ops.COLSUM_TWO_STAGE and rows * cols >= (4 << 20) and cols < 8192)
 
 
 @pytest.mark.gpu
@@ -1620,6 +1620,8 @@ def test_stacked_linear_equals_linear_on_the_concatenated_weights(C, bias):
     torch.cat(weights): y, dx and the gradients of all six parameters are identical."""
     import torch
     from efficient_attention import _ops
+    if not _ops.USE_STACKED_LINEAR:
+        pytest.skip("StackedLinearFn is switched off (EA_STACKED_LINEAR=0)")
     torch.manual_seed(C)
     lins = [torch.nn.Linear(C, C, bias=bias).cuda() for _ in range(3)]
     x = torch.randn(96, 4, C, device="cuda")
