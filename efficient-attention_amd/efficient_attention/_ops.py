@@ -2018,6 +2018,47 @@ class PerformerCore:
         return performer_f32_bwd(dout, qkv5, self.mask_u8, self.W, saved[0], saved[1], saved[2]), ()
 
 
+USE_LARA_1D_MODULE_FN = os.environ.get("EA_LARA_1D_MODULE_FN", "1") == "1"
+
+
+class GraphCore:
+    """Core spec of CoreModuleFn for a core that is itself a small autograd graph -- LinearRA 'adaptive-1d': segment kernels ->
+    landmark kernels -> estimator, three Functions with hand-overs between them (_GradSlot).  fwd() builds that graph on a
+    detached qkv with autograd switched back on (a Function's forward runs without it), bwd() differentiates it with
+    torch.autograd.grad: the launches are exactly those of the three-node module, but the two projections around them now
+    share CoreModuleFn's backward -- both weight gradients in one launch (ea_wgrad_pair) and one terminal ea_multi_sum instead of
+    two ea_wgrad + two ea_part_sum (cfg5 LARA at the recipe's batch of one: 28 launches of ~10 us each, profiles/
+    r06_step_trace_cfg5_lara_b1.txt).  fn(qkv5, *inputs) -> out [B,N,h,d]; the differentiable inputs are its parameters."""
+
+    def __init__(self, fn, n_inputs, need_grad):
+        self.fn, self.n_inputs, self.need_grad = fn, int(n_inputs), bool(need_grad)
+        self.leaf = self.out = self.inputs = None
+
+    def fwd(self, qkv5, inputs):
+        if not self.need_grad:
+            return self.fn(qkv5, *inputs), ()
+        with torch.enable_grad():
+            leaf = qkv5.detach().requires_grad_(True)
+            out = self.fn(leaf, *inputs)
+        self.leaf, self.out, self.inputs = leaf, out, list(inputs)
+        return out.detach(), ()
+
+    def bwd(self, dout, qkv5, out, saved):
+        if self.out is None:
+            raise RuntimeError("GraphCore: backward without a recorded forward (or a second backward through it)")
+        idx = [i for i, t in enumerate(self.inputs) if t is not None and t.requires_grad]
+        g = torch.autograd.grad(self.out, [self.leaf] + [self.inputs[i] for i in idx], dout.to(self.out.dtype),
+                                allow_unused=True)
+        extra = [None] * len(self.inputs)
+        for i, gi in zip(idx, g[1:]):
+            extra[i] = gi
+        dqkv5 = g[0]
+        self.leaf = self.out = self.inputs = None
+        if dqkv5 is None:
+            dqkv5 = torch.zeros_like(qkv5)
+        return (dqkv5 if dqkv5.is_contiguous() else dqkv5.contiguous()), tuple(extra)
+
+
 class CoreModuleFn(torch.autograd.Function):
     """qkv projection -> attention core -> output projection as ONE autograd node for the softmax and local-window baselines
     (round 4; LaraModuleFn's scheme for cores without landmark parameters): the projections read the fp32 master weights, both

@@ -266,6 +266,16 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
         qkv5 = None
         if over128:
             fold_1d = module_fn = False
+        # 'adaptive-1d' on the segment kernels as ONE autograd node as well (round 6, _ops.GraphCore inside CoreModuleFn): the
+        # projections of the three-node path ran two weight-gradient launches and two partial sums of their own
+        fits_fused = n_lm * (2 if dup else 1) <= 64
+        if (seglin and not over128 and fits_fused and _ops.USE_LARA_1D_MODULE_FN and torch.is_autocast_enabled()
+                and getattr(type(self).project_qkv, "_ea_builtin", False)
+                and type(self).merge_and_project is MultiheadAttention.merge_and_project
+                and (self.proj_drop.p == 0.0 or not self.training)
+                and _ops.core_module_fn_supported(x, self.qkv, self.proj, torch.get_autocast_dtype("cuda"))):
+            mode1 = (2 if self.use_multisample else (1 if self.use_antithetics else 0)) if self.training else 0
+            return self._forward_1d_module(x, key_padding_mask, B, N, C, mode1)
         if not module_fn:
             qkv5 = self._project_qkv_folded(x.reshape(B, N, C)) if fold_1d else self.project_qkv(x.reshape(B, N, C))
         mode = 0
@@ -338,6 +348,36 @@ class LinearRA(_ops.DerivedCacheOwner, MultiheadAttention):
             out = _ops.lara_attention(qkv5, mask, pq, pq + pk, noise, self.mis_type, self.alpha_coeff,
                                       mode, self.scale, slot)
         return self.merge_and_project(out, B, seq_shape, C, x.dtype)
+
+    def _forward_1d_module(self, x, key_padding_mask, B, N, C, mode):
+        """'adaptive-1d' proposals + estimator between the two projections of ONE autograd node (_ops.CoreModuleFn with a
+        _ops.GraphCore): the same kernels in the same order as the three-node path below it in forward()."""
+        h, d, L = self.num_heads, self.head_dim, self.num_landmarks
+        mask = _ops._mask_u8(key_padding_mask, B, N, x.device)
+        noise = None
+        if self.training:                                # (the one sampling call of the step, shapes as in forward())
+            if self.use_multisample:
+                noise = torch.randn(B, h, L * 2, d, dtype=torch.float32, device=x.device)
+            else:
+                noise = torch.randn_like(torch.empty(B, h, L, d, dtype=torch.float32, device=x.device))
+        mis, kappa, scale, mis_type = _ops.MIS[self.mis_type], float(self.alpha_coeff), self.scale, self.mis_type
+
+        def core(qkv5, lqw, lqb, lkw, lkb, nqw, nqb, nkw, nkb):
+            slot = _ops._GradSlot()
+            if key_padding_mask is not None:           # padded tokens: q = k = v = 0 for the generator AND the estimator (:93-96)
+                keep = (~key_padding_mask.to(torch.bool)).to(qkv5.dtype).view(B, N, 1, 1, 1)
+                qkv5 = qkv5 * keep
+            pq, pk = _ops.SegLinLnMeanFn.apply(qkv5, L, slot, lqw, lqb, lkw, lkb, nqw, nqb, nkw, nkb)
+            slot.defer_fin = bool(_ops.USE_SEGLIN_FIN and pq.requires_grad and torch.is_grad_enabled())
+            omega, qrows, bhv, lp = _ops.lara_landmarks(pq, pk, noise, mis_type, mode, scale, None, False, None)
+            return _ops.LaraAttnFn.apply(qkv5, mask, omega, qrows, bhv, lp, mis, kappa, slot)
+
+        lq, nq, lk, nk = self.q_bar_gen[0], self.q_bar_gen[1], self.k_bar_gen[0], self.k_bar_gen[1]
+        params = (lq.weight, lq.bias, lk.weight, lk.bias, nq.weight, nq.bias, nk.weight, nk.bias)
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        y = _ops.CoreModuleFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias,
+                                    _ops.GraphCore(core, len(params), need_grad), torch.get_autocast_dtype("cuda"), h, *params)
+        return self.proj_drop(y)
 
     @staticmethod
     def add_attn_specific_args(parent_parser, struct_name="attn_args", prefix=""):

@@ -1650,3 +1650,55 @@ def test_stacked_linear_equals_linear_on_the_concatenated_weights(C, bias):
     small = [torch.nn.Linear(128, 128).cuda() for _ in range(3)]
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert _ops.linear_stacked(torch.randn(64, 2, 128, device="cuda"), small) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,heads,N,L,variant", [(512, 8, 1024, 64, "plain"), (128, 2, 600, 16, "mask"), (512, 8, 520, 32, "antithetic"),
+                                                     (192, 3, 768, 49, "eval")])
+def test_lara_1d_module_path_equals_three_node_path(dim, heads, N, L, variant, monkeypatch):
+    """LinearRA 'adaptive-1d' as ONE autograd node (round 6: CoreModuleFn around a GraphCore that holds the segment / landmark /
+    estimator Functions) against the three-node path (EA_LARA_1D_MODULE_FN=0): the same kernels in the same order, so y is
+    identical and every gradient agrees to the rounding of the weight-gradient slice order."""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    if not (_ops.USE_SEGLIN and _ops.USE_CORE_MODULE_FN and _ops.USE_LARA_MODULE_FN and _ops.USE_WIDE_MODULE_FN):
+        pytest.skip("the segment kernels or the single-node paths are switched off")
+    kw = dict(dim=dim, num_heads=heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, num_landmarks=L, proposal_gen="adaptive-1d",
+              use_antithetics=variant == "antithetic", fp32=False)
+    torch.manual_seed(5)
+    m = ea.AttentionFactory.build_attention("lara", kw).cuda()
+    m.train(variant != "eval")
+    B = 4
+    x = torch.randn(B, N, dim, device="cuda")
+    gy = torch.randn(B, N, dim, device="cuda")
+    mask = None
+    if variant == "mask":
+        mask = torch.zeros(B, N, dtype=torch.bool, device="cuda")
+        mask[1, N - 37:] = True
+        mask[3, N - 200:] = True
+    res, nodes = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_LARA_1D_MODULE_FN", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi, mask) if mask is not None else m(xi)
+        nodes.append(type(y.grad_fn).__name__)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in m.parameters()])
+    assert "CoreModuleFn" in nodes[0] and "CoreModuleFn" not in nodes[1], nodes
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    assert torch.equal(res[0][0], res[1][0])
+    for n, a, b in zip(names, *res):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
+    # inference: no graph is recorded, same output
+    m.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        monkeypatch.setattr(_ops, "USE_LARA_1D_MODULE_FN", True)
+        y1 = m(x, mask) if mask is not None else m(x)
+        monkeypatch.setattr(_ops, "USE_LARA_1D_MODULE_FN", False)
+        y0 = m(x, mask) if mask is not None else m(x)
+    assert torch.equal(y1, y0)
