@@ -2019,6 +2019,7 @@ class PerformerCore:
 
 
 USE_LARA_1D_MODULE_FN = os.environ.get("EA_LARA_1D_MODULE_FN", "1") == "1"
+USE_CAUSAL_MODULE_FN = os.environ.get("EA_CAUSAL_MODULE_FN", "1") == "1"
 
 
 class GraphCore:

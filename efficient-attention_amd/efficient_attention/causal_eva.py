@@ -200,6 +200,11 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
             if key_padding_mask is not None:
                 mask[:, :tgt_len] = key_padding_mask.to(torch.bool)
             mask[:, tgt_len:] = True
+        y = self._forward_module(x, mask, N, B, C) if self.self_attention else None
+        if y is not None:
+            if N != tgt_len:
+                y = y[:tgt_len]
+            return y.contiguous(), None
         # (the full-sequence path has fp32 cores; decoding does not -- an explicit argument, not module state: forward stays
         #  re-entrant)
         if self.self_attention:
@@ -257,6 +262,61 @@ class CausalEVAttention(_ops.DerivedCacheOwner, nn.Module):
         if N != tgt_len:
             y = y[:tgt_len]
         return y.contiguous(), None
+
+    # ---- the training step as ONE autograd node ---------------------------------------------
+    def _forward_module(self, x, mask, N, B, C):
+        """Self-attention under 16-bit autocast with autograd on (a training / scoring-with-gradients step): q / k / v projection ->
+        causal EVA core -> output projection as one autograd node (_ops.CoreModuleFn around an _ops.GraphCore that records the
+        core's own Function), so that both projections' weight gradients leave in one launch and their partial sums in one
+        more -- the three-node path below pays two of each.  Returns None when it does not apply (fp32 activations, more than
+        64 chunks, quantization noise in training -- its draws keep the reference's order on the three-node path --, tracing)."""
+        w, e, h, d = self.window_size, self.ext_size, self.num_heads, self.head_dim
+        if not (_ops.USE_CAUSAL_MODULE_FN and torch.is_autocast_enabled() and torch.is_grad_enabled() and x.is_cuda
+                and not (self.training and self.q_noise > 0)):
+            return None
+        cdtype = torch.get_autocast_dtype("cuda")
+        r = self.chunk_size if self.chunk_size is not None else int(N // max(int(self.num_chunks or 1), 1))
+        if cdtype not in (torch.bfloat16, torch.float16) or r <= 0 or r >= N or N % r != 0 or N // r > 64:
+            return None
+        L = N // r
+        ws = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
+        bs = [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]
+        if any(wt.dtype != torch.float32 or not wt.is_contiguous() for wt in ws) or any((b is None) != (bs[0] is None) for b in bs):
+            return None
+        wq = torch.cat(ws, 0)
+        bq = None if bs[0] is None else torch.cat(bs, 0)
+
+        class _W:                                        # (what core_module_fn_supported reads of an nn.Linear)
+            def __init__(self, weight):
+                self.weight = weight
+        if not _ops.core_module_fn_supported(x, _W(wq), self.out_proj, cdtype):
+            return None
+        tb_ok = bool(self.use_t5_rpe and _ops.USE_TABLE_BIAS)
+        noise = None
+        if self.training:
+            noise = torch.randn_like(torch.empty(B, h, L, d, device=x.device, dtype=torch.float32))
+        mask_u8 = _ops._mask_u8(mask, B, N, x.device)
+        mu = self._mu_params()
+        table = self.rel_pos_bias.relative_attention_bias.weight if self.use_t5_rpe else None
+        adaptive = "default" if self.adaptive_proj == "qk" else "no-ln"
+
+        def core(qkv_tf, *params):                       # [N, B, 3, h, d] time-first -> out [N, B, h, d]
+            qkv5 = qkv_tf.transpose(0, 1)
+            cfg = (False, (N,), w, e, r, L, adaptive, 2 if self.causal else 1, 1.0) \
+                + (self._dropout_keep(B, h, N, w + e, L, x.device) or (None, 1.0))
+            bias = None
+            if tb_ok:
+                bias = table
+                cfg = cfg + (self.rel_pos_bias.table_spec(w, w + e),)
+            elif self.use_t5_rpe:
+                bias = self.rel_pos_bias.dense(w, w + e, x.device).expand(h, w, w + e)
+            out = _ops.EvaAttnFn.apply(qkv5, bias, noise, mask_u8, cfg, *mu)
+            return out.transpose(0, 1)
+
+        inputs = ([table] if table is not None else []) + list(mu)
+        y = _ops.CoreModuleFn.apply(x, wq, bq, self.out_proj.weight, self.out_proj.bias,
+                                    _ops.GraphCore(core, len(inputs), True), cdtype, h, *inputs)
+        return y
 
     # ---- incremental decoding (reference :537-665) ------------------------------------------
     def _decode(self, query, key_padding_mask, incremental_state):

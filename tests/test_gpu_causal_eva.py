@@ -340,3 +340,66 @@ def test_incremental_decoding_refuses_what_it_cannot_pin():
     x = torch.randn(1, 2, 256, device="cuda")
     with pytest.raises(NotImplementedError):
         m(x, x, x, incremental_state={})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["recipe_d64", "recipe_d128_dropout", "overlap_mask_noln", "narrow_d64"])
+def test_single_node_path_equals_three_node_path(variant, monkeypatch):
+    """The training step of the self-attention module as ONE autograd node (round 6: _ops.CoreModuleFn around a GraphCore holding
+    the causal EVA core) against the three-node path (EA_CAUSAL_MODULE_FN=0): the same kernels in the same order -- y identical,
+    gradients to the rounding of the weight-gradient slice order; wide layers (library GEMMs inside the node) and a narrow one
+    (this library's own projection kernels), T5 table, attention dropout with fixed keep decisions, a pad mask."""
+    from efficient_attention import _ops
+    if not (_ops.USE_CORE_MODULE_FN and _ops.USE_LARA_MODULE_FN and _ops.USE_WIDE_MODULE_FN):
+        pytest.skip("the single-node paths are switched off")
+    aa = dict(RECIPE)
+    embed, heads, T, B, dropout = 512, 8, 256, 3, 0.0
+    if variant == "recipe_d128_dropout":
+        embed, T, dropout = 1024, 384, 0.1
+    elif variant == "overlap_mask_noln":
+        aa.update(overlap_window=True, window_size=32, adaptive_proj="no-ln", use_t5_rpe=False)
+        T = 150
+    elif variant == "narrow_d64":
+        aa.update(window_size=32)
+        embed, heads, T = 128, 2, 128
+    m = _build(embed, heads, aa, dropout=dropout).train()
+    torch.manual_seed(21)
+    x = torch.randn(T, B, embed, device="cuda")
+    gy = torch.randn(T, B, embed, device="cuda")
+    mask = None
+    if variant == "overlap_mask_noln":
+        mask = torch.zeros(B, T, dtype=torch.bool, device="cuda")
+        mask[1, T - 21:] = True
+    keeps = {}
+
+    def keep_fn(shape):                                  # the same dropout decisions on both paths
+        if shape not in keeps:
+            g = torch.Generator(device="cuda").manual_seed(7)
+            keeps[shape] = (torch.rand(shape, device="cuda", generator=g) >= dropout).to(torch.uint8)
+        return keeps[shape]
+    m._keep_mask_fn = keep_fn
+    res, nodes = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_CAUSAL_MODULE_FN", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)                            # the landmark noise
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y, _ = m(xi, xi, xi, key_padding_mask=mask)
+        nodes.append(type(y.grad_fn).__name__)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in m.parameters()])
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
+    for n, a, b in zip(names, *res):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
+    # the node really is the single one (y is a slice / contiguous copy of its output)
+    from efficient_attention.causal_eva import CausalEVAttention
+    calls = []
+    orig = _ops.CoreModuleFn.apply
+    monkeypatch.setattr(_ops, "USE_CAUSAL_MODULE_FN", True)
+    monkeypatch.setattr(_ops.CoreModuleFn, "apply", staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1]))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        m(x, x, x, key_padding_mask=mask)
+    assert calls == [1]
