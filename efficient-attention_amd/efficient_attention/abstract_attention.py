@@ -120,9 +120,22 @@ class MultiheadAttention(nn.Module):
         """(core spec for _ops.CoreModuleFn, its differentiable inputs), or (None, ()) for subclasses that only override
         _attend: they keep the three-node path."""
         if type(self)._attend is not MultiheadAttention._attend:
-            return None, ()
+            return self._graph_core_spec(key_padding_mask, seq_shape)
         mask = _ops._mask_u8(key_padding_mask, B, N, device)
         return _ops.SoftmaxCore(mask, *self._attn_keep(B, N, device)), ()
+
+    # A subclass whose `_attend` is a chain of autograd Functions of its own (randomized attention) joins the single-node path by
+    # NAMING the parameters that chain reads besides qkv / proj (round 6, _ops.GraphCore: the chain is recorded inside the node's
+    # forward and differentiated inside its backward; a parameter it reads but does not name would get no gradient, hence opt-in)
+    _graph_core_params = None            # None: keep the three-node path; a tuple of attribute names (may be empty) opts in
+
+    def _graph_core_spec(self, key_padding_mask, seq_shape):
+        names = type(self)._graph_core_params
+        if names is None or not _ops.USE_GRAPH_CORE:
+            return None, ()
+        params = tuple(getattr(self, n) for n in names)
+        need = torch.is_grad_enabled()
+        return _ops.GraphCore(lambda qkv5, *ps: self._attend(qkv5, key_padding_mask, seq_shape), len(params), need), params
 
     def _attend(self, qkv5, key_padding_mask, seq_shape):
         B, N = qkv5.shape[:2]

@@ -23,6 +23,8 @@ from .abstract_attention import MultiheadAttention
 
 
 class RandomizedAttention(MultiheadAttention):
+    _graph_core_params = ()             # `_attend` reads no parameter of its own: the single-node path applies (round 6)
+
     def __init__(self, num_samples=1, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.num_samples = num_samples

@@ -1702,3 +1702,42 @@ def test_lara_1d_module_path_equals_three_node_path(dim, heads, N, L, variant, m
         monkeypatch.setattr(_ops, "USE_LARA_1D_MODULE_FN", False)
         y0 = m(x, mask) if mask is not None else m(x)
     assert torch.equal(y1, y0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_samples", [1, -1, 0])
+def test_randomized_attention_single_node_path_equals_three_node_path(num_samples, monkeypatch):
+    """Randomized attention joins the single-node module path through _ops.GraphCore (round 6: its `_attend`, a chain of this
+    library's Functions and framework glue, recorded inside CoreModuleFn's forward): same kernels as the three-node path
+    (EA_GRAPH_CORE=0), y identical, gradients to the rounding of the weight-gradient slice order."""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    if not (_ops.USE_CORE_MODULE_FN and _ops.USE_LARA_MODULE_FN):
+        pytest.skip("the single-node paths are switched off")
+    torch.manual_seed(9)
+    m = ea.AttentionFactory.build_attention("ra", dict(dim=192, num_heads=3, qkv_bias=True, attn_drop=0.0, proj_drop=0.0,
+                                                       num_samples=num_samples)).cuda().train()
+    B, H, W = 8, 14, 14
+    x = torch.randn(B, H, W, 192, device="cuda")
+    gy = torch.randn(B, H, W, 192, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    index = torch.randint(0, H * W, (B, 3, H * W), device="cuda", generator=g)
+    m._sample_index_fn = lambda shape: index
+    res, nodes = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_GRAPH_CORE", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        nodes.append(type(y.grad_fn).__name__)
+        y.backward(gy.to(y.dtype))
+        res.append([y.float(), xi.grad] + [p.grad.clone() for p in m.parameters()])
+    assert "CoreModuleFn" in nodes[0] and "CoreModuleFn" not in nodes[1], nodes
+    assert torch.equal(res[0][0], res[1][0])
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, *res):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
