@@ -81,6 +81,20 @@ class ScatterBrain(KernelizedAttention, LocalAttention):
                     mask[:, :orig_n] = key_padding_mask.to(torch.bool)
                 mask[:, orig_n:] = True
             seq_shape = [N]
+        # the training step as ONE autograd node (round 6, _ops.GraphCore: `_scatter` -- window kernel, feature kernels and their
+        # glue -- recorded inside CoreModuleFn's forward); the relative-position table is the one parameter `_scatter` reads
+        from .abstract_attention import MultiheadAttention
+        if (_ops.USE_GRAPH_CORE and torch.is_autocast_enabled() and xs.is_cuda and (self.proj_drop.p == 0.0 or not self.training)
+                and type(self).merge_and_project is MultiheadAttention.merge_and_project
+                and type(self).project_qkv is ScatterBrain.project_qkv
+                and _ops.core_module_fn_supported(xs, self.qkv, self.proj, torch.get_autocast_dtype("cuda"))):
+            params = (self.local_relative_position_bias_table,) if self.use_rpe else ()
+            shape = list(seq_shape)
+            core = _ops.GraphCore(lambda qkv5, *ps: self._scatter(qkv5, mask, shape), len(params), torch.is_grad_enabled())
+            y = _ops.CoreModuleFn.apply(xs, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, core,
+                                        torch.get_autocast_dtype("cuda"), self.num_heads, *params)
+            y = self.proj_drop(y.view(B, *seq_shape, C))
+            return y if self.attn_2d else y[..., :orig_n, :]
         qkv5 = self.project_qkv(xs)
         out = self._scatter(qkv5, mask, seq_shape)
         y = self.merge_and_project(out, B, seq_shape, C, x.dtype)

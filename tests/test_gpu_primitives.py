@@ -1741,3 +1741,42 @@ def test_randomized_attention_single_node_path_equals_three_node_path(num_sample
     names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
     for n, a, b in zip(names, *res):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn_2d,overlap", [(True, False), (False, False)])
+def test_scatterbrain_single_node_path_equals_three_node_path(attn_2d, overlap, monkeypatch):
+    """ScatterBrain's training step through CoreModuleFn + GraphCore (round 6) against its three-node path (EA_GRAPH_CORE=0):
+    y identical, gradients (the relative-position table's included) to the rounding of the weight-gradient slice order.
+    (The overlapping-window variant is only finite for small keys -- DESIGN 4b -- and is covered, on the single-node path as
+    well, by its golden fixtures in test_gpu_modules.py.)"""
+    import torch
+    import efficient_attention as ea
+    from efficient_attention import _ops
+    if not (_ops.USE_CORE_MODULE_FN and _ops.USE_LARA_MODULE_FN):
+        pytest.skip("the single-node paths are switched off")
+    torch.manual_seed(9)
+    kw = dict(dim=192, num_heads=3, qkv_bias=True, attn_drop=0.0, proj_drop=0.0, window_size=7 if attn_2d else 8, attn_2d=attn_2d,
+              use_rpe=True, overlap_window=overlap, approx_attn_dim=64)
+    m = ea.AttentionFactory.build_attention("scatterbrain", kw).cuda().train()
+    x = torch.randn(8, 14, 14, 192, device="cuda") if attn_2d else torch.randn(8, 200, 192, device="cuda")
+    x = x * (0.3 if overlap else 1.0)                        # (the overlapping variant is only finite for small keys: DESIGN 4b)
+    gy = torch.randn_like(x)
+    res, nodes = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "USE_GRAPH_CORE", on)
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        y.backward(gy.to(y.dtype))
+        assert y.shape == x.shape
+        res.append([y.float(), xi.grad] + [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in m.parameters()])
+    names = ["y", "dx"] + [n for n, _ in m.named_parameters()]
+    assert torch.equal(res[0][0], res[1][0])
+    assert float(res[0][2 + [n for n, _ in m.named_parameters()].index("local_relative_position_bias_table")].abs().max()) > 0
+    for n, a, b in zip(names, *res):
+        assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()) + 1e-12), \
+            (n, float((a - b).abs().max()), float(b.abs().max()))
