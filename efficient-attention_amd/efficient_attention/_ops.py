@@ -2020,6 +2020,7 @@ class PerformerCore:
 
 USE_LARA_1D_MODULE_FN = os.environ.get("EA_LARA_1D_MODULE_FN", "1") == "1"
 USE_CAUSAL_MODULE_FN = os.environ.get("EA_CAUSAL_MODULE_FN", "1") == "1"
+EVA_1D_NO_MASK = os.environ.get("EA_EVA_1D_NO_MASK", "1") == "1"            # dev switch: 1-D EVA builds no all-false mask
 USE_GRAPH_CORE = os.environ.get("EA_GRAPH_CORE", "1") == "1"                # opt-in subclasses of MultiheadAttention (RA, ScatterBrain)
 
 

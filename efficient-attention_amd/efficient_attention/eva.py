@@ -154,6 +154,10 @@ class EVA(LocalAttention):
             return x, key_padding_mask, seq_shape
         n = seq_shape[0]
         n_pad = int(math.ceil(n / w) * w) if w > 0 else n
+        if key_padding_mask is None and n_pad == n and _ops.EVA_1D_NO_MASK:
+            # nothing padded and nobody masked: no mask at all (round 6) -- an all-false one cost two framework launches per step
+            # and kept the window kernels off their static-key-validity instantiations
+            return x, None, [n_pad]
         mask = torch.zeros(B, n_pad, dtype=torch.bool, device=x.device)
         if key_padding_mask is not None:
             mask[:, :n] = key_padding_mask.to(torch.bool)
